@@ -1,0 +1,24 @@
+# Builds libevmi_hip.so (gfx950 code object + host runtime) and the oracle's C pieces.
+# No cmake: plain hipcc / gcc, outputs stay in-tree so they travel with gpurun snapshots.
+HIPCC      ?= /opt/rocm/bin/hipcc
+ARCH       ?= gfx950
+CSRC       := everyvoice_amd/csrc
+BUILD      := build/evmi
+HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+SRCS       := $(wildcard $(CSRC)/*.hip)
+OBJS       := $(patsubst $(CSRC)/%.hip,$(BUILD)/%.o,$(SRCS))
+LIB        := everyvoice_amd/libevmi_hip.so
+
+all: $(LIB)
+
+$(BUILD)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/evmi.h
+	@mkdir -p $(BUILD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+
+clean:
+	rm -rf $(BUILD) $(LIB)
+
+.PHONY: all clean

@@ -1,0 +1,139 @@
+"""ctypes binding of libevmi_hip.so (the C ABI declared in include/evmi.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent, importing the
+compute modules fails loudly — the product never silently runs a CPU or eager-PyTorch path.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_NAME = "libevmi_hip.so"
+
+EVMI_OK = 0
+EVMI_PREC_BF16 = 0
+EVMI_PREC_F32 = 1
+EVMI_MAX_UPSAMPLES = 8
+EVMI_MAX_RESBLOCK_KERNELS = 8
+EVMI_MAX_DILATIONS = 8
+
+
+class EvmiError(RuntimeError):
+    """A libevmi_hip call returned a non-zero status."""
+
+
+class GeneratorConfig(C.Structure):
+    _fields_ = [
+        ("n_mels", C.c_int),
+        ("upsample_initial_channel", C.c_int),
+        ("num_upsamples", C.c_int),
+        ("upsample_rates", C.c_int * EVMI_MAX_UPSAMPLES),
+        ("upsample_kernel_sizes", C.c_int * EVMI_MAX_UPSAMPLES),
+        ("resblock_type", C.c_int),
+        ("num_kernels", C.c_int),
+        ("resblock_kernel_sizes", C.c_int * EVMI_MAX_RESBLOCK_KERNELS),
+        ("num_dilations", C.c_int * EVMI_MAX_RESBLOCK_KERNELS),
+        ("resblock_dilations", (C.c_int * EVMI_MAX_DILATIONS) * EVMI_MAX_RESBLOCK_KERNELS),
+        ("lrelu_slope", C.c_float),
+        ("post_lrelu_slope", C.c_float),
+        ("istft_layer", C.c_int),
+        ("istft_n_fft", C.c_int),
+        ("istft_hop", C.c_int),
+    ]
+
+
+class LaunchRecord(C.Structure):
+    _fields_ = [
+        ("kernel", C.c_char * 48),
+        ("layer", C.c_char * 48),
+        ("ms", C.c_float),
+        ("flops", C.c_double),
+        ("bytes", C.c_double),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/evmi.h declares
+SYMBOLS = {
+    "evmi_abi_version": (C.c_int, []),
+    "evmi_last_error": (C.c_char_p, []),
+    "evmi_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "evmi_length_regulate": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "evmi_length_regulate_bwd_f32": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    ),
+    "evmi_conv1d_f32": (
+        C.c_int,
+        [C.c_void_p] * 5 + [C.c_int] * 9 + [C.c_float, C.c_float, C.c_int, C.c_void_p],
+    ),
+    "evmi_conv_transpose1d_f32": (
+        C.c_int,
+        [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_float, C.c_void_p],
+    ),
+    "evmi_generator_create": (C.c_int, [C.POINTER(GeneratorConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    "evmi_generator_destroy": (None, [C.c_void_p]),
+    "evmi_generator_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
+    "evmi_generator_num_weights": (C.c_int, [C.c_void_p]),
+    "evmi_generator_weight_info": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64)]),
+    "evmi_generator_finalize": (C.c_int, [C.c_void_p]),
+    "evmi_generator_hop": (C.c_int, [C.c_void_p]),
+    "evmi_generator_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "evmi_generator_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "evmi_generator_forward_profiled": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(LaunchRecord), C.c_int, C.POINTER(C.c_int)],
+    ),
+    "evmi_generator_macs_per_sample": (C.c_double, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib_path() -> Path:
+    override = os.environ.get("EVMI_LIB")
+    return Path(override) if override else _HERE / LIB_NAME
+
+
+def load() -> C.CDLL:
+    """Load the library once and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise ImportError(
+            f"{path} not found: build it with `make` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "everyvoice_amd has no CPU fallback."
+        )
+    lib = C.CDLL(str(path))
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.evmi_abi_version() != 1:
+        raise ImportError(f"{path}: ABI version {lib.evmi_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != EVMI_OK:
+        msg = load().evmi_last_error()
+        raise EvmiError(f"{what or 'libevmi_hip'} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t) -> int:
+    """Device/host pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream_ptr(device=None) -> int:
+    import torch
+
+    return torch.cuda.current_stream(device).cuda_stream

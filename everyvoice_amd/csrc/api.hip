@@ -1,0 +1,50 @@
+// C-ABI entry points that map 1:1 onto a kernel family (see include/evmi.h).
+#include "common.h"
+
+namespace evmi {
+int length_regulate(const void*, const int64_t*, void*, int64_t*, int32_t*, int, int, int, int, int, hipStream_t);
+int length_regulate_bwd_f32(const float*, const int64_t*, float*, int, int, int, int, hipStream_t);
+int launch_conv1d_f32(const float*, const float*, const float*, const float*, float*, int, int, int, int,
+                      int, int, int, int, int, float, float, int, hipStream_t);
+int launch_conv_transpose1d_f32(const float*, const float*, const float*, float*, int, int, int, int, int,
+                                int, int, float, hipStream_t);
+}  // namespace evmi
+
+using namespace evmi;
+
+extern "C" {
+
+int evmi_length_regulate(const void* values_dev, const int64_t* durations_dev, void* out_dev,
+                         int64_t* out_lens_dev, int32_t* index_dev, int B, int L, int D, int t_max,
+                         int elem_bytes, void* stream) {
+  if ((!values_dev && B * L * D > 0) || (!durations_dev && B * L > 0) || (!out_dev && B * t_max * D > 0))
+    return fail(EVMI_ERR_INVALID_ARG, "length_regulate: null pointer");
+  return length_regulate(values_dev, durations_dev, out_dev, out_lens_dev, index_dev, B, L, D, t_max,
+                         elem_bytes, (hipStream_t)stream);
+}
+
+int evmi_length_regulate_bwd_f32(const float* grad_out_dev, const int64_t* durations_dev,
+                                 float* grad_values_dev, int B, int L, int D, int t_max, void* stream) {
+  if (!grad_out_dev || !durations_dev || !grad_values_dev)
+    return fail(EVMI_ERR_INVALID_ARG, "length_regulate_bwd: null pointer");
+  return length_regulate_bwd_f32(grad_out_dev, durations_dev, grad_values_dev, B, L, D, t_max,
+                                 (hipStream_t)stream);
+}
+
+int evmi_conv1d_f32(const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
+                    float* y_dev, int B, int c_in, int t_in, int c_out, int k, int stride, int pad, int dil,
+                    int groups, float pre_slope, float out_scale, int accumulate, void* stream) {
+  if (!x_dev || !w_dev || !y_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_f32: null pointer");
+  return launch_conv1d_f32(x_dev, w_dev, bias_dev, residual_dev, y_dev, B, c_in, t_in, c_out, k, stride, pad,
+                           dil, groups, pre_slope, out_scale, accumulate, (hipStream_t)stream);
+}
+
+int evmi_conv_transpose1d_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int B,
+                              int c_in, int t_in, int c_out, int k, int stride, int pad, float pre_slope,
+                              void* stream) {
+  if (!x_dev || !w_dev || !y_dev) return fail(EVMI_ERR_INVALID_ARG, "conv_transpose1d_f32: null pointer");
+  return launch_conv_transpose1d_f32(x_dev, w_dev, bias_dev, y_dev, B, c_in, t_in, c_out, k, stride, pad,
+                                     pre_slope, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+/*
+ * evmi.h — C ABI of libevmi_hip.so: the MI355X (gfx950) native implementation of the
+ * EveryVoice TTS hot path (HiFiGAN / iSTFTNet vocoder, FastSpeech2 length regulator,
+ * STFT/mel front-end).
+ *
+ * The reference (EveryVoiceTTS/EveryVoice 0.5.0) is pure Python on PyTorch and has no FFI; this
+ * header is the boundary a maintainer binds with ctypes.  Each entry point
+ * cites the reference interface it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer named *_dev is a DEVICE pointer the caller allocated (e.g. torch tensor
+ *     .data_ptr()); *_host pointers are host memory; no ownership is transferred;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued
+ *     on it and nothing synchronises unless stated;
+ *   - return value 0 = EVMI_OK, otherwise an EVMI_ERR_* code; evmi_last_error() returns a
+ *     thread-local message for the last failure on the calling thread;
+ *   - no torch types, no C++ types, no global state besides per-object workspaces.
+ */
+#ifndef EVMI_H
+#define EVMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVMI_ABI_VERSION 1
+
+enum {
+  EVMI_OK = 0,
+  EVMI_ERR_INVALID_ARG = 1,
+  EVMI_ERR_HIP = 2,          /* a HIP runtime call or kernel launch failed */
+  EVMI_ERR_NOT_READY = 3,    /* weights missing / object not finalised */
+  EVMI_ERR_UNSUPPORTED = 4,  /* configuration outside what the kernels cover */
+  EVMI_ERR_OOM = 5
+};
+
+/* Arithmetic the generator computes in. */
+enum {
+  EVMI_PREC_BF16 = 0, /* bf16 operands, fp32 accumulate on MFMA (the fast path)          */
+  EVMI_PREC_F32 = 1   /* fp32 direct convolutions (exact-arithmetic path for parity work) */
+};
+
+int evmi_abi_version(void);
+const char* evmi_last_error(void);
+/* Fills name (<= name_len bytes, NUL terminated), compute-unit count and HBM bytes of `device`. */
+int evmi_device_info(int device, char* name, int name_len, int* compute_units, int64_t* hbm_bytes);
+
+/* ------------------------------------------------------------------------------------------
+ * Length regulator — replaces everyvoice/utils/heavy.py:12-21 `expand(values, durations)` applied
+ * per batch item and zero-padded (FastSpeech2 length regulator).
+ *
+ *   values_dev    [B, L, D]  elements of `elem_bytes` (2 or 4) bytes — copied bit-for-bit
+ *   durations_dev [B, L]     int64; row i is emitted max(0, d_i) times (the reference's
+ *                            int(d) truncation of float durations is done by the caller)
+ *   out_dev       [B, t_max, D]  frames past an item's total are zero
+ *   out_lens_dev  [B] int64  min(sum_i max(0,d_i), t_max)      (may be NULL)
+ *   index_dev     [B, t_max] int32 source row per frame, -1 in the padding (may be NULL)
+ * Integer/byte work: results are bit-exact.
+ * ------------------------------------------------------------------------------------------ */
+int evmi_length_regulate(const void* values_dev, const int64_t* durations_dev, void* out_dev,
+                         int64_t* out_lens_dev, int32_t* index_dev, int B, int L, int D,
+                         int t_max, int elem_bytes, void* stream);
+
+/* Backward of the above: grad_values[b, i, :] = sum over frames t with index[b,t]==i of
+ * grad_out[b, t, :] (fp32), frames summed in increasing t (deterministic). */
+int evmi_length_regulate_bwd_f32(const float* grad_out_dev, const int64_t* durations_dev,
+                                 float* grad_values_dev, int B, int L, int D, int t_max,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generic fp32 direct convolutions on torch-native layouts (the exact-arithmetic path and the
+ * building block of EVMI_PREC_F32).  Semantics of torch.nn.functional.conv1d /
+ * conv_transpose1d, which is what every Conv1d/ConvTranspose1d of the reference's vocoder
+ * resolves to (call sites: SURVEY.md §2.2).
+ *
+ *   y = [accumulate ? y : 0] + out_scale * ( conv(lrelu(x, pre_slope)) + bias + residual )
+ * pre_slope = 1 disables the input activation; bias/residual may be NULL.
+ *   x [B, c_in, t_in]   w [c_out, c_in/groups, k]   y [B, c_out, t_out]
+ *   t_out = (t_in + 2*pad - dil*(k-1) - 1) / stride + 1
+ * ------------------------------------------------------------------------------------------ */
+int evmi_conv1d_f32(const float* x_dev, const float* w_dev, const float* bias_dev,
+                    const float* residual_dev, float* y_dev, int B, int c_in, int t_in, int c_out,
+                    int k, int stride, int pad, int dil, int groups, float pre_slope,
+                    float out_scale, int accumulate, void* stream);
+
+/*   x [B, c_in, t_in]   w [c_in, c_out, k]   y [B, c_out, t_out],  t_out = (t_in-1)*stride - 2*pad + k */
+int evmi_conv_transpose1d_f32(const float* x_dev, const float* w_dev, const float* bias_dev,
+                              float* y_dev, int B, int c_in, int t_in, int c_out, int k, int stride,
+                              int pad, float pre_slope, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * HiFiGAN / iSTFTNet generator — replaces the forward of `hfgl.utils.HiFiGANGenerator` /
+ * the generator inside `hfgl.model.HiFiGAN` (absent submodule; call sites
+ * everyvoice/demo/app.py:28-33,457-459, everyvoice/base_cli/checkpoint.py:92-103;
+ * hyper-parameters everyvoice/.schema/everyvoice-spec-to-wav-0.5.json:293-415).
+ * ------------------------------------------------------------------------------------------ */
+#define EVMI_MAX_UPSAMPLES 8
+#define EVMI_MAX_RESBLOCK_KERNELS 8
+#define EVMI_MAX_DILATIONS 8
+
+typedef struct evmi_generator_config {
+  int n_mels;                   /* AudioConfig.n_mels (80)                                  */
+  int upsample_initial_channel; /* 512                                                       */
+  int num_upsamples;
+  int upsample_rates[EVMI_MAX_UPSAMPLES];        /* [8,8,2,2]                              */
+  int upsample_kernel_sizes[EVMI_MAX_UPSAMPLES]; /* [16,16,4,4]                            */
+  int resblock_type;                             /* 1 or 2                                   */
+  int num_kernels;
+  int resblock_kernel_sizes[EVMI_MAX_RESBLOCK_KERNELS]; /* [3,7,11]                        */
+  int num_dilations[EVMI_MAX_RESBLOCK_KERNELS];
+  int resblock_dilations[EVMI_MAX_RESBLOCK_KERNELS][EVMI_MAX_DILATIONS]; /* [[1,3,5]]*3  */
+  float lrelu_slope;      /* activation_function: original_hifigan_leaky_relu = 0.1          */
+  float post_lrelu_slope; /* slope before conv_post (upstream F.leaky_relu default 0.01)     */
+  int istft_layer;        /* 0: conv_post -> tanh ; 1: iSTFTNet head                         */
+  int istft_n_fft;        /* 16 */
+  int istft_hop;          /* 4  */
+} evmi_generator_config;
+
+typedef struct evmi_generator evmi_generator; /* opaque */
+
+int evmi_generator_create(const evmi_generator_config* cfg, int device, evmi_generator** out);
+void evmi_generator_destroy(evmi_generator* g);
+
+/* Weights are given with weight norm already folded (w = g * v / ||v||), fp32, HOST memory, in
+ * torch's native layouts under the upstream state-dict names: "conv_pre.weight" [C0,n_mels,7],
+ * "conv_pre.bias", "ups.{i}.weight" [Cin,Cout,k], "ups.{i}.bias",
+ * "resblocks.{n}.convs1.{m}.weight" [C,C,k], "...bias", "resblocks.{n}.convs2.{m}.*"
+ * ("resblocks.{n}.convs.{m}.*" for resblock type 2), "conv_post.weight", "conv_post.bias". */
+int evmi_generator_set_weight(evmi_generator* g, const char* name, const float* data_host,
+                              int64_t numel);
+/* Number of weight tensors the config expects; name of the i-th and its element count. */
+int evmi_generator_num_weights(const evmi_generator* g);
+int evmi_generator_weight_info(const evmi_generator* g, int i, char* name, int name_len,
+                               int64_t* numel);
+/* Re-lays out and uploads the weights for both precisions.  Must be called after all
+ * evmi_generator_set_weight calls and before the first forward. */
+int evmi_generator_finalize(evmi_generator* g);
+
+/* Samples produced per mel frame (prod(upsample_rates) [* istft_hop]). */
+int evmi_generator_hop(const evmi_generator* g);
+/* Device bytes of scratch one forward at (B, T) needs in `precision`; the object grows its own
+ * workspace to this on first use (hipMalloc outside the timed path). */
+int64_t evmi_generator_workspace_bytes(const evmi_generator* g, int B, int T, int precision);
+
+/* mel_dev [B, n_mels, T] fp32 (torch layout)  ->  wav_dev [B, 1, T*hop] fp32. */
+int evmi_generator_forward(evmi_generator* g, const float* mel_dev, float* wav_dev, int B, int T,
+                           int precision, void* stream);
+
+/* Same forward with every kernel launch bracketed by HIP events on `stream` (synchronises).
+ * Fills up to `cap` records; returns the number of launches through *n_out. */
+typedef struct evmi_launch_record {
+  char kernel[48]; /* kernel family, e.g. "conv_tc_mfma<c128,k11>" */
+  char layer[48];  /* e.g. "resblocks.4.convs1.2"                   */
+  float ms;        /* HIP-event duration of this launch             */
+  double flops;    /* algorithmic FLOPs of this launch (2*MAC)      */
+  double bytes;    /* algorithmic HBM bytes (inputs+outputs+weights once) */
+} evmi_launch_record;
+int evmi_generator_forward_profiled(evmi_generator* g, const float* mel_dev, float* wav_dev, int B,
+                                    int T, int precision, void* stream, evmi_launch_record* records,
+                                    int cap, int* n_out);
+
+/* Algorithmic MACs per output sample of this configuration (V1: 1,199,424). */
+double evmi_generator_macs_per_sample(const evmi_generator* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVMI_H */

@@ -1,0 +1,108 @@
+"""Length regulator on the GPU (through the C ABI) vs the oracle: bit-exact."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import heavy_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def test_expand_golden_bit_exact(golden_dir, cuda_device):
+    from everyvoice_amd.heavy import expand
+
+    g = np.load(golden_dir / "expand.npz")
+    for i in range(5):
+        v = torch.from_numpy(g[f"lj{i}_val"]).to(cuda_device)
+        d = torch.from_numpy(g[f"lj{i}_dur"]).to(cuda_device)
+        out = expand(v, d)
+        assert out.dtype == torch.float32
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), g[f"lj{i}_out"].view(np.uint32))
+    out = expand(torch.from_numpy(g["edge_val"]).to(cuda_device), torch.from_numpy(g["edge_dur"]).to(cuda_device))
+    assert np.array_equal(out.cpu().numpy(), g["edge_out"])  # zero and negative durations
+    out = expand(torch.from_numpy(g["frac_val"]).to(cuda_device), torch.from_numpy(g["frac_dur"]).to(cuda_device))
+    assert np.array_equal(out.cpu().numpy(), g["frac_out"])  # float durations truncate like int()
+    out = expand(torch.arange(5, dtype=torch.float32, device=cuda_device), [1, 2, 0, 1, 3])
+    assert np.array_equal(out.cpu().numpy(), g["np1d_out"])
+    with pytest.raises(RuntimeError):  # the reference's torch.stack([]) error on an all-zero duration vector
+        expand(torch.ones(3, 4, device=cuda_device), [0, 0, -1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16, torch.int32])
+@pytest.mark.parametrize("D", [256, 80, 7])
+def test_batched_vs_oracle(cuda_device, dtype, D):
+    from everyvoice_amd.heavy import length_regulate
+
+    rng = np.random.default_rng(1234)
+    B, L = 9, 61
+    durs = rng.integers(-1, 9, size=(B, L)).astype(np.int64)
+    durs[3] = 0  # one empty item
+    if dtype == torch.int32:
+        vals = torch.from_numpy(rng.integers(-2**31, 2**31 - 1, size=(B, L, D)).astype(np.int32))
+    else:
+        vals = torch.from_numpy(rng.standard_normal((B, L, D)).astype(np.float32)).to(dtype)
+    want, want_lens = heavy_ref.length_regulate_batch_ref(vals.view(torch.int16 if vals.element_size() == 2 else torch.int32).numpy(), durs)
+    out, lens, idx = length_regulate(vals.to(cuda_device), torch.from_numpy(durs).to(cuda_device), return_index=True)
+    got = out.cpu().view(torch.int16 if vals.element_size() == 2 else torch.int32).numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(lens.cpu().numpy(), want_lens)
+    idx = idx.cpu().numpy()
+    for b in range(B):
+        ref_idx = heavy_ref.expand_index_ref(durs[b])
+        assert np.array_equal(idx[b, : len(ref_idx)], ref_idx) and (idx[b, len(ref_idx) :] == -1).all()
+    # explicit max_len: truncation and extra padding
+    for max_len in (5, want.shape[1] + 13):
+        o2, l2 = length_regulate(vals.to(cuda_device), torch.from_numpy(durs).to(cuda_device), max_len=max_len)
+        w2, wl2 = heavy_ref.length_regulate_batch_ref(vals.view(torch.int16 if vals.element_size() == 2 else torch.int32).numpy(), durs, max_len)
+        assert np.array_equal(o2.cpu().view(torch.int16 if vals.element_size() == 2 else torch.int32).numpy(), w2)
+        assert np.array_equal(l2.cpu().numpy(), wl2)
+
+
+def test_empty_and_degenerate(cuda_device):
+    from everyvoice_amd.heavy import length_regulate
+
+    out, lens = length_regulate(torch.zeros(2, 0, 8, device=cuda_device), torch.zeros(2, 0, dtype=torch.int64, device=cuda_device), max_len=4)
+    assert out.shape == (2, 4, 8) and not out.any() and not lens.any()
+    out, lens = length_regulate(torch.ones(2, 3, 8, device=cuda_device), torch.zeros(2, 3, dtype=torch.int64, device=cuda_device))
+    assert out.shape == (2, 0, 8) and not lens.any()
+
+
+def test_full_size_properties(cuda_device):
+    """BASELINE config 3 shape (B=32, L=187, D=256, T<=947): size-independent checks."""
+    from everyvoice_amd.heavy import length_regulate
+
+    g = torch.Generator().manual_seed(1234)
+    B, L, D = 32, 187, 256
+    durs = torch.randint(0, 11, (B, L), generator=g)
+    vals = torch.randn(B, L, D, generator=g)
+    out, lens, idx = length_regulate(vals.to(cuda_device), durs.to(cuda_device), return_index=True)
+    out, lens, idx = out.cpu(), lens.cpu(), idx.cpu().long()
+    assert torch.equal(lens, durs.sum(1))
+    for b in range(B):
+        n = int(lens[b])
+        assert (idx[b, :n].diff() >= 0).all() and (idx[b, n:] == -1).all()  # sortedness
+        assert torch.equal(torch.bincount(idx[b, :n], minlength=L), durs[b])  # each token d_i times
+        assert torch.equal(out[b, :n], vals[b][idx[b, :n]]) and not out[b, n:].any()  # pure gather, bitwise
+    # checksum of checksums on the raw bits
+    bits = vals.view(torch.int32).long().sum(-1)
+    assert int((bits * durs).sum()) == int(out.view(torch.int32).long().sum())
+
+
+def test_backward_is_segment_sum(cuda_device):
+    from everyvoice_amd.heavy import length_regulate, length_regulate_backward
+
+    g = torch.Generator().manual_seed(7)
+    B, L, D = 4, 33, 80
+    durs = torch.randint(0, 6, (B, L), generator=g)
+    T = int(durs.sum(1).max())
+    go = torch.randn(B, T, D, generator=g)
+    gv = length_regulate_backward(go.to(cuda_device), durs.to(cuda_device)).cpu()
+    vals = torch.randn(B, L, D, generator=g, dtype=torch.float64).requires_grad_()
+    # autograd of the oracle formulation
+    outs = []
+    for b in range(B):
+        e = vals[b][torch.from_numpy(heavy_ref.expand_index_ref(durs[b].numpy()))]
+        outs.append(torch.nn.functional.pad(e, (0, 0, 0, T - e.shape[0])))
+    torch.stack(outs).backward(go.double())
+    torch.testing.assert_close(gv.double(), vals.grad, rtol=1e-5, atol=1e-5)

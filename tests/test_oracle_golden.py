@@ -1,0 +1,140 @@
+"""The oracle's in-tree utilities vs golden vectors produced by the reference itself
+(tests/golden/make_golden.py imports /root/reference; only data is committed)."""
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention_prior_ref, heavy_ref, mel_ref
+
+
+def test_expand_matches_reference_on_lj_durations(golden_dir):
+    g = np.load(golden_dir / "expand.npz")
+    sums = []
+    for i in range(5):
+        d, v, want = g[f"lj{i}_dur"], g[f"lj{i}_val"], g[f"lj{i}_out"]
+        got = heavy_ref.expand_ref(v, d)
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+        assert np.array_equal(v[heavy_ref.expand_index_ref(d)], want)
+        sums.append(int(d.sum()))
+    # the sums SURVEY.md §4 reports for tests/data/lj/preprocessed/duration/*.pt
+    assert sorted(sums) == sorted([443, 599, 644, 639, 465])
+
+
+def test_expand_edge_cases(golden_dir):
+    g = np.load(golden_dir / "expand.npz")
+    assert np.array_equal(heavy_ref.expand_ref(g["edge_val"], g["edge_dur"]), g["edge_out"])  # zeros, negatives
+    assert np.array_equal(heavy_ref.expand_ref(g["frac_val"], g["frac_dur"]), g["frac_out"])  # int() truncation
+    assert np.array_equal(heavy_ref.expand_ref(np.array([10, 20, 30]), [2, 0, 3]), g["list_out"])
+    assert np.array_equal(heavy_ref.expand_ref(np.arange(5, dtype=np.float32), [1, 2, 0, 1, 3]), g["np1d_out"])
+    assert heavy_ref.expand_ref(np.zeros((3, 4), np.float32), [0, 0, -2]).shape == (0, 4)
+
+
+def test_length_regulate_batch_is_expand_padded(golden_dir):
+    g = np.load(golden_dir / "expand.npz")
+    L = min(len(g[f"lj{i}_dur"]) for i in range(5))
+    vals = np.stack([g[f"lj{i}_val"][:L] for i in range(5)])
+    durs = np.stack([g[f"lj{i}_dur"][:L] for i in range(5)])
+    out, lens = heavy_ref.length_regulate_batch_ref(vals, durs)
+    for b in range(5):
+        want = heavy_ref.expand_ref(vals[b], durs[b])
+        assert lens[b] == len(want)
+        assert np.array_equal(out[b, : lens[b]], want)
+        assert not out[b, lens[b] :].any()
+
+
+def test_collate_matches_reference(golden_dir):
+    g = np.load(golden_dir / "collate.npz")
+    batch = [
+        {
+            "mel": g[f"in{i}_mel"],
+            "text": g[f"in{i}_text"],
+            "nested": {"pitch": g[f"in{i}_pitch"], "speaker_id": int(g[f"in{i}_speaker_id"])},
+            "basename": f"utt{i}",
+        }
+        for i in range(4)
+    ]
+    out = heavy_ref.collate_ref(batch)
+    assert sorted(out.keys()) == list(g["out_keys"])
+    for k in ("mel", "text", "nested_pitch", "nested_speaker_id"):
+        assert np.array_equal(out[k], g[f"out_{k}"]), k
+    assert out["nested_speaker_id"].dtype == np.int32
+    assert out["basename"] == [f"utt{i}" for i in range(4)]
+
+
+def test_dynamic_range_compression(golden_dir):
+    g = np.load(golden_dir / "drc.npz")
+    np.testing.assert_allclose(heavy_ref.drc_ref(g["x"]), g["drc"], rtol=0, atol=1e-6)  # libm vs torch log: 1 ulp
+    np.testing.assert_allclose(heavy_ref.drd_ref(g["drc"]), g["drd"], rtol=1e-6)
+
+
+def test_get_segments(golden_dir):
+    g = np.load(golden_dir / "segments.npz")
+    st = g["starts"]
+    seg, s = heavy_ref.get_segments_ref(g["mel"], 32, int(st[0]))
+    assert s == 17 and np.array_equal(seg, g["seg_mel"])
+    seg, s = heavy_ref.get_segments_ref(g["wav"], 8192, int(st[1]))
+    assert np.array_equal(seg, g["seg_wav"])
+    seg, s = heavy_ref.get_segments_ref(g["short"], 32, 0)
+    assert s == 0 and np.array_equal(seg, g["seg_short"]) and seg.shape == (80, 32)
+    seg, s = heavy_ref.get_segments_ref(g["exact"], 32, 0)
+    assert np.array_equal(seg, g["seg_exact"])
+    with pytest.raises(AssertionError):  # start beyond len - seg - 1 is rejected, as in the reference
+        heavy_ref.get_segments_ref(g["exact"], 32, 1)
+
+
+def test_attention_prior(golden_dir):
+    g = np.load(golden_dir / "attn_prior.npz")
+    for i, (T, L) in enumerate(g["shapes"]):
+        got = attention_prior_ref.attention_prior_ref(int(T), int(L))
+        assert got.dtype == np.float64 and got.shape == (T, L)
+        np.testing.assert_allclose(got, g[f"p{i}"], rtol=0, atol=1e-12)
+
+
+def test_lrelu_fixture(golden_dir):
+    g = np.load(golden_dir / "lrelu.npz")
+    x = g["x"]
+    assert np.array_equal(np.where(x > 0, x, x * np.float32(0.1)).astype(np.float32), g["y"])
+
+
+def test_depthwise_separable_factory_fixture(golden_dir):
+    """everyvoice/model/utils.py:5-48: weight-normed depthwise + pointwise; as shipped only the
+    transposed branch is constructible (the Conv1d branch passes output_padding)."""
+    g = np.load(golden_dir / "dwsep.npz")
+    assert "output_padding" in str(g["conv_branch_error"])
+    assert list(g["names"]) == ["0.bias", "0.weight_g", "0.weight_v", "1.bias", "1.weight_g", "1.weight_v"]
+
+    def fold(gw, v):
+        return v * (gw / np.sqrt((v**2).sum(axis=(1, 2), keepdims=True)))
+
+    x = torch.from_numpy(g["x"])
+    w0 = torch.from_numpy(fold(g["0__weight_g"], g["0__weight_v"]))
+    w1 = torch.from_numpy(fold(g["1__weight_g"], g["1__weight_v"]))
+    y = torch.nn.functional.conv_transpose1d(x, w0, torch.from_numpy(g["0__bias"]), padding=1, groups=16)
+    y = torch.nn.functional.conv_transpose1d(y, w1, torch.from_numpy(g["1__bias"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-6)
+
+
+def test_mel_frontend_against_ming024_anchor(golden_dir):
+    """Sanity anchor (not a bit pin): the mel of LJ010-0008.wav held in the reference's test data."""
+    g = np.load(golden_dir / "mel_anchor.npz")
+    audio = g["pcm"].astype(np.float32) / 32768.0
+    mel = mel_ref.mel_spectrogram_ref(audio).numpy().T
+    ref = g["mel_ming024"]
+    n = min(len(mel), len(ref))
+    diff = np.abs(mel[:n] - ref[:n])
+    assert diff.mean() < 3e-4
+    assert diff[4 : n - 4].max() < 0.02
+    # frame-count invariants of the reference's tests (test_preprocessing.py:356-383)
+    S = len(audio) // 256 * 256
+    t = mel_ref.mel_spectrogram_ref(audio[:S], truncate=True)
+    assert t.shape == (80, S // 256)
+
+
+def test_slaney_basis_properties():
+    b = mel_ref.slaney_mel_basis(22050, 1024, 80, 0, 8000)
+    assert b.shape == (80, 513) and b.dtype == np.float32
+    assert (b >= 0).all() and (b.sum(axis=1) > 0).all()
+    assert not b[:, 372:].any()  # nothing above f_max = 8000 Hz (bin 371.5)
+    energy = heavy_ref.energy_ref(np.log(np.maximum(b @ np.ones((513, 3), np.float32), 1e-5)))
+    assert energy.shape == (3,)
