@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Headline benchmark: HiFiGAN-V1 generator inference, 22.05 kHz audio samples / second.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): mel = clamp(N(-5, 2^2), -11.5129, 2.0) of
+shape [32, 80, 768] per GPU, seed 1234 + rank, already resident in HBM; weights N(0, 0.01) upstream
+init with weight norm folded; one step = one generator forward = 32 x 768 x 256 = 6,291,456 samples.
+Inference does not shard anything between GPUs ("replicas only"): N ranks run N
+independent replicas, `value` is the sum over ranks, scaling is weak.
+
+The JSON line carries, besides the driver's contract fields:
+  roofline      the dominant kernel family of the forward, timed live with HIP events on the launch
+                stream (evmi_generator_forward_profiled); achieved = algorithmic FLOP per launch /
+                mean launch duration, against the dense bf16 MFMA peak (2.5 PFLOP/s)
+  cpu_baseline  the CPU oracle (oracle/hifigan_ref.py, a port: the reference's own vocoder code is an
+                un-vendored submodule) timed on this box's host cores on a bounded slice of the
+                same workload (rank 0, N = 1 only)
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+B_PER_GPU = 32
+T_FRAMES = 768
+HOP = 256
+MFMA_PEAK_TFLOPS_BF16 = 2500.0  # dense; /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+METRIC = "hifigan_v1_infer_audio_samples_per_sec"
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--batch", type=int, default=B_PER_GPU)
+    p.add_argument("--frames", type=int, default=T_FRAMES)
+    p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-frames", type=int, default=64, help="mel frames per item of the CPU-baseline sample")
+    p.add_argument("--cpu-batch", type=int, default=4)
+    p.add_argument("--profile-passes", type=int, default=3)
+    return p.parse_args(argv)
+
+
+def dist_env():
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return rank, local_rank, world
+
+
+def timed_region(step_fn, steps: int, warmup: int, sync_fn, barrier_fn, max_reduce_fn) -> float:
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both
+    sides; returns the MAX over ranks of the elapsed seconds."""
+    for _ in range(warmup):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    sync_fn()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    sync_fn()
+    barrier_fn()
+    sync_fn()
+    elapsed = time.perf_counter() - t0
+    return max_reduce_fn(elapsed)
+
+
+def upstream_init_generator(precision: str):
+    """HiFi-GAN V1 (schema defaults), upstream N(0, 0.01) init, fixed seed."""
+    import torch
+
+    from everyvoice_amd.config import HiFiGANConfig
+    from everyvoice_amd.vocoder import HiFiGANGenerator
+
+    torch.manual_seed(1234)
+    return HiFiGANGenerator(HiFiGANConfig(), precision=precision)
+
+
+def synthetic_mel(batch: int, frames: int, seed: int):
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(batch, 80, frames, generator=g) * 2.0 - 5.0).clamp(-11.5129, 2.0)
+
+
+def roofline_from_records(passes: list[list[dict]]) -> dict:
+    """Aggregate HIP-event launch records by kernel family; describe the dominant one."""
+    tot_ms, tot_flops, tot_bytes, count = defaultdict(float), defaultdict(float), defaultdict(float), defaultdict(int)
+    for recs in passes:
+        for r in recs:
+            k = r["kernel"]
+            tot_ms[k] += r["ms"]
+            tot_flops[k] += r["flops"]
+            tot_bytes[k] += r["bytes"]
+            count[k] += 1
+    all_ms = sum(tot_ms.values())
+    dom = max(tot_ms, key=tot_ms.get)
+    avg_ms = tot_ms[dom] / count[dom]
+    achieved = (tot_flops[dom] / count[dom]) / (avg_ms * 1e-3) / 1e12
+    fams = sorted(tot_ms, key=tot_ms.get, reverse=True)
+    return {
+        "bound": "mfma",
+        "kernel": dom,
+        "achieved": round(achieved, 2),
+        "peak": MFMA_PEAK_TFLOPS_BF16,
+        "unit": "TFLOP/s",
+        "frac": round(achieved / MFMA_PEAK_TFLOPS_BF16, 4),
+        "traffic": None,
+        "avg_launch_ms": round(avg_ms, 4),
+        "launches_per_forward": count[dom] // len(passes),
+        "share_of_forward_time": round(tot_ms[dom] / all_ms, 4),
+        "algorithmic_gflop_per_launch": round(tot_flops[dom] / count[dom] / 1e9, 3),
+        "algorithmic_hbm_gbs": round((tot_bytes[dom] / count[dom]) / (avg_ms * 1e-3) / 1e9, 1),
+        "whole_forward": {
+            "event_ms": round(all_ms / len(passes), 3),
+            "tflops": round(sum(tot_flops.values()) / len(passes) / (all_ms / len(passes) * 1e-3) / 1e12, 2),
+            "by_kernel_ms": {k: round(tot_ms[k] / len(passes), 3) for k in fams[:8]},
+        },
+    }
+
+
+def cpu_baseline(frames: int, batch: int) -> dict:
+    """The CPU oracle on this box's host cores, on a bounded slice of the same workload."""
+    import torch
+
+    from oracle.hifigan_ref import GeneratorRef
+
+    torch.manual_seed(1234)
+    ref = GeneratorRef().eval().remove_weight_norm()
+    mel = synthetic_mel(batch, frames, 1234)
+    # host cores this process may use; torch's intra-op pool oversubscribes badly past ~64 threads on
+    # these convolutions, so pick the fastest of a few thread counts on a tiny probe and say which
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    best = None
+    with torch.no_grad():
+        for n in sorted({min(avail, c) for c in (8, 16, 32, 64, avail)}):
+            torch.set_num_threads(n)
+            ref(mel[:1, :, :8])
+            t0 = time.perf_counter()
+            ref(mel[:1, :, :8])
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, n)
+        cores = best[1]
+        torch.set_num_threads(cores)
+        t0 = time.perf_counter()
+        wav = ref(mel)
+        dt = time.perf_counter() - t0
+    return {
+        "value": round(wav.numel() / dt, 1),
+        "unit": "samples/s",
+        "cores": cores,
+        "host_cores_available": avail,
+        "kind": "port",
+        "sample": f"oracle/hifigan_ref.py GeneratorRef fp32, torch {torch.__version__} CPU, {cores} threads, "
+                  f"mel [{batch},80,{frames}] slice of the bench input ({wav.numel()} samples in {dt:.2f} s)",
+    }
+
+
+def main(argv=None) -> int:
+    args = parse_args(argv)
+    import torch
+
+    rank, local_rank, world = dist_env()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})", file=sys.stderr)
+            return 2
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
+        return 2
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+        def barrier():
+            dist.barrier(device_ids=[local_rank])
+
+        def max_reduce(x):
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+    else:
+        barrier = lambda: None  # noqa: E731
+        max_reduce = lambda x: x  # noqa: E731
+
+    model = upstream_init_generator(args.precision).to(dev).eval()
+    mel = synthetic_mel(args.batch, args.frames, 1234 + rank).to(dev)
+    gen = model.generator
+    samples_per_step = args.batch * args.frames * gen.hop
+    out = {}
+
+    def step():
+        out["wav"] = gen(mel)
+
+    elapsed = timed_region(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    value = world * samples_per_step * args.steps / elapsed
+
+    result = None
+    if rank == 0:
+        passes = []
+        for _ in range(args.profile_passes):
+            _, recs = gen.forward_profiled(mel)
+            passes.append(recs)
+        roof = roofline_from_records(passes)
+        flops_per_sample = 2.0 * gen.macs_per_sample()
+        result = {
+            "metric": METRIC,
+            "value": round(value, 1),
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {
+                "workload": f"HiFiGAN-V1 generator inference, mel[{args.batch},80,{args.frames}] -> wav[{args.batch},1,{args.frames * gen.hop}] "
+                            f"per GPU, {world} replica(s), upstream N(0,0.01) init, weight norm folded",
+                "global_batch": args.batch * world,
+                "frames": args.frames,
+                "samples_per_step_per_gpu": samples_per_step,
+                "parallelism": f"replicas x{world}",
+                "flop_per_sample": flops_per_sample,
+            },
+            "whole_job_tflops": round(value * flops_per_sample / 1e12, 2),
+            "realtime_factor": round(value / 22050.0, 1),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_batch)
+            result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+    if use_dist:
+        import torch.distributed as dist
+
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

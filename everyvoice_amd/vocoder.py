@@ -103,7 +103,7 @@ class Generator(nn.Module):
         post_out = config.gen_istft_n_fft + 2 if m.istft_layer else 1
         self.conv_post = _ConvParams(post_out, ch_last, 7, bias=post_out)
         self._c_cfg = _model_cfg_to_c(config)
-        self._handle = None
+        object.__setattr__(self, "_handle", None)
         self._uploaded_version = None
         self.reset_parameters()
 
@@ -145,7 +145,7 @@ class Generator(nn.Module):
         if self._handle is None:
             h = C.c_void_p()
             _lib.check(lib.evmi_generator_create(C.byref(self._c_cfg), device.index or 0, C.byref(h)), "evmi_generator_create")
-            self._handle = h
+            object.__setattr__(self, "_handle", h)
         ver = self._weights_version()
         if self._uploaded_version != ver:
             for name, p in self.named_parameters():
@@ -159,9 +159,12 @@ class Generator(nn.Module):
         return lib
 
     def __del__(self):
-        h, self._handle = getattr(self, "_handle", None), None
-        if h is not None and _lib._lib is not None:
-            _lib._lib.evmi_generator_destroy(h)
+        try:
+            h = self.__dict__.pop("_handle", None)
+            if h is not None and _lib._lib is not None:
+                _lib._lib.evmi_generator_destroy(h)
+        except Exception:  # interpreter shutdown: module globals may already be gone
+            pass
 
     @property
     def hop(self) -> int:
@@ -175,7 +178,7 @@ class Generator(nn.Module):
         if self._handle is None:
             h = C.c_void_p()
             _lib.check(lib.evmi_generator_create(C.byref(self._c_cfg), 0, C.byref(h)), "evmi_generator_create")
-            self._handle = h
+            object.__setattr__(self, "_handle", h)
         return float(lib.evmi_generator_macs_per_sample(self._handle))
 
     def _check_input(self, mel: torch.Tensor) -> torch.Tensor:
