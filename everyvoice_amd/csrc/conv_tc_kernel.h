@@ -1,0 +1,240 @@
+// Device template of the MFMA implicit-GEMM convolution (included by conv_tc_mfma.hip, which
+// instantiates the product table, and by bench_kernels.hip, which instantiates tuning variants).
+#pragma once
+
+#include "conv_tc_mfma.h"
+
+namespace evmi {
+
+// ABL: ablation bits for the micro-benchmark only (tools/sweep_conv.py); 0 in the product table.
+//   1 = no weight streaming after step 0   2 = activation tile loaded for chunk 0 only
+//   4 = no epilogue                        8 = no MFMA (data movement only)
+template <int CIN_, int KC_, int BM_, int BN_, int WM_, int WN_, int KS_, int TAPS_, int MAXDIL_, int ABL_ = 0, int OCC_ = 0>
+struct ConvTcCfg {
+  static constexpr int CIN = CIN_, KC = KC_, BM = BM_, BN = BN_, WM = WM_, WN = WN_, KS = KS_,
+                       TAPS = TAPS_, MAXDIL = MAXDIL_, ABL = ABL_;
+  // waves per SIMD the register allocator must leave room for (0: no constraint beyond the block)
+  static constexpr int OCC = OCC_ > 0 ? OCC_ : (WM_ * WN_ + 3) / 4;
+  static constexpr int NTHREADS = WM * WN * 64;
+  static constexpr int MT = BM / (WM * 32), NT = BN / (WN * 32);
+  static constexpr int XS = KC + 8, AS = KC + 8, OS = BM + 8;
+  static constexpr int R_MAX = BN + (KS - 1) * MAXDIL;
+  static constexpr int NCHUNK = CIN / KC;
+  static constexpr int NGROUP = (KS + TAPS - 1) / TAPS;
+  static constexpr int NSTEP = NCHUNK * NGROUP;
+  static constexpr int NABUF = NSTEP > 1 ? 2 : 1;
+  static constexpr int A_TILE = TAPS * BM * AS;       // LDS elements per buffer
+  static constexpr int A_VECS = TAPS * BM * (KC / 8); // 16-B vectors per tap group
+  static constexpr int A_PER_THREAD = (A_VECS + NTHREADS - 1) / NTHREADS;
+  // every tap group is full and divides evenly over the threads: no per-vector guards needed
+  static constexpr bool A_EXACT = (KS % TAPS == 0) && (A_VECS % NTHREADS == 0);
+  static constexpr size_t LDS_MAIN = size_t(R_MAX * XS + NABUF * A_TILE) * 2;
+  static constexpr size_t LDS_OUT = size_t(BN) * OS * 2;
+  static constexpr size_t LDS = LDS_MAIN > LDS_OUT ? LDS_MAIN : LDS_OUT;
+  static_assert(CIN % KC == 0 && KC % 16 == 0, "channel chunking");
+  static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiling");
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <class C>
+__global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* As = Xs + C::R_MAX * C::XS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / C::WN, wn = wave % C::WN;
+  const int r0 = blockIdx.x * C::BN;
+  const int b = blockIdx.y;
+  const int mtile = blockIdx.z;
+  const int m0 = mtile * C::BM;
+
+  const bf16_t* __restrict__ xb = a.x + (long long)b * a.x_batch_stride;
+  // weights pre-laid-out by the host as [mtile][chunk][tap][BM][KC] (see relayout_conv_tc_weights)
+  const bf16_t* __restrict__ wb = a.w + (long long)mtile * C::NCHUNK * C::KS * C::BM * C::KC;
+
+  f32x16 acc[C::MT][C::NT];
+#pragma unroll
+  for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  bf16x8 areg[C::A_PER_THREAD];
+
+  auto a_prefetch = [&](int step) {
+    const int chunk = step / C::NGROUP, grp = step % C::NGROUP;
+    const bf16_t* src = wb + ((long long)chunk * C::KS + grp * C::TAPS) * C::BM * C::KC;
+    const int ntaps = (C::KS - grp * C::TAPS) < C::TAPS ? (C::KS - grp * C::TAPS) : C::TAPS;
+    const int nvec = ntaps * C::BM * (C::KC / 8);
+#pragma unroll
+    for (int i = 0; i < C::A_PER_THREAD; ++i) {
+      const int v = tid + i * C::NTHREADS;
+      if (C::A_EXACT || v < nvec) areg[i] = *reinterpret_cast<const bf16x8*>(src + (long long)v * 8);
+    }
+  };
+  auto a_commit = [&](int step) {
+    bf16_t* dst = As + (step & (C::NABUF - 1)) * C::A_TILE;
+    const int grp = step % C::NGROUP;
+    const int ntaps = (C::KS - grp * C::TAPS) < C::TAPS ? (C::KS - grp * C::TAPS) : C::TAPS;
+    const int nvec = ntaps * C::BM * (C::KC / 8);
+#pragma unroll
+    for (int i = 0; i < C::A_PER_THREAD; ++i) {
+      const int v = tid + i * C::NTHREADS;
+      if (C::A_EXACT || v < nvec) {
+        const int row = v / (C::KC / 8);  // tap*BM + m
+        const int c8 = v % (C::KC / 8);
+        *reinterpret_cast<bf16x8*>(dst + row * C::AS + c8 * 8) = areg[i];
+      }
+    }
+  };
+
+  const int rows_needed = C::BN + (C::KS - 1) * a.dil;
+  const float pre = a.pre_slope;
+
+  a_prefetch(0);
+#pragma unroll 1
+  for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
+    if (chunk > 0) __syncthreads();  // everyone is done reading the previous X chunk
+    // ---- activation tile: rows [r0 - pad, r0 - pad + rows_needed) x channels [chunk*KC, +KC)
+    if (!(C::ABL & 2) || chunk == 0) {
+      const int nvec = rows_needed * (C::KC / 8);
+      for (int v = tid; v < nvec; v += C::NTHREADS) {
+        const int i = v / (C::KC / 8), c8 = v % (C::KC / 8);
+        const int rr = r0 - a.pad + i;
+        bf16x8 val;
+        if (rr >= 0 && rr < a.t_in) {
+          val = *reinterpret_cast<const bf16x8*>(xb + (long long)rr * C::CIN + chunk * C::KC + c8 * 8);
+          if (pre != 1.f) {  // slope in [0, 1]: lrelu(x) = max(x, slope * x)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float f = (float)val[e];
+              val[e] = (bf16_t)fmaxf(f, f * pre);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) val[e] = (bf16_t)0.f;
+        }
+        *reinterpret_cast<bf16x8*>(Xs + i * C::XS + c8 * 8) = val;
+      }
+    }
+#pragma unroll 1
+    for (int grp = 0; grp < C::NGROUP; ++grp) {
+      const int step = chunk * C::NGROUP + grp;
+      if (!(C::ABL & 1) || step == 0) a_commit(step);
+      __syncthreads();
+      if (step + 1 < C::NSTEP && !(C::ABL & 1)) a_prefetch(step + 1);
+      const bf16_t* Ab = As + ((C::ABL & 1) ? 0 : (step & (C::NABUF - 1))) * C::A_TILE;
+#pragma unroll
+      for (int jj = 0; jj < C::TAPS; ++jj) {
+        const int j = grp * C::TAPS + jj;
+        if (j < C::KS) {
+          const bf16_t* Arow = Ab + (jj * C::BM + wm * C::MT * 32 + (lane & 31)) * C::AS + (lane >> 5) * 8;
+          const bf16_t* Brow = Xs + (wn * C::NT * 32 + (lane & 31) + j * a.dil) * C::XS + (lane >> 5) * 8;
+#pragma unroll
+          for (int ks = 0; ks < C::KC / 16; ++ks) {
+            bf16x8 af[C::MT], bfr[C::NT];
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+              af[mt] = *reinterpret_cast<const bf16x8*>(Arow + mt * 32 * C::AS + ks * 16);
+#pragma unroll
+            for (int nt = 0; nt < C::NT; ++nt)
+              bfr[nt] = *reinterpret_cast<const bf16x8*>(Brow + nt * 32 * C::XS + ks * 16);
+#pragma unroll
+            for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < C::NT; ++nt)
+                if (!(C::ABL & 8))
+                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
+                else
+                  acc[mt][nt][0] += (float)af[mt][0] * (float)bfr[nt][0];
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: acc + bias -> bf16 -> LDS [BN][BM+8] -> coalesced fused store -----------------
+  if (C::ABL & 4) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[mt][nt][r];
+    if (sacc == 12345.678f) a.out[0] = (bf16_t)sacc;  // keep the accumulators live
+    return;
+  }
+  __syncthreads();
+  bf16_t* Os = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = wm * C::MT * 32 + mt * 32 + 8 * q + 4 * (lane >> 5);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + m0 + c);
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) {
+        const int n = wn * C::NT * 32 + nt * 32 + (lane & 31);
+        bf16x4 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk[i] = (bf16_t)(acc[mt][nt][4 * q + i] + bv[i]);
+        *reinterpret_cast<bf16x4*>(Os + n * C::OS + c) = pk;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const long long ob = (long long)b * a.out_batch_stride;
+    const float scale = a.out_scale, post = a.post_slope;
+    constexpr int VPR = C::BM / 8;
+    for (int v = tid; v < C::BN * VPR; v += C::NTHREADS) {
+      const int n = v / VPR, c8 = v % VPR;
+      const int r = r0 + n;
+      if (r >= a.n_rows) continue;
+      const long long flat = (long long)r * a.out_row_stride + m0 + c8 * 8 + a.out_shift;
+      if (flat < 0 || flat >= a.out_limit) continue;
+      const bf16x8 o = *reinterpret_cast<const bf16x8*>(Os + n * C::OS + c8 * 8);
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = (float)o[e];
+      if (a.res) {
+        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + ob + flat);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += (float)rv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] *= scale;
+      if (a.accumulate) {
+        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(a.out + ob + flat);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] += (float)pv[e];
+      }
+      bf16x8 res;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) res[e] = (bf16_t)(post != 1.f ? lrelu(f[e], post) : f[e]);
+      *reinterpret_cast<bf16x8*>(a.out + ob + flat) = res;
+    }
+  }
+}
+
+
+template <class C>
+static ConvTcLaunch make_conv_tc_launch(const char* name) {
+  ConvTcLaunch l;
+  l.kernel = conv_tc_kernel<C>;
+  l.bm = C::BM;
+  l.bn = C::BN;
+  l.kc = C::KC;
+  l.threads = C::NTHREADS;
+  l.lds_bytes = C::LDS;
+  l.name = name;
+  return l;
+}
+
+}  // namespace evmi
