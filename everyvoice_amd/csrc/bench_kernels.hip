@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "conv_tc_kernel.h"
+#include "resblock_pair_kernel.h"
 
 namespace evmi {
 
@@ -23,25 +24,16 @@ struct Variant {
   X("c128k11_noA_noX", 128, 64, 128, 128, 2, 2, 11, 1, 5, 3)       \
   X("c128k11_noA_noX_noEpi", 128, 64, 128, 128, 2, 2, 11, 1, 5, 7) \
   X("c128k11_bm64", 128, 64, 64, 128, 1, 4, 11, 1, 5, 0)           \
-  X("c128k11_bm64_t2", 128, 64, 64, 128, 1, 4, 11, 2, 5, 0)        \
   X("c128k11_bn256", 128, 64, 128, 256, 2, 4, 11, 1, 5, 0)         \
   X("c128k11_kc128", 128, 128, 128, 128, 2, 2, 11, 1, 5, 0)        \
   X("c128k11_kc128_bn256", 128, 128, 128, 256, 2, 4, 11, 1, 5, 0)  \
-  X("c128k11_t2", 128, 64, 128, 128, 2, 2, 11, 2, 5, 0)            \
   X("c128k3_base", 128, 64, 128, 128, 2, 2, 3, 1, 5, 0)            \
   X("c128k3_noX", 128, 64, 128, 128, 2, 2, 3, 1, 5, 2)             \
   X("c128k3_noEpi", 128, 64, 128, 128, 2, 2, 3, 1, 5, 4)           \
   X("c128k3_kc128", 128, 128, 128, 128, 2, 2, 3, 1, 5, 0)          \
   X("c128k3_kc128_t3", 128, 128, 128, 128, 2, 2, 3, 3, 5, 0)       \
   X("c128k3_bm64_kc128_t3", 128, 128, 64, 128, 1, 4, 3, 3, 5, 0)   \
-  X("c64k11_base", 64, 64, 64, 128, 1, 4, 11, 2, 5, 0)             \
-  X("c64k11_noEpi", 64, 64, 64, 128, 1, 4, 11, 2, 5, 4)            \
-  X("c64k11_noX", 64, 64, 64, 128, 1, 4, 11, 2, 5, 2)              \
-  X("c64k11_noA", 64, 64, 64, 128, 1, 4, 11, 2, 5, 1)              \
   X("c64k11_t1", 64, 64, 64, 128, 1, 4, 11, 1, 5, 0)               \
-  X("c64k11_bn256", 64, 64, 64, 256, 1, 4, 11, 2, 5, 0)            \
-  X("c64k11_bn256_w8", 64, 64, 64, 256, 1, 8, 11, 2, 5, 0)         \
-  X("c64k11_wm2", 64, 64, 64, 128, 2, 2, 11, 2, 5, 0)              \
   X("c64k3_base", 64, 64, 64, 128, 1, 4, 3, 3, 5, 0)               \
   X("c64k3_bn256", 64, 64, 64, 256, 1, 4, 3, 3, 5, 0)              \
   X("c32k11_base", 32, 32, 32, 256, 1, 4, 11, 11, 5, 0)            \
@@ -168,3 +160,38 @@ int evmi_bench_conv_tc(const char* name, int B, int T, int c_out, int dil, int w
 }
 
 }  // extern "C"
+
+// Cycle timeline of workgroup 0 of the fused pair kernel (debug instantiation): returns up to `cap`
+// s_memtime stamps (tile start, x committed, one per step, loops done, stores issued, ... per tile).
+extern "C" int evmi_debug_pair_timeline(int c, int ks, int dil, int B, int T, long long* stamps_host, int cap) {
+  using namespace evmi;
+  PairLaunch L;
+  if (c == 64 && ks == 11) L = make_pair_launch<PairCfg<64, 11, 256, 2, 5, 8, 1>>("dbg_pair_c64k11");
+  else if (c == 64 && ks == 3) L = make_pair_launch<PairCfg<64, 3, 256, 2, 5, 8, 1>>("dbg_pair_c64k3");
+  else if (c == 32 && ks == 11) L = make_pair_launch<PairCfg<32, 11, 512, 4, 5, 8, 1>>("dbg_pair_c32k11");
+  else return fail(EVMI_ERR_INVALID_ARG, "debug timeline: unsupported (c, ks)");
+  const size_t xe = (size_t)B * T * c, we = (size_t)2 * c * c * ks;
+  bf16_t *x = nullptr, *w = nullptr, *out = nullptr;
+  float* bias = nullptr;
+  long long* tl = nullptr;
+  EVMI_HIP_CHECK(hipMalloc((void**)&x, xe * 2));
+  EVMI_HIP_CHECK(hipMalloc((void**)&w, we * 2));
+  EVMI_HIP_CHECK(hipMalloc((void**)&out, xe * 2));
+  EVMI_HIP_CHECK(hipMalloc((void**)&bias, (size_t)2 * c * 4));
+  EVMI_HIP_CHECK(hipMalloc((void**)&tl, 256 * 8));
+  EVMI_HIP_CHECK(hipMemset(tl, 0, 256 * 8));
+  hipLaunchKernelGGL(fill_bf16_kernel, dim3((unsigned)((xe + 255) / 256)), dim3(256), 0, 0, x, (long long)xe, 1u, 1.f);
+  hipLaunchKernelGGL(fill_bf16_kernel, dim3((unsigned)((we + 255) / 256)), dim3(256), 0, 0, w, (long long)we, 2u, 0.05f);
+  EVMI_HIP_CHECK(hipMemset(bias, 0, (size_t)2 * c * 4));
+  PairArgs a;
+  a.x = x; a.w1 = w; a.w2 = w + (size_t)c * c * ks; a.b1 = bias; a.b2 = bias + c; a.out = out;
+  a.T = T; a.dil1 = dil; a.slope = 0.1f; a.post_slope = 1.f; a.out_scale = 1.f; a.accumulate = 0; a.timeline = tl;
+  for (int i = 0; i < 2; ++i) {
+    int rc = launch_resblock_pair(&L, a, B, 256, 0);
+    if (rc) return rc;
+  }
+  EVMI_HIP_CHECK(hipDeviceSynchronize());
+  EVMI_HIP_CHECK(hipMemcpy(stamps_host, tl, (size_t)(cap < 256 ? cap : 256) * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(x); (void)hipFree(w); (void)hipFree(out); (void)hipFree(bias); (void)hipFree(tl);
+  return EVMI_OK;
+}

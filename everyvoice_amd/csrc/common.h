@@ -40,6 +40,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// One tap group of the implicit GEMM for one wave: NTAPS taps x KSTEPS 16-deep k-steps, fragments
+// read from LDS one k-step ahead of the MFMAs that consume them (explicit software pipelining: the
+// compiler otherwise issues the ds_reads of step k+1 only after the last MFMA of step k).
+//   Arow: this lane's A row (tap 0, m-tile 0) + (lane>>5)*8;  A tap stride / m-tile stride in elements
+//   Brow: this lane's B row (tap 0, n-tile 0) + (lane>>5)*8;  b_tap_stride = dilation * row stride
+template <int MT, int NT, int KSTEPS, int NTAPS, int A_TAP_STRIDE, int A_MT_STRIDE, int B_NT_STRIDE>
+__device__ __forceinline__ void mma_tap_group(const bf16_t* __restrict__ Arow, const bf16_t* __restrict__ Brow,
+                                              int b_tap_stride, f32x16 (&acc)[MT][NT]) {
+  constexpr int N = NTAPS * KSTEPS;
+  bf16x8 af[2][MT], bfr[2][NT];
+  auto load = [&](int kk, int buf) {
+    const int jj = kk / KSTEPS, ks = kk % KSTEPS;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      af[buf][mt] = *reinterpret_cast<const bf16x8*>(Arow + jj * A_TAP_STRIDE + mt * A_MT_STRIDE + ks * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      bfr[buf][nt] = *reinterpret_cast<const bf16x8*>(Brow + jj * b_tap_stride + nt * B_NT_STRIDE + ks * 16);
+  };
+  load(0, 0);
+#pragma unroll
+  for (int kk = 0; kk < N; ++kk) {
+    const int cur = kk & 1;
+    if (kk + 1 < N) load(kk + 1, cur ^ 1);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mt], bfr[cur][nt], acc[mt][nt], 0, 0, 0);
+  }
+}
+
 // host-side round-to-nearest-even fp32 -> bf16 bits (NaN kept quiet)
 inline uint16_t f32_to_bf16_bits(float f) {
   uint32_t u;

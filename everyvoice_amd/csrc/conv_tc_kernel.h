@@ -32,6 +32,7 @@ struct ConvTcCfg {
   static constexpr size_t LDS_OUT = size_t(BN) * OS * 2;
   static constexpr size_t LDS = LDS_MAIN > LDS_OUT ? LDS_MAIN : LDS_OUT;
   static_assert(CIN % KC == 0 && KC % 16 == 0, "channel chunking");
+  static_assert(KS % TAPS == 0, "tap groups must be full");
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiling");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -129,31 +130,14 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
       __syncthreads();
       if (step + 1 < C::NSTEP && !(C::ABL & 1)) a_prefetch(step + 1);
       const bf16_t* Ab = As + ((C::ABL & 1) ? 0 : (step & (C::NABUF - 1))) * C::A_TILE;
-#pragma unroll
-      for (int jj = 0; jj < C::TAPS; ++jj) {
-        const int j = grp * C::TAPS + jj;
-        if (j < C::KS) {
-          const bf16_t* Arow = Ab + (jj * C::BM + wm * C::MT * 32 + (lane & 31)) * C::AS + (lane >> 5) * 8;
-          const bf16_t* Brow = Xs + (wn * C::NT * 32 + (lane & 31) + j * a.dil) * C::XS + (lane >> 5) * 8;
-#pragma unroll
-          for (int ks = 0; ks < C::KC / 16; ++ks) {
-            bf16x8 af[C::MT], bfr[C::NT];
-#pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt)
-              af[mt] = *reinterpret_cast<const bf16x8*>(Arow + mt * 32 * C::AS + ks * 16);
-#pragma unroll
-            for (int nt = 0; nt < C::NT; ++nt)
-              bfr[nt] = *reinterpret_cast<const bf16x8*>(Brow + nt * 32 * C::XS + ks * 16);
-#pragma unroll
-            for (int mt = 0; mt < C::MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < C::NT; ++nt)
-                if (!(C::ABL & 8))
-                  acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bfr[nt], acc[mt][nt], 0, 0, 0);
-                else
-                  acc[mt][nt][0] += (float)af[mt][0] * (float)bfr[nt][0];
-          }
-        }
+      {
+        const bf16_t* Arow = Ab + (wm * C::MT * 32 + (lane & 31)) * C::AS + (lane >> 5) * 8;
+        const bf16_t* Brow = Xs + (wn * C::NT * 32 + (lane & 31) + grp * C::TAPS * a.dil) * C::XS + (lane >> 5) * 8;
+        if (!(C::ABL & 8))
+          mma_tap_group<C::MT, C::NT, C::KC / 16, C::TAPS, C::BM * C::AS, 32 * C::AS, 32 * C::XS>(
+              Arow, Brow, a.dil * C::XS, acc);
+        else
+          acc[0][0][0] += (float)Arow[0] * (float)Brow[0];
       }
     }
   }

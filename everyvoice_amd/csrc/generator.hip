@@ -12,12 +12,14 @@
 // Every convolution's input activation is therefore applied exactly once per element, either
 // in the producer's epilogue or on load of the residual stream.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
 #include <vector>
 
 #include "conv_tc_mfma.h"
+#include "resblock_pair_kernel.h"
 
 namespace evmi {
 
@@ -93,6 +95,11 @@ struct evmi_generator {
   TcConv tc_pre;
   std::vector<TcConv> tc_ups;
   std::vector<std::vector<TcConv>> tc_rb;  // [resblock index][conv order: c1_0, c2_0, c1_1, ...]
+  // fused (c1, c2) pair launches where the working set fits LDS; nullptr -> two conv_tc launches
+  std::vector<std::vector<const PairLaunch*>> tc_pair;  // [resblock index][pair]
+  std::vector<std::vector<size_t>> tc_pair_w;           // element offsets of the pair's [KS][C][C] weights (w1 then w2)
+  int n_cu = 256;
+  bool use_pairs = true;
 
   DevBuf ws;
 
@@ -235,6 +242,8 @@ static int prepare_tc(evmi_generator* g) {
   }
   // residual blocks
   g->tc_rb.clear();
+  g->tc_pair.clear();
+  g->tc_pair_w.clear();
   for (int i = 0; i < c.num_upsamples; ++i) {
     const int cc = g->ch(i + 1);
     for (int j = 0; j < c.num_kernels; ++j) {
@@ -256,6 +265,30 @@ static int prepare_tc(evmi_generator* g) {
           convs.push_back(t);
         }
       }
+      // fused pairs need the plain [tap][C][C] layout: stored as extra copies in the arena
+      std::vector<const PairLaunch*> pairs;
+      std::vector<size_t> pair_w;
+      for (int m = 0; m < c.num_dilations[j]; ++m) {
+        const PairLaunch* pl = nullptr;
+        if (c.resblock_type == 1 && g->use_pairs) pl = find_resblock_pair(cc, k, c.resblock_dilations[j][m]);
+        pairs.push_back(pl);
+        size_t off = 0;
+        if (pl) {
+          off = warena.size();
+          warena.resize(warena.size() + 2 * (size_t)cc * cc * k);
+          for (int which = 1; which <= 2; ++which) {
+            const float* w = g->host_w[rb_name(c, n, which, m, "weight")].data();
+            uint16_t* dst = &warena[off + (size_t)(which - 1) * cc * cc * k];
+            for (int mo = 0; mo < cc; ++mo)
+              for (int ci = 0; ci < cc; ++ci)
+                for (int jt = 0; jt < k; ++jt)
+                  dst[((size_t)jt * cc + mo) * cc + ci] = f32_to_bf16_bits(w[((size_t)mo * cc + ci) * k + jt]);
+          }
+        }
+        pair_w.push_back(off);
+      }
+      g->tc_pair.push_back(pairs);
+      g->tc_pair_w.push_back(pair_w);
       g->tc_rb.push_back(convs);
     }
   }
@@ -410,7 +443,27 @@ static int forward_tc(evmi_generator* g, const float* mel, float* wav, int B, in
         const float scale = last ? 1.f / c.num_kernels : 1.f;
         const int accum = last && j > 0;
         const float post = (last && j == c.num_kernels - 1) ? (last_stage ? c.post_lrelu_slope : c.lrelu_slope) : 1.f;
-        if (c.resblock_type == 1) {
+        const PairLaunch* pl = g->tc_pair[i * c.num_kernels + j][m];
+        if (c.resblock_type == 1 && pl) {
+          PairArgs pa;
+          pa.x = cur;
+          pa.w1 = warena + g->tc_pair_w[i * c.num_kernels + j][m];
+          pa.w2 = pa.w1 + (size_t)cout * cout * convs[2 * m].ks;
+          pa.b1 = barena + convs[2 * m].bias_off;
+          pa.b2 = barena + convs[2 * m + 1].bias_off;
+          pa.out = nxt;
+          pa.T = len_out;
+          pa.dil1 = convs[2 * m].dil;
+          pa.slope = c.lrelu_slope;
+          pa.post_slope = post;
+          pa.out_scale = scale;
+          pa.accumulate = accum;
+          pa.timeline = nullptr;
+          EVMI_TRY(rec.begin());
+          EVMI_TRY(launch_resblock_pair(pl, pa, B, g->n_cu, s));
+          EVMI_TRY(rec.end(pl->name, convs[2 * m].layer + "+2", 4.0 * B * (double)len_out * cout * cout * convs[2 * m].ks,
+                           2.0 * B * (double)lim * (2 + accum) + 4.0 * cout * cout * convs[2 * m].ks));
+        } else if (c.resblock_type == 1) {
           EVMI_TRY(run(convs[2 * m], cur, len_out, len_out, T1, nullptr, cout, 0, lim, c.lrelu_slope,
                        c.lrelu_slope, 1.f, 0));
           EVMI_TRY(run(convs[2 * m + 1], T1, len_out, len_out, nxt, cur, cout, 0, lim, 1.f, post, scale, accum));
@@ -565,6 +618,13 @@ int evmi_generator_finalize(evmi_generator* g) {
   for (const WeightSpec& s : g->specs)
     EVMI_HIP_CHECK(hipMemcpy((float*)g->f32_arena.p + g->f32_off[s.name], g->host_w[s.name].data(),
                              (size_t)s.numel * 4, hipMemcpyHostToDevice));
+  {
+    hipDeviceProp_t prop;
+    EVMI_HIP_CHECK(hipGetDeviceProperties(&prop, g->device));
+    g->n_cu = prop.multiProcessorCount;
+    const char* e = getenv("EVMI_NO_FUSED_PAIRS");  // tuning switch: fall back to two launches per pair
+    g->use_pairs = !(e && e[0] == '1');
+  }
   EVMI_TRY(prepare_tc(g));
   g->finalized = true;
   return EVMI_OK;

@@ -1,0 +1,55 @@
+// Instantiations and launcher of the fused residual-pair kernel (resblock_pair_kernel.h).
+#include "resblock_pair_kernel.h"
+
+namespace evmi {
+
+//                  C  KS  BN  TAPS MAXDIL WAVES
+#define EVMI_PAIR_TABLE(X)      \
+  X(64, 3, 256, 2, 5, 8)        \
+  X(64, 7, 256, 2, 5, 8)        \
+  X(64, 11, 256, 2, 5, 8)       \
+  X(32, 3, 512, 3, 5, 8)        \
+  X(32, 7, 512, 4, 5, 8)        \
+  X(32, 11, 512, 4, 5, 8)
+
+static const PairLaunch* pair_table(int* n) {
+#define X(c, ks, bn, taps, md, waves) \
+  make_pair_launch<PairCfg<c, ks, bn, taps, md, waves>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
+  static const PairLaunch table[] = {EVMI_PAIR_TABLE(X)};
+#undef X
+  *n = (int)(sizeof(table) / sizeof(table[0]));
+  return table;
+}
+
+const PairLaunch* find_resblock_pair(int c, int ks, int dil) {
+  int n = 0;
+  const PairLaunch* t = pair_table(&n);
+  for (int i = 0; i < n; ++i)
+    if (t[i].c == c && t[i].ks == ks && dil <= t[i].max_dil) return &t[i];
+  return nullptr;
+}
+
+int launch_resblock_pair(const PairLaunch* L, PairArgs a, int B, int n_cu, hipStream_t stream) {
+  static thread_local const void* configured[32];
+  static thread_local int n_configured = 0;
+  bool seen = false;
+  for (int i = 0; i < n_configured; ++i) seen |= (configured[i] == (const void*)L->kernel);
+  if (!seen) {
+    EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)L->kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)L->lds_bytes));
+    if (n_configured < 32) configured[n_configured++] = (const void*)L->kernel;
+  }
+  a.tiles_per_item = (a.T + L->tt - 1) / L->tt;
+  a.n_tiles = a.tiles_per_item * B;
+  // persistent: one workgroup per CU (LDS-bound residency), a multiple of 8 so every XCD gets the
+  // same number of workgroups (the kernel's tile walk relies on it)
+  int grid = n_cu > 0 ? n_cu : 256;
+  grid = (grid + 7) / 8 * 8;
+  const int needed = (a.n_tiles + 7) / 8 * 8;
+  if (grid > needed) grid = needed;
+  hipLaunchKernelGGL(L->kernel, dim3(grid), dim3(L->threads), L->lds_bytes, stream, a);
+  EVMI_LAUNCH_CHECK(L->name);
+  return EVMI_OK;
+}
+
+}  // namespace evmi
