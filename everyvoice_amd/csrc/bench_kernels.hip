@@ -66,7 +66,14 @@ struct Variant {
   X("c32k3_bn1024_w16", 32, 32, 32, 1024, 1, 16, 3, 3, 5, 0)       \
   X("c256k11_bn256_bm256", 256, 64, 256, 256, 4, 4, 11, 1, 5, 0)   \
   X("c256k3_bn256", 256, 64, 128, 256, 2, 4, 3, 1, 5, 0)           \
-  X("c256k7_bn256", 256, 64, 128, 256, 2, 4, 7, 1, 5, 0)
+  X("c256k7_bn256", 256, 64, 128, 256, 2, 4, 7, 1, 5, 0)           \
+  X("c128k11_bn512_wm1", 128, 64, 128, 512, 1, 8, 11, 1, 5, 0)     \
+  X("c128k7_bn512_wm1", 128, 64, 128, 512, 1, 8, 7, 1, 5, 0)       \
+  X("c128k3_bn512_wm1", 128, 64, 128, 512, 1, 8, 3, 1, 5, 0)       \
+  X("c256k11_bn512_wm1", 256, 64, 128, 512, 1, 8, 11, 1, 5, 0)     \
+  X("c256k11_bm256_mt4", 256, 64, 256, 256, 2, 4, 11, 1, 5, 0)     \
+  X("c256k3_bn512_wm1", 256, 64, 128, 512, 1, 8, 3, 1, 5, 0)       \
+  X("c128k11_bn256_wm1_w4", 128, 64, 128, 256, 1, 4, 11, 1, 5, 0)
 
 #define EVMI_VARIANTS_OCC(X)                                              \
   X("c128k11_bn256_occ4", 128, 64, 128, 256, 2, 4, 11, 1, 5, 0, 4)      \

@@ -40,6 +40,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope release fence,
+// which on gfx950 waits vmcnt(0): in a persistent kernel it would drain every global load that is
+// deliberately kept in flight across the barrier (next tile's activation rows, next tap group's
+// weights) and every epilogue store.  Here only this wave's LDS operations are completed before the
+// barrier; global loads are waited for by the compiler exactly where their registers are consumed.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // One tap group of the implicit GEMM for one wave: NTAPS taps x KSTEPS 16-deep k-steps, fragments
 // read from LDS one k-step ahead of the MFMAs that consume them (explicit software pipelining: the
 // compiler otherwise issues the ds_reads of step k+1 only after the last MFMA of step k).

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
       for (int grp = 0; grp < P::NG; ++grp) {
         const int s = conv * P::NG + grp;
         w_commit(s);
-        __syncthreads();
+        lds_barrier();
         w_prefetch(s + 1 == P::NSTEP ? 0 : s + 1);  // wraps to the next tile's first group
         if (s == 0 && next < tile_hi) x_issue(next);  // after the weight loads: they stay in flight
         const bf16_t* Arow = WS + (s & 1) * P::W_TILE + (lane & 31) * S + (lane >> 5) * 8;
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
 
     stamp();  // conv loops done (includes the T1 epilogue of conv1)
     // ---- epilogue: conv2 + b2 -> LDS staging -> + residual (LDS) -> fused coalesced store --------
-    __syncthreads();  // all waves done with XA (conv1) and T1/WS reads of the last step
+    lds_barrier();  // all waves done with XA (conv1) and T1/WS reads of the last step
 #pragma unroll
     for (int mt = 0; mt < P::MT; ++mt) {
 #pragma unroll
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     {
       bf16_t* ob = a.out + (long long)item * a.T * C;
       const float scale = a.out_scale, post = a.post_slope;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
       }
     }
     stamp();  // stores issued
-    __syncthreads();  // staging / residual tiles are free again for the next tile's commit
+    lds_barrier();  // staging / residual tiles are free again for the next tile's commit
   }
 }
 
