@@ -133,6 +133,22 @@ def roofline_from_records(passes: list[list[dict]]) -> dict:
     }
 
 
+def recorded_pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_summary.json,
+    produced by tools/gpu_profile.sh + tools/pmc_summarize.py from separate rocprofv3 --pmc passes of this
+    same bench command; FETCH_SIZE doubled per the gfx950 correction).  PMC counters cannot be read from
+    inside the process, so this is the recorded measurement, or None when the kernel has none."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*_pmc_summary.json")):
+        try:
+            e = json.loads(f.read_text()).get(kernel)
+        except (OSError, ValueError):
+            continue
+        if e and "hbm_bytes_per_launch" in e:
+            best = (e["hbm_bytes_per_launch"], f.name)
+    return best
+
+
 def cpu_baseline(frames: int, batch: int) -> dict:
     """The CPU oracle on this box's host cores, on a bounded slice of the same workload."""
     import torch
@@ -223,6 +239,11 @@ def main(argv=None) -> int:
             _, recs = gen.forward_profiled(mel)
             passes.append(recs)
         roof = roofline_from_records(passes)
+        pmc = recorded_pmc_traffic(roof["kernel"])
+        if pmc:
+            roof["traffic"] = pmc[0]
+            roof["traffic_source"] = f"profiles/{pmc[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
+            roof["algorithmic_bytes_per_launch"] = round(roof["algorithmic_hbm_gbs"] * 1e9 * roof["avg_launch_ms"] * 1e-3)
         flops_per_sample = 2.0 * gen.macs_per_sample()
         result = {
             "metric": METRIC,

@@ -1,0 +1,74 @@
+"""The N > 1 path of bench.py on CPU: two ranks over gloo run the same barrier / max-over-ranks
+timing and whole-job aggregation that the GPU replicas use (inference shards nothing between
+ranks: "replicas only")."""
+
+import json
+import os
+import socket
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import bench  # noqa: E402
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"n": 0}
+
+    def step():
+        calls["n"] += 1
+        time.sleep(0.01 * (rank + 1))  # rank 1 is the slow one: the max over ranks must win
+
+    def max_reduce(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = bench.timed_region(step, steps=5, warmup=2, sync_fn=lambda: None, barrier_fn=dist.barrier, max_reduce_fn=max_reduce)
+    samples = 1000
+    value = world * samples * 5 / elapsed
+    Path(out_dir, f"rank{rank}.json").write_text(json.dumps({"elapsed": elapsed, "calls": calls["n"], "value": value}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_timing_and_aggregation(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [json.loads(Path(tmp_path, f"rank{i}.json").read_text()) for i in range(world)]
+    assert r[0]["calls"] == r[1]["calls"] == 7  # W warm-up + exactly K timed steps
+    assert r[0]["elapsed"] == r[1]["elapsed"]  # every rank reports the max over ranks
+    assert r[0]["elapsed"] >= 5 * 0.02 * 0.9  # the slow rank (20 ms / step) sets the time
+    assert abs(r[0]["value"] - 2 * 1000 * 5 / r[0]["elapsed"]) < 1e-6  # whole-job aggregate, not per-GPU
+
+
+def test_dist_env_and_roofline_aggregation(monkeypatch):
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    assert bench.dist_env() == (3, 1, 4)
+    recs = [
+        dict(kernel="a", layer="l0", ms=1.0, flops=2e9, bytes=1e6),
+        dict(kernel="a", layer="l1", ms=3.0, flops=2e9, bytes=1e6),
+        dict(kernel="b", layer="l2", ms=1.0, flops=1e9, bytes=4e6),
+    ]
+    roof = bench.roofline_from_records([recs, recs])
+    assert roof["kernel"] == "a" and roof["launches_per_forward"] == 2
+    assert abs(roof["avg_launch_ms"] - 2.0) < 1e-9
+    assert abs(roof["achieved"] - 2e9 / 2e-3 / 1e12) < 1e-2  # algorithmic FLOP per launch / mean duration
+    assert roof["peak"] == 2500.0 and roof["bound"] == "mfma"
+    assert abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-3
