@@ -76,6 +76,10 @@ SYMBOLS = {
         C.c_int,
         [C.c_void_p] * 4 + [C.c_int] * 7 + [C.c_float, C.c_void_p],
     ),
+    "evmi_mel_spectrogram_f32": (
+        C.c_int,
+        [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p],
+    ),
     "evmi_generator_create": (C.c_int, [C.POINTER(GeneratorConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "evmi_generator_destroy": (None, [C.c_void_p]),
     "evmi_generator_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),

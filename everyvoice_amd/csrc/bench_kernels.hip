@@ -73,7 +73,12 @@ struct Variant {
   X("c256k11_bn512_wm1", 256, 64, 128, 512, 1, 8, 11, 1, 5, 0)     \
   X("c256k11_bm256_mt4", 256, 64, 256, 256, 2, 4, 11, 1, 5, 0)     \
   X("c256k3_bn512_wm1", 256, 64, 128, 512, 1, 8, 3, 1, 5, 0)       \
-  X("c128k11_bn256_wm1_w4", 128, 64, 128, 256, 1, 4, 11, 1, 5, 0)
+  X("c128k11_bn256_wm1_w4", 128, 64, 128, 256, 1, 4, 11, 1, 5, 0)  \
+  X("c128k11_bn512_nt4", 128, 64, 128, 512, 2, 4, 11, 1, 5, 0)     \
+  X("c128k7_bn512_nt4", 128, 64, 128, 512, 2, 4, 7, 1, 5, 0)       \
+  X("c128k3_bn512_nt4", 128, 64, 128, 512, 2, 4, 3, 1, 5, 0)       \
+  X("c256k11_bn512_nt4", 256, 64, 128, 512, 2, 4, 11, 1, 5, 0)     \
+  X("c256k3_bn512_nt4", 256, 64, 128, 512, 2, 4, 3, 1, 5, 0)
 
 #define EVMI_VARIANTS_OCC(X)                                              \
   X("c128k11_bn256_occ4", 128, 64, 128, 256, 2, 4, 11, 1, 5, 0, 4)      \
@@ -175,7 +180,8 @@ extern "C" int evmi_debug_pair_timeline(int c, int ks, int dil, int B, int T, lo
   PairLaunch L;
   if (c == 64 && ks == 11) L = make_pair_launch<PairCfg<64, 11, 256, 2, 5, 8, 1>>("dbg_pair_c64k11");
   else if (c == 64 && ks == 3) L = make_pair_launch<PairCfg<64, 3, 256, 2, 5, 8, 1>>("dbg_pair_c64k3");
-  else if (c == 32 && ks == 11) L = make_pair_launch<PairCfg<32, 11, 512, 4, 5, 8, 1>>("dbg_pair_c32k11");
+  else if (c == 32 && ks == 11) L = make_pair_launch<PairCfg<32, 11, 512, 11, 5, 8, 1, 1>>("dbg_pair_c32k11");
+  else if (c == 32 && ks == 3) L = make_pair_launch<PairCfg<32, 3, 512, 3, 5, 8, 1, 2>>("dbg_pair_c32k3");
   else return fail(EVMI_ERR_INVALID_ARG, "debug timeline: unsupported (c, ks)");
   const size_t xe = (size_t)B * T * c, we = (size_t)2 * c * c * ks;
   bf16_t *x = nullptr, *w = nullptr, *out = nullptr;

@@ -1,0 +1,140 @@
+// STFT -> magnitude -> mel -> log front-end of the reference's default "mel-librosa" spectrogram
+// (everyvoice/utils/heavy.py:69-100 and :39-40), one kernel, fp32 throughout.
+//
+//   frames[f][k] = audio_reflect_padded[f*hop + k] * hann[k]          (center=True, pad_mode="reflect")
+//   re/im[f][b]  = sum_k frames[f][k] * cos/sin(2*pi*b*k/n_fft)        b in [0, n_fft/2]
+//   mag          = sqrt(re^2 + im^2 + 1e-9)
+//   mel[m][f]    = sum_b basis[m][b] * mag[f][b]                        (librosa Slaney basis, given by the host)
+//   out          = log(max(mel, 1e-5))                                 (optional)
+//
+// The DFT is a GEMM [32 frames x n_fft] x [n_fft x 2*(n_fft/2+1)] on the fp32-input matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chains, 157 TFLOP/s class) against a window-folded basis
+// held in HBM/L2 (n_fft=1024: 4.2 MB).  The frame matrix is never materialised: the padded audio
+// segment of a 32-frame block sits once in LDS with a skew of one word per hop (index s + s/hop),
+// which makes the 32 lanes of an A-fragment read (stride hop) hit 32 distinct banks.
+#include "common.h"
+
+namespace evmi {
+
+constexpr int MEL_FRAMES = 32;   // frames per workgroup (one MFMA M tile)
+constexpr int MEL_THREADS = 512;
+
+__device__ __forceinline__ int reflect_index(int i, int n) {
+  // torch "reflect" padding (no edge repeat); valid for |overshoot| < n
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// basis_ri: [n_fft][2*NB] fp32, column 2b = hann[k]*cos(2 pi b k / n_fft), column 2b+1 = -hann[k]*sin(...)
+//           (NB = n_fft/2 + 1 padded up to a multiple of 16 -> 2*NB multiple of 32, extra columns zero)
+// melb:     [n_mels][n_bins] fp32
+// out:      [B][n_mels][n_frames] fp32 (torch layout)      energy: [B][n_frames] or nullptr
+__global__ __launch_bounds__(MEL_THREADS) void mel_frontend_kernel(
+    const float* __restrict__ audio, const float* __restrict__ basis_ri, const float* __restrict__ melb,
+    float* __restrict__ out, float* __restrict__ energy, float* __restrict__ mag_out, int n_samples, int n_frames,
+    int n_fft, int hop, int nb_pad, int n_bins, int n_mels, int apply_log) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int seg = (MEL_FRAMES - 1) * hop + n_fft;           // audio samples a block needs
+  float* As = reinterpret_cast<float*>(smem);                // skewed: index s + s / hop
+  const int as_words = seg + seg / hop + 1;
+  float* Ms = As + ((as_words + 3) & ~3);                    // magnitudes [MEL_FRAMES][n_bins + 1]
+  const int ms_stride = n_bins + 1;
+
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * MEL_FRAMES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* ab = audio + (long long)b * n_samples;
+  const int pad = n_fft / 2;
+
+  for (int s = tid; s < seg; s += MEL_THREADS) {
+    const int g = f0 * hop + s - pad;  // position in the un-padded signal
+    // positions beyond the reflect-padded signal only feed frames >= n_frames (never stored)
+    const float v = (g >= -pad && g <= n_samples - 1 + pad) ? ab[reflect_index(g, n_samples)] : 0.f;
+    As[s + s / hop] = v;
+  }
+  __syncthreads();
+
+  // ---- DFT on the fp32 matrix cores: wave w takes column tiles w, w+8, ... of the (re, im) basis ------
+  const int n_col_tiles = (2 * nb_pad) / 32;
+  const int i = lane & 31, kh = lane >> 5;
+  const int a_base = i * hop + i;  // skewed start of frame i: (i*hop) + (i*hop)/hop
+  for (int ct = wave; ct < n_col_tiles; ct += MEL_THREADS / 64) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* bcol = basis_ri + ct * 32 + i;  // column of this lane
+    const int ld = 2 * nb_pad;
+#pragma unroll 8
+    for (int k = 0; k < n_fft; k += 2) {
+      const int kk = k + kh;
+      // frame i, sample kk: skewed index a_base + kk + kk / hop  (the window is folded into the basis)
+      const float av = As[a_base + kk + kk / hop];
+      const float bv = bcol[(long long)kk * ld];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    // D layout: lane holds column j = lane&31 (even = re, odd = im of bin ct*16 + j/2) for frames
+    // (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float sq = acc[r] * acc[r];
+      const float other = __shfl_xor(sq, 1, 64);
+      const int frame = (r & 3) + 8 * (r >> 2) + 4 * kh;
+      const int bin = ct * 16 + (i >> 1);
+      if (!(i & 1) && bin < n_bins) Ms[frame * ms_stride + bin] = sqrtf(sq + other + 1e-9f);
+    }
+  }
+  __syncthreads();
+
+  if (mag_out) {  // optional linear-magnitude output [B][n_bins][n_frames]
+    for (int v = tid; v < MEL_FRAMES * n_bins; v += MEL_THREADS) {
+      const int bin = v / MEL_FRAMES, fr = v % MEL_FRAMES;
+      if (f0 + fr < n_frames) mag_out[((long long)b * n_bins + bin) * n_frames + f0 + fr] = Ms[fr * ms_stride + bin];
+    }
+  }
+  // ---- mel projection + log: thread -> (frame = tid % 32, mel rows tid/32, tid/32 + 16, ...) ----------
+  float* Ls = As;  // the audio tile is dead: log-mel rows [MEL_FRAMES][n_mels + 1] for the energy reduction
+  {
+    const int fr = tid & 31;
+    const float* mrow = Ms + fr * ms_stride;
+    for (int m = tid >> 5; m < n_mels; m += MEL_THREADS / 32) {
+      const float* wrow = melb + (long long)m * n_bins;
+      float acc = 0.f;
+      for (int bin = 0; bin < n_bins; ++bin) acc = fmaf(wrow[bin], mrow[bin], acc);  // ascending-bin fmaf chain
+      if (apply_log) acc = logf(fmaxf(acc, 1e-5f));
+      if (f0 + fr < n_frames) out[((long long)b * n_mels + m) * n_frames + f0 + fr] = acc;
+      Ls[fr * (n_mels + 1) + m] = acc;
+    }
+  }
+  if (energy) {  // energy[f] = || mel[:, f] ||_2 over the (log-)mel bins (everyvoice/preprocessor/preprocessor.py:302-309)
+    __syncthreads();
+    if (tid < MEL_FRAMES && f0 + tid < n_frames) {
+      float e = 0.f;
+      for (int m = 0; m < n_mels; ++m) e = fmaf(Ls[tid * (n_mels + 1) + m], Ls[tid * (n_mels + 1) + m], e);
+      energy[(long long)b * n_frames + f0 + tid] = sqrtf(e);
+    }
+  }
+}
+
+int launch_mel_frontend(const float* audio, const float* basis_ri, const float* melb, float* out, float* energy,
+                        float* mag_out, int B, int n_samples, int n_frames, int n_fft, int hop, int nb_pad,
+                        int n_bins, int n_mels, int apply_log, hipStream_t s) {
+  if (n_fft % hop || n_fft % 2 || hop <= 0) return fail(EVMI_ERR_UNSUPPORTED, "mel: n_fft must be a multiple of hop");
+  if (n_samples <= n_fft / 2) return fail(EVMI_ERR_INVALID_ARG, "mel: reflect padding needs n_samples > n_fft/2");
+  const int seg = (MEL_FRAMES - 1) * hop + n_fft;
+  const int as_words = (seg + seg / hop + 1 + 3) & ~3;
+  const size_t lds = ((size_t)as_words + (size_t)MEL_FRAMES * (n_bins + 1)) * sizeof(float);
+  if (lds > 160 * 1024) return fail(EVMI_ERR_UNSUPPORTED, "mel: n_fft / hop too large for the LDS tile");
+  static thread_local size_t configured = 0;
+  if (lds > configured) {
+    EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)mel_frontend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  dim3 grid((n_frames + MEL_FRAMES - 1) / MEL_FRAMES, B);
+  hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(MEL_THREADS), lds, s, audio, basis_ri, melb, out, energy, mag_out,
+                     n_samples, n_frames, n_fft, hop, nb_pad, n_bins, n_mels, apply_log);
+  EVMI_LAUNCH_CHECK("mel_frontend");
+  return EVMI_OK;
+}
+
+}  // namespace evmi

@@ -3,18 +3,19 @@
 
 namespace evmi {
 
-//                  C  KS  BN  TAPS MAXDIL WAVES
+//                  C  KS  BN  TAPS MAXDIL WAVES NWBUF
+// C = 32: all taps of one convolution fit LDS at once (single buffer): 2 weight steps per tile
 #define EVMI_PAIR_TABLE(X)      \
-  X(64, 3, 256, 2, 5, 8)        \
-  X(64, 7, 256, 2, 5, 8)        \
-  X(64, 11, 256, 2, 5, 8)       \
-  X(32, 3, 512, 3, 5, 8)        \
-  X(32, 7, 512, 4, 5, 8)        \
-  X(32, 11, 512, 4, 5, 8)
+  X(64, 3, 256, 2, 5, 8, 2)     \
+  X(64, 7, 256, 2, 5, 8, 2)     \
+  X(64, 11, 256, 2, 5, 8, 2)    \
+  X(32, 3, 512, 3, 5, 8, 2)     \
+  X(32, 7, 512, 7, 5, 8, 1)     \
+  X(32, 11, 512, 11, 5, 8, 1)
 
 static const PairLaunch* pair_table(int* n) {
-#define X(c, ks, bn, taps, md, waves) \
-  make_pair_launch<PairCfg<c, ks, bn, taps, md, waves>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
+#define X(c, ks, bn, taps, md, waves, nwbuf) \
+  make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
   static const PairLaunch table[] = {EVMI_PAIR_TABLE(X)};
 #undef X
   *n = (int)(sizeof(table) / sizeof(table[0]));

@@ -46,9 +46,12 @@ struct PairLaunch {
   const char* name;
 };
 
-template <int C_, int KS_, int BN_, int TAPS_, int MAXDIL_, int WAVES_, int DBG_ = 0>
+template <int C_, int KS_, int BN_, int TAPS_, int MAXDIL_, int WAVES_, int DBG_ = 0, int NWBUF_ = 2>
 struct PairCfg {
   static constexpr int C = C_, KS = KS_, BN = BN_, TAPS = TAPS_, MAXDIL = MAXDIL_, WAVES = WAVES_, DBG = DBG_;
+  // weight tap-group buffers in LDS: 2 = commit the next group while the current one is read; 1 = one
+  // buffer (lets a whole convolution's taps sit in LDS at once) at the price of a barrier before each commit
+  static constexpr int NWBUF = NWBUF_;
   static constexpr int NTHREADS = WAVES * 64;
   static constexpr int MT = C / 32, NT = BN / (WAVES * 32);
   static constexpr int S = C + 8;  // LDS row stride (elements): odd multiple of 16 B -> conflict-free b128 reads
@@ -68,7 +71,7 @@ struct PairCfg {
   static constexpr size_t OFF_RS = OFF_XA + size_t(RA_MAX) * S;
   static constexpr size_t OFF_T1 = OFF_RS + size_t(BN) * S;
   static constexpr size_t OFF_WS = OFF_T1 + size_t(T1_ROWS) * S;
-  static constexpr size_t LDS = (OFF_WS + 2 * size_t(W_TILE)) * 2;
+  static constexpr size_t LDS = (OFF_WS + NWBUF * size_t(W_TILE)) * 2;
   static_assert(BN % (WAVES * 32) == 0 && C % 32 == 0, "tiling");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
     }
   };
   auto w_commit = [&](int s) {
-    bf16_t* dst = WS + (s & 1) * P::W_TILE;
+    bf16_t* dst = WS + (s & (P::NWBUF - 1)) * P::W_TILE;
     const int grp = s % P::NG;
     const int ntaps = (KS - grp * P::TAPS) < P::TAPS ? (KS - grp * P::TAPS) : P::TAPS;
     const int nvec = ntaps * C * (C / 8);
@@ -195,11 +198,12 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
 #pragma unroll
       for (int grp = 0; grp < P::NG; ++grp) {
         const int s = conv * P::NG + grp;
+        if (P::NWBUF == 1 && s > 0) lds_barrier();  // everyone is done reading the single weight buffer
         w_commit(s);
         lds_barrier();
         w_prefetch(s + 1 == P::NSTEP ? 0 : s + 1);  // wraps to the next tile's first group
         if (s == 0 && next < tile_hi) x_issue(next);  // after the weight loads: they stay in flight
-        const bf16_t* Arow = WS + (s & 1) * P::W_TILE + (lane & 31) * S + (lane >> 5) * 8;
+        const bf16_t* Arow = WS + (s & (P::NWBUF - 1)) * P::W_TILE + (lane & 31) * S + (lane >> 5) * 8;
         const bf16_t* Brow = Bsrc + (wn * P::NT * 32 + (lane & 31)) * S + grp * P::TAPS * b_tap_stride + (lane >> 5) * 8;
         if (grp + 1 < P::NG || P::LAST_TAPS == P::TAPS)
           mma_tap_group<P::MT, P::NT, C / 16, P::TAPS, C * S, 32 * S, 32 * S>(Arow, Brow, b_tap_stride, acc);

@@ -92,6 +92,28 @@ int evmi_conv_transpose1d_f32(const float* x_dev, const float* w_dev, const floa
                               int pad, float pre_slope, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * STFT / mel front-end — replaces the transform returned by everyvoice/utils/heavy.py:69-100
+ * get_spectral_transform("mel-librosa", ...) followed by dynamic_range_compression_torch
+ * (everyvoice/utils/heavy.py:39-40), i.e. Preprocessor.extract_spectral_features
+ * (everyvoice/preprocessor/preprocessor.py:220-233), and extract_energy (:302-309).
+ *
+ *   audio_dev      [B, n_samples] fp32
+ *   dft_basis_dev  [n_fft, 2*n_bins_padded] fp32: column 2b = window[k]*cos(2 pi b k / n_fft),
+ *                  column 2b+1 = -window[k]*sin(...), zero beyond bin n_fft/2 (host-built constant;
+ *                  n_bins_padded = n_fft/2+1 rounded up to a multiple of 16)
+ *   mel_basis_dev  [n_mels, n_fft/2+1] fp32 (librosa Slaney filterbank)
+ *   mel_dev        [B, n_mels, 1 + n_samples/hop] fp32 = log(max(basis @ sqrt(|STFT|^2 + 1e-9), 1e-5))
+ *                  (apply_log = 0: the linear mel)
+ *   energy_dev     [B, frames] L2 norm over the mel bins of mel_dev (NULL to skip)
+ *   mag_dev        [B, n_fft/2+1, frames] sqrt(|STFT|^2 + 1e-9) (NULL to skip)
+ * center=True, reflect padding, one-sided, win_length == n_fft, n_fft a multiple of hop.
+ * ------------------------------------------------------------------------------------------ */
+int evmi_mel_spectrogram_f32(const float* audio_dev, const float* dft_basis_dev,
+                             const float* mel_basis_dev, float* mel_dev, float* energy_dev,
+                             float* mag_dev, int B, int n_samples, int n_fft, int hop,
+                             int n_bins_padded, int n_mels, int apply_log, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * HiFiGAN / iSTFTNet generator — replaces the forward of `hfgl.utils.HiFiGANGenerator` /
  * the generator inside `hfgl.model.HiFiGAN` (absent submodule; call sites
  * everyvoice/demo/app.py:28-33,457-459, everyvoice/base_cli/checkpoint.py:92-103;

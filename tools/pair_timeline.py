@@ -11,7 +11,7 @@ from everyvoice_amd import _lib  # noqa: E402
 
 lib = _lib.load()
 torch.zeros(1, device="cuda")
-for c, ks, T in ((64, 11, 98304), (64, 3, 98304), (32, 11, 196608)):
+for c, ks, T in ((64, 11, 98304), (32, 11, 196608), (32, 3, 196608)):
     buf = (C.c_longlong * 256)()
     rc = lib.evmi_debug_pair_timeline(c, ks, 5, 32, T, buf, 256)
     if rc:
