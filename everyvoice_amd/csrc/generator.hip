@@ -39,6 +39,9 @@ int launch_conv_transpose1d_f32(const float*, const float*, const float*, float*
 int launch_tanh_f32(float*, long long, hipStream_t);
 int launch_nct_f32_to_tc_bf16(const float*, bf16_t*, int, int, int, hipStream_t);
 int launch_conv_post_tanh(const bf16_t*, const float*, float, float*, int, int, int, int, float, hipStream_t);
+int launch_istft_head(const bf16_t*, const bf16_t*, const float*, float*, int, int, int, hipStream_t);
+int launch_reflect_pad_left1_f32(const float*, float*, long long, int, float, hipStream_t);
+int launch_istft_f32(const float*, float*, int, int, hipStream_t);
 
 struct WeightSpec {
   std::string name;
@@ -99,6 +102,7 @@ struct evmi_generator {
   std::vector<std::vector<const PairLaunch*>> tc_pair;  // [resblock index][pair]
   std::vector<std::vector<size_t>> tc_pair_w;           // element offsets of the pair's [KS][C][C] weights (w1 then w2)
   int n_cu = 256;
+  size_t istft_w_off = 0, istft_b_off = 0;
   bool use_pairs = true;
 
   DevBuf ws;
@@ -186,8 +190,8 @@ static void relayout_conv(const float* w, int c_out, int c_in, int ks, const Con
 static int prepare_tc(evmi_generator* g) {
   const auto& c = g->cfg;
   g->tc_ok = false;
-  if (c.istft_layer) {
-    g->tc_why = "iSTFT head not yet on the MFMA path";
+  if (c.istft_layer && (c.istft_n_fft != 16 || c.istft_hop != 4)) {
+    g->tc_why = "iSTFT head: only n_fft 16 / hop 4 (the reference's gen_istft_* values)";
     return EVMI_OK;
   }
   std::vector<uint16_t> warena;
@@ -292,6 +296,23 @@ static int prepare_tc(evmi_generator* g) {
       g->tc_rb.push_back(convs);
     }
   }
+  if (c.istft_layer) {
+    // conv_post of the iSTFT head: w[18][c][7] -> bf16 [7][32][c] (rows >= 18 zero), bias [32]
+    const int cl = g->ch(c.num_upsamples);
+    if (!(cl == 32 || cl == 64 || cl == 128)) return missing("istft head c_in=" + std::to_string(cl));
+    const int co = c.istft_n_fft + 2;
+    const std::vector<float>& w = g->host_w["conv_post.weight"];
+    const std::vector<float>& bs = g->host_w["conv_post.bias"];
+    g->istft_w_off = warena.size();
+    warena.resize(warena.size() + (size_t)7 * 32 * cl, 0);
+    for (int m = 0; m < co; ++m)
+      for (int ci = 0; ci < cl; ++ci)
+        for (int j = 0; j < 7; ++j)
+          warena[g->istft_w_off + ((size_t)j * 32 + m) * cl + ci] = f32_to_bf16_bits(w[((size_t)m * cl + ci) * 7 + j]);
+    g->istft_b_off = barena.size();
+    barena.resize(barena.size() + 32, 0.f);
+    for (int m = 0; m < co; ++m) barena[g->istft_b_off + m] = bs[m];
+  } else
   // conv_post: w[1][c][7] -> [7][c] fp32
   {
     const int cl = g->ch(c.num_upsamples);
@@ -372,7 +393,7 @@ static size_t stage_elems_max(const evmi_generator* g, int B, int T) {
   size_t len = T;
   for (int i = 0; i < g->cfg.num_upsamples; ++i) {
     len *= g->cfg.upsample_rates[i];
-    const size_t e = (size_t)B * len * g->ch(i + 1);
+    const size_t e = (size_t)B * (len + 1) * g->ch(i + 1);  // + 1 row: the iSTFT head's reflection pad
     if (e > mx) mx = e;
   }
   return mx;
@@ -478,14 +499,21 @@ static int forward_tc(evmi_generator* g, const float* mel, float* wav, int B, in
   }
   const int cl = g->ch(c.num_upsamples);
   EVMI_TRY(rec.begin());
-  EVMI_TRY(launch_conv_post_tanh(A, (const float*)g->post_w.p, g->post_bias, wav, B, len, cl, 7, 1.f, s));
-  EVMI_TRY(rec.end("conv_post_tanh", "conv_post", 2.0 * B * (double)len * cl * 7, (double)B * len * (2.0 * cl + 4)));
+  if (c.istft_layer) {
+    EVMI_TRY(launch_istft_head(A, warena + g->istft_w_off, barena + g->istft_b_off, wav, B, len, cl, s));
+    EVMI_TRY(rec.end("istft_head", "conv_post+istft", 2.0 * B * (double)(len + 1) * cl * 7 * (c.istft_n_fft + 2),
+                     (double)B * len * (2.0 * cl + 4.0 * c.istft_hop)));
+  } else {
+    EVMI_TRY(launch_conv_post_tanh(A, (const float*)g->post_w.p, g->post_bias, wav, B, len, cl, 7, 1.f, s));
+    EVMI_TRY(rec.end("conv_post_tanh", "conv_post", 2.0 * B * (double)len * cl * 7, (double)B * len * (2.0 * cl + 4)));
+  }
   return EVMI_OK;
 }
 
 static int forward_f32(evmi_generator* g, const float* mel, float* wav, int B, int T, hipStream_t s, Recorder& rec) {
   const auto& c = g->cfg;
-  if (c.istft_layer) return fail(EVMI_ERR_UNSUPPORTED, "iSTFT head: not implemented in libevmi_hip yet");
+  if (c.istft_layer && (c.istft_n_fft != 16 || c.istft_hop != 4))
+    return fail(EVMI_ERR_UNSUPPORTED, "iSTFT head: only n_fft 16 / hop 4 (the reference's gen_istft_* values)");
   const size_t se = align_up(stage_elems_max(g, B, T), 64);
   EVMI_TRY(g->ws.ensure(5 * se * 4));
   float* buf[5];
@@ -544,6 +572,17 @@ static int forward_f32(evmi_generator* g, const float* mel, float* wav, int B, i
     len = len_out;
   }
   const int cl = g->ch(c.num_upsamples);
+  if (c.istft_layer) {
+    float* XP = buf[0];  // [B][cl][len + 1]: leaky-relu then reflection pad (1, 0)
+    float* Z = buf[1];   // [B][n_fft + 2][len + 1]
+    EVMI_TRY(rec.begin());
+    EVMI_TRY(launch_reflect_pad_left1_f32(A, XP, (long long)B * cl, len, c.post_lrelu_slope, s));
+    EVMI_TRY(rec.end("reflect_pad_left1_f32", "reflection_pad", 0.0, 8.0 * B * cl * len));
+    EVMI_TRY(conv("conv_post", XP, "conv_post", nullptr, Z, cl, len + 1, c.istft_n_fft + 2, 7, 3, 1, 1.f, 1.f, 0));
+    EVMI_TRY(rec.begin());
+    EVMI_TRY(launch_istft_f32(Z, wav, B, len + 1, s));
+    return rec.end("istft_f32", "istft", 0.0, 4.0 * B * len * (c.istft_n_fft + 2 + c.istft_hop));
+  }
   EVMI_TRY(conv("conv_post", A, "conv_post", nullptr, wav, cl, len, 1, 7, 3, 1, c.post_lrelu_slope, 1.f, 0));
   EVMI_TRY(rec.begin());
   EVMI_TRY(launch_tanh_f32(wav, (long long)B * len, s));

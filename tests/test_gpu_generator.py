@@ -171,3 +171,32 @@ def test_no_cpu_fallback():
 
     with pytest.raises(RuntimeError, match="GPU only"):
         HiFiGANGenerator(HiFiGANConfig())(torch.zeros(1, 80, 4))
+
+
+ISTFT_CONFIGS = {
+    # the reference's own test config (everyvoice/tests/data/relative/config/everyvoice-spec-to-wav.yaml): C8C8I
+    "test_config_c8c8i": dict(istft_layer=True, upsample_rates=[8, 8], upsample_kernel_sizes=[16, 16]),
+    # BASELINE config 5 style: hop 512 = 8*8*2 * istft hop 4
+    "hop512_c8c8c2i": dict(istft_layer=True, upsample_rates=[8, 8, 2], upsample_kernel_sizes=[16, 16, 4]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ISTFT_CONFIGS))
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 9), (1, 70)])
+def test_istft_generator_vs_oracle(cuda_device, name, B, T):
+    from oracle.hifigan_ref import HiFiGANModelConfigRef
+
+    cfg = HiFiGANModelConfigRef(**ISTFT_CONFIGS[name])
+    ref = make_ref_generator(cfg, seed=4321)
+    mel = synthetic_mel(B, T, seed=7 + T)
+    with torch.no_grad():
+        want = ref(mel)
+    assert want.shape == (B, 1, T * ref.hop)
+    got32 = _product_from_ref(ref, cuda_device, "f32")(mel.to(cuda_device)).cpu()
+    assert got32.shape == want.shape
+    scale = float(want.abs().max())
+    assert float((got32 - want).abs().max()) <= 2e-4 * max(1.0, scale)
+    got16 = _product_from_ref(ref, cuda_device, "bf16")(mel.to(cuda_device)).cpu()
+    err = rel_l2(got16, want)
+    print(f"istft {name} B={B} T={T}: bf16 rel_l2={err:.3e} (|wav| max {scale:.2f})")
+    assert torch.isfinite(got16).all() and err <= BF16_REL_L2
