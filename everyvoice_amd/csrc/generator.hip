@@ -286,7 +286,8 @@ static int prepare_tc(evmi_generator* g) {
             for (int mo = 0; mo < cc; ++mo)
               for (int ci = 0; ci < cc; ++ci)
                 for (int jt = 0; jt < k; ++jt)
-                  dst[((size_t)jt * cc + mo) * cc + ci] = f32_to_bf16_bits(w[((size_t)mo * cc + ci) * k + jt]);
+                  dst[((((size_t)(ci / pl->kc)) * k + jt) * cc + mo) * pl->kc + ci % pl->kc] =
+                      f32_to_bf16_bits(w[((size_t)mo * cc + ci) * k + jt]);  // [chunk][tap][C][kc]
           }
         }
         pair_w.push_back(off);

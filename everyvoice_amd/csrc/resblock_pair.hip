@@ -1,5 +1,5 @@
 // Instantiations and launcher of the fused residual-pair kernel (resblock_pair_kernel.h).
-#include "resblock_pair_kernel.h"
+#include "resblock_pair_chunked_kernel.h"
 
 namespace evmi {
 
@@ -16,7 +16,13 @@ namespace evmi {
 static const PairLaunch* pair_table(int* n) {
 #define X(c, ks, bn, taps, md, waves, nwbuf) \
   make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
-  static const PairLaunch table[] = {EVMI_PAIR_TABLE(X)};
+  static const PairLaunch table[] = {
+      EVMI_PAIR_TABLE(X)
+      // C = 128: chunked variant (64-channel operand chunks, 2 x 4 waves of 64 x 64).  Measured on MI355X
+      // (B=32, T=49152): k3 0.49 ms fused vs 0.56 ms as two conv_tc launches; k7 / k11 are MFMA/LDS-bound
+      // either way and 3-4 % slower fused (0.86 vs 0.83, 1.19 vs 1.14 ms), so only k3 is routed here.
+      make_pair_chunked_launch<PairChunkedCfg<128, 64, 3, 256, 5, 2, 4>>("resblock_pair_mfma<c128,k3,bn256,kc64>"),
+  };
 #undef X
   *n = (int)(sizeof(table) / sizeof(table[0]));
   return table;

@@ -42,6 +42,7 @@ struct PairArgs {
 struct PairLaunch {
   void (*kernel)(PairArgs);
   int c, ks, bn, tt, threads, max_dil;
+  int kc;  // channel chunk of the weight layout [chunk][tap][C][kc] (== c when the layer is not chunked)
   size_t lds_bytes;
   const char* name;
 };
@@ -307,6 +308,7 @@ static PairLaunch make_pair_launch(const char* name) {
   l.max_dil = P::MAXDIL;
   l.lds_bytes = P::LDS;
   l.name = name;
+  l.kc = P::C;
   return l;
 }
 
