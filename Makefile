@@ -16,7 +16,7 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/evmi.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib -o $@
 
 clean:
 	rm -rf $(BUILD) $(LIB)

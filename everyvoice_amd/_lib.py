@@ -80,6 +80,20 @@ SYMBOLS = {
         C.c_int,
         [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p],
     ),
+    "evmi_gemm_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
+    "evmi_unfold_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
+    "evmi_fold_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
+    "evmi_bias_add_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
+    "evmi_row_reduce_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_int, C.c_void_p]),
+    "evmi_elementwise_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_void_p]),
+    "evmi_scalar_reduce_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "evmi_avgpool4s2_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
+    "evmi_period_view_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "evmi_stft_frames_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "evmi_weight_norm_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
+    "evmi_weight_norm_bwd_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
+    "evmi_normalize_vec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "evmi_adamw_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_float] * 5 + [C.c_int, C.c_void_p]),
     "evmi_generator_create": (C.c_int, [C.POINTER(GeneratorConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "evmi_generator_destroy": (None, [C.c_void_p]),
     "evmi_generator_set_weight": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),

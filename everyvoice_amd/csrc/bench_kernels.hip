@@ -83,7 +83,12 @@ struct Variant {
 #define EVMI_VARIANTS_OCC(X)                                              \
   X("c128k11_bn256_occ4", 128, 64, 128, 256, 2, 4, 11, 1, 5, 0, 4)      \
   X("c128k11_bn128_occ3", 128, 64, 128, 128, 2, 2, 11, 1, 5, 0, 3)      \
-  X("c256k11_bn256_occ4", 256, 64, 128, 256, 2, 4, 11, 1, 5, 0, 4)
+  X("c256k11_bn256_occ4", 256, 64, 128, 256, 2, 4, 11, 1, 5, 0, 4)      \
+  X("c128k11_bn256_md1_occ4", 128, 64, 128, 256, 2, 4, 11, 1, 1, 0, 4)  \
+  X("c128k11_bn256_md1_occ2", 128, 64, 128, 256, 2, 4, 11, 1, 1, 0, 2)  \
+  X("c128k11_bn256_md1_occ3", 128, 64, 128, 256, 2, 4, 11, 1, 1, 0, 3)  \
+  X("c128k3_bn256_md1_occ4", 128, 64, 128, 256, 2, 4, 3, 1, 1, 0, 4)    \
+  X("c128k3_bn256_md1_occ2", 128, 64, 128, 256, 2, 4, 3, 1, 1, 0, 2)
 
 static const std::vector<Variant>& variants() {
   static const std::vector<Variant> v = {

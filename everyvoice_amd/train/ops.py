@@ -1,0 +1,262 @@
+"""Training-time operators on libevmi_hip (fp32, channel-major "CBT" activations [C, B, T]).
+
+Thin host wrappers: torch allocates device memory and provides the stream, every arithmetic step is a
+libevmi_hip call (unfold / fold / activation / loss / norm kernels, rocBLAS sgemm for the plain GEMMs).
+Forward functions return what their backward needs; nothing here uses torch autograd or torch math.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+
+# elementwise op codes (csrc/train_ops.hip)
+EW_LRELU, EW_LRELU_BWD, EW_TANH, EW_TANH_BWD, EW_AXPBY, EW_SCALE, EW_MUL = 0, 1, 2, 3, 4, 5, 6
+EW_SIGN_DIFF, EW_SQ_GRAD, EW_LOG_CLAMP, EW_DIV_MASK, EW_MAG, EW_MUL_DIV = 7, 8, 9, 10, 11, 12
+
+
+def _s(t: torch.Tensor) -> int:
+    return _lib.current_stream_ptr(t.device)
+
+
+def _chk(rc: int, what: str) -> None:
+    _lib.check(rc, what)
+
+
+class Workspace:
+    """Grow-only scratch buffers keyed by role (unfold matrices are large and short-lived)."""
+
+    def __init__(self):
+        self._bufs: dict[str, torch.Tensor] = {}
+
+    def get(self, key: str, numel: int, device) -> torch.Tensor:
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < numel or buf.device != device:
+            buf = torch.empty(max(numel, 1), device=device, dtype=torch.float32)
+            self._bufs[key] = buf
+        return buf[:numel]
+
+
+WS = Workspace()
+
+
+def gemm(a, b, out, ta=False, tb=False, alpha=1.0, beta=0.0, M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
+    """Row-major out[M, N] = alpha * op(a) @ op(b) + beta * out (a, b, out: 2-D views or raw buffers + explicit dims)."""
+    lib = _lib.load()
+    if M is None:
+        M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+        N = b.shape[0] if tb else b.shape[1]
+        lda, ldb, ldc = a.stride(0), b.stride(0), out.stride(0)
+    _chk(lib.evmi_gemm_f32(int(ta), int(tb), M, N, K, alpha, a.data_ptr(), lda, b.data_ptr(), ldb, beta, out.data_ptr(), ldc, _s(out)), "evmi_gemm_f32")
+    return out
+
+
+def conv_out_len(t_in, k, stride, pad, dil):
+    return (t_in + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def unfold(x, k, stride, pad, dil, key="col"):
+    """x [C, B, T] -> col [C*k, B*T_out] (a workspace view; valid until the next unfold with the same key)."""
+    C, B, t_in = x.shape
+    t_out = conv_out_len(t_in, k, stride, pad, dil)
+    if k == 1 and stride == 1 and pad == 0:
+        return x.reshape(C, B * t_in), t_out
+    col = WS.get(key, C * k * B * t_out, x.device)
+    _chk(_lib.load().evmi_unfold_cbt_f32(x.data_ptr(), col.data_ptr(), C, B, t_in, t_out, k, stride, pad, dil, _s(x)), "evmi_unfold_cbt_f32")
+    return col.view(C * k, B * t_out), t_out
+
+
+def fold(dcol, C, B, t_in, t_out, k, stride, pad, dil, out=None, accumulate=False):
+    """Adjoint of unfold: dcol [C*k, B*T_out] -> dx [C, B, T_in]."""
+    if out is None:
+        out = torch.empty(C, B, t_in, device=dcol.device, dtype=torch.float32)
+    if k == 1 and stride == 1 and pad == 0 and not accumulate:
+        out.view(-1).copy_(dcol.reshape(-1))
+        return out
+    _chk(_lib.load().evmi_fold_cbt_f32(dcol.data_ptr(), out.data_ptr(), C, B, t_in, t_out, k, stride, pad, dil, int(accumulate), _s(out)), "evmi_fold_cbt_f32")
+    return out
+
+
+def elementwise(op, a, b=None, c=None, out=None, p0=0.0, p1=0.0):
+    if out is None:
+        out = torch.empty_like(a)
+    _chk(_lib.load().evmi_elementwise_f32(op, a.data_ptr(), _lib.ptr(b), _lib.ptr(c), out.data_ptr(), a.numel(), p0, p1, _s(a)), "evmi_elementwise_f32")
+    return out
+
+
+def row_reduce(mode, a, b, out, rows, n_per_row, scale=1.0, accumulate=False):
+    _chk(_lib.load().evmi_row_reduce_f32(mode, a.data_ptr(), _lib.ptr(b), out.data_ptr(), rows, n_per_row, scale, int(accumulate), _s(a)), "evmi_row_reduce_f32")
+    return out
+
+
+def scalar_reduce(mode, a, b, out, scale=1.0, p=0.0, accumulate=False):
+    _chk(_lib.load().evmi_scalar_reduce_f32(mode, a.data_ptr(), _lib.ptr(b), out.data_ptr(), a.numel(), scale, p, int(accumulate), _s(a)), "evmi_scalar_reduce_f32")
+    return out
+
+
+# ---- convolutions ---------------------------------------------------------------------------------------
+def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1):
+    """x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out]."""
+    cin, B, t_in = x.shape
+    cout, cin_g, k = w.shape
+    col, t_out = unfold(x, k, stride, pad, dil)
+    y = torch.empty(cout, B, t_out, device=x.device, dtype=torch.float32)
+    N = B * t_out
+    cout_g = cout // groups
+    wm = w.reshape(cout, cin_g * k)
+    for g in range(groups):
+        gemm(wm[g * cout_g : (g + 1) * cout_g], col[g * cin_g * k : (g + 1) * cin_g * k], y.view(cout, N)[g * cout_g : (g + 1) * cout_g])
+    if bias is not None:
+        _chk(_lib.load().evmi_bias_add_rows_f32(y.data_ptr(), bias.data_ptr(), cout, N, _s(y)), "evmi_bias_add_rows_f32")
+    return y
+
+
+def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=None, db_out=None, accumulate=False):
+    """Returns (dx, dw, db); dw/db are written (or accumulated) into the given buffers when provided."""
+    cin, B, t_in = x.shape
+    cout, cin_g, k = w.shape
+    t_out = dy.shape[2]
+    N = B * t_out
+    cout_g = cout // groups
+    dym = dy.view(cout, N)
+    wm = w.reshape(cout, cin_g * k)
+    dw = dw_out if dw_out is not None else torch.empty_like(w)
+    dwm = dw.view(cout, cin_g * k)
+    col, _ = unfold(x, k, stride, pad, dil)
+    beta = 1.0 if accumulate else 0.0
+    for g in range(groups):
+        gemm(dym[g * cout_g : (g + 1) * cout_g], col[g * cin_g * k : (g + 1) * cin_g * k], dwm[g * cout_g : (g + 1) * cout_g], tb=True, beta=beta)
+    db = None
+    if db_out is not None:
+        db = row_reduce(0, dy, None, db_out, cout, N, accumulate=accumulate)
+    dx = None
+    if need_dx:
+        pointwise = k == 1 and stride == 1 and pad == 0
+        dcol = (torch.empty(cin, B * t_in, device=x.device, dtype=torch.float32) if pointwise
+                else WS.get("dcol", cin * k * N, x.device).view(cin * k, N))
+        for g in range(groups):
+            gemm(wm[g * cout_g : (g + 1) * cout_g], dym[g * cout_g : (g + 1) * cout_g], dcol[g * cin_g * k : (g + 1) * cin_g * k], ta=True)
+        dx = dcol.view(cin, B, t_in) if pointwise else fold(dcol, cin, B, t_in, t_out, k, stride, pad, dil)
+    return dx, dw, db
+
+
+def conv_transpose1d_fwd(x, w, bias, stride, pad):
+    """x [Cin, B, T], w [Cin, Cout, k] -> y [Cout, B, (T-1)*stride - 2*pad + k]  (= dgrad of a strided conv)."""
+    cin, B, t_in = x.shape
+    _, cout, k = w.shape
+    t_out = (t_in - 1) * stride - 2 * pad + k
+    col = WS.get("dcol", cout * k * B * t_in, x.device).view(cout * k, B * t_in)
+    gemm(w.reshape(cin, cout * k), x.view(cin, B * t_in), col, ta=True)
+    y = fold(col, cout, B, t_out, t_in, k, stride, pad, 1)
+    if bias is not None:
+        _chk(_lib.load().evmi_bias_add_rows_f32(y.data_ptr(), bias.data_ptr(), cout, B * t_out, _s(y)), "evmi_bias_add_rows_f32")
+    return y
+
+
+def conv_transpose1d_bwd(x, w, dy, stride, pad, need_dx=True, dw_out=None, db_out=None, accumulate=False):
+    cin, B, t_in = x.shape
+    _, cout, k = w.shape
+    t_out = dy.shape[2]
+    col, t_chk = unfold(dy, k, stride, pad, 1)  # [Cout*k, B*T_in]
+    assert t_chk == t_in
+    dw = dw_out if dw_out is not None else torch.empty_like(w)
+    gemm(x.view(cin, B * t_in), col, dw.view(cin, cout * k), tb=True, beta=1.0 if accumulate else 0.0)
+    db = None
+    if db_out is not None:
+        db = row_reduce(0, dy, None, db_out, cout, B * t_out, accumulate=accumulate)
+    dx = None
+    if need_dx:
+        dx = torch.empty(cin, B, t_in, device=x.device, dtype=torch.float32)
+        gemm(w.reshape(cin, cout * k), col, dx.view(cin, B * t_in))
+    return dx, dw, db
+
+
+# ---- activations / pooling / views -------------------------------------------------------------------------
+def lrelu(x, slope):
+    return elementwise(EW_LRELU, x, p0=slope)
+
+
+def lrelu_bwd(dy, x, slope):
+    return elementwise(EW_LRELU_BWD, dy, x, p0=slope)
+
+
+def tanh(x):
+    return elementwise(EW_TANH, x)
+
+
+def tanh_bwd(dy, y):
+    return elementwise(EW_TANH_BWD, dy, y)
+
+
+def axpby(a, x, b, y, out=None):
+    return elementwise(EW_AXPBY, x, y, out=out, p0=a, p1=b)
+
+
+def avgpool4s2(x):
+    C, B, t_in = x.shape
+    y = torch.empty(C, B, t_in // 2 + 1, device=x.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_avgpool4s2_f32(x.data_ptr(), y.data_ptr(), C * B, t_in, 0, _s(x)), "evmi_avgpool4s2_f32")
+    return y
+
+
+def avgpool4s2_bwd(dy, t_in):
+    C, B, _ = dy.shape
+    dx = torch.empty(C, B, t_in, device=dy.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_avgpool4s2_f32(dy.data_ptr(), dx.data_ptr(), C * B, t_in, 1, _s(dy)), "evmi_avgpool4s2_f32")
+    return dx
+
+
+def period_view(x, period):
+    """x [1, B, T] -> [1, B*period, ceil(T/period)] (reflect padding on the right, as DiscriminatorP)."""
+    _, B, T = x.shape
+    H = (T + period - 1) // period
+    y = torch.empty(1, B * period, H, device=x.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_period_view_f32(x.data_ptr(), y.data_ptr(), B, T, period, 0, _s(x)), "evmi_period_view_f32")
+    return y
+
+
+def period_view_bwd(dy, B, T, period):
+    dx = torch.empty(1, B, T, device=dy.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_period_view_f32(dy.data_ptr(), dx.data_ptr(), B, T, period, 1, _s(dy)), "evmi_period_view_f32")
+    return dx
+
+
+# ---- norms / optimiser -----------------------------------------------------------------------------------------
+def weight_norm_fwd(g, v):
+    rows = v.shape[0]
+    n = v.numel() // rows
+    w = torch.empty_like(v)
+    norm = torch.empty(rows, device=v.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_weight_norm_fwd_f32(g.data_ptr(), v.data_ptr(), w.data_ptr(), norm.data_ptr(), rows, n, _s(v)), "evmi_weight_norm_fwd_f32")
+    return w, norm
+
+
+def weight_norm_bwd(g, v, norm, dw, dg_out, dv_out):
+    rows = v.shape[0]
+    n = v.numel() // rows
+    _chk(_lib.load().evmi_weight_norm_bwd_f32(g.data_ptr(), v.data_ptr(), norm.data_ptr(), dw.data_ptr(), dg_out.data_ptr(), dv_out.data_ptr(), rows, n, _s(v)), "evmi_weight_norm_bwd_f32")
+
+
+def normalize_vec(x, out, eps=1e-12):
+    _chk(_lib.load().evmi_normalize_vec_f32(x.data_ptr(), out.data_ptr(), x.numel(), eps, _s(x)), "evmi_normalize_vec_f32")
+    return out
+
+
+def adamw_step(p, g, m, v, lr, betas, eps, weight_decay, step):
+    _chk(_lib.load().evmi_adamw_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1], eps, weight_decay, step, _s(p)), "evmi_adamw_f32")
+
+
+def stft_frames(x, n_fft, hop):
+    """x [B, T] -> frames [n_fft, B*F], F = 1 + T // hop (centred, reflect padding; window lives in the DFT basis)."""
+    B, T = x.shape
+    F = 1 + T // hop
+    fr = torch.empty(n_fft, B * F, device=x.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_stft_frames_f32(x.data_ptr(), fr.data_ptr(), B, T, n_fft, hop, 0, _s(x)), "evmi_stft_frames_f32")
+    return fr, F
+
+
+def stft_frames_bwd(dfr, B, T, n_fft, hop):
+    dx = torch.empty(B, T, device=dfr.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_stft_frames_f32(dfr.data_ptr(), dx.data_ptr(), B, T, n_fft, hop, 1, _s(dfr)), "evmi_stft_frames_f32")
+    return dx

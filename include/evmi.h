@@ -187,6 +187,60 @@ int evmi_generator_forward_profiled(evmi_generator* g, const float* mel_dev, flo
 /* Algorithmic MACs per output sample of this configuration (V1: 1,199,424). */
 double evmi_generator_macs_per_sample(const evmi_generator* g);
 
+/* ------------------------------------------------------------------------------------------
+ * GAN training building blocks (fp32) — what the training_step of `hfgl.model.HiFiGAN` (absent
+ * submodule; call sites everyvoice/base_cli/helpers.py:36,184, SURVEY.md §3.1 hot loop) executes
+ * through ATen: convolutions of generator / MPD / MSD and their gradients, activations, pooling,
+ * the mel loss, weight / spectral norm, AdamW.
+ *
+ * Activations are channel-major "CBT": x[c][b][t] == a row-major [C][B*T] matrix (audio [B,1,T]
+ * and logits have the same bytes as torch's layout).  A convolution is unfold + one GEMM
+ * (everyvoice_amd/train/ops.py composes them):
+ *   fwd  Y[C_out][B*T_out] = W[C_out][C_in*k] . col      dgrad  dcol = W^T . dY -> fold
+ *   wgrad dW = dY . col^T
+ * ------------------------------------------------------------------------------------------ */
+/* Row-major C[M][N] = alpha * op(A)[M][K] . op(B)[K][N] + beta * C   (rocBLAS sgemm underneath). */
+int evmi_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* a_dev,
+                  int lda, const float* b_dev, int ldb, float beta, float* c_dev, int ldc,
+                  void* stream);
+/* col[(c*k + j)][b][to] = x[c][b][to*stride + j*dil - pad] (0 outside);  fold is its adjoint. */
+int evmi_unfold_cbt_f32(const float* x_dev, float* col_dev, int C, int B, int t_in, int t_out, int k,
+                        int stride, int pad, int dil, void* stream);
+int evmi_fold_cbt_f32(const float* dcol_dev, float* dx_dev, int C, int B, int t_in, int t_out, int k,
+                      int stride, int pad, int dil, int accumulate, void* stream);
+int evmi_bias_add_rows_f32(float* y_dev, const float* bias_dev, int rows, long long n_per_row,
+                           void* stream);
+/* out[r] (+)= scale * sum_n f;  mode 0: a, 1: a*b, 2: a*a  (bias gradients, per-row dots). */
+int evmi_row_reduce_f32(int mode, const float* a_dev, const float* b_dev, float* out_dev, int rows,
+                        long long n_per_row, float scale, int accumulate, void* stream);
+/* Elementwise ops (op codes documented in csrc/train_ops.hip: leaky-relu / tanh and their
+ * derivatives, axpby, products, L1 / LSGAN loss derivatives, log-clamp and the mel-loss chain). */
+int evmi_elementwise_f32(int op, const float* a_dev, const float* b_dev, const float* c_dev,
+                         float* y_dev, long long n, float p0, float p1, void* stream);
+/* out[0] (+)= scale * sum f;  mode 0: |a-b|, 1: (a-p)^2, 2: a   (fixed order: reproducible). */
+int evmi_scalar_reduce_f32(int mode, const float* a_dev, const float* b_dev, float* out_dev,
+                           long long n, float scale, float p, int accumulate, void* stream);
+/* AvgPool1d(4, 2, padding=2) on [rows][t_in] (MSD) and its adjoint. */
+int evmi_avgpool4s2_f32(const float* x_dev, float* y_dev, long long rows, int t_in, int backward,
+                        void* stream);
+/* MPD view: reflect-pad [B][T] on the right to a multiple of `period`, then [B*period][T'/period]. */
+int evmi_period_view_f32(const float* x_dev, float* x2_dev, int B, int T, int period, int backward,
+                         void* stream);
+/* frames[k][b][f] = reflect_pad(x)[b][f*hop + k] -> [n_fft][B*(1 + T/hop)] (centred STFT) / adjoint. */
+int evmi_stft_frames_f32(const float* x_dev, float* frames_dev, int B, int T, int n_fft, int hop,
+                         int backward, void* stream);
+/* torch.nn.utils.weight_norm (dim 0): w = g * v / ||v|| per row, and its backward. */
+int evmi_weight_norm_fwd_f32(const float* g_dev, const float* v_dev, float* w_dev, float* norm_dev,
+                             int rows, int n_per_row, void* stream);
+int evmi_weight_norm_bwd_f32(const float* g_dev, const float* v_dev, const float* norm_dev,
+                             const float* dw_dev, float* dg_dev, float* dv_dev, int rows,
+                             int n_per_row, void* stream);
+/* y = x / max(||x||, eps) (spectral norm's power iteration). */
+int evmi_normalize_vec_f32(const float* x_dev, float* y_dev, int n, float eps, void* stream);
+/* torch.optim.AdamW step `step` (1-based) on a flat parameter buffer. */
+int evmi_adamw_f32(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

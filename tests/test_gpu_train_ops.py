@@ -1,0 +1,152 @@
+"""Training building blocks on the GPU vs torch-CPU autograd (the oracle for gradients).
+fp32 everywhere: tolerances are summation-order noise (rtol 1e-4 / atol 1e-5 unless noted)."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def cbt(t):  # torch [B, C, T] -> CBT [C, B, T]
+    return t.permute(1, 0, 2).contiguous()
+
+
+def bct(t):
+    return t.permute(1, 0, 2).contiguous()
+
+
+CONVS = [
+    dict(cin=8, cout=12, k=3, stride=1, pad=1, dil=1, groups=1),
+    dict(cin=16, cout=16, k=11, stride=1, pad=25, dil=5, groups=1),
+    dict(cin=16, cout=32, k=41, stride=4, pad=20, dil=1, groups=4),   # MSD-style grouped strided
+    dict(cin=1, cout=8, k=15, stride=1, pad=7, dil=1, groups=1),
+    dict(cin=4, cout=6, k=5, stride=3, pad=2, dil=1, groups=1),       # MPD-style (k,1)/(3,1) on the period view
+    dict(cin=24, cout=8, k=1, stride=1, pad=0, dil=1, groups=1),      # pointwise: no unfold
+]
+
+
+@pytest.mark.parametrize("c", CONVS)
+def test_conv1d_fwd_bwd(cuda_device, c):
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(1)
+    B, T = 3, 101
+    x = torch.randn(B, c["cin"], T, generator=g, requires_grad=True)
+    w = (torch.randn(c["cout"], c["cin"] // c["groups"], c["k"], generator=g) * 0.2).requires_grad_()
+    b = torch.randn(c["cout"], generator=g, requires_grad=True)
+    y = F.conv1d(x, w, b, c["stride"], c["pad"], c["dil"], c["groups"])
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd, wd, bd, dyd = cbt(x.detach()).to(cuda_device), w.detach().to(cuda_device), b.detach().to(cuda_device), cbt(dy).to(cuda_device)
+    yg = ops.conv1d_fwd(xd, wd, bd, c["stride"], c["pad"], c["dil"], c["groups"])
+    torch.testing.assert_close(bct(yg.cpu()), y.detach(), rtol=1e-4, atol=1e-5)
+    dbuf = torch.zeros(c["cout"], device=cuda_device)
+    dx, dw, db = ops.conv1d_bwd(xd, wd, dyd, c["stride"], c["pad"], c["dil"], c["groups"], db_out=dbuf)
+    torch.testing.assert_close(bct(dx.cpu()), x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-4)
+    # accumulation into existing gradient buffers
+    dw2 = dw.clone()
+    ops.conv1d_bwd(xd, wd, dyd, c["stride"], c["pad"], c["dil"], c["groups"], need_dx=False, dw_out=dw2, db_out=dbuf, accumulate=True)
+    torch.testing.assert_close(dw2.cpu(), 2 * w.grad, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(dbuf.cpu(), 2 * b.grad, rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("u,k", [(8, 16), (2, 4), (3, 7)])
+def test_conv_transpose1d_fwd_bwd(cuda_device, u, k):
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(2)
+    B, T, cin, cout = 2, 37, 12, 6
+    p = (k - u) // 2
+    x = torch.randn(B, cin, T, generator=g, requires_grad=True)
+    w = (torch.randn(cin, cout, k, generator=g) * 0.2).requires_grad_()
+    b = torch.randn(cout, generator=g, requires_grad=True)
+    y = F.conv_transpose1d(x, w, b, u, p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd, wd, bd, dyd = cbt(x.detach()).to(cuda_device), w.detach().to(cuda_device), b.detach().to(cuda_device), cbt(dy).to(cuda_device)
+    yg = ops.conv_transpose1d_fwd(xd, wd, bd, u, p)
+    torch.testing.assert_close(bct(yg.cpu()), y.detach(), rtol=1e-4, atol=1e-5)
+    dbuf = torch.zeros(cout, device=cuda_device)
+    dx, dw, db = ops.conv_transpose1d_bwd(xd, wd, dyd, u, p, db_out=dbuf)
+    torch.testing.assert_close(bct(dx.cpu()), x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_pool_period_view_activations(cuda_device):
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 50, generator=g, requires_grad=True)
+    y = F.avg_pool1d(x, 4, 2, padding=2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    yg = ops.avgpool4s2(cbt(x.detach()).to(cuda_device))
+    torch.testing.assert_close(bct(yg.cpu()), y.detach())
+    torch.testing.assert_close(bct(ops.avgpool4s2_bwd(cbt(dy).to(cuda_device), 50).cpu()), x.grad)
+    for period, T in ((2, 64), (3, 64), (5, 61), (7, 50), (11, 8192)):
+        a = torch.randn(2, 1, T, generator=g, requires_grad=True)
+        n_pad = (period - T % period) % period
+        ap = F.pad(a, (0, n_pad), "reflect") if n_pad else a
+        v = ap.view(2, 1, -1, period)  # [B, 1, H, p]
+        want = v.permute(1, 0, 3, 2).reshape(1, 2 * period, -1)  # [1, B*p, H]
+        got = ops.period_view(cbt(a.detach()).to(cuda_device), period)
+        torch.testing.assert_close(got.cpu(), want.detach())
+        dv = torch.randn(want.shape, generator=g)
+        want.backward(dv)
+        torch.testing.assert_close(bct(ops.period_view_bwd(dv.to(cuda_device), 2, T, period).cpu()), a.grad)
+    t = torch.randn(1000, generator=g)
+    torch.testing.assert_close(ops.lrelu(t.to(cuda_device), 0.1).cpu(), F.leaky_relu(t, 0.1))
+    torch.testing.assert_close(ops.lrelu_bwd(t.to(cuda_device), (-t).to(cuda_device), 0.1).cpu(), t * torch.where(-t > 0, 1.0, 0.1))
+    torch.testing.assert_close(ops.tanh(t.to(cuda_device)).cpu(), torch.tanh(t), rtol=1e-5, atol=1e-6)
+    th = torch.tanh(t)
+    torch.testing.assert_close(ops.tanh_bwd(t.to(cuda_device), th.to(cuda_device)).cpu(), t * (1 - th * th), rtol=1e-5, atol=1e-6)
+
+
+def test_weight_norm_and_adamw(cuda_device):
+    from everyvoice_amd.train import ops
+
+    torch.manual_seed(4)
+    for conv in (torch.nn.Conv1d(6, 10, 5), torch.nn.ConvTranspose1d(6, 4, 4, 2, padding=1)):
+        wn = torch.nn.utils.weight_norm(conv)
+        gw, vw = wn.weight_g.detach().clone(), wn.weight_v.detach().clone()
+        w, norm = ops.weight_norm_fwd(gw.to(cuda_device), vw.to(cuda_device))
+        torch.testing.assert_close(w.cpu(), wn.weight.detach(), rtol=1e-5, atol=1e-6)
+        dw = torch.randn(wn.weight.shape)
+        wn.weight_g.grad = wn.weight_v.grad = None
+        torch._weight_norm(wn.weight_v, wn.weight_g, 0).backward(dw)
+        dg, dv = torch.empty_like(gw, device=cuda_device), torch.empty_like(vw, device=cuda_device)
+        ops.weight_norm_bwd(gw.to(cuda_device), vw.to(cuda_device), norm, dw.to(cuda_device), dg, dv)
+        torch.testing.assert_close(dg.cpu(), wn.weight_g.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(dv.cpu(), wn.weight_v.grad, rtol=1e-4, atol=1e-5)
+    p = torch.nn.Parameter(torch.randn(1000))
+    opt = torch.optim.AdamW([p], lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
+    pd = p.detach().clone().to(cuda_device)
+    m, v = torch.zeros_like(pd), torch.zeros_like(pd)
+    for step in range(1, 4):
+        gr = torch.randn(1000)
+        p.grad = gr.clone()
+        opt.step()
+        ops.adamw_step(pd, gr.to(cuda_device), m, v, 2e-4, (0.8, 0.99), 1e-8, 0.01, step)
+        torch.testing.assert_close(pd.cpu(), p.detach(), rtol=1e-5, atol=1e-7)
+
+
+def test_stft_frames_and_adjoint(cuda_device):
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(5)
+    B, T, n_fft, hop = 3, 2048, 1024, 256
+    x = torch.randn(B, T, generator=g, requires_grad=True)
+    xp = F.pad(x.unsqueeze(1), (n_fft // 2, n_fft // 2), "reflect").squeeze(1)
+    fr = xp.unfold(1, n_fft, hop)  # [B, F, n_fft]
+    want = fr.permute(2, 0, 1).reshape(n_fft, -1)
+    got, Fr = ops.stft_frames(x.detach().to(cuda_device), n_fft, hop)
+    assert Fr == 1 + T // hop
+    torch.testing.assert_close(got.cpu(), want.detach())
+    d = torch.randn(want.shape, generator=g)
+    want.backward(d)
+    dx = ops.stft_frames_bwd(d.to(cuda_device), B, T, n_fft, hop)
+    torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-5, atol=1e-5)

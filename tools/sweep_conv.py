@@ -22,7 +22,7 @@ for n in names:
     if only and not any(o in n for o in only):
         continue
     c = int(n[1:].split("k")[0])
-    for dil, pre, res in ((5, 0.1, 0), (1, 1.0, 1)):
+    for dil, pre, res in (((5, 0.1, 0), (1, 1.0, 1)) if "_md1" not in n else ((1, 0.1, 0), (1, 1.0, 1))):
         ms, fl = C.c_float(), C.c_double()
         rc = lib.evmi_bench_conv_tc(n.encode(), 32, T_BY_C[c], 0, dil, res, pre, 5, C.byref(ms), C.byref(fl))
         if rc:
