@@ -1,0 +1,330 @@
+"""GAN training step of the HiFiGAN vocoder on libevmi_hip — the host-side mirror of the hot loop of
+``hfgl.model.HiFiGAN.training_step`` (absent submodule): manual optimisation with
+two optimisers, ``gan_type = "original"`` (LSGAN):
+
+    y_hat = G(mel)
+    D step:  loss_d = sum_i mean((1 - D_i(y))^2) + mean(D_i(y_hat.detach())^2)            -> AdamW(D)
+    G step:  loss_g = sum_i mean((1 - D_i(y_hat))^2) + 2 * sum L1(fmaps) + 45 * L1(logmel(y), logmel(y_hat)) -> AdamW(G)
+
+Layer structure and state-dict names follow upstream (jik876 HiFi-GAN generator / MPD / MSD; the first MSD scale
+is spectral-normalised), see oracle/hifigan_ref.py for the pins.  All arithmetic runs in libevmi_hip kernels
+(fp32, channel-major activations); torch owns memory and, for data parallel training, the RCCL all-reduce of
+the two flat gradient buffers.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from ..config import ACTIVATION_SLOPES, HiFiGANConfig
+from ..spectral import slaney_mel_filterbank, windowed_dft_basis
+from . import autograd as ag
+from . import ops
+from .layers import ParamGroup, SNConv, WNConv, kaiming_uniform_conv_init_
+
+
+def _to_cbt(x_bct: torch.Tensor) -> torch.Tensor:
+    return x_bct.permute(1, 0, 2).contiguous()  # layout change only (memory plumbing)
+
+
+class GeneratorT:
+    def __init__(self, cfg: HiFiGANConfig, group: ParamGroup):
+        m = cfg.model
+        if m.istft_layer or str(getattr(m.resblock, "value", m.resblock)) != "1":
+            raise NotImplementedError("training path: resblock '1' without the iSTFT head (this round)")
+        self.slope = ACTIVATION_SLOPES[m.activation_function]
+        ch0, n_mels = m.upsample_initial_channel, cfg.preprocessing.audio.n_mels
+        self.conv_pre = WNConv(group, "conv_pre", n_mels, ch0, 7, pad=3)
+        self.ups = [
+            WNConv(group, f"ups.{i}", ch0 >> i, ch0 >> (i + 1), k, stride=u, pad=(k - u) // 2, transposed=True)
+            for i, (u, k) in enumerate(zip(m.upsample_rates, m.upsample_kernel_sizes))
+        ]
+        self.resblocks = []
+        for i in range(len(m.upsample_rates)):
+            c = ch0 >> (i + 1)
+            for j, (k, dils) in enumerate(zip(m.resblock_kernel_sizes, m.resblock_dilation_sizes)):
+                n = i * len(m.resblock_kernel_sizes) + j
+                self.resblocks.append([
+                    (WNConv(group, f"resblocks.{n}.convs1.{q}", c, c, k, pad=d * (k - 1) // 2, dil=d),
+                     WNConv(group, f"resblocks.{n}.convs2.{q}", c, c, k, pad=(k - 1) // 2))
+                    for q, d in enumerate(dils)
+                ])
+        self.num_kernels = len(m.resblock_kernel_sizes)
+        self.conv_post = WNConv(group, "conv_post", ch0 >> len(m.upsample_rates), 1, 7, pad=3)
+
+    def layers(self):
+        out = [self.conv_pre, *self.ups, self.conv_post]
+        for rb in self.resblocks:
+            for c1, c2 in rb:
+                out += [c1, c2]
+        return out
+
+    def forward(self, tape: ag.Tape, mel: ag.Var) -> ag.Var:
+        x = ag.conv1d(tape, mel, self.conv_pre)
+        for i, up in enumerate(self.ups):
+            x = ag.lrelu(tape, x, self.slope)
+            x = ag.conv_transpose1d(tape, x, up)
+            xs = None
+            for j in range(self.num_kernels):
+                y = x
+                for c1, c2 in self.resblocks[i * self.num_kernels + j]:
+                    t = ag.lrelu(tape, y, self.slope)
+                    t = ag.conv1d(tape, t, c1)
+                    t = ag.lrelu(tape, t, self.slope)
+                    t = ag.conv1d(tape, t, c2)
+                    y = ag.add(tape, t, y)
+                xs = y if xs is None else ag.add(tape, xs, y)
+            x = ag.scale(tape, xs, 1.0 / self.num_kernels)
+        x = ag.lrelu(tape, x, 0.01)
+        x = ag.conv1d(tape, x, self.conv_post)
+        return ag.tanh(tape, x)
+
+
+class DiscriminatorPT:
+    def __init__(self, group: ParamGroup, prefix: str, period: int):
+        self.period = period
+        chans = [1, 32, 128, 512, 1024]
+        self.convs = [WNConv(group, f"{prefix}.convs.{i}", chans[i], chans[i + 1], 5, stride=3, pad=2) for i in range(4)]
+        self.convs.append(WNConv(group, f"{prefix}.convs.4", 1024, 1024, 5, pad=2))
+        self.conv_post = WNConv(group, f"{prefix}.conv_post", 1024, 1, 3, pad=1)
+
+    def layers(self):
+        return [*self.convs, self.conv_post]
+
+    def forward(self, tape, audio: ag.Var, training=True):
+        x = ag.period_view(tape, audio, self.period)  # [1, B*p, H]: Conv2d((k,1)) == Conv1d over H per column
+        fmap = []
+        for conv in self.convs:
+            x = ag.lrelu(tape, ag.conv1d(tape, x, conv, training), 0.1)
+            fmap.append(x)
+        x = ag.conv1d(tape, x, self.conv_post, training)
+        fmap.append(x)
+        return x, fmap
+
+
+class DiscriminatorST:
+    SPEC = [(1, 128, 15, 1, 1, 7), (128, 128, 41, 2, 4, 20), (128, 256, 41, 2, 16, 20), (256, 512, 41, 4, 16, 20),
+            (512, 1024, 41, 4, 16, 20), (1024, 1024, 41, 1, 16, 20), (1024, 1024, 5, 1, 1, 2)]
+
+    def __init__(self, group: ParamGroup, prefix: str, spectral: bool):
+        cls = SNConv if spectral else WNConv
+        self.convs = [cls(group, f"{prefix}.convs.{i}", ci, co, k, stride=s, pad=p, groups=g)
+                      for i, (ci, co, k, s, g, p) in enumerate(self.SPEC)]
+        self.conv_post = cls(group, f"{prefix}.conv_post", 1024, 1, 3, pad=1)
+
+    def layers(self):
+        return [*self.convs, self.conv_post]
+
+    def forward(self, tape, x: ag.Var, training=True):
+        fmap = []
+        for conv in self.convs:
+            x = ag.lrelu(tape, ag.conv1d(tape, x, conv, training), 0.1)
+            fmap.append(x)
+        x = ag.conv1d(tape, x, self.conv_post, training)
+        fmap.append(x)
+        return x, fmap
+
+
+class MelLoss:
+    """45 * L1(logmel(y), logmel(y_hat)) with the reference's mel-librosa front-end (heavy.py:69-100, 39-40), as
+    GEMMs: frames [n_fft, B*F] -> (cos | sin) DFT -> magnitude -> mel basis -> log-clamp."""
+
+    def __init__(self, audio_cfg, device):
+        self.n_fft, self.hop = audio_cfg.n_fft, audio_cfg.fft_hop_size
+        basis, nb_pad = windowed_dft_basis(self.n_fft, audio_cfg.fft_window_size)
+        nb = self.n_fft // 2 + 1
+        b = torch.from_numpy(basis)  # [n_fft, 2*nb_pad] interleaved (w cos, -w sin)
+        self.cos = b[:, 0 : 2 * nb : 2].t().contiguous().to(device)  # [nb, n_fft]
+        self.sin = b[:, 1 : 2 * nb : 2].t().contiguous().to(device)
+        self.melb = torch.from_numpy(slaney_mel_filterbank(audio_cfg.input_sampling_rate, self.n_fft, audio_cfg.n_mels,
+                                                           audio_cfg.f_min, audio_cfg.f_max)).to(device)
+        self.nb, self.n_mels = nb, audio_cfg.n_mels
+
+    def logmel(self, audio_bt: torch.Tensor):
+        fr, F = ops.stft_frames(audio_bt, self.n_fft, self.hop)
+        N = fr.shape[1]
+        re = torch.empty(self.nb, N, device=fr.device)
+        im = torch.empty(self.nb, N, device=fr.device)
+        ops.gemm(self.cos, fr, re)
+        ops.gemm(self.sin, fr, im)
+        mag = ops.elementwise(ops.EW_MAG, re, im, p0=1e-9)
+        mel = torch.empty(self.n_mels, N, device=fr.device)
+        ops.gemm(self.melb, mag, mel)
+        return ops.elementwise(ops.EW_LOG_CLAMP, mel, p0=1e-5), (re, im, mag, mel)
+
+    def loss_and_grad(self, y_bt, yhat_bt, weight, loss_out):
+        """loss_out[0] += weight * mean|logmel(y) - logmel(y_hat)|; returns d loss / d y_hat [B, T]."""
+        B, T = yhat_bt.shape
+        lm_y, _ = self.logmel(y_bt)
+        lm_g, (re, im, mag, mel) = self.logmel(yhat_bt)
+        n = lm_g.numel()
+        ops.scalar_reduce(0, lm_g, lm_y, loss_out, scale=weight / n, accumulate=True)
+        dlog = ops.elementwise(ops.EW_SIGN_DIFF, lm_g, lm_y, p0=weight / n)
+        dmel = ops.elementwise(ops.EW_DIV_MASK, dlog, mel, p0=1e-5)
+        dmag = torch.empty_like(mag)
+        ops.gemm(self.melb, dmel, dmag, ta=True)
+        dre = ops.elementwise(ops.EW_MUL_DIV, dmag, re, mag)
+        dim = ops.elementwise(ops.EW_MUL_DIV, dmag, im, mag)
+        dfr = torch.empty(self.n_fft, dre.shape[1], device=dre.device)
+        ops.gemm(self.cos, dre, dfr, ta=True)
+        ops.gemm(self.sin, dim, dfr, ta=True, beta=1.0)
+        return ops.stft_frames_bwd(dfr, B, T, self.n_fft, self.hop)
+
+
+class HiFiGANTrainer:
+    """Generator + MPD + MSD with two AdamW optimisers; ``training_step`` is one full GAN step."""
+
+    def __init__(self, config: HiFiGANConfig | None = None, device="cuda:0", lr=2e-4, betas=(0.8, 0.99), eps=1e-8,
+                 weight_decay=0.01, seed=1234, process_group=None):
+        self.config = config or HiFiGANConfig()
+        self.device = torch.device(device)
+        self.opt = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.pg = process_group
+        self.g_params, self.d_params = ParamGroup(self.device), ParamGroup(self.device)
+        self.generator = GeneratorT(self.config, self.g_params)
+        m = self.config.model
+        self.mpd = [DiscriminatorPT(self.d_params, f"mpd.discriminators.{i}", p) for i, p in enumerate(m.mpd_layers)]
+        self.msd = [DiscriminatorST(self.d_params, f"msd.discriminators.{i}", spectral=(i == 0)) for i in range(m.msd_layers)]
+        self.g_params.finalize()
+        self.d_params.finalize()
+        self.mel_loss = MelLoss(self.config.preprocessing.audio, self.device)
+        gen = torch.Generator().manual_seed(seed)
+        for layer in self.generator.layers():
+            std = None if layer.name == "conv_pre" else 0.01  # upstream init_weights: N(0, 0.01) except conv_pre
+            kaiming_uniform_conv_init_(layer, gen, std)
+        for d in [*self.mpd, *self.msd]:
+            for layer in d.layers():
+                kaiming_uniform_conv_init_(layer, gen)
+        self.global_step = 0
+        self.keep_grads = False  # tests: keep copies of both gradient buffers of the last step
+        self.last_grads = {}
+
+    # -- state ------------------------------------------------------------------------------------------
+    def d_layers(self):
+        return [layer for d in [*self.mpd, *self.msd] for layer in d.layers()]
+
+    def load_reference_state(self, gen_sd=None, mpd_sd=None, msd_sd=None):
+        """Load upstream-named state dicts (weight_g / weight_v / weight_orig / bias, SN buffers weight_u / weight_v)."""
+        def put(group, prefix, sd, layers):
+            by_name = {l.name: l for l in layers}
+            for k, v in sd.items():
+                name = prefix + k
+                base = name.rsplit(".", 1)[0]
+                layer = by_name.get(base)
+                if layer is None:
+                    raise KeyError(name)
+                leaf = name.rsplit(".", 1)[1]
+                if isinstance(layer, SNConv) and leaf in ("weight_u", "weight_v"):
+                    (layer.u if leaf == "weight_u" else layer.v).copy_(v.to(self.device))
+                else:
+                    group.load(name, v)
+        if gen_sd is not None:
+            put(self.g_params, "", gen_sd, self.generator.layers())
+        if mpd_sd is not None:
+            put(self.d_params, "mpd.", mpd_sd, self.d_layers())
+        if msd_sd is not None:
+            put(self.d_params, "msd.", msd_sd, self.d_layers())
+
+    def _materialize(self, layers):
+        for layer in layers:
+            layer.materialize()
+
+    def _allreduce(self, group: ParamGroup):
+        if self.pg is not None:
+            import torch.distributed as dist
+
+            dist.all_reduce(group.grad, group=self.pg if self.pg is not True else None)
+            ops.elementwise(ops.EW_SCALE, group.grad, out=group.grad, p0=1.0 / dist.get_world_size())
+
+    # -- discriminators on one waveform ----------------------------------------------------------------------
+    def _discriminate(self, tape, audio: ag.Var, training=True):
+        logits, fmaps = [], []
+        for d in self.mpd:
+            o, f = d.forward(tape, audio, training)
+            logits.append(o)
+            fmaps.append(f)
+        x = audio
+        for i, d in enumerate(self.msd):
+            if i > 0:
+                x = ag.avgpool4s2(tape, x)
+            o, f = d.forward(tape, x, training)
+            logits.append(o)
+            fmaps.append(f)
+        return logits, fmaps
+
+    # -- one GAN step -----------------------------------------------------------------------------------------
+    def training_step(self, mel_bct: torch.Tensor, audio_bct: torch.Tensor) -> dict:
+        """mel [B, n_mels, T/hop], audio [B, 1, T] on the device.  Returns the scalar losses (python floats)."""
+        dev = self.device
+        B = audio_bct.shape[0]
+        y = audio_bct.to(torch.float32).reshape(1, B, -1).contiguous()  # [B,1,T] and [1,B,T] are the same bytes
+        mel = _to_cbt(mel_bct.to(torch.float32))
+        g_layers, d_layers = self.generator.layers(), self.d_layers()
+        self._materialize(g_layers)
+        self._materialize(d_layers)
+        losses = {k: torch.zeros(1, device=dev) for k in ("d", "g_adv", "g_fm", "g_mel")}
+
+        # ---- generator forward (tape kept for the generator step) ----
+        g_tape = ag.Tape()
+        y_hat = self.generator.forward(g_tape, ag.Var(mel, needs_grad=False))
+
+        # ---- discriminator step ----
+        self.d_params.zero_grad()
+        for layer in d_layers:
+            layer.frozen = False
+        d_tape = ag.Tape()
+        real_logits, _ = self._discriminate(d_tape, ag.Var(y, needs_grad=False))
+        fake_logits, _ = self._discriminate(d_tape, ag.Var(y_hat.data, needs_grad=False))  # y_hat.detach()
+        for dr, dg in zip(real_logits, fake_logits):
+            n = dr.data.numel()
+            ops.scalar_reduce(1, dr.data, None, losses["d"], scale=1.0 / n, p=1.0, accumulate=True)
+            ops.scalar_reduce(1, dg.data, None, losses["d"], scale=1.0 / n, p=0.0, accumulate=True)
+            dr.grad = ops.elementwise(ops.EW_SQ_GRAD, dr.data, p0=1.0 / n, p1=1.0)
+            dg.grad = ops.elementwise(ops.EW_SQ_GRAD, dg.data, p0=1.0 / n, p1=0.0)
+        d_tape.backward()
+        for layer in d_layers:
+            layer.finish_grads()
+        self._allreduce(self.d_params)
+        if self.keep_grads:
+            self.last_grads["d"] = {k: v.clone() for k, v in self.d_params.gradients().items()}
+        self.d_params.adamw(**self.opt)
+        self._materialize(d_layers)  # the generator step sees the updated discriminators
+
+        # ---- generator step ----
+        self.g_params.zero_grad()
+        for layer in d_layers:
+            layer.frozen = True  # gradients flow through the discriminators to y_hat only
+        gd_tape = ag.Tape()
+        y_hat_in = ag.Var(y_hat.data)  # boundary between the discriminator tape and the generator tape
+        _, fmaps_r = self._discriminate(gd_tape, ag.Var(y, needs_grad=False))
+        fake_logits, fmaps_g = self._discriminate(gd_tape, y_hat_in)
+        for dg in fake_logits:
+            n = dg.data.numel()
+            ops.scalar_reduce(1, dg.data, None, losses["g_adv"], scale=1.0 / n, p=1.0, accumulate=True)
+            dg.grad = ops.elementwise(ops.EW_SQ_GRAD, dg.data, p0=1.0 / n, p1=1.0)
+        for fr_list, fg_list in zip(fmaps_r, fmaps_g):
+            for fr, fg in zip(fr_list, fg_list):
+                n = fg.data.numel()
+                ops.scalar_reduce(0, fg.data, fr.data, losses["g_fm"], scale=2.0 / n, accumulate=True)
+                fg.accumulate(ops.elementwise(ops.EW_SIGN_DIFF, fg.data, fr.data, p0=2.0 / n))
+        gd_tape.backward()
+        for layer in d_layers:
+            if isinstance(layer, SNConv):
+                layer._calls.clear()  # frozen: no parameter gradients from this pass
+        d_mel = self.mel_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), 45.0, losses["g_mel"])
+        total = d_mel.view(1, B, -1)
+        if y_hat_in.grad is not None:
+            total = ops.axpby(1.0, total, 1.0, y_hat_in.grad)
+        y_hat.grad = total
+        g_tape.backward()
+        for layer in g_layers:
+            layer.finish_grads()
+        self._allreduce(self.g_params)
+        if self.keep_grads:
+            self.last_grads["g"] = {k: v.clone() for k, v in self.g_params.gradients().items()}
+            self.last_grads["y_hat"] = y_hat.data.clone()
+        self.g_params.adamw(**self.opt)
+        self.global_step += 1
+        out = {k: float(v.item()) for k, v in losses.items()}
+        out["g_total"] = out["g_adv"] + out["g_fm"] + out["g_mel"]
+        return out

@@ -1,0 +1,199 @@
+"""Parameters and (weight- / spectral-) normalised convolution layers of the training path.
+
+Parameters of one optimiser live in one flat fp32 buffer (``ParamGroup``): AdamW is a single kernel over it
+and data-parallel training all-reduces one contiguous gradient buffer per optimiser (the generator side and
+the discriminator side of the GAN step separately).  State-dict names follow upstream
+(``conv_pre.weight_g`` / ``weight_v`` / ``bias``, ``...weight_orig`` / ``weight_u`` / ``weight_v`` for the
+spectral-norm discriminator) so reference checkpoints map one to one.
+"""
+
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+
+class ParamGroup:
+    def __init__(self, device):
+        self.device = device
+        self._specs = []  # (name, shape, offset)
+        self._n = 0
+        self.flat = self.grad = self.m = self.v = None
+        self.step = 0
+
+    def declare(self, name: str, shape) -> int:
+        n = math.prod(shape)
+        self._specs.append((name, tuple(shape), self._n))
+        self._n += (n + 3) // 4 * 4  # keep every tensor 16-byte aligned
+        return len(self._specs) - 1
+
+    def finalize(self):
+        self.flat = torch.zeros(self._n, device=self.device, dtype=torch.float32)
+        self.grad = torch.zeros_like(self.flat)
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self._index = {name: i for i, (name, _, _) in enumerate(self._specs)}
+
+    def _view(self, buf, i):
+        _, shape, off = self._specs[i]
+        return buf[off : off + math.prod(shape)].view(shape)
+
+    def data(self, i):
+        return self._view(self.flat, i)
+
+    def gradient(self, i):
+        return self._view(self.grad, i)
+
+    def names(self):
+        return [s[0] for s in self._specs]
+
+    def numel(self):
+        return sum(math.prod(s[1]) for s in self._specs)
+
+    def state_dict(self):
+        return {name: self._view(self.flat, i).detach().clone() for i, (name, _, _) in enumerate(self._specs)}
+
+    def gradients(self):
+        return {name: self._view(self.grad, i) for i, (name, _, _) in enumerate(self._specs)}
+
+    def load(self, name: str, value: torch.Tensor):
+        self._view(self.flat, self._index[name]).copy_(value.to(self.device, torch.float32).reshape(self._specs[self._index[name]][1]))
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def adamw(self, lr, betas, eps, weight_decay):
+        self.step += 1
+        ops.adamw_step(self.flat, self.grad, self.m, self.v, lr, betas, eps, weight_decay, self.step)
+
+
+class _ConvBase:
+    transposed = False
+
+    def __init__(self, group: ParamGroup, name, cin, cout, k, stride=1, pad=0, dil=1, groups=1, transposed=False):
+        self.group, self.name = group, name
+        self.cin, self.cout, self.k = cin, cout, k
+        self.stride, self.pad, self.dil, self.groups = stride, pad, dil, groups
+        self.transposed = transposed
+        self.wshape = (cin, cout, k) if transposed else (cout, cin // groups, k)
+        self.i_bias = group.declare(name + ".bias", (cout,))
+        self._dw = None
+        self.frozen = False  # True: backward propagates to the input only (discriminators during the generator step)
+
+    def bias_data(self):
+        return self.group.data(self.i_bias)
+
+    def db_sink(self):
+        return self.group.gradient(self.i_bias)
+
+    def _shared_sink(self):
+        """Gradient wrt the EFFECTIVE weight accumulates here during backward; ``finish_grads`` maps it to the
+        stored parameters (g, v) or weight_orig."""
+        if self._dw is None:
+            self._dw = torch.zeros(self.wshape, device=self.group.device, dtype=torch.float32)
+        return self._dw
+
+
+class WNConv(_ConvBase):
+    """weight_norm(Conv1d / ConvTranspose1d): parameters weight_g [rows,1,1], weight_v [rows, ...], bias."""
+
+    def __init__(self, group, name, cin, cout, k, **kw):
+        super().__init__(group, name, cin, cout, k, **kw)
+        rows = self.wshape[0]
+        self.i_g = group.declare(name + ".weight_g", (rows, 1, 1))
+        self.i_v = group.declare(name + ".weight_v", self.wshape)
+        self._w = self._norm = None
+
+    def materialize(self):
+        """Recompute w = g * v / ||v|| from the current parameters (once per optimiser step)."""
+        self._w, self._norm = ops.weight_norm_fwd(self.group.data(self.i_g), self.group.data(self.i_v))
+
+    def effective(self, training=True):
+        """(effective weight, gradient sink) for one forward call."""
+        if self._w is None:
+            self.materialize()
+        return self._w, self._shared_sink()
+
+    def finish_grads(self):
+        if self._dw is None:
+            return
+        ops.weight_norm_bwd(self.group.data(self.i_g), self.group.data(self.i_v), self._norm, self._dw,
+                            self.group.gradient(self.i_g), self.group.gradient(self.i_v))
+        self._dw.zero_()
+
+
+class SNConv(_ConvBase):
+    """spectral_norm(Conv1d) as torch.nn.utils.spectral_norm: parameter weight_orig, buffers weight_u / weight_v;
+    in training mode every forward call runs one power iteration (and therefore sees its own sigma)."""
+
+    def __init__(self, group, name, cin, cout, k, **kw):
+        super().__init__(group, name, cin, cout, k, **kw)
+        self.i_w = group.declare(name + ".weight_orig", self.wshape)
+        h, wdt = self.wshape[0], math.prod(self.wshape[1:])
+        self.u = torch.zeros(h, device=group.device)
+        self.v = torch.zeros(wdt, device=group.device)
+        self._calls = []  # (sigma tensor [1], u, v, dw buffer) per forward call of this step
+
+    def materialize(self):
+        pass  # the effective weight depends on the power-iteration state: computed per forward call
+
+    def effective(self, training=True):
+        """One forward call: (one power iteration in training mode,) sigma = u^T W v, w = W / sigma."""
+        W = self.group.data(self.i_w)
+        h, wdt = self.wshape[0], math.prod(self.wshape[1:])
+        Wm = W.view(h, wdt)
+        if training:
+            tmp_v = torch.empty(wdt, device=W.device)
+            ops.gemm(Wm, self.u.view(h, 1), tmp_v.view(wdt, 1), ta=True)   # W^T u
+            ops.normalize_vec(tmp_v, self.v)
+            tmp_u = torch.empty(h, device=W.device)
+            ops.gemm(Wm, self.v.view(wdt, 1), tmp_u.view(h, 1))            # W v
+            ops.normalize_vec(tmp_u, self.u)
+        u, v = self.u.clone(), self.v.clone()
+        wv = torch.empty(h, device=W.device)
+        ops.gemm(Wm, v.view(wdt, 1), wv.view(h, 1))
+        sigma_t = torch.empty(1, device=W.device)
+        ops.row_reduce(1, u, wv, sigma_t, 1, h)                            # sigma = u . (W v)
+        sigma = float(sigma_t.item())
+        w = ops.elementwise(ops.EW_SCALE, W, p0=1.0 / sigma)
+        dw = torch.zeros(self.wshape, device=W.device)
+        self._calls.append((sigma, u, v, dw))
+        return w, dw
+
+    def finish_grads(self):
+        W = self.group.data(self.i_w)
+        gW = self.group.gradient(self.i_w)
+        h, wdt = self.wshape[0], math.prod(self.wshape[1:])
+        for sigma, u, v, dw in self._calls:
+            # d weight_orig += dw / sigma - (<dw, W> / sigma^2) u v^T
+            dot = torch.empty(1, device=W.device)
+            ops.scalar_reduce(2, ops.elementwise(ops.EW_MUL, dw, W), None, dot)
+            coef = -float(dot.item()) / (sigma * sigma)
+            ops.axpby(1.0, gW, 1.0 / sigma, dw, out=gW)
+            ops.gemm(u.view(h, 1), v.view(1, wdt), gW.view(h, wdt), alpha=coef, beta=1.0)
+        self._calls.clear()
+
+
+def kaiming_uniform_conv_init_(layer: _ConvBase, gen: torch.Generator, std: float | None = None):
+    """torch's default Conv1d init (kaiming_uniform a=sqrt(5)) or N(0, std) like upstream init_weights, expressed on
+    (g, v): v = w0, g = ||w0|| per row, so the effective weight starts as w0 exactly like torch's weight_norm."""
+    shape = layer.wshape
+    fan_in = (shape[1] if not layer.transposed else shape[0]) * shape[2] if not layer.transposed else shape[1] * shape[2]
+    bound = 1.0 / math.sqrt(fan_in)
+    if std is None:
+        w0 = (torch.rand(shape, generator=gen) * 2 - 1) * bound
+    else:
+        w0 = torch.randn(shape, generator=gen) * std
+    b0 = (torch.rand(layer.cout, generator=gen) * 2 - 1) * bound
+    g = layer.group
+    g.load(layer.name + ".bias", b0)
+    if isinstance(layer, WNConv):
+        g.load(layer.name + ".weight_v", w0)
+        g.load(layer.name + ".weight_g", w0.reshape(shape[0], -1).norm(dim=1).reshape(shape[0], 1, 1))
+    else:
+        g.load(layer.name + ".weight_orig", w0)
+        layer.u.copy_(torch.nn.functional.normalize(torch.randn(shape[0], generator=gen), dim=0))
+        layer.v.copy_(torch.nn.functional.normalize(torch.randn(math.prod(shape[1:]), generator=gen), dim=0))

@@ -112,7 +112,8 @@ def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1):
     return y
 
 
-def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=None, db_out=None, accumulate=False):
+def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=None, db_out=None, accumulate=False,
+               need_dw=True):
     """Returns (dx, dw, db); dw/db are written (or accumulated) into the given buffers when provided."""
     cin, B, t_in = x.shape
     cout, cin_g, k = w.shape
@@ -121,15 +122,16 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
     cout_g = cout // groups
     dym = dy.view(cout, N)
     wm = w.reshape(cout, cin_g * k)
-    dw = dw_out if dw_out is not None else torch.empty_like(w)
-    dwm = dw.view(cout, cin_g * k)
-    col, _ = unfold(x, k, stride, pad, dil)
-    beta = 1.0 if accumulate else 0.0
-    for g in range(groups):
-        gemm(dym[g * cout_g : (g + 1) * cout_g], col[g * cin_g * k : (g + 1) * cin_g * k], dwm[g * cout_g : (g + 1) * cout_g], tb=True, beta=beta)
-    db = None
-    if db_out is not None:
-        db = row_reduce(0, dy, None, db_out, cout, N, accumulate=accumulate)
+    dw = db = None
+    if need_dw:
+        dw = dw_out if dw_out is not None else torch.empty_like(w)
+        dwm = dw.view(cout, cin_g * k)
+        col, _ = unfold(x, k, stride, pad, dil)
+        beta = 1.0 if accumulate else 0.0
+        for g in range(groups):
+            gemm(dym[g * cout_g : (g + 1) * cout_g], col[g * cin_g * k : (g + 1) * cin_g * k], dwm[g * cout_g : (g + 1) * cout_g], tb=True, beta=beta)
+        if db_out is not None:
+            db = row_reduce(0, dy, None, db_out, cout, N, accumulate=accumulate)
     dx = None
     if need_dx:
         pointwise = k == 1 and stride == 1 and pad == 0

@@ -1,0 +1,155 @@
+"""One full GAN training step on the GPU vs the torch-CPU oracle (autograd + torch.optim.AdamW).
+
+fp32 on both sides; differences are summation order only.  Tolerances: losses rtol 2e-4; gradients are
+compared per tensor with max|diff| <= 2e-3 * max|grad| + 1e-7 (relative to the tensor's scale)."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import mel_ref
+from oracle.hifigan_ref import (GeneratorRef, MultiPeriodDiscriminatorRef, MultiScaleDiscriminatorRef,
+                                discriminator_loss_ref, feature_loss_ref, generator_loss_ref)
+
+pytestmark = pytest.mark.gpu
+
+
+def _params_close(name, got, want, grad, lr=2e-4):
+    """Updated parameters after one AdamW step.  The first step moves every element by lr * g / (|g| + eps), i.e.
+    by +-lr whatever |g| is, so an element whose gradient sits at rounding-noise level can legitimately move the
+    other way: compare where the oracle's gradient is clearly above noise, bound the rest by 2 * lr."""
+    diff = (got.reshape(want.shape) - want).abs()
+    assert float(diff.max()) <= 2.2 * lr, name
+    if grad is not None:
+        solid = grad.abs() > 1e-2 * grad.abs().max()
+        if solid.any():
+            assert float(diff[solid].max()) <= 5e-6, name
+
+
+def _grad_close(name, got, want, rel=2e-3):
+    scale = float(want.abs().max())
+    err = float((got.reshape(want.shape) - want).abs().max())
+    assert err <= rel * scale + 1e-7, f"{name}: err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.fixture(scope="module")
+def oracle_models():
+    torch.manual_seed(1234)
+    torch.set_num_threads(8)
+    g = GeneratorRef().train()
+    # livelier than the N(0, 0.01) init so every layer's gradient is well above rounding noise
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if n.endswith("weight_v"):
+                p.mul_(8.0)
+            if n.endswith("weight_g"):
+                p.mul_(8.0)
+    return g, MultiPeriodDiscriminatorRef().train(), MultiScaleDiscriminatorRef().train()
+
+
+def test_discriminators_forward_match(cuda_device, oracle_models):
+    from everyvoice_amd.train import autograd as ag
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    _, mpd0, msd0 = oracle_models
+    mpd, msd = MultiPeriodDiscriminatorRef().eval(), MultiScaleDiscriminatorRef().eval()  # eval: no power iteration
+    mpd.load_state_dict(mpd0.state_dict())
+    msd.load_state_dict(msd0.state_dict())
+    tr = HiFiGANTrainer(device=cuda_device)
+    tr.load_reference_state(None, mpd.state_dict(), msd.state_dict())
+    tr._materialize(tr.d_layers())
+    g = torch.Generator().manual_seed(9)
+    y = 0.3 * torch.tanh(torch.randn(2, 1, 2048, generator=g))
+    with torch.no_grad():
+        r_p, _, f_p, _ = mpd(y, y)
+        r_s, _, f_s, _ = msd(y, y)
+    logits, fmaps = tr._discriminate(ag.Tape(), ag.Var(y.reshape(1, 2, -1).to(cuda_device), needs_grad=False), training=False)
+    want_logits, want_fmaps = r_p + r_s, f_p + f_s
+    assert len(logits) == 8 and [len(f) for f in fmaps] == [6] * 5 + [8] * 3
+    for i, (lg, wl) in enumerate(zip(logits, want_logits)):
+        got = lg.data.cpu()
+        if i < 5:  # MPD: ours is [1, B*p, H]; torch flattens [B, 1, H, p]
+            p = tr.mpd[i].period
+            got = got.view(2, p, -1).permute(0, 2, 1).reshape(2, -1)
+        else:
+            got = got.view(2, -1)
+        _grad_close(f"logits[{i}]", got, wl, rel=5e-5)
+    for i in range(8):
+        for fm, wf in zip(fmaps[i], want_fmaps[i]):
+            got = fm.data.cpu()
+            if i < 5:
+                p = tr.mpd[i].period
+                C = got.shape[0]
+                got = got.view(C, 2, p, -1).permute(1, 0, 3, 2)  # -> [B, C, H, p]
+            else:
+                got = got.permute(1, 0, 2)
+            _grad_close(f"fmap[{i}]", got.contiguous(), wf, rel=2e-5)
+
+
+def test_full_gan_step_matches_oracle(cuda_device, oracle_models):
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g_ref, mpd_ref, msd_ref = GeneratorRef().train(), MultiPeriodDiscriminatorRef().train(), MultiScaleDiscriminatorRef().train()
+    for new, old in zip((g_ref, mpd_ref, msd_ref), oracle_models):  # weight-normed modules do not deepcopy
+        new.load_state_dict(old.state_dict())
+    opt_kw = dict(lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
+    tr = HiFiGANTrainer(device=cuda_device, **opt_kw)
+    tr.load_reference_state(g_ref.state_dict(), mpd_ref.state_dict(), msd_ref.state_dict())
+    tr.keep_grads = True
+
+    gen = torch.Generator().manual_seed(11)
+    B, S = 2, 2048
+    y = 0.3 * torch.tanh(torch.randn(B, 1, S, generator=gen))
+    mel = mel_ref.mel_spectrogram_ref(y.squeeze(1))[:, :, : S // 256]
+
+    # ---- oracle step (jik876 training loop order: D step, then G step) ----
+    opt_g = torch.optim.AdamW(g_ref.parameters(), **opt_kw)
+    opt_d = torch.optim.AdamW(list(mpd_ref.parameters()) + list(msd_ref.parameters()), **opt_kw)
+    y_hat = g_ref(mel)
+    opt_d.zero_grad()
+    r1, g1, _, _ = mpd_ref(y, y_hat.detach())
+    r2, g2, _, _ = msd_ref(y, y_hat.detach())
+    loss_d = discriminator_loss_ref(r1, g1) + discriminator_loss_ref(r2, g2)
+    loss_d.backward()
+    d_grads = {"mpd." + k: v.grad.clone() for k, v in mpd_ref.named_parameters()}
+    d_grads.update({"msd." + k: v.grad.clone() for k, v in msd_ref.named_parameters()})
+    opt_d.step()
+    opt_g.zero_grad()
+    lm_y = mel_ref.mel_spectrogram_ref(y.squeeze(1))
+    lm_g = mel_ref.mel_spectrogram_ref(y_hat.squeeze(1))
+    loss_mel = F.l1_loss(lm_y, lm_g) * 45
+    _, g1, fr1, fg1 = mpd_ref(y, y_hat)
+    _, g2, fr2, fg2 = msd_ref(y, y_hat)
+    loss_fm = feature_loss_ref(fr1, fg1) + feature_loss_ref(fr2, fg2)
+    loss_adv = generator_loss_ref(g1) + generator_loss_ref(g2)
+    (loss_adv + loss_fm + loss_mel).backward()
+    g_grads = {k: v.grad.clone() for k, v in g_ref.named_parameters()}
+    opt_g.step()
+
+    # ---- the same step on the GPU ----
+    out = tr.training_step(mel.to(cuda_device), y.to(cuda_device))
+    torch.testing.assert_close(tr.last_grads["y_hat"].cpu().view(B, 1, S), y_hat.detach(), rtol=1e-4, atol=1e-5)
+    assert out["d"] == pytest.approx(float(loss_d.detach()), rel=2e-4)
+    assert out["g_adv"] == pytest.approx(float(loss_adv.detach()), rel=2e-4)
+    assert out["g_fm"] == pytest.approx(float(loss_fm.detach()), rel=2e-4)
+    assert out["g_mel"] == pytest.approx(float(loss_mel.detach()), rel=2e-4)
+    for name, want in d_grads.items():
+        _grad_close(name, tr.last_grads["d"][name].cpu(), want)
+    for name, want in g_grads.items():
+        _grad_close(name, tr.last_grads["g"][name].cpu(), want)
+    # updated parameters after AdamW on both sides
+    sd_g = tr.g_params.state_dict()
+    for k, v in g_ref.state_dict().items():
+        _params_close(k, sd_g[k].cpu(), v, g_grads.get(k))
+    sd_d = tr.d_params.state_dict()
+    ref_d = {"mpd." + k: v for k, v in mpd_ref.state_dict().items()}
+    ref_d.update({"msd." + k: v for k, v in msd_ref.state_dict().items()})
+    for k, v in ref_d.items():
+        if k.endswith("weight_u") or k.endswith("weight_v") and "discriminators.0" in k and k.startswith("msd."):
+            continue  # spectral-norm buffers: checked below
+        if k in sd_d:
+            _params_close(k, sd_d[k].cpu(), v, d_grads.get(k))
+    # power-iteration state of the spectral-norm discriminator after the step's four forward calls
+    for i, conv in enumerate(tr.msd[0].layers()):
+        name = f"discriminators.0.convs.{i}" if i < 7 else "discriminators.0.conv_post"
+        torch.testing.assert_close(conv.u.cpu(), msd_ref.state_dict()[name + ".weight_u"], rtol=1e-3, atol=1e-5)
