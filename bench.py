@@ -51,6 +51,9 @@ def parse_args(argv=None):
     p.add_argument("--cpu-frames", type=int, default=64, help="mel frames per item of the CPU-baseline sample")
     p.add_argument("--cpu-batch", type=int, default=4)
     p.add_argument("--profile-passes", type=int, default=3)
+    p.add_argument("--no-train", action="store_true", help="skip the GAN-training leg (second half of the metric)")
+    p.add_argument("--train-steps", type=int, default=6)
+    p.add_argument("--train-warmup", type=int, default=2)
     return p.parse_args(argv)
 
 
@@ -187,6 +190,46 @@ def cpu_baseline(frames: int, batch: int) -> dict:
     }
 
 
+def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
+    """Second half of BASELINE.json's metric: HiFiGAN-V1 GAN training steps/s at bs 16 per GPU (config 4:
+    generator + MPD + MSD, LSGAN + feature matching + 45 x mel L1, two AdamW optimisers), data parallel with one
+    RCCL all-reduce per optimiser (discriminator 283 MB, generator 56 MB of fp32 gradients) when N > 1.
+    Synthetic segments y = 0.3 * tanh(N(0,1)) [16, 1, 8192] per rank (seed 1234 + rank), mel from the device
+    front-end.  fp32 (unfold + rocBLAS GEMM convolutions): the first, parity-checked version of this path."""
+    import torch
+
+    from everyvoice_amd.spectral import MelSpectrogram
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    B, S = 16, 8192
+    g = torch.Generator().manual_seed(1234 + rank)
+    y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(dev)
+    mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
+    trainer = HiFiGANTrainer(device=dev, process_group=True if use_dist else None)
+    losses = {}
+
+    def step():
+        losses.update(trainer.training_step(mel, y))
+
+    elapsed = timed_region(step, args.train_steps, args.train_warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    return {
+        "metric": "hifigan_v1_gan_train_steps_per_sec",
+        "value": round(args.train_steps / elapsed, 3),
+        "unit": "steps/s",
+        "ms_per_step": round(elapsed / args.train_steps * 1e3, 2),
+        "steps": args.train_steps,
+        "warmup": args.train_warmup,
+        "batch_per_gpu": B,
+        "global_batch": B * world,
+        "segment_samples": S,
+        "scaling": "weak",
+        "dtype": "f32",
+        "parallelism": f"dp{world}" + (" (RCCL all-reduce of 2 flat gradient buffers per step)" if world > 1 else ""),
+        "params": {"generator": trainer.g_params.numel(), "discriminators": trainer.d_params.numel()},
+        "last_losses": {k: round(v, 4) for k, v in losses.items()},
+    }
+
+
 def main(argv=None) -> int:
     args = parse_args(argv)
     import torch
@@ -232,6 +275,10 @@ def main(argv=None) -> int:
     elapsed = timed_region(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     value = world * samples_per_step * args.steps / elapsed
 
+    train = None
+    if not args.no_train:
+        train = train_leg(args, dev, rank, world, use_dist, barrier, max_reduce)
+
     result = None
     if rank == 0:
         passes = []
@@ -271,6 +318,8 @@ def main(argv=None) -> int:
             "realtime_factor": round(value / 22050.0, 1),
             "roofline": roof,
         }
+        if train is not None:
+            result["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_batch)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)

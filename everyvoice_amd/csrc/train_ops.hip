@@ -29,6 +29,21 @@ static int blas_handle(hipStream_t s, rocblas_handle* out) {
   return EVMI_OK;
 }
 
+// out[i] = beta * out[i] + sum_s part[s][i]   (split-K partial sums; out is [M][ldc], part is [S][M][N])
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int M, int N, int ldc, int S,
+                                     float beta) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx % N);
+  float acc = 0.f;
+  for (int sidx = 0; sidx < S; ++sidx) acc += part[(long long)sidx * M * N + idx];
+  float* o = out + (long long)m * ldc + n;
+  *o = beta == 0.f ? acc : beta * *o + acc;
+}
+
+static thread_local float* g_splitk_ws = nullptr;
+static thread_local size_t g_splitk_cap = 0;
+
 // Row-major C[M][N] = alpha * op(A) . op(B) + beta * C;  op(A) is M x K, op(B) is K x N.
 // (row-major C is column-major C^T = op(B)^T . op(A)^T: operands swapped for rocBLAS)
 int gemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
@@ -36,6 +51,39 @@ int gemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float* A, 
   rocblas_handle h;
   int rc = blas_handle(s, &h);
   if (rc) return rc;
+  // Weight-gradient shapes: a small [M][N] output reduced over a very long K (= batch * time).  A single GEMM
+  // puts that on a handful of workgroups; split K into equal slabs as a strided-batched GEMM and add the slabs.
+  if (K >= 8192 && (long long)M * N <= (1ll << 21)) {
+    int S = K / 4096;
+    if (S > 128) S = 128;
+    const int kc = K / S, tail = K - kc * S;
+    const int slabs = S + (tail ? 1 : 0);
+    const size_t need = (size_t)slabs * M * N;
+    if (need > g_splitk_cap) {
+      if (g_splitk_ws) (void)hipFree(g_splitk_ws);
+      g_splitk_ws = nullptr;
+      g_splitk_cap = 0;
+      EVMI_HIP_CHECK(hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
+      g_splitk_cap = need;
+    }
+    const float zero = 0.f;
+    const long long sa = ta ? (long long)kc * lda : kc;  // advance of op(A) along K
+    const long long sb = tb ? kc : (long long)kc * ldb;
+    rocblas_status st = rocblas_sgemm_strided_batched(
+        h, tb ? rocblas_operation_transpose : rocblas_operation_none, ta ? rocblas_operation_transpose : rocblas_operation_none,
+        N, M, kc, &alpha, B, ldb, sb, A, lda, sa, &zero, g_splitk_ws, N, (long long)M * N, S);
+    if (st != rocblas_status_success) return fail(EVMI_ERR_HIP, "rocblas_sgemm_strided_batched failed: " + std::to_string((int)st));
+    if (tail) {
+      st = rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
+                         ta ? rocblas_operation_transpose : rocblas_operation_none, N, M, tail, &alpha, B + sb * S, ldb,
+                         A + sa * S, lda, &zero, g_splitk_ws + (size_t)S * M * N, N);
+      if (st != rocblas_status_success) return fail(EVMI_ERR_HIP, "rocblas_sgemm (split-K tail) failed");
+    }
+    const long long n = (long long)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g_splitk_ws, C, M, N, ldc, slabs, beta);
+    EVMI_LAUNCH_CHECK("splitk_reduce");
+    return EVMI_OK;
+  }
   const rocblas_status st = rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
                                           ta ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &alpha, B,
                                           ldb, A, lda, &beta, C, ldc);
@@ -137,24 +185,33 @@ __global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__
 }
 
 // deterministic scalar reductions: out[0] (+)= scale * sum f;  MODE 0: |a-b| ; 1: (a-p)^2 ; 2: a
+// two fixed-shape passes (grid of partial sums in double, then one workgroup): bitwise reproducible
 template <int MODE>
-__global__ __launch_bounds__(1024) void scalar_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                             float* __restrict__ out, long long n, float scale, float p,
-                                                             int accumulate) {
-  __shared__ double part[16];
-  double acc = 0.0;  // one workgroup, fixed order: bitwise reproducible
-  for (long long i = threadIdx.x; i < n; i += 1024) {
+__global__ __launch_bounds__(256) void scalar_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                             double* __restrict__ part, long long n, float p) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float av = a[i];
     acc += MODE == 0 ? (double)fabsf(av - b[i]) : (MODE == 1 ? (double)((av - p) * (av - p)) : (double)av);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+__global__ __launch_bounds__(256) void scalar_final_kernel(const double* __restrict__ part, int n_part, float* __restrict__ out,
+                                                           float scale, int accumulate) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n_part; i += 256) acc += part[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int i = 0; i < 16; ++i) t += part[i];
-    const float r = (float)(t * scale);
+    const float r = (float)((sh[0] + sh[1] + sh[2] + sh[3]) * scale);
     out[0] = accumulate ? out[0] + r : r;
   }
 }
@@ -398,16 +455,24 @@ int evmi_elementwise_f32(int op, const float* a_dev, const float* b_dev, const f
   return EVMI_OK;
 }
 
-/* out[0] (+)= scale * sum f;  mode 0: |a-b|, 1: (a-p)^2, 2: a   (single workgroup, fixed order: reproducible) */
+/* out[0] (+)= scale * sum f;  mode 0: |a-b|, 1: (a-p)^2, 2: a   (fixed-shape two-pass reduction: reproducible) */
 int evmi_scalar_reduce_f32(int mode, const float* a_dev, const float* b_dev, float* out_dev, long long n, float scale,
                            float p, int accumulate, void* stream) {
   EVMI_NONNULL(a_dev && out_dev, "scalar_reduce");
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 0) hipLaunchKernelGGL(scalar_reduce_kernel<0>, dim3(1), dim3(1024), 0, s, a_dev, b_dev, out_dev, n, scale, p, accumulate);
-  else if (mode == 1) hipLaunchKernelGGL(scalar_reduce_kernel<1>, dim3(1), dim3(1024), 0, s, a_dev, b_dev, out_dev, n, scale, p, accumulate);
-  else if (mode == 2) hipLaunchKernelGGL(scalar_reduce_kernel<2>, dim3(1), dim3(1024), 0, s, a_dev, b_dev, out_dev, n, scale, p, accumulate);
+  static thread_local double* part = nullptr;
+  constexpr int MAXB = 1024;
+  if (!part) EVMI_HIP_CHECK(hipMalloc((void**)&part, MAXB * sizeof(double)));
+  int nb = (int)((n + 256 * 8 - 1) / (256 * 8));
+  if (nb < 1) nb = 1;
+  if (nb > MAXB) nb = MAXB;
+  if (mode == 0) hipLaunchKernelGGL(scalar_partial_kernel<0>, dim3(nb), dim3(256), 0, s, a_dev, b_dev, part, n, p);
+  else if (mode == 1) hipLaunchKernelGGL(scalar_partial_kernel<1>, dim3(nb), dim3(256), 0, s, a_dev, b_dev, part, n, p);
+  else if (mode == 2) hipLaunchKernelGGL(scalar_partial_kernel<2>, dim3(nb), dim3(256), 0, s, a_dev, b_dev, part, n, p);
   else return fail(EVMI_ERR_INVALID_ARG, "scalar_reduce: mode");
-  EVMI_LAUNCH_CHECK("scalar_reduce");
+  EVMI_LAUNCH_CHECK("scalar_partial");
+  hipLaunchKernelGGL(scalar_final_kernel, dim3(1), dim3(256), 0, s, part, nb, out_dev, scale, accumulate);
+  EVMI_LAUNCH_CHECK("scalar_final");
   return EVMI_OK;
 }
 

@@ -171,6 +171,15 @@ class MelLoss:
         return ops.stft_frames_bwd(dfr, B, T, self.n_fft, self.hop)
 
 
+def allreduce_mean_(flat_grad: torch.Tensor, process_group, scale_fn) -> torch.Tensor:
+    """flat_grad <- mean over ranks (sum all-reduce, then ``scale_fn(flat_grad, 1 / world)``)."""
+    import torch.distributed as dist
+
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group)
+    scale_fn(flat_grad, 1.0 / dist.get_world_size(process_group))
+    return flat_grad
+
+
 class HiFiGANTrainer:
     """Generator + MPD + MSD with two AdamW optimisers; ``training_step`` is one full GAN step."""
 
@@ -230,11 +239,11 @@ class HiFiGANTrainer:
             layer.materialize()
 
     def _allreduce(self, group: ParamGroup):
+        """Data-parallel exchange: ONE all-reduce (RCCL over xGMI under backend "nccl") of the optimiser's flat
+        gradient buffer, then the 1/world scaling — discriminator side and generator side separately."""
         if self.pg is not None:
-            import torch.distributed as dist
-
-            dist.all_reduce(group.grad, group=self.pg if self.pg is not True else None)
-            ops.elementwise(ops.EW_SCALE, group.grad, out=group.grad, p0=1.0 / dist.get_world_size())
+            allreduce_mean_(group.grad, self.pg if self.pg is not True else None,
+                            lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
 
     # -- discriminators on one waveform ----------------------------------------------------------------------
     def _discriminate(self, tape, audio: ag.Var, training=True):

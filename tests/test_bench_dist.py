@@ -56,6 +56,26 @@ def test_two_rank_timing_and_aggregation(tmp_path):
     assert abs(r[0]["value"] - 2 * 1000 * 5 / r[0]["elapsed"]) < 1e-6  # whole-job aggregate, not per-GPU
 
 
+def _allreduce_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from everyvoice_amd.train.hifigan import allreduce_mean_
+
+    flat = torch.arange(10, dtype=torch.float32) * (rank + 1)  # the optimiser's flat gradient buffer of this rank
+    allreduce_mean_(flat, None, lambda t, s: t.mul_(s))        # CPU stand-in for the device scaling kernel
+    torch.save(flat, Path(out_dir, f"g{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_is_a_mean_over_ranks(tmp_path):
+    """The data-parallel exchange of the training step (one all-reduce per optimiser's flat gradient buffer)."""
+    world = 2
+    mp.spawn(_allreduce_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = (torch.load(Path(tmp_path, f"g{i}.pt")) for i in range(world))
+    want = torch.arange(10, dtype=torch.float32) * 1.5
+    assert torch.equal(g0, g1) and torch.allclose(g0, want)
+
+
 def test_dist_env_and_roofline_aggregation(monkeypatch):
     monkeypatch.setenv("RANK", "3")
     monkeypatch.setenv("LOCAL_RANK", "1")

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Time the GAN training step (BASELINE config 4: bs 16, 8192-sample segments) on one GPU."""
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+import torch  # noqa: E402
+
+from everyvoice_amd.spectral import MelSpectrogram  # noqa: E402
+from everyvoice_amd.train.hifigan import HiFiGANTrainer  # noqa: E402
+
+dev = torch.device("cuda:0")
+B, S = 16, 8192
+g = torch.Generator().manual_seed(1234)
+y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(dev)
+mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
+tr = HiFiGANTrainer(device=dev)
+for i in range(2):
+    out = tr.training_step(mel, y)
+torch.cuda.synchronize()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+t0 = time.perf_counter()
+for i in range(n):
+    out = tr.training_step(mel, y)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / n
+print(f"step {dt*1e3:.1f} ms -> {1/dt:.2f} steps/s; losses {out}")
+print(f"G params {tr.g_params.numel():,}  D params {tr.d_params.numel():,}")
