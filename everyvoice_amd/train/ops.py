@@ -52,6 +52,13 @@ def gemm(a, b, out, ta=False, tb=False, alpha=1.0, beta=0.0, M=None, N=None, K=N
     return out
 
 
+def gemm_groups(a, b, out, groups, M, N, K, lda, ldb, ldc, sa, sb, sc, ta=False, tb=False, alpha=1.0, beta=0.0):
+    """``groups`` independent GEMMs at fixed element strides (one per convolution group)."""
+    _chk(_lib.load().evmi_gemm_batched_f32(int(ta), int(tb), M, N, K, alpha, a.data_ptr(), lda, sa, b.data_ptr(), ldb, sb, beta,
+                                           out.data_ptr(), ldc, sc, groups, _s(out)), "evmi_gemm_batched_f32")
+    return out
+
+
 def conv_out_len(t_in, k, stride, pad, dil):
     return (t_in + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -104,9 +111,9 @@ def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1):
     y = torch.empty(cout, B, t_out, device=x.device, dtype=torch.float32)
     N = B * t_out
     cout_g = cout // groups
-    wm = w.reshape(cout, cin_g * k)
-    for g in range(groups):
-        gemm(wm[g * cout_g : (g + 1) * cout_g], col[g * cin_g * k : (g + 1) * cin_g * k], y.view(cout, N)[g * cout_g : (g + 1) * cout_g])
+    kg = cin_g * k
+    # Y_g [cout_g, N] = W_g [cout_g, kg] . col_g [kg, N]
+    gemm_groups(w, col, y, groups, cout_g, N, kg, kg, N, N, cout_g * kg, kg * N, cout_g * N)
     if bias is not None:
         _chk(_lib.load().evmi_bias_add_rows_f32(y.data_ptr(), bias.data_ptr(), cout, N, _s(y)), "evmi_bias_add_rows_f32")
     return y
@@ -128,8 +135,9 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
         dwm = dw.view(cout, cin_g * k)
         col, _ = unfold(x, k, stride, pad, dil)
         beta = 1.0 if accumulate else 0.0
-        for g in range(groups):
-            gemm(dym[g * cout_g : (g + 1) * cout_g], col[g * cin_g * k : (g + 1) * cin_g * k], dwm[g * cout_g : (g + 1) * cout_g], tb=True, beta=beta)
+        kg = cin_g * k
+        # dW_g [cout_g, kg] (+)= dY_g [cout_g, N] . col_g^T
+        gemm_groups(dy, col, dw, groups, cout_g, kg, N, N, N, kg, cout_g * N, kg * N, cout_g * kg, tb=True, beta=beta)
         if db_out is not None:
             db = row_reduce(0, dy, None, db_out, cout, N, accumulate=accumulate)
     dx = None
@@ -137,8 +145,9 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
         pointwise = k == 1 and stride == 1 and pad == 0
         dcol = (torch.empty(cin, B * t_in, device=x.device, dtype=torch.float32) if pointwise
                 else WS.get("dcol", cin * k * N, x.device).view(cin * k, N))
-        for g in range(groups):
-            gemm(wm[g * cout_g : (g + 1) * cout_g], dym[g * cout_g : (g + 1) * cout_g], dcol[g * cin_g * k : (g + 1) * cin_g * k], ta=True)
+        kg = cin_g * k
+        # dcol_g [kg, N] = W_g^T . dY_g
+        gemm_groups(w, dy, dcol, groups, kg, N, cout_g, kg, N, N, cout_g * kg, cout_g * N, kg * N, ta=True)
         dx = dcol.view(cin, B, t_in) if pointwise else fold(dcol, cin, B, t_in, t_out, k, stride, pad, dil)
     return dx, dw, db
 

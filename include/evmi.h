@@ -203,6 +203,11 @@ double evmi_generator_macs_per_sample(const evmi_generator* g);
 int evmi_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* a_dev,
                   int lda, const float* b_dev, int ldb, float beta, float* c_dev, int ldc,
                   void* stream);
+/* `batch` such GEMMs at fixed element strides (the groups of a grouped convolution). */
+int evmi_gemm_batched_f32(int trans_a, int trans_b, int M, int N, int K, float alpha,
+                          const float* a_dev, int lda, long long stride_a, const float* b_dev, int ldb,
+                          long long stride_b, float beta, float* c_dev, int ldc, long long stride_c,
+                          int batch, void* stream);
 /* col[(c*k + j)][b][to] = x[c][b][to*stride + j*dil - pad] (0 outside);  fold is its adjoint. */
 int evmi_unfold_cbt_f32(const float* x_dev, float* col_dev, int C, int B, int t_in, int t_out, int k,
                         int stride, int pad, int dil, void* stream);
