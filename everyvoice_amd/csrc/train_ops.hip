@@ -114,8 +114,43 @@ int gemm_rm_batched(bool ta, bool tb, int M, int N, int K, float alpha, const fl
 
 // ---- unfold / fold ------------------------------------------------------------------------------------
 // col[(c*k + j)][b][to] = x[c][b][to*stride + j*dil - pad]  (0 outside)
-__global__ void unfold_cbt_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int t_in, int t_out, int k,
-                                  int stride, int pad, int dil, long long n) {
+// grid (T_out tiles, B, C*k): the row decomposition is per workgroup (scalar), threads walk contiguous `to`
+__global__ __launch_bounds__(256) void unfold_cbt_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int t_in,
+                                                         int t_out, int k, int stride, int pad, int dil) {
+  const int row = blockIdx.z, b = blockIdx.y;
+  const int c = row / k, j = row - c * k;
+  const float* xr = x + ((long long)c * B + b) * t_in;
+  float* cr = col + ((long long)row * B + b) * t_out;
+  const int off = j * dil - pad;
+  for (int to = blockIdx.x * 1024 + threadIdx.x; to < min(t_out, (int)(blockIdx.x + 1) * 1024); to += 256) {
+    const int ti = to * stride + off;
+    cr[to] = (ti >= 0 && ti < t_in) ? xr[ti] : 0.f;
+  }
+}
+
+// dx[c][b][ti] = sum_j dcol[(c*k + j)][b][(ti + pad - j*dil) / stride]   (terms that divide evenly and are in range)
+__global__ __launch_bounds__(256) void fold_cbt_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int t_in,
+                                                       int t_out, int k, int stride, int pad, int dil, int accumulate) {
+  const int c = blockIdx.z, b = blockIdx.y;
+  float* xr = dx + ((long long)c * B + b) * t_in;
+  const float* cbase = dcol + ((long long)c * k * B + b) * t_out;
+  const long long jstride = (long long)B * t_out;
+  for (int ti = blockIdx.x * 1024 + threadIdx.x; ti < min(t_in, (int)(blockIdx.x + 1) * 1024); ti += 256) {
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) {
+      const int num = ti + pad - j * dil;
+      if (num < 0) break;  // num only decreases with j
+      if (stride > 1 && num % stride) continue;
+      const int to = stride > 1 ? num / stride : num;
+      if (to < t_out) acc += cbase[j * jstride + to];
+    }
+    xr[ti] = accumulate ? xr[ti] + acc : acc;
+  }
+}
+
+// flat variants (one element per thread) for short rows, where a per-row grid would be mostly empty workgroups
+__global__ void unfold_cbt_flat_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int t_in, int t_out, int k,
+                                       int stride, int pad, int dil, long long n) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   const int to = (int)(idx % t_out);
@@ -127,10 +162,8 @@ __global__ void unfold_cbt_kernel(const float* __restrict__ x, float* __restrict
   const int ti = to * stride + j * dil - pad;
   col[idx] = (ti >= 0 && ti < t_in) ? x[(c * B + b) * t_in + ti] : 0.f;
 }
-
-// dx[c][b][ti] = sum_j dcol[(c*k + j)][b][(ti + pad - j*dil) / stride]   (terms that divide evenly and are in range)
-__global__ void fold_cbt_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int t_in, int t_out, int k,
-                                int stride, int pad, int dil, long long n, int accumulate) {
+__global__ void fold_cbt_flat_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int t_in, int t_out, int k,
+                                     int stride, int pad, int dil, long long n, int accumulate) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n) return;
   const int ti = (int)(idx % t_in);
@@ -140,7 +173,8 @@ __global__ void fold_cbt_kernel(const float* __restrict__ dcol, float* __restric
   float acc = 0.f;
   for (int j = 0; j < k; ++j) {
     const int num = ti + pad - j * dil;
-    if (num < 0 || num % stride) continue;
+    if (num < 0) break;
+    if (num % stride) continue;
     const int to = num / stride;
     if (to < t_out) acc += dcol[((c * k + j) * B + b) * t_out + to];
   }
@@ -435,8 +469,14 @@ int evmi_gemm_batched_f32(int trans_a, int trans_b, int M, int N, int K, float a
 int evmi_unfold_cbt_f32(const float* x_dev, float* col_dev, int C, int B, int t_in, int t_out, int k, int stride, int pad,
                         int dil, void* stream) {
   EVMI_NONNULL(x_dev && col_dev, "unfold_cbt");
-  const long long n = (long long)C * k * B * t_out;
-  hipLaunchKernelGGL(unfold_cbt_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x_dev, col_dev, B, t_in, t_out, k, stride, pad, dil, n);
+  if (t_out >= 512 && (long long)C * k <= 65535 && B <= 65535) {
+    hipLaunchKernelGGL(unfold_cbt_kernel, dim3((t_out + 1023) / 1024, B, C * k), dim3(256), 0, (hipStream_t)stream, x_dev, col_dev,
+                       B, t_in, t_out, k, stride, pad, dil);
+  } else {
+    const long long n = (long long)C * k * B * t_out;
+    hipLaunchKernelGGL(unfold_cbt_flat_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, x_dev, col_dev, B, t_in, t_out, k,
+                       stride, pad, dil, n);
+  }
   EVMI_LAUNCH_CHECK("unfold_cbt");
   return EVMI_OK;
 }
@@ -444,8 +484,14 @@ int evmi_unfold_cbt_f32(const float* x_dev, float* col_dev, int C, int B, int t_
 int evmi_fold_cbt_f32(const float* dcol_dev, float* dx_dev, int C, int B, int t_in, int t_out, int k, int stride, int pad,
                       int dil, int accumulate, void* stream) {
   EVMI_NONNULL(dcol_dev && dx_dev, "fold_cbt");
-  const long long n = (long long)C * B * t_in;
-  hipLaunchKernelGGL(fold_cbt_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, dcol_dev, dx_dev, B, t_in, t_out, k, stride, pad, dil, n, accumulate);
+  if (t_in >= 512 && C <= 65535 && B <= 65535) {
+    hipLaunchKernelGGL(fold_cbt_kernel, dim3((t_in + 1023) / 1024, B, C), dim3(256), 0, (hipStream_t)stream, dcol_dev, dx_dev, B,
+                       t_in, t_out, k, stride, pad, dil, accumulate);
+  } else {
+    const long long n = (long long)C * B * t_in;
+    hipLaunchKernelGGL(fold_cbt_flat_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, dcol_dev, dx_dev, B, t_in, t_out, k,
+                       stride, pad, dil, n, accumulate);
+  }
   EVMI_LAUNCH_CHECK("fold_cbt");
   return EVMI_OK;
 }
