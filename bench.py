@@ -48,8 +48,8 @@ def parse_args(argv=None):
     p.add_argument("--frames", type=int, default=T_FRAMES)
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-frames", type=int, default=64, help="mel frames per item of the CPU-baseline sample")
-    p.add_argument("--cpu-batch", type=int, default=4)
+    p.add_argument("--cpu-frames", type=int, default=768, help="mel frames per item of the CPU-baseline sample")
+    p.add_argument("--cpu-batch", type=int, default=16, help="items of the bench batch the CPU baseline runs (10-20 s of CPU work)")
     p.add_argument("--profile-passes", type=int, default=3)
     p.add_argument("--no-train", action="store_true", help="skip the GAN-training leg (second half of the metric)")
     p.add_argument("--train-steps", type=int, default=6)
