@@ -53,6 +53,9 @@ struct Variant {
   X("c128k11_bn256_noX", 128, 64, 128, 256, 2, 4, 11, 1, 5, 2)     \
   X("c128k11_bn256_noA", 128, 64, 128, 256, 2, 4, 11, 1, 5, 1)     \
   X("c128k11_bn256_noMfma", 128, 64, 128, 256, 2, 4, 11, 1, 5, 8)  \
+  X("c128k11_bn256_prio", 128, 64, 128, 256, 2, 4, 11, 1, 5, 32)   \
+  X("c256k11_bn256_prio", 256, 64, 128, 256, 2, 4, 11, 1, 5, 32)   \
+  X("c128k3_bn256_prio", 128, 64, 128, 256, 2, 4, 3, 1, 5, 32)     \
   X("c128k7_bn256", 128, 64, 128, 256, 2, 4, 7, 1, 5, 0)           \
   X("c128k3_bn256", 128, 64, 128, 256, 2, 4, 3, 1, 5, 0)           \
   X("c128k3_bn512", 128, 64, 128, 512, 2, 8, 3, 1, 5, 0)           \

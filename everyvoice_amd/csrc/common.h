@@ -55,7 +55,7 @@ __device__ __forceinline__ void lds_barrier() {
 // compiler otherwise issues the ds_reads of step k+1 only after the last MFMA of step k).
 //   Arow: this lane's A row (tap 0, m-tile 0) + (lane>>5)*8;  A tap stride / m-tile stride in elements
 //   Brow: this lane's B row (tap 0, n-tile 0) + (lane>>5)*8;  b_tap_stride = dilation * row stride
-template <int MT, int NT, int KSTEPS, int NTAPS, int A_TAP_STRIDE, int A_MT_STRIDE, int B_NT_STRIDE>
+template <int MT, int NT, int KSTEPS, int NTAPS, int A_TAP_STRIDE, int A_MT_STRIDE, int B_NT_STRIDE, int PRIO = 0>
 __device__ __forceinline__ void mma_tap_group(const bf16_t* __restrict__ Arow, const bf16_t* __restrict__ Brow,
                                               int b_tap_stride, f32x16 (&acc)[MT][NT]) {
   constexpr int N = NTAPS * KSTEPS;
@@ -74,11 +74,13 @@ __device__ __forceinline__ void mma_tap_group(const bf16_t* __restrict__ Arow, c
   for (int kk = 0; kk < N; ++kk) {
     const int cur = kk & 1;
     if (kk + 1 < N) load(kk + 1, cur ^ 1);
+    if (PRIO) __builtin_amdgcn_s_setprio(1);  // favour the wave that has its operands over the one issuing loads
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][mt], bfr[cur][nt], acc[mt][nt], 0, 0, 0);
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
   }
 }
 

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
         const bf16_t* Arow = Ab + (wm * C::MT * 32 + (lane & 31)) * C::AS + (lane >> 5) * 8;
         const bf16_t* Brow = Xs + (wn * C::NT * 32 + (lane & 31) + grp * C::TAPS * a.dil) * C::XS + (lane >> 5) * 8;
         if (!(C::ABL & 8))
-          mma_tap_group<C::MT, C::NT, C::KC / 16, C::TAPS, C::BM * C::AS, 32 * C::AS, 32 * C::XS>(
+          mma_tap_group<C::MT, C::NT, C::KC / 16, C::TAPS, C::BM * C::AS, 32 * C::AS, 32 * C::XS, (C::ABL >> 5) & 1>(
               Arow, Brow, a.dil * C::XS, acc);
         else
           acc[0][0][0] += (float)Arow[0] * (float)Brow[0];
