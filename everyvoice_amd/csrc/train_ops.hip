@@ -181,6 +181,23 @@ __global__ void fold_cbt_flat_kernel(const float* __restrict__ dcol, float* __re
   dx[idx] = accumulate ? dx[idx] + acc : acc;
 }
 
+// Weights of the convolution that computes an input gradient.  For phase `phi` of a stride-s convolution
+// (stride 1: the single phase 0) with taps j = phi + s*m, m < M:
+//   wt[g*cin_g + ci][co_l][m'] = w[g*cout_g + co_l][ci][phi + s*(M - 1 - m')]
+// so that dx_phi = conv1d(dy, wt, groups) (see everyvoice_amd/train/ops.py: conv1d_bwd_data_mfma).
+__global__ void dgrad_weights_kernel(const float* __restrict__ w, float* __restrict__ wt, int cin_g, int cout_g, int k,
+                                     int stride, int phi, int M, long long n) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const int mp = (int)(idx % M);
+  long long r = idx / M;
+  const int co_l = (int)(r % cout_g);
+  const long long ci_all = r / cout_g;  // g*cin_g + ci
+  const int g = (int)(ci_all / cin_g), ci = (int)(ci_all % cin_g);
+  const int j = phi + stride * (M - 1 - mp);
+  wt[idx] = w[((long long)(g * cout_g + co_l) * cin_g + ci) * k + j];
+}
+
 // ---- row-wise helpers on [R][N] matrices ---------------------------------------------------------------
 __global__ void bias_add_rows_kernel(float* __restrict__ y, const float* __restrict__ bias, long long N, long long n) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -464,6 +481,18 @@ int evmi_gemm_batched_f32(int trans_a, int trans_b, int M, int N, int K, float a
   if (M <= 0 || N <= 0 || K <= 0 || batch <= 0) return fail(EVMI_ERR_INVALID_ARG, "gemm_batched_f32: empty problem");
   return gemm_rm_batched(trans_a != 0, trans_b != 0, M, N, K, alpha, a_dev, lda, stride_a, b_dev, ldb, stride_b, beta, c_dev, ldc,
                          stride_c, batch, (hipStream_t)stream);
+}
+
+int evmi_dgrad_weights_f32(const float* w_dev, float* wt_dev, int c_in, int c_out, int k, int groups, int stride, int phi,
+                           void* stream) {
+  EVMI_NONNULL(w_dev && wt_dev, "dgrad_weights");
+  if (phi < 0 || phi >= stride || phi >= k) return fail(EVMI_ERR_INVALID_ARG, "dgrad_weights: phase");
+  const int M = (k - phi + stride - 1) / stride;
+  const long long n = (long long)c_in * (c_out / groups) * M;
+  hipLaunchKernelGGL(dgrad_weights_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, w_dev, wt_dev, c_in / groups, c_out / groups, k,
+                     stride, phi, M, n);
+  EVMI_LAUNCH_CHECK("dgrad_weights");
+  return EVMI_OK;
 }
 
 int evmi_unfold_cbt_f32(const float* x_dev, float* col_dev, int C, int B, int t_in, int t_out, int k, int stride, int pad,

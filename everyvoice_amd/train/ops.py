@@ -103,8 +103,57 @@ def scalar_reduce(mode, a, b, out, scale=1.0, p=0.0, accumulate=False):
 
 
 # ---- convolutions ---------------------------------------------------------------------------------------
+def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=None, out_stride=1, out_offset=0,
+                accumulate=False):
+    """fp32 matrix-core implicit GEMM (evmi_conv1d_cbt_f32): x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out]."""
+    cin, B, t_in = x.shape
+    cout, cin_g, k = w.shape
+    t_conv = conv_out_len(t_in, k, stride, pad, dil)
+    if out is None:
+        out = torch.empty(cout, B, t_conv, device=x.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_conv1d_cbt_f32(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), B, cin, t_in, cout,
+                                         out.shape[2], t_conv if n_out is None else n_out, k, stride, pad, dil, groups,
+                                         out_stride, out_offset, int(accumulate), _s(x)), "evmi_conv1d_cbt_f32")
+    return out
+
+
+
+def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
+    """Input gradient of conv1d on the fp32 matrix cores: `stride` polyphase stride-1 convolutions of dy with
+    re-indexed weights, each writing its own residue class of dx (strided layers all have dilation 1)."""
+    cout, B, t_out = dy.shape
+    _, cin_g, k = w.shape
+    cin = cin_g * groups
+    lib = _lib.load()
+    if stride == 1:
+        wt = WS.get("wt", cin * (cout // groups) * k, dy.device)
+        _chk(lib.evmi_dgrad_weights_f32(w.data_ptr(), wt.data_ptr(), cin, cout, k, groups, 1, 0, _s(dy)), "evmi_dgrad_weights_f32")
+        dx = torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
+        return conv1d_mfma(dy, wt.view(cin, cout // groups, k), None, 1, dil * (k - 1) - pad, dil, groups, out=dx, n_out=t_in)
+    assert dil == 1, "strided convolutions of this model are not dilated"
+    dx = torch.zeros(cin, B, t_in, device=dy.device, dtype=torch.float32)
+    for phi in range(min(stride, k)):
+        M = (k - phi + stride - 1) // stride
+        q0 = max(0, -((phi - pad) // stride))          # first q with stride*q + phi - pad >= 0
+        q_hi = (t_in - 1 + pad - phi) // stride         # last q with stride*q + phi - pad <= t_in - 1
+        n_out = q_hi - q0 + 1
+        if n_out <= 0:
+            continue
+        wt = WS.get("wt", cin * (cout // groups) * M, dy.device)
+        _chk(lib.evmi_dgrad_weights_f32(w.data_ptr(), wt.data_ptr(), cin, cout, k, groups, stride, phi, _s(dy)), "evmi_dgrad_weights_f32")
+        # dx[stride*q + phi - pad] = sum_m' wt[m'] * dy[q - (M-1) + m'],  q = q0 + to
+        conv1d_mfma(dy, wt.view(cin, cout // groups, M), None, 1, (M - 1) - q0, 1, groups, out=dx, n_out=n_out,
+                    out_stride=stride, out_offset=stride * q0 + phi - pad)
+    return dx
+
+
+CONV_BACKEND = {"fwd": "gemm", "dgrad": "gemm"}  # "mfma": implicit GEMM on the fp32 matrix cores (conv_cbt_f32_mfma.hip)
+
+
 def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1):
     """x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out]."""
+    if CONV_BACKEND["fwd"] == "mfma":
+        return conv1d_mfma(x, w, bias, stride, pad, dil, groups)
     cin, B, t_in = x.shape
     cout, cin_g, k = w.shape
     col, t_out = unfold(x, k, stride, pad, dil)
@@ -141,7 +190,9 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
         if db_out is not None:
             db = row_reduce(0, dy, None, db_out, cout, N, accumulate=accumulate)
     dx = None
-    if need_dx:
+    if need_dx and CONV_BACKEND["dgrad"] == "mfma":
+        dx = conv1d_bwd_data_mfma(dy, w, t_in, stride, pad, dil, groups)
+    elif need_dx:
         pointwise = k == 1 and stride == 1 and pad == 0
         dcol = (torch.empty(cin, B * t_in, device=x.device, dtype=torch.float32) if pointwise
                 else WS.get("dcol", cin * k * N, x.device).view(cin * k, N))

@@ -203,6 +203,19 @@ double evmi_generator_macs_per_sample(const evmi_generator* g);
 int evmi_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* a_dev,
                   int lda, const float* b_dev, int ldb, float beta, float* c_dev, int ldc,
                   void* stream);
+/* fp32 implicit-GEMM convolution on the fp32-input matrix cores (no unfold, no library GEMM):
+ *   y[co][b][to*out_stride + out_offset] (+)= bias[co] + conv(x, w)[co][b][to]   for to < n_out
+ * x [c_in][B][t_in], w [c_out][c_in/groups][k], y [c_out][B][t_out_total]; out_stride 1 / offset 0 /
+ * n_out = t_out_total is the plain convolution, other values place a polyphase component of a strided
+ * convolution's input gradient. */
+int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int B,
+                        int c_in, int t_in, int c_out, int t_out_total, int n_out, int k, int stride,
+                        int pad, int dil, int groups, int out_stride, int out_offset, int accumulate,
+                        void* stream);
+/* Weights of the stride-1 convolution that yields phase `phi` of a convolution's input gradient:
+ * wt[c_in][c_out/groups][M], M = ceil((k - phi) / stride), wt[g*cin_g+ci][co][m] = w[g*cout_g+co][ci][phi + stride*(M-1-m)]. */
+int evmi_dgrad_weights_f32(const float* w_dev, float* wt_dev, int c_in, int c_out, int k, int groups,
+                           int stride, int phi, void* stream);
 /* `batch` such GEMMs at fixed element strides (the groups of a grouped convolution). */
 int evmi_gemm_batched_f32(int trans_a, int trans_b, int M, int N, int K, float alpha,
                           const float* a_dev, int lda, long long stride_a, const float* b_dev, int ldb,

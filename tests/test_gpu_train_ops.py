@@ -53,6 +53,39 @@ def test_conv1d_fwd_bwd(cuda_device, c):
     torch.testing.assert_close(dbuf.cpu(), 2 * b.grad, rtol=1e-4, atol=2e-4)
 
 
+MFMA_CONVS = CONVS + [
+    dict(cin=128, cout=128, k=11, stride=1, pad=25, dil=5, groups=1),   # generator resblock shape
+    dict(cin=40, cout=100, k=7, stride=1, pad=3, dil=1, groups=1),      # partial M tile, channels not a multiple of 16
+    dict(cin=128, cout=256, k=41, stride=2, pad=20, dil=1, groups=16),  # MSD layer 2
+    dict(cin=32, cout=128, k=5, stride=3, pad=2, dil=1, groups=1),      # MPD layer 1
+    dict(cin=64, cout=1, k=3, stride=1, pad=1, dil=1, groups=1),        # conv_post of a discriminator
+]
+
+
+@pytest.mark.parametrize("c", MFMA_CONVS)
+@pytest.mark.parametrize("T", [101, 700])
+def test_conv1d_mfma_fwd(cuda_device, c, T):
+    """fp32 matrix-core implicit GEMM vs torch: exact fp32 fmaf chains, only the summation order differs."""
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(T)
+    B = 3
+    x = torch.randn(B, c["cin"], T, generator=g)
+    w = torch.randn(c["cout"], c["cin"] // c["groups"], c["k"], generator=g) * 0.2
+    b = torch.randn(c["cout"], generator=g)
+    want = F.conv1d(x, w, b, c["stride"], c["pad"], c["dil"], c["groups"])
+    got = ops.conv1d_mfma(cbt(x).to(cuda_device), w.to(cuda_device), b.to(cuda_device), c["stride"], c["pad"], c["dil"], c["groups"])
+    torch.testing.assert_close(bct(got.cpu()), want, rtol=1e-4, atol=2e-5)
+    # accumulate into an existing tensor on a strided output grid (the polyphase placement used for input gradients)
+    base = torch.randn(c["cout"], B, want.shape[2] * 2 + 1, generator=g)
+    out = base.clone().to(cuda_device)
+    ops.conv1d_mfma(cbt(x).to(cuda_device), w.to(cuda_device), None, c["stride"], c["pad"], c["dil"], c["groups"], out=out,
+                    n_out=want.shape[2], out_stride=2, out_offset=1, accumulate=True)
+    ref = base.clone()
+    ref[:, :, 1::2] += cbt(F.conv1d(x, w, None, c["stride"], c["pad"], c["dil"], c["groups"]))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=2e-5)
+
+
 @pytest.mark.parametrize("u,k", [(8, 16), (2, 4), (3, 7)])
 def test_conv_transpose1d_fwd_bwd(cuda_device, u, k):
     from everyvoice_amd.train import ops
