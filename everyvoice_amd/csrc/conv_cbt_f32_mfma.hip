@@ -3,21 +3,36 @@
 //
 //   y[co][b][to*os + oo] (+)= bias[co] + sum_{ci in group} sum_{j<k} w[co][ci][j] * x[ci][b][to*s + j*d - p]
 //
-// GEMM per workgroup: D[BM out-channels x BN output positions of one batch item] over K = (ci, j) in the
-// order the weights are stored (w[co] is a contiguous K-slice: no weight re-layout).  Channels are staged CB
-// at a time: their input span ((BN-1)*s + (k-1)*d + 1 samples) sits in LDS once and every tap reads it at
-// an offset; the weights of the chunk stream through LDS in 32-deep K steps (double-buffered).  With K = 2
-// per MFMA the operand traffic is one float per lane per operand per 64-cycle instruction: the kernel is
-// bound by the fp32 MFMA rate, not by LDS or HBM.  Any stride / dilation / groups; `os`, `oo` place the
-// outputs on a strided grid so that the gradient of a strided convolution runs as `stride` polyphase
+// GEMM per workgroup: D[BM out-channels x BN columns], columns = the flattened (b, to) index n = b*n_out + to,
+// so short sequences (the period discriminators' H = 4..50 rows) fill a tile with several batch items instead
+// of wasting it.  K runs over (channel pair, tap, channel parity): the two K slots of one MFMA are the even and
+// the odd channel of a pair at the same tap, so the per-lane part of every operand address is a constant and
+// the per-K part a wave-uniform scalar (A: +1 fragment, X: + the dilation per tap).
+//
+// Weights are first re-laid (wfrag_kernel, a few microseconds) into MFMA fragment order
+//   wf[g][m-block of 32 rows][channel pair][tap][parity][32 rows]      (zero padded),
+// i.e. one 256-byte fragment per (m-block, K pair) that a wave reads with lane-linear ds_read_b32 and that the
+// loader copies as contiguous kilobytes.  Both operands travel global -> LDS with the LDS-direct loads of gfx950
+// (global_load_lds_dwordx4 for the weight fragments, global_load_lds_dword for the input windows): no staging
+// registers, so the K loop is a three-slot LDS ring -- the loads of step t+2 are in flight while step t feeds the
+// matrix cores (one barrier per step, vmcnt counted so that only the older group is waited for), and the waves
+// keep their registers for a 64x64 (or 32x128) accumulator tile at two workgroups per CU.  Small workgroup tiles
+// (needed to fill 256 CUs on the short layers) keep that wave tile by splitting the K pairs of each step over the
+// waves (KS) and adding the partial tiles through LDS at the end.  Any stride / dilation / groups; `os`, `oo`
+// place the outputs on a strided grid so that the gradient of a strided convolution runs as `stride` polyphase
 // stride-1 convolutions through this same kernel.
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace evmi {
 
 struct ConvF32Args {
   const float* x;     // [c_in][B][t_in]
-  const float* w;     // [c_out][cin_g][k]  (or any array with the same [co][K] indexing)
+  const float* wf;    // fragment-ordered weights (wfrag_kernel)
   const float* bias;  // [c_out] or nullptr
   float* y;           // [c_out][B][t_out_total]
   int B, t_in, t_out_total;
@@ -26,31 +41,110 @@ struct ConvF32Args {
   int out_stride, out_offset;  // y index = to * out_stride + out_offset
   int accumulate;              // y += instead of y =
   int mtiles_per_group;
+  int mblocks, pairs;          // wf dims: ceil(cout_g / 32), ceil(cin_g / 2)
+  // tiling chosen by the host
+  int ps;       // channel pairs per step
+  int xrow;     // LDS row stride of the staged input rows (odd)
+  int pieces;   // ceil(xrow / 64)
+  int stage;    // floats per ring slot (weights fragments, then input rows)
+  int ablate;   // timing experiments only (EVMI_F32_ABLATE): 1 no input loads, 2 no weight loads, 4 no MFMA
+  long long* tl;  // timing experiments only (EVMI_F32_TL): s_memtime stamps of workgroup (0, 0), [step][wave][4]
 };
 
-constexpr int F32_CB = 16;     // input channels staged per chunk
-constexpr int F32_KSTEP = 32;  // K depth of one weight tile
-constexpr int F32_AS = F32_KSTEP + 1;
+constexpr int F32_PMAX = 10;  // 64-column pieces of a staged row (xrow <= 640)
+constexpr int F32_NST = 3;    // LDS ring slots
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void conv_cbt_f32_mfma_kernel(ConvF32Args a) {
-  constexpr int NTHREADS = WM * WN * 64;
+__device__ float g_zero_line[64];  // source of the zeros staged for padding / out-of-range columns
+
+typedef __attribute__((address_space(3))) float lds_float_t;
+typedef __attribute__((address_space(1))) const float glb_float_t;
+__device__ __forceinline__ void lds_direct_b32(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((glb_float_t*)g, (lds_float_t*)l, 4, 0, 0);
+}
+__device__ __forceinline__ void lds_direct_b128(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((glb_float_t*)g, (lds_float_t*)l, 16, 0, 0);
+}
+
+// wait until at most n (wave-uniform) vector-memory operations of this wave are outstanding
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+  n = __builtin_amdgcn_readfirstlane(n);
+#define EVMI_VMCASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    EVMI_VMCASE(0) EVMI_VMCASE(1) EVMI_VMCASE(2) EVMI_VMCASE(3) EVMI_VMCASE(4) EVMI_VMCASE(5) EVMI_VMCASE(6)
+    EVMI_VMCASE(7) EVMI_VMCASE(8) EVMI_VMCASE(9) EVMI_VMCASE(10) EVMI_VMCASE(11) EVMI_VMCASE(12) EVMI_VMCASE(13)
+    EVMI_VMCASE(14) EVMI_VMCASE(15) EVMI_VMCASE(16) EVMI_VMCASE(17) EVMI_VMCASE(18) EVMI_VMCASE(19) EVMI_VMCASE(20)
+    EVMI_VMCASE(21) EVMI_VMCASE(22) EVMI_VMCASE(23) EVMI_VMCASE(24) EVMI_VMCASE(25) EVMI_VMCASE(26) EVMI_VMCASE(27)
+    EVMI_VMCASE(28) EVMI_VMCASE(29) EVMI_VMCASE(30) EVMI_VMCASE(31) EVMI_VMCASE(32) EVMI_VMCASE(33) EVMI_VMCASE(34)
+    EVMI_VMCASE(35) EVMI_VMCASE(36) EVMI_VMCASE(37) EVMI_VMCASE(38) EVMI_VMCASE(39) EVMI_VMCASE(40) EVMI_VMCASE(41)
+    EVMI_VMCASE(42) EVMI_VMCASE(43) EVMI_VMCASE(44) EVMI_VMCASE(45) EVMI_VMCASE(46) EVMI_VMCASE(47) EVMI_VMCASE(48)
+    EVMI_VMCASE(49) EVMI_VMCASE(50) EVMI_VMCASE(51) EVMI_VMCASE(52) EVMI_VMCASE(53) EVMI_VMCASE(54) EVMI_VMCASE(55)
+    EVMI_VMCASE(56) EVMI_VMCASE(57) EVMI_VMCASE(58) EVMI_VMCASE(59) EVMI_VMCASE(60) EVMI_VMCASE(61) EVMI_VMCASE(62)
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+  }
+#undef EVMI_VMCASE
+}
+
+// wf[(((g*MB + mb)*P + p)*k + j)*64 + kh*32 + mi] = w[g*cout_g + mb*32 + mi][2p + kh][j]  (0 outside)
+// grid (P, groups*MB): one workgroup per (m-block, channel pair) = k fragments of 64 floats
+__global__ __launch_bounds__(256) void wfrag_kernel(const float* __restrict__ w, float* __restrict__ wf, int cout_g,
+                                                    int cin_g, int k, int MB, int P) {
+  const int p = blockIdx.x, gmb = blockIdx.y;
+  const int g = gmb / MB, mb = gmb - g * MB;
+  float* dst = wf + ((long long)gmb * P + p) * k * 64;
+  for (int e = threadIdx.x; e < k * 64; e += 256) {
+    const int j = e >> 6, kh = (e >> 5) & 1, mi = e & 31;
+    const int m = mb * 32 + mi, ci = 2 * p + kh;
+    dst[e] = (m < cout_g && ci < cin_g) ? w[((long long)(g * cout_g + m) * cin_g + ci) * k + j] : 0.f;
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int KS>
+__global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a) {
+  constexpr int NTHREADS = 256;
+  static_assert(WM * WN * KS == 4, "four waves");
   constexpr int MT = BM / (WM * 32), NT = BN / (WN * 32);
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* As = reinterpret_cast<float*>(smem);  // [2][BM][F32_AS]
-  float* Xs = As + 2 * BM * F32_AS;            // [F32_CB + 3][span_pad]
+  constexpr int U = 2;              // K pairs per software-pipeline group
+  constexpr int MBT = BM / 32;      // m-blocks of the tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int g = blockIdx.z / a.mtiles_per_group, mt_idx = blockIdx.z % a.mtiles_per_group;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
+  const int kh = lane >> 5, ln = lane & 31;
+  const int g = blockIdx.y / a.mtiles_per_group, mt_idx = blockIdx.y % a.mtiles_per_group;
   const int co0 = g * a.cout_g + mt_idx * BM;
-  const int b = blockIdx.y;
-  const int to0 = blockIdx.x * BN;
-  const int k = a.k, s = a.stride, d = a.dil;
-  const int span = (BN - 1) * s + (k - 1) * d + 1;
-  const int span_pad = span | 1;  // odd row stride
-  const int ti0 = to0 * s - a.pad;
-  const int Kg = a.cin_g * k;
+  const int k = a.k, s = a.stride, d = a.dil, xrow = a.xrow, ps = a.ps, pieces = a.pieces;
+  const int nqa_pad = (ps * k + 3) & ~3;      // fragments per m-block per slot (whole 1 KB quads)
+  const int a_floats = MBT * nqa_pad * 64;    // weight part of a slot
+  const int halo = (k - 1) * d + 1;
+  const long long n_total = (long long)a.B * a.n_out;
+  const long long n0 = (long long)blockIdx.x * BN;
+  const int b_first = (int)(n0 / a.n_out);
+  const int to_first = (int)(n0 - (long long)b_first * a.n_out);
+  const int m_valid = min(BM, a.cout_g - mt_idx * BM);
+  const long long ch_stride = (long long)a.B * a.t_in;
+  const float* xgrp = a.x + (long long)g * a.cin_g * ch_stride;
+
+  // per-lane column bookkeeping: tile column c -> (b, to); LDS column base = c*s + (b - b_first)*halo
+  int xbase[NT], col_b[NT], col_to[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = (wn * NT + nt) * 32 + ln;
+    const long long n = n0 + c;
+    if (n < n_total) {
+      const int bb = (int)(n / a.n_out);
+      col_b[nt] = bb;
+      col_to[nt] = (int)(n - (long long)bb * a.n_out);
+      xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * halo;
+    } else {
+      col_b[nt] = -1;
+      col_to[nt] = 0;
+      xbase[nt] = a_floats + kh * xrow;  // finite staged data; the column is never stored
+    }
+  }
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = (wm * MT + mt) * nqa_pad * 64 + lane;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -60,71 +154,193 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cbt_f32_mfma_kernel(ConvF32
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // rows of this M tile that exist (the last tile of a group may be partial)
-  const int m_valid = min(BM, a.cout_g - mt_idx * BM);
-  const float* wbase = a.w + (long long)co0 * Kg;
-
-  const int kh = lane >> 5, ln = lane & 31;
-  for (int c0 = 0; c0 < a.cin_g; c0 += F32_CB) {
-    const int cb = min(F32_CB, a.cin_g - c0);
-    __syncthreads();  // previous chunk fully consumed
-    // ---- stage the input span of cb channels (+ zero rows that padded K indices may touch) ----
-    for (int v = tid; v < (F32_CB + 3) * span; v += NTHREADS) {
-      const int r = v / span, i = v - r * span;
-      const int ti = ti0 + i;
-      float val = 0.f;
-      if (r < cb && ti >= 0 && ti < a.t_in) val = a.x[((long long)(g * a.cin_g + c0 + r) * a.B + b) * a.t_in + ti];
-      Xs[r * span_pad + i] = val;
+  // source offset (b*t_in + ti, -1 = zero) of the staged columns this lane loads: the same for every step and row
+  int so[F32_PMAX];
+  {
+    int* Stab = reinterpret_cast<int*>(smem);
+    for (int v = tid; v < pieces * 64; v += NTHREADS) Stab[v] = -1;
+    lds_barrier();
+    int c = 0, bb = b_first, to_lo = to_first;
+    while (c < BN && bb < a.B) {
+      const int cnt = min(a.n_out - to_lo, BN - c);
+      const int seglen = (cnt - 1) * s + halo;
+      const int ti0 = to_lo * s - a.pad;
+      int* seg = Stab + c * s + (bb - b_first) * halo;
+      for (int i = tid; i < seglen; i += NTHREADS) {
+        const int ti = ti0 + i;
+        seg[i] = (ti >= 0 && ti < a.t_in) ? bb * a.t_in + ti : -1;
+      }
+      c += cnt;
+      ++bb;
+      to_lo = 0;
     }
-    const int kc = cb * k;                                   // K indices of this chunk
-    const int nsteps = (kc + F32_KSTEP - 1) / F32_KSTEP;
-    const long long kbase = (long long)c0 * k;               // offset of the chunk inside a weight row
-    auto load_a = [&](int step, int buf) {
-      float* dst = As + buf * BM * F32_AS;
-      for (int v = tid; v < BM * F32_KSTEP; v += NTHREADS) {
-        const int m = v / F32_KSTEP, kk = v - m * F32_KSTEP;
-        const int kl = step * F32_KSTEP + kk;
-        float val = 0.f;
-        if (m < m_valid && kl < kc) val = wbase[(long long)m * Kg + kbase + kl];
-        dst[m * F32_AS + kk] = val;
+    lds_barrier();
+#pragma unroll
+    for (int pi = 0; pi < F32_PMAX; ++pi) so[pi] = pi < pieces ? Stab[pi * 64 + lane] : -1;
+    lds_barrier();
+  }
+
+  const int nsteps = (a.pairs + ps - 1) / ps;
+  if (a.ablate) {  // experiments read uninitialised LDS otherwise
+    for (int v = tid; v < F32_NST * a.stage; v += NTHREADS) smem[v] = 0.f;
+    lds_barrier();
+  }
+
+  // ---- loader: every wave brings its share of the operands of step t -> ring slot t%3 (LDS-direct, no registers).
+  // Weights: the 1 KB quads of the step round-robin over the waves (SGPR base + lane offset addressing);
+  // inputs: rows round-robin over the waves.  Returns the number of loads this wave issued. ----
+  const long long mb_stride = (long long)a.pairs * k * 64;
+  const float* wf_tile = a.wf + (long long)(g * a.mblocks + mt_idx * MBT) * mb_stride;
+  const int mb_last = a.mblocks - 1 - mt_idx * MBT;  // m-blocks past the group re-read the last one (never stored)
+  const unsigned lane16 = lane * 16;
+  auto issue = [&](int t, int slot) -> int {
+    const int c0 = t * 2 * ps;
+    const int cbcur = min(2 * ps, a.cin_g - c0);
+    const int pairs_cur = (cbcur + 1) >> 1;
+    const int nquads = (pairs_cur * k + 3) >> 2;  // whole quads: the tail fragments belong to the next step (or the slack)
+    float* sa = smem + slot * a.stage;
+    float* sx = sa + a_floats;
+    int issued = 0;
+    if (!(a.ablate & 2)) {
+      int u = wave;  // unit = (m-block, quad), round-robin over the four waves
+#pragma unroll
+      for (int mbi = 0; mbi < MBT; ++mbi) {
+        const char* src = reinterpret_cast<const char*>(wf_tile + min(mbi, mb_last) * mb_stride + (long long)t * ps * k * 64);
+        float* dst = sa + mbi * nqa_pad * 64;
+        for (; u < nquads; u += 4) {
+          lds_direct_b128(reinterpret_cast<const float*>(src + (size_t)u * 1024 + lane16), dst + u * 256);
+          ++issued;
+        }
+        u -= nquads;
+      }
+    }
+    if (!(a.ablate & 1)) {
+      const float* xr = xgrp + (long long)(c0 + wave) * ch_stride;
+      float* dstrow = sx + wave * xrow;
+      for (int r = wave; r < 2 * pairs_cur; r += 4) {
+        const bool zero_row = r >= cbcur;
+#pragma unroll
+        for (int pi = 0; pi < F32_PMAX; ++pi) {
+          if (pi >= pieces) break;
+          const float* srcp = (zero_row || so[pi] < 0) ? g_zero_line + lane : xr + so[pi];
+          if (pi * 64 + lane < xrow) lds_direct_b32(srcp, dstrow + pi * 64);
+          ++issued;
+        }
+        xr += 4 * ch_stride;
+        dstrow += 4 * xrow;
+      }
+    }
+    return issued;
+  };
+  int n_next = 0;  // loads of the group issued after the one about to be consumed
+  issue(0, 0);
+  if (nsteps > 1) n_next = issue(1, 1);
+
+  for (int t = 0; t < nsteps; ++t) {
+    const int slot = t % F32_NST;
+    const bool stamp = a.tl && blockIdx.x == 0 && blockIdx.y == 0 && t < 24;
+    long long* tl = a.tl + (t * 4 + wave) * 4;
+    if (stamp && lane == 0) tl[0] = __builtin_readcyclecounter();
+    wait_vmcnt_le(n_next);  // step t has landed (this wave's part); step t+1 may still be in flight
+    lds_barrier();          // ... everyone's part; slot (t+2)%3 was last read in step t-1
+    if (stamp && lane == 0) tl[1] = __builtin_readcyclecounter();
+    n_next = t + 2 < nsteps ? issue(t + 2, (t + 2) % F32_NST) : 0;
+    if (stamp && lane == 0) tl[2] = __builtin_readcyclecounter();
+    const int cbcur = min(2 * ps, a.cin_g - t * 2 * ps);
+    const int nq_all = ((cbcur + 1) >> 1) * k;
+    const int q_lo = KS == 1 ? 0 : (ks * nq_all) / KS;
+    const int q_hi = KS == 1 ? nq_all : ((ks + 1) * nq_all) / KS;
+    const int nq = q_hi - q_lo;
+    // wave-uniform operand offsets of the current K pair
+    int pl0 = 0, j = 0;
+    if (KS > 1) { pl0 = q_lo / k; j = q_lo - pl0 * k; }
+    int off_a = slot * a.stage + q_lo * 64;
+    int off_x = slot * a.stage + pl0 * 2 * xrow + j * d;
+    float fa[U][MT], fb[U][NT], ga[U][MT], gb[U][NT];
+    auto load_group = [&](float (&da)[U][MT], float (&db)[U][NT]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) da[u][mt] = smem[abase[mt] + off_a];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) db[u][nt] = smem[xbase[nt] + off_x];
+        ++j; off_a += 64; off_x += d;
+        if (j == k) { j = 0; off_x += 2 * xrow - k * d; }
       }
     };
-    load_a(0, 0);
-    // (ci_l, j) of this lane's K index, advanced by 2 per MFMA
-    int ci_l = kh / k, j = kh - ci_l * k;
-    for (int step = 0; step < nsteps; ++step) {
-      __syncthreads();  // tile `step` (and, for step 0, the input span) visible; previous tile consumed
-      if (step + 1 < nsteps) load_a(step + 1, (step + 1) & 1);
-      const float* Ab = As + (step & 1) * BM * F32_AS;
-#pragma unroll 4
-      for (int q = 0; q < F32_KSTEP / 2; ++q) {
-        float af[MT], bf[NT];
+    load_group(fa, fb);
+    const int nfull = nq / U, rem = nq - nfull * U;
+    if (!(a.ablate & 4))
+    for (int gi = 0; gi < nfull; ++gi) {
+      load_group(ga, gb);  // the group after this one (past the end: in-bounds LDS, never used)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = Ab[((wm * MT + mt) * 32 + ln) * F32_AS + 2 * q + kh];
-        // K indices past the chunk (zero weights) may point past the staged channels: park them on a zero row
-        const float* xr = Xs + min(ci_l, F32_CB + 2) * span_pad + j * d;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bf[nt] = xr[((wn * NT + nt) * 32 + ln) * s];
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-        // advance the K index by 2: (ci_l, j) <- divmod(ci_l * k + j + 2, k)
-        j += 2;
-        if (k == 1) { ci_l += 2; j = 0; }
-        else if (j >= k) { j -= k; ci_l += 1; }
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][mt], fb[u][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fa[u][mt] = ga[u][mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[u][nt] = gb[u][nt];
       }
+      // issue order: one operand read and its address arithmetic behind every MFMA
+#pragma unroll
+      for (int i = 0; i < U * MT * NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U - 1; ++u)
+      if (u < rem) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][mt], fb[u][nt], acc[mt][nt], 0, 0, 0);
+      }
+    if (stamp && lane == 0) tl[3] = __builtin_readcyclecounter();
+  }
+
+  // ---- K-split partial tiles: waves ks > 0 hand their accumulators to wave ks == 0 through LDS ----
+  if (KS > 1) {
+    float* R = smem;  // [KS-1][WM*WN][MT][NT][16][64]
+    lds_barrier();
+    if (ks > 0) {
+      float* dst = R + ((ks - 1) * WM * WN + wmn) * (MT * NT * 16 * 64) + lane;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((mt * NT + nt) * 16 + r) * 64] = acc[mt][nt][r];
+    }
+    lds_barrier();
+    if (ks > 0) return;
+#pragma unroll 1
+    for (int kk = 0; kk < KS - 1; ++kk) {
+      const float* src = R + (kk * WM * WN + wmn) * (MT * NT * 16 * 64) + lane;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] += src[((mt * NT + nt) * 16 + r) * 64];
     }
   }
 
   // ---- epilogue: D layout: lane column = output position, registers = output channels ----
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int nt = 0; nt < NT; ++nt) {
+    if (col_b[nt] < 0) continue;
+    float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + a.out_offset;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int to = to0 + (wn * NT + nt) * 32 + ln;
-      if (to >= a.n_out) continue;
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -132,43 +348,134 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_cbt_f32_mfma_kernel(ConvF32
         const int co = co0 + m;
         float v = acc[mt][nt][r];
         if (a.bias) v += a.bias[co];
-        float* dst = a.y + ((long long)co * a.B + b) * a.t_out_total + (long long)to * a.out_stride + a.out_offset;
+        float* dst = ycol + (long long)co * a.B * a.t_out_total;
         *dst = a.accumulate ? *dst + v : v;
       }
     }
+  }
 }
 
-static int launch_cfg(const ConvF32Args& a, int& bm) {
-  bm = a.cout_g >= 96 ? 128 : (a.cout_g >= 48 ? 64 : 32);
-  return (a.cout_g + bm - 1) / bm;
+struct F32Tile { int bm, bn, ks; };
+static const F32Tile kTiles[] = {{128, 128, 1}, {64, 128, 2}, {64, 64, 4}, {32, 256, 2}, {32, 128, 4}};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
 }
 
-int launch_conv_cbt_f32_mfma(ConvF32Args a, int groups, hipStream_t stream) {
+static int pick_tile(const ConvF32Args& a, int groups) {
+  const int forced = env_int("EVMI_F32_TILE", -1);
+  if (forced >= 0 && forced < kNumTiles) return forced;
+  const long long n_total = (long long)a.B * a.n_out;
+  auto blocks = [&](int i) {
+    return ((n_total + kTiles[i].bn - 1) / kTiles[i].bn) * ((a.cout_g + kTiles[i].bm - 1) / kTiles[i].bm) * groups;
+  };
+  const long long want = 512;  // two workgroups per CU before a larger tile is worth its reuse
+  if (a.cout_g > 64) {
+    if (blocks(0) >= want) return 0;
+    if (blocks(1) >= want) return 1;
+    return 2;
+  }
+  if (a.cout_g > 32) return blocks(1) >= want ? 1 : 2;
+  return blocks(3) >= want ? 3 : 4;
+}
+
+static long long wfrag_elems(int c_out, int c_in, int k, int groups) {
+  const int cout_g = c_out / groups, cin_g = c_in / groups;
+  return (long long)groups * ((cout_g + 31) / 32) * ((cin_g + 1) / 2) * k * 64 + 4 * 64;  // + slack: the loader reads whole quads
+}
+
+int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, long long wfrag_ws_elems, int groups,
+                             hipStream_t stream) {
   if (a.cin_g <= 0 || a.cout_g <= 0 || a.k <= 0 || a.stride <= 0 || a.dil <= 0 || a.n_out <= 0 || a.B <= 0)
     return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_f32_mfma: bad shape");
-  int bm;
-  a.mtiles_per_group = launch_cfg(a, bm);
-  const int bn = bm == 128 ? 128 : (bm == 64 ? 128 : 256);
-  const int span = (bn - 1) * a.stride + (a.k - 1) * a.dil + 1;
-  const size_t lds = ((size_t)2 * bm * F32_AS + (size_t)(F32_CB + 3) * (span | 1)) * sizeof(float);
-  if (lds > 160 * 1024) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: input span too large for LDS");
-  dim3 grid((a.n_out + bn - 1) / bn, a.B, groups * a.mtiles_per_group);
-  if (grid.y > 65535 || grid.z > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: grid limits");
-  static thread_local size_t configured[3] = {0, 0, 0};
-#define EVMI_F32_LAUNCH(BM, BN, WM, WN, IDX)                                                                       \
+  if ((long long)a.B * a.t_in >= (1LL << 31)) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: B*t_in >= 2^31");
+  a.mblocks = (a.cout_g + 31) / 32;
+  a.pairs = (a.cin_g + 1) / 2;
+  const long long wf_total = wfrag_elems(a.cout_g * groups, a.cin_g * groups, a.k, groups);
+  if (!wfrag_ws || wfrag_ws_elems < wf_total || (reinterpret_cast<uintptr_t>(wfrag_ws) & 15))
+    return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_f32_mfma: weight-fragment workspace missing, too small or unaligned");
+  const int halo = (a.k - 1) * a.dil + 1;
+  auto xrow_of = [&](int bn) {
+    const int items_max = (int)std::min<long long>(a.B, (bn + a.n_out - 2) / a.n_out + 1);
+    return (bn * a.stride + items_max * halo) | 1;
+  };
+  int ti = pick_tile(a, groups);
+  // strided layers: narrower tiles until the staged row fits the loader (tiles are ordered wide -> narrow per BM class)
+  while (xrow_of(kTiles[ti].bn) > 64 * F32_PMAX && ti != 2 && ti != kNumTiles - 1) ++ti;
+  const int bm = kTiles[ti].bm, bn = kTiles[ti].bn, ks = kTiles[ti].ks;
+  a.mtiles_per_group = (a.cout_g + bm - 1) / bm;
+  a.xrow = xrow_of(bn);
+  a.pieces = (a.xrow + 63) / 64;
+  if (a.pieces > F32_PMAX) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: input span too large");
+  // channel pairs per step: as deep as ~78 KB of LDS for the three ring slots allow (two workgroups per CU)
+  auto stage_floats = [&](int ps) {
+    return ((bm / 32) * ((ps * a.k + 3) & ~3) * 64 + 2 * ps * a.xrow + 2 * a.xrow + 3) & ~3;  // + slack for the read-ahead past a step
+  };
+  auto lds_bytes = [&](int ps) { return (size_t)F32_NST * stage_floats(ps) * sizeof(float); };
+  if (lds_bytes(1) > 160 * 1024) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: LDS budget");
+  int ps = 1;
+  while (ps < 16 && ps < a.pairs && lds_bytes(ps * 2) <= 78 * 1024) ps *= 2;
+  const int forced_ps = env_int("EVMI_F32_PS", 0);
+  if (forced_ps > 0 && lds_bytes(forced_ps) <= 160 * 1024) ps = forced_ps;
+  a.ps = ps;
+  a.stage = stage_floats(ps);
+  a.ablate = env_int("EVMI_F32_ABLATE", 0);
+  size_t lds = lds_bytes(ps);
+  lds = std::max(lds, (size_t)(ks - 1) * bm * bn * sizeof(float));
+  lds = std::max(lds, (size_t)a.pieces * 64 * sizeof(int));
+  if (lds > 160 * 1024) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: LDS budget");
+  const long long n_total = (long long)a.B * a.n_out;
+  dim3 grid((unsigned)((n_total + bn - 1) / bn), groups * a.mtiles_per_group, 1);
+  if (grid.y > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: grid limits");
+
+  if (groups * a.mblocks > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: grid limits");
+  hipLaunchKernelGGL(wfrag_kernel, dim3(a.pairs, groups * a.mblocks), dim3(256), 0, stream, w, wfrag_ws, a.cout_g, a.cin_g,
+                     a.k, a.mblocks, a.pairs);
+  a.wf = wfrag_ws;
+  a.tl = nullptr;
+  const bool want_tl = env_int("EVMI_F32_TL", 0) != 0;
+  if (want_tl) {
+    EVMI_HIP_CHECK(hipMalloc(&a.tl, 24 * 4 * 4 * sizeof(long long)));
+    EVMI_HIP_CHECK(hipMemsetAsync(a.tl, 0, 24 * 4 * 4 * sizeof(long long), stream));
+  }
+
+  static thread_local size_t configured[kNumTiles] = {0, 0, 0, 0, 0};
+#define EVMI_F32_LAUNCH(BM, BN, WM, WN, KS, IDX)                                                                   \
   {                                                                                                                \
     if (lds > configured[IDX]) {                                                                                   \
-      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_cbt_f32_mfma_kernel<BM, BN, WM, WN>,                    \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_cbt_f32_mfma_kernel<BM, BN, WM, WN, KS>,                \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
       configured[IDX] = lds;                                                                                       \
     }                                                                                                              \
-    hipLaunchKernelGGL((conv_cbt_f32_mfma_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), lds, stream, a);      \
+    hipLaunchKernelGGL((conv_cbt_f32_mfma_kernel<BM, BN, WM, WN, KS>), grid, dim3(256), lds, stream, a);           \
   }
-  if (bm == 128) EVMI_F32_LAUNCH(128, 128, 2, 2, 0)
-  else if (bm == 64) EVMI_F32_LAUNCH(64, 128, 1, 4, 1)
-  else EVMI_F32_LAUNCH(32, 256, 1, 4, 2)
+  switch (ti) {
+    case 0: EVMI_F32_LAUNCH(128, 128, 2, 2, 1, 0) break;
+    case 1: EVMI_F32_LAUNCH(64, 128, 1, 2, 2, 1) break;
+    case 2: EVMI_F32_LAUNCH(64, 64, 1, 1, 4, 2) break;
+    case 3: EVMI_F32_LAUNCH(32, 256, 1, 2, 2, 3) break;
+    default: EVMI_F32_LAUNCH(32, 128, 1, 1, 4, 4) break;
+  }
 #undef EVMI_F32_LAUNCH
   EVMI_LAUNCH_CHECK("conv_cbt_f32_mfma");
+  if (want_tl) {  // stamps of workgroup (0,0): per step and wave: arrive, past barrier, loads issued, MFMAs done (100 MHz ticks)
+    long long h[24 * 4 * 4];
+    EVMI_HIP_CHECK(hipStreamSynchronize(stream));
+    EVMI_HIP_CHECK(hipMemcpy(h, a.tl, sizeof(h), hipMemcpyDeviceToHost));
+    EVMI_HIP_CHECK(hipFree(a.tl));
+    fprintf(stderr, "[f32 timeline] tile %dx%d ks %d ps %d k %d xrow %d grid %u x %u\n", bm, bn, ks, a.ps, a.k, a.xrow, grid.x, grid.y);
+    const long long t0 = h[0];
+    for (int t = 0; t < 24 && h[(t * 4) * 4]; ++t) {
+      fprintf(stderr, "  step %2d:", t);
+      for (int w = 0; w < 4; ++w) {
+        const long long* e = h + (t * 4 + w) * 4;
+        fprintf(stderr, "  w%d %6lld +%4lld +%4lld +%5lld", w, e[0] - t0, e[1] - e[0], e[2] - e[1], e[3] - e[2]);
+      }
+      fprintf(stderr, "\n");
+    }
+  }
   return EVMI_OK;
 }
 
@@ -178,20 +485,23 @@ using namespace evmi;
 
 extern "C" {
 
-/* y[co][b][to*out_stride + out_offset] (+)= bias[co] + conv(x, w)[co][b][to] for to < n_out; x [c_in][B][t_in],
- * w [c_out][c_in/groups][k], y [c_out][B][t_out_total].  out_stride = 1, out_offset = 0, n_out = t_out_total is the
- * plain convolution. */
-int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int B, int c_in,
-                        int t_in, int c_out, int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups,
-                        int out_stride, int out_offset, int accumulate, void* stream) {
+long long evmi_conv_wfrag_elems(int c_out, int c_in, int k, int groups) {
+  if (groups <= 0 || c_out <= 0 || c_in <= 0 || k <= 0 || c_in % groups || c_out % groups) return -1;
+  return wfrag_elems(c_out, c_in, k, groups);
+}
+
+int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
+                        float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
+                        int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups, int out_stride,
+                        int out_offset, int accumulate, void* stream) {
   if (!x_dev || !w_dev || !y_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_f32: null pointer");
   if (groups <= 0 || c_in % groups || c_out % groups) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_f32: groups");
   ConvF32Args a;
-  a.x = x_dev; a.w = w_dev; a.bias = bias_dev; a.y = y_dev;
+  a.x = x_dev; a.wf = nullptr; a.bias = bias_dev; a.y = y_dev;
   a.B = B; a.t_in = t_in; a.t_out_total = t_out_total; a.n_out = n_out;
   a.cin_g = c_in / groups; a.cout_g = c_out / groups; a.k = k; a.stride = stride; a.dil = dil; a.pad = pad;
   a.out_stride = out_stride; a.out_offset = out_offset; a.accumulate = accumulate; a.mtiles_per_group = 1;
-  return launch_conv_cbt_f32_mfma(a, groups, (hipStream_t)stream);
+  return launch_conv_cbt_f32_mfma(a, w_dev, wfrag_ws_dev, wfrag_ws_elems, groups, (hipStream_t)stream);
 }
 
 }  // extern "C"

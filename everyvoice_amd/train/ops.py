@@ -111,7 +111,10 @@ def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=No
     t_conv = conv_out_len(t_in, k, stride, pad, dil)
     if out is None:
         out = torch.empty(cout, B, t_conv, device=x.device, dtype=torch.float32)
-    _chk(_lib.load().evmi_conv1d_cbt_f32(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), B, cin, t_in, cout,
+    lib = _lib.load()
+    wf_elems = lib.evmi_conv_wfrag_elems(cout, cin, k, groups)
+    wf = WS.get("wfrag", wf_elems, x.device)
+    _chk(lib.evmi_conv1d_cbt_f32(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), wf.data_ptr(), wf_elems, B, cin, t_in, cout,
                                          out.shape[2], t_conv if n_out is None else n_out, k, stride, pad, dil, groups,
                                          out_stride, out_offset, int(accumulate), _s(x)), "evmi_conv1d_cbt_f32")
     return out
@@ -147,7 +150,7 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
     return dx
 
 
-CONV_BACKEND = {"fwd": "gemm", "dgrad": "gemm"}  # "mfma": implicit GEMM on the fp32 matrix cores (conv_cbt_f32_mfma.hip)
+CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma"}  # "gemm": unfold + rocBLAS (kept for A/B and as the reference variant)
 
 
 def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1):

@@ -208,10 +208,13 @@ int evmi_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, co
  * x [c_in][B][t_in], w [c_out][c_in/groups][k], y [c_out][B][t_out_total]; out_stride 1 / offset 0 /
  * n_out = t_out_total is the plain convolution, other values place a polyphase component of a strided
  * convolution's input gradient. */
-int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int B,
-                        int c_in, int t_in, int c_out, int t_out_total, int n_out, int k, int stride,
-                        int pad, int dil, int groups, int out_stride, int out_offset, int accumulate,
-                        void* stream);
+int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
+                        float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
+                        int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups,
+                        int out_stride, int out_offset, int accumulate, void* stream);
+/* Floats of the 16-byte aligned device workspace evmi_conv1d_cbt_f32 needs for the MFMA-fragment copy of the
+ * weights (re-laid on the stream before every convolution: the weights change every optimiser step). */
+long long evmi_conv_wfrag_elems(int c_out, int c_in, int k, int groups);
 /* Weights of the stride-1 convolution that yields phase `phi` of a convolution's input gradient:
  * wt[c_in][c_out/groups][M], M = ceil((k - phi) / stride), wt[g*cin_g+ci][co][m] = w[g*cout_g+co][ci][phi + stride*(M-1-m)]. */
 int evmi_dgrad_weights_f32(const float* w_dev, float* wt_dev, int c_in, int c_out, int k, int groups,

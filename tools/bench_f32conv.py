@@ -30,6 +30,10 @@ SHAPES = [
     ("MPD p11 L3 512->1024 k5 s3", 512, 1024, 5, 3, 2, 1, 1, B * 11, 28),
     ("MPD p11 L4 1024->1024 k5", 1024, 1024, 5, 1, 2, 1, 1, B * 11, 10),
 ]
+import os
+flt = os.environ.get("F32_LAYERS", "")
+if flt:
+    SHAPES = [sh for sh in SHAPES if any(f in sh[0] for f in flt.split(","))]
 print(f"{'layer':32s} {'GFLOP':>8s} | {'mfma ms':>8s} {'TF/s':>7s} | {'gemm ms':>8s} {'TF/s':>7s}")
 for name, cin, cout, k, s, p, d, g, b, t in SHAPES:
     x = torch.randn(cin, b, t, device=dev)

@@ -1,0 +1,15 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+import torch
+from everyvoice_amd.train import ops
+dev = torch.device("cuda:0")
+def run(cin, cout, k, s, p, d, g, b, t):
+    x = torch.randn(cin, b, t, device=dev); w = torch.randn(cout, cin // g, k, device=dev) * 0.1
+    os.environ.pop("EVMI_F32_TL", None)
+    for _ in range(2): ops.conv1d_mfma(x, w, None, s, p, d, g)
+    torch.cuda.synchronize()
+    os.environ["EVMI_F32_TL"] = "1"
+    ops.conv1d_mfma(x, w, None, s, p, d, g)
+    torch.cuda.synchronize()
+run(1024, 1024, 5, 1, 2, 1, 1, 176, 10)
+run(128, 128, 11, 1, 25, 5, 1, 16, 2048)
