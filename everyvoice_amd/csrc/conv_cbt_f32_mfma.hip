@@ -386,16 +386,14 @@ static long long wfrag_elems(int c_out, int c_in, int k, int groups) {
   return (long long)groups * ((cout_g + 31) / 32) * ((cin_g + 1) / 2) * k * 64 + 4 * 64;  // + slack: the loader reads whole quads
 }
 
-int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, long long wfrag_ws_elems, int groups,
-                             hipStream_t stream) {
-  if (a.cin_g <= 0 || a.cout_g <= 0 || a.k <= 0 || a.stride <= 0 || a.dil <= 0 || a.n_out <= 0 || a.B <= 0)
-    return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_f32_mfma: bad shape");
-  if ((long long)a.B * a.t_in >= (1LL << 31)) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: B*t_in >= 2^31");
+struct F32Plan { int ti; size_t lds; dim3 grid; };
+
+// Tile, step depth and LDS budget for a shape; fills the tiling fields of `a`.  nullptr = runnable, else the reason.
+static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
+  if (a.cin_g <= 0 || a.cout_g <= 0 || a.k <= 0 || a.stride <= 0 || a.dil <= 0 || a.n_out <= 0 || a.B <= 0) return "bad shape";
+  if ((long long)a.B * a.t_in >= (1LL << 29)) return "B*t_in >= 2^29";
   a.mblocks = (a.cout_g + 31) / 32;
   a.pairs = (a.cin_g + 1) / 2;
-  const long long wf_total = wfrag_elems(a.cout_g * groups, a.cin_g * groups, a.k, groups);
-  if (!wfrag_ws || wfrag_ws_elems < wf_total || (reinterpret_cast<uintptr_t>(wfrag_ws) & 15))
-    return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_f32_mfma: weight-fragment workspace missing, too small or unaligned");
   const int halo = (a.k - 1) * a.dil + 1;
   auto xrow_of = [&](int bn) {
     const int items_max = (int)std::min<long long>(a.B, (bn + a.n_out - 2) / a.n_out + 1);
@@ -408,29 +406,46 @@ int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, lon
   a.mtiles_per_group = (a.cout_g + bm - 1) / bm;
   a.xrow = xrow_of(bn);
   a.pieces = (a.xrow + 63) / 64;
-  if (a.pieces > F32_PMAX) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: input span too large");
+  if (a.pieces > F32_PMAX) return "input span too large (very short rows with a long kernel)";
   // channel pairs per step: as deep as ~78 KB of LDS for the three ring slots allow (two workgroups per CU)
   auto stage_floats = [&](int ps) {
     return ((bm / 32) * ((ps * a.k + 3) & ~3) * 64 + 2 * ps * a.xrow + 2 * a.xrow + 3) & ~3;  // + slack for the read-ahead past a step
   };
   auto lds_bytes = [&](int ps) { return (size_t)F32_NST * stage_floats(ps) * sizeof(float); };
-  if (lds_bytes(1) > 160 * 1024) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: LDS budget");
+  if (lds_bytes(1) > 160 * 1024) return "LDS budget";
   int ps = 1;
   while (ps < 16 && ps < a.pairs && lds_bytes(ps * 2) <= 78 * 1024) ps *= 2;
   const int forced_ps = env_int("EVMI_F32_PS", 0);
   if (forced_ps > 0 && lds_bytes(forced_ps) <= 160 * 1024) ps = forced_ps;
   a.ps = ps;
   a.stage = stage_floats(ps);
-  a.ablate = env_int("EVMI_F32_ABLATE", 0);
   size_t lds = lds_bytes(ps);
   lds = std::max(lds, (size_t)(ks - 1) * bm * bn * sizeof(float));
   lds = std::max(lds, (size_t)a.pieces * 64 * sizeof(int));
-  if (lds > 160 * 1024) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: LDS budget");
+  if (lds > 160 * 1024) return "LDS budget";
   const long long n_total = (long long)a.B * a.n_out;
-  dim3 grid((unsigned)((n_total + bn - 1) / bn), groups * a.mtiles_per_group, 1);
-  if (grid.y > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: grid limits");
+  if ((n_total + bn - 1) / bn > 0x7fffffffLL || groups * a.mtiles_per_group > 65535 || groups * a.mblocks > 65535) return "grid limits";
+  pl.ti = ti;
+  pl.lds = lds;
+  pl.grid = dim3((unsigned)((n_total + bn - 1) / bn), groups * a.mtiles_per_group, 1);
+  return nullptr;
+}
 
-  if (groups * a.mblocks > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_f32_mfma: grid limits");
+int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, long long wfrag_ws_elems, int groups,
+                             hipStream_t stream) {
+  F32Plan pl;
+  if (const char* why = plan_conv_f32(a, groups, pl)) {
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_cbt_f32_mfma: ") + why);
+  }
+  const long long wf_total = wfrag_elems(a.cout_g * groups, a.cin_g * groups, a.k, groups);
+  if (!wfrag_ws || wfrag_ws_elems < wf_total || (reinterpret_cast<uintptr_t>(wfrag_ws) & 15))
+    return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_f32_mfma: weight-fragment workspace missing, too small or unaligned");
+  const int ti = pl.ti;
+  const size_t lds = pl.lds;
+  const dim3 grid = pl.grid;
+  const int bm = kTiles[ti].bm, bn = kTiles[ti].bn, ks = kTiles[ti].ks;
+  a.ablate = env_int("EVMI_F32_ABLATE", 0);
+
   hipLaunchKernelGGL(wfrag_kernel, dim3(a.pairs, groups * a.mblocks), dim3(256), 0, stream, w, wfrag_ws, a.cout_g, a.cin_g,
                      a.k, a.mblocks, a.pairs);
   a.wf = wfrag_ws;
@@ -488,6 +503,14 @@ extern "C" {
 long long evmi_conv_wfrag_elems(int c_out, int c_in, int k, int groups) {
   if (groups <= 0 || c_out <= 0 || c_in <= 0 || k <= 0 || c_in % groups || c_out % groups) return -1;
   return wfrag_elems(c_out, c_in, k, groups);
+}
+
+int evmi_conv1d_cbt_f32_supported(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int dil, int groups) {
+  if (groups <= 0 || c_in <= 0 || c_out <= 0 || c_in % groups || c_out % groups) return 0;
+  ConvF32Args a = {};
+  a.B = B; a.t_in = t_in; a.n_out = n_out; a.cin_g = c_in / groups; a.cout_g = c_out / groups; a.k = k; a.stride = stride; a.dil = dil;
+  F32Plan pl;
+  return plan_conv_f32(a, groups, pl) == nullptr ? 1 : 0;
 }
 
 int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,

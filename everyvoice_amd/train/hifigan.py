@@ -261,6 +261,24 @@ class HiFiGANTrainer:
             fmaps.append(f)
         return logits, fmaps
 
+    def _discriminate_pair(self, tape, y: torch.Tensor, y_hat: torch.Tensor):
+        """Discriminator step: real and generated waveforms as ONE batch of 2B items (columns of the same GEMMs), so
+        every convolution, its input gradient and its weight gradient run once over twice the columns.  The
+        spectral-norm scale discriminator keeps the reference's two forward calls: each call runs its own power
+        iteration and sees its own sigma.  Returns [(logits Var, "pair" | "real" | "fake")]."""
+        pair = ag.Var(torch.cat([y, y_hat], dim=1), needs_grad=False)
+        outs = [(d.forward(tape, pair)[0], "pair") for d in self.mpd]
+        x = pair
+        for i, d in enumerate(self.msd):
+            if i > 0:
+                x = ag.avgpool4s2(tape, x)
+            if any(isinstance(layer, SNConv) for layer in d.layers()):
+                outs.append((d.forward(tape, ag.Var(y, needs_grad=False))[0], "real"))
+                outs.append((d.forward(tape, ag.Var(y_hat, needs_grad=False))[0], "fake"))
+            else:
+                outs.append((d.forward(tape, x)[0], "pair"))
+        return outs
+
     # -- one GAN step -----------------------------------------------------------------------------------------
     def training_step(self, mel_bct: torch.Tensor, audio_bct: torch.Tensor) -> dict:
         """mel [B, n_mels, T/hop], audio [B, 1, T] on the device.  Returns the scalar losses (python floats)."""
@@ -282,14 +300,18 @@ class HiFiGANTrainer:
         for layer in d_layers:
             layer.frozen = False
         d_tape = ag.Tape()
-        real_logits, _ = self._discriminate(d_tape, ag.Var(y, needs_grad=False))
-        fake_logits, _ = self._discriminate(d_tape, ag.Var(y_hat.data, needs_grad=False))  # y_hat.detach()
-        for dr, dg in zip(real_logits, fake_logits):
-            n = dr.data.numel()
-            ops.scalar_reduce(1, dr.data, None, losses["d"], scale=1.0 / n, p=1.0, accumulate=True)
-            ops.scalar_reduce(1, dg.data, None, losses["d"], scale=1.0 / n, p=0.0, accumulate=True)
-            dr.grad = ops.elementwise(ops.EW_SQ_GRAD, dr.data, p0=1.0 / n, p1=1.0)
-            dg.grad = ops.elementwise(ops.EW_SQ_GRAD, dg.data, p0=1.0 / n, p1=0.0)
+        for o, kind in self._discriminate_pair(d_tape, y, y_hat.data):  # y_hat.detach()
+            if kind == "pair":  # real items first, generated items second along the batch axis
+                n, h = o.data.numel() // 2, o.data.shape[1] // 2  # period discriminators: the batch axis is (item, column)
+                o.grad = torch.empty_like(o.data)
+                parts = ((o.data[:, :h], o.grad[:, :h], 1.0), (o.data[:, h:], o.grad[:, h:], 0.0))
+            else:
+                n = o.data.numel()
+                o.grad = torch.empty_like(o.data)
+                parts = ((o.data, o.grad, 1.0 if kind == "real" else 0.0),)
+            for logits, grad, target in parts:
+                ops.scalar_reduce(1, logits, None, losses["d"], scale=1.0 / n, p=target, accumulate=True)
+                ops.elementwise(ops.EW_SQ_GRAD, logits, out=grad, p0=1.0 / n, p1=target)
         d_tape.backward()
         for layer in d_layers:
             layer.finish_grads()

@@ -121,6 +121,15 @@ def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=No
 
 
 
+def dgrad_mfma_supported(B, cin, t_in, cout, t_out, k, stride, dil, groups) -> bool:
+    """The input gradient runs as stride-1 convolutions of dy (c_out channels) with at most ceil(k / stride) taps."""
+    if stride > 1 and dil != 1:
+        return False
+    M = k if stride == 1 else (k + stride - 1) // stride
+    n_out = t_in if stride == 1 else max(1, t_in // stride)
+    return mfma_conv_supported(B, cout, t_out, cin, n_out, M, 1, dil if stride == 1 else 1, groups)
+
+
 def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
     """Input gradient of conv1d on the fp32 matrix cores: `stride` polyphase stride-1 convolutions of dy with
     re-indexed weights, each writing its own residue class of dx (strided layers all have dilation 1)."""
@@ -153,12 +162,17 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
 CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma"}  # "gemm": unfold + rocBLAS (kept for A/B and as the reference variant)
 
 
+def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bool:
+    """False for the degenerate shapes the matrix-core kernel does not stage (rows of a few samples under a long kernel)."""
+    return bool(_lib.load().evmi_conv1d_cbt_f32_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups))
+
+
 def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1):
     """x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out]."""
-    if CONV_BACKEND["fwd"] == "mfma":
-        return conv1d_mfma(x, w, bias, stride, pad, dil, groups)
     cin, B, t_in = x.shape
     cout, cin_g, k = w.shape
+    if CONV_BACKEND["fwd"] == "mfma" and mfma_conv_supported(B, cin, t_in, cout, conv_out_len(t_in, k, stride, pad, dil), k, stride, dil, groups):
+        return conv1d_mfma(x, w, bias, stride, pad, dil, groups)
     col, t_out = unfold(x, k, stride, pad, dil)
     y = torch.empty(cout, B, t_out, device=x.device, dtype=torch.float32)
     N = B * t_out
@@ -193,7 +207,7 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
         if db_out is not None:
             db = row_reduce(0, dy, None, db_out, cout, N, accumulate=accumulate)
     dx = None
-    if need_dx and CONV_BACKEND["dgrad"] == "mfma":
+    if need_dx and CONV_BACKEND["dgrad"] == "mfma" and dgrad_mfma_supported(B, cin, t_in, cout, t_out, k, stride, dil, groups):
         dx = conv1d_bwd_data_mfma(dy, w, t_in, stride, pad, dil, groups)
     elif need_dx:
         pointwise = k == 1 and stride == 1 and pad == 0

@@ -212,6 +212,9 @@ int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bia
                         float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
                         int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups,
                         int out_stride, int out_offset, int accumulate, void* stream);
+/* 1 when evmi_conv1d_cbt_f32 can run this shape (degenerate ones -- rows of a few samples under a 41-tap kernel --
+ * exceed its staging limits and return EVMI_ERR_UNSUPPORTED; callers use the unfold + GEMM path for those). */
+int evmi_conv1d_cbt_f32_supported(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int dil, int groups);
 /* Floats of the 16-byte aligned device workspace evmi_conv1d_cbt_f32 needs for the MFMA-fragment copy of the
  * weights (re-laid on the stream before every convolution: the weights change every optimiser step). */
 long long evmi_conv_wfrag_elems(int c_out, int c_in, int k, int groups);
