@@ -82,7 +82,7 @@ SYMBOLS = {
     ),
     "evmi_gemm_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "evmi_conv1d_cbt_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 14 + [C.c_void_p]),
-    "evmi_conv_wfrag_elems": (C.c_longlong, [C.c_int] * 4),
+    "evmi_conv1d_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 6),
     "evmi_conv1d_cbt_f32_supported": (C.c_int, [C.c_int] * 9),
     "evmi_dgrad_weights_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "evmi_gemm_batched_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p]),

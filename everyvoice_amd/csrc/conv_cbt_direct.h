@@ -1,0 +1,23 @@
+// Direct fp32 convolutions for GEMV / outer-product shapes of the training layout (conv_cbt_direct.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace evmi {
+
+struct ConvDirectArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  float* y;
+  float* partial;  // few-output-channel kernel, channel-split mode: [nchunks][c_out][B*n_out]
+  int B, t_in, t_out_total, n_out;
+  int c_in, c_out, k, stride, dil, pad;
+  int out_stride, out_offset, accumulate;
+  int cc, nchunks;  // channels per workgroup / number of channel chunks
+};
+
+// 0: not a direct-kernel shape; otherwise 1 + floats of scratch the few-output-channel kernel needs
+long long conv_direct_plan(const ConvDirectArgs& in, int groups, int& cc, int& nchunks);
+int launch_conv_direct(ConvDirectArgs a, int groups, float* ws, long long ws_elems, hipStream_t stream);
+
+}  // namespace evmi

@@ -1,0 +1,170 @@
+// Direct (non matrix-core) fp32 convolutions for the two degenerate GEMM shapes of the discriminators in the
+// channel-major training layout x[c][b][t]:
+//
+//   * few output channels (c_out <= 4: the logit convolutions 1024 -> 1, and the input gradients of every
+//     first layer): a GEMV -- per column a dot product over (channel, tap).  Bound by reading x once.
+//   * one input channel (c_in == 1: the first layers 1 -> 32 / 1 -> 128, and the input gradients of the logit
+//     convolutions): an outer product -- per column k multiplies per output channel.  Bound by writing y once.
+//
+// Same contract as the matrix-core kernel (evmi_conv1d_cbt_f32): columns are the flattened (b, to) index,
+// outputs may be placed on a strided grid (out_stride / out_offset) and accumulated.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "conv_cbt_direct.h"
+
+namespace evmi {
+
+constexpr int SMALLCO_MAX = 4;
+
+// grid (ceil(N / 64), nchunks), 256 threads: lane = column, wave = quarter of the workgroup's channels
+__global__ __launch_bounds__(256) void conv_smallco_kernel(ConvDirectArgs a) {
+  extern __shared__ float lds[];
+  float* wl = lds;                                   // [c_out][cc][k]
+  float* red = lds + a.c_out * a.cc * a.k;           // [4][SMALLCO_MAX][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.y * a.cc;
+  const int cc = min(a.cc, a.c_in - c0);
+  for (int v = tid; v < a.c_out * a.cc * a.k; v += 256) {
+    const int co = v / (a.cc * a.k), r = v - co * (a.cc * a.k), c = r / a.k, j = r - c * a.k;
+    wl[v] = c < cc ? a.w[((long long)co * a.c_in + c0 + c) * a.k + j] : 0.f;
+  }
+  __syncthreads();
+  const long long n_total = (long long)a.B * a.n_out;
+  const long long n = (long long)blockIdx.x * 64 + lane;
+  const bool live = n < n_total;
+  const int b = live ? (int)(n / a.n_out) : 0;
+  const int to = live ? (int)(n - (long long)b * a.n_out) : 0;
+  const int ti0 = to * a.stride - a.pad;
+  float acc[SMALLCO_MAX] = {0.f, 0.f, 0.f, 0.f};
+  const int per_wave = (cc + 3) >> 2;
+  const int cb = wave * per_wave, ce = min(cc, cb + per_wave);
+  for (int c = cb; c < ce; ++c) {
+    const float* xr = a.x + ((long long)(c0 + c) * a.B + b) * a.t_in;
+    for (int j = 0; j < a.k; ++j) {
+      const int ti = ti0 + j * a.dil;
+      const float xv = (live && ti >= 0 && ti < a.t_in) ? xr[ti] : 0.f;
+#pragma unroll
+      for (int co = 0; co < SMALLCO_MAX; ++co)
+        if (co < a.c_out) acc[co] = fmaf(wl[(co * a.cc + c) * a.k + j], xv, acc[co]);
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < SMALLCO_MAX; ++co) red[(wave * SMALLCO_MAX + co) * 64 + lane] = acc[co];
+  __syncthreads();
+  if (wave != 0 || !live) return;
+  for (int co = 0; co < a.c_out; ++co) {
+    float v = red[co * 64 + lane] + red[(SMALLCO_MAX + co) * 64 + lane] + red[(2 * SMALLCO_MAX + co) * 64 + lane] +
+              red[(3 * SMALLCO_MAX + co) * 64 + lane];
+    if (a.nchunks > 1) {
+      a.partial[((long long)blockIdx.y * a.c_out + co) * n_total + n] = v;
+    } else {
+      if (a.bias) v += a.bias[co];
+      float* dst = a.y + ((long long)co * a.B + b) * a.t_out_total + (long long)to * a.out_stride + a.out_offset;
+      *dst = a.accumulate ? *dst + v : v;
+    }
+  }
+}
+
+// y = bias + sum over channel chunks (fixed order: deterministic)
+__global__ void conv_smallco_reduce_kernel(ConvDirectArgs a) {
+  const long long n_total = (long long)a.B * a.n_out;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_total * a.c_out) return;
+  const int co = (int)(i / n_total);
+  const long long n = i - (long long)co * n_total;
+  float v = a.bias ? a.bias[co] : 0.f;
+  for (int ch = 0; ch < a.nchunks; ++ch) v += a.partial[((long long)ch * a.c_out + co) * n_total + n];
+  const int b = (int)(n / a.n_out);
+  const int to = (int)(n - (long long)b * a.n_out);
+  float* dst = a.y + ((long long)co * a.B + b) * a.t_out_total + (long long)to * a.out_stride + a.out_offset;
+  *dst = a.accumulate ? *dst + v : v;
+}
+
+constexpr int CIN1_KMAX = 16;
+constexpr int CIN1_CO = 32;  // output channels per workgroup
+
+// grid (ceil(N / 256), ceil(c_out / 32)): thread = column; its k inputs stay in registers for 32 output channels
+__global__ __launch_bounds__(256) void conv_cin1_kernel(ConvDirectArgs a) {
+  __shared__ float wl[CIN1_CO * CIN1_KMAX];
+  __shared__ float bl[CIN1_CO];
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.y * CIN1_CO;
+  const int nco = min(CIN1_CO, a.c_out - co0);
+  for (int v = tid; v < CIN1_CO * CIN1_KMAX; v += 256) {
+    const int co = v / CIN1_KMAX, j = v - co * CIN1_KMAX;
+    wl[v] = (co < nco && j < a.k) ? a.w[(long long)(co0 + co) * a.k + j] : 0.f;
+  }
+  if (tid < CIN1_CO) bl[tid] = (a.bias && tid < nco) ? a.bias[co0 + tid] : 0.f;
+  __syncthreads();
+  const long long n_total = (long long)a.B * a.n_out;
+  const long long n = (long long)blockIdx.x * 256 + tid;
+  if (n >= n_total) return;
+  const int b = (int)(n / a.n_out);
+  const int to = (int)(n - (long long)b * a.n_out);
+  const float* xr = a.x + (long long)b * a.t_in;
+  const int ti0 = to * a.stride - a.pad;
+  float xv[CIN1_KMAX];
+#pragma unroll
+  for (int j = 0; j < CIN1_KMAX; ++j) {
+    const int ti = ti0 + j * a.dil;
+    xv[j] = (j < a.k && ti >= 0 && ti < a.t_in) ? xr[ti] : 0.f;
+  }
+  float* dst = a.y + ((long long)co0 * a.B + b) * a.t_out_total + (long long)to * a.out_stride + a.out_offset;
+  const long long co_stride = (long long)a.B * a.t_out_total;
+  for (int co = 0; co < nco; ++co) {
+    float v = bl[co];
+#pragma unroll
+    for (int j = 0; j < CIN1_KMAX; ++j) v = fmaf(wl[co * CIN1_KMAX + j], xv[j], v);
+    *dst = a.accumulate ? *dst + v : v;
+    dst += co_stride;
+  }
+}
+
+long long conv_direct_plan(const ConvDirectArgs& in, int groups, int& cc, int& nchunks) {
+  cc = nchunks = 0;
+  static const bool disabled = getenv("EVMI_NO_DIRECT_CONV") != nullptr;  // A/B against the matrix-core kernel
+  if (groups != 1 || disabled) return 0;
+  if (in.c_in == 1 && in.k <= CIN1_KMAX) return 1;
+  if (in.c_out > SMALLCO_MAX) return 0;
+  const long long n_total = (long long)in.B * in.n_out;
+  const long long nblk = (n_total + 63) / 64;
+  // enough workgroups for the chip: split the channels when there are few columns; weights of a chunk fit 32 KB of LDS
+  long long want = std::max<long long>(1, std::min<long long>((512 + nblk - 1) / nblk, (in.c_in + 15) / 16));
+  cc = (int)((in.c_in + want - 1) / want);
+  const int cc_lds = std::max(4, 8192 / (in.k * in.c_out));
+  cc = std::max(4, std::min(cc, cc_lds));
+  cc = (cc + 3) & ~3;
+  nchunks = (in.c_in + cc - 1) / cc;
+  return 1 + (nchunks > 1 ? (long long)nchunks * in.c_out * n_total : 0);
+}
+
+int launch_conv_direct(ConvDirectArgs a, int groups, float* ws, long long ws_elems, hipStream_t stream) {
+  int cc, nchunks;
+  const long long need = conv_direct_plan(a, groups, cc, nchunks);
+  if (need == 0) return fail(EVMI_ERR_UNSUPPORTED, "conv_direct: not a direct-kernel shape");
+  const long long n_total = (long long)a.B * a.n_out;
+  if (a.c_in == 1 && a.k <= CIN1_KMAX) {
+    dim3 grid((unsigned)((n_total + 255) / 256), (a.c_out + CIN1_CO - 1) / CIN1_CO);
+    hipLaunchKernelGGL(conv_cin1_kernel, grid, dim3(256), 0, stream, a);
+    EVMI_LAUNCH_CHECK("conv_cin1");
+    return EVMI_OK;
+  }
+  a.cc = cc;
+  a.nchunks = nchunks;
+  a.partial = ws;
+  if (nchunks > 1 && (!ws || ws_elems < need - 1)) return fail(EVMI_ERR_INVALID_ARG, "conv_direct: workspace missing or too small");
+  const size_t lds = ((size_t)a.c_out * cc * a.k + 4 * SMALLCO_MAX * 64) * sizeof(float);
+  dim3 grid((unsigned)((n_total + 63) / 64), nchunks);
+  hipLaunchKernelGGL(conv_smallco_kernel, grid, dim3(256), lds, stream, a);
+  EVMI_LAUNCH_CHECK("conv_smallco");
+  if (nchunks > 1) {
+    const long long total = n_total * a.c_out;
+    hipLaunchKernelGGL(conv_smallco_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    EVMI_LAUNCH_CHECK("conv_smallco_reduce");
+  }
+  return EVMI_OK;
+}
+
+}  // namespace evmi

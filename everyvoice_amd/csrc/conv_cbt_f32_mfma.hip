@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "conv_cbt_direct.h"
 
 namespace evmi {
 
@@ -494,14 +495,25 @@ int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, lon
   return EVMI_OK;
 }
 
+static ConvDirectArgs direct_args(int B, int c_in, int t_in, int c_out, int t_out_total, int n_out, int k, int stride, int pad,
+                                  int dil) {
+  ConvDirectArgs d = {};
+  d.B = B; d.t_in = t_in; d.t_out_total = t_out_total; d.n_out = n_out; d.c_in = c_in; d.c_out = c_out; d.k = k;
+  d.stride = stride; d.dil = dil; d.pad = pad; d.out_stride = 1;
+  return d;
+}
+
 }  // namespace evmi
 
 using namespace evmi;
 
 extern "C" {
 
-long long evmi_conv_wfrag_elems(int c_out, int c_in, int k, int groups) {
-  if (groups <= 0 || c_out <= 0 || c_in <= 0 || k <= 0 || c_in % groups || c_out % groups) return -1;
+long long evmi_conv1d_cbt_f32_ws_elems(int B, int c_in, int c_out, int n_out, int k, int groups) {
+  if (groups <= 0 || c_out <= 0 || c_in <= 0 || k <= 0 || B <= 0 || n_out <= 0 || c_in % groups || c_out % groups) return -1;
+  int cc, nchunks;
+  const long long direct = conv_direct_plan(direct_args(B, c_in, 0, c_out, n_out, n_out, k, 1, 0, 1), groups, cc, nchunks);
+  if (direct > 0) return direct;  // scratch of the few-output-channel kernel (+1: never 0)
   return wfrag_elems(c_out, c_in, k, groups);
 }
 
@@ -509,6 +521,8 @@ int evmi_conv1d_cbt_f32_supported(int B, int c_in, int t_in, int c_out, int n_ou
   if (groups <= 0 || c_in <= 0 || c_out <= 0 || c_in % groups || c_out % groups) return 0;
   ConvF32Args a = {};
   a.B = B; a.t_in = t_in; a.n_out = n_out; a.cin_g = c_in / groups; a.cout_g = c_out / groups; a.k = k; a.stride = stride; a.dil = dil;
+  int cc, nchunks;
+  if (conv_direct_plan(direct_args(B, c_in, t_in, c_out, n_out, n_out, k, stride, 0, dil), groups, cc, nchunks) > 0) return 1;
   F32Plan pl;
   return plan_conv_f32(a, groups, pl) == nullptr ? 1 : 0;
 }
@@ -519,6 +533,14 @@ int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bia
                         int out_offset, int accumulate, void* stream) {
   if (!x_dev || !w_dev || !y_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_f32: null pointer");
   if (groups <= 0 || c_in % groups || c_out % groups) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_f32: groups");
+  {  // GEMV / outer-product shapes: direct kernels (conv_cbt_direct.hip)
+    ConvDirectArgs d = direct_args(B, c_in, t_in, c_out, t_out_total, n_out, k, stride, pad, dil);
+    d.x = x_dev; d.w = w_dev; d.bias = bias_dev; d.y = y_dev; d.out_stride = out_stride; d.out_offset = out_offset;
+    d.accumulate = accumulate;
+    int cc, nchunks;
+    if (conv_direct_plan(d, groups, cc, nchunks) > 0)
+      return launch_conv_direct(d, groups, wfrag_ws_dev, wfrag_ws_elems, (hipStream_t)stream);
+  }
   ConvF32Args a;
   a.x = x_dev; a.wf = nullptr; a.bias = bias_dev; a.y = y_dev;
   a.B = B; a.t_in = t_in; a.t_out_total = t_out_total; a.n_out = n_out;

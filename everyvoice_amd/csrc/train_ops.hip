@@ -12,6 +12,8 @@
 // layer by layer in later rounds.
 #include <rocblas/rocblas.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace evmi {
@@ -205,15 +207,19 @@ __global__ void bias_add_rows_kernel(float* __restrict__ y, const float* __restr
 }
 
 // out[r] (+)= scale * sum_n f(a[r][n], b[r][n]);  MODE 0: a ; 1: a*b ; 2: a*a
+// grid (rows, nseg): workgroup (r, sg) sums its segment of the row; nseg == 1 writes out[r], otherwise part[r][sg]
+// and row_reduce_final_kernel adds the segments in a fixed order (reproducible).
 template <int MODE>
 __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         float* __restrict__ out, long long N, float scale, int accumulate) {
+                                                         float* __restrict__ out, float* __restrict__ part_out, long long N,
+                                                         long long seg, float scale, int accumulate) {
   __shared__ float part[4];
   const long long r = blockIdx.x;
+  const long long lo = (long long)blockIdx.y * seg, hi = min(N, lo + seg);
   const float* ar = a + r * N;
   const float* br = b ? b + r * N : nullptr;
   float acc = 0.f;
-  for (long long i = threadIdx.x; i < N; i += 256) {
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const float av = ar[i];
     acc += MODE == 0 ? av : (MODE == 1 ? av * br[i] : av * av);
   }
@@ -222,9 +228,19 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float t = (part[0] + part[1] + part[2] + part[3]) * scale;
-    out[r] = accumulate ? out[r] + t : t;
+    const float t = part[0] + part[1] + part[2] + part[3];
+    if (gridDim.y == 1) out[r] = accumulate ? out[r] + t * scale : t * scale;
+    else part_out[r * gridDim.y + blockIdx.y] = t;
   }
+}
+
+__global__ void row_reduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int rows, int nseg,
+                                        float scale, int accumulate) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float t = 0.f;
+  for (int sg = 0; sg < nseg; ++sg) t += part[(long long)r * nseg + sg];
+  out[r] = accumulate ? out[r] + t * scale : t * scale;
 }
 
 // ---- elementwise -----------------------------------------------------------------------------------------
@@ -538,10 +554,24 @@ int evmi_row_reduce_f32(int mode, const float* a_dev, const float* b_dev, float*
                         float scale, int accumulate, void* stream) {
   EVMI_NONNULL(a_dev && out_dev, "row_reduce");
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 0) hipLaunchKernelGGL(row_reduce_kernel<0>, dim3(rows), dim3(256), 0, s, a_dev, b_dev, out_dev, n_per_row, scale, accumulate);
-  else if (mode == 1) hipLaunchKernelGGL(row_reduce_kernel<1>, dim3(rows), dim3(256), 0, s, a_dev, b_dev, out_dev, n_per_row, scale, accumulate);
-  else if (mode == 2) hipLaunchKernelGGL(row_reduce_kernel<2>, dim3(rows), dim3(256), 0, s, a_dev, b_dev, out_dev, n_per_row, scale, accumulate);
+  // few long rows: split every row into segments so the chip is busy (two passes, fixed summation order)
+  constexpr int MAXSEG = 64;
+  static thread_local float* part = nullptr;
+  static thread_local long long part_elems = 0;
+  int nseg = 1;
+  if (rows < 512 && n_per_row > 16384) nseg = (int)std::min<long long>(MAXSEG, std::min<long long>((1024 + rows - 1) / rows, (n_per_row + 8191) / 8192));
+  const long long seg = (n_per_row + nseg - 1) / nseg;
+  if (nseg > 1 && part_elems < (long long)rows * nseg) {
+    if (part) EVMI_HIP_CHECK(hipFree(part));
+    part_elems = (long long)rows * MAXSEG;
+    EVMI_HIP_CHECK(hipMalloc((void**)&part, part_elems * sizeof(float)));
+  }
+  const dim3 grid(rows, nseg);
+  if (mode == 0) hipLaunchKernelGGL(row_reduce_kernel<0>, grid, dim3(256), 0, s, a_dev, b_dev, out_dev, part, n_per_row, seg, scale, accumulate);
+  else if (mode == 1) hipLaunchKernelGGL(row_reduce_kernel<1>, grid, dim3(256), 0, s, a_dev, b_dev, out_dev, part, n_per_row, seg, scale, accumulate);
+  else if (mode == 2) hipLaunchKernelGGL(row_reduce_kernel<2>, grid, dim3(256), 0, s, a_dev, b_dev, out_dev, part, n_per_row, seg, scale, accumulate);
   else return fail(EVMI_ERR_INVALID_ARG, "row_reduce: mode");
+  if (nseg > 1) hipLaunchKernelGGL(row_reduce_final_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, out_dev, rows, nseg, scale, accumulate);
   EVMI_LAUNCH_CHECK("row_reduce");
   return EVMI_OK;
 }

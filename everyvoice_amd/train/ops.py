@@ -112,7 +112,7 @@ def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=No
     if out is None:
         out = torch.empty(cout, B, t_conv, device=x.device, dtype=torch.float32)
     lib = _lib.load()
-    wf_elems = lib.evmi_conv_wfrag_elems(cout, cin, k, groups)
+    wf_elems = lib.evmi_conv1d_cbt_f32_ws_elems(B, cin, cout, t_conv if n_out is None else n_out, k, groups)
     wf = WS.get("wfrag", wf_elems, x.device)
     _chk(lib.evmi_conv1d_cbt_f32(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), wf.data_ptr(), wf_elems, B, cin, t_in, cout,
                                          out.shape[2], t_conv if n_out is None else n_out, k, stride, pad, dil, groups,

@@ -207,7 +207,7 @@ int evmi_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, co
  *   y[co][b][to*out_stride + out_offset] (+)= bias[co] + conv(x, w)[co][b][to]   for to < n_out
  * x [c_in][B][t_in], w [c_out][c_in/groups][k], y [c_out][B][t_out_total]; out_stride 1 / offset 0 /
  * n_out = t_out_total is the plain convolution, other values place a polyphase component of a strided
- * convolution's input gradient. */
+ * convolution's input gradient.  c_out <= 4 and c_in == 1 (GEMV / outer-product shapes) run as direct kernels. */
 int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
                         float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
                         int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups,
@@ -215,9 +215,10 @@ int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bia
 /* 1 when evmi_conv1d_cbt_f32 can run this shape (degenerate ones -- rows of a few samples under a 41-tap kernel --
  * exceed its staging limits and return EVMI_ERR_UNSUPPORTED; callers use the unfold + GEMM path for those). */
 int evmi_conv1d_cbt_f32_supported(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int dil, int groups);
-/* Floats of the 16-byte aligned device workspace evmi_conv1d_cbt_f32 needs for the MFMA-fragment copy of the
- * weights (re-laid on the stream before every convolution: the weights change every optimiser step). */
-long long evmi_conv_wfrag_elems(int c_out, int c_in, int k, int groups);
+/* Floats of the 16-byte aligned device workspace (`wfrag_ws_dev`) evmi_conv1d_cbt_f32 needs for this shape: the
+ * MFMA-fragment copy of the weights (re-laid on the stream before every convolution: the weights change every
+ * optimiser step), or the channel-split scratch of the few-output-channel kernel. */
+long long evmi_conv1d_cbt_f32_ws_elems(int B, int c_in, int c_out, int n_out, int k, int groups);
 /* Weights of the stride-1 convolution that yields phase `phi` of a convolution's input gradient:
  * wt[c_in][c_out/groups][M], M = ceil((k - phi) / stride), wt[g*cin_g+ci][co][m] = w[g*cout_g+co][ci][phi + stride*(M-1-m)]. */
 int evmi_dgrad_weights_f32(const float* w_dev, float* wt_dev, int c_in, int c_out, int k, int groups,

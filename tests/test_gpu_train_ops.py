@@ -58,7 +58,11 @@ MFMA_CONVS = CONVS + [
     dict(cin=40, cout=100, k=7, stride=1, pad=3, dil=1, groups=1),      # partial M tile, channels not a multiple of 16
     dict(cin=128, cout=256, k=41, stride=2, pad=20, dil=1, groups=16),  # MSD layer 2
     dict(cin=32, cout=128, k=5, stride=3, pad=2, dil=1, groups=1),      # MPD layer 1
-    dict(cin=64, cout=1, k=3, stride=1, pad=1, dil=1, groups=1),        # conv_post of a discriminator
+    dict(cin=64, cout=1, k=3, stride=1, pad=1, dil=1, groups=1),        # conv_post of a discriminator (direct GEMV kernel)
+    dict(cin=1024, cout=1, k=3, stride=1, pad=1, dil=1, groups=1),      # ... at full width: channel-split + reduce pass
+    dict(cin=130, cout=3, k=15, stride=1, pad=7, dil=1, groups=1),      # few outputs, ragged channel chunks
+    dict(cin=1, cout=128, k=15, stride=1, pad=7, dil=1, groups=1),      # first scale-discriminator layer (outer product)
+    dict(cin=1, cout=40, k=5, stride=3, pad=2, dil=1, groups=1),        # first period-discriminator layer
 ]
 
 
