@@ -195,7 +195,9 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     generator + MPD + MSD, LSGAN + feature matching + 45 x mel L1, two AdamW optimisers), data parallel with one
     RCCL all-reduce per optimiser (discriminator 283 MB, generator 56 MB of fp32 gradients) when N > 1.
     Synthetic segments y = 0.3 * tanh(N(0,1)) [16, 1, 8192] per rank (seed 1234 + rank), mel from the device
-    front-end.  fp32 (unfold + rocBLAS GEMM convolutions): the first, parity-checked version of this path."""
+    front-end.  fp32: forward / input-gradient convolutions on the fp32 matrix cores (conv_cbt_f32_mfma.hip), weight
+    gradients as unfold + rocBLAS GEMM.  The roofline object prices the step at SURVEY.md 8(d)'s 25.8 MFLOP per
+    segment sample (12.9 M MAC: D step 6.21 M + G step 6.70 M) against the 157 TFLOP/s fp32 matrix peak."""
     import torch
 
     from everyvoice_amd.spectral import MelSpectrogram
@@ -212,7 +214,11 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
         losses.update(trainer.training_step(mel, y))
 
     elapsed = timed_region(step, args.train_steps, args.train_warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    flop_per_step = 25.8e6 * B * S  # per GPU
+    tflops = flop_per_step * args.train_steps / elapsed / 1e12
     return {
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.0, "unit": "TFLOP/s",
+                     "frac": round(tflops / 157.0, 4), "traffic": None, "flop_per_step_per_gpu": flop_per_step},
         "metric": "hifigan_v1_gan_train_steps_per_sec",
         "value": round(args.train_steps / elapsed, 3),
         "unit": "steps/s",
