@@ -84,6 +84,15 @@ SYMBOLS = {
     "evmi_conv1d_cbt_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 14 + [C.c_void_p]),
     "evmi_conv1d_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 6),
     "evmi_conv1d_cbt_f32_supported": (C.c_int, [C.c_int] * 9),
+    "evmi_fs2_embed_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
+    "evmi_fs2_add_posemb_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
+    "evmi_mask_cols_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
+    "evmi_layernorm_cbt_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
+    "evmi_dwconv1d_cbt_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 6 + [C.c_void_p]),
+    "evmi_fs2_bucket_embed_add_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "evmi_fs2_durations_i32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_float, C.c_void_p]),
+    "evmi_length_regulate_cbt_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "evmi_attention_cbt_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_dgrad_weights_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "evmi_gemm_batched_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
     "evmi_unfold_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),

@@ -1,0 +1,323 @@
+// FastSpeech2 feature-prediction forward path in the channel-major layout x[c][b][t], fp32.
+// Dense layers (Linear, pointwise and postnet convolutions) run on the fp32 matrix-core implicit GEMM
+// (conv_cbt_f32_mfma.hip, k = 1 is a plain GEMM); this file holds everything else:
+//   * attention_cbt_kernel  fused multi-head self-attention: S^T = K.Q^T and O^T = V^T.P^T on v_mfma_f32_32x32x2_f32
+//                           with the online softmax between them.  Working on the transposed problem makes the
+//                           accumulator layout of S^T (lane = query, registers = keys) exactly the B-operand layout
+//                           of the second product: P never leaves the registers.  Key padding mask from lengths.
+//   * layernorm_cbt_kernel  LayerNorm over the channel axis of every column
+//   * dwconv_cbt_kernel     depthwise convolution (+ folded BatchNorm) with SiLU / ReLU epilogue
+//   * embedding + FastPitch positional sinusoid, variance bucketise + embedding add, durations from log-durations,
+//     the length regulator as a gather in this layout, column masking.
+#include <cmath>
+
+#include "common.h"
+#include "evmi.h"
+
+namespace evmi {
+
+// ---- embedding + positional sinusoid --------------------------------------------------------------------------------
+// out[c][b][l] = l < len[b] ? table[ids[b][l]][c] + pe(l, c) : 0 ;  pe = cat(sin(l * inv_freq), cos(l * inv_freq))
+__global__ void fs2_embed_kernel(const int* __restrict__ ids, const int* __restrict__ lens, const float* __restrict__ table,
+                                 const float* __restrict__ inv_freq, float* __restrict__ out, int B, int L, int D) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)D * B * L) return;
+  const int l = (int)(i % L), b = (int)((i / L) % B), c = (int)(i / ((long long)L * B));
+  float v = 0.f;
+  if (l < lens[b]) {
+    const int h = D / 2;
+    const float ang = (float)l * inv_freq[c < h ? c : c - h];
+    v = table[(long long)ids[b * L + l] * D + c] + (c < h ? sinf(ang) : cosf(ang));
+  }
+  out[i] = v;
+}
+
+// x[c][b][t] = t < len[b] ? x + pe(t, c) : 0
+__global__ void fs2_add_posemb_kernel(float* __restrict__ x, const int* __restrict__ lens, const float* __restrict__ inv_freq,
+                                      int B, int T, int D) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)D * B * T) return;
+  const int t = (int)(i % T), b = (int)((i / T) % B), c = (int)(i / ((long long)T * B));
+  float v = 0.f;
+  if (t < lens[b]) {
+    const int h = D / 2;
+    const float ang = (float)t * inv_freq[c < h ? c : c - h];
+    v = x[i] + (c < h ? sinf(ang) : cosf(ang));
+  }
+  x[i] = v;
+}
+
+// x[c][b][t] = t < len[b] ? x : 0
+__global__ void mask_cols_kernel(float* __restrict__ x, const int* __restrict__ lens, int B, int T, int C) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)C * B * T) return;
+  const int t = (int)(i % T), b = (int)((i / T) % B);
+  if (t >= lens[b]) x[i] = 0.f;
+}
+
+// ---- LayerNorm over channels: one thread per column, two passes (columns are contiguous across threads) --------------
+__global__ __launch_bounds__(256) void layernorm_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y, int C,
+                                                           long long N, float eps) {
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += x[(long long)c * N + n];
+  const float mean = s / (float)C;
+  float v = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = x[(long long)c * N + n] - mean;
+    v = fmaf(d, d, v);
+  }
+  const float rstd = 1.f / sqrtf(v / (float)C + eps);
+  for (int c = 0; c < C; ++c) y[(long long)c * N + n] = (x[(long long)c * N + n] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// ---- depthwise conv: y[c][b][t] = act(bias[c] + sum_j w[c][j] * x[c][b][t + j - pad]) ---------------------------------
+__global__ void dwconv_cbt_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                  float* __restrict__ y, int C, int B, int T, int k, int pad, int act) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)C * B * T) return;
+  const int t = (int)(i % T);
+  const int c = (int)(i / ((long long)T * B));
+  const float* xr = x + (i - t);
+  float v = bias ? bias[c] : 0.f;
+  for (int j = 0; j < k; ++j) {
+    const int ti = t + j - pad;
+    if (ti >= 0 && ti < T) v = fmaf(w[c * k + j], xr[ti], v);
+  }
+  if (act == 1) v = v / (1.f + expf(-v));
+  else if (act == 2) v = fmaxf(v, 0.f);
+  y[i] = v;
+}
+
+// ---- variance adaptor pieces ---------------------------------------------------------------------------------------
+// x[c][b][l] += table[bucket(values[b][l] * control)][c]; bucket = #bins strictly below the value (torch.bucketize)
+__global__ void fs2_bucket_embed_add_kernel(float* __restrict__ x, const float* __restrict__ values, const float* __restrict__ bins,
+                                            const float* __restrict__ table, int n_bins, int B, int L, int D, float control) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)D * B * L) return;
+  const int c = (int)(i / ((long long)L * B));
+  const float v = values[i % ((long long)L * B)] * control;
+  int lo = 0, hi = n_bins - 1;  // bins has n_bins - 1 boundaries
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (bins[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  x[i] += table[(long long)lo * D + c];
+}
+
+// dur[b][l] = l < len[b] ? max(0, rint(exp(log_d) - 1) * control) : 0  (int32), the reference's inference rule
+__global__ void fs2_durations_kernel(const float* __restrict__ log_d, const int* __restrict__ lens, int* __restrict__ dur, int B,
+                                     int L, float control) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * L) return;
+  const int l = i % L, b = i / L;
+  float d = rintf(expf(log_d[i]) - 1.f) * control;
+  d = fmaxf(d, 0.f);
+  dur[i] = l < lens[b] ? (int)d : 0;
+}
+
+// length regulator in this layout: out[c][b][t] = t < total[b] ? x[c][b][token(b, t)] : 0, token by binary search
+// in the inclusive prefix sums cum[b][l] of the durations
+__global__ void length_regulate_cbt_kernel(const float* __restrict__ x, const int* __restrict__ cum, float* __restrict__ out, int C,
+                                           int B, int L, int T) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)C * B * T) return;
+  const int t = (int)(i % T), b = (int)((i / T) % B), c = (int)(i / ((long long)T * B));
+  const int* cb = cum + b * L;
+  float v = 0.f;
+  if (t < cb[L - 1]) {
+    int lo = 0, hi = L - 1;  // first l with cum[l] > t
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cb[mid] > t) hi = mid; else lo = mid + 1;
+    }
+    v = x[((long long)c * B + b) * L + lo];
+  }
+  out[i] = v;
+}
+
+// ---- fused self-attention ------------------------------------------------------------------------------------------
+// qkv [3*D][B][T] (q rows, then k rows, then v rows; head h owns channels h*DH .. h*DH+DH-1), lens [B] -> out [D][B][T].
+// grid (ceil(T / 128), H, B), 256 threads: every wave owns 32 queries and walks the key tiles of 32.
+template <int DH>
+__global__ __launch_bounds__(256) void attention_cbt_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+                                                           float* __restrict__ out, int B, int T, int D, float scale) {
+  constexpr int VS = 33;  // V rows are read across channels: odd stride
+  __shared__ float Ks[DH * 32];
+  __shared__ float Vs[DH * VS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int len = min(lens[b], T);
+  const long long N = (long long)B * T;
+  const float* q = qkv + ((long long)(h * DH) * B + b) * T;
+  const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
+  const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
+  const int tq = blockIdx.x * 128 + wave * 32 + ln;
+  const bool qlive = tq < T;
+  // Q^T as the B operand of S^T = K.Q^T: lane (query, half) holds Q[query][2s + half], pre-scaled
+  float qreg[DH / 2];
+#pragma unroll
+  for (int s = 0; s < DH / 2; ++s) qreg[s] = qlive ? q[(long long)(2 * s + kh) * N + tq] * scale : 0.f;
+  f32x16 acc[DH / 32];
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int k0 = 0; k0 < len; k0 += 32) {
+    __syncthreads();  // previous tile consumed
+    for (int v = tid; v < DH * 32; v += 256) {
+      const int d = v >> 5, kk = v & 31;
+      const bool in = k0 + kk < T;
+      Ks[d * 32 + kk] = in ? kg[(long long)d * N + k0 + kk] : 0.f;
+      Vs[d * VS + kk] = in ? vg[(long long)d * N + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+    // S^T tile: rows = keys (A operand lane (key, half): K[key][2s + half]), columns = queries
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH / 2; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * s + kh) * 32 + ln], qreg[s], st, 0, 0, 0);
+    // online softmax over the keys of this lane's query: registers x the two halves
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (key >= len) st[r] = -INFINITY;
+      mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);  // finite: every processed tile has a valid key
+    const float corr = expf(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = expf(st[r] - m_new);
+      ps += st[r];
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * corr + ps;
+    m_run = m_new;
+    // O^T += V^T . P^T: step r contracts key (r&3)+8(r>>2) [half 0] and that key + 4 [half 1]: P^T is st[r] as it lies
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(i * 32 + ln) * VS + (r & 3) + 8 * (r >> 2) + 4 * kh], st[r], acc[i], 0, 0, 0);
+    }
+  }
+  if (!qlive) return;
+  const float inv = 1.f / l_run;
+  float* o = out + ((long long)(h * DH) * B + b) * T + tq;
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(long long)(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * N] = acc[i][r] * inv;
+}
+
+static dim3 grid1d(long long n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace evmi
+
+using namespace evmi;
+
+#define EVMI_NONNULL(cond, what) \
+  if (!(cond)) return fail(EVMI_ERR_INVALID_ARG, std::string(what) + ": null pointer")
+
+extern "C" {
+
+int evmi_fs2_embed_f32(const int* ids_dev, const int* lens_dev, const float* table_dev, const float* inv_freq_dev, float* out_dev,
+                       int B, int L, int D, void* stream) {
+  EVMI_NONNULL(ids_dev && lens_dev && table_dev && inv_freq_dev && out_dev, "fs2_embed");
+  if (B <= 0 || L <= 0 || D <= 0 || (D & 1)) return fail(EVMI_ERR_INVALID_ARG, "fs2_embed: shape");
+  hipLaunchKernelGGL(fs2_embed_kernel, grid1d((long long)D * B * L), dim3(256), 0, (hipStream_t)stream, ids_dev, lens_dev, table_dev,
+                     inv_freq_dev, out_dev, B, L, D);
+  EVMI_LAUNCH_CHECK("fs2_embed");
+  return EVMI_OK;
+}
+
+int evmi_fs2_add_posemb_f32(float* x_dev, const int* lens_dev, const float* inv_freq_dev, int B, int T, int D, void* stream) {
+  EVMI_NONNULL(x_dev && lens_dev && inv_freq_dev, "fs2_add_posemb");
+  hipLaunchKernelGGL(fs2_add_posemb_kernel, grid1d((long long)D * B * T), dim3(256), 0, (hipStream_t)stream, x_dev, lens_dev,
+                     inv_freq_dev, B, T, D);
+  EVMI_LAUNCH_CHECK("fs2_add_posemb");
+  return EVMI_OK;
+}
+
+int evmi_mask_cols_f32(float* x_dev, const int* lens_dev, int C, int B, int T, void* stream) {
+  EVMI_NONNULL(x_dev && lens_dev, "mask_cols");
+  hipLaunchKernelGGL(mask_cols_kernel, grid1d((long long)C * B * T), dim3(256), 0, (hipStream_t)stream, x_dev, lens_dev, B, T, C);
+  EVMI_LAUNCH_CHECK("mask_cols");
+  return EVMI_OK;
+}
+
+int evmi_layernorm_cbt_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, int C, long long n_cols,
+                           float eps, void* stream) {
+  EVMI_NONNULL(x_dev && gamma_dev && beta_dev && y_dev, "layernorm_cbt");
+  if (C <= 0 || n_cols <= 0) return fail(EVMI_ERR_INVALID_ARG, "layernorm_cbt: shape");
+  hipLaunchKernelGGL(layernorm_cbt_kernel, grid1d(n_cols), dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, y_dev, C,
+                     n_cols, eps);
+  EVMI_LAUNCH_CHECK("layernorm_cbt");
+  return EVMI_OK;
+}
+
+int evmi_dwconv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int C, int B, int T, int k,
+                          int pad, int act, void* stream) {
+  EVMI_NONNULL(x_dev && w_dev && y_dev, "dwconv1d_cbt");
+  if (C <= 0 || B <= 0 || T <= 0 || k <= 0 || act < 0 || act > 2) return fail(EVMI_ERR_INVALID_ARG, "dwconv1d_cbt: shape");
+  hipLaunchKernelGGL(dwconv_cbt_kernel, grid1d((long long)C * B * T), dim3(256), 0, (hipStream_t)stream, x_dev, w_dev, bias_dev,
+                     y_dev, C, B, T, k, pad, act);
+  EVMI_LAUNCH_CHECK("dwconv1d_cbt");
+  return EVMI_OK;
+}
+
+int evmi_fs2_bucket_embed_add_f32(float* x_dev, const float* values_dev, const float* bins_dev, const float* table_dev, int n_bins,
+                                  int B, int L, int D, float control, void* stream) {
+  EVMI_NONNULL(x_dev && values_dev && bins_dev && table_dev, "fs2_bucket_embed_add");
+  if (n_bins < 2) return fail(EVMI_ERR_INVALID_ARG, "fs2_bucket_embed_add: n_bins");
+  hipLaunchKernelGGL(fs2_bucket_embed_add_kernel, grid1d((long long)D * B * L), dim3(256), 0, (hipStream_t)stream, x_dev, values_dev,
+                     bins_dev, table_dev, n_bins, B, L, D, control);
+  EVMI_LAUNCH_CHECK("fs2_bucket_embed_add");
+  return EVMI_OK;
+}
+
+int evmi_fs2_durations_i32(const float* log_d_dev, const int* lens_dev, int* dur_dev, int B, int L, float control, void* stream) {
+  EVMI_NONNULL(log_d_dev && lens_dev && dur_dev, "fs2_durations");
+  hipLaunchKernelGGL(fs2_durations_kernel, grid1d((long long)B * L), dim3(256), 0, (hipStream_t)stream, log_d_dev, lens_dev, dur_dev,
+                     B, L, control);
+  EVMI_LAUNCH_CHECK("fs2_durations");
+  return EVMI_OK;
+}
+
+int evmi_length_regulate_cbt_f32(const float* x_dev, const int* cum_dev, float* out_dev, int C, int B, int L, int T, void* stream) {
+  EVMI_NONNULL(x_dev && cum_dev && out_dev, "length_regulate_cbt");
+  if (C <= 0 || B <= 0 || L <= 0 || T <= 0) return fail(EVMI_ERR_INVALID_ARG, "length_regulate_cbt: shape");
+  hipLaunchKernelGGL(length_regulate_cbt_kernel, grid1d((long long)C * B * T), dim3(256), 0, (hipStream_t)stream, x_dev, cum_dev,
+                     out_dev, C, B, L, T);
+  EVMI_LAUNCH_CHECK("length_regulate_cbt");
+  return EVMI_OK;
+}
+
+int evmi_attention_cbt_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, int B, int T, int D, int heads, void* stream) {
+  EVMI_NONNULL(qkv_dev && lens_dev && out_dev, "attention_cbt");
+  if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads) return fail(EVMI_ERR_INVALID_ARG, "attention_cbt: shape");
+  if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "attention_cbt: grid limits");
+  const int dh = D / heads;
+  const float scale = 1.f / sqrtf((float)dh);
+  const dim3 grid((T + 127) / 128, heads, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (dh == 128) hipLaunchKernelGGL(attention_cbt_kernel<128>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, B, T, D, scale);
+  else if (dh == 64) hipLaunchKernelGGL(attention_cbt_kernel<64>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, B, T, D, scale);
+  else if (dh == 32) hipLaunchKernelGGL(attention_cbt_kernel<32>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, B, T, D, scale);
+  else return fail(EVMI_ERR_UNSUPPORTED, "attention_cbt: head dimension must be 32, 64 or 128");
+  EVMI_LAUNCH_CHECK("attention_cbt");
+  return EVMI_OK;
+}
+
+}  // extern "C"

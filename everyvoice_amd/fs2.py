@@ -1,0 +1,373 @@
+"""FastSpeech2 feature prediction (text ids -> mel), inference forward path on libevmi_hip.
+
+Host-side mirror of what the reference constructs as ``FastSpeech2(config, stats=..., lang2id=..., speaker2id=...)``
+(``everyvoice/tests/model_stubs.py:44-58``; the module itself lives in the absent submodule
+EveryVoiceTTS/FastSpeech2_lightning).  Configuration names follow the reference's schema
+(``everyvoice/.schema/everyvoice-text-to-spec-0.5.json``: ConformerConfig {layers, heads, input_dim, feedforward_dim,
+conv_kernel_size, dropout}, VariancePredictorConfig {n_layers, kernel_size, input_dim, n_bins, depthwise, level}); the
+state-dict layout is the one of ``torchaudio.models.Conformer`` for encoder / decoder (the ConformerConfig field set is
+exactly that constructor) plus ``text_input_layer``, ``position_embedding.inv_freq`` (the tensor
+``everyvoice/tests/data/test.ckpt`` holds), ``{duration,pitch,energy}_predictor``, ``{pitch,energy}_embedding``,
+``mel_linear`` and ``postnet``.
+
+Everything runs channel-major ``x[c][b][t]`` in fp32: Linear / pointwise / postnet layers on the fp32 matrix-core
+implicit GEMM (``evmi_conv1d_cbt_f32``), attention, LayerNorm, depthwise convolutions (eval-mode BatchNorm and weight norm
+folded at load time), embeddings, bucketisation, the integer length regulator in ``csrc/fs2_ops.hip``.  No CPU fallback.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import torch
+
+from . import _lib
+from .train import ops
+
+
+@dataclass
+class ConformerConfig:
+    layers: int = 4
+    heads: int = 2
+    input_dim: int = 256
+    feedforward_dim: int = 1024
+    conv_kernel_size: int = 9
+    dropout: float = 0.2
+
+
+@dataclass
+class VariancePredictorConfig:
+    loss: str = "mse"
+    n_layers: int = 5
+    kernel_size: int = 3
+    dropout: float = 0.5
+    input_dim: int = 256
+    n_bins: int = 256
+    depthwise: bool = True
+    level: str = "phone"
+
+
+@dataclass
+class StatsInfo:
+    """``everyvoice/tests/model_stubs.py:50-57``."""
+    min: float = -3.0
+    max: float = 3.0
+    std: float = 1.0
+    mean: float = 0.0
+    norm_min: float = -3.0
+    norm_max: float = 3.0
+
+
+@dataclass
+class Stats:
+    pitch: StatsInfo = field(default_factory=StatsInfo)
+    energy: StatsInfo = field(default_factory=StatsInfo)
+
+
+@dataclass
+class VariancePredictors:
+    energy: VariancePredictorConfig = field(default_factory=VariancePredictorConfig)
+    duration: VariancePredictorConfig = field(default_factory=VariancePredictorConfig)
+    pitch: VariancePredictorConfig = field(default_factory=VariancePredictorConfig)
+
+
+@dataclass
+class FastSpeech2ModelConfig:
+    encoder: ConformerConfig = field(default_factory=ConformerConfig)
+    decoder: ConformerConfig = field(default_factory=ConformerConfig)
+    variance_predictors: VariancePredictors = field(default_factory=VariancePredictors)
+    learn_alignment: bool = True
+    max_length: int = 1000
+    mel_loss: str = "mse"
+    use_postnet: bool = True
+    multilingual: bool = False
+    multispeaker: bool = False
+    # not in the reference's schema (fixed inside the absent module): sizes of the embedding table and the postnet
+    n_symbols: int = 80
+    n_mels: int = 80
+    postnet_channels: int = 512
+    postnet_kernel: int = 5
+    postnet_layers: int = 5
+
+
+_LN_EPS = 1e-5
+_BN_EPS = 1e-5
+
+
+def _chk(rc, what):
+    _lib.check(rc, what)
+
+
+def _s(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _conv(x, w, b, k=1):
+    return ops.conv1d_mfma(x, w, b, 1, (k - 1) // 2, 1, 1)
+
+
+def _layernorm(x, g, b):
+    y = torch.empty_like(x)
+    _chk(_lib.load().evmi_layernorm_cbt_f32(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1] * x.shape[2],
+                                            _LN_EPS, _s(x)), "evmi_layernorm_cbt_f32")
+    return y
+
+
+def _dwconv(x, w, b, k, act):
+    y = torch.empty_like(x)
+    C, B, T = x.shape
+    _chk(_lib.load().evmi_dwconv1d_cbt_f32(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), C, B, T, k, (k - 1) // 2, act, _s(x)),
+         "evmi_dwconv1d_cbt_f32")
+    return y
+
+
+def _fold_weight_norm(sd, prefix):
+    g, v = sd[prefix + ".weight_g"].float(), sd[prefix + ".weight_v"].float()
+    return g * v / v.flatten(1).norm(dim=1).view(-1, *([1] * (v.dim() - 1)))
+
+
+def _fold_bn(w, b, sd, prefix):
+    """Eval-mode BatchNorm1d after a convolution: y = (conv - mean) / sqrt(var + eps) * gamma + beta."""
+    s = sd[prefix + ".weight"].float() / torch.sqrt(sd[prefix + ".running_var"].float() + _BN_EPS)
+    return w * s.view(-1, *([1] * (w.dim() - 1))), (b - sd[prefix + ".running_mean"].float()) * s + sd[prefix + ".bias"].float()
+
+
+class _Conformer:
+    def __init__(self, cfg: ConformerConfig, sd: dict, prefix: str, dev):
+        self.cfg = cfg
+        self.layers = []
+        d = cfg.input_dim
+        put = lambda t: t.to(dev, torch.float32).contiguous()
+        for i in range(cfg.layers):
+            p = f"{prefix}.conformer_layers.{i}."
+            L = {}
+            for name in ("ffn1", "ffn2"):
+                L[name] = dict(ln_g=put(sd[p + name + ".sequential.0.weight"]), ln_b=put(sd[p + name + ".sequential.0.bias"]),
+                               w1=put(sd[p + name + ".sequential.1.weight"].unsqueeze(-1)), b1=put(sd[p + name + ".sequential.1.bias"]),
+                               w2=put(sd[p + name + ".sequential.4.weight"].unsqueeze(-1)), b2=put(sd[p + name + ".sequential.4.bias"]))
+            L["attn"] = dict(ln_g=put(sd[p + "self_attn_layer_norm.weight"]), ln_b=put(sd[p + "self_attn_layer_norm.bias"]),
+                             w_in=put(sd[p + "self_attn.in_proj_weight"].unsqueeze(-1)), b_in=put(sd[p + "self_attn.in_proj_bias"]),
+                             w_out=put(sd[p + "self_attn.out_proj.weight"].unsqueeze(-1)), b_out=put(sd[p + "self_attn.out_proj.bias"]))
+            c = p + "conv_module."
+            wdw, bdw = _fold_bn(sd[c + "sequential.2.weight"].float(), sd[c + "sequential.2.bias"].float(), sd, c + "sequential.3")
+            L["conv"] = dict(ln_g=put(sd[c + "layer_norm.weight"]), ln_b=put(sd[c + "layer_norm.bias"]),
+                             w_pw1=put(sd[c + "sequential.0.weight"]), b_pw1=put(sd[c + "sequential.0.bias"]),
+                             w_dw=put(wdw.reshape(d, -1)), b_dw=put(bdw),
+                             w_pw2=put(sd[c + "sequential.5.weight"]), b_pw2=put(sd[c + "sequential.5.bias"]))
+            L["final"] = dict(g=put(sd[p + "final_layer_norm.weight"]), b=put(sd[p + "final_layer_norm.bias"]))
+            self.layers.append(L)
+
+    def _ffn(self, x, P):
+        h = _conv(_layernorm(x, P["ln_g"], P["ln_b"]), P["w1"], P["b1"])
+        h = ops.elementwise(13, h, out=h)  # SiLU
+        return ops.axpby(1.0, x, 0.5, _conv(h, P["w2"], P["b2"]))
+
+    def forward(self, x, lens):
+        """x [D, B, T] (padded positions are computed, not masked: the convolution module sees them, as in the reference)."""
+        lib = _lib.load()
+        D, B, T = x.shape
+        for L in self.layers:
+            x = self._ffn(x, L["ffn1"])
+            A = L["attn"]
+            qkv = _conv(_layernorm(x, A["ln_g"], A["ln_b"]), A["w_in"], A["b_in"])
+            att = torch.empty_like(x)
+            _chk(lib.evmi_attention_cbt_f32(qkv.data_ptr(), lens.data_ptr(), att.data_ptr(), B, T, D, self.cfg.heads, _s(x)), "evmi_attention_cbt_f32")
+            x = ops.axpby(1.0, x, 1.0, _conv(att, A["w_out"], A["b_out"]))
+            Cm = L["conv"]
+            p = _conv(_layernorm(x, Cm["ln_g"], Cm["ln_b"]), Cm["w_pw1"], Cm["b_pw1"])
+            g = ops.elementwise(15, p[:D], p[D:])  # GLU over the channel halves
+            h = _dwconv(g, Cm["w_dw"], Cm["b_dw"], self.cfg.conv_kernel_size, 1)  # depthwise + folded BatchNorm + SiLU
+            x = ops.axpby(1.0, x, 1.0, _conv(h, Cm["w_pw2"], Cm["b_pw2"]))
+            x = self._ffn(x, L["ffn2"])
+            x = _layernorm(x, L["final"]["g"], L["final"]["b"])
+        return x
+
+
+class _VariancePredictor:
+    def __init__(self, cfg: VariancePredictorConfig, sd: dict, prefix: str, dev):
+        self.cfg = cfg
+        put = lambda t: t.to(dev, torch.float32).contiguous()
+        self.layers = []
+        d = cfg.input_dim
+        for i in range(cfg.n_layers):
+            p = f"{prefix}.convs.{i}"
+            if cfg.depthwise:
+                conv = dict(w_dw=put(_fold_weight_norm(sd, p + ".0").reshape(d, -1)), b_dw=put(sd[p + ".0.bias"]),
+                            w_pw=put(_fold_weight_norm(sd, p + ".1")), b_pw=put(sd[p + ".1.bias"]))
+            else:
+                conv = dict(w=put(sd[p + ".weight"]), b=put(sd[p + ".bias"]))
+            conv.update(ln_g=put(sd[f"{prefix}.norms.{i}.weight"]), ln_b=put(sd[f"{prefix}.norms.{i}.bias"]))
+            self.layers.append(conv)
+        self.w_lin, self.b_lin = put(sd[prefix + ".linear.weight"].unsqueeze(-1)), put(sd[prefix + ".linear.bias"])
+
+    def forward(self, x, lens):
+        """x [D, B, L] -> [B, L] (zero at padded positions)."""
+        k = self.cfg.kernel_size
+        for P in self.layers:
+            h = _conv(_dwconv(x, P["w_dw"], P["b_dw"], k, 0), P["w_pw"], P["b_pw"]) if self.cfg.depthwise else _conv(x, P["w"], P["b"], k)
+            h = ops.elementwise(14, h, out=h)  # ReLU
+            x = _layernorm(h, P["ln_g"], P["ln_b"])
+        y = _conv(x, self.w_lin, self.b_lin)  # [1, B, L]
+        _chk(_lib.load().evmi_mask_cols_f32(y.data_ptr(), lens.data_ptr(), 1, y.shape[1], y.shape[2], _s(y)), "evmi_mask_cols_f32")
+        return y[0]
+
+
+class FastSpeech2:
+    """``model = FastSpeech2(config, stats); model.load_state_dict(sd); mel, post, durations, pitch, energy, mel_lens = model(ids, lens)``"""
+
+    def __init__(self, config: FastSpeech2ModelConfig | None = None, stats: Stats | None = None, device="cuda:0",
+                 lang2id: dict | None = None, speaker2id: dict | None = None):
+        self.config = config or FastSpeech2ModelConfig()
+        self.stats = stats or Stats()
+        self.device = torch.device(device)
+        self.lang2id, self.speaker2id = lang2id or {}, speaker2id or {}
+        if self.config.multilingual or self.config.multispeaker:
+            raise NotImplementedError("speaker / language embeddings: later round")
+        if self.device.type != "cuda":
+            raise RuntimeError("FastSpeech2 runs on libevmi_hip (MI355X) only; there is no CPU path")
+        _lib.load()
+        self._ready = False
+
+    # -- parameters -----------------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: dict):
+        c, dev = self.config, self.device
+        put = lambda t: t.to(dev, torch.float32).contiguous()
+        self.table = put(sd["text_input_layer.weight"])
+        self.inv_freq = put(sd["position_embedding.inv_freq"])
+        self.encoder = _Conformer(c.encoder, sd, "encoder", dev)
+        self.decoder = _Conformer(c.decoder, sd, "decoder", dev)
+        vp = c.variance_predictors
+        self.duration_predictor = _VariancePredictor(vp.duration, sd, "duration_predictor", dev)
+        self.pitch_predictor = _VariancePredictor(vp.pitch, sd, "pitch_predictor", dev)
+        self.energy_predictor = _VariancePredictor(vp.energy, sd, "energy_predictor", dev)
+        lin = lambda st, n: torch.linspace(st.norm_min, st.norm_max, n - 1)
+        self.pitch_bins = put(sd["pitch_bins"] if "pitch_bins" in sd else lin(self.stats.pitch, vp.pitch.n_bins))
+        self.energy_bins = put(sd["energy_bins"] if "energy_bins" in sd else lin(self.stats.energy, vp.energy.n_bins))
+        self.pitch_table, self.energy_table = put(sd["pitch_embedding.weight"]), put(sd["energy_embedding.weight"])
+        self.w_mel, self.b_mel = put(sd["mel_linear.weight"].unsqueeze(-1)), put(sd["mel_linear.bias"])
+        self.postnet = []
+        if c.use_postnet:
+            for i in range(c.postnet_layers):
+                p = f"postnet.convolutions.{i}"
+                w, b = _fold_bn(sd[p + ".0.weight"].float(), sd[p + ".0.bias"].float(), sd, p + ".1")
+                self.postnet.append((put(w), put(b)))
+        self._ready = True
+        return self
+
+    @staticmethod
+    def state_dict_shapes(c: FastSpeech2ModelConfig) -> dict:
+        """Names and shapes of the state dict (``torchaudio.models.Conformer`` layout for encoder / decoder)."""
+        shapes = {"text_input_layer.weight": (c.n_symbols, c.encoder.input_dim), "position_embedding.inv_freq": (c.encoder.input_dim // 2,)}
+        for name, cf in (("encoder", c.encoder), ("decoder", c.decoder)):
+            d, f, k = cf.input_dim, cf.feedforward_dim, cf.conv_kernel_size
+            for i in range(cf.layers):
+                p = f"{name}.conformer_layers.{i}."
+                for ffn in ("ffn1", "ffn2"):
+                    shapes.update({p + ffn + ".sequential.0.weight": (d,), p + ffn + ".sequential.0.bias": (d,),
+                                   p + ffn + ".sequential.1.weight": (f, d), p + ffn + ".sequential.1.bias": (f,),
+                                   p + ffn + ".sequential.4.weight": (d, f), p + ffn + ".sequential.4.bias": (d,)})
+                shapes.update({p + "self_attn_layer_norm.weight": (d,), p + "self_attn_layer_norm.bias": (d,),
+                               p + "self_attn.in_proj_weight": (3 * d, d), p + "self_attn.in_proj_bias": (3 * d,),
+                               p + "self_attn.out_proj.weight": (d, d), p + "self_attn.out_proj.bias": (d,),
+                               p + "conv_module.layer_norm.weight": (d,), p + "conv_module.layer_norm.bias": (d,),
+                               p + "conv_module.sequential.0.weight": (2 * d, d, 1), p + "conv_module.sequential.0.bias": (2 * d,),
+                               p + "conv_module.sequential.2.weight": (d, 1, k), p + "conv_module.sequential.2.bias": (d,),
+                               p + "conv_module.sequential.3.weight": (d,), p + "conv_module.sequential.3.bias": (d,),
+                               p + "conv_module.sequential.3.running_mean": (d,), p + "conv_module.sequential.3.running_var": (d,),
+                               p + "conv_module.sequential.5.weight": (d, d, 1), p + "conv_module.sequential.5.bias": (d,),
+                               p + "final_layer_norm.weight": (d,), p + "final_layer_norm.bias": (d,)})
+        vp = c.variance_predictors
+        for name, cf in (("duration_predictor", vp.duration), ("pitch_predictor", vp.pitch), ("energy_predictor", vp.energy)):
+            d, k = cf.input_dim, cf.kernel_size
+            for i in range(cf.n_layers):
+                p = f"{name}.convs.{i}"
+                shapes.update({p + ".0.weight_g": (d, 1, 1), p + ".0.weight_v": (d, 1, k), p + ".0.bias": (d,),
+                               p + ".1.weight_g": (d, 1, 1), p + ".1.weight_v": (d, d, 1), p + ".1.bias": (d,),
+                               f"{name}.norms.{i}.weight": (d,), f"{name}.norms.{i}.bias": (d,)})
+            shapes.update({name + ".linear.weight": (1, d), name + ".linear.bias": (1,)})
+        d = c.encoder.input_dim
+        shapes.update({"pitch_embedding.weight": (vp.pitch.n_bins, d), "energy_embedding.weight": (vp.energy.n_bins, d),
+                       "mel_linear.weight": (c.n_mels, c.decoder.input_dim), "mel_linear.bias": (c.n_mels,)})
+        if c.use_postnet:
+            dims = [c.n_mels] + [c.postnet_channels] * (c.postnet_layers - 1) + [c.n_mels]
+            for i in range(c.postnet_layers):
+                p = f"postnet.convolutions.{i}"
+                shapes.update({p + ".0.weight": (dims[i + 1], dims[i], c.postnet_kernel), p + ".0.bias": (dims[i + 1],),
+                               p + ".1.weight": (dims[i + 1],), p + ".1.bias": (dims[i + 1],),
+                               p + ".1.running_mean": (dims[i + 1],), p + ".1.running_var": (dims[i + 1],)})
+        return shapes
+
+    def init_random(self, seed: int = 1234):
+        """Random parameters of the right shapes (benchmarks; there is no network for checkpoints)."""
+        g = torch.Generator().manual_seed(seed)
+        sd = {}
+        for name, shape in self.state_dict_shapes(self.config).items():
+            if name.endswith("inv_freq"):
+                d = self.config.encoder.input_dim
+                sd[name] = 1.0 / (10000 ** (torch.arange(0.0, d, 2.0) / d))
+            elif name.endswith("running_var") or name.endswith("weight_g") or (len(shape) == 1 and name.endswith(".weight")):
+                sd[name] = torch.ones(shape)
+            elif name.endswith("bias") or name.endswith("running_mean"):
+                sd[name] = torch.zeros(shape)
+            else:
+                fan_in = max(1, int(torch.tensor(shape[1:]).prod())) if len(shape) > 1 else shape[0]
+                sd[name] = torch.randn(shape, generator=g) / fan_in ** 0.5
+        return self.load_state_dict(sd)
+
+    # -- forward --------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, ids: torch.Tensor, lens: torch.Tensor, duration_control=1.0, pitch_control=1.0, energy_control=1.0,
+                 durations: torch.Tensor | None = None):
+        """ids [B, L] (0 = padding), lens [B] -> (mel [B, T, n_mels], postnet mel, durations [B, L], pitch [B, L],
+        energy [B, L], mel_lens [B]) on the device."""
+        if not self._ready:
+            raise RuntimeError("load_state_dict() or init_random() first")
+        lib, dev, c = _lib.load(), self.device, self.config
+        B, L = ids.shape
+        if L > c.max_length:
+            raise ValueError(f"text of {L} symbols exceeds max_length {c.max_length}")
+        D = c.encoder.input_dim
+        ids32 = ids.to(dev, torch.int32).contiguous()
+        lens32 = lens.to(dev, torch.int32).contiguous()
+        x = torch.empty(D, B, L, device=dev, dtype=torch.float32)
+        _chk(lib.evmi_fs2_embed_f32(ids32.data_ptr(), lens32.data_ptr(), self.table.data_ptr(), self.inv_freq.data_ptr(), x.data_ptr(),
+                                    B, L, D, _s(x)), "evmi_fs2_embed_f32")
+        x = self.encoder.forward(x, lens32)
+        log_d = self.duration_predictor.forward(x, lens32)
+        pitch = self.pitch_predictor.forward(x, lens32)
+        vp = c.variance_predictors
+        _chk(lib.evmi_fs2_bucket_embed_add_f32(x.data_ptr(), pitch.data_ptr(), self.pitch_bins.data_ptr(), self.pitch_table.data_ptr(),
+                                               vp.pitch.n_bins, B, L, D, float(pitch_control), _s(x)), "evmi_fs2_bucket_embed_add_f32")
+        energy = self.energy_predictor.forward(x, lens32)
+        _chk(lib.evmi_fs2_bucket_embed_add_f32(x.data_ptr(), energy.data_ptr(), self.energy_bins.data_ptr(), self.energy_table.data_ptr(),
+                                               vp.energy.n_bins, B, L, D, float(energy_control), _s(x)), "evmi_fs2_bucket_embed_add_f32")
+        if durations is None:
+            dur = torch.empty(B, L, device=dev, dtype=torch.int32)
+            _chk(lib.evmi_fs2_durations_i32(log_d.data_ptr(), lens32.data_ptr(), dur.data_ptr(), B, L, float(duration_control), _s(x)),
+                 "evmi_fs2_durations_i32")
+        else:
+            pad = torch.arange(L, device=dev)[None, :] >= lens32[:, None]
+            dur = durations.to(dev, torch.int32).clamp_min(0).masked_fill(pad, 0).contiguous()
+        cum = torch.cumsum(dur, 1, dtype=torch.int32).contiguous()
+        mel_lens = cum[:, -1].contiguous()
+        T = int(mel_lens.max())  # the one host sync of the forward: the output length
+        if T <= 0:
+            raise ValueError("all predicted durations are zero")
+        frames = torch.empty(D, B, T, device=dev, dtype=torch.float32)
+        _chk(lib.evmi_length_regulate_cbt_f32(x.data_ptr(), cum.data_ptr(), frames.data_ptr(), D, B, L, T, _s(x)), "evmi_length_regulate_cbt_f32")
+        _chk(lib.evmi_fs2_add_posemb_f32(frames.data_ptr(), mel_lens.data_ptr(), self.inv_freq.data_ptr(), B, T, D, _s(x)), "evmi_fs2_add_posemb_f32")
+        y = self.decoder.forward(frames, mel_lens)
+        mel = _conv(y, self.w_mel, self.b_mel)
+        _chk(lib.evmi_mask_cols_f32(mel.data_ptr(), mel_lens.data_ptr(), c.n_mels, B, T, _s(x)), "evmi_mask_cols_f32")
+        post = mel
+        if self.postnet:
+            h = mel
+            for i, (w, b) in enumerate(self.postnet):
+                h = _conv(h, w, b, c.postnet_kernel)
+                if i < len(self.postnet) - 1:
+                    h = ops.elementwise(ops.EW_TANH, h, out=h)
+            post = ops.axpby(1.0, mel, 1.0, h)
+            _chk(lib.evmi_mask_cols_f32(post.data_ptr(), mel_lens.data_ptr(), c.n_mels, B, T, _s(x)), "evmi_mask_cols_f32")
+        to_btc = lambda t: t.permute(1, 2, 0).contiguous()
+        mult = lambda v, s: v if s == 1.0 else v * s
+        return to_btc(mel), to_btc(post), dur.to(torch.int64), mult(pitch, pitch_control), mult(energy, energy_control), mel_lens.to(torch.int64)

@@ -239,7 +239,7 @@ int evmi_bias_add_rows_f32(float* y_dev, const float* bias_dev, int rows, long l
 int evmi_row_reduce_f32(int mode, const float* a_dev, const float* b_dev, float* out_dev, int rows,
                         long long n_per_row, float scale, int accumulate, void* stream);
 /* Elementwise ops (op codes documented in csrc/train_ops.hip: leaky-relu / tanh and their
- * derivatives, axpby, products, L1 / LSGAN loss derivatives, log-clamp and the mel-loss chain). */
+ * derivatives, axpby, products, L1 / LSGAN loss derivatives, log-clamp, the mel-loss chain, SiLU / ReLU / GLU). */
 int evmi_elementwise_f32(int op, const float* a_dev, const float* b_dev, const float* c_dev,
                          float* y_dev, long long n, float p0, float p1, void* stream);
 /* out[0] (+)= scale * sum f;  mode 0: |a-b|, 1: (a-p)^2, 2: a   (fixed order: reproducible). */
@@ -265,6 +265,47 @@ int evmi_normalize_vec_f32(const float* x_dev, float* y_dev, int n, float eps, v
 /* torch.optim.AdamW step `step` (1-based) on a flat parameter buffer. */
 int evmi_adamw_f32(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------
+ * FastSpeech2 feature-prediction forward path, channel-major fp32 x[c][b][t].
+ * The reference keeps these inside the absent submodule FastSpeech2_lightning (package fs2); call
+ * sites: everyvoice/tests/model_stubs.py:44-58 (constructor), everyvoice/demo/app.py:84-106
+ * (synthesize_helper).  Linear / pointwise / postnet convolutions go through evmi_conv1d_cbt_f32.
+ * ------------------------------------------------------------------------------------------ */
+/* out[c][b][l] = l < lens[b] ? table[ids[b][l]][c] + pe(l, c) : 0, pe = cat(sin(l*inv_freq), cos(l*inv_freq))
+ * (`position_embedding.inv_freq` [D/2] is the tensor everyvoice/tests/data/test.ckpt holds). */
+int evmi_fs2_embed_f32(const int* ids_dev, const int* lens_dev, const float* table_dev,
+                       const float* inv_freq_dev, float* out_dev, int B, int L, int D, void* stream);
+/* x[c][b][t] = t < lens[b] ? x + pe(t, c) : 0   (decoder input). */
+int evmi_fs2_add_posemb_f32(float* x_dev, const int* lens_dev, const float* inv_freq_dev, int B, int T,
+                            int D, void* stream);
+/* x[c][b][t] = 0 for t >= lens[b]. */
+int evmi_mask_cols_f32(float* x_dev, const int* lens_dev, int C, int B, int T, void* stream);
+/* LayerNorm over the channel axis of every column (biased variance, eps inside the root). */
+int evmi_layernorm_cbt_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
+                           int C, long long n_cols, float eps, void* stream);
+/* Depthwise Conv1d(C, C, k, groups=C, padding=pad) per item, act: 0 none, 1 SiLU, 2 ReLU
+ * (the conformer's convolution module with its eval-mode BatchNorm folded into w / bias; the depthwise half
+ * of everyvoice/model/utils.py:5-48). */
+int evmi_dwconv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, int C,
+                          int B, int T, int k, int pad, int act, void* stream);
+/* x[c][b][l] += table[bucketize(values[b][l] * control, bins)][c]  (pitch / energy embeddings; bins has
+ * n_bins - 1 boundaries, torch.bucketize semantics). */
+int evmi_fs2_bucket_embed_add_f32(float* x_dev, const float* values_dev, const float* bins_dev,
+                                  const float* table_dev, int n_bins, int B, int L, int D, float control,
+                                  void* stream);
+/* dur[b][l] = l < lens[b] ? max(0, round_half_even(exp(log_d) - 1) * control) : 0. */
+int evmi_fs2_durations_i32(const float* log_d_dev, const int* lens_dev, int* dur_dev, int B, int L,
+                           float control, void* stream);
+/* Length regulator in this layout (everyvoice/utils/heavy.py:12-21 per item, zero padded to T):
+ * out[c][b][t] = x[c][b][token(b, t)], cum = inclusive prefix sums of the integer durations [B][L]. */
+int evmi_length_regulate_cbt_f32(const float* x_dev, const int* cum_dev, float* out_dev, int C, int B, int L,
+                                 int T, void* stream);
+/* Multi-head self-attention with key padding mask from lens: qkv [3*D][B][T] -> out [D][B][T]
+ * (softmax(Q K^T / sqrt(d_head)) V per head; fp32 matrix cores, online softmax; d_head 32 / 64 / 128). */
+int evmi_attention_cbt_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, int B, int T, int D,
+                           int heads, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,150 @@
+"""FastSpeech2 forward path (csrc/fs2_ops.hip + the fp32 matrix-core GEMM) against the torch-CPU oracle.
+
+Tolerances: fp32 everywhere; the only differences are summation order and expf / sinf implementations, so activations agree
+to ~1e-5 relative; 2e-4 (relative to the tensor's largest entry) leaves room for 8 conformer layers of accumulation.
+Durations are integers: with durations given they must be bit-exact; predicted ones are compared where exp(log_d) - 1 is
+not within 1e-3 of a rounding boundary."""
+
+import pytest
+import torch
+
+from oracle.fs2_ref import FastSpeech2ConfigRef, FastSpeech2Ref, randomize_norm_stats_
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, rel=2e-4):
+    scale = float(want.abs().max()) + 1e-12
+    err = float((got - want).abs().max())
+    assert err <= rel * scale, f"err {err:.3e} vs scale {scale:.3e}"
+
+
+def _product_config(ref_cfg):
+    from everyvoice_amd.fs2 import ConformerConfig, FastSpeech2ModelConfig, VariancePredictorConfig, VariancePredictors
+
+    conf = lambda c: ConformerConfig(layers=c.layers, heads=c.heads, input_dim=c.input_dim, feedforward_dim=c.feedforward_dim,
+                                     conv_kernel_size=c.conv_kernel_size, dropout=c.dropout)
+    vpc = lambda v: VariancePredictorConfig(n_layers=v.n_layers, kernel_size=v.kernel_size, input_dim=v.input_dim, n_bins=v.n_bins,
+                                            depthwise=v.depthwise, level=v.level)
+    return FastSpeech2ModelConfig(encoder=conf(ref_cfg.encoder), decoder=conf(ref_cfg.decoder),
+                                  variance_predictors=VariancePredictors(energy=vpc(ref_cfg.energy), duration=vpc(ref_cfg.duration), pitch=vpc(ref_cfg.pitch)),
+                                  n_symbols=ref_cfg.n_symbols, n_mels=ref_cfg.n_mels, use_postnet=ref_cfg.use_postnet,
+                                  postnet_channels=ref_cfg.postnet_channels, postnet_kernel=ref_cfg.postnet_kernel,
+                                  postnet_layers=ref_cfg.postnet_layers)
+
+
+def _models(ref_cfg, cuda_device, seed):
+    from everyvoice_amd.fs2 import FastSpeech2
+
+    torch.manual_seed(seed)
+    ref = FastSpeech2Ref(ref_cfg).eval()
+    g = torch.Generator().manual_seed(seed + 1)
+    randomize_norm_stats_(ref, g)
+    with torch.no_grad():  # livelier than the default init: biases and embeddings that matter
+        for n, p in ref.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    model = FastSpeech2(_product_config(ref_cfg), device=cuda_device).load_state_dict(ref.state_dict())
+    return ref, model
+
+
+def _batch(n_symbols, B, L, seed, lens=None):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.tensor(lens) if lens is not None else torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+    lens[0] = L
+    ids = torch.randint(1, n_symbols, (B, L), generator=g)
+    ids = ids.masked_fill(torch.arange(L)[None] >= lens[:, None], 0)
+    return ids, lens, g
+
+
+@pytest.mark.parametrize("B,L", [(3, 12), (1, 5), (4, 33)])
+def test_fs2_small_given_durations(cuda_device, B, L):
+    ref, model = _models(FastSpeech2ConfigRef.small(), cuda_device, seed=B * 100 + L)
+    ids, lens, g = _batch(20, B, L, seed=7)
+    durs = torch.randint(0, 6, (B, L), generator=g)
+    durs[:, 0] += 1
+    want = ref(ids, lens, durations=durs)
+    got = model(ids, lens, durations=durs)
+    assert torch.equal(got[2].cpu(), want[2])          # durations: integers, bit-exact
+    assert torch.equal(got[5].cpu(), want[5])          # mel lengths
+    _close(got[3].cpu(), want[3])                      # pitch
+    _close(got[4].cpu(), want[4])                      # energy
+    _close(got[0].cpu(), want[0])                      # decoder mel
+    _close(got[1].cpu(), want[1])                      # postnet mel
+    fpad = torch.arange(got[1].shape[1])[None, :] >= want[5][:, None]  # padded frames are exactly zero
+    assert float(got[1].cpu()[fpad].abs().sum()) == 0.0 and float(got[0].cpu()[fpad].abs().sum()) == 0.0
+
+
+def test_fs2_small_predicted_durations_and_controls(cuda_device):
+    ref, model = _models(FastSpeech2ConfigRef.small(), cuda_device, seed=5)
+    with torch.no_grad():
+        ref.duration_predictor.linear.bias.fill_(1.2)  # durations of a few frames instead of 0
+    model.load_state_dict(ref.state_dict())
+    ids, lens, _ = _batch(20, 3, 14, seed=9)
+    kw = dict(duration_control=1.0, pitch_control=1.3, energy_control=0.8)
+    want = ref(ids, lens, **kw)
+    # the oracle's log-durations, to know which tokens sit on a rounding boundary
+    pad = torch.arange(14)[None] >= lens[:, None]
+    x = ref.text_input_layer(ids) + ref.position_embedding(14)[None]
+    x, _ = ref.encoder(x.masked_fill(pad[..., None], 0.0), lens)
+    raw = torch.exp(ref.duration_predictor(x, pad)) - 1.0
+    safe = ((raw - torch.floor(raw) - 0.5).abs() > 1e-3) | pad
+    got = model(ids, lens, **kw)
+    assert safe.all(), "test input sits on a rounding boundary: pick another seed"
+    assert torch.equal(got[2].cpu(), want[2])
+    _close(got[3].cpu(), want[3])
+    _close(got[4].cpu(), want[4])
+    _close(got[1].cpu(), want[1])
+
+
+def test_fs2_default_config(cuda_device):
+    """The reference's default sizes (conformer 4 x 256 / 1024 / k9, 2 heads of 128; predictors 5 x k3; postnet 5 x 512)."""
+    ref, model = _models(FastSpeech2ConfigRef(), cuda_device, seed=3)
+    ids, lens, g = _batch(80, 2, 40, seed=11, lens=[40, 23])
+    durs = torch.randint(2, 9, (2, 40), generator=g)
+    want = ref(ids, lens, durations=durs)
+    got = model(ids, lens, durations=durs)
+    assert torch.equal(got[5].cpu(), want[5])
+    _close(got[0].cpu(), want[0], rel=5e-4)
+    _close(got[1].cpu(), want[1], rel=5e-4)
+
+
+def test_attention_kernel_alone(cuda_device):
+    """evmi_attention_cbt_f32 vs torch scaled-dot-product attention with a key padding mask, ragged lengths, T not a multiple of 32."""
+    from everyvoice_amd import _lib
+
+    g = torch.Generator().manual_seed(2)
+    for (B, T, D, H) in ((2, 50, 64, 2), (3, 200, 256, 2), (1, 33, 128, 2)):
+        qkv = torch.randn(3 * D, B, T, generator=g)
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        lens[0] = T
+        q, k, v = [t.view(H, D // H, B, T).permute(2, 0, 3, 1) for t in qkv.split(D)]  # [B, H, T, dh]
+        mask = (torch.arange(T)[None] >= lens[:, None])[:, None, None, :]
+        s = (q @ k.transpose(-1, -2)) / (D // H) ** 0.5
+        want = (s.masked_fill(mask, float("-inf")).softmax(-1) @ v).permute(1, 3, 0, 2).reshape(D, B, T)
+        qd, ld = qkv.to(cuda_device), lens.to(cuda_device, torch.int32)
+        out = torch.empty(D, B, T, device=cuda_device)
+        _lib.check(_lib.load().evmi_attention_cbt_f32(qd.data_ptr(), ld.data_ptr(), out.data_ptr(), B, T, D, H,
+                                                      torch.cuda.current_stream().cuda_stream), "attention")
+        torch.testing.assert_close(out.cpu(), want, rtol=2e-5, atol=2e-5)
+
+
+def test_fs2_against_committed_golden(cuda_device):
+    """The committed fixture (inputs, parameters and the oracle's outputs) through the HIP path."""
+    import numpy as np
+
+    from pathlib import Path
+
+    from everyvoice_amd.fs2 import FastSpeech2
+
+    z = np.load(Path(__file__).parent / "golden" / "fs2_small.npz")
+    sd = {k[len("param:"):]: torch.from_numpy(z[k].astype(np.float32) if z[k].dtype == np.float16 else z[k]) for k in z.files if k.startswith("param:")}
+    model = FastSpeech2(_product_config(FastSpeech2ConfigRef.small()), device=cuda_device).load_state_dict(sd)
+    ids, lens = torch.from_numpy(z["ids"]), torch.from_numpy(z["lens"])
+    tf = model(ids, lens, durations=torch.from_numpy(z["given_durations"]))
+    free = model(ids, lens, duration_control=1.0, pitch_control=1.2, energy_control=0.9)
+    for tag, o in (("tf", tf), ("free", free)):
+        assert torch.equal(o[2].cpu(), torch.from_numpy(z[f"{tag}_durations"]))
+        assert torch.equal(o[5].cpu(), torch.from_numpy(z[f"{tag}_mel_lens"]))
+        _close(o[1].cpu(), torch.from_numpy(z[f"{tag}_post"]))
+        _close(o[3].cpu(), torch.from_numpy(z[f"{tag}_pitch"]))

@@ -1,0 +1,69 @@
+"""CPU: the FastSpeech2 oracle against its committed golden vectors (tests/golden/fs2_small.npz, made by
+tests/golden/make_fs2_golden.py), the pieces the reference tree does pin, and the host-side model description."""
+
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.fs2_ref import FastSpeech2ConfigRef, FastSpeech2Ref, PositionalEmbeddingRef
+
+GOLD = Path(__file__).parent / "golden" / "fs2_small.npz"
+
+
+def load_golden_model():
+    z = np.load(GOLD)
+    m = FastSpeech2Ref(FastSpeech2ConfigRef.small()).eval()
+    sd = {k[len("param:"):]: torch.from_numpy(z[k].astype(np.float32) if z[k].dtype == np.float16 else z[k]) for k in z.files if k.startswith("param:")}
+    m.load_state_dict(sd)
+    return z, m
+
+
+def test_oracle_reproduces_golden():
+    z, m = load_golden_model()
+    ids, lens = torch.from_numpy(z["ids"]), torch.from_numpy(z["lens"])
+    tf = m(ids, lens, durations=torch.from_numpy(z["given_durations"]))
+    free = m(ids, lens, duration_control=1.0, pitch_control=1.2, energy_control=0.9)
+    for tag, o in (("tf", tf), ("free", free)):
+        for name, t in zip(("mel", "post", "durations", "pitch", "energy", "mel_lens"), o):
+            want = torch.from_numpy(z[f"{tag}_{name}"])
+            if want.dtype in (torch.int64, torch.int32):
+                assert torch.equal(t, want), (tag, name)
+            else:
+                torch.testing.assert_close(t, want, rtol=1e-5, atol=1e-6)
+
+
+def test_length_regulation_inside_the_model_is_expand():
+    """Frames of one item = its tokens repeated by the durations (everyvoice/utils/heavy.py:12-21), zero padded."""
+    z, m = load_golden_model()
+    d = torch.from_numpy(z["given_durations"]).masked_fill(torch.arange(14)[None] >= torch.from_numpy(z["lens"])[:, None], 0)
+    assert torch.equal(torch.from_numpy(z["tf_mel_lens"]), d.sum(1))
+    assert z["tf_mel"].shape[1] == int(d.sum(1).max())
+
+
+def test_positional_embedding_matches_reference_checkpoint_buffer():
+    """`position_embedding.inv_freq` is the one tensor everyvoice/tests/data/test.ckpt holds: 10000^(-2i/256), i < 128."""
+    inv = PositionalEmbeddingRef(256).inv_freq
+    assert inv.shape == (128,)
+    want = torch.tensor([1.0 / 10000 ** (2 * i / 256) for i in range(128)])
+    torch.testing.assert_close(inv, want, rtol=1e-6, atol=0)
+    ref = Path("/root/reference/everyvoice/tests/data/test.ckpt")
+    if ref.exists():  # only in the build container
+        ck = torch.load(ref, map_location="cpu", weights_only=False)
+        torch.testing.assert_close(inv, ck["state_dict"]["position_embedding.inv_freq"], rtol=1e-6, atol=0)
+
+
+def test_default_sizes_follow_the_reference_schema():
+    c = FastSpeech2ConfigRef()
+    assert (c.encoder.layers, c.encoder.heads, c.encoder.input_dim, c.encoder.feedforward_dim, c.encoder.conv_kernel_size) == (4, 2, 256, 1024, 9)
+    assert (c.pitch.n_layers, c.pitch.kernel_size, c.pitch.n_bins, c.pitch.depthwise) == (5, 3, 256, True)
+
+
+def test_product_state_dict_description_matches_oracle():
+    """everyvoice_amd.fs2 describes the same parameter names and shapes as the oracle module (no GPU needed)."""
+    from everyvoice_amd.fs2 import FastSpeech2, FastSpeech2ModelConfig
+
+    shapes = FastSpeech2.state_dict_shapes(FastSpeech2ModelConfig())
+    ref = {k: tuple(v.shape) for k, v in FastSpeech2Ref().state_dict().items() if not k.endswith("num_batches_tracked") and not k.endswith("_bins")}
+    assert shapes == ref
