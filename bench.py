@@ -52,6 +52,7 @@ def parse_args(argv=None):
     p.add_argument("--cpu-batch", type=int, default=16, help="items of the bench batch the CPU baseline runs (10-20 s of CPU work)")
     p.add_argument("--profile-passes", type=int, default=3)
     p.add_argument("--no-train", action="store_true", help="skip the GAN-training leg (second half of the metric)")
+    p.add_argument("--no-fs2", action="store_true", help="skip the FastSpeech2 feature-prediction inference leg")
     p.add_argument("--train-steps", type=int, default=6)
     p.add_argument("--train-warmup", type=int, default=2)
     return p.parse_args(argv)
@@ -236,6 +237,28 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     }
 
 
+def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
+    """FastSpeech2 feature prediction, inference: text ids -> mel on an LJSpeech-shaped synthetic
+    batch (8d C3 shapes: B = 32, L ~ N(99.9, 34) in [12, 187], T ~ 5.67 L, durations given so the length is fixed),
+    default model sizes, random parameters.  fp32 on the fp32 matrix cores.  Replicas only across GPUs."""
+    import torch
+
+    from everyvoice_amd.fs2 import FastSpeech2
+    sys.path.insert(0, str(ROOT / "tools"))
+    from fs2_bench import synthetic_batch
+
+    model = FastSpeech2(device=dev).init_random(1234)
+    ids, lens, durs, t_i = synthetic_batch(32, 1234 + rank)
+    ids, lens, durs = ids.to(dev), lens.to(dev), durs.to(dev)
+    steps, warmup = 10, 3
+    elapsed = timed_region(lambda: model(ids, lens, durations=durs), steps, warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    frames = int(t_i.sum())
+    return {"metric": "fastspeech2_infer_mel_frames_per_sec", "value": round(world * frames * steps / elapsed, 1), "unit": "frames/s",
+            "ms_per_batch": round(elapsed / steps * 1e3, 3), "batch": 32, "max_tokens": int(ids.shape[1]), "frames_per_batch": frames,
+            "dtype": "f32", "steps": steps, "warmup": warmup, "parallelism": f"replicas x{world}",
+            "realtime_factor": round(world * frames * 256 / 22050.0 * steps / elapsed, 1)}
+
+
 def main(argv=None) -> int:
     args = parse_args(argv)
     import torch
@@ -284,6 +307,7 @@ def main(argv=None) -> int:
     train = None
     if not args.no_train:
         train = train_leg(args, dev, rank, world, use_dist, barrier, max_reduce)
+    fs2 = None if args.no_fs2 else fs2_leg(args, dev, rank, world, barrier, max_reduce)
 
     result = None
     if rank == 0:
@@ -326,6 +350,8 @@ def main(argv=None) -> int:
         }
         if train is not None:
             result["train"] = train
+        if fs2 is not None:
+            result["fs2"] = fs2
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_batch)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)

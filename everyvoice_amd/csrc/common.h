@@ -93,4 +93,24 @@ inline uint16_t f32_to_bf16_bits(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// wait until at most n (wave-uniform) vector-memory operations of this wave are outstanding
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+  n = __builtin_amdgcn_readfirstlane(n);
+#define EVMI_VMCASE(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    EVMI_VMCASE(0) EVMI_VMCASE(1) EVMI_VMCASE(2) EVMI_VMCASE(3) EVMI_VMCASE(4) EVMI_VMCASE(5) EVMI_VMCASE(6)
+    EVMI_VMCASE(7) EVMI_VMCASE(8) EVMI_VMCASE(9) EVMI_VMCASE(10) EVMI_VMCASE(11) EVMI_VMCASE(12) EVMI_VMCASE(13)
+    EVMI_VMCASE(14) EVMI_VMCASE(15) EVMI_VMCASE(16) EVMI_VMCASE(17) EVMI_VMCASE(18) EVMI_VMCASE(19) EVMI_VMCASE(20)
+    EVMI_VMCASE(21) EVMI_VMCASE(22) EVMI_VMCASE(23) EVMI_VMCASE(24) EVMI_VMCASE(25) EVMI_VMCASE(26) EVMI_VMCASE(27)
+    EVMI_VMCASE(28) EVMI_VMCASE(29) EVMI_VMCASE(30) EVMI_VMCASE(31) EVMI_VMCASE(32) EVMI_VMCASE(33) EVMI_VMCASE(34)
+    EVMI_VMCASE(35) EVMI_VMCASE(36) EVMI_VMCASE(37) EVMI_VMCASE(38) EVMI_VMCASE(39) EVMI_VMCASE(40) EVMI_VMCASE(41)
+    EVMI_VMCASE(42) EVMI_VMCASE(43) EVMI_VMCASE(44) EVMI_VMCASE(45) EVMI_VMCASE(46) EVMI_VMCASE(47) EVMI_VMCASE(48)
+    EVMI_VMCASE(49) EVMI_VMCASE(50) EVMI_VMCASE(51) EVMI_VMCASE(52) EVMI_VMCASE(53) EVMI_VMCASE(54) EVMI_VMCASE(55)
+    EVMI_VMCASE(56) EVMI_VMCASE(57) EVMI_VMCASE(58) EVMI_VMCASE(59) EVMI_VMCASE(60) EVMI_VMCASE(61) EVMI_VMCASE(62)
+    default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+  }
+#undef EVMI_VMCASE
+}
+
+
 }  // namespace evmi

@@ -55,22 +55,45 @@ __global__ void mask_cols_kernel(float* __restrict__ x, const int* __restrict__ 
   if (t >= lens[b]) x[i] = 0.f;
 }
 
-// ---- LayerNorm over channels: one thread per column, two passes (columns are contiguous across threads) --------------
+// ---- LayerNorm over channels ---------------------------------------------------------------------------------------
+// Workgroup = 64 columns x 4 channel slices: every thread keeps its slice of one column in registers (one global
+// read, one write), the four partial sums / squared deviations meet in LDS.  Columns are contiguous across lanes.
+template <int CPT>  // channels per thread, C <= 4 * CPT
 __global__ __launch_bounds__(256) void layernorm_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ y, int C,
                                                            long long N, float eps) {
-  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const long long n = (long long)blockIdx.x * 64 + lane;
+  const bool live = n < N;
+  const int per = (C + 3) >> 2, c0 = slice * per, c1 = min(C, c0 + per);
+  float v[CPT];
   float s = 0.f;
-  for (int c = 0; c < C; ++c) s += x[(long long)c * N + n];
-  const float mean = s / (float)C;
-  float v = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float d = x[(long long)c * N + n] - mean;
-    v = fmaf(d, d, v);
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = c0 + i;
+    v[i] = (live && c < c1) ? x[(long long)c * N + n] : 0.f;
+    s += v[i];
   }
-  const float rstd = 1.f / sqrtf(v / (float)C + eps);
-  for (int c = 0; c < C; ++c) y[(long long)c * N + n] = (x[(long long)c * N + n] - mean) * rstd * gamma[c] + beta[c];
+  red[0][slice][lane] = s;
+  __syncthreads();
+  const float mean = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const float d = (c0 + i < c1) ? v[i] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  red[1][slice][lane] = q;
+  __syncthreads();
+  const float var = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = c0 + i;
+    if (c < c1) y[(long long)c * N + n] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+  }
 }
 
 // ---- depthwise conv: y[c][b][t] = act(bias[c] + sum_j w[c][j] * x[c][b][t + j - pad]) ---------------------------------
@@ -261,8 +284,12 @@ int evmi_layernorm_cbt_f32(const float* x_dev, const float* gamma_dev, const flo
                            float eps, void* stream) {
   EVMI_NONNULL(x_dev && gamma_dev && beta_dev && y_dev, "layernorm_cbt");
   if (C <= 0 || n_cols <= 0) return fail(EVMI_ERR_INVALID_ARG, "layernorm_cbt: shape");
-  hipLaunchKernelGGL(layernorm_cbt_kernel, grid1d(n_cols), dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, y_dev, C,
-                     n_cols, eps);
+  const dim3 grid((unsigned)((n_cols + 63) / 64));
+  hipStream_t s = (hipStream_t)stream;
+  if (C <= 64) hipLaunchKernelGGL(layernorm_cbt_kernel<16>, grid, dim3(256), 0, s, x_dev, gamma_dev, beta_dev, y_dev, C, n_cols, eps);
+  else if (C <= 256) hipLaunchKernelGGL(layernorm_cbt_kernel<64>, grid, dim3(256), 0, s, x_dev, gamma_dev, beta_dev, y_dev, C, n_cols, eps);
+  else if (C <= 1024) hipLaunchKernelGGL(layernorm_cbt_kernel<256>, grid, dim3(256), 0, s, x_dev, gamma_dev, beta_dev, y_dev, C, n_cols, eps);
+  else return fail(EVMI_ERR_UNSUPPORTED, "layernorm_cbt: more than 1024 channels");
   EVMI_LAUNCH_CHECK("layernorm_cbt");
   return EVMI_OK;
 }

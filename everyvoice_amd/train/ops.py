@@ -159,7 +159,7 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
     return dx
 
 
-CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma"}  # "gemm": unfold + rocBLAS (kept for A/B and as the reference variant)
+CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma", "wgrad": "mfma"}  # "gemm": unfold + rocBLAS (kept for A/B and as the reference variant)
 
 
 def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bool:
@@ -198,12 +198,18 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
     dw = db = None
     if need_dw:
         dw = dw_out if dw_out is not None else torch.empty_like(w)
-        dwm = dw.view(cout, cin_g * k)
-        col, _ = unfold(x, k, stride, pad, dil)
-        beta = 1.0 if accumulate else 0.0
-        kg = cin_g * k
-        # dW_g [cout_g, kg] (+)= dY_g [cout_g, N] . col_g^T
-        gemm_groups(dy, col, dw, groups, cout_g, kg, N, N, N, kg, cout_g * N, kg * N, cout_g * kg, tb=True, beta=beta)
+        lib = _lib.load()
+        ws_elems = lib.evmi_conv1d_wgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) if CONV_BACKEND["wgrad"] == "mfma" else 0
+        if ws_elems > 0:  # implicit GEMM on the fp32 matrix cores (conv_wgrad_f32_mfma.hip)
+            ws = WS.get("wgrad", ws_elems, x.device)
+            _chk(lib.evmi_conv1d_wgrad_cbt_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
+                                               k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_f32")
+        else:
+            col, _ = unfold(x, k, stride, pad, dil)
+            beta = 1.0 if accumulate else 0.0
+            kg = cin_g * k
+            # dW_g [cout_g, kg] (+)= dY_g [cout_g, N] . col_g^T
+            gemm_groups(dy, col, dw, groups, cout_g, kg, N, N, N, kg, cout_g * N, kg * N, cout_g * kg, tb=True, beta=beta)
         if db_out is not None:
             db = row_reduce(0, dy, None, db_out, cout, N, accumulate=accumulate)
     dx = None

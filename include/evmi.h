@@ -219,6 +219,16 @@ int evmi_conv1d_cbt_f32_supported(int B, int c_in, int t_in, int c_out, int n_ou
  * MFMA-fragment copy of the weights (re-laid on the stream before every convolution: the weights change every
  * optimiser step), or the channel-split scratch of the few-output-channel kernel. */
 long long evmi_conv1d_cbt_f32_ws_elems(int B, int c_in, int c_out, int n_out, int k, int groups);
+/* Weight gradient of the same convolution as an implicit GEMM on the fp32 matrix cores (no unfold):
+ *   dw[co][ci][j] (+)= sum_{b,to} dy[co][b][to] * x[ci][b][to*stride + j*dil - pad]
+ * x [c_in][B][t_in], dy [c_out][B][n_out], dw [c_out][c_in/groups][k]; `ws_dev`: 16-byte aligned scratch of
+ * evmi_conv1d_wgrad_cbt_f32_ws_elems floats (padded operand copies and split-K partial tiles; 0 = shape not supported,
+ * use unfold + evmi_gemm_f32). */
+long long evmi_conv1d_wgrad_cbt_f32_ws_elems(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride,
+                                             int pad, int dil, int groups);
+int evmi_conv1d_wgrad_cbt_f32(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev,
+                              long long ws_elems, int B, int c_in, int t_in, int c_out, int n_out, int k,
+                              int stride, int pad, int dil, int groups, int accumulate, void* stream);
 /* Weights of the stride-1 convolution that yields phase `phi` of a convolution's input gradient:
  * wt[c_in][c_out/groups][M], M = ceil((k - phi) / stride), wt[g*cin_g+ci][co][m] = w[g*cout_g+co][ci][phi + stride*(M-1-m)]. */
 int evmi_dgrad_weights_f32(const float* w_dev, float* wt_dev, int c_in, int c_out, int k, int groups,

@@ -187,3 +187,44 @@ def test_stft_frames_and_adjoint(cuda_device):
     want.backward(d)
     dx = ops.stft_frames_bwd(d.to(cuda_device), B, T, n_fft, hop)
     torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-5, atol=1e-5)
+
+
+WGRAD_CASES = [
+    # (B, T, cin, cout, k, stride, pad, dil, groups)
+    (16, 300, 128, 128, 11, 1, 25, 5, 1),     # generator resblock: split over workgroups along the contraction
+    (176, 10, 96, 160, 5, 1, 2, 1, 1),        # period discriminator tail: rows of 10 samples, several items per step, ragged M tile
+    (22, 28, 64, 96, 5, 3, 2, 1, 1),          # strided (k,1) convolution on short rows
+    (4, 513, 64, 128, 41, 4, 20, 1, 16),      # scale discriminator: grouped, stride 4, odd length
+    (3, 65, 40, 1, 3, 1, 1, 1, 1),            # logit convolution (one output channel)
+    (5, 333, 1, 32, 15, 1, 7, 1, 1),          # first layer (one input channel)
+    (2, 1000, 32, 32, 3, 1, 1, 1, 1),         # 42 channels per column tile would exceed cin: clipped tile
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv1d_wgrad_mfma(cuda_device, case):
+    """Implicit-GEMM weight gradient vs torch autograd (fp32 fmaf chains; only the summation order differs)."""
+    from everyvoice_amd import _lib
+    from everyvoice_amd.train import ops
+
+    B, T, cin, cout, k, s, p, d, groups = case
+    g = torch.Generator().manual_seed(B * 7 + T)
+    x = torch.randn(B, cin, T, generator=g)
+    w = (torch.randn(cout, cin // groups, k, generator=g) * 0.2).requires_grad_()
+    y = F.conv1d(x, w, None, s, p, d, groups)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    lib = _lib.load()
+    n_out = y.shape[2]
+    ws_elems = lib.evmi_conv1d_wgrad_cbt_f32_ws_elems(B, cin, T, cout, n_out, k, s, p, d, groups)
+    assert ws_elems > 0
+    xd, dyd = cbt(x).to(cuda_device), cbt(dy).to(cuda_device)
+    ws = torch.empty(ws_elems, device=cuda_device)
+    base = torch.randn(w.shape, generator=g)
+    for accumulate in (0, 1):
+        dw = base.clone().to(cuda_device)
+        _lib.check(lib.evmi_conv1d_wgrad_cbt_f32(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, T, cout, n_out,
+                                                 k, s, p, d, groups, accumulate, torch.cuda.current_stream().cuda_stream), "wgrad")
+        want = w.grad + (base if accumulate else 0)
+        scale = float(w.grad.abs().max())
+        assert float((dw.cpu() - want).abs().max()) <= 2e-5 * scale + 1e-6, case

@@ -13,8 +13,8 @@ from everyvoice_amd.train.hifigan import HiFiGANTrainer  # noqa: E402
 import os  # noqa: E402
 from everyvoice_amd.train import ops  # noqa: E402
 if os.environ.get("EVMI_CONV_BACKEND"):  # e.g. "mfma,mfma" / "gemm,gemm" / "mfma,gemm"
-    f, dgr = os.environ["EVMI_CONV_BACKEND"].split(",")
-    ops.CONV_BACKEND.update(fwd=f, dgrad=dgr)
+    parts = os.environ["EVMI_CONV_BACKEND"].split(",")
+    ops.CONV_BACKEND.update(fwd=parts[0], dgrad=parts[1], wgrad=parts[2] if len(parts) > 2 else "mfma")
 dev = torch.device("cuda:0")
 B, S = 16, 8192
 g = torch.Generator().manual_seed(1234)
