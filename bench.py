@@ -191,13 +191,78 @@ def cpu_baseline(frames: int, batch: int) -> dict:
     }
 
 
+def cpu_baseline_train(cores: int, batch: int = 16) -> dict:
+    """One full GAN step (D step, then G step, AdamW on both) of the torch-CPU oracle on `batch` 8192-sample segments;
+    steps/s scaled to the bench's 16 segments per step (the step is linear in the batch)."""
+    import torch
+    import torch.nn.functional as F
+
+    from oracle import mel_ref
+    from oracle.hifigan_ref import (GeneratorRef, MultiPeriodDiscriminatorRef, MultiScaleDiscriminatorRef, discriminator_loss_ref,
+                                    feature_loss_ref, generator_loss_ref)
+
+    torch.manual_seed(1234)
+    torch.set_num_threads(cores)
+    g, mpd, msd = GeneratorRef().train(), MultiPeriodDiscriminatorRef().train(), MultiScaleDiscriminatorRef().train()
+    kw = dict(lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
+    opt_g = torch.optim.AdamW(g.parameters(), **kw)
+    opt_d = torch.optim.AdamW(list(mpd.parameters()) + list(msd.parameters()), **kw)
+    y = 0.3 * torch.tanh(torch.randn(batch, 1, 8192))
+    mel = mel_ref.mel_spectrogram_ref(y.squeeze(1))[:, :, :32]
+
+    def step():
+        y_hat = g(mel)
+        opt_d.zero_grad()
+        r1, g1, _, _ = mpd(y, y_hat.detach())
+        r2, g2, _, _ = msd(y, y_hat.detach())
+        (discriminator_loss_ref(r1, g1) + discriminator_loss_ref(r2, g2)).backward()
+        opt_d.step()
+        opt_g.zero_grad()
+        loss_mel = F.l1_loss(mel_ref.mel_spectrogram_ref(y.squeeze(1)), mel_ref.mel_spectrogram_ref(y_hat.squeeze(1))) * 45
+        _, g1, fr1, fg1 = mpd(y, y_hat)
+        _, g2, fr2, fg2 = msd(y, y_hat)
+        (generator_loss_ref(g1) + generator_loss_ref(g2) + feature_loss_ref(fr1, fg1) + feature_loss_ref(fr2, fg2) + loss_mel).backward()
+        opt_g.step()
+
+    step()
+    t0 = time.perf_counter()
+    step()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch / 16.0 / dt, 4), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/hifigan_ref.py full GAN step (torch autograd + AdamW) on {batch} segments of 8192 samples, {cores} threads: "
+                      f"{dt:.2f} s; scaled to 16 segments per step"}
+
+
+def cpu_baseline_fs2(cores: int, batch: int = 32, repeats: int = 10) -> dict:
+    import torch
+
+    from oracle.fs2_ref import FastSpeech2Ref
+    sys.path.insert(0, str(ROOT / "tools"))
+    from fs2_bench import synthetic_batch
+
+    torch.manual_seed(1234)
+    torch.set_num_threads(cores)
+    ref = FastSpeech2Ref().eval()
+    ids, lens, durs, t_i = synthetic_batch(32, 1234)
+    ids, lens, durs = ids[:batch], lens[:batch], durs[:batch]
+    L = int(lens.max())
+    ref(ids[:, :L], lens, durations=durs[:, :L])
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        ref(ids[:, :L], lens, durations=durs[:, :L])
+    dt = (time.perf_counter() - t0) / repeats
+    frames = int(t_i[:batch].sum())
+    return {"value": round(frames / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/fs2_ref.py FastSpeech2Ref fp32, first {batch} utterances of the bench batch ({frames} frames in {dt:.2f} s, mean of {repeats} passes), {cores} threads"}
+
+
 def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     """Second half of BASELINE.json's metric: HiFiGAN-V1 GAN training steps/s at bs 16 per GPU (config 4:
     generator + MPD + MSD, LSGAN + feature matching + 45 x mel L1, two AdamW optimisers), data parallel with one
     RCCL all-reduce per optimiser (discriminator 283 MB, generator 56 MB of fp32 gradients) when N > 1.
     Synthetic segments y = 0.3 * tanh(N(0,1)) [16, 1, 8192] per rank (seed 1234 + rank), mel from the device
-    front-end.  fp32: forward / input-gradient convolutions on the fp32 matrix cores (conv_cbt_f32_mfma.hip), weight
-    gradients as unfold + rocBLAS GEMM.  The roofline object prices the step at SURVEY.md 8(d)'s 25.8 MFLOP per
+    front-end.  fp32: every convolution's forward, input gradient and weight gradient on the fp32 matrix cores
+    (conv_cbt_f32_mfma.hip, conv_wgrad_f32_mfma.hip).  The roofline object prices the step at SURVEY.md 8(d)'s 25.8 MFLOP per
     segment sample (12.9 M MAC: D step 6.21 M + G step 6.70 M) against the 157 TFLOP/s fp32 matrix peak."""
     import torch
 
@@ -355,6 +420,11 @@ def main(argv=None) -> int:
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_batch)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+            cores = result["cpu_baseline"]["cores"]
+            if train is not None:
+                train["cpu_baseline"] = cpu_baseline_train(cores)
+            if fs2 is not None:
+                fs2["cpu_baseline"] = cpu_baseline_fs2(cores)
     if use_dist:
         import torch.distributed as dist
 

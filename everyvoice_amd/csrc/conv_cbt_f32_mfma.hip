@@ -48,12 +48,13 @@ struct ConvF32Args {
   int xrow;     // LDS row stride of the staged input rows (odd)
   int pieces;   // ceil(xrow / 64)
   int stage;    // floats per ring slot (weights fragments, then input rows)
+  int nst;      // ring slots: 3 (loads two steps ahead) or 2 (one step ahead, twice the step depth in the same LDS)
   int ablate;   // timing experiments only (EVMI_F32_ABLATE): 1 no input loads, 2 no weight loads, 4 no MFMA
   long long* tl;  // timing experiments only (EVMI_F32_TL): s_memtime stamps of workgroup (0, 0), [step][wave][4]
 };
 
 constexpr int F32_PMAX = 10;  // 64-column pieces of a staged row (xrow <= 640)
-constexpr int F32_NST = 3;    // LDS ring slots
+constexpr int F32_NST = 3;    // LDS ring slots (maximum)
 
 __device__ float g_zero_line[64];  // source of the zeros staged for padding / out-of-range columns
 
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
 
   const int nsteps = (a.pairs + ps - 1) / ps;
   if (a.ablate) {  // experiments read uninitialised LDS otherwise
-    for (int v = tid; v < F32_NST * a.stage; v += NTHREADS) smem[v] = 0.f;
+    for (int v = tid; v < a.nst * a.stage; v += NTHREADS) smem[v] = 0.f;
     lds_barrier();
   }
 
@@ -215,18 +216,24 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
     return issued;
   };
   int n_next = 0;  // loads of the group issued after the one about to be consumed
+  const int nst = a.nst;
   issue(0, 0);
-  if (nsteps > 1) n_next = issue(1, 1);
+  if (nst == 3 && nsteps > 1) n_next = issue(1, 1);
 
+  int slot = -1;
   for (int t = 0; t < nsteps; ++t) {
-    const int slot = t % F32_NST;
+    slot = slot + 1 == nst ? 0 : slot + 1;       // t % nst
+    const int slot_ahead = slot == 0 ? nst - 1 : slot - 1;  // (t + nst - 1) % nst: the slot step t-1 just released
     const bool stamp = a.tl && blockIdx.x == 0 && blockIdx.y == 0 && t < 24;
     long long* tl = a.tl + (t * 4 + wave) * 4;
     if (stamp && lane == 0) tl[0] = __builtin_readcyclecounter();
     wait_vmcnt_le(n_next);  // step t has landed (this wave's part); step t+1 may still be in flight
     lds_barrier();          // ... everyone's part; slot (t+2)%3 was last read in step t-1
     if (stamp && lane == 0) tl[1] = __builtin_readcyclecounter();
-    n_next = t + 2 < nsteps ? issue(t + 2, (t + 2) % F32_NST) : 0;
+    {
+      const int issued = t + nst - 1 < nsteps ? issue(t + nst - 1, slot_ahead) : 0;
+      n_next = nst == 3 ? issued : 0;  // two slots: the step just issued is the next one consumed: wait for all of it
+    }
     if (stamp && lane == 0) tl[2] = __builtin_readcyclecounter();
     const int cbcur = min(2 * ps, a.cin_g - t * 2 * ps);
     const int nq_all = ((cbcur + 1) >> 1) * k;
@@ -353,7 +360,7 @@ static int pick_tile(const ConvF32Args& a, int groups) {
   auto blocks = [&](int i) {
     return ((n_total + kTiles[i].bn - 1) / kTiles[i].bn) * ((a.cout_g + kTiles[i].bm - 1) / kTiles[i].bm) * groups;
   };
-  const long long want = 512;  // two workgroups per CU before a larger tile is worth its reuse
+  static const long long want = env_int("EVMI_F32_WANT", 384);  // two workgroups per CU before a larger tile is worth its reuse
   if (a.cout_g > 64) {
     if (blocks(0) >= want) return 0;
     if (blocks(1) >= want) return 1;
@@ -393,15 +400,25 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   auto stage_floats = [&](int ps) {
     return ((bm / 32) * ((ps * a.k + 3) & ~3) * 64 + 2 * ps * a.xrow + 2 * a.xrow + 3) & ~3;  // + slack for the read-ahead past a step
   };
-  auto lds_bytes = [&](int ps) { return (size_t)F32_NST * stage_floats(ps) * sizeof(float); };
-  if (lds_bytes(1) > 160 * 1024) return "LDS budget";
-  int ps = 1;
-  while (ps < 16 && ps < a.pairs && lds_bytes(ps * 2) <= 78 * 1024) ps *= 2;
+  auto lds_bytes = [&](int ps, int nst) { return (size_t)nst * stage_floats(ps) * sizeof(float); };
+  if (lds_bytes(1, 2) > 160 * 1024) return "LDS budget";
+  auto deepest = [&](int nst) {
+    int ps = 1;
+    while (ps < 16 && ps < a.pairs && lds_bytes(ps * 2, nst) <= 78 * 1024) ps *= 2;
+    return ps;
+  };
+  // three slots hide the load latency best; two slots buy twice the step depth (half the per-step barrier / issue
+  // overhead) when three would leave less than ~24 K pairs of work per wave and step
+  int nst = 3, ps = deepest(3);
+  if (lds_bytes(ps, 3) > 78 * 1024 || (ps * a.k < 24 * ks && deepest(2) > ps)) { nst = 2; ps = deepest(2); }
+  const int forced_nst = env_int("EVMI_F32_NST", 0);
+  if (forced_nst == 2 || forced_nst == 3) { nst = forced_nst; ps = deepest(nst); }
   const int forced_ps = env_int("EVMI_F32_PS", 0);
-  if (forced_ps > 0 && lds_bytes(forced_ps) <= 160 * 1024) ps = forced_ps;
+  if (forced_ps > 0 && lds_bytes(forced_ps, nst) <= 160 * 1024) ps = forced_ps;
+  a.nst = nst;
   a.ps = ps;
   a.stage = stage_floats(ps);
-  size_t lds = lds_bytes(ps);
+  size_t lds = lds_bytes(ps, nst);
   lds = std::max(lds, (size_t)(ks - 1) * bm * bn * sizeof(float));
   lds = std::max(lds, (size_t)a.pieces * 64 * sizeof(int));
   if (lds > 160 * 1024) return "LDS budget";
