@@ -348,3 +348,45 @@ int evmi_attention_cbt_f32(const float* qkv_dev, const int* lens_dev, float* out
 }
 
 }  // extern "C"
+
+// ---- beta-binomial attention prior (everyvoice/preprocessor/attention_prior.py:34-67), float64 -----------
+namespace evmi {
+
+__device__ inline double betaln_d(double x, double y) { return lgamma(x) + lgamma(y) - lgamma(x + y); }
+
+// table[ti][li] = pmf of BetaBinomial(n = bw, a = li + 1, b = bh - li) at k = ti  (the reference's bank, transposed)
+__device__ inline double prior_table(int ti, int li, int bw, int bh) {
+  if (ti < 0 || ti >= bw || li < 0 || li >= bh) return 0.0;  // scipy.ndimage.zoom(mode='constant', cval=0)
+  const double n = (double)bw, k = (double)ti, a = (double)(li + 1), b = (double)(bh - li);
+  const double log_comb = lgamma(n + 1.0) - lgamma(k + 1.0) - lgamma(n - k + 1.0);
+  return exp(log_comb + betaln_d(k + a, n - k + b) - betaln_d(a, b));
+}
+
+// out[t][l] = order-1 zoom of table [bw][bh] to [T][L]: output index o samples input coordinate o * (in-1)/(out-1)
+__global__ void attention_prior_kernel(double* __restrict__ out, int T, int L, int bw, int bh) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * L) return;
+  const int t = i / L, l = i - t * L;
+  const double zt = T > 1 ? (double)(bw - 1) / (double)(T - 1) : 0.0;
+  const double zl = L > 1 ? (double)(bh - 1) / (double)(L - 1) : 0.0;
+  const double ct = t * zt, cl = l * zl;
+  const int ft = (int)floor(ct), fl = (int)floor(cl);
+  const double wt = ct - ft, wl = cl - fl;
+  double v = 0.0;
+  v += (1.0 - wt) * (1.0 - wl) * prior_table(ft, fl, bw, bh);
+  if (wl != 0.0) v += (1.0 - wt) * wl * prior_table(ft, fl + 1, bw, bh);
+  if (wt != 0.0) v += wt * (1.0 - wl) * prior_table(ft + 1, fl, bw, bh);
+  if (wt != 0.0 && wl != 0.0) v += wt * wl * prior_table(ft + 1, fl + 1, bw, bh);
+  out[i] = v;
+}
+
+}  // namespace evmi
+
+extern "C" int evmi_attention_prior_f64(double* out_dev, int T, int L, int grid_mel, int grid_text, void* stream) {
+  if (!out_dev) return evmi::fail(EVMI_ERR_INVALID_ARG, "attention_prior: null pointer");
+  if (T <= 0 || L <= 0 || grid_mel <= 0 || grid_text <= 0) return evmi::fail(EVMI_ERR_INVALID_ARG, "attention_prior: shape");
+  hipLaunchKernelGGL(evmi::attention_prior_kernel, dim3((T * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, out_dev, T, L, grid_mel,
+                     grid_text);
+  EVMI_LAUNCH_CHECK("attention_prior");
+  return EVMI_OK;
+}

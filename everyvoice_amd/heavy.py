@@ -83,3 +83,112 @@ def length_regulate_backward(grad_out: torch.Tensor, durations, L: int | None = 
             "evmi_length_regulate_bwd_f32",
         )
     return gv
+
+
+# ---- batch assembly and small tensor utilities of everyvoice/utils/heavy.py --------------------------------------------
+def _flatten(structure, key="", path="", flattened=None):
+    """Nested dict -> flat dict with ``_``-joined keys (everyvoice/utils/__init__.py:121-133)."""
+    if flattened is None:
+        flattened = {}
+    if not isinstance(structure, dict):
+        flattened[(f"{path}_" if path else "") + key] = structure
+    else:
+        for new_key, value in structure.items():
+            _flatten(value, new_key, (f"{path}_" if path else "") + key, flattened)
+    return flattened
+
+
+def collate_fn(data: list[dict]) -> dict:
+    """everyvoice/utils/heavy.py:24-36: list of (nested) dicts -> dict of batches.  Tensors (on any device: items that
+    already live on the GPU are padded there) and numpy arrays are zero padded along dim 0 to the longest item
+    (``pad_sequence(batch_first=True)``), python ints become an IntTensor, everything else stays a list."""
+    import numpy as np
+    from torch.nn.utils.rnn import pad_sequence
+
+    data = [_flatten(x) for x in data]
+    out = {k: [dic[k] for dic in data] for k in data[0]}
+    for key in out:
+        if isinstance(out[key][0], np.ndarray):
+            out[key] = [torch.tensor(x) for x in out[key]]
+        if torch.is_tensor(out[key][0]):
+            out[key] = pad_sequence(out[key], batch_first=True, padding_value=0)
+        if isinstance(out[key][0], int):
+            out[key] = torch.IntTensor(out[key])
+    return out
+
+
+def get_segments(t: torch.Tensor, segment_size: int, start=None) -> tuple[torch.Tensor, int]:
+    """everyvoice/utils/heavy.py:122-148: a segment of ``segment_size`` along dim 1 (random start in
+    ``[0, len - segment_size - 1]`` from python's ``random`` unless given), right zero padded when the input is shorter."""
+    import random
+
+    t_len = t.size(1)
+    if t_len >= segment_size:
+        max_start = t_len - segment_size - 1
+        if start is not None:
+            assert start <= max_start, f"Segment start was set to be {start} but max is {max_start}"
+        else:
+            start = random.randint(0, max_start)
+        t = t[:, start : start + segment_size]
+    else:
+        start = 0
+        t = torch.nn.functional.pad(t, (0, segment_size - t_len), "constant")
+    return t, start
+
+
+def vocoder_training_batch(specs: list[torch.Tensor], audios: list[torch.Tensor], segment_frames: int, hop: int, starts=None):
+    """The HiFiGAN training batch from device-resident utterances (what hfgl's SpecDataset + collate_fn deliver,
+    everyvoice/tests/test_dataloader.py:55-65): spec [B, n_mels, segment_frames] and audio [B, segment_frames * hop] cropped at
+    the same position (``start`` frames / ``start * hop`` samples)."""
+    segs, wavs, used = [], [], []
+    for i, (spec, audio) in enumerate(zip(specs, audios)):
+        seg, st = get_segments(spec, segment_frames, None if starts is None else starts[i])
+        wav, _ = get_segments(audio.reshape(1, -1), segment_frames * hop, st * hop if spec.size(1) >= segment_frames else None)
+        segs.append(seg)
+        wavs.append(wav.squeeze(0))
+        used.append(st)
+    return torch.stack(segs), torch.stack(wavs), used
+
+
+def dynamic_range_compression_torch(x: torch.Tensor, C=1, clip_val=1e-5) -> torch.Tensor:
+    """log(clamp(x, min=clip_val) * C) on the GPU (everyvoice/utils/heavy.py:39-40)."""
+    if not x.is_cuda:
+        raise RuntimeError("everyvoice_amd.heavy computes on the GPU only (no CPU fallback)")
+    x = x.to(torch.float32).contiguous()
+    y = torch.empty_like(x)
+    # log(max(x, clip) * C) = log(max(x * C, clip * C)): one fused elementwise kernel (op 9: log(max(a, p0)))
+    src = x if C == 1 else x * float(C)
+    _lib.check(_lib.load().evmi_elementwise_f32(9, src.data_ptr(), 0, 0, y.data_ptr(), x.numel(), float(clip_val) * float(C), 0.0,
+                                                _lib.current_stream_ptr(x.device)), "evmi_elementwise_f32")
+    return y
+
+
+def dynamic_range_decompression_torch(x: torch.Tensor, C=1) -> torch.Tensor:
+    """exp(x) / C (everyvoice/utils/heavy.py:43-44); plumbing, left to torch."""
+    return torch.exp(x) / C
+
+
+class BetaBinomialInterpolator:
+    """everyvoice/preprocessor/attention_prior.py:34-67: ``interp(w, h)`` -> float64 prior [w, h] (mel frames x text tokens),
+    the beta-binomial table on a grid rounded to (100, 20) zoomed with order-1 interpolation.  Computed by
+    ``evmi_attention_prior_f64`` on the device, cached per shape like the reference's lru_cache."""
+
+    def __init__(self, round_mel_len_to=100, round_text_len_to=20, device="cuda:0"):
+        self.round_mel_len_to, self.round_text_len_to = round_mel_len_to, round_text_len_to
+        self.device = torch.device(device)
+        self._cache: dict = {}
+
+    @staticmethod
+    def round(val, to):
+        return max(1, int(round((val + 1) / to))) * to  # python round = numpy round: half to even
+
+    def __call__(self, w: int, h: int) -> torch.Tensor:
+        key = (int(w), int(h))
+        if key not in self._cache:
+            bw, bh = self.round(w, self.round_mel_len_to), self.round(h, self.round_text_len_to)
+            out = torch.empty(key, device=self.device, dtype=torch.float64)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.load().evmi_attention_prior_f64(out.data_ptr(), key[0], key[1], bw, bh, _lib.current_stream_ptr(self.device)),
+                           "evmi_attention_prior_f64")
+            self._cache[key] = out
+        return self._cache[key]

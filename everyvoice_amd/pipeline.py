@@ -152,3 +152,50 @@ def synthesize_from_spec(spec: torch.Tensor, vocoder, out_dir, basename: str, sp
     path = Path(out_dir) / SEP.join([basename, speaker, language, "pred.wav"])
     save_wav(wav[0, 0], path, sr)
     return path
+
+
+class Scaler:
+    """everyvoice/preprocessor/helpers.py:47-106: running collection of per-utterance value tensors; min / max / nanmean /
+    unbiased std over the non-NaN values; ``(x - mean) / std`` normalisation.  Works on whatever device the data lives on."""
+
+    def __init__(self):
+        self._data = []
+        self._tensor_data = None
+        self.min = self.max = self.std = self.mean = self.norm_min = self.norm_max = None
+
+    def __len__(self):
+        return len(self._data)
+
+    @property
+    def data(self):
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        raise ValueError(f"Sorry, you tried to change the data to {value} but it cannot be changed directly. "
+                         "Either Scaler.append(data), or Scaler.clear_data()")
+
+    def append(self, value):
+        self._data.append(value)
+
+    def clear_data(self):
+        self.__init__()
+
+    def normalize(self, data):
+        return (data - self.mean) / self.std
+
+    def denormalize(self, data):
+        return (data * self.std) + self.mean
+
+    def calculate_stats(self):
+        if not len(self):
+            return None
+        if self._tensor_data is None:
+            self._tensor_data = torch.cat(self._data)
+        non_nan = self._tensor_data[~torch.isnan(self._tensor_data)]
+        self.min, self.max = torch.min(non_nan), torch.max(non_nan)
+        self.mean = torch.nanmean(self._tensor_data)
+        self.std = torch.std(non_nan)
+        self.norm_max, self.norm_min = self.normalize(self.max), self.normalize(self.min)
+        return {"sample_size": len(self), "norm_min": float(self.norm_min), "norm_max": float(self.norm_max),
+                "min": float(self.min), "max": float(self.max), "mean": float(self.mean), "std": float(self.std)}

@@ -316,6 +316,10 @@ int evmi_length_regulate_cbt_f32(const float* x_dev, const int* cum_dev, float* 
  * (softmax(Q K^T / sqrt(d_head)) V per head; fp32 matrix cores, online softmax; d_head 32 / 64 / 128). */
 int evmi_attention_cbt_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, int B, int T, int D,
                            int heads, void* stream);
+/* Beta-binomial attention prior (everyvoice/preprocessor/attention_prior.py:34-67): the pmf table of
+ * BetaBinomial(n = grid_mel, a = i, b = grid_text + 1 - i), i = 1..grid_text, on a [grid_mel][grid_text] grid,
+ * zoomed with order-1 interpolation (scipy.ndimage.zoom semantics) to out [T][L], float64. */
+int evmi_attention_prior_f64(double* out_dev, int T, int L, int grid_mel, int grid_text, void* stream);
 
 #ifdef __cplusplus
 }
