@@ -234,6 +234,65 @@ class HiFiGANTrainer:
         if msd_sd is not None:
             put(self.d_params, "msd.", msd_sd, self.d_layers())
 
+    # -- checkpoint / resume / export (reference conventions: everyvoice/tests/test_model.py:85-151, 302-313, 454-459) --
+    _VERSION = "1.0"
+
+    def state_dict(self) -> dict:
+        """Reference layout of the ``HiFiGAN`` LightningModule: ``generator.*``, ``mpd.*``, ``msd.*`` with the upstream
+        parameter names (weight_g / weight_v, and weight_orig + weight_u / weight_v buffers of the spectral-norm scale)."""
+        sd = {"generator." + k: v.cpu() for k, v in self.g_params.state_dict().items()}
+        sd.update({k: v.cpu() for k, v in self.d_params.state_dict().items()})
+        for layer in self.d_layers():
+            if isinstance(layer, SNConv):
+                sd[layer.name + ".weight_u"] = layer.u.detach().cpu().clone()
+                sd[layer.name + ".weight_v"] = layer.v.detach().cpu().clone()
+        return sd
+
+    def checkpoint(self) -> dict:
+        """A Lightning-shaped checkpoint dict: ``state_dict``, JSON-only ``hyper_parameters["config"]``, ``model_info``, the
+        step counters and both optimisers' moments (flat buffers: this trainer's own optimiser-state format)."""
+        return {
+            "epoch": 0, "global_step": self.global_step, "state_dict": self.state_dict(),
+            "hyper_parameters": {"config": self.config.model_dump(mode="json")},
+            "model_info": {"name": "HiFiGAN", "version": self._VERSION},
+            "optimizer_states": [
+                {"evmi_flat_adamw": {"group": name, "step": grp.step, "exp_avg": grp.m.cpu(), "exp_avg_sq": grp.v.cpu(), **self.opt}}
+                for name, grp in (("generator", self.g_params), ("discriminators", self.d_params))],
+        }
+
+    def load_checkpoint(self, ckpt: dict, restore_optimizers: bool = True):
+        info = ckpt.get("model_info") if isinstance(ckpt, dict) else None
+        if isinstance(info, dict) and info.get("name") != "HiFiGAN":
+            raise TypeError(f"Wrong model type ({info.get('name')}), we are expecting a 'HiFiGAN' model")
+        if isinstance(info, dict):
+            ck_major, my_major = str(info.get("version", "1.0")).split(".")[0], self._VERSION.split(".")[0]
+            if int(ck_major) > int(my_major):
+                raise ValueError("Your model was created with a newer version of EveryVoice, please update your software.")
+        try:
+            sd = ckpt["state_dict"]
+        except (KeyError, TypeError) as e:
+            raise TypeError("Unable to load config.  Possible causes: is it really a VocoderConfig? or the correct version?") from e
+        strip = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+        self.load_reference_state(strip("generator."), strip("mpd."), strip("msd."))
+        self.global_step = int(ckpt.get("global_step", 0))
+        if restore_optimizers:
+            for st in ckpt.get("optimizer_states", []):
+                st = st.get("evmi_flat_adamw") if isinstance(st, dict) else None
+                if st is None:
+                    continue
+                grp = self.g_params if st["group"] == "generator" else self.d_params
+                grp.m.copy_(st["exp_avg"].to(self.device))
+                grp.v.copy_(st["exp_avg_sq"].to(self.device))
+                grp.step = int(st["step"])
+        return self
+
+    def export_generator_checkpoint(self) -> dict:
+        """What ``everyvoice export spec-to-wav`` writes (cli.py:381-386): the generator alone, loadable by
+        ``everyvoice_amd.vocoder.load_hifigan_from_checkpoint`` for inference."""
+        return {"state_dict": {"generator." + k: v.cpu() for k, v in self.g_params.state_dict().items()},
+                "hyper_parameters": {"config": self.config.model_dump(mode="json")},
+                "model_info": {"name": "HiFiGANGenerator", "version": self._VERSION}}
+
     def _materialize(self, layers):
         for layer in layers:
             layer.materialize()

@@ -162,3 +162,43 @@ def test_full_gan_step_matches_oracle(cuda_device, oracle_models):
     for i, conv in enumerate(tr.msd[0].layers()):
         name = f"discriminators.0.convs.{i}" if i < 7 else "discriminators.0.conv_post"
         torch.testing.assert_close(conv.u.cpu(), msd_ref.state_dict()[name + ".weight_u"], rtol=1e-3, atol=1e-5)
+
+
+def test_checkpoint_resume_and_export(cuda_device, tmp_path):
+    """Save after one step, resume in a fresh trainer: the second step is bitwise the same as without the interruption;
+    the exported generator checkpoint loads into the inference vocoder and reproduces the trainer's generator."""
+    from everyvoice_amd.train import autograd as ag
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer, _to_cbt
+    from everyvoice_amd.vocoder import load_hifigan_from_checkpoint
+
+    g = torch.Generator().manual_seed(4)
+    B, S = 2, 2048
+    y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device)
+    mel = torch.randn(B, 80, S // 256, generator=g).to(cuda_device)
+    a = HiFiGANTrainer(device=cuda_device, seed=7)
+    a.training_step(mel, y)
+    path = tmp_path / "step1.ckpt"
+    torch.save(a.checkpoint(), path)
+    out_a = a.training_step(mel, y)
+
+    b = HiFiGANTrainer(device=cuda_device, seed=99)  # different init: everything must come from the file
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    assert ckpt["model_info"] == {"name": "HiFiGAN", "version": "1.0"}
+    import json
+    json.dumps(ckpt["hyper_parameters"]["config"])  # JSON-only, as the reference requires
+    b.load_checkpoint(ckpt)
+    assert b.global_step == 1
+    out_b = b.training_step(mel, y)
+    assert out_a == out_b
+    for (k, va), vb in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.equal(va, vb), k
+
+    with pytest.raises(TypeError, match="Wrong model type"):
+        b.load_checkpoint({**ckpt, "model_info": {"name": "FastSpeech2", "version": "1.0"}})
+    with pytest.raises(ValueError, match="newer version"):
+        b.load_checkpoint({**ckpt, "model_info": {"name": "HiFiGAN", "version": "2.0"}})
+
+    model, _ = load_hifigan_from_checkpoint(a.export_generator_checkpoint(), cuda_device, precision="f32")
+    a._materialize(a.generator.layers())
+    want = a.generator.forward(ag.Tape(), ag.Var(_to_cbt(mel), needs_grad=False)).data.view(B, 1, -1)
+    torch.testing.assert_close(model(mel), want, rtol=1e-4, atol=1e-5)
