@@ -344,6 +344,243 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   }
 }
 
+// ---- wave-private variant (the K-split tiles) -------------------------------------------------------------------------
+// In a K-split tile no two waves share an operand: wave (wn, ks) owns the columns [wn*BNW, +BNW) of the tile and every
+// KS-th step of the contraction.  So each wave runs its own two-slot LDS ring -- its own LDS-direct loads, its own
+// vmcnt waits -- with NO workgroup barrier in the K loop; the partial tiles meet in LDS once at the end.  A wave's
+// step is then KS times longer than a step of the shared kernel above for the same LDS (the per-step barrier + load
+// issue phase was what limited these tiles: timeline stamps), and the load issue of one wave overlaps the
+// MFMAs of the waves of the other co-resident workgroup.
+template <int BM, int BNW, int NWN, int KS>
+__global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Args a) {
+  static_assert(NWN * KS == 4, "four waves");
+  constexpr int MT = BM / 32, NT = BNW / 32;
+  constexpr int U = 2;
+  constexpr int MBT = BM / 32;
+  constexpr int BN = BNW * NWN;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = wave / NWN, wn = wave % NWN;
+  const int kh = lane >> 5, ln = lane & 31;
+  const int g = blockIdx.y / a.mtiles_per_group, mt_idx = blockIdx.y % a.mtiles_per_group;
+  const int co0 = g * a.cout_g + mt_idx * BM;
+  const int k = a.k, s = a.stride, d = a.dil, xrow = a.xrow, ps = a.ps, pieces = a.pieces;
+  const int nqa_pad = (ps * k + 3) & ~3;
+  const int a_floats = MBT * nqa_pad * 64;
+  const int halo = (k - 1) * d + 1;
+  const long long n_total = (long long)a.B * a.n_out;
+  const long long n0 = (long long)blockIdx.x * BN + wn * BNW;  // first column of this wave
+  const bool wave_live = n0 < n_total;
+  const int b_first = wave_live ? (int)(n0 / a.n_out) : 0;
+  const int to_first = wave_live ? (int)(n0 - (long long)b_first * a.n_out) : 0;
+  const int m_valid = min(BM, a.cout_g - mt_idx * BM);
+  const long long ch_stride = (long long)a.B * a.t_in;
+  const float* xgrp = a.x + (long long)g * a.cin_g * ch_stride;
+  float* wsm = smem + wave * (2 * a.stage);  // this wave's two slots
+
+  int xbase[NT], col_b[NT], col_to[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = nt * 32 + ln;
+    const long long n = n0 + c;
+    if (n < n_total) {
+      const int bb = (int)(n / a.n_out);
+      col_b[nt] = bb;
+      col_to[nt] = (int)(n - (long long)bb * a.n_out);
+      xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * halo;
+    } else {
+      col_b[nt] = -1;
+      col_to[nt] = 0;
+      xbase[nt] = a_floats + kh * xrow;
+    }
+  }
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = mt * nqa_pad * 64 + lane;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // source offsets of the staged columns of this wave (wave-private scratch: in-order LDS within a wave, no barrier)
+  int so[F32_PMAX];
+  {
+    int* Stab = reinterpret_cast<int*>(wsm);
+    for (int v = lane; v < pieces * 64; v += 64) Stab[v] = -1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    int c = 0, bb = b_first, to_lo = to_first;
+    while (wave_live && c < BNW && bb < a.B) {
+      const int cnt = min(a.n_out - to_lo, BNW - c);
+      const int seglen = (cnt - 1) * s + halo;
+      const int ti0 = to_lo * s - a.pad;
+      int* seg = Stab + c * s + (bb - b_first) * halo;
+      for (int i = lane; i < seglen; i += 64) {
+        const int ti = ti0 + i;
+        seg[i] = (ti >= 0 && ti < a.t_in) ? bb * a.t_in + ti : -1;
+      }
+      c += cnt;
+      ++bb;
+      to_lo = 0;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int pi = 0; pi < F32_PMAX; ++pi) so[pi] = pi < pieces ? Stab[pi * 64 + lane] : -1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  const int nsteps = (a.pairs + ps - 1) / ps;
+  const long long mb_stride = (long long)a.pairs * k * 64;
+  const float* wf_tile = a.wf + (long long)(g * a.mblocks + mt_idx * MBT) * mb_stride;
+  const int mb_last = a.mblocks - 1 - mt_idx * MBT;
+  const unsigned lane16 = lane * 16;
+  auto issue = [&](int t, int slot) -> int {
+    const int c0 = t * 2 * ps;
+    const int cbcur = min(2 * ps, a.cin_g - c0);
+    const int pairs_cur = (cbcur + 1) >> 1;
+    const int nquads = (pairs_cur * k + 3) >> 2;
+    float* sa = wsm + slot * a.stage;
+    float* sx = sa + a_floats;
+    int issued = 0;
+#pragma unroll
+    for (int mbi = 0; mbi < MBT; ++mbi) {
+      const char* src = reinterpret_cast<const char*>(wf_tile + min(mbi, mb_last) * mb_stride + (long long)t * ps * k * 64);
+      float* dst = sa + mbi * nqa_pad * 64;
+      for (int u = 0; u < nquads; ++u) {
+        lds_direct_b128(reinterpret_cast<const float*>(src + (size_t)u * 1024 + lane16), dst + u * 256);
+        ++issued;
+      }
+    }
+    const float* xr = xgrp + (long long)c0 * ch_stride;
+    float* dstrow = sx;
+    for (int r = 0; r < 2 * pairs_cur; ++r) {
+      const bool zero_row = r >= cbcur;
+#pragma unroll
+      for (int pi = 0; pi < F32_PMAX; ++pi) {
+        if (pi >= pieces) break;
+        const float* srcp = (zero_row || so[pi] < 0) ? g_zero_line + lane : xr + so[pi];
+        if (pi * 64 + lane < xrow) lds_direct_b32(srcp, dstrow + pi * 64);
+        ++issued;
+      }
+      xr += ch_stride;
+      dstrow += xrow;
+    }
+    return issued;
+  };
+
+  if (wave_live) {
+    int slot = 0;
+    if (ks < nsteps) issue(ks, 0);
+    for (int t = ks; t < nsteps; t += KS) {
+      // the next step of this wave goes to the other slot (its previous contents were consumed one iteration ago)
+      const int n_next = t + KS < nsteps ? issue(t + KS, slot ^ 1) : 0;
+      wait_vmcnt_le(n_next);  // step t has landed; step t + KS may still be in flight
+      const int cbcur = min(2 * ps, a.cin_g - t * 2 * ps);
+      const int nq = ((cbcur + 1) >> 1) * k;
+      int j = 0;
+      int off_a = slot * a.stage;
+      int off_x = slot * a.stage;
+      float fa[U][MT], fb[U][NT], ga[U][MT], gb[U][NT];
+      auto load_group = [&](float (&da)[U][MT], float (&db)[U][NT]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) da[u][mt] = wsm[abase[mt] + off_a];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) db[u][nt] = wsm[xbase[nt] + off_x];
+          ++j; off_a += 64; off_x += d;
+          if (j == k) { j = 0; off_x += 2 * xrow - k * d; }
+        }
+      };
+      load_group(fa, fb);
+      const int nfull = nq / U, rem = nq - nfull * U;
+      for (int gi = 0; gi < nfull; ++gi) {
+        load_group(ga, gb);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][mt], fb[u][nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) fa[u][mt] = ga[u][mt];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) fb[u][nt] = gb[u][nt];
+        }
+#pragma unroll
+        for (int i = 0; i < U * MT * NT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U - 1; ++u)
+        if (u < rem) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[u][mt], fb[u][nt], acc[mt][nt], 0, 0, 0);
+        }
+      slot ^= 1;
+    }
+  }
+
+  // ---- partial tiles of the K slices meet in LDS; wave ks == 0 of every column slice adds and stores ----
+  {
+    float* R = smem;  // [KS-1][NWN][MT][NT][16][64]
+    lds_barrier();
+    if (ks > 0) {
+      float* dst = R + ((ks - 1) * NWN + wn) * (MT * NT * 16 * 64) + lane;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[((mt * NT + nt) * 16 + r) * 64] = acc[mt][nt][r];
+    }
+    lds_barrier();
+    if (ks > 0) return;
+#pragma unroll 1
+    for (int kk = 0; kk < KS - 1; ++kk) {
+      const float* src = R + (kk * NWN + wn) * (MT * NT * 16 * 64) + lane;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mt][nt][r] += src[((mt * NT + nt) * 16 + r) * 64];
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    if (col_b[nt] < 0) continue;
+    float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + a.out_offset;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m >= m_valid) continue;
+        const int co = co0 + m;
+        float v = acc[mt][nt][r];
+        if (a.bias) v += a.bias[co];
+        float* dst = ycol + (long long)co * a.B * a.t_out_total;
+        *dst = a.accumulate ? *dst + v : v;
+      }
+    }
+  }
+}
+
 struct F32Tile { int bm, bn, ks; };
 static const F32Tile kTiles[] = {{128, 128, 1}, {64, 128, 2}, {64, 64, 4}, {32, 256, 2}, {32, 128, 4}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
@@ -375,7 +612,7 @@ static long long wfrag_elems(int c_out, int c_in, int k, int groups) {
   return (long long)groups * ((cout_g + 31) / 32) * ((cin_g + 1) / 2) * k * 64 + 4 * 64;  // + slack: the loader reads whole quads
 }
 
-struct F32Plan { int ti; size_t lds; dim3 grid; };
+struct F32Plan { int ti; size_t lds; dim3 grid; bool wp; };
 
 // Tile, step depth and LDS budget for a shape; fills the tiling fields of `a`.  nullptr = runnable, else the reason.
 static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
@@ -388,19 +625,30 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
     const int items_max = (int)std::min<long long>(a.B, (bn + a.n_out - 2) / a.n_out + 1);
     return (bn * a.stride + items_max * halo) | 1;
   };
+  static const bool use_wp = env_int("EVMI_F32_WP", 1) != 0;  // wave-private rings for the K-split tiles (A/B switch)
   int ti = pick_tile(a, groups);
-  // strided layers: narrower tiles until the staged row fits the loader (tiles are ordered wide -> narrow per BM class)
-  while (xrow_of(kTiles[ti].bn) > 64 * F32_PMAX && ti != 2 && ti != kNumTiles - 1) ++ti;
+  // wave-private rings (K-split tiles): every wave stages only its own column slice, but a workgroup holds 8 slots:
+  // taken where one step of one wave fits 1/8 of the LDS budget; long kernels (the 41-tap scale-discriminator layers)
+  // keep the shared ring
+  auto wp_fits = [&](int t) {
+    if (!use_wp || kTiles[t].ks <= 1) return false;
+    const int xr = xrow_of(kTiles[t].bn / (4 / kTiles[t].ks));
+    const size_t st1 = (size_t)(((kTiles[t].bm / 32) * ((a.k + 3) & ~3) * 64 + 2 * xr + 2 * xr + 3) & ~3) * sizeof(float);
+    return xr <= 64 * F32_PMAX && 8 * st1 <= 78 * 1024;
+  };
+  const bool wp = wp_fits(ti);
+  if (!wp)  // shared ring, strided layers: narrower tiles until the staged row fits the loader (tiles are ordered wide -> narrow)
+    while (xrow_of(kTiles[ti].bn) > 64 * F32_PMAX && ti != 2 && ti != kNumTiles - 1) ++ti;
   const int bm = kTiles[ti].bm, bn = kTiles[ti].bn, ks = kTiles[ti].ks;
   a.mtiles_per_group = (a.cout_g + bm - 1) / bm;
-  a.xrow = xrow_of(bn);
+  a.xrow = xrow_of(wp ? bn / (4 / ks) : bn);
   a.pieces = (a.xrow + 63) / 64;
   if (a.pieces > F32_PMAX) return "input span too large (very short rows with a long kernel)";
-  // channel pairs per step: as deep as ~78 KB of LDS for the three ring slots allow (two workgroups per CU)
   auto stage_floats = [&](int ps) {
     return ((bm / 32) * ((ps * a.k + 3) & ~3) * 64 + 2 * ps * a.xrow + 2 * a.xrow + 3) & ~3;  // + slack for the read-ahead past a step
   };
-  auto lds_bytes = [&](int ps, int nst) { return (size_t)nst * stage_floats(ps) * sizeof(float); };
+  // shared rings: nst slots per workgroup; wave-private rings: two slots per wave
+  auto lds_bytes = [&](int ps, int nst) { return (size_t)(wp ? 8 : nst) * stage_floats(ps) * sizeof(float); };
   if (lds_bytes(1, 2) > 160 * 1024) return "LDS budget";
   auto deepest = [&](int nst) {
     int ps = 1;
@@ -410,9 +658,9 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   // three slots hide the load latency best; two slots buy twice the step depth (half the per-step barrier / issue
   // overhead) when three would leave less than ~24 K pairs of work per wave and step
   int nst = 3, ps = deepest(3);
-  if (lds_bytes(ps, 3) > 78 * 1024 || (ps * a.k < 24 * ks && deepest(2) > ps)) { nst = 2; ps = deepest(2); }
+  if (wp || lds_bytes(ps, 3) > 78 * 1024 || (ps * a.k < 24 * ks && deepest(2) > ps)) { nst = 2; ps = deepest(2); }
   const int forced_nst = env_int("EVMI_F32_NST", 0);
-  if (forced_nst == 2 || forced_nst == 3) { nst = forced_nst; ps = deepest(nst); }
+  if (!wp && (forced_nst == 2 || forced_nst == 3)) { nst = forced_nst; ps = deepest(nst); }
   const int forced_ps = env_int("EVMI_F32_PS", 0);
   if (forced_ps > 0 && lds_bytes(forced_ps, nst) <= 160 * 1024) ps = forced_ps;
   a.nst = nst;
@@ -422,6 +670,7 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   lds = std::max(lds, (size_t)(ks - 1) * bm * bn * sizeof(float));
   lds = std::max(lds, (size_t)a.pieces * 64 * sizeof(int));
   if (lds > 160 * 1024) return "LDS budget";
+  pl.wp = wp;
   const long long n_total = (long long)a.B * a.n_out;
   if ((n_total + bn - 1) / bn > 0x7fffffffLL || groups * a.mtiles_per_group > 65535 || groups * a.mblocks > 65535) return "grid limits";
   pl.ti = ti;
@@ -455,7 +704,7 @@ int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, lon
     EVMI_HIP_CHECK(hipMemsetAsync(a.tl, 0, 24 * 4 * 4 * sizeof(long long), stream));
   }
 
-  static thread_local size_t configured[kNumTiles] = {0, 0, 0, 0, 0};
+  static thread_local size_t configured[2 * kNumTiles] = {0};
 #define EVMI_F32_LAUNCH(BM, BN, WM, WN, KS, IDX)                                                                   \
   {                                                                                                                \
     if (lds > configured[IDX]) {                                                                                   \
@@ -465,13 +714,32 @@ int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, lon
     }                                                                                                              \
     hipLaunchKernelGGL((conv_cbt_f32_mfma_kernel<BM, BN, WM, WN, KS>), grid, dim3(256), lds, stream, a);           \
   }
-  switch (ti) {
-    case 0: EVMI_F32_LAUNCH(128, 128, 2, 2, 1, 0) break;
-    case 1: EVMI_F32_LAUNCH(64, 128, 1, 2, 2, 1) break;
-    case 2: EVMI_F32_LAUNCH(64, 64, 1, 1, 4, 2) break;
-    case 3: EVMI_F32_LAUNCH(32, 256, 1, 2, 2, 3) break;
-    default: EVMI_F32_LAUNCH(32, 128, 1, 1, 4, 4) break;
+#define EVMI_F32_LAUNCH_WP(BM, BNW, NWN, KS, IDX)                                                                   \
+  {                                                                                                                \
+    if (lds > configured[IDX]) {                                                                                   \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_cbt_f32_mfma_wp_kernel<BM, BNW, NWN, KS>,               \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+      configured[IDX] = lds;                                                                                       \
+    }                                                                                                              \
+    hipLaunchKernelGGL((conv_cbt_f32_mfma_wp_kernel<BM, BNW, NWN, KS>), grid, dim3(256), lds, stream, a);          \
   }
+  if (pl.wp) {
+    switch (ti) {
+      case 1: EVMI_F32_LAUNCH_WP(64, 64, 2, 2, 5) break;
+      case 2: EVMI_F32_LAUNCH_WP(64, 64, 1, 4, 6) break;
+      case 3: EVMI_F32_LAUNCH_WP(32, 128, 2, 2, 7) break;
+      default: EVMI_F32_LAUNCH_WP(32, 128, 1, 4, 8) break;
+    }
+  } else {
+    switch (ti) {
+      case 0: EVMI_F32_LAUNCH(128, 128, 2, 2, 1, 0) break;
+      case 1: EVMI_F32_LAUNCH(64, 128, 1, 2, 2, 1) break;
+      case 2: EVMI_F32_LAUNCH(64, 64, 1, 1, 4, 2) break;
+      case 3: EVMI_F32_LAUNCH(32, 256, 1, 2, 2, 3) break;
+      default: EVMI_F32_LAUNCH(32, 128, 1, 1, 4, 4) break;
+    }
+  }
+#undef EVMI_F32_LAUNCH_WP
 #undef EVMI_F32_LAUNCH
   EVMI_LAUNCH_CHECK("conv_cbt_f32_mfma");
   if (want_tl) {  // stamps of workgroup (0,0): per step and wave: arrive, past barrier, loads issued, MFMAs done (100 MHz ticks)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Time the GAN training step (BASELINE config 4: bs 16, 8192-sample segments) on one GPU."""
+import os
 import sys
 import time
 from pathlib import Path
@@ -16,7 +17,7 @@ if os.environ.get("EVMI_CONV_BACKEND"):  # e.g. "mfma,mfma" / "gemm,gemm" / "mfm
     parts = os.environ["EVMI_CONV_BACKEND"].split(",")
     ops.CONV_BACKEND.update(fwd=parts[0], dgrad=parts[1], wgrad=parts[2] if len(parts) > 2 else "mfma")
 dev = torch.device("cuda:0")
-B, S = 16, 8192
+B, S = int(os.environ.get("EVMI_TRAIN_B", "16")), 8192
 g = torch.Generator().manual_seed(1234)
 y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(dev)
 mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
