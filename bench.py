@@ -282,9 +282,18 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     elapsed = timed_region(step, args.train_steps, args.train_warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     flop_per_step = 25.8e6 * B * S  # per GPU
     tflops = flop_per_step * args.train_steps / elapsed / 1e12
+    roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.0, "unit": "TFLOP/s", "frac": round(tflops / 157.0, 4),
+            "traffic": None, "flop_per_step_per_gpu": flop_per_step, "scope": "whole training step"}
+    pmc_files = sorted((ROOT / "profiles").glob("*train_pmc_summary.json"))
+    if pmc_files:  # recorded rocprofv3 --pmc passes (tools/gpu_profile_train.sh): the kernel with the most HBM reads per step
+        pmc = json.loads(pmc_files[-1].read_text())
+        name, top = max(pmc.items(), key=lambda kv: kv[1]["fetch_bytes_per_launch"] * kv[1]["launches"])
+        roof["traffic"] = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in pmc.values()) / 3)
+        roof["traffic_source"] = f"profiles/{pmc_files[-1].name}: HBM bytes per step, all kernels (FETCH_SIZE + WRITE_SIZE, raw KiB counters)"
+        roof["dominant_kernel"] = {"name": name, "mfma_busy_frac": round(top.get("mfma_busy_frac", 0.0), 4),
+                                   "hbm_bytes_per_launch": round(top["fetch_bytes_per_launch"] + top["write_bytes_per_launch"])}
     return {
-        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.0, "unit": "TFLOP/s",
-                     "frac": round(tflops / 157.0, 4), "traffic": None, "flop_per_step_per_gpu": flop_per_step},
+        "roofline": roof,
         "metric": "hifigan_v1_gan_train_steps_per_sec",
         "value": round(args.train_steps / elapsed, 3),
         "unit": "steps/s",

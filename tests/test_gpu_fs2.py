@@ -148,3 +148,27 @@ def test_fs2_against_committed_golden(cuda_device):
         assert torch.equal(o[5].cpu(), torch.from_numpy(z[f"{tag}_mel_lens"]))
         _close(o[1].cpu(), torch.from_numpy(z[f"{tag}_post"]))
         _close(o[3].cpu(), torch.from_numpy(z[f"{tag}_pitch"]))
+
+
+def test_synthesize_from_text_writes_reference_named_files(cuda_device, tmp_path):
+    """ids -> FastSpeech2 -> HiFiGAN -> wav + spec files (file counts and names, as tests/test_cli.py:106-169 checks)."""
+    import wave
+
+    from everyvoice_amd.config import HiFiGANConfig
+    from everyvoice_amd.fs2 import FastSpeech2
+    from everyvoice_amd.pipeline import synthesize_from_text
+    from everyvoice_amd.vocoder import HiFiGANGenerator
+
+    fs2 = FastSpeech2(device=cuda_device).init_random(3)
+    # durations of a few frames per token instead of the zeros a random duration predictor gives
+    fs2.duration_predictor.b_lin.fill_(1.0)
+    voc = HiFiGANGenerator(HiFiGANConfig(), precision="bf16").to(cuda_device).eval()
+    ids, lens, _ = _batch(80, 2, 9, seed=1, lens=[9, 6])
+    recs = synthesize_from_text(ids, lens, fs2, voc, tmp_path, ["utt-a", "utt-b"])
+    assert sorted(p.name for p in (tmp_path / "wav").iterdir()) == ["utt-a--default--default--pred.wav", "utt-b--default--default--pred.wav"]
+    assert len(list((tmp_path / "synthesized_spec").iterdir())) == 2
+    for r in recs:
+        spec = torch.load(r["spec"])
+        assert spec.shape == (80, r["frames"]) and r["frames"] == int(r["durations"].sum())
+        with wave.open(str(r["wav"])) as w:
+            assert w.getframerate() == 22050 and w.getnframes() == r["frames"] * 256 and w.getsampwidth() == 2
