@@ -34,13 +34,11 @@ class GeneratorT:
             raise NotImplementedError("training path: resblock '1' without the iSTFT head (this round)")
         self.slope = ACTIVATION_SLOPES[m.activation_function]
         ch0, n_mels = m.upsample_initial_channel, cfg.preprocessing.audio.n_mels
+        # declaration order = forward order: backward then finishes the flat gradient buffer suffix-first (BucketReducer)
         self.conv_pre = WNConv(group, "conv_pre", n_mels, ch0, 7, pad=3)
-        self.ups = [
-            WNConv(group, f"ups.{i}", ch0 >> i, ch0 >> (i + 1), k, stride=u, pad=(k - u) // 2, transposed=True)
-            for i, (u, k) in enumerate(zip(m.upsample_rates, m.upsample_kernel_sizes))
-        ]
-        self.resblocks = []
-        for i in range(len(m.upsample_rates)):
+        self.ups, self.resblocks = [], []
+        for i, (u, ku) in enumerate(zip(m.upsample_rates, m.upsample_kernel_sizes)):
+            self.ups.append(WNConv(group, f"ups.{i}", ch0 >> i, ch0 >> (i + 1), ku, stride=u, pad=(ku - u) // 2, transposed=True))
             c = ch0 >> (i + 1)
             for j, (k, dils) in enumerate(zip(m.resblock_kernel_sizes, m.resblock_dilation_sizes)):
                 n = i * len(m.resblock_kernel_sizes) + j
@@ -59,9 +57,20 @@ class GeneratorT:
                 out += [c1, c2]
         return out
 
-    def forward(self, tape: ag.Tape, mel: ag.Var) -> ag.Var:
+    def stage_layers(self, i):
+        out = [self.ups[i]]
+        for j in range(self.num_kernels):
+            for c1, c2 in self.resblocks[i * self.num_kernels + j]:
+                out += [c1, c2]
+        return out
+
+    def forward(self, tape: ag.Tape, mel: ag.Var, bucket_hook=None) -> ag.Var:
+        """`bucket_hook(layers)` is called before the forward of each group of layers whose parameters form one gradient bucket."""
+        hook = bucket_hook or (lambda layers: None)
+        hook([self.conv_pre])
         x = ag.conv1d(tape, mel, self.conv_pre)
         for i, up in enumerate(self.ups):
+            hook(self.stage_layers(i))
             x = ag.lrelu(tape, x, self.slope)
             x = ag.conv_transpose1d(tape, x, up)
             xs = None
@@ -75,6 +84,7 @@ class GeneratorT:
                     y = ag.add(tape, t, y)
                 xs = y if xs is None else ag.add(tape, xs, y)
             x = ag.scale(tape, xs, 1.0 / self.num_kernels)
+        hook([self.conv_post])
         x = ag.lrelu(tape, x, 0.01)
         x = ag.conv1d(tape, x, self.conv_post)
         return ag.tanh(tape, x)
@@ -178,6 +188,44 @@ def allreduce_mean_(flat_grad: torch.Tensor, process_group, scale_fn) -> torch.T
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group)
     scale_fn(flat_grad, 1.0 / dist.get_world_size(process_group))
     return flat_grad
+
+
+class BucketReducer:
+    """Data-parallel gradient exchange overlapped with backward: the flat gradient buffer of one optimiser is
+    reduced in contiguous buckets, each launched -- asynchronously, on a side stream when the buffer lives on a GPU -- the
+    moment backward has finished the last layer that writes into it; ``finish()`` waits for all of them and applies the
+    1/world scaling.  Backward visits the layers in reverse declaration order, so finished gradients form a growing suffix
+    of the buffer: ``launch(lo, hi)`` is called with adjacent, descending ranges.  RCCL over xGMI under backend "nccl"."""
+
+    def __init__(self, flat_grad: torch.Tensor, process_group, scale_fn):
+        self.flat, self.pg, self.scale_fn = flat_grad, process_group, scale_fn
+        self.works = []
+        self.stream = torch.cuda.Stream(flat_grad.device) if flat_grad.is_cuda else None
+
+    def launch(self, lo: int, hi: int) -> None:
+        import torch.distributed as dist
+
+        if hi <= lo:
+            return
+        chunk = self.flat[lo:hi]
+        if self.stream is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.flat.device))  # gradients of this bucket are final from here on
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ready)
+                self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self) -> None:
+        import torch.distributed as dist
+
+        for w in self.works:
+            w.wait()
+        self.works.clear()
+        if self.stream is not None:
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        self.scale_fn(self.flat, 1.0 / dist.get_world_size(self.pg))
 
 
 class HiFiGANTrainer:
@@ -297,12 +345,26 @@ class HiFiGANTrainer:
         for layer in layers:
             layer.materialize()
 
-    def _allreduce(self, group: ParamGroup):
-        """Data-parallel exchange: ONE all-reduce (RCCL over xGMI under backend "nccl") of the optimiser's flat
-        gradient buffer, then the 1/world scaling — discriminator side and generator side separately."""
-        if self.pg is not None:
-            allreduce_mean_(group.grad, self.pg if self.pg is not True else None,
-                            lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
+    def _reducer(self, group: ParamGroup):
+        """Bucketed all-reduce of one optimiser's flat gradient buffer, overlapped with backward (None on one GPU)."""
+        if self.pg is None:
+            return None
+        return BucketReducer(group.grad, self.pg if self.pg is not True else None,
+                             lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
+
+    @staticmethod
+    def _bucket_hook(tape, group: ParamGroup, layers, reducer, state):
+        """Record, BEFORE the forward of `layers`, the closure that backward runs AFTER all of their gradient closures:
+        turn the effective-weight gradients into parameter gradients and hand the now-final slice of the flat buffer to the
+        reducer.  `state["hi"]` is the start of the suffix already handed over."""
+        def done():
+            for layer in layers:
+                layer.finish_grads()
+            if reducer is not None:
+                lo = min(group.offset_of(n) for layer in layers for n in layer.param_names())
+                reducer.launch(lo, state["hi"])
+                state["hi"] = lo
+        tape.record(done)
 
     # -- discriminators on one waveform ----------------------------------------------------------------------
     def _discriminate(self, tape, audio: ag.Var, training=True):
@@ -320,17 +382,21 @@ class HiFiGANTrainer:
             fmaps.append(f)
         return logits, fmaps
 
-    def _discriminate_pair(self, tape, y: torch.Tensor, y_hat: torch.Tensor):
+    def _discriminate_pair(self, tape, y: torch.Tensor, y_hat: torch.Tensor, reducer=None, state=None):
         """Discriminator step: real and generated waveforms as ONE batch of 2B items (columns of the same GEMMs), so
         every convolution, its input gradient and its weight gradient run once over twice the columns.  The
         spectral-norm scale discriminator keeps the reference's two forward calls: each call runs its own power
         iteration and sees its own sigma.  Returns [(logits Var, "pair" | "real" | "fake")]."""
         pair = ag.Var(torch.cat([y, y_hat], dim=1), needs_grad=False)
-        outs = [(d.forward(tape, pair)[0], "pair") for d in self.mpd]
+        outs = []
+        for d in self.mpd:
+            self._bucket_hook(tape, self.d_params, d.layers(), reducer, state)
+            outs.append((d.forward(tape, pair)[0], "pair"))
         x = pair
         for i, d in enumerate(self.msd):
             if i > 0:
                 x = ag.avgpool4s2(tape, x)
+            self._bucket_hook(tape, self.d_params, d.layers(), reducer, state)
             if any(isinstance(layer, SNConv) for layer in d.layers()):
                 outs.append((d.forward(tape, ag.Var(y, needs_grad=False))[0], "real"))
                 outs.append((d.forward(tape, ag.Var(y_hat, needs_grad=False))[0], "fake"))
@@ -352,14 +418,17 @@ class HiFiGANTrainer:
 
         # ---- generator forward (tape kept for the generator step) ----
         g_tape = ag.Tape()
-        y_hat = self.generator.forward(g_tape, ag.Var(mel, needs_grad=False))
+        g_reducer, g_state = self._reducer(self.g_params), {"hi": self.g_params.grad.numel()}
+        y_hat = self.generator.forward(g_tape, ag.Var(mel, needs_grad=False),
+                                       lambda layers: self._bucket_hook(g_tape, self.g_params, layers, g_reducer, g_state))
 
         # ---- discriminator step ----
         self.d_params.zero_grad()
         for layer in d_layers:
             layer.frozen = False
         d_tape = ag.Tape()
-        for o, kind in self._discriminate_pair(d_tape, y, y_hat.data):  # y_hat.detach()
+        d_reducer, d_state = self._reducer(self.d_params), {"hi": self.d_params.grad.numel()}
+        for o, kind in self._discriminate_pair(d_tape, y, y_hat.data, d_reducer, d_state):  # y_hat.detach()
             if kind == "pair":  # real items first, generated items second along the batch axis
                 n, h = o.data.numel() // 2, o.data.shape[1] // 2  # period discriminators: the batch axis is (item, column)
                 o.grad = torch.empty_like(o.data)
@@ -371,10 +440,10 @@ class HiFiGANTrainer:
             for logits, grad, target in parts:
                 ops.scalar_reduce(1, logits, None, losses["d"], scale=1.0 / n, p=target, accumulate=True)
                 ops.elementwise(ops.EW_SQ_GRAD, logits, out=grad, p0=1.0 / n, p1=target)
-        d_tape.backward()
-        for layer in d_layers:
-            layer.finish_grads()
-        self._allreduce(self.d_params)
+        d_tape.backward()  # every discriminator's bucket is finished (and its all-reduce launched) as backward leaves it
+        if d_reducer is not None:
+            d_reducer.launch(0, d_state["hi"])  # alignment padding in front of the first parameter, if any
+            d_reducer.finish()
         if self.keep_grads:
             self.last_grads["d"] = {k: v.clone() for k, v in self.d_params.gradients().items()}
         self.d_params.adamw(**self.opt)
@@ -406,10 +475,10 @@ class HiFiGANTrainer:
         if y_hat_in.grad is not None:
             total = ops.axpby(1.0, total, 1.0, y_hat_in.grad)
         y_hat.grad = total
-        g_tape.backward()
-        for layer in g_layers:
-            layer.finish_grads()
-        self._allreduce(self.g_params)
+        g_tape.backward()  # buckets: conv_post, the four upsampling stages, conv_pre
+        if g_reducer is not None:
+            g_reducer.launch(0, g_state["hi"])
+            g_reducer.finish()
         if self.keep_grads:
             self.last_grads["g"] = {k: v.clone() for k, v in self.g_params.gradients().items()}
             self.last_grads["y_hat"] = y_hat.data.clone()

@@ -50,6 +50,10 @@ class ParamGroup:
     def names(self):
         return [s[0] for s in self._specs]
 
+    def offset_of(self, name: str) -> int:
+        """Start of a parameter in the flat buffers (parameters are laid out in declaration order)."""
+        return self._specs[self._index[name]][2]
+
     def numel(self):
         return sum(math.prod(s[1]) for s in self._specs)
 
@@ -85,6 +89,9 @@ class _ConvBase:
 
     def bias_data(self):
         return self.group.data(self.i_bias)
+
+    def param_names(self):
+        return [n for n in self.group.names() if n.startswith(self.name + ".")]
 
     def db_sink(self):
         return self.group.gradient(self.i_bias)

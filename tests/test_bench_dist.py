@@ -76,6 +76,33 @@ def test_gradient_allreduce_is_a_mean_over_ranks(tmp_path):
     assert torch.equal(g0, g1) and torch.allclose(g0, want)
 
 
+def _bucket_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from everyvoice_amd.train.hifigan import BucketReducer
+
+    flat = torch.arange(23, dtype=torch.float32) * (rank + 1)
+    red = BucketReducer(flat, None, lambda t, s: t.mul_(s))
+    hi = flat.numel()
+    for lo in (17, 9, 4):  # backward finishes the buffer suffix-first, bucket by bucket
+        red.launch(lo, hi)
+        hi = lo
+    red.launch(0, hi)      # what is left in front of the first bucket
+    red.launch(0, 0)       # empty ranges are ignored
+    red.finish()
+    torch.save(flat, Path(out_dir, f"b{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_allreduce_is_a_mean_over_ranks(tmp_path):
+    """The exchange the training step uses on N > 1 GPUs: asynchronous all-reduces of contiguous buckets launched during
+    backward, one wait + 1/world scaling at the end (gloo stands in for RCCL; the side stream is GPU-only)."""
+    world = 2
+    mp.spawn(_bucket_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    b0, b1 = (torch.load(Path(tmp_path, f"b{i}.pt")) for i in range(world))
+    assert torch.equal(b0, b1) and torch.allclose(b0, torch.arange(23, dtype=torch.float32) * 1.5)
+
+
 def test_dist_env_and_roofline_aggregation(monkeypatch):
     monkeypatch.setenv("RANK", "3")
     monkeypatch.setenv("LOCAL_RANK", "1")

@@ -202,3 +202,38 @@ def test_checkpoint_resume_and_export(cuda_device, tmp_path):
     a._materialize(a.generator.layers())
     want = a.generator.forward(ag.Tape(), ag.Var(_to_cbt(mel), needs_grad=False)).data.view(B, 1, -1)
     torch.testing.assert_close(model(mel), want, rtol=1e-4, atol=1e-5)
+
+
+def test_bucketed_allreduce_path_on_rccl_world_of_one(cuda_device):
+    """The N > 1 code path (BucketReducer: side stream, events, async RCCL all-reduces launched during backward, 1/world scaling)
+    on a one-rank "nccl" group: the step must equal the plain single-GPU step bit for bit."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(8)
+    B, S = 2, 2048
+    y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device)
+    mel = torch.randn(B, 80, S // 256, generator=g).to(cuda_device)
+    plain = HiFiGANTrainer(device=cuda_device, seed=5)
+    plain.keep_grads = True
+    out_plain = plain.training_step(mel, y)
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_device)
+    try:
+        dp = HiFiGANTrainer(device=cuda_device, seed=5, process_group=True)
+        dp.keep_grads = True
+        out_dp = dp.training_step(mel, y)
+    finally:
+        dist.destroy_process_group()
+    assert out_plain == out_dp
+    for side in ("d", "g"):
+        for k, v in plain.last_grads[side].items():
+            assert torch.equal(v, dp.last_grads[side][k]), (side, k)
