@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   const int nqa_pad = (ps * k + 3) & ~3;      // fragments per m-block per slot (whole 1 KB quads)
   const int a_floats = MBT * nqa_pad * 64;    // weight part of a slot
   const int halo = (k - 1) * d + 1;
+  const int gap = max(halo - s, 0);  // extra columns between the staged segments of consecutive items
   const long long n_total = (long long)a.B * a.n_out;
   const long long n0 = (long long)blockIdx.x * BN;
   const int b_first = (int)(n0 / a.n_out);
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   const long long ch_stride = (long long)a.B * a.t_in;
   const float* xgrp = a.x + (long long)g * a.cin_g * ch_stride;
 
-  // per-lane column bookkeeping: tile column c -> (b, to); LDS column base = c*s + (b - b_first)*halo
+  // per-lane column bookkeeping: tile column c -> (b, to); LDS column base = c*s + (b - b_first)*gap
   int xbase[NT], col_b[NT], col_to[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
       const int bb = (int)(n / a.n_out);
       col_b[nt] = bb;
       col_to[nt] = (int)(n - (long long)bb * a.n_out);
-      xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * halo;
+      xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * gap;
     } else {
       col_b[nt] = -1;
       col_to[nt] = 0;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
       const int cnt = min(a.n_out - to_lo, BN - c);
       const int seglen = (cnt - 1) * s + halo;
       const int ti0 = to_lo * s - a.pad;
-      int* seg = Stab + c * s + (bb - b_first) * halo;
+      int* seg = Stab + c * s + (bb - b_first) * gap;
       for (int i = tid; i < seglen; i += NTHREADS) {
         const int ti = ti0 + i;
         seg[i] = (ti >= 0 && ti < a.t_in) ? bb * a.t_in + ti : -1;
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
   const int nqa_pad = (ps * k + 3) & ~3;
   const int a_floats = MBT * nqa_pad * 64;
   const int halo = (k - 1) * d + 1;
+  const int gap = max(halo - s, 0);  // extra columns between the staged segments of consecutive items
   const long long n_total = (long long)a.B * a.n_out;
   const long long n0 = (long long)blockIdx.x * BN + wn * BNW;  // first column of this wave
   const bool wave_live = n0 < n_total;
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
       const int bb = (int)(n / a.n_out);
       col_b[nt] = bb;
       col_to[nt] = (int)(n - (long long)bb * a.n_out);
-      xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * halo;
+      xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * gap;
     } else {
       col_b[nt] = -1;
       col_to[nt] = 0;
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
       const int cnt = min(a.n_out - to_lo, BNW - c);
       const int seglen = (cnt - 1) * s + halo;
       const int ti0 = to_lo * s - a.pad;
-      int* seg = Stab + c * s + (bb - b_first) * halo;
+      int* seg = Stab + c * s + (bb - b_first) * gap;
       for (int i = lane; i < seglen; i += 64) {
         const int ti = ti0 + i;
         seg[i] = (ti >= 0 && ti < a.t_in) ? bb * a.t_in + ti : -1;
@@ -623,7 +625,7 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   const int halo = (a.k - 1) * a.dil + 1;
   auto xrow_of = [&](int bn) {
     const int items_max = (int)std::min<long long>(a.B, (bn + a.n_out - 2) / a.n_out + 1);
-    return (bn * a.stride + items_max * halo) | 1;
+    return ((bn - 1) * a.stride + (items_max - 1) * std::max(halo - a.stride, 0) + halo) | 1;
   };
   static const bool use_wp = env_int("EVMI_F32_WP", 1) != 0;  // wave-private rings for the K-split tiles (A/B switch)
   int ti = pick_tile(a, groups);
