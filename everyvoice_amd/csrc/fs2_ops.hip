@@ -390,3 +390,60 @@ extern "C" int evmi_attention_prior_f64(double* out_dev, int T, int L, int grid_
   EVMI_LAUNCH_CHECK("attention_prior");
   return EVMI_OK;
 }
+
+// ---- monotonic alignment search (hard alignments; Glow-TTS maximum_path) -----------------------------
+namespace evmi {
+
+// One workgroup per item.  The DP runs row by row (frames), tokens in parallel, two rows of Q in LDS; the decisions
+// (came from x - 1?) are kept as one bit per cell in global scratch for the read-back.  Same arithmetic and tie rule as the
+// published kernel: Q[y][x] = value + max(prev, cur) in fp32, move left when x == y or Q[y-1][x] < Q[y-1][x-1].
+__global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ value, const int* __restrict__ mel_lens,
+                                                  const int* __restrict__ text_lens, int* __restrict__ path, int* __restrict__ dur,
+                                                  unsigned char* __restrict__ left, int T, int L) {
+  extern __shared__ float q[];  // [2][L]
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int t_y = min(mel_lens[b], T), t_x = min(text_lens[b], L);
+  const float* v = value + (long long)b * T * L;
+  int* p = path + (long long)b * T * L;
+  unsigned char* lf = left + (long long)b * T * L;
+  const float MAX_NEG = -1e9f;
+  for (int i = tid; i < T * L; i += 256) p[i] = 0;
+  for (int x = tid; x < L; x += 256) dur[b * L + x] = 0;
+  for (int y = 0; y < t_y; ++y) {
+    float* cur = q + (y & 1) * L;
+    const float* prev = q + ((y & 1) ^ 1) * L;
+    const int lo = max(0, t_x + y - t_y), hi = min(t_x, y + 1);
+    for (int x = lo + tid; x < hi; x += 256) {
+      const float v_cur = x == y ? MAX_NEG : prev[x];
+      const float v_prev = x == 0 ? (y == 0 ? 0.f : MAX_NEG) : prev[x - 1];
+      cur[x] = v[(long long)y * L + x] + fmaxf(v_prev, v_cur);
+      // the read-back at row y + 1 ... asks about row y: decide "x came from x - 1" now, while both values are here
+      lf[(long long)y * L + x] = (x != 0 && (x == y || v_cur < v_prev)) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && t_y > 0 && t_x > 0) {
+    // read-back: at row y the published kernel tests Q[y-1][index] < Q[y-1][index-1] or index == y: exactly the bit stored
+    // for cell (y, index) (v_cur / v_prev are those two values; x == y covers the diagonal)
+    int index = t_x - 1;
+    for (int y = t_y - 1; y >= 0; --y) {
+      p[(long long)y * L + index] = 1;
+      dur[b * L + index] += 1;
+      if (index != 0 && lf[(long long)y * L + index]) --index;
+    }
+  }
+}
+
+}  // namespace evmi
+
+extern "C" int evmi_monotonic_align_f32(const float* value_dev, const int* mel_lens_dev, const int* text_lens_dev, int* path_dev,
+                                        int* dur_dev, unsigned char* scratch_dev, int B, int T, int L, void* stream) {
+  if (!value_dev || !mel_lens_dev || !text_lens_dev || !path_dev || !dur_dev || !scratch_dev)
+    return evmi::fail(EVMI_ERR_INVALID_ARG, "monotonic_align: null pointer");
+  if (B <= 0 || T <= 0 || L <= 0) return evmi::fail(EVMI_ERR_INVALID_ARG, "monotonic_align: shape");
+  if ((size_t)2 * L * sizeof(float) > 64 * 1024) return evmi::fail(EVMI_ERR_UNSUPPORTED, "monotonic_align: more than 8192 tokens");
+  hipLaunchKernelGGL(evmi::mas_kernel, dim3(B), dim3(256), 2 * L * sizeof(float), (hipStream_t)stream, value_dev, mel_lens_dev,
+                     text_lens_dev, path_dev, dur_dev, scratch_dev, T, L);
+  EVMI_LAUNCH_CHECK("monotonic_align");
+  return EVMI_OK;
+}

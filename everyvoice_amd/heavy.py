@@ -192,3 +192,21 @@ class BetaBinomialInterpolator:
                            "evmi_attention_prior_f64")
             self._cache[key] = out
         return self._cache[key]
+
+
+def maximum_path(value: torch.Tensor, mel_lens: torch.Tensor, text_lens: torch.Tensor):
+    """Monotonic alignment search on the device (the reference's ``monotonic_align.maximum_path``, third-party
+    ilt-monotonic-align): value [B, T, L] float32 log-likelihoods -> (path [B, T, L] int32, durations [B, L] int64)."""
+    if not value.is_cuda:
+        raise RuntimeError("everyvoice_amd.heavy computes on the GPU only (no CPU fallback)")
+    v = value.to(torch.float32).contiguous()
+    B, T, L = v.shape
+    dev = v.device
+    ml, tl = mel_lens.to(dev, torch.int32).contiguous(), text_lens.to(dev, torch.int32).contiguous()
+    path = torch.empty(B, T, L, device=dev, dtype=torch.int32)
+    dur = torch.empty(B, L, device=dev, dtype=torch.int32)
+    scratch = torch.empty(B * T * L, device=dev, dtype=torch.uint8)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().evmi_monotonic_align_f32(v.data_ptr(), ml.data_ptr(), tl.data_ptr(), path.data_ptr(), dur.data_ptr(),
+                                                        scratch.data_ptr(), B, T, L, _lib.current_stream_ptr(dev)), "evmi_monotonic_align_f32")
+    return path, dur.to(torch.int64)

@@ -320,6 +320,12 @@ int evmi_attention_cbt_f32(const float* qkv_dev, const int* lens_dev, float* out
  * BetaBinomial(n = grid_mel, a = i, b = grid_text + 1 - i), i = 1..grid_text, on a [grid_mel][grid_text] grid,
  * zoomed with order-1 interpolation (scipy.ndimage.zoom semantics) to out [T][L], float64. */
 int evmi_attention_prior_f64(double* out_dev, int T, int L, int grid_mel, int grid_text, void* stream);
+/* Monotonic alignment search (the reference's hard alignments: third-party ilt-monotonic-align 1.2.1 = Glow-TTS
+ * maximum_path): value [B][T][L] log-likelihoods, mel_lens / text_lens [B] -> path [B][T][L] (0/1, one token per
+ * frame, monotonic, every token used) and durations [B][L] = frames per token.  scratch: B*T*L bytes. */
+int evmi_monotonic_align_f32(const float* value_dev, const int* mel_lens_dev, const int* text_lens_dev,
+                             int* path_dev, int* dur_dev, unsigned char* scratch_dev, int B, int T, int L,
+                             void* stream);
 
 #ifdef __cplusplus
 }

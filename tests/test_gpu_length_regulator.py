@@ -134,3 +134,28 @@ def test_dynamic_range_compression_matches_reference_golden(cuda_device, golden_
     np.testing.assert_allclose(got.cpu().numpy(), g["drc"], rtol=4e-7, atol=1e-6)  # the device logf is within 2 ulp of torch's
     np.testing.assert_allclose(dynamic_range_decompression_torch(got).cpu().numpy(), g["drd"], rtol=4e-6)
     np.testing.assert_allclose(dynamic_range_compression_torch(x, C=2.0).cpu().numpy(), np.log(np.maximum(g["x"], 1e-5) * 2.0), rtol=4e-7, atol=2e-6)
+
+
+def test_monotonic_alignment_search_matches_oracle(cuda_device):
+    """evmi_monotonic_align_f32 vs the restated Glow-TTS dynamic programme: paths and durations are integers -> exact,
+    including ties (quantised scores), ragged lengths, t_x == t_y (pure diagonal) and a single token."""
+    import numpy as np
+
+    from everyvoice_amd.heavy import maximum_path
+    from oracle.mas_ref import maximum_path_batch_ref
+
+    g = torch.Generator().manual_seed(6)
+    for B, T, L, quant in ((4, 60, 17, False), (3, 200, 45, True), (2, 9, 9, False), (2, 30, 1, False), (5, 947, 187, False)):
+        v = torch.randn(B, T, L, generator=g) * 3
+        if quant:
+            v = (v * 2).round() / 2  # many exact ties
+        mel_lens = torch.randint(max(L, T // 2), T + 1, (B,), generator=g)
+        text_lens = torch.minimum(torch.randint(max(1, L // 2), L + 1, (B,), generator=g), mel_lens)
+        mel_lens[0], text_lens[0] = T, L
+        if T == L:
+            mel_lens[:], text_lens[:] = T, L
+        want_path, want_dur = maximum_path_batch_ref(v.numpy(), mel_lens.numpy(), text_lens.numpy())
+        path, dur = maximum_path(v.to(cuda_device), mel_lens, text_lens)
+        assert np.array_equal(path.cpu().numpy(), want_path), (B, T, L)
+        assert np.array_equal(dur.cpu().numpy(), want_dur)
+        assert torch.equal(dur.sum(1).cpu(), mel_lens)  # every frame belongs to exactly one token

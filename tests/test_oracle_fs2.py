@@ -67,3 +67,22 @@ def test_product_state_dict_description_matches_oracle():
     shapes = FastSpeech2.state_dict_shapes(FastSpeech2ModelConfig())
     ref = {k: tuple(v.shape) for k, v in FastSpeech2Ref().state_dict().items() if not k.endswith("num_batches_tracked") and not k.endswith("_bins")}
     assert shapes == ref
+
+
+def test_monotonic_alignment_oracle_properties():
+    """oracle/mas_ref.py: one token per frame, monotonic, every token used, maximal among a brute-force enumeration (tiny case)."""
+    import itertools
+
+    from oracle.mas_ref import maximum_path_ref
+
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=(7, 4)).astype(np.float32)
+    path = maximum_path_ref(v, 7, 4)
+    tok = path.argmax(1)
+    assert (path.sum(1) == 1).all() and tok[0] == 0 and tok[-1] == 3 and ((np.diff(tok) == 0) | (np.diff(tok) == 1)).all()
+    best = max(sum(v[y, x] for y, x in enumerate(np.repeat(np.arange(4), np.diff((0,) + cuts + (7,)))))
+               for cuts in itertools.combinations(range(1, 7), 3))
+    assert abs(float((v * path).sum()) - float(best)) < 1e-5
+    # ragged: frames / tokens past the lengths are untouched
+    p2 = maximum_path_ref(v, 5, 3)
+    assert not p2[5:].any() and not p2[:, 3:].any() and p2[:5].sum() == 5
