@@ -49,10 +49,16 @@ struct ConvF32Args {
   int pieces;   // ceil(xrow / 64)
   int stage;    // floats per ring slot (weights fragments, then input rows)
   int nst;      // ring slots: 3 (loads two steps ahead) or 2 (one step ahead, twice the step depth in the same LDS)
+  // polyphase input gradients: grid.z = phase, every phase its own padding / extent / output offset / weight fragments
+  int phases;
+  int n_out_min;  // planning: shortest phase (most items per tile); 0 = n_out
+  long long wf_phase_stride;
+  int ph_pad[8], ph_nout[8], ph_off[8];
   int ablate;   // timing experiments only (EVMI_F32_ABLATE): 1 no input loads, 2 no weight loads, 4 no MFMA
   long long* tl;  // timing experiments only (EVMI_F32_TL): s_memtime stamps of workgroup (0, 0), [step][wave][4]
 };
 
+constexpr int SMALLCO_DIRECT = 4;  // output channels up to which conv_cbt_direct.hip takes the shape
 constexpr int F32_PMAX = 10;  // 64-column pieces of a staged row (xrow <= 640)
 constexpr int F32_NST = 3;    // LDS ring slots (maximum)
 
@@ -81,6 +87,30 @@ __global__ __launch_bounds__(256) void wfrag_kernel(const float* __restrict__ w,
   }
 }
 
+// Fragment-ordered weights of the polyphase input-gradient convolutions, straight from w [c_out][cin_g][k]:
+// the gradient of y = conv(x, w, stride s) with respect to x is, for every phase phi < min(s, k), a stride-1 convolution of
+// dy (c_out channels in, c_in channels out) with the taps j = phi + s*m of w in reverse order.  All phases get the same
+// tap count M = ceil(k / s) (phases with fewer taps are zero padded in front), so they share one launch geometry:
+//   wfd[ph][(((g*MB + mb)*P + p)*M + m)*64 + kh*32 + mi] = w[g*cout_g + 2p+kh][mb*32+mi][phi + s*(M_phi - 1 - (m - (M - M_phi)))]
+// with MB = ceil(cin_g / 32), P = ceil(cout_g / 2).  grid (P, groups*MB, phases)
+__global__ __launch_bounds__(256) void wfrag_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wfd, int cout_g, int cin_g,
+                                                          int k, int stride, int M, int MB, int P, long long phase_stride) {
+  const int p = blockIdx.x, gmb = blockIdx.y, phi = blockIdx.z;
+  const int g = gmb / MB, mb = gmb - g * MB;
+  const int m_phi = (k - phi + stride - 1) / stride, lead = M - m_phi;
+  float* dst = wfd + phi * phase_stride + ((long long)gmb * P + p) * M * 64;
+  for (int e = threadIdx.x; e < M * 64; e += 256) {
+    const int m = e >> 6, kh = (e >> 5) & 1, mi = e & 31;
+    const int ci = mb * 32 + mi, co = 2 * p + kh;
+    float v = 0.f;
+    if (ci < cin_g && co < cout_g && m >= lead) {
+      const int j = phi + stride * (m_phi - 1 - (m - lead));
+      v = w[((long long)(g * cout_g + co) * cin_g + ci) * k + j];
+    }
+    dst[e] = v;
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int KS>
 __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a) {
   constexpr int NTHREADS = 256;
@@ -101,10 +131,15 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   const int a_floats = MBT * nqa_pad * 64;    // weight part of a slot
   const int halo = (k - 1) * d + 1;
   const int gap = max(halo - s, 0);  // extra columns between the staged segments of consecutive items
-  const long long n_total = (long long)a.B * a.n_out;
+  const int ph = blockIdx.z;
+  const int n_out = a.ph_nout[ph], pad_ = a.ph_pad[ph], out_off = a.ph_off[ph];
+  if (n_out <= 0) return;  // a phase without outputs
+  const float* wf_ = a.wf + (long long)ph * a.wf_phase_stride;
+  const long long n_total = (long long)a.B * n_out;
   const long long n0 = (long long)blockIdx.x * BN;
-  const int b_first = (int)(n0 / a.n_out);
-  const int to_first = (int)(n0 - (long long)b_first * a.n_out);
+  if (n0 >= n_total) return;  // tiles past a (shorter) phase
+  const int b_first = (int)(n0 / n_out);
+  const int to_first = (int)(n0 - (long long)b_first * n_out);
   const int m_valid = min(BM, a.cout_g - mt_idx * BM);
   const long long ch_stride = (long long)a.B * a.t_in;
   const float* xgrp = a.x + (long long)g * a.cin_g * ch_stride;
@@ -116,9 +151,9 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
     const int c = (wn * NT + nt) * 32 + ln;
     const long long n = n0 + c;
     if (n < n_total) {
-      const int bb = (int)(n / a.n_out);
+      const int bb = (int)(n / n_out);
       col_b[nt] = bb;
-      col_to[nt] = (int)(n - (long long)bb * a.n_out);
+      col_to[nt] = (int)(n - (long long)bb * n_out);
       xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * gap;
     } else {
       col_b[nt] = -1;
@@ -146,9 +181,9 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
     lds_barrier();
     int c = 0, bb = b_first, to_lo = to_first;
     while (c < BN && bb < a.B) {
-      const int cnt = min(a.n_out - to_lo, BN - c);
+      const int cnt = min(n_out - to_lo, BN - c);
       const int seglen = (cnt - 1) * s + halo;
-      const int ti0 = to_lo * s - a.pad;
+      const int ti0 = to_lo * s - pad_;
       int* seg = Stab + c * s + (bb - b_first) * gap;
       for (int i = tid; i < seglen; i += NTHREADS) {
         const int ti = ti0 + i;
@@ -174,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   // Weights: the 1 KB quads of the step round-robin over the waves (SGPR base + lane offset addressing);
   // inputs: rows round-robin over the waves.  Returns the number of loads this wave issued. ----
   const long long mb_stride = (long long)a.pairs * k * 64;
-  const float* wf_tile = a.wf + (long long)(g * a.mblocks + mt_idx * MBT) * mb_stride;
+  const float* wf_tile = wf_ + (long long)(g * a.mblocks + mt_idx * MBT) * mb_stride;
   const int mb_last = a.mblocks - 1 - mt_idx * MBT;  // m-blocks past the group re-read the last one (never stored)
   const unsigned lane16 = lane * 16;
   auto issue = [&](int t, int slot) -> int {
@@ -328,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     if (col_b[nt] < 0) continue;
-    float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + a.out_offset;
+    float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -372,11 +407,16 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
   const int a_floats = MBT * nqa_pad * 64;
   const int halo = (k - 1) * d + 1;
   const int gap = max(halo - s, 0);  // extra columns between the staged segments of consecutive items
-  const long long n_total = (long long)a.B * a.n_out;
+  const int ph = blockIdx.z;
+  const int n_out = a.ph_nout[ph], pad_ = a.ph_pad[ph], out_off = a.ph_off[ph];
+  if (n_out <= 0) return;  // a phase without outputs
+  const float* wf_ = a.wf + (long long)ph * a.wf_phase_stride;
+  const long long n_total = (long long)a.B * n_out;
+  if ((long long)blockIdx.x * BN >= n_total) return;  // tiles past a (shorter) phase
   const long long n0 = (long long)blockIdx.x * BN + wn * BNW;  // first column of this wave
   const bool wave_live = n0 < n_total;
-  const int b_first = wave_live ? (int)(n0 / a.n_out) : 0;
-  const int to_first = wave_live ? (int)(n0 - (long long)b_first * a.n_out) : 0;
+  const int b_first = wave_live ? (int)(n0 / n_out) : 0;
+  const int to_first = wave_live ? (int)(n0 - (long long)b_first * n_out) : 0;
   const int m_valid = min(BM, a.cout_g - mt_idx * BM);
   const long long ch_stride = (long long)a.B * a.t_in;
   const float* xgrp = a.x + (long long)g * a.cin_g * ch_stride;
@@ -388,9 +428,9 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
     const int c = nt * 32 + ln;
     const long long n = n0 + c;
     if (n < n_total) {
-      const int bb = (int)(n / a.n_out);
+      const int bb = (int)(n / n_out);
       col_b[nt] = bb;
-      col_to[nt] = (int)(n - (long long)bb * a.n_out);
+      col_to[nt] = (int)(n - (long long)bb * n_out);
       xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * gap;
     } else {
       col_b[nt] = -1;
@@ -418,9 +458,9 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     int c = 0, bb = b_first, to_lo = to_first;
     while (wave_live && c < BNW && bb < a.B) {
-      const int cnt = min(a.n_out - to_lo, BNW - c);
+      const int cnt = min(n_out - to_lo, BNW - c);
       const int seglen = (cnt - 1) * s + halo;
-      const int ti0 = to_lo * s - a.pad;
+      const int ti0 = to_lo * s - pad_;
       int* seg = Stab + c * s + (bb - b_first) * gap;
       for (int i = lane; i < seglen; i += 64) {
         const int ti = ti0 + i;
@@ -438,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
 
   const int nsteps = (a.pairs + ps - 1) / ps;
   const long long mb_stride = (long long)a.pairs * k * 64;
-  const float* wf_tile = a.wf + (long long)(g * a.mblocks + mt_idx * MBT) * mb_stride;
+  const float* wf_tile = wf_ + (long long)(g * a.mblocks + mt_idx * MBT) * mb_stride;
   const int mb_last = a.mblocks - 1 - mt_idx * MBT;
   const unsigned lane16 = lane * 16;
   auto issue = [&](int t, int slot) -> int {
@@ -566,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     if (col_b[nt] < 0) continue;
-    float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + a.out_offset;
+    float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -624,7 +664,8 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   a.pairs = (a.cin_g + 1) / 2;
   const int halo = (a.k - 1) * a.dil + 1;
   auto xrow_of = [&](int bn) {
-    const int items_max = (int)std::min<long long>(a.B, (bn + a.n_out - 2) / a.n_out + 1);
+    const int nmin = a.n_out_min > 0 ? a.n_out_min : a.n_out;
+    const int items_max = (int)std::min<long long>(a.B, (bn + nmin - 2) / nmin + 1);
     return ((bn - 1) * a.stride + (items_max - 1) * std::max(halo - a.stride, 0) + halo) | 1;
   };
   static const bool use_wp = env_int("EVMI_F32_WP", 1) != 0;  // wave-private rings for the K-split tiles (A/B switch)
@@ -681,24 +722,13 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   return nullptr;
 }
 
-int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, long long wfrag_ws_elems, int groups,
-                             hipStream_t stream) {
-  F32Plan pl;
-  if (const char* why = plan_conv_f32(a, groups, pl)) {
-    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_cbt_f32_mfma: ") + why);
-  }
-  const long long wf_total = wfrag_elems(a.cout_g * groups, a.cin_g * groups, a.k, groups);
-  if (!wfrag_ws || wfrag_ws_elems < wf_total || (reinterpret_cast<uintptr_t>(wfrag_ws) & 15))
-    return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_f32_mfma: weight-fragment workspace missing, too small or unaligned");
+static int dispatch_conv_f32(ConvF32Args a, const F32Plan& pl, hipStream_t stream) {
   const int ti = pl.ti;
   const size_t lds = pl.lds;
-  const dim3 grid = pl.grid;
+  dim3 grid = pl.grid;
+  grid.z = a.phases;
   const int bm = kTiles[ti].bm, bn = kTiles[ti].bn, ks = kTiles[ti].ks;
   a.ablate = env_int("EVMI_F32_ABLATE", 0);
-
-  hipLaunchKernelGGL(wfrag_kernel, dim3(a.pairs, groups * a.mblocks), dim3(256), 0, stream, w, wfrag_ws, a.cout_g, a.cin_g,
-                     a.k, a.mblocks, a.pairs);
-  a.wf = wfrag_ws;
   a.tl = nullptr;
   const bool want_tl = env_int("EVMI_F32_TL", 0) != 0;
   if (want_tl) {
@@ -771,6 +801,72 @@ static ConvDirectArgs direct_args(int B, int c_in, int t_in, int c_out, int t_ou
   return d;
 }
 
+int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, long long wfrag_ws_elems, int groups,
+                             hipStream_t stream) {
+  F32Plan pl;
+  if (const char* why = plan_conv_f32(a, groups, pl)) {
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_cbt_f32_mfma: ") + why);
+  }
+  const long long wf_total = wfrag_elems(a.cout_g * groups, a.cin_g * groups, a.k, groups);
+  if (!wfrag_ws || wfrag_ws_elems < wf_total || (reinterpret_cast<uintptr_t>(wfrag_ws) & 15))
+    return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_f32_mfma: weight-fragment workspace missing, too small or unaligned");
+  hipLaunchKernelGGL(wfrag_kernel, dim3(a.pairs, groups * a.mblocks), dim3(256), 0, stream, w, wfrag_ws, a.cout_g, a.cin_g,
+                     a.k, a.mblocks, a.pairs);
+  a.wf = wfrag_ws;
+  a.phases = 1; a.wf_phase_stride = 0;
+  a.ph_pad[0] = a.pad; a.ph_nout[0] = a.n_out; a.ph_off[0] = a.out_offset;
+  return dispatch_conv_f32(a, pl, stream);
+}
+
+// Input gradient of y = conv1d(x, w, stride, pad, dil, groups): dx [c_in][B][t_in] from dy [c_out][B][t_out], all phases in
+// one launch (grid.z).  Strided layers must not be dilated.
+static const char* plan_dgrad(int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
+                              ConvF32Args& a, F32Plan& pl) {
+  if (groups <= 0 || c_in <= 0 || c_out <= 0 || c_in % groups || c_out % groups) return "bad shape";
+  if (stride > 1 && dil != 1) return "strided and dilated";
+  if (stride > 8) return "stride above 8";
+  const int cin_g = c_in / groups, cout_g = c_out / groups;
+  if (cin_g <= SMALLCO_DIRECT || cout_g == 1) return "direct-kernel shape";  // GEMV / outer product: conv_cbt_direct.hip
+  const int phases = std::min(stride, k), M = (k + stride - 1) / stride;
+  a.B = B; a.t_in = t_out; a.t_out_total = t_in;
+  a.cin_g = cout_g; a.cout_g = cin_g; a.k = M; a.stride = 1; a.dil = stride == 1 ? dil : 1;
+  a.out_stride = stride; a.accumulate = 0; a.bias = nullptr; a.phases = phases;
+  int n_max = 0, n_min = 0;
+  for (int phi = 0; phi < phases; ++phi) {
+    if (stride == 1) {
+      a.ph_pad[0] = dil * (k - 1) - pad; a.ph_nout[0] = t_in; a.ph_off[0] = 0;
+    } else {
+      const int num = pad - phi;  // first q with stride*q + phi - pad >= 0
+      const int q0 = num > 0 ? (num + stride - 1) / stride : 0;
+      const int q_hi = (t_in - 1 + pad - phi) >= 0 ? (t_in - 1 + pad - phi) / stride : -1;
+      a.ph_pad[phi] = (M - 1) - q0;
+      a.ph_nout[phi] = std::max(0, q_hi - q0 + 1);
+      a.ph_off[phi] = stride * q0 + phi - pad;
+    }
+    n_max = std::max(n_max, a.ph_nout[phi]);
+    if (a.ph_nout[phi] > 0) n_min = n_min == 0 ? a.ph_nout[phi] : std::min(n_min, a.ph_nout[phi]);
+  }
+  if (n_max <= 0) return "no outputs";
+  a.n_out = n_max; a.n_out_min = n_min; a.pad = 0; a.out_offset = 0;
+  return plan_conv_f32(a, groups, pl);
+}
+
+int launch_conv_dgrad_f32_mfma(const float* dy, const float* w, float* dx, float* ws, long long ws_elems, int B, int c_in, int t_in,
+                               int c_out, int t_out, int k, int stride, int pad, int dil, int groups, hipStream_t stream) {
+  ConvF32Args a = {};
+  F32Plan pl;
+  if (const char* why = plan_dgrad(B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups, a, pl))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_dgrad_f32_mfma: ") + why);
+  const long long per_phase = wfrag_elems(c_in, c_out, a.k, groups);  // dy channels in, x channels out
+  if (!ws || ws_elems < per_phase * a.phases || (reinterpret_cast<uintptr_t>(ws) & 15))
+    return fail(EVMI_ERR_INVALID_ARG, "conv_dgrad_f32_mfma: workspace missing, too small or unaligned");
+  if (a.pairs > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_dgrad_f32_mfma: grid limits");
+  hipLaunchKernelGGL(wfrag_dgrad_kernel, dim3(a.pairs, groups * a.mblocks, a.phases), dim3(256), 0, stream, w, ws, c_out / groups,
+                     c_in / groups, k, stride, a.k, a.mblocks, a.pairs, per_phase);
+  a.x = dy; a.y = dx; a.wf = ws; a.wf_phase_stride = per_phase;
+  return dispatch_conv_f32(a, pl, stream);
+}
+
 }  // namespace evmi
 
 using namespace evmi;
@@ -795,6 +891,22 @@ int evmi_conv1d_cbt_f32_supported(int B, int c_in, int t_in, int c_out, int n_ou
   return plan_conv_f32(a, groups, pl) == nullptr ? 1 : 0;
 }
 
+long long evmi_conv1d_dgrad_cbt_f32_ws_elems(int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil,
+                                             int groups) {
+  ConvF32Args a = {};
+  F32Plan pl;
+  if (plan_dgrad(B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups, a, pl)) return 0;
+  return wfrag_elems(c_in, c_out, a.k, groups) * a.phases;
+}
+
+int evmi_conv1d_dgrad_cbt_f32(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems, int B,
+                              int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
+                              void* stream) {
+  if (!dy_dev || !w_dev || !dx_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_f32: null pointer");
+  return launch_conv_dgrad_f32_mfma(dy_dev, w_dev, dx_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups,
+                                    (hipStream_t)stream);
+}
+
 int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
                         float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
                         int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups, int out_stride,
@@ -809,7 +921,7 @@ int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bia
     if (conv_direct_plan(d, groups, cc, nchunks) > 0)
       return launch_conv_direct(d, groups, wfrag_ws_dev, wfrag_ws_elems, (hipStream_t)stream);
   }
-  ConvF32Args a;
+  ConvF32Args a = {};
   a.x = x_dev; a.wf = nullptr; a.bias = bias_dev; a.y = y_dev;
   a.B = B; a.t_in = t_in; a.t_out_total = t_out_total; a.n_out = n_out;
   a.cin_g = c_in / groups; a.cout_g = c_out / groups; a.k = k; a.stride = stride; a.dil = dil; a.pad = pad;

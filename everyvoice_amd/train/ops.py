@@ -137,6 +137,13 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
     _, cin_g, k = w.shape
     cin = cin_g * groups
     lib = _lib.load()
+    ws_elems = lib.evmi_conv1d_dgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+    if ws_elems > 0:  # every phase in one launch, weight fragments straight from w
+        ws = WS.get("wfrag", ws_elems, dy.device)
+        dx = (torch.zeros if k < stride else torch.empty)(cin, B, t_in, device=dy.device, dtype=torch.float32)
+        _chk(lib.evmi_conv1d_dgrad_cbt_f32(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
+                                           k, stride, pad, dil, groups, _s(dy)), "evmi_conv1d_dgrad_cbt_f32")
+        return dx
     if stride == 1:
         wt = WS.get("wt", cin * (cout // groups) * k, dy.device)
         _chk(lib.evmi_dgrad_weights_f32(w.data_ptr(), wt.data_ptr(), cin, cout, k, groups, 1, 0, _s(dy)), "evmi_dgrad_weights_f32")

@@ -219,6 +219,16 @@ int evmi_conv1d_cbt_f32_supported(int B, int c_in, int t_in, int c_out, int n_ou
  * MFMA-fragment copy of the weights (re-laid on the stream before every convolution: the weights change every
  * optimiser step), or the channel-split scratch of the few-output-channel kernel. */
 long long evmi_conv1d_cbt_f32_ws_elems(int B, int c_in, int c_out, int n_out, int k, int groups);
+/* Input gradient of the same convolution: dx [c_in][B][t_in] from dy [c_out][B][t_out] and the forward weights w.
+ * A strided layer's gradient is min(stride, k) polyphase stride-1 convolutions of dy; they run as ONE launch (the weight
+ * fragments of all phases are built straight from w, phases with fewer taps zero padded).  ws: 16-byte aligned scratch of
+ * evmi_conv1d_dgrad_cbt_f32_ws_elems floats; 0 = shape not taken here (GEMV / outer-product shapes, dilated strided
+ * layers): compose evmi_dgrad_weights_f32 + evmi_conv1d_cbt_f32 per phase instead. */
+long long evmi_conv1d_dgrad_cbt_f32_ws_elems(int B, int c_in, int t_in, int c_out, int t_out, int k, int stride,
+                                             int pad, int dil, int groups);
+int evmi_conv1d_dgrad_cbt_f32(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev,
+                              long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k,
+                              int stride, int pad, int dil, int groups, void* stream);
 /* Weight gradient of the same convolution as an implicit GEMM on the fp32 matrix cores (no unfold):
  *   dw[co][ci][j] (+)= sum_{b,to} dy[co][b][to] * x[ci][b][to*stride + j*dil - pad]
  * x [c_in][B][t_in], dy [c_out][B][n_out], dw [c_out][c_in/groups][k]; `ws_dev`: 16-byte aligned scratch of

@@ -228,3 +228,31 @@ def test_conv1d_wgrad_mfma(cuda_device, case):
         want = w.grad + (base if accumulate else 0)
         scale = float(w.grad.abs().max())
         assert float((dw.cpu() - want).abs().max()) <= 2e-5 * scale + 1e-6, case
+
+
+DGRAD_CASES = [
+    # (B, T, cin, cout, k, stride, pad, dil, groups)
+    (22, 28, 64, 96, 5, 3, 2, 1, 1),         # strided on short rows: three phases of different lengths in one launch
+    (12, 9, 128, 160, 5, 3, 2, 1, 1),        # rows of 9 -> phases of 3 samples: the staged row is planned for the shortest phase
+    (4, 513, 64, 128, 41, 4, 20, 1, 16),     # grouped, stride 4, odd length
+    (3, 100, 48, 40, 2, 3, 0, 1, 1),         # kernel shorter than the stride: one residue class is never written (stays zero)
+    (16, 300, 128, 128, 11, 1, 25, 5, 1),    # dilated stride-1
+    (5, 64, 40, 72, 7, 2, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv1d_dgrad_fused_phases(cuda_device, case):
+    """evmi_conv1d_dgrad_cbt_f32 (all polyphase components in one launch) vs torch autograd."""
+    from everyvoice_amd.train import ops
+
+    B, T, cin, cout, k, s, p, d, groups = case
+    g = torch.Generator().manual_seed(T * 3 + k)
+    x = torch.randn(B, cin, T, generator=g, requires_grad=True)
+    w = torch.randn(cout, cin // groups, k, generator=g) * 0.2
+    y = F.conv1d(x, w, None, s, p, d, groups)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dx = ops.conv1d_bwd_data_mfma(cbt(dy).to(cuda_device), w.to(cuda_device), T, s, p, d, groups)
+    scale = float(x.grad.abs().max())
+    assert float((bct(dx.cpu()) - x.grad).abs().max()) <= 2e-5 * scale + 1e-6, case
