@@ -13,6 +13,8 @@ struct ConvDirectArgs {
   int B, t_in, t_out_total, n_out;
   int c_in, c_out, k, stride, dil, pad;
   int out_stride, out_offset, accumulate;
+  int act;          // epilogue: 0 none, 1 leaky-relu(act_param), 2 SiLU, 3 ReLU, 4 tanh
+  float act_param;
   int cc, nchunks;  // channels per workgroup / number of channel chunks
 };
 

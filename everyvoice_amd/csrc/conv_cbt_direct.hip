@@ -16,6 +16,14 @@
 
 namespace evmi {
 
+__device__ __forceinline__ float direct_act(float v, int act, float p) {
+  if (act == 1) return v > 0.f ? v : v * p;
+  if (act == 2) return v / (1.f + expf(-v));
+  if (act == 3) return fmaxf(v, 0.f);
+  if (act == 4) return tanhf(v);
+  return v;
+}
+
 constexpr int SMALLCO_MAX = 4;
 
 // grid (ceil(N / 64), nchunks), 256 threads: lane = column, wave = quarter of the workgroup's channels
@@ -61,6 +69,7 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(ConvDirectArgs a) {
       a.partial[((long long)blockIdx.y * a.c_out + co) * n_total + n] = v;
     } else {
       if (a.bias) v += a.bias[co];
+      v = direct_act(v, a.act, a.act_param);
       float* dst = a.y + ((long long)co * a.B + b) * a.t_out_total + (long long)to * a.out_stride + a.out_offset;
       *dst = a.accumulate ? *dst + v : v;
     }
@@ -76,6 +85,7 @@ __global__ void conv_smallco_reduce_kernel(ConvDirectArgs a) {
   const long long n = i - (long long)co * n_total;
   float v = a.bias ? a.bias[co] : 0.f;
   for (int ch = 0; ch < a.nchunks; ++ch) v += a.partial[((long long)ch * a.c_out + co) * n_total + n];
+  v = direct_act(v, a.act, a.act_param);
   const int b = (int)(n / a.n_out);
   const int to = (int)(n - (long long)b * a.n_out);
   float* dst = a.y + ((long long)co * a.B + b) * a.t_out_total + (long long)to * a.out_stride + a.out_offset;
@@ -117,6 +127,7 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(ConvDirectArgs a) {
     float v = bl[co];
 #pragma unroll
     for (int j = 0; j < CIN1_KMAX; ++j) v = fmaf(wl[co * CIN1_KMAX + j], xv[j], v);
+    v = direct_act(v, a.act, a.act_param);
     *dst = a.accumulate ? *dst + v : v;
     dst += co_stride;
   }

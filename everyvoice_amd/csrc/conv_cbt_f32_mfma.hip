@@ -23,6 +23,7 @@
 // stride-1 convolutions through this same kernel.
 #include <algorithm>
 #include <cstdint>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 
@@ -41,6 +42,8 @@ struct ConvF32Args {
   int cin_g, cout_g, k, stride, dil, pad;
   int out_stride, out_offset;  // y index = to * out_stride + out_offset
   int accumulate;              // y += instead of y =
+  int act;                     // epilogue on (conv + bias): 0 none, 1 leaky-relu(act_param), 2 SiLU, 3 ReLU, 4 tanh
+  float act_param;
   int mtiles_per_group;
   int mblocks, pairs;          // wf dims: ceil(cout_g / 32), ceil(cin_g / 2)
   // tiling chosen by the host
@@ -57,6 +60,27 @@ struct ConvF32Args {
   int ablate;   // timing experiments only (EVMI_F32_ABLATE): 1 no input loads, 2 no weight loads, 4 no MFMA
   long long* tl;  // timing experiments only (EVMI_F32_TL): s_memtime stamps of workgroup (0, 0), [step][wave][4]
 };
+
+// activation epilogue shared by the convolution kernels (the code is wave-uniform: one branch)
+template <int ACT>
+__device__ __forceinline__ float conv_act(float v, float p) {
+  if (ACT == 1) return v > 0.f ? v : v * p;
+  if (ACT == 2) return v / (1.f + expf(-v));
+  if (ACT == 3) return fmaxf(v, 0.f);
+  if (ACT == 4) return tanhf(v);
+  return v;
+}
+// run `body(integral_constant<ACT>)` for the runtime activation code: one wave-uniform switch outside the store loops
+template <class F>
+__device__ __forceinline__ void with_act(int act, F&& body) {
+  switch (act) {
+    case 1: body(std::integral_constant<int, 1>{}); break;
+    case 2: body(std::integral_constant<int, 2>{}); break;
+    case 3: body(std::integral_constant<int, 3>{}); break;
+    case 4: body(std::integral_constant<int, 4>{}); break;
+    default: body(std::integral_constant<int, 0>{}); break;
+  }
+}
 
 constexpr int SMALLCO_DIRECT = 4;  // output channels up to which conv_cbt_direct.hip takes the shape
 constexpr int F32_PMAX = 10;  // 64-column pieces of a staged row (xrow <= 640)
@@ -360,24 +384,28 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   }
 
   // ---- epilogue: D layout: lane column = output position, registers = output channels ----
+  with_act(a.act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    if (col_b[nt] < 0) continue;
-    float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
+    for (int nt = 0; nt < NT; ++nt) {
+      if (col_b[nt] < 0) continue;
+      float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m >= m_valid) continue;
-        const int co = co0 + m;
-        float v = acc[mt][nt][r];
-        if (a.bias) v += a.bias[co];
-        float* dst = ycol + (long long)co * a.B * a.t_out_total;
-        *dst = a.accumulate ? *dst + v : v;
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (m >= m_valid) continue;
+          const int co = co0 + m;
+          float v = acc[mt][nt][r];
+          if (a.bias) v += a.bias[co];
+          v = conv_act<ACT>(v, a.act_param);
+          float* dst = ycol + (long long)co * a.B * a.t_out_total;
+          *dst = a.accumulate ? *dst + v : v;
+        }
       }
     }
-  }
+  });
 }
 
 // ---- wave-private variant (the K-split tiles) -------------------------------------------------------------------------
@@ -603,24 +631,28 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
           for (int r = 0; r < 16; ++r) acc[mt][nt][r] += src[((mt * NT + nt) * 16 + r) * 64];
     }
   }
+  with_act(a.act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    if (col_b[nt] < 0) continue;
-    float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
+    for (int nt = 0; nt < NT; ++nt) {
+      if (col_b[nt] < 0) continue;
+      float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m >= m_valid) continue;
-        const int co = co0 + m;
-        float v = acc[mt][nt][r];
-        if (a.bias) v += a.bias[co];
-        float* dst = ycol + (long long)co * a.B * a.t_out_total;
-        *dst = a.accumulate ? *dst + v : v;
+        for (int r = 0; r < 16; ++r) {
+          const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (m >= m_valid) continue;
+          const int co = co0 + m;
+          float v = acc[mt][nt][r];
+          if (a.bias) v += a.bias[co];
+          v = conv_act<ACT>(v, a.act_param);
+          float* dst = ycol + (long long)co * a.B * a.t_out_total;
+          *dst = a.accumulate ? *dst + v : v;
+        }
       }
     }
-  }
+  });
 }
 
 struct F32Tile { int bm, bn, ks; };
@@ -910,13 +942,13 @@ int evmi_conv1d_dgrad_cbt_f32(const float* dy_dev, const float* w_dev, float* dx
 int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
                         float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
                         int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups, int out_stride,
-                        int out_offset, int accumulate, void* stream) {
+                        int out_offset, int accumulate, int act, float act_param, void* stream) {
   if (!x_dev || !w_dev || !y_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_f32: null pointer");
   if (groups <= 0 || c_in % groups || c_out % groups) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_f32: groups");
   {  // GEMV / outer-product shapes: direct kernels (conv_cbt_direct.hip)
     ConvDirectArgs d = direct_args(B, c_in, t_in, c_out, t_out_total, n_out, k, stride, pad, dil);
     d.x = x_dev; d.w = w_dev; d.bias = bias_dev; d.y = y_dev; d.out_stride = out_stride; d.out_offset = out_offset;
-    d.accumulate = accumulate;
+    d.accumulate = accumulate; d.act = act; d.act_param = act_param;
     int cc, nchunks;
     if (conv_direct_plan(d, groups, cc, nchunks) > 0)
       return launch_conv_direct(d, groups, wfrag_ws_dev, wfrag_ws_elems, (hipStream_t)stream);
@@ -926,6 +958,8 @@ int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bia
   a.B = B; a.t_in = t_in; a.t_out_total = t_out_total; a.n_out = n_out;
   a.cin_g = c_in / groups; a.cout_g = c_out / groups; a.k = k; a.stride = stride; a.dil = dil; a.pad = pad;
   a.out_stride = out_stride; a.out_offset = out_offset; a.accumulate = accumulate; a.mtiles_per_group = 1;
+  a.act = act; a.act_param = act_param;
+  if (act < 0 || act > 4 || (act && accumulate)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_f32: activation (0..4, not with accumulate)");
   return launch_conv_cbt_f32_mfma(a, w_dev, wfrag_ws_dev, wfrag_ws_elems, groups, (hipStream_t)stream);
 }
 

@@ -102,8 +102,8 @@ def _s(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def _conv(x, w, b, k=1):
-    return ops.conv1d_mfma(x, w, b, 1, (k - 1) // 2, 1, 1)
+def _conv(x, w, b, k=1, act=ops.ACT_NONE):
+    return ops.conv1d_mfma(x, w, b, 1, (k - 1) // 2, 1, 1, act=act)
 
 
 def _layernorm(x, g, b):
@@ -158,8 +158,7 @@ class _Conformer:
             self.layers.append(L)
 
     def _ffn(self, x, P):
-        h = _conv(_layernorm(x, P["ln_g"], P["ln_b"]), P["w1"], P["b1"])
-        h = ops.elementwise(13, h, out=h)  # SiLU
+        h = _conv(_layernorm(x, P["ln_g"], P["ln_b"]), P["w1"], P["b1"], act=ops.ACT_SILU)
         return ops.axpby(1.0, x, 0.5, _conv(h, P["w2"], P["b2"]))
 
     def forward(self, x, lens):
@@ -204,8 +203,8 @@ class _VariancePredictor:
         """x [D, B, L] -> [B, L] (zero at padded positions)."""
         k = self.cfg.kernel_size
         for P in self.layers:
-            h = _conv(_dwconv(x, P["w_dw"], P["b_dw"], k, 0), P["w_pw"], P["b_pw"]) if self.cfg.depthwise else _conv(x, P["w"], P["b"], k)
-            h = ops.elementwise(14, h, out=h)  # ReLU
+            h = (_conv(_dwconv(x, P["w_dw"], P["b_dw"], k, 0), P["w_pw"], P["b_pw"], act=ops.ACT_RELU) if self.cfg.depthwise
+                 else _conv(x, P["w"], P["b"], k, act=ops.ACT_RELU))
             x = _layernorm(h, P["ln_g"], P["ln_b"])
         y = _conv(x, self.w_lin, self.b_lin)  # [1, B, L]
         _chk(_lib.load().evmi_mask_cols_f32(y.data_ptr(), lens.data_ptr(), 1, y.shape[1], y.shape[2], _s(y)), "evmi_mask_cols_f32")
@@ -363,9 +362,7 @@ class FastSpeech2:
         if self.postnet:
             h = mel
             for i, (w, b) in enumerate(self.postnet):
-                h = _conv(h, w, b, c.postnet_kernel)
-                if i < len(self.postnet) - 1:
-                    h = ops.elementwise(ops.EW_TANH, h, out=h)
+                h = _conv(h, w, b, c.postnet_kernel, act=ops.ACT_TANH if i < len(self.postnet) - 1 else ops.ACT_NONE)
             post = ops.axpby(1.0, mel, 1.0, h)
             _chk(lib.evmi_mask_cols_f32(post.data_ptr(), mel_lens.data_ptr(), c.n_mels, B, T, _s(x)), "evmi_mask_cols_f32")
         to_btc = lambda t: t.permute(1, 2, 0).contiguous()

@@ -60,6 +60,25 @@ def conv1d(tape: Tape, x: Var, layer, training: bool = True) -> Var:
     return y
 
 
+def conv1d_lrelu(tape: Tape, x: Var, layer, slope: float, training: bool = True) -> Var:
+    """leaky_relu(conv1d(x)) with the activation in the convolution's epilogue: the pre-activation is never stored; the
+    backward takes its sign from the output (same sign for slope > 0)."""
+    w, dw_sink = layer.effective(training)
+    y = Var(ops.conv1d_fwd(x.data, w, layer.bias_data(), layer.stride, layer.pad, layer.dil, layer.groups, lrelu_slope=slope))
+
+    def bwd():
+        if y.grad is None:
+            return
+        dpre = ops.lrelu_bwd(y.grad, y.data, slope)
+        dx, _, _ = ops.conv1d_bwd(x.data, w, dpre, layer.stride, layer.pad, layer.dil, layer.groups, need_dx=x.needs_grad,
+                                  dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True, need_dw=not layer.frozen)
+        if dx is not None:
+            x.accumulate(dx)
+
+    tape.record(bwd)
+    return y
+
+
 def conv_transpose1d(tape: Tape, x: Var, layer, training: bool = True) -> Var:
     w, dw_sink = layer.effective(training)
     y = Var(ops.conv_transpose1d_fwd(x.data, w, layer.bias_data(), layer.stride, layer.pad))

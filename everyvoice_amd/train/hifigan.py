@@ -78,8 +78,7 @@ class GeneratorT:
                 y = x
                 for c1, c2 in self.resblocks[i * self.num_kernels + j]:
                     t = ag.lrelu(tape, y, self.slope)
-                    t = ag.conv1d(tape, t, c1)
-                    t = ag.lrelu(tape, t, self.slope)
+                    t = ag.conv1d_lrelu(tape, t, c1, self.slope)
                     t = ag.conv1d(tape, t, c2)
                     y = ag.add(tape, t, y)
                 xs = y if xs is None else ag.add(tape, xs, y)
@@ -105,7 +104,7 @@ class DiscriminatorPT:
         x = ag.period_view(tape, audio, self.period)  # [1, B*p, H]: Conv2d((k,1)) == Conv1d over H per column
         fmap = []
         for conv in self.convs:
-            x = ag.lrelu(tape, ag.conv1d(tape, x, conv, training), 0.1)
+            x = ag.conv1d_lrelu(tape, x, conv, 0.1, training)
             fmap.append(x)
         x = ag.conv1d(tape, x, self.conv_post, training)
         fmap.append(x)
@@ -128,7 +127,7 @@ class DiscriminatorST:
     def forward(self, tape, x: ag.Var, training=True):
         fmap = []
         for conv in self.convs:
-            x = ag.lrelu(tape, ag.conv1d(tape, x, conv, training), 0.1)
+            x = ag.conv1d_lrelu(tape, x, conv, 0.1, training)
             fmap.append(x)
         x = ag.conv1d(tape, x, self.conv_post, training)
         fmap.append(x)

@@ -103,8 +103,11 @@ def scalar_reduce(mode, a, b, out, scale=1.0, p=0.0, accumulate=False):
 
 
 # ---- convolutions ---------------------------------------------------------------------------------------
+ACT_NONE, ACT_LRELU, ACT_SILU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
+
+
 def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=None, out_stride=1, out_offset=0,
-                accumulate=False):
+                accumulate=False, act=ACT_NONE, act_param=0.0):
     """fp32 matrix-core implicit GEMM (evmi_conv1d_cbt_f32): x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out]."""
     cin, B, t_in = x.shape
     cout, cin_g, k = w.shape
@@ -116,7 +119,7 @@ def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=No
     wf = WS.get("wfrag", wf_elems, x.device)
     _chk(lib.evmi_conv1d_cbt_f32(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), wf.data_ptr(), wf_elems, B, cin, t_in, cout,
                                          out.shape[2], t_conv if n_out is None else n_out, k, stride, pad, dil, groups,
-                                         out_stride, out_offset, int(accumulate), _s(x)), "evmi_conv1d_cbt_f32")
+                                         out_stride, out_offset, int(accumulate), act, float(act_param), _s(x)), "evmi_conv1d_cbt_f32")
     return out
 
 
@@ -174,12 +177,17 @@ def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bo
     return bool(_lib.load().evmi_conv1d_cbt_f32_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups))
 
 
-def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1):
-    """x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out]."""
+def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, lrelu_slope=None):
+    """x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out] (leaky-relu applied in the epilogue when a slope is given)."""
     cin, B, t_in = x.shape
     cout, cin_g, k = w.shape
     if CONV_BACKEND["fwd"] == "mfma" and mfma_conv_supported(B, cin, t_in, cout, conv_out_len(t_in, k, stride, pad, dil), k, stride, dil, groups):
-        return conv1d_mfma(x, w, bias, stride, pad, dil, groups)
+        if lrelu_slope is None:
+            return conv1d_mfma(x, w, bias, stride, pad, dil, groups)
+        return conv1d_mfma(x, w, bias, stride, pad, dil, groups, act=ACT_LRELU, act_param=lrelu_slope)
+    if lrelu_slope is not None:
+        y = conv1d_fwd(x, w, bias, stride, pad, dil, groups)
+        return elementwise(EW_LRELU, y, out=y, p0=lrelu_slope)
     col, t_out = unfold(x, k, stride, pad, dil)
     y = torch.empty(cout, B, t_out, device=x.device, dtype=torch.float32)
     N = B * t_out

@@ -207,11 +207,13 @@ int evmi_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, co
  *   y[co][b][to*out_stride + out_offset] (+)= bias[co] + conv(x, w)[co][b][to]   for to < n_out
  * x [c_in][B][t_in], w [c_out][c_in/groups][k], y [c_out][B][t_out_total]; out_stride 1 / offset 0 /
  * n_out = t_out_total is the plain convolution, other values place a polyphase component of a strided
- * convolution's input gradient.  c_out <= 4 and c_in == 1 (GEMV / outer-product shapes) run as direct kernels. */
+ * convolution's input gradient.  c_out <= 4 and c_in == 1 (GEMV / outer-product shapes) run as direct kernels.
+ * act: epilogue on conv + bias: 0 none, 1 leaky-relu(act_param), 2 SiLU, 3 ReLU, 4 tanh (not with accumulate). */
 int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
                         float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
                         int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups,
-                        int out_stride, int out_offset, int accumulate, void* stream);
+                        int out_stride, int out_offset, int accumulate, int act, float act_param,
+                        void* stream);
 /* 1 when evmi_conv1d_cbt_f32 can run this shape (degenerate ones -- rows of a few samples under a 41-tap kernel --
  * exceed its staging limits and return EVMI_ERR_UNSUPPORTED; callers use the unfold + GEMM path for those). */
 int evmi_conv1d_cbt_f32_supported(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int dil, int groups);
