@@ -447,3 +447,23 @@ extern "C" int evmi_monotonic_align_f32(const float* value_dev, const int* mel_l
   EVMI_LAUNCH_CHECK("monotonic_align");
   return EVMI_OK;
 }
+
+// ---- per-item embeddings (speaker / language): x[c][b][l] += table[ids[b]][c] for l < lens[b] ---------------------------
+namespace evmi {
+__global__ void fs2_add_item_embedding_kernel(float* __restrict__ x, const int* __restrict__ ids, const int* __restrict__ lens,
+                                              const float* __restrict__ table, int B, int L, int D) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)D * B * L) return;
+  const int l = (int)(i % L), b = (int)((i / L) % B), c = (int)(i / ((long long)L * B));
+  if (l < lens[b]) x[i] += table[(long long)ids[b] * D + c];
+}
+}  // namespace evmi
+
+extern "C" int evmi_fs2_add_item_embedding_f32(float* x_dev, const int* ids_dev, const int* lens_dev, const float* table_dev, int B,
+                                               int L, int D, void* stream) {
+  if (!x_dev || !ids_dev || !lens_dev || !table_dev) return evmi::fail(EVMI_ERR_INVALID_ARG, "fs2_add_item_embedding: null pointer");
+  hipLaunchKernelGGL(evmi::fs2_add_item_embedding_kernel, dim3((unsigned)(((long long)D * B * L + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, x_dev, ids_dev, lens_dev, table_dev, B, L, D);
+  EVMI_LAUNCH_CHECK("fs2_add_item_embedding");
+  return EVMI_OK;
+}

@@ -88,6 +88,8 @@ class FastSpeech2ModelConfig:
     postnet_channels: int = 512
     postnet_kernel: int = 5
     postnet_layers: int = 5
+    n_speakers: int = 0   # table sizes when multispeaker / multilingual (len(speaker2id) / len(lang2id) in the reference)
+    n_languages: int = 0
 
 
 _LN_EPS = 1e-5
@@ -220,8 +222,6 @@ class FastSpeech2:
         self.stats = stats or Stats()
         self.device = torch.device(device)
         self.lang2id, self.speaker2id = lang2id or {}, speaker2id or {}
-        if self.config.multilingual or self.config.multispeaker:
-            raise NotImplementedError("speaker / language embeddings: later round")
         if self.device.type != "cuda":
             raise RuntimeError("FastSpeech2 runs on libevmi_hip (MI355X) only; there is no CPU path")
         _lib.load()
@@ -235,6 +235,8 @@ class FastSpeech2:
         self.inv_freq = put(sd["position_embedding.inv_freq"])
         self.encoder = _Conformer(c.encoder, sd, "encoder", dev)
         self.decoder = _Conformer(c.decoder, sd, "decoder", dev)
+        self.speaker_table = put(sd["speaker_embedding.weight"]) if c.multispeaker else None
+        self.language_table = put(sd["language_embedding.weight"]) if c.multilingual else None
         vp = c.variance_predictors
         self.duration_predictor = _VariancePredictor(vp.duration, sd, "duration_predictor", dev)
         self.pitch_predictor = _VariancePredictor(vp.pitch, sd, "pitch_predictor", dev)
@@ -285,6 +287,10 @@ class FastSpeech2:
                                f"{name}.norms.{i}.weight": (d,), f"{name}.norms.{i}.bias": (d,)})
             shapes.update({name + ".linear.weight": (1, d), name + ".linear.bias": (1,)})
         d = c.encoder.input_dim
+        if c.multispeaker:
+            shapes["speaker_embedding.weight"] = (max(1, c.n_speakers), d)
+        if c.multilingual:
+            shapes["language_embedding.weight"] = (max(1, c.n_languages), d)
         shapes.update({"pitch_embedding.weight": (vp.pitch.n_bins, d), "energy_embedding.weight": (vp.energy.n_bins, d),
                        "mel_linear.weight": (c.n_mels, c.decoder.input_dim), "mel_linear.bias": (c.n_mels,)})
         if c.use_postnet:
@@ -313,10 +319,42 @@ class FastSpeech2:
                 sd[name] = torch.randn(shape, generator=g) / fan_in ** 0.5
         return self.load_state_dict(sd)
 
+    # -- checkpoints (conventions of the reference: everyvoice/tests/test_model.py:85-151, 302-313, 454-459) -----------
+    _VERSION = "1.0"
+
+    def hyper_parameters(self) -> dict:
+        from dataclasses import asdict
+        return {"config": asdict(self.config), "stats": asdict(self.stats), "lang2id": dict(self.lang2id), "speaker2id": dict(self.speaker2id)}
+
+    def to_checkpoint(self, state_dict: dict) -> dict:
+        """Lightning-shaped dict: state_dict, JSON-only hyper_parameters (config, stats, lang2id, speaker2id), model_info."""
+        return {"state_dict": {k: v.detach().cpu() for k, v in state_dict.items()}, "hyper_parameters": self.hyper_parameters(),
+                "model_info": {"name": "FastSpeech2", "version": self._VERSION}}
+
+    @classmethod
+    def from_checkpoint(cls, ckpt: dict, device="cuda:0"):
+        info = ckpt.get("model_info") if isinstance(ckpt, dict) else None
+        if isinstance(info, dict) and info.get("name") != "FastSpeech2":
+            raise TypeError(f"Wrong model type ({info.get('name')}), we are expecting a 'FastSpeech2' model")
+        if isinstance(info, dict) and int(str(info.get("version", "1.0")).split(".")[0]) > int(cls._VERSION.split(".")[0]):
+            raise ValueError("Your model was created with a newer version of EveryVoice, please update your software.")
+        try:
+            hp = ckpt["hyper_parameters"]
+            c = hp["config"]
+            cfg = FastSpeech2ModelConfig(
+                encoder=ConformerConfig(**c["encoder"]), decoder=ConformerConfig(**c["decoder"]),
+                variance_predictors=VariancePredictors(**{k: VariancePredictorConfig(**v) for k, v in c["variance_predictors"].items()}),
+                **{k: v for k, v in c.items() if k not in ("encoder", "decoder", "variance_predictors")})
+            stats = Stats(pitch=StatsInfo(**hp["stats"]["pitch"]), energy=StatsInfo(**hp["stats"]["energy"]))
+        except (KeyError, TypeError) as e:
+            raise TypeError("Unable to load config.  Possible causes: is it really a FastSpeech2Config? or the correct version?") from e
+        model = cls(cfg, stats, device=device, lang2id=hp.get("lang2id"), speaker2id=hp.get("speaker2id"))
+        return model.load_state_dict(ckpt["state_dict"])
+
     # -- forward --------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, ids: torch.Tensor, lens: torch.Tensor, duration_control=1.0, pitch_control=1.0, energy_control=1.0,
-                 durations: torch.Tensor | None = None):
+                 durations: torch.Tensor | None = None, speakers: torch.Tensor | None = None, languages: torch.Tensor | None = None):
         """ids [B, L] (0 = padding), lens [B] -> (mel [B, T, n_mels], postnet mel, durations [B, L], pitch [B, L],
         energy [B, L], mel_lens [B]) on the device."""
         if not self._ready:
@@ -332,6 +370,13 @@ class FastSpeech2:
         _chk(lib.evmi_fs2_embed_f32(ids32.data_ptr(), lens32.data_ptr(), self.table.data_ptr(), self.inv_freq.data_ptr(), x.data_ptr(),
                                     B, L, D, _s(x)), "evmi_fs2_embed_f32")
         x = self.encoder.forward(x, lens32)
+        for table, item_ids, what in ((self.speaker_table, speakers, "speakers"), (self.language_table, languages, "languages")):
+            if table is not None:
+                if item_ids is None:
+                    raise ValueError(f"this model needs `{what}` ids [B]")
+                item32 = item_ids.to(dev, torch.int32).contiguous()
+                _chk(lib.evmi_fs2_add_item_embedding_f32(x.data_ptr(), item32.data_ptr(), lens32.data_ptr(), table.data_ptr(), B, L, D, _s(x)),
+                     "evmi_fs2_add_item_embedding_f32")
         log_d = self.duration_predictor.forward(x, lens32)
         pitch = self.pitch_predictor.forward(x, lens32)
         vp = c.variance_predictors

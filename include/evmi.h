@@ -328,6 +328,9 @@ int evmi_length_regulate_cbt_f32(const float* x_dev, const int* cum_dev, float* 
  * (softmax(Q K^T / sqrt(d_head)) V per head; fp32 matrix cores, online softmax; d_head 32 / 64 / 128). */
 int evmi_attention_cbt_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, int B, int T, int D,
                            int heads, void* stream);
+/* Speaker / language embedding of a multi-speaker / multilingual model: x[c][b][l] += table[ids[b]][c] for l < lens[b]. */
+int evmi_fs2_add_item_embedding_f32(float* x_dev, const int* ids_dev, const int* lens_dev, const float* table_dev,
+                                    int B, int L, int D, void* stream);
 /* Beta-binomial attention prior (everyvoice/preprocessor/attention_prior.py:34-67): the pmf table of
  * BetaBinomial(n = grid_mel, a = i, b = grid_text + 1 - i), i = 1..grid_text, on a [grid_mel][grid_text] grid,
  * zoomed with order-1 interpolation (scipy.ndimage.zoom semantics) to out [T][L], float64. */

@@ -76,6 +76,8 @@ class FastSpeech2ConfigRef:
     pitch: VariancePredictorConfigRef = field(default_factory=VariancePredictorConfigRef)
     n_symbols: int = 80
     n_mels: int = 80
+    n_speakers: int = 0   # > 0: multispeaker (an embedding added to the encoder output, as ming024/FastSpeech2 does)
+    n_languages: int = 0  # > 0: multilingual
     use_postnet: bool = True
     max_length: int = 1000
     postnet_channels: int = 512
@@ -210,6 +212,8 @@ class FastSpeech2Ref(nn.Module):
         self.text_input_layer = nn.Embedding(cfg.n_symbols, d, padding_idx=0)
         self.position_embedding = PositionalEmbeddingRef(d)
         self.encoder = ConformerRef(cfg.encoder)
+        self.speaker_embedding = nn.Embedding(cfg.n_speakers, d) if cfg.n_speakers else None
+        self.language_embedding = nn.Embedding(cfg.n_languages, d) if cfg.n_languages else None
         self.duration_predictor = VariancePredictorRef(cfg.duration)
         self.pitch_predictor = VariancePredictorRef(cfg.pitch)
         self.energy_predictor = VariancePredictorRef(cfg.energy)
@@ -223,12 +227,16 @@ class FastSpeech2Ref(nn.Module):
         self.postnet = PostNetRef(cfg.n_mels, cfg.postnet_channels, cfg.postnet_kernel, cfg.postnet_layers) if cfg.use_postnet else None
 
     @torch.no_grad()
-    def forward(self, ids, lens, duration_control=1.0, pitch_control=1.0, energy_control=1.0, durations=None):
+    def forward(self, ids, lens, duration_control=1.0, pitch_control=1.0, energy_control=1.0, durations=None, speakers=None, languages=None):
         B, L = ids.shape
         pad = torch.arange(L)[None, :] >= lens[:, None]
         x = self.text_input_layer(ids) + self.position_embedding(L)[None]
         x = x.masked_fill(pad[..., None], 0.0)
         x, _ = self.encoder(x, lens)
+        if self.speaker_embedding is not None:
+            x = x + self.speaker_embedding(speakers)[:, None, :].masked_fill(pad[..., None], 0.0)
+        if self.language_embedding is not None:
+            x = x + self.language_embedding(languages)[:, None, :].masked_fill(pad[..., None], 0.0)
         log_d = self.duration_predictor(x, pad)
         pitch = self.pitch_predictor(x, pad) * pitch_control
         x = x + self.pitch_embedding(torch.bucketize(pitch, self.pitch_bins))

@@ -172,3 +172,38 @@ def test_synthesize_from_text_writes_reference_named_files(cuda_device, tmp_path
         assert spec.shape == (80, r["frames"]) and r["frames"] == int(r["durations"].sum())
         with wave.open(str(r["wav"])) as w:
             assert w.getframerate() == 22050 and w.getnframes() == r["frames"] * 256 and w.getsampwidth() == 2
+
+
+def test_multispeaker_multilingual_and_checkpoint_roundtrip(cuda_device):
+    """Speaker / language embeddings (BASELINE config 5: multi-speaker FastSpeech2) and the checkpoint conventions."""
+    import json
+
+    from everyvoice_amd.fs2 import FastSpeech2
+
+    cfg = FastSpeech2ConfigRef.small()
+    cfg.n_speakers, cfg.n_languages = 4, 2
+    torch.manual_seed(12)
+    ref = FastSpeech2Ref(cfg).eval()
+    randomize_norm_stats_(ref, torch.Generator().manual_seed(13))
+    pc = _product_config(cfg)
+    pc.multispeaker, pc.multilingual, pc.n_speakers, pc.n_languages = True, True, 4, 2
+    model = FastSpeech2(pc, device=cuda_device, speaker2id={"a": 0, "b": 1, "c": 2, "d": 3}, lang2id={"x": 0, "y": 1}).load_state_dict(ref.state_dict())
+    ids, lens, g = _batch(20, 3, 11, seed=2)
+    durs = torch.randint(1, 5, (3, 11), generator=g)
+    spk, lang = torch.tensor([3, 0, 2]), torch.tensor([1, 1, 0])
+    want = ref(ids, lens, durations=durs, speakers=spk, languages=lang)
+    got = model(ids, lens, durations=durs, speakers=spk, languages=lang)
+    _close(got[1].cpu(), want[1])
+    with pytest.raises(ValueError, match="speakers"):
+        model(ids, lens, durations=durs)
+
+    ckpt = model.to_checkpoint(ref.state_dict())
+    json.dumps(ckpt["hyper_parameters"])  # JSON-only, like the reference's on_save_checkpoint
+    assert ckpt["model_info"] == {"name": "FastSpeech2", "version": "1.0"}
+    again = FastSpeech2.from_checkpoint(ckpt, device=cuda_device)
+    assert again.speaker2id == {"a": 0, "b": 1, "c": 2, "d": 3}
+    _close(again(ids, lens, durations=durs, speakers=spk, languages=lang)[1].cpu(), want[1])
+    with pytest.raises(TypeError, match="Wrong model type"):
+        FastSpeech2.from_checkpoint({**ckpt, "model_info": {"name": "HiFiGAN", "version": "1.0"}}, device=cuda_device)
+    with pytest.raises(ValueError, match="newer version"):
+        FastSpeech2.from_checkpoint({**ckpt, "model_info": {"name": "FastSpeech2", "version": "9.0"}}, device=cuda_device)
