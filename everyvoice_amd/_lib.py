@@ -99,6 +99,9 @@ SYMBOLS = {
     "evmi_attention_cbt_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_fs2_add_item_embedding_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "evmi_attention_prior_f64": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
+    "evmi_align_attention_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "evmi_forward_sum_loss_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
+    "evmi_binarization_partials_f64": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_longlong, C.c_void_p]),
     "evmi_monotonic_align_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]),
     "evmi_dgrad_weights_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "evmi_gemm_batched_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p]),

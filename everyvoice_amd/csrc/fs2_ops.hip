@@ -467,3 +467,186 @@ extern "C" int evmi_fs2_add_item_embedding_f32(float* x_dev, const int* ids_dev,
   EVMI_LAUNCH_CHECK("fs2_add_item_embedding");
   return EVMI_OK;
 }
+
+// ---- alignment learning (Badlani et al. 2021 as implemented in FastPitch) ------------------------------
+namespace evmi {
+
+// One workgroup per (item, frame): scores over the tokens, log-softmax (+ log prior), masked softmax.
+// q [A][B][T], k [A][B][L] channel-major; prior [B][T][L] float64 or nullptr; soft / logprob [B][T][L].
+__global__ __launch_bounds__(256) void align_attention_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                             const double* __restrict__ prior, const int* __restrict__ text_lens,
+                                                             float* __restrict__ soft, float* __restrict__ logprob, int A, int B,
+                                                             int T, int L, float temperature) {
+  extern __shared__ float sm[];  // [A] query vector, [L] scores, [8] reduction scratch
+  float* qv = sm;
+  float* sc = sm + A;
+  float* red = sc + L;
+  const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < A; c += 256) qv[c] = q[((long long)c * B + b) * T + t];
+  __syncthreads();
+  for (int l = tid; l < L; l += 256) {
+    float d = 0.f;
+    for (int c = 0; c < A; ++c) {
+      const float df = qv[c] - k[((long long)c * B + b) * L + l];
+      d = fmaf(df, df, d);
+    }
+    sc[l] = -temperature * d;
+  }
+  __syncthreads();
+  auto block_max = [&](float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    return v;
+  };
+  auto block_sum = [&](float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    v = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return v;
+  };
+  const long long row = ((long long)b * T + t) * L;
+  if (prior) {  // log_softmax over ALL tokens (padding included, as the reference does), then the prior
+    float m = -INFINITY;
+    for (int l = tid; l < L; l += 256) m = fmaxf(m, sc[l]);
+    m = block_max(m);
+    float s = 0.f;
+    for (int l = tid; l < L; l += 256) s += expf(sc[l] - m);
+    s = block_sum(s);
+    const float lse = m + logf(s);
+    for (int l = tid; l < L; l += 256) sc[l] = sc[l] - lse + logf((float)prior[row + l] + 1e-8f);
+    __syncthreads();
+  }
+  for (int l = tid; l < L; l += 256) logprob[row + l] = sc[l];
+  const int len = min(text_lens[b], L);
+  float m = -INFINITY;
+  for (int l = tid; l < len; l += 256) m = fmaxf(m, sc[l]);
+  m = block_max(m);
+  float s = 0.f;
+  for (int l = tid; l < len; l += 256) s += expf(sc[l] - m);
+  s = block_sum(s);
+  for (int l = tid; l < L; l += 256) soft[row + l] = l < len ? expf(sc[l] - m) / s : 0.f;
+}
+
+__device__ inline float logaddexp_f(float a, float b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  const float m = fmaxf(a, b);
+  return m + log1pf(expf(-fabsf(a - b)));
+}
+
+// CTC forward-sum per item: targets 1..L_b, blank 0 prepended with a fixed log-probability; one workgroup per item,
+// the extended target (2 L_b + 1 states) in parallel, frames in sequence.  loss[b] = -log p(target) / L_b.
+__global__ __launch_bounds__(256) void forward_sum_kernel(const float* __restrict__ logprob, const int* __restrict__ text_lens,
+                                                         const int* __restrict__ mel_lens, float* __restrict__ loss, int T, int L,
+                                                         float blank_logprob) {
+  extern __shared__ float sm[];  // [L + 1] normalised row, 2 x [2L + 1] alpha, [8] scratch
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int Lb = min(text_lens[b], L), Tb = min(mel_lens[b], T), S = 2 * Lb + 1;
+  float* lp = sm;
+  float* alpha0 = lp + (L + 1);
+  float* alpha1 = alpha0 + (2 * L + 1);
+  float* red = alpha1 + (2 * L + 1);
+  if (Lb <= 0 || Tb <= 0) { if (tid == 0) loss[b] = 0.f; return; }
+  for (int t = 0; t < Tb; ++t) {
+    const float* row = logprob + ((long long)b * T + t) * L;
+    // log_softmax over [blank, tokens 0..Lb-1]
+    float m = blank_logprob;
+    for (int l = tid; l < Lb; l += 256) m = fmaxf(m, row[l]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = tid == 0 ? expf(blank_logprob - m) : 0.f;
+    for (int l = tid; l < Lb; l += 256) s += expf(row[l] - m);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float lse = m + logf(red[0] + red[1] + red[2] + red[3]);
+    __syncthreads();
+    if (tid == 0) lp[0] = blank_logprob - lse;
+    for (int l = tid; l < Lb; l += 256) lp[l + 1] = row[l] - lse;
+    __syncthreads();
+    float* cur = (t & 1) ? alpha1 : alpha0;
+    const float* prev = (t & 1) ? alpha0 : alpha1;
+    for (int st = tid; st < S; st += 256) {
+      const int lab = (st & 1) ? (st + 1) / 2 : 0;  // extended target: blank, 1, blank, 2, ...
+      float a;
+      if (t == 0) a = st < 2 ? 0.f : -INFINITY;
+      else {
+        a = prev[st];
+        if (st >= 1) a = logaddexp_f(a, prev[st - 1]);
+        if ((st & 1) && st >= 3) a = logaddexp_f(a, prev[st - 2]);  // consecutive labels always differ
+      }
+      cur[st] = a + lp[lab];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float* fin = ((Tb - 1) & 1) ? alpha1 : alpha0;
+    const float ll = S >= 2 ? logaddexp_f(fin[S - 1], fin[S - 2]) : fin[S - 1];
+    loss[b] = ll == -INFINITY ? 0.f : -ll / (float)Lb;  // zero_infinity; reduction 'mean' divides by the target length
+  }
+}
+
+// partial sums of log(max(soft, 1e-12)) over hard == 1 cells and of hard; finished on the host side of the wrapper
+__global__ __launch_bounds__(256) void binarization_kernel(const int* __restrict__ hard, const float* __restrict__ soft, double* __restrict__ out,
+                                                          long long n) {
+  __shared__ double sh[2][4];
+  double a = 0.0, c = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    if (hard[i] == 1) { a += (double)logf(fmaxf(soft[i], 1e-12f)); c += 1.0; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off, 64); c += __shfl_down(c, off, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = a; sh[1][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    out[2 * blockIdx.x + 1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+  }
+}
+
+}  // namespace evmi
+
+extern "C" {
+
+int evmi_align_attention_f32(const float* q_dev, const float* k_dev, const double* prior_dev, const int* text_lens_dev, float* soft_dev,
+                             float* logprob_dev, int A, int B, int T, int L, float temperature, void* stream) {
+  if (!q_dev || !k_dev || !text_lens_dev || !soft_dev || !logprob_dev) return evmi::fail(EVMI_ERR_INVALID_ARG, "align_attention: null pointer");
+  if (A <= 0 || B <= 0 || T <= 0 || L <= 0 || B > 65535) return evmi::fail(EVMI_ERR_INVALID_ARG, "align_attention: shape");
+  const size_t lds = (size_t)(A + L + 8) * sizeof(float);
+  hipLaunchKernelGGL(evmi::align_attention_kernel, dim3(T, B), dim3(256), lds, (hipStream_t)stream, q_dev, k_dev, prior_dev, text_lens_dev,
+                     soft_dev, logprob_dev, A, B, T, L, temperature);
+  EVMI_LAUNCH_CHECK("align_attention");
+  return EVMI_OK;
+}
+
+int evmi_forward_sum_loss_f32(const float* logprob_dev, const int* text_lens_dev, const int* mel_lens_dev, float* loss_per_item_dev, int B,
+                              int T, int L, float blank_logprob, void* stream) {
+  if (!logprob_dev || !text_lens_dev || !mel_lens_dev || !loss_per_item_dev) return evmi::fail(EVMI_ERR_INVALID_ARG, "forward_sum_loss: null pointer");
+  if (B <= 0 || T <= 0 || L <= 0) return evmi::fail(EVMI_ERR_INVALID_ARG, "forward_sum_loss: shape");
+  const size_t lds = (size_t)((L + 1) + 2 * (2 * L + 1) + 8) * sizeof(float);
+  if (lds > 64 * 1024) return evmi::fail(EVMI_ERR_UNSUPPORTED, "forward_sum_loss: too many tokens");
+  hipLaunchKernelGGL(evmi::forward_sum_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, logprob_dev, text_lens_dev, mel_lens_dev,
+                     loss_per_item_dev, T, L, blank_logprob);
+  EVMI_LAUNCH_CHECK("forward_sum_loss");
+  return EVMI_OK;
+}
+
+int evmi_binarization_partials_f64(const int* hard_dev, const float* soft_dev, double* partials_dev, int n_blocks, long long n, void* stream) {
+  if (!hard_dev || !soft_dev || !partials_dev || n_blocks <= 0) return evmi::fail(EVMI_ERR_INVALID_ARG, "binarization: arguments");
+  hipLaunchKernelGGL(evmi::binarization_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, hard_dev, soft_dev, partials_dev, n);
+  EVMI_LAUNCH_CHECK("binarization");
+  return EVMI_OK;
+}
+
+}  // extern "C"

@@ -210,3 +210,53 @@ def maximum_path(value: torch.Tensor, mel_lens: torch.Tensor, text_lens: torch.T
         _lib.check(_lib.load().evmi_monotonic_align_f32(v.data_ptr(), ml.data_ptr(), tl.data_ptr(), path.data_ptr(), dur.data_ptr(),
                                                         scratch.data_ptr(), B, T, L, _lib.current_stream_ptr(dev)), "evmi_monotonic_align_f32")
     return path, dur.to(torch.int64)
+
+
+# ---- alignment learning: attention over (mel, text), forward-sum loss, binarisation loss --------------
+def alignment_attention(q_enc: torch.Tensor, k_enc: torch.Tensor, text_lens: torch.Tensor, prior: torch.Tensor | None = None,
+                        temperature: float = 1.0):
+    """q_enc [B, A, T], k_enc [B, A, L] (the projected mel / text of the aligner), prior [B, T, L] (float64, A9) ->
+    (soft attention [B, T, L], log-probabilities [B, T, L])."""
+    if not q_enc.is_cuda:
+        raise RuntimeError("everyvoice_amd.heavy computes on the GPU only (no CPU fallback)")
+    B, A, T = q_enc.shape
+    L = k_enc.shape[2]
+    dev = q_enc.device
+    q = q_enc.to(torch.float32).permute(1, 0, 2).contiguous()
+    k = k_enc.to(torch.float32).permute(1, 0, 2).contiguous()
+    tl = text_lens.to(dev, torch.int32).contiguous()
+    pr = None if prior is None else prior.to(dev, torch.float64).contiguous()
+    soft = torch.empty(B, T, L, device=dev, dtype=torch.float32)
+    logprob = torch.empty_like(soft)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().evmi_align_attention_f32(q.data_ptr(), k.data_ptr(), _lib.ptr(pr), tl.data_ptr(), soft.data_ptr(),
+                                                        logprob.data_ptr(), A, B, T, L, float(temperature), _lib.current_stream_ptr(dev)),
+                   "evmi_align_attention_f32")
+    return soft, logprob
+
+
+def forward_sum_loss(attn_logprob: torch.Tensor, text_lens: torch.Tensor, mel_lens: torch.Tensor, blank_logprob: float = -1.0) -> torch.Tensor:
+    """Mean over the batch of the CTC forward-sum loss of every item (attn_logprob [B, T, L])."""
+    B, T, L = attn_logprob.shape
+    dev = attn_logprob.device
+    lp = attn_logprob.to(torch.float32).contiguous()
+    tl, ml = text_lens.to(dev, torch.int32).contiguous(), mel_lens.to(dev, torch.int32).contiguous()
+    per_item = torch.empty(B, device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().evmi_forward_sum_loss_f32(lp.data_ptr(), tl.data_ptr(), ml.data_ptr(), per_item.data_ptr(), B, T, L,
+                                                         float(blank_logprob), _lib.current_stream_ptr(dev)), "evmi_forward_sum_loss_f32")
+    return per_item.mean()
+
+
+def binarization_loss(hard: torch.Tensor, soft: torch.Tensor) -> torch.Tensor:
+    """-sum log(clamp(soft, 1e-12)) over the hard alignment's cells / number of cells."""
+    dev = soft.device
+    h, s = hard.to(dev, torch.int32).contiguous(), soft.to(torch.float32).contiguous()
+    n = s.numel()
+    nb = max(1, min(256, (n + 2047) // 2048))
+    part = torch.empty(nb, 2, device=dev, dtype=torch.float64)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().evmi_binarization_partials_f64(h.data_ptr(), s.data_ptr(), part.data_ptr(), nb, n, _lib.current_stream_ptr(dev)),
+                   "evmi_binarization_partials_f64")
+    tot = part.sum(0)
+    return (-tot[0] / tot[1]).to(torch.float32)

@@ -335,6 +335,19 @@ int evmi_fs2_add_item_embedding_f32(float* x_dev, const int* ids_dev, const int*
  * BetaBinomial(n = grid_mel, a = i, b = grid_text + 1 - i), i = 1..grid_text, on a [grid_mel][grid_text] grid,
  * zoomed with order-1 interpolation (scipy.ndimage.zoom semantics) to out [T][L], float64. */
 int evmi_attention_prior_f64(double* out_dev, int T, int L, int grid_mel, int grid_text, void* stream);
+/* Alignment learning (Badlani et al. 2021; FastPitch ConvAttention / AttentionCTCLoss / AttentionBinarizationLoss):
+ * scores -temperature * ||q_t - k_l||^2 over the projected mel q [A][B][T] and text k [A][B][L], log-softmax over the tokens
+ * plus log(prior + 1e-8) (prior [B][T][L] float64 or NULL) -> logprob [B][T][L]; soft = softmax over the unpadded tokens. */
+int evmi_align_attention_f32(const float* q_dev, const float* k_dev, const double* prior_dev, const int* text_lens_dev,
+                             float* soft_dev, float* logprob_dev, int A, int B, int T, int L, float temperature,
+                             void* stream);
+/* CTC forward-sum loss per item over logprob [B][T][L] (blank with log-probability `blank_logprob` prepended, targets
+ * 1..L_b, zero_infinity, divided by L_b); the batch loss is their mean. */
+int evmi_forward_sum_loss_f32(const float* logprob_dev, const int* text_lens_dev, const int* mel_lens_dev,
+                              float* loss_per_item_dev, int B, int T, int L, float blank_logprob, void* stream);
+/* Binarisation loss partial sums: partials[2*i] = sum log(max(soft, 1e-12)) over hard == 1, partials[2*i+1] = count. */
+int evmi_binarization_partials_f64(const int* hard_dev, const float* soft_dev, double* partials_dev, int n_blocks,
+                                   long long n, void* stream);
 /* Monotonic alignment search (the reference's hard alignments: third-party ilt-monotonic-align 1.2.1 = Glow-TTS
  * maximum_path): value [B][T][L] log-likelihoods, mel_lens / text_lens [B] -> path [B][T][L] (0/1, one token per
  * frame, monotonic, every token used) and durations [B][L] = frames per token.  scratch: B*T*L bytes. */

@@ -1,0 +1,44 @@
+"""Alignment learning of the feature-prediction model, restated -- TEST INFRASTRUCTURE ONLY.
+
+The reference's implementation lives in the absent submodule FastSpeech2_lightning; its configuration names the method
+(``learn_alignment``: Badlani et al. 2021, arXiv 2108.10447) and the loss weights (``attn_ctc_loss_weight``,
+``attn_bin_loss_weight``, ``everyvoice/.schema/everyvoice-text-to-spec-0.5.json`` FastSpeech2TrainingConfig).  PARITY UNPINNED;
+this follows the public implementation of that paper (NVIDIA FastPitch ``ConvAttention`` / ``AttentionCTCLoss`` /
+``AttentionBinarizationLoss``) with the beta-binomial prior of ``everyvoice/preprocessor/attention_prior.py`` (A9, pinned).
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def alignment_attention_ref(q_enc, k_enc, text_lens, prior=None, temperature: float = 1.0):
+    """q_enc [B, A, T] (projected mel), k_enc [B, A, L] (projected text), prior [B, T, L] or None ->
+    (attn soft [B, T, L] with padded keys at probability 0, attn_logprob [B, T, L] before masking)."""
+    attn = -temperature * ((q_enc[:, :, :, None] - k_enc[:, :, None, :]) ** 2).sum(1)  # [B, T, L]
+    if prior is not None:
+        attn = F.log_softmax(attn, dim=2) + torch.log(prior.to(attn.dtype) + 1e-8)
+    logprob = attn.clone()
+    L = k_enc.shape[2]
+    mask = torch.arange(L)[None, None, :] >= text_lens[:, None, None]
+    soft = F.softmax(attn.masked_fill(mask, float("-inf")), dim=2)
+    return soft, logprob
+
+
+def forward_sum_loss_ref(attn_logprob, text_lens, mel_lens, blank_logprob: float = -1.0):
+    """CTC forward-sum loss over the alignment log-probabilities [B, T, L] (blank prepended at index 0)."""
+    padded = F.pad(attn_logprob, (1, 0), value=blank_logprob)  # [B, T, L + 1]
+    total = attn_logprob.new_zeros(())
+    for b in range(attn_logprob.shape[0]):
+        Lb, Tb = int(text_lens[b]), int(mel_lens[b])
+        target = torch.arange(1, Lb + 1).unsqueeze(0)
+        cur = F.log_softmax(padded[b, :Tb, : Lb + 1], dim=1).unsqueeze(1)  # [T, 1, L + 1]
+        total = total + F.ctc_loss(cur, target, input_lengths=torch.tensor([Tb]), target_lengths=torch.tensor([Lb]), blank=0,
+                                   zero_infinity=True)
+    return total / attn_logprob.shape[0]
+
+
+def binarization_loss_ref(hard, soft):
+    """-mean log soft attention on the cells of the hard (monotonic) alignment."""
+    return -torch.log(torch.clamp(soft[hard == 1], min=1e-12)).sum() / hard.sum()

@@ -159,3 +159,33 @@ def test_monotonic_alignment_search_matches_oracle(cuda_device):
         assert np.array_equal(path.cpu().numpy(), want_path), (B, T, L)
         assert np.array_equal(dur.cpu().numpy(), want_dur)
         assert torch.equal(dur.sum(1).cpu(), mel_lens)  # every frame belongs to exactly one token
+
+
+def test_alignment_learning_forward_matches_oracle(cuda_device):
+    """F5 forward: attention (with the A9 prior), CTC forward-sum loss, MAS hard alignment, binarisation loss vs torch CPU."""
+    from everyvoice_amd.heavy import (BetaBinomialInterpolator, alignment_attention, binarization_loss, forward_sum_loss, maximum_path)
+    from oracle.alignment_ref import alignment_attention_ref, binarization_loss_ref, forward_sum_loss_ref
+    from oracle.attention_prior_ref import attention_prior_ref
+
+    g = torch.Generator().manual_seed(21)
+    B, A, T, L = 3, 80, 57, 19
+    text_lens, mel_lens = torch.tensor([19, 11, 15]), torch.tensor([57, 40, 52])
+    q, k = torch.randn(B, A, T, generator=g) * 0.3, torch.randn(B, A, L, generator=g) * 0.3
+    prior = torch.zeros(B, T, L, dtype=torch.float64)
+    interp = BetaBinomialInterpolator(device=cuda_device)
+    for b in range(B):
+        prior[b, : mel_lens[b], : text_lens[b]] = torch.from_numpy(attention_prior_ref(int(mel_lens[b]), int(text_lens[b])))
+        torch.testing.assert_close(interp(int(mel_lens[b]), int(text_lens[b])).cpu(), prior[b, : mel_lens[b], : text_lens[b]], rtol=1e-9, atol=1e-13)
+    for pr in (prior, None):
+        want_soft, want_lp = alignment_attention_ref(q, k, text_lens, pr)
+        soft, lp = alignment_attention(q.to(cuda_device), k.to(cuda_device), text_lens, pr)
+        torch.testing.assert_close(lp.cpu(), want_lp, rtol=2e-5, atol=2e-5)
+        torch.testing.assert_close(soft.cpu(), want_soft, rtol=2e-5, atol=1e-7)
+        want_ctc = forward_sum_loss_ref(want_lp, text_lens, mel_lens)
+        got_ctc = forward_sum_loss(lp, text_lens, mel_lens)
+        assert float(got_ctc) == pytest.approx(float(want_ctc), rel=2e-5)
+    # hard alignment from the soft one (log domain, as the reference's binarisation does), then the binarisation loss
+    path, dur = maximum_path(torch.log(soft.clamp_min(1e-12)), mel_lens, text_lens)
+    hard = path.cpu()
+    assert float(binarization_loss(path, soft)) == pytest.approx(float(binarization_loss_ref(hard, want_soft)), rel=2e-5)
+    assert torch.equal(dur.sum(1).cpu(), mel_lens)
