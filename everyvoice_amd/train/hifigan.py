@@ -180,6 +180,55 @@ class MelLoss:
         return ops.stft_frames_bwd(dfr, B, T, self.n_fft, self.hop)
 
 
+class MultiResolutionSTFTLoss:
+    """Multi-resolution STFT loss (spectral convergence + log-magnitude L1, mean over the resolutions; Yamamoto et al. 2020) --
+    the selectable alternative to the 45 x mel-L1 term that BASELINE.json's config 4 names.  Same GEMM
+    formulation as MelLoss: frames -> windowed DFT (cos | sin) -> sqrt(re^2 + im^2 + eps).  The two Frobenius norms of the
+    spectral-convergence term are read back to the host (one sync per resolution)."""
+
+    def __init__(self, device, resolutions=((1024, 120, 600), (2048, 240, 1200), (512, 50, 240)), eps=1e-7):
+        self.eps, self.res = eps, []
+        for n_fft, hop, win in resolutions:
+            basis, _ = windowed_dft_basis(n_fft, win)
+            nb = n_fft // 2 + 1
+            b = torch.from_numpy(basis)
+            self.res.append((n_fft, hop, nb, b[:, 0 : 2 * nb : 2].t().contiguous().to(device), b[:, 1 : 2 * nb : 2].t().contiguous().to(device)))
+
+    def _mag(self, audio_bt, n_fft, hop, nb, cos, sin):
+        fr, _ = ops.stft_frames(audio_bt, n_fft, hop)
+        re = torch.empty(nb, fr.shape[1], device=fr.device)
+        im = torch.empty_like(re)
+        ops.gemm(cos, fr, re)
+        ops.gemm(sin, fr, im)
+        return ops.elementwise(ops.EW_MAG, re, im, p0=self.eps), re, im
+
+    def loss_and_grad(self, y_bt, yhat_bt, weight, loss_out):
+        """loss_out[0] += weight * mean_r (sc_r + logmag_r); returns d loss / d y_hat [B, T]."""
+        B, T = yhat_bt.shape
+        grad = None
+        w = weight / len(self.res)
+        for n_fft, hop, nb, cos, sin in self.res:
+            my, _, _ = self._mag(y_bt, n_fft, hop, nb, cos, sin)
+            mg, re, im = self._mag(yhat_bt, n_fft, hop, nb, cos, sin)
+            n = mg.numel()
+            sq = torch.zeros(2, device=mg.device)
+            ops.scalar_reduce(1, ops.axpby(1.0, mg, -1.0, my), None, sq[0:1], p=0.0)   # ||mg - my||^2
+            ops.scalar_reduce(1, my, None, sq[1:2], p=0.0)                              # ||my||^2
+            nd, ny = (float(v) ** 0.5 for v in sq.tolist())
+            loss_out += w * nd / ny
+            ops.scalar_reduce(0, ops.elementwise(16, mg), ops.elementwise(16, my), loss_out, scale=w / n, accumulate=True)
+            # d/dmg: spectral convergence (mg - my) / (||mg - my|| ||my||), log-magnitude sign(mg - my) / (n mg)
+            dmag = ops.elementwise(17, mg, my, p0=w / (nd * ny) if nd > 0 else 0.0, p1=w / n)
+            dre = ops.elementwise(ops.EW_MUL_DIV, dmag, re, mg)
+            dim = ops.elementwise(ops.EW_MUL_DIV, dmag, im, mg)
+            dfr = torch.empty(n_fft, dre.shape[1], device=dre.device)
+            ops.gemm(cos, dre, dfr, ta=True)
+            ops.gemm(sin, dim, dfr, ta=True, beta=1.0)
+            g = ops.stft_frames_bwd(dfr, B, T, n_fft, hop)
+            grad = g if grad is None else ops.axpby(1.0, grad, 1.0, g)
+        return grad
+
+
 def allreduce_mean_(flat_grad: torch.Tensor, process_group, scale_fn) -> torch.Tensor:
     """flat_grad <- mean over ranks (sum all-reduce, then ``scale_fn(flat_grad, 1 / world)``)."""
     import torch.distributed as dist
@@ -231,7 +280,7 @@ class HiFiGANTrainer:
     """Generator + MPD + MSD with two AdamW optimisers; ``training_step`` is one full GAN step."""
 
     def __init__(self, config: HiFiGANConfig | None = None, device="cuda:0", lr=2e-4, betas=(0.8, 0.99), eps=1e-8,
-                 weight_decay=0.01, seed=1234, process_group=None):
+                 weight_decay=0.01, seed=1234, process_group=None, reconstruction_loss="mel", stft_loss_weight=45.0):
         self.config = config or HiFiGANConfig()
         self.device = torch.device(device)
         self.opt = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -244,6 +293,10 @@ class HiFiGANTrainer:
         self.g_params.finalize()
         self.d_params.finalize()
         self.mel_loss = MelLoss(self.config.preprocessing.audio, self.device)
+        if reconstruction_loss not in ("mel", "mrstft", "mel+mrstft"):
+            raise ValueError("reconstruction_loss: 'mel' (45 x mel-L1, the upstream default), 'mrstft' or 'mel+mrstft'")
+        self.reconstruction_loss, self.stft_loss_weight = reconstruction_loss, stft_loss_weight
+        self.stft_loss = MultiResolutionSTFTLoss(self.device) if "mrstft" in reconstruction_loss else None
         gen = torch.Generator().manual_seed(seed)
         for layer in self.generator.layers():
             std = None if layer.name == "conv_pre" else 0.01  # upstream init_weights: N(0, 0.01) except conv_pre
@@ -413,7 +466,7 @@ class HiFiGANTrainer:
         g_layers, d_layers = self.generator.layers(), self.d_layers()
         self._materialize(g_layers)
         self._materialize(d_layers)
-        losses = {k: torch.zeros(1, device=dev) for k in ("d", "g_adv", "g_fm", "g_mel")}
+        losses = {k: torch.zeros(1, device=dev) for k in ("d", "g_adv", "g_fm", "g_mel", "g_stft")}
 
         # ---- generator forward (tape kept for the generator step) ----
         g_tape = ag.Tape()
@@ -469,8 +522,13 @@ class HiFiGANTrainer:
         for layer in d_layers:
             if isinstance(layer, SNConv):
                 layer._calls.clear()  # frozen: no parameter gradients from this pass
-        d_mel = self.mel_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), 45.0, losses["g_mel"])
-        total = d_mel.view(1, B, -1)
+        if "mel" in self.reconstruction_loss.split("+"):
+            total = self.mel_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), 45.0, losses["g_mel"]).view(1, B, -1)
+        else:
+            total = torch.zeros(1, B, y.shape[-1], device=dev)
+        if self.stft_loss is not None:
+            d_stft = self.stft_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), self.stft_loss_weight, losses["g_stft"])
+            total = ops.axpby(1.0, total, 1.0, d_stft.view(1, B, -1))
         if y_hat_in.grad is not None:
             total = ops.axpby(1.0, total, 1.0, y_hat_in.grad)
         y_hat.grad = total
@@ -484,5 +542,5 @@ class HiFiGANTrainer:
         self.g_params.adamw(**self.opt)
         self.global_step += 1
         out = {k: float(v.item()) for k, v in losses.items()}
-        out["g_total"] = out["g_adv"] + out["g_fm"] + out["g_mel"]
+        out["g_total"] = out["g_adv"] + out["g_fm"] + out["g_mel"] + out["g_stft"]
         return out

@@ -348,3 +348,22 @@ def seeded_generator(cfg: HiFiGANModelConfigRef | None = None, seed: int = 1234,
     if fold:
         g.remove_weight_norm()
     return g
+
+
+def mrstft_loss_ref(y, y_hat, resolutions=((1024, 120, 600), (2048, 240, 1200), (512, 50, 240)), eps: float = 1e-7):
+    """Multi-resolution STFT loss (Yamamoto et al. 2020, Parallel WaveGAN: spectral convergence + log-magnitude L1, averaged
+    over the resolutions (n_fft, hop, win)), the selectable alternative BASELINE.json's config 4 names next to the 45 x mel-L1
+    term.  y, y_hat [B, T].  Magnitudes are sqrt(re^2 + im^2 + eps) (additive epsilon: smooth everywhere)."""
+    import torch
+
+    total = y.new_zeros(())
+    for n_fft, hop, win in resolutions:
+        window = torch.hann_window(win, periodic=True)
+        def mag(x):
+            spec = torch.stft(x, n_fft, hop, win, window, center=True, pad_mode="reflect", return_complex=True)
+            return torch.sqrt(spec.real ** 2 + spec.imag ** 2 + eps)
+        my, mg = mag(y), mag(y_hat)
+        sc = torch.norm(my - mg, p="fro") / torch.norm(my, p="fro")
+        lm = (torch.log(my) - torch.log(mg)).abs().mean()
+        total = total + sc + lm
+    return total / len(resolutions)

@@ -237,3 +237,36 @@ def test_bucketed_allreduce_path_on_rccl_world_of_one(cuda_device):
     for side in ("d", "g"):
         for k, v in plain.last_grads[side].items():
             assert torch.equal(v, dp.last_grads[side][k]), (side, k)
+
+
+def test_multi_resolution_stft_loss_value_and_gradient(cuda_device):
+    """The selectable multi-resolution STFT loss (BASELINE config 4) vs torch.stft + autograd on the CPU."""
+    from everyvoice_amd.train.hifigan import MultiResolutionSTFTLoss
+    from oracle.hifigan_ref import mrstft_loss_ref
+
+    g = torch.Generator().manual_seed(31)
+    B, T = 3, 8192
+    y = 0.3 * torch.tanh(torch.randn(B, T, generator=g))
+    y_hat = (y + 0.1 * torch.randn(B, T, generator=g)).requires_grad_()
+    want = mrstft_loss_ref(y, y_hat) * 2.5
+    want.backward()
+    out = torch.zeros(1, device=cuda_device)
+    grad = MultiResolutionSTFTLoss(cuda_device).loss_and_grad(y.to(cuda_device), y_hat.detach().to(cuda_device), 2.5, out)
+    assert float(out) == pytest.approx(float(want), rel=2e-5)
+    # the log-magnitude term's gradient is sign / (n |Y^|): bins with tiny magnitude amplify the fp32 differences between
+    # torch's FFT and the DFT-as-GEMM by 1 / |Y^|, so the bound is on the L2 norm (and a looser one on the worst sample)
+    diff = grad.cpu() - y_hat.grad
+    assert float(diff.norm() / y_hat.grad.norm()) <= 2e-3
+    assert float(diff.abs().max()) <= 1e-2 * float(y_hat.grad.abs().max())
+
+
+def test_training_step_with_mrstft_option_runs(cuda_device):
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(2)
+    y = (0.3 * torch.tanh(torch.randn(2, 1, 2048, generator=g))).to(cuda_device)
+    mel = torch.randn(2, 80, 8, generator=g).to(cuda_device)
+    out = HiFiGANTrainer(device=cuda_device, reconstruction_loss="mel+mrstft").training_step(mel, y)
+    assert out["g_stft"] > 0 and out["g_mel"] > 0 and out["g_total"] == pytest.approx(out["g_adv"] + out["g_fm"] + out["g_mel"] + out["g_stft"])
+    with pytest.raises(ValueError):
+        HiFiGANTrainer(device=cuda_device, reconstruction_loss="l2")
