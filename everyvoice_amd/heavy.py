@@ -86,54 +86,56 @@ def length_regulate_backward(grad_out: torch.Tensor, durations, L: int | None = 
 
 
 # ---- batch assembly and small tensor utilities of everyvoice/utils/heavy.py --------------------------------------------
-def _flatten(structure, key="", path="", flattened=None):
-    """Nested dict -> flat dict with ``_``-joined keys (everyvoice/utils/__init__.py:121-133)."""
-    if flattened is None:
-        flattened = {}
-    if not isinstance(structure, dict):
-        flattened[(f"{path}_" if path else "") + key] = structure
-    else:
-        for new_key, value in structure.items():
-            _flatten(value, new_key, (f"{path}_" if path else "") + key, flattened)
-    return flattened
+def _flatten(tree: dict, prefix: str = "") -> dict:
+    """Nested dict -> flat dict whose keys join the path with ``_`` (the reference's ``_flatten``,
+    ``everyvoice/utils/__init__.py:121-133``: ``{"a": {"b": 2, "c": {"d": "e"}}, "g": 5} -> {"a_b": 2, "a_c_d": "e", "g": 5}``)."""
+    flat = {}
+    for key, value in tree.items():
+        name = f"{prefix}_{key}" if prefix else key
+        if isinstance(value, dict):
+            flat.update(_flatten(value, name))
+        else:
+            flat[name] = value
+    return flat
 
 
 def collate_fn(data: list[dict]) -> dict:
-    """everyvoice/utils/heavy.py:24-36: list of (nested) dicts -> dict of batches.  Tensors (on any device: items that
-    already live on the GPU are padded there) and numpy arrays are zero padded along dim 0 to the longest item
-    (``pad_sequence(batch_first=True)``), python ints become an IntTensor, everything else stays a list."""
+    """Batch a list of (nested) sample dicts the way ``everyvoice/utils/heavy.py:24-36`` does: one entry per flattened key;
+    numpy arrays and tensors are zero padded along dim 0 to the longest sample (``pad_sequence(batch_first=True)``; tensors
+    already on the GPU are padded there), python ints become an ``IntTensor``, anything else stays a list."""
     import numpy as np
     from torch.nn.utils.rnn import pad_sequence
 
-    data = [_flatten(x) for x in data]
-    out = {k: [dic[k] for dic in data] for k in data[0]}
-    for key in out:
-        if isinstance(out[key][0], np.ndarray):
-            out[key] = [torch.tensor(x) for x in out[key]]
-        if torch.is_tensor(out[key][0]):
-            out[key] = pad_sequence(out[key], batch_first=True, padding_value=0)
-        if isinstance(out[key][0], int):
-            out[key] = torch.IntTensor(out[key])
-    return out
+    samples = [_flatten(sample) for sample in data]
+    batch = {}
+    for key in samples[0]:
+        column = [sample[key] for sample in samples]
+        if isinstance(column[0], np.ndarray):
+            column = [torch.tensor(item) for item in column]
+        if torch.is_tensor(column[0]):
+            batch[key] = pad_sequence(column, batch_first=True, padding_value=0)
+        elif isinstance(column[0], int):
+            batch[key] = torch.IntTensor(column)
+        else:
+            batch[key] = column
+    return batch
 
 
 def get_segments(t: torch.Tensor, segment_size: int, start=None) -> tuple[torch.Tensor, int]:
-    """everyvoice/utils/heavy.py:122-148: a segment of ``segment_size`` along dim 1 (random start in
-    ``[0, len - segment_size - 1]`` from python's ``random`` unless given), right zero padded when the input is shorter."""
+    """A window of ``segment_size`` along dim 1 and where it starts (``everyvoice/utils/heavy.py:122-148``).  Inputs at least
+    as long as the window are cropped at ``start`` (which must not exceed ``len - segment_size - 1``; drawn with python's
+    ``random.randint(0, len - segment_size - 1)`` when not given); shorter inputs are zero padded on the right, start 0."""
     import random
 
-    t_len = t.size(1)
-    if t_len >= segment_size:
-        max_start = t_len - segment_size - 1
-        if start is not None:
-            assert start <= max_start, f"Segment start was set to be {start} but max is {max_start}"
-        else:
-            start = random.randint(0, max_start)
-        t = t[:, start : start + segment_size]
+    length = t.size(1)
+    if length < segment_size:
+        return torch.nn.functional.pad(t, (0, segment_size - length)), 0
+    last_start = length - segment_size - 1
+    if start is None:
+        start = random.randint(0, last_start)
     else:
-        start = 0
-        t = torch.nn.functional.pad(t, (0, segment_size - t_len), "constant")
-    return t, start
+        assert start <= last_start, f"segment start {start} is past the last admissible start {last_start}"
+    return t[:, start : start + segment_size], start
 
 
 def vocoder_training_batch(specs: list[torch.Tensor], audios: list[torch.Tensor], segment_frames: int, hop: int, starts=None):

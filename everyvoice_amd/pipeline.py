@@ -155,73 +155,50 @@ def synthesize_from_spec(spec: torch.Tensor, vocoder, out_dir, basename: str, sp
 
 
 class Scaler:
-    """everyvoice/preprocessor/helpers.py:47-106: running collection of per-utterance value tensors; min / max / nanmean /
-    unbiased std over the non-NaN values; ``(x - mean) / std`` normalisation.  Works on whatever device the data lives on."""
+    """Dataset-level statistics of a per-utterance feature (pitch, energy) and its standardisation -- the behaviour of the
+    reference's ``Scaler`` (``everyvoice/preprocessor/helpers.py:47-106``): values are collected with ``append``; ``calculate_stats``
+    takes min / max / unbiased std over the non-NaN entries and ``nanmean`` over all of them, and reports the extrema after
+    ``(x - mean) / std``; the collected list is read-only from outside.  Tensors may live on any device."""
+
+    _FIELDS = ("min", "max", "std", "mean", "norm_min", "norm_max")
 
     def __init__(self):
-        self._data = []
-        self._tensor_data = None
-        self.min = self.max = self.std = self.mean = self.norm_min = self.norm_max = None
+        self.clear_data()
 
-    def __len__(self):
-        return len(self._data)
+    def clear_data(self):
+        self._chunks: list[torch.Tensor] = []
+        self._all: torch.Tensor | None = None
+        for f in self._FIELDS:
+            setattr(self, f, None)
+
+    def append(self, value: torch.Tensor):
+        self._chunks.append(value)
+        self._all = None
 
     @property
     def data(self):
-        return self._data
+        return self._chunks
 
     @data.setter
     def data(self, value):
-        raise ValueError(f"Sorry, you tried to change the data to {value} but it cannot be changed directly. "
-                         "Either Scaler.append(data), or Scaler.clear_data()")
+        raise ValueError(f"Scaler.data is read-only (got {value!r}): use Scaler.append(...) or Scaler.clear_data()")
 
-    def append(self, value):
-        self._data.append(value)
+    def __len__(self):
+        return len(self._chunks)
 
-    def clear_data(self):
-        self.__init__()
+    def normalize(self, x):
+        return (x - self.mean) / self.std
 
-    def normalize(self, data):
-        return (data - self.mean) / self.std
-
-    def denormalize(self, data):
-        return (data * self.std) + self.mean
+    def denormalize(self, x):
+        return x * self.std + self.mean
 
     def calculate_stats(self):
-        if not len(self):
+        if not self._chunks:
             return None
-        if self._tensor_data is None:
-            self._tensor_data = torch.cat(self._data)
-        non_nan = self._tensor_data[~torch.isnan(self._tensor_data)]
-        self.min, self.max = torch.min(non_nan), torch.max(non_nan)
-        self.mean = torch.nanmean(self._tensor_data)
-        self.std = torch.std(non_nan)
-        self.norm_max, self.norm_min = self.normalize(self.max), self.normalize(self.min)
-        return {"sample_size": len(self), "norm_min": float(self.norm_min), "norm_max": float(self.norm_max),
-                "min": float(self.min), "max": float(self.max), "mean": float(self.mean), "std": float(self.std)}
-
-
-def synthesize_from_text(ids: torch.Tensor, lens: torch.Tensor, fs2, vocoder, out_dir, basenames: list[str], speaker: str = "default",
-                         language: str = "default", output_types=("wav", "spec"), sr: int = 22050, hop: int = 256,
-                         duration_control: float = 1.0, global_step: int | None = None) -> list[dict]:
-    """The device part of ``everyvoice synthesize from-text`` (``fs2.cli.synthesize.synthesize_helper``,
-    ``everyvoice/demo/app.py:84-106``): token ids -> FastSpeech2 (postnet mel) -> HiFiGAN -> files named as the reference's
-    prediction writers name them (``everyvoice/base_cli/prediction_writing_callback.py:35-41``):
-    ``<out_dir>/wav/<basename>--<speaker>--<language>--pred.wav`` and ``<out_dir>/synthesized_spec/...--spec-pred....pt``
-    holding ``[n_mels, T]``.  Text normalisation / g2p (CPU string work) stays with the caller: ``ids`` are symbol ids, 0 pads."""
-    mel, post, durations, _, _, mel_lens = fs2(ids, lens, duration_control=duration_control)
-    wav = vocoder(post.transpose(1, 2).contiguous()) if "wav" in output_types else None
-    results = []
-    for i, base in enumerate(basenames):
-        T = int(mel_lens[i])
-        rec = {"basename": base, "frames": T, "durations": durations[i, : int(lens[i])].cpu()}
-        if "spec" in output_types:
-            p = Path(out_dir) / "synthesized_spec" / SEP.join([base, speaker, language, f"spec-pred-{sr}-mel-librosa.pt"])
-            save_tensor(post[i, :T].transpose(0, 1).contiguous(), p)
-            rec["spec"] = p
-        if wav is not None:
-            p = Path(out_dir) / "wav" / SEP.join([base, speaker, language, "pred.wav"])
-            save_wav(wav[i, 0, : T * hop], p, sr)
-            rec["wav"] = p
-        results.append(rec)
-    return results
+        if self._all is None:
+            self._all = torch.cat(self._chunks)
+        finite = self._all[~torch.isnan(self._all)]
+        self.min, self.max, self.std = finite.min(), finite.max(), finite.std()
+        self.mean = torch.nanmean(self._all)
+        self.norm_min, self.norm_max = self.normalize(self.min), self.normalize(self.max)
+        return {"sample_size": len(self), **{f: float(getattr(self, f)) for f in self._FIELDS}}
