@@ -202,3 +202,29 @@ class Scaler:
         self.mean = torch.nanmean(self._all)
         self.norm_min, self.norm_max = self.normalize(self.min), self.normalize(self.max)
         return {"sample_size": len(self), **{f: float(getattr(self, f)) for f in self._FIELDS}}
+
+
+def synthesize_from_text(ids: torch.Tensor, lens: torch.Tensor, fs2, vocoder, out_dir, basenames: list[str], speaker: str = "default",
+                         language: str = "default", output_types=("wav", "spec"), sr: int = 22050, hop: int = 256,
+                         duration_control: float = 1.0, global_step: int | None = None) -> list[dict]:
+    """The device part of ``everyvoice synthesize from-text`` (``fs2.cli.synthesize.synthesize_helper``,
+    ``everyvoice/demo/app.py:84-106``): token ids -> FastSpeech2 (postnet mel) -> HiFiGAN -> files named as the reference's
+    prediction writers name them (``everyvoice/base_cli/prediction_writing_callback.py:35-41``):
+    ``<out_dir>/wav/<basename>--<speaker>--<language>--pred.wav`` and ``<out_dir>/synthesized_spec/...--spec-pred....pt``
+    holding ``[n_mels, T]``.  Text normalisation / g2p (CPU string work) stays with the caller: ``ids`` are symbol ids, 0 pads."""
+    mel, post, durations, _, _, mel_lens = fs2(ids, lens, duration_control=duration_control)
+    wav = vocoder(post.transpose(1, 2).contiguous()) if "wav" in output_types else None
+    results = []
+    for i, base in enumerate(basenames):
+        T = int(mel_lens[i])
+        rec = {"basename": base, "frames": T, "durations": durations[i, : int(lens[i])].cpu()}
+        if "spec" in output_types:
+            p = Path(out_dir) / "synthesized_spec" / SEP.join([base, speaker, language, f"spec-pred-{sr}-mel-librosa.pt"])
+            save_tensor(post[i, :T].transpose(0, 1).contiguous(), p)
+            rec["spec"] = p
+        if wav is not None:
+            p = Path(out_dir) / "wav" / SEP.join([base, speaker, language, "pred.wav"])
+            save_wav(wav[i, 0, : T * hop], p, sr)
+            rec["wav"] = p
+        results.append(rec)
+    return results
