@@ -207,3 +207,37 @@ def test_multispeaker_multilingual_and_checkpoint_roundtrip(cuda_device):
         FastSpeech2.from_checkpoint({**ckpt, "model_info": {"name": "HiFiGAN", "version": "1.0"}}, device=cuda_device)
     with pytest.raises(ValueError, match="newer version"):
         FastSpeech2.from_checkpoint({**ckpt, "model_info": {"name": "FastSpeech2", "version": "9.0"}}, device=cuda_device)
+
+
+def test_fs2_edge_cases(cuda_device):
+    """One token, zero durations for some tokens, an all-zero item next to a normal one, max_length guard, duration_control."""
+    from everyvoice_amd.fs2 import FastSpeech2
+
+    ref, model = _models(FastSpeech2ConfigRef.small(), cuda_device, seed=77)
+    # a single token, single item
+    ids, lens = torch.tensor([[5]]), torch.tensor([1])
+    durs = torch.tensor([[3]])
+    want, got = ref(ids, lens, durations=durs), model(ids, lens, durations=durs)
+    assert got[1].shape == (1, 3, 16)
+    _close(got[1].cpu(), want[1])
+    # tokens with zero duration vanish from the frames; item 1 is much shorter than item 0
+    ids, lens, g = _batch(20, 2, 9, seed=5, lens=[9, 2])
+    durs = torch.tensor([[2, 0, 0, 3, 1, 0, 4, 0, 1], [0, 1, 7, 7, 7, 7, 7, 7, 7]])  # entries past lens are ignored
+    want, got = ref(ids, lens, durations=durs), model(ids, lens, durations=durs)
+    assert torch.equal(got[5].cpu(), torch.tensor([11, 1])) and torch.equal(got[2].cpu(), want[2])
+    _close(got[1].cpu(), want[1])
+    # all durations zero everywhere: nothing to synthesise
+    with pytest.raises(ValueError, match="zero"):
+        model(ids, lens, durations=torch.zeros(2, 9, dtype=torch.long))
+    # max_length guard of FastSpeech2ModelConfig
+    model.config.max_length = 4
+    with pytest.raises(ValueError, match="max_length"):
+        model(ids, lens, durations=durs)
+    model.config.max_length = 1000
+    # duration_control scales the rounded predictions (here: 2x) -- integer-exact against the oracle
+    with torch.no_grad():
+        ref.duration_predictor.linear.bias.fill_(1.0)
+    model.load_state_dict(ref.state_dict())
+    a = model(ids, lens, duration_control=1.0)[2]
+    b = model(ids, lens, duration_control=2.0)[2]
+    assert torch.equal(b, 2 * a) and torch.equal(b.cpu(), ref(ids, lens, duration_control=2.0)[2])

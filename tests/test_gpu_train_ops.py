@@ -256,3 +256,24 @@ def test_conv1d_dgrad_fused_phases(cuda_device, case):
     dx = ops.conv1d_bwd_data_mfma(cbt(dy).to(cuda_device), w.to(cuda_device), T, s, p, d, groups)
     scale = float(x.grad.abs().max())
     assert float((bct(dx.cpu()) - x.grad).abs().max()) <= 2e-5 * scale + 1e-6, case
+
+
+def test_conv_kernels_edge_shapes(cuda_device):
+    """Single item, single output position, output length 1 per item with many items, channels not a multiple of anything."""
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(99)
+    for (B, T, cin, cout, k, s, p, d, groups) in ((1, 7, 5, 7, 3, 1, 1, 1, 1), (1, 1, 6, 10, 1, 1, 0, 1, 1), (37, 3, 9, 33, 3, 3, 0, 1, 1),
+                                                  (2, 50, 6, 9, 5, 1, 2, 2, 3), (1, 8192, 2, 2, 7, 1, 3, 1, 1)):
+        x = torch.randn(B, cin, T, generator=g, requires_grad=True)
+        w = (torch.randn(cout, cin // groups, k, generator=g) * 0.3).requires_grad_()
+        b = torch.randn(cout, generator=g)
+        y = F.conv1d(x, w, b, s, p, d, groups)
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        xd, wd, dyd = cbt(x.detach()).to(cuda_device), w.detach().to(cuda_device), cbt(dy).to(cuda_device)
+        yg = ops.conv1d_fwd(xd, wd, b.to(cuda_device), s, p, d, groups)
+        torch.testing.assert_close(bct(yg.cpu()), y.detach(), rtol=1e-4, atol=1e-5)
+        dx, dw, _ = ops.conv1d_bwd(xd, wd, dyd, s, p, d, groups)
+        torch.testing.assert_close(bct(dx.cpu()), x.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-4, atol=1e-4)
