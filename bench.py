@@ -319,7 +319,7 @@ def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
 
     from everyvoice_amd.fs2 import FastSpeech2
     sys.path.insert(0, str(ROOT / "tools"))
-    from fs2_bench import synthetic_batch
+    from fs2_bench import forward_flops, synthetic_batch
 
     model = FastSpeech2(device=dev).init_random(1234)
     ids, lens, durs, t_i = synthetic_batch(32, 1234 + rank)
@@ -327,7 +327,11 @@ def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
     steps, warmup = 10, 3
     elapsed = timed_region(lambda: model(ids, lens, durations=durs), steps, warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     frames = int(t_i.sum())
-    return {"metric": "fastspeech2_infer_mel_frames_per_sec", "value": round(world * frames * steps / elapsed, 1), "unit": "frames/s",
+    flops = forward_flops(lens.cpu(), t_i, int(ids.shape[1]), int(t_i.max()), 32)
+    tflops = flops * steps / elapsed / 1e12
+    return {"roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.0, "unit": "TFLOP/s", "frac": round(tflops / 157.0, 4),
+                         "traffic": None, "flop_per_batch": flops, "scope": "whole forward (dense layers on the padded grids)"},
+            "metric": "fastspeech2_infer_mel_frames_per_sec", "value": round(world * frames * steps / elapsed, 1), "unit": "frames/s",
             "ms_per_batch": round(elapsed / steps * 1e3, 3), "batch": 32, "max_tokens": int(ids.shape[1]), "frames_per_batch": frames,
             "dtype": "f32", "steps": steps, "warmup": warmup, "parallelism": f"replicas x{world}",
             "realtime_factor": round(world * frames * 256 / 22050.0 * steps / elapsed, 1)}

@@ -25,6 +25,21 @@ def synthetic_batch(B=32, seed=1234):
     return ids, L_i, durs, T_i
 
 
+def forward_flops(lens, mel_lens, L_pad, T_pad, B, d=256, f=1024, k=9, heads=2, layers=4, n_mels=80, pn_ch=512, pn_k=5, vp_layers=5, vp_k=3):
+    """Algorithmic FLOPs of one inference forward at the default sizes (2 per multiply-add).  Dense layers are computed on the
+    padded [B, L_pad] / [B, T_pad] grids (as the reference does); attention per item over its padded queries and real keys."""
+    def conformer(n_cols, q_len, k_lens):
+        dense = 2 * (2 * d * f) + (3 * d * d + d * d) + (2 * d * d + d * d) + k * d  # FFN x2, QKV + out, pointwise x2, depthwise
+        attn = sum(2 * q_len * int(kl) * d for kl in k_lens)                           # QK^T and PV over all heads
+        return layers * (n_cols * dense + attn)
+    enc = conformer(B * L_pad, L_pad, lens)
+    dec = conformer(B * T_pad, T_pad, mel_lens)
+    predictors = 3 * B * L_pad * (vp_layers * (vp_k * d + d * d) + d)
+    mel = B * T_pad * d * n_mels
+    postnet = B * T_pad * pn_k * (n_mels * pn_ch + 3 * pn_ch * pn_ch + pn_ch * n_mels)
+    return 2.0 * (enc + dec + predictors + mel + postnet)
+
+
 def main():
     dev = torch.device("cuda:0")
     model = FastSpeech2(device=dev).init_random(1234)
@@ -40,6 +55,8 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     frames = int(T_i.sum())
+    fl = forward_flops(lens.cpu(), T_i, ids.shape[1], out[0].shape[1], ids.shape[0])
+    print(f"algorithmic {fl/1e9:.1f} GFLOP per batch -> {fl/dt/1e12:.1f} TFLOP/s ({fl/dt/157e12*100:.1f} % of the 157 TFLOP/s fp32 matrix peak)")
     print(f"B={ids.shape[0]} L={ids.shape[1]} T={out[0].shape[1]} frames={frames}: {dt*1e3:.2f} ms / batch -> {frames/dt/1e6:.3f} M mel frames/s, "
           f"{ids.shape[0]/dt:.0f} utterances/s, {frames*256/22050/dt:.0f} x real time")
 
