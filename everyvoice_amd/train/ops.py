@@ -169,7 +169,10 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
     return dx
 
 
-CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma", "wgrad": "mfma"}  # "gemm": unfold + rocBLAS (kept for A/B and as the reference variant)
+# "mfma": the hand-written fp32 matrix-core kernels; "gemm": unfold + rocBLAS (A/B and reference variant).
+# wgrad "auto": implicit GEMM for grouped layers (2-5x over unfold + per-group GEMMs), unfold + ONE library GEMM for dense
+# ones, where rocBLAS is still 1.2-1.8x ahead of conv_wgrad_f32_mfma.hip (tools/bench_f32wgrad.py): 83.6 -> 79.4 ms/step.
+CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma", "wgrad": "auto"}
 
 
 def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bool:
@@ -214,7 +217,7 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
     if need_dw:
         dw = dw_out if dw_out is not None else torch.empty_like(w)
         lib = _lib.load()
-        ws_elems = lib.evmi_conv1d_wgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) if CONV_BACKEND["wgrad"] == "mfma" else 0
+        ws_elems = lib.evmi_conv1d_wgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) if (CONV_BACKEND["wgrad"] == "mfma" or (CONV_BACKEND["wgrad"] == "auto" and groups > 1)) else 0
         if ws_elems > 0:  # implicit GEMM on the fp32 matrix cores (conv_wgrad_f32_mfma.hip)
             ws = WS.get("wgrad", ws_elems, x.device)
             _chk(lib.evmi_conv1d_wgrad_cbt_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
