@@ -103,6 +103,19 @@ SYMBOLS = {
     "evmi_forward_sum_loss_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
     "evmi_binarization_partials_f64": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_longlong, C.c_void_p]),
     "evmi_monotonic_align_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]),
+    "evmi_layernorm_bwd_cbt_f32_ws_elems": (C.c_longlong, [C.c_int, C.c_longlong]),
+    "evmi_layernorm_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_longlong, C.c_int, C.c_longlong, C.c_float, C.c_int, C.c_void_p]),
+    "evmi_batchnorm_fwd_cbt_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "evmi_batchnorm_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
+    "evmi_dwconv1d_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
+    "evmi_softmax_rows_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_ulonglong, C.c_void_p]),
+    "evmi_softmax_bwd_rows_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_ulonglong, C.c_void_p]),
+    "evmi_glu_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
+    "evmi_dropout_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_float, C.c_ulonglong, C.c_void_p]),
+    "evmi_fs2_embed_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
+    "evmi_fs2_bucket_embed_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "evmi_fs2_item_embedding_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    "evmi_length_regulate_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_dgrad_weights_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "evmi_gemm_batched_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
     "evmi_unfold_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),

@@ -1,0 +1,528 @@
+// FastSpeech2 training: the backward (and training-mode forward) operators that are not convolutions, channel-major
+// fp32 layout x[c][b][t] (column n = b * T + t contiguous per channel row).  Dense layers reuse the fp32 matrix-core
+// convolution kernels (forward / input gradient / weight gradient, k = 1 is a GEMM); attention in training mode keeps
+// the probabilities (needed again by the backward and by attention dropout) and runs as batched GEMMs around the two
+// row kernels here.
+//
+//   layernorm_bwd_cbt_kernel     dx of LayerNorm over channels + per-workgroup partial sums of d gamma / d beta
+//   colsum_partials_kernel       fixed-order reduction of those partials (deterministic: no atomics on parameters
+//                                except embedding tables, where rows collide by construction)
+//   batchnorm_{stats,apply,bwd}  training-mode BatchNorm1d (batch statistics over every column, padded ones included:
+//                                torchaudio's Conformer does not mask them) with SiLU / tanh fused behind it
+//   dwconv_bwd_{dx,dw}           depthwise convolution backward
+//   softmax_rows / softmax_bwd   key-masked softmax rows (+ dropout) and its backward, in place on [B][Tq][Tk]
+//   glu_bwd, dropout             elementwise
+//   embedding / bucket / item-embedding backward (scatter-add), length regulator backward (segment sums)
+#include <cmath>
+
+#include "common.h"
+#include "evmi.h"
+
+namespace evmi {
+
+// counter-based uniform in [0, 1): splitmix64 of (seed, element index) -- the backward regenerates the same mask
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- LayerNorm backward --------------------------------------------------------------------------------------------
+// Same decomposition as the forward (64 columns x 4 channel slices).  part[blk][0][c] = sum_cols dy * xhat,
+// part[blk][1][c] = sum_cols dy for the workgroup's 64 columns.
+template <int CPT>
+__global__ __launch_bounds__(256) void layernorm_bwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ dy, float* __restrict__ dx,
+                                                               float* __restrict__ part, int C, long long N, float eps,
+                                                               int accumulate) {
+  __shared__ float red[4][4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const long long n = (long long)blockIdx.x * 64 + lane;
+  const bool live = n < N;
+  const int per = (C + 3) >> 2, c0 = slice * per, c1 = min(C, c0 + per);
+  float v[CPT], g[CPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = c0 + i;
+    v[i] = (live && c < c1) ? x[(long long)c * N + n] : 0.f;
+    s += v[i];
+  }
+  red[0][slice][lane] = s;
+  __syncthreads();
+  const float mean = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const float d = (c0 + i < c1) ? v[i] - mean : 0.f;
+    q = fmaf(d, d, q);
+  }
+  red[1][slice][lane] = q;
+  __syncthreads();
+  const float var = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
+  const float rstd = 1.f / sqrtf(var + eps);
+  float s1 = 0.f, s2 = 0.f;
+  float* pg = part + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = c0 + i;
+    const bool on = c < c1;
+    const float d = (live && on) ? dy[(long long)c * N + n] : 0.f;
+    v[i] = on ? (v[i] - mean) * rstd : 0.f;  // xhat
+    g[i] = on ? d * gamma[c] : 0.f;
+    s1 += g[i];
+    s2 = fmaf(g[i], v[i], s2);
+    const float a = wave_sum(d * v[i]), b = wave_sum(d);
+    if (on && lane == 0) {
+      pg[c] = a;
+      pg[C + c] = b;
+    }
+  }
+  red[2][slice][lane] = s1;
+  red[3][slice][lane] = s2;
+  __syncthreads();
+  const float m1 = (red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane]) / (float)C;
+  const float m2 = (red[3][0][lane] + red[3][1][lane] + red[3][2][lane] + red[3][3][lane]) / (float)C;
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = c0 + i;
+    if (c < c1) {
+      const float r = rstd * (g[i] - m1 - v[i] * m2);
+      float* dst = dx + (long long)c * N + n;
+      *dst = accumulate ? *dst + r : r;
+    }
+  }
+}
+
+// out0[c] += sum_blk part[blk][0][c]; out1[c] += sum_blk part[blk][1][c]   (fixed order)
+__global__ void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1, int C,
+                                       int nblk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * C) return;
+  double acc = 0.0;
+  for (int b = 0; b < nblk; ++b) acc += (double)part[(long long)b * 2 * C + i];
+  float* dst = i < C ? out0 + i : out1 + (i - C);
+  *dst += (float)acc;
+}
+
+// ---- BatchNorm1d, training mode --------------------------------------------------------------------------------------
+// one workgroup per channel row (N = B * T contiguous values)
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ __forceinline__ float bn_act(float z, int act) {
+  if (act == 2) return z * sigmoidf_(z);
+  if (act == 4) return tanhf(z);
+  return z;
+}
+__device__ __forceinline__ float bn_act_grad(float z, int act) {
+  if (act == 2) { const float s = sigmoidf_(z); return s * (1.f + z * (1.f - s)); }
+  if (act == 4) { const float t = tanhf(z); return 1.f - t * t; }
+  return 1.f;
+}
+
+__global__ __launch_bounds__(256) void batchnorm_fwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ y,
+                                                               float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               long long N, float eps, float momentum, int act) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  const float* xr = x + (long long)c * N;
+  double s = 0.0;
+  for (long long i = threadIdx.x; i < N; i += 256) s += (double)xr[i];
+  const float mean = (float)(block_sum(s, sh) / (double)N);
+  double q = 0.0;
+  for (long long i = threadIdx.x; i < N; i += 256) { const float d = xr[i] - mean; q += (double)(d * d); }
+  const double ss = block_sum(q, sh);
+  const float var = (float)(ss / (double)N);
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(ss / (double)(N > 1 ? N - 1 : 1));
+    }
+  }
+  const float ga = gamma[c] * rstd, be = beta[c];
+  float* yr = y + (long long)c * N;
+  for (long long i = threadIdx.x; i < N; i += 256) yr[i] = bn_act((xr[i] - mean) * ga + be, act);
+}
+
+__global__ __launch_bounds__(256) void batchnorm_bwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ mean_in,
+                                                               const float* __restrict__ rstd_in, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, long long N, int act) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  const float* xr = x + (long long)c * N;
+  const float* dr = dy + (long long)c * N;
+  const float mean = mean_in[c], rstd = rstd_in[c], ga = gamma[c], be = beta[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (long long i = threadIdx.x; i < N; i += 256) {
+    const float xh = (xr[i] - mean) * rstd;
+    const float dz = dr[i] * bn_act_grad(xh * ga + be, act);
+    s1 += (double)dz;
+    s2 += (double)(dz * xh);
+  }
+  const double t1 = block_sum(s1, sh);
+  const double t2 = block_sum(s2, sh);
+  if (threadIdx.x == 0) {
+    dbeta[c] += (float)t1;
+    dgamma[c] += (float)t2;
+  }
+  const float m1 = (float)(t1 / (double)N), m2 = (float)(t2 / (double)N);
+  float* dxr = dx + (long long)c * N;
+  for (long long i = threadIdx.x; i < N; i += 256) {
+    const float xh = (xr[i] - mean) * rstd;
+    const float dz = dr[i] * bn_act_grad(xh * ga + be, act);
+    dxr[i] = ga * rstd * (dz - m1 - xh * m2);
+  }
+}
+
+// ---- depthwise convolution backward ----------------------------------------------------------------------------------
+// dx[c][b][t] = sum_j w[c][j] * dy[c][b][t + pad - j]
+__global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int C, int B,
+                                     int T, int k, int pad) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)C * B * T) return;
+  const int t = (int)(i % T);
+  const int c = (int)(i / ((long long)T * B));
+  const float* dr = dy + (i - t);
+  float v = 0.f;
+  for (int j = 0; j < k; ++j) {
+    const int to = t + pad - j;
+    if (to >= 0 && to < T) v = fmaf(w[c * k + j], dr[to], v);
+  }
+  dx[i] = v;
+}
+
+constexpr int DW_KMAX = 32;
+// dw[c][j] += sum_{b,t} x[c][b][t + j - pad] * dy[c][b][t] ; db[c] += sum dy : one workgroup per channel
+__global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dw, float* __restrict__ db, int B, int T, int k,
+                                                           int pad) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  const long long N = (long long)B * T;
+  const float* xr = x + (long long)c * N;
+  const float* dr = dy + (long long)c * N;
+  float acc[DW_KMAX];
+#pragma unroll
+  for (int j = 0; j < DW_KMAX; ++j) acc[j] = 0.f;
+  float sb = 0.f;
+  for (long long i = threadIdx.x; i < N; i += 256) {
+    const int t = (int)(i % T);
+    const float d = dr[i];
+    sb += d;
+#pragma unroll
+    for (int j = 0; j < DW_KMAX; ++j) {
+      const int ti = t + j - pad;
+      if (j < k && ti >= 0 && ti < T) acc[j] = fmaf(xr[i - t + ti], d, acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < DW_KMAX; ++j) {
+    if (j < k) {
+      const double tot = block_sum((double)acc[j], sh);
+      if (threadIdx.x == 0) dw[c * k + j] += (float)tot;
+    }
+  }
+  const double tb = block_sum((double)sb, sh);
+  if (threadIdx.x == 0 && db) db[c] += (float)tb;
+}
+
+// ---- attention rows ------------------------------------------------------------------------------------------------
+// S[b][tq][tk] (scores, already scaled) -> P = softmax over tk < len[b] (0 beyond); Pd = dropout(P) when p > 0
+// one wave per row; grid = rows / 4
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ S, float* __restrict__ Pd, const int* __restrict__ lens,
+                                                          int B, int Tq, int Tk, float p, unsigned long long seed) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long long)B * Tq) return;
+  const int b = (int)(row / Tq);
+  const int len = min(lens[b], Tk);
+  float* sr = S + row * Tk;
+  float m = -INFINITY;
+  for (int i = lane; i < len; i += 64) m = fmaxf(m, sr[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  float s = 0.f;
+  for (int i = lane; i < len; i += 64) s += expf(sr[i] - m);
+  s = wave_sum(s);
+  const float inv = 1.f / s, keep = 1.f / (1.f - p);
+  for (int i = lane; i < Tk; i += 64) {
+    const float v = i < len ? expf(sr[i] - m) * inv : 0.f;
+    sr[i] = v;
+    if (Pd) Pd[row * Tk + i] = uniform01(seed, (unsigned long long)(row * Tk + i)) >= p ? v * keep : 0.f;
+  }
+}
+
+// dS = scale * P * (dPm - sum_k P * dPm), dPm = dP * dropout mask / (1 - p); in place on dP
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, long long rows,
+                                                              int Tk, float scale, float p, unsigned long long seed) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* pr = P + row * Tk;
+  float* dr = dP + row * Tk;
+  const float keep = 1.f / (1.f - p);
+  float s = 0.f;
+  for (int i = lane; i < Tk; i += 64) {
+    float d = dr[i];
+    if (p > 0.f) d = uniform01(seed, (unsigned long long)(row * Tk + i)) >= p ? d * keep : 0.f;
+    s = fmaf(pr[i], d, s);
+  }
+  s = wave_sum(s);
+  for (int i = lane; i < Tk; i += 64) {
+    float d = dr[i];
+    if (p > 0.f) d = uniform01(seed, (unsigned long long)(row * Tk + i)) >= p ? d * keep : 0.f;
+    dr[i] = scale * pr[i] * (d - s);
+  }
+}
+
+// ---- elementwise ---------------------------------------------------------------------------------------------------
+// p = [a; b] (two halves of n elements): y = a * sigmoid(b);  da = dy * sigmoid(b), db = dy * a * sigmoid(b) (1 - sigmoid(b))
+__global__ void glu_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dy, float* __restrict__ dp, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a = p[i], s = sigmoidf_(p[n + i]), d = dy[i];
+  dp[i] = d * s;
+  dp[n + i] = d * a * s * (1.f - s);
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float p, unsigned long long seed) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  y[i] = uniform01(seed, (unsigned long long)i) >= p ? x[i] / (1.f - p) : 0.f;
+}
+
+// ---- embeddings, backward ------------------------------------------------------------------------------------------
+// One thread per (table row, channel) walks the tokens in order and adds the ones that map to its row: a fixed order
+// of additions (bitwise reproducible, unlike a scatter with atomics); the row test is wave-uniform (scalar loads).
+// mode 0: text embedding   row = ids[b][l] for l < lens[b], ids != skip_id
+// mode 2: variance buckets row = precomputed bucket index of every position (the forward adds everywhere, pads included)
+__global__ __launch_bounds__(256) void fs2_table_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ ids,
+                                                           const int* __restrict__ lens, const float* __restrict__ values,
+                                                           const float* __restrict__ bins, float* __restrict__ dtable, int n_bins,
+                                                           int B, int L, int D, int skip_id, float control, int mode) {
+  const int r = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const long long N = (long long)B * L;
+  const float* row = dx + (long long)(c < D ? c : 0) * N;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const int len = mode == 0 ? min(lens[b], L) : L;
+    for (int l = 0; l < len; ++l) {
+      const int id = ids[b * L + l];
+      if (id == r && id != skip_id) acc += row[(long long)b * L + l];
+    }
+  }
+  if (c < D) dtable[(long long)r * D + c] += acc;
+}
+
+// bucket index of every token: first boundary >= value (torch.bucketize, right = False)
+__global__ void fs2_bucket_index_kernel(const float* __restrict__ values, const float* __restrict__ bins, int* __restrict__ idx, int n,
+                                        int n_bins, float control) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = values[i] * control;
+  int lo = 0, hi = n_bins - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (bins[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  idx[i] = lo;
+}
+
+// dtable[r][c] += sum over the items b with ids[b] == r of sum_{l < len[b]} dx[c][b][l]   (fixed order)
+__global__ void fs2_item_embedding_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ ids, const int* __restrict__ lens,
+                                              float* __restrict__ dtable, int B, int L, int D, int rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= D * rows) return;
+  const int c = i % D, r = i / D;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    if (ids[b] != r) continue;
+    const float* p = dx + ((long long)c * B + b) * L;
+    float s = 0.f;
+    for (int l = 0; l < lens[b] && l < L; ++l) s += p[l];
+    acc += s;
+  }
+  dtable[(long long)r * D + c] += acc;
+}
+
+// ---- length regulator backward: dx[c][b][l] = sum_{t in [cum[l-1], cum[l])} dframes[c][b][t] ----------------------------
+__global__ void length_regulate_bwd_cbt_kernel(const float* __restrict__ dframes, const int* __restrict__ cum, float* __restrict__ dx,
+                                               int C, int B, int L, int T) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)C * B * L) return;
+  const int l = (int)(i % L), b = (int)((i / L) % B), c = (int)(i / ((long long)L * B));
+  const int t0 = l ? cum[b * L + l - 1] : 0, t1 = min(cum[b * L + l], T);
+  const float* r = dframes + ((long long)c * B + b) * T;
+  float s = 0.f;
+  for (int t = t0; t < t1; ++t) s += r[t];
+  dx[i] = s;
+}
+
+static inline unsigned blocks_for(long long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace evmi
+
+using namespace evmi;
+
+extern "C" {
+
+long long evmi_layernorm_bwd_cbt_f32_ws_elems(int C, long long n_cols) { return ((n_cols + 63) / 64) * 2ll * C; }
+
+int evmi_layernorm_bwd_cbt_f32(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* ws,
+                               long long ws_elems, int C, long long n_cols, float eps, int accumulate_dx, void* stream) {
+  if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !ws) return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd: null pointer");
+  if (C < 1 || C > 256 || n_cols < 1) return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd: 1 <= C <= 256 and n_cols >= 1 required");
+  if (ws_elems < evmi_layernorm_bwd_cbt_f32_ws_elems(C, n_cols)) return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned nblk = (unsigned)((n_cols + 63) / 64);
+  const int per = (C + 3) / 4;
+  if (per <= 16) hipLaunchKernelGGL(layernorm_bwd_cbt_kernel<16>, dim3(nblk), dim3(256), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
+  else hipLaunchKernelGGL(layernorm_bwd_cbt_kernel<64>, dim3(nblk), dim3(256), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
+  EVMI_LAUNCH_CHECK("layernorm_bwd_cbt");
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(blocks_for(2 * C)), dim3(256), 0, s, ws, dgamma, dbeta, C, (int)nblk);
+  EVMI_LAUNCH_CHECK("colsum_partials");
+  return EVMI_OK;
+}
+
+int evmi_batchnorm_fwd_cbt_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean_out, float* rstd_out,
+                               float* running_mean, float* running_var, int C, long long n_cols, float eps, float momentum, int act,
+                               void* stream) {
+  if (!x || !gamma || !beta || !y || !mean_out || !rstd_out) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: null pointer");
+  if ((running_mean == nullptr) != (running_var == nullptr)) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: running_mean and running_var go together");
+  if (C < 1 || n_cols < 1) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: empty input");
+  if (act != 0 && act != 2 && act != 4) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: act must be 0 (none), 2 (SiLU) or 4 (tanh)");
+  hipLaunchKernelGGL(batchnorm_fwd_cbt_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean_out, rstd_out,
+                     running_mean, running_var, n_cols, eps, momentum, act);
+  EVMI_LAUNCH_CHECK("batchnorm_fwd_cbt");
+  return EVMI_OK;
+}
+
+int evmi_batchnorm_bwd_cbt_f32(const float* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+                               const float* dy, float* dx, float* dgamma, float* dbeta, int C, long long n_cols, int act, void* stream) {
+  if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx || !dgamma || !dbeta) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_bwd: null pointer");
+  if (C < 1 || n_cols < 1) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_bwd: empty input");
+  if (act != 0 && act != 2 && act != 4) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_bwd: act must be 0 (none), 2 (SiLU) or 4 (tanh)");
+  hipLaunchKernelGGL(batchnorm_bwd_cbt_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, mean, rstd, dy, dx, dgamma,
+                     dbeta, n_cols, act);
+  EVMI_LAUNCH_CHECK("batchnorm_bwd_cbt");
+  return EVMI_OK;
+}
+
+int evmi_dwconv1d_bwd_cbt_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int C, int B, int T,
+                              int k, int pad, void* stream) {
+  if (!x || !w || !dy) return fail(EVMI_ERR_INVALID_ARG, "dwconv_bwd: null pointer");
+  if (C < 1 || B < 1 || T < 1 || k < 1 || k > DW_KMAX) return fail(EVMI_ERR_INVALID_ARG, "dwconv_bwd: 1 <= k <= 32 and a non-empty input required");
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) {
+    hipLaunchKernelGGL(dwconv_bwd_dx_kernel, dim3(blocks_for((long long)C * B * T)), dim3(256), 0, s, dy, w, dx, C, B, T, k, pad);
+    EVMI_LAUNCH_CHECK("dwconv_bwd_dx");
+  }
+  if (dw) {
+    hipLaunchKernelGGL(dwconv_bwd_dw_kernel, dim3(C), dim3(256), 0, s, x, dy, dw, db, B, T, k, pad);
+    EVMI_LAUNCH_CHECK("dwconv_bwd_dw");
+  }
+  return EVMI_OK;
+}
+
+int evmi_softmax_rows_f32(float* scores, float* dropped, const int* lens, int B, int Tq, int Tk, float p, unsigned long long seed,
+                          void* stream) {
+  if (!scores || !lens) return fail(EVMI_ERR_INVALID_ARG, "softmax_rows: null pointer");
+  if (B < 1 || Tq < 1 || Tk < 1) return fail(EVMI_ERR_INVALID_ARG, "softmax_rows: empty input");
+  if (p < 0.f || p >= 1.f || (p > 0.f && !dropped)) return fail(EVMI_ERR_INVALID_ARG, "softmax_rows: 0 <= p < 1, and p > 0 needs the second buffer");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(blocks_for((long long)B * Tq, 4)), dim3(256), 0, (hipStream_t)stream, scores,
+                     p > 0.f ? dropped : nullptr, lens, B, Tq, Tk, p, seed);
+  EVMI_LAUNCH_CHECK("softmax_rows");
+  return EVMI_OK;
+}
+
+int evmi_softmax_bwd_rows_f32(const float* probs, float* dprobs, long long rows, int Tk, float scale, float p, unsigned long long seed,
+                              void* stream) {
+  if (!probs || !dprobs) return fail(EVMI_ERR_INVALID_ARG, "softmax_bwd_rows: null pointer");
+  if (rows < 1 || Tk < 1 || p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "softmax_bwd_rows: bad sizes");
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(blocks_for(rows, 4)), dim3(256), 0, (hipStream_t)stream, probs, dprobs, rows, Tk,
+                     scale, p, seed);
+  EVMI_LAUNCH_CHECK("softmax_bwd_rows");
+  return EVMI_OK;
+}
+
+int evmi_glu_bwd_f32(const float* p, const float* dy, float* dp, long long n_half, void* stream) {
+  if (!p || !dy || !dp || n_half < 1) return fail(EVMI_ERR_INVALID_ARG, "glu_bwd: null pointer or empty input");
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(blocks_for(n_half)), dim3(256), 0, (hipStream_t)stream, p, dy, dp, n_half);
+  EVMI_LAUNCH_CHECK("glu_bwd");
+  return EVMI_OK;
+}
+
+int evmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned long long seed, void* stream) {
+  if (!x || !y || n < 1 || p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "dropout: null pointer, empty input or p outside [0, 1)");
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, seed);
+  EVMI_LAUNCH_CHECK("dropout");
+  return EVMI_OK;
+}
+
+int evmi_fs2_embed_bwd_f32(const float* dx, const int* ids, const int* lens, float* dtable, int rows, int B, int L, int D, int skip_id,
+                           void* stream) {
+  if (!dx || !ids || !lens || !dtable || rows < 1 || B < 1 || L < 1 || D < 1) return fail(EVMI_ERR_INVALID_ARG, "fs2_embed_bwd: bad arguments");
+  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(rows, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, ids, lens, nullptr, nullptr,
+                     dtable, 0, B, L, D, skip_id, 1.f, 0);
+  EVMI_LAUNCH_CHECK("fs2_embed_bwd");
+  return EVMI_OK;
+}
+
+int evmi_fs2_bucket_embed_bwd_f32(const float* dx, const float* values, const float* bins, float* dtable, int* idx_ws, int n_bins, int B,
+                                  int L, int D, float control, void* stream) {
+  if (!dx || !values || !bins || !dtable || !idx_ws || n_bins < 2 || B < 1 || L < 1 || D < 1)
+    return fail(EVMI_ERR_INVALID_ARG, "fs2_bucket_embed_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(fs2_bucket_index_kernel, dim3(blocks_for((long long)B * L)), dim3(256), 0, s, values, bins, idx_ws, B * L, n_bins, control);
+  EVMI_LAUNCH_CHECK("fs2_bucket_index");
+  // the text-embedding walk over precomputed indices: every position counts (lens = NULL -> full rows), no skipped id
+  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(n_bins, (D + 255) / 256), dim3(256), 0, s, dx, idx_ws, nullptr, nullptr, nullptr, dtable, 0, B,
+                     L, D, -1, 1.f, 2);
+  EVMI_LAUNCH_CHECK("fs2_bucket_embed_bwd");
+  return EVMI_OK;
+}
+
+int evmi_fs2_item_embedding_bwd_f32(const float* dx, const int* ids, const int* lens, float* dtable, int rows, int B, int L, int D,
+                                    void* stream) {
+  if (!dx || !ids || !lens || !dtable || rows < 1 || B < 1 || L < 1 || D < 1) return fail(EVMI_ERR_INVALID_ARG, "fs2_item_embedding_bwd: bad arguments");
+  hipLaunchKernelGGL(fs2_item_embedding_bwd_kernel, dim3(blocks_for((long long)D * rows)), dim3(256), 0, (hipStream_t)stream, dx, ids, lens,
+                     dtable, B, L, D, rows);
+  EVMI_LAUNCH_CHECK("fs2_item_embedding_bwd");
+  return EVMI_OK;
+}
+
+int evmi_length_regulate_bwd_cbt_f32(const float* dframes, const int* cum, float* dx, int C, int B, int L, int T, void* stream) {
+  if (!dframes || !cum || !dx || C < 1 || B < 1 || L < 1 || T < 1) return fail(EVMI_ERR_INVALID_ARG, "length_regulate_bwd_cbt: bad arguments");
+  hipLaunchKernelGGL(length_regulate_bwd_cbt_kernel, dim3(blocks_for((long long)C * B * L)), dim3(256), 0, (hipStream_t)stream, dframes,
+                     cum, dx, C, B, L, T);
+  EVMI_LAUNCH_CHECK("length_regulate_bwd_cbt");
+  return EVMI_OK;
+}
+
+}  // extern "C"

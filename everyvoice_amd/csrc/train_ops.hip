@@ -251,6 +251,8 @@ __global__ void row_reduce_final_kernel(const float* __restrict__ part, float* _
 //    9: y = log(max(a, p0))                 10: y = b > p0 ? a / b : 0              (dmel from dlogmel, b = mel)
 //   11: y = sqrt(a*a + b*b + p0)            12: y = a * b / c  (dre = dmag * re / mag)
 //   13: y = silu(a)                         14: y = relu(a)                        15: y = a * sigmoid(b)  (GLU)
+//   20: y = a * min(1, p0 / (sqrt(c[0]) + 1e-6))   (gradient-norm clipping, c[0] = sum of squares on the device)
+//   18: y = a * silu'(b)                    19: y = b > 0 ? a : 0  (ReLU backward from the output)
 //   16: y = log(a)                          17: y = p0 * (a - b) + p1 * sign(a - b) / a   (d/da of the two STFT-loss terms, a = |Y^|, b = |Y|)
 template <int OP>
 __global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
@@ -275,6 +277,9 @@ __global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__
   else if (OP == 14) r = fmaxf(a[i], 0.f);
   else if (OP == 15) r = a[i] / (1.f + expf(-b[i]));
   else if (OP == 16) r = logf(a[i]);
+  else if (OP == 18) { const float z = b[i], sg = 1.f / (1.f + expf(-z)); r = a[i] * sg * (1.f + z * (1.f - sg)); }
+  else if (OP == 19) r = b[i] > 0.f ? a[i] : 0.f;
+  else if (OP == 20) r = a[i] * fminf(1.f, p0 / (sqrtf(c[0]) + 1e-6f));
   else r = p0 * (a[i] - b[i]) + p1 * (a[i] > b[i] ? 1.f : (a[i] < b[i] ? -1.f : 0.f)) / a[i];
   y[i] = r;
 }
@@ -589,7 +594,7 @@ int evmi_elementwise_f32(int op, const float* a_dev, const float* b_dev, const f
   hipStream_t s = (hipStream_t)stream;
 #define EW(OPN) case OPN: hipLaunchKernelGGL(ew_kernel<OPN>, grid1d(n), dim3(256), 0, s, a_dev, b_dev, c_dev, y_dev, n, p0, p1); break;
   switch (op) {
-    EW(0) EW(1) EW(2) EW(3) EW(4) EW(5) EW(6) EW(7) EW(8) EW(9) EW(10) EW(11) EW(12) EW(13) EW(14) EW(15) EW(16) EW(17)
+    EW(0) EW(1) EW(2) EW(3) EW(4) EW(5) EW(6) EW(7) EW(8) EW(9) EW(10) EW(11) EW(12) EW(13) EW(14) EW(15) EW(16) EW(17) EW(18) EW(19) EW(20)
     default: return fail(EVMI_ERR_INVALID_ARG, "elementwise: unknown op");
   }
 #undef EW

@@ -1,0 +1,587 @@
+"""FastSpeech2 feature-prediction TRAINING on libevmi_hip (BASELINE config 3; SURVEY.md 8a F1-F4, 8b driver contract).
+
+The reference trains ``fs2.model.FastSpeech2`` (absent submodule FastSpeech2_lightning) under Lightning:
+``train_base_command(model_config, data_module, model, monitor, ...)`` (``everyvoice/base_cli/helpers.py:173-195``) owns the
+Trainer; the module owns the optimiser, the step and ``on_save_checkpoint``.  ``FastSpeech2Trainer`` is that module-side
+contract without Lightning: ``training_step(batch) -> losses`` (forward in training mode, every loss, backward, gradient
+all-reduce, clipping, Noam-scheduled AdamW), ``state_dict()`` with the state-dict names ``everyvoice_amd.fs2.FastSpeech2``
+loads, ``checkpoint()`` with ``model_info`` and JSON-only hyper-parameters (``everyvoice/tests/test_model.py:85-151``).
+
+Teacher forcing as FastSpeech2 trains: ground-truth durations drive the length regulator, ground-truth (phone-level) pitch
+and energy are bucketised into the embeddings, the predictors are regressed on them; loss weights are the reference's
+``FastSpeech2TrainingConfig`` defaults (``everyvoice/.schema/everyvoice-text-to-spec-0.5.json``: mel 1.0, postnet 1.0, pitch /
+energy / duration 0.1; optimiser ``noam``: lr 1e-3, betas (0.9, 0.999), eps 1e-8, weight decay 1e-6, warm-up 1000).
+Durations come from the dataset (``learn_alignment: false``) or from the alignment module's monotonic search
+(``everyvoice_amd.heavy.maximum_path``); the gradient of the alignment losses themselves is not part of this step yet.
+
+Everything is channel-major fp32 ``x[c][b][t]``; no torch autograd and no torch math in the step.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import asdict, dataclass, field
+
+import torch
+
+from .. import _lib
+from ..fs2 import FastSpeech2ModelConfig, Stats
+from . import ops
+from .autograd import Tape, Var
+from .layers import ParamGroup, WNConv
+
+
+@dataclass
+class NoamOptimizerConfig:
+    """``everyvoice/config/shared_types.py:311-320`` with the FastSpeech2TrainingConfig defaults."""
+    learning_rate: float = 1e-3
+    eps: float = 1e-8
+    weight_decay: float = 1e-6
+    betas: tuple = (0.9, 0.999)
+    name: str = "noam"
+    warmup_steps: int = 1000
+
+
+@dataclass
+class FastSpeech2TrainingConfig:
+    batch_size: int = 16
+    optimizer: NoamOptimizerConfig = field(default_factory=NoamOptimizerConfig)
+    mel_loss_weight: float = 1.0
+    postnet_loss_weight: float = 1.0
+    pitch_loss_weight: float = 0.1
+    energy_loss_weight: float = 0.1
+    duration_loss_weight: float = 0.1
+    gradient_clip_val: float | None = 1.0
+
+
+def _s(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _chk(rc, what):
+    _lib.check(rc, what)
+
+
+# ---- parameter holders (names = the reference state dict) ---------------------------------------------------------------
+class Dense:
+    """Unnormalised Conv1d / Linear weights: the gradient of the effective weight IS the parameter gradient."""
+    stride, dil, groups, frozen, transposed = 1, 1, 1, False, False
+
+    def __init__(self, group: ParamGroup, wname: str, bname: str, cin: int, cout: int, k: int = 1, linear: bool = False):
+        self.group, self.cin, self.cout, self.k = group, cin, cout, k
+        self.pad = (k - 1) // 2
+        self.wshape = (cout, cin, k)
+        self.i_w = group.declare(wname, (cout, cin) if linear else (cout, cin, k))
+        self.i_bias = group.declare(bname, (cout,))
+
+    def effective(self, training=True):
+        return self.group.data(self.i_w).view(self.wshape), self.group.gradient(self.i_w).view(self.wshape)
+
+    def bias_data(self):
+        return self.group.data(self.i_bias)
+
+    def db_sink(self):
+        return self.group.gradient(self.i_bias)
+
+    def materialize(self):
+        pass
+
+    def finish_grads(self):
+        pass
+
+
+class Affine:
+    """LayerNorm / BatchNorm scale and shift."""
+
+    def __init__(self, group: ParamGroup, prefix: str, C: int, batchnorm: bool = False):
+        self.group, self.C = group, C
+        self.i_g = group.declare(prefix + ".weight", (C,))
+        self.i_b = group.declare(prefix + ".bias", (C,))
+        self.prefix = prefix
+        if batchnorm:
+            self.running_mean = torch.zeros(C, device=group.device)
+            self.running_var = torch.ones(C, device=group.device)
+            self.batches = 0
+
+    def gamma(self):
+        return self.group.data(self.i_g)
+
+    def beta(self):
+        return self.group.data(self.i_b)
+
+    def dgamma(self):
+        return self.group.gradient(self.i_g)
+
+    def dbeta(self):
+        return self.group.gradient(self.i_b)
+
+
+class Table:
+    def __init__(self, group: ParamGroup, name: str, rows: int, D: int):
+        self.group, self.rows, self.D = group, rows, D
+        self.i = group.declare(name, (rows, D))
+
+    def data(self):
+        return self.group.data(self.i)
+
+    def grad(self):
+        return self.group.gradient(self.i)
+
+
+# ---- tape operators ---------------------------------------------------------------------------------------------------
+def dense(tape: Tape, x: Var, layer, act=ops.ACT_NONE) -> Var:
+    """conv1d / Linear (+ ReLU or tanh in the epilogue: their backward only needs the output)."""
+    assert act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_TANH)
+    w, dw_sink = layer.effective(True)
+    y = Var(ops.conv1d_fwd(x.data, w, layer.bias_data(), 1, layer.pad, 1, 1, act=act))
+
+    def bwd():
+        if y.grad is None:
+            return
+        dy = y.grad
+        if act == ops.ACT_RELU:
+            dy = ops.elementwise(ops.EW_RELU_BWD, dy, y.data)
+        elif act == ops.ACT_TANH:
+            dy = ops.tanh_bwd(dy, y.data)
+        dx, _, _ = ops.conv1d_bwd(x.data, w, dy, 1, layer.pad, 1, 1, need_dx=x.needs_grad, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True)
+        if dx is not None:
+            x.accumulate(dx)
+
+    tape.record(bwd)
+    return y
+
+
+def silu(tape: Tape, x: Var) -> Var:
+    y = Var(ops.elementwise(ops.EW_SILU, x.data))
+    tape.record(lambda: y.grad is not None and x.accumulate(ops.elementwise(ops.EW_SILU_BWD, y.grad, x.data)))
+    return y
+
+
+def glu(tape: Tape, p: Var) -> Var:
+    D = p.data.shape[0] // 2
+    y = Var(ops.elementwise(ops.EW_GLU, p.data[:D], p.data[D:]))
+    tape.record(lambda: y.grad is not None and p.accumulate(ops.glu_bwd(p.data, y.grad)))
+    return y
+
+
+def layernorm(tape: Tape, x: Var, ln: Affine) -> Var:
+    y = Var(ops.layernorm(x.data, ln.gamma(), ln.beta()))
+    tape.record(lambda: y.grad is not None and x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), y.grad, ln.dgamma(), ln.dbeta())))
+    return y
+
+
+def batchnorm(tape: Tape, x: Var, bn: Affine, act=ops.ACT_NONE) -> Var:
+    out, mean, rstd = ops.batchnorm_fwd(x.data, bn.gamma(), bn.beta(), bn.running_mean, bn.running_var, act)
+    bn.batches += 1
+    y = Var(out)
+    tape.record(lambda: y.grad is not None and x.accumulate(ops.batchnorm_bwd(x.data, bn.gamma(), bn.beta(), mean, rstd, y.grad, bn.dgamma(), bn.dbeta(), act)))
+    return y
+
+
+def dwconv(tape: Tape, x: Var, layer) -> Var:
+    """Depthwise convolution; ``layer``: Dense or WNConv with wshape (C, 1, k)."""
+    w, dw_sink = layer.effective(True)
+    k = layer.k
+    y = Var(ops.dwconv_fwd(x.data, w, layer.bias_data(), k))
+
+    def bwd():
+        if y.grad is None:
+            return
+        dx = ops.dwconv_bwd(x.data, w, y.grad, dw_sink, layer.db_sink(), k, need_dx=x.needs_grad)
+        if dx is not None:
+            x.accumulate(dx)
+
+    tape.record(bwd)
+    return y
+
+
+def dropout(tape: Tape, x: Var, p: float, seed: int) -> Var:
+    if p <= 0.0:
+        return x
+    y = Var(ops.dropout(x.data, p, seed))
+    tape.record(lambda: y.grad is not None and x.accumulate(ops.dropout(y.grad, p, seed)))
+    return y
+
+
+def residual(tape: Tape, a: Var, b: Var, sb: float = 1.0) -> Var:
+    """a + sb * b"""
+    y = Var(ops.axpby(1.0, a.data, sb, b.data))
+
+    def bwd():
+        if y.grad is None:
+            return
+        b.accumulate(ops.elementwise(ops.EW_SCALE, y.grad, p0=sb))
+        a.accumulate(y.grad)  # y.grad is not used again: handing it over is safe, b got its own tensor
+
+    tape.record(bwd)
+    return y
+
+
+def attention(tape: Tape, qkv: Var, lens32, heads: int, p: float, seed: int) -> Var:
+    out, saved = ops.attention_train_fwd(qkv.data, lens32, heads, p, seed)
+    y = Var(out)
+    tape.record(lambda: y.grad is not None and qkv.accumulate(ops.attention_train_bwd(qkv.data, saved, y.grad, heads, p, seed)))
+    return y
+
+
+def masked(tape: Tape, x: Var, lens32) -> Var:
+    """Zero the columns t >= len[b] (a copy: earlier operators may still need the unmasked values)."""
+    y = Var(ops.mask_cols_(x.data.clone(), lens32))
+    tape.record(lambda: y.grad is not None and x.accumulate(ops.mask_cols_(y.grad.clone(), lens32)))
+    return y
+
+
+def mse_loss(tape: Tape, pred: Var, target: torch.Tensor, count: float, weight: float) -> torch.Tensor:
+    """weight * sum((pred - target)^2) / count -> device scalar; both operands are zero outside the valid region."""
+    diff = ops.axpby(1.0, pred.data, -1.0, target)
+    out = torch.empty(1, device=diff.device, dtype=torch.float32)
+    ops.scalar_reduce(1, diff, None, out, scale=weight / count, p=0.0)
+    tape.record(lambda: pred.accumulate(ops.elementwise(ops.EW_SCALE, diff, p0=2.0 * weight / count)))
+    return out
+
+
+# ---- the model ---------------------------------------------------------------------------------------------------------
+class _ConformerT:
+    def __init__(self, g: ParamGroup, cfg, prefix: str):
+        self.cfg = cfg
+        d, f, k = cfg.input_dim, cfg.feedforward_dim, cfg.conv_kernel_size
+        self.layers = []
+        for i in range(cfg.layers):
+            p = f"{prefix}.conformer_layers.{i}."
+            L = {}
+            for name in ("ffn1",):
+                L[name] = self._ffn(g, p + name, d, f)
+            L["attn_ln"] = Affine(g, p + "self_attn_layer_norm", d)
+            L["in_proj"] = Dense(g, p + "self_attn.in_proj_weight", p + "self_attn.in_proj_bias", d, 3 * d, linear=True)
+            L["out_proj"] = Dense(g, p + "self_attn.out_proj.weight", p + "self_attn.out_proj.bias", d, d, linear=True)
+            c = p + "conv_module."
+            L["conv_ln"] = Affine(g, c + "layer_norm", d)
+            L["pw1"] = Dense(g, c + "sequential.0.weight", c + "sequential.0.bias", d, 2 * d)
+            L["dw"] = Dense(g, c + "sequential.2.weight", c + "sequential.2.bias", 1, d, k)
+            L["bn"] = Affine(g, c + "sequential.3", d, batchnorm=True)
+            L["pw2"] = Dense(g, c + "sequential.5.weight", c + "sequential.5.bias", d, d)
+            L["ffn2"] = self._ffn(g, p + "ffn2", d, f)
+            L["final_ln"] = Affine(g, p + "final_layer_norm", d)
+            self.layers.append(L)
+
+    @staticmethod
+    def _ffn(g, p, d, f):
+        return dict(ln=Affine(g, p + ".sequential.0", d), l1=Dense(g, p + ".sequential.1.weight", p + ".sequential.1.bias", d, f, linear=True),
+                    l2=Dense(g, p + ".sequential.4.weight", p + ".sequential.4.bias", f, d, linear=True))
+
+    def batchnorms(self):
+        return [L["bn"] for L in self.layers]
+
+    def forward(self, tape: Tape, x: Var, lens32, seeds) -> Var:
+        p = self.cfg.dropout
+        for L in self.layers:
+            x = self._ffn_fwd(tape, x, L["ffn1"], p, seeds)
+            h = dense(tape, layernorm(tape, x, L["attn_ln"]), L["in_proj"])
+            h = attention(tape, h, lens32, self.cfg.heads, p, seeds(self.cfg.heads))
+            h = dropout(tape, dense(tape, h, L["out_proj"]), p, seeds())
+            x = residual(tape, x, h)
+            h = glu(tape, dense(tape, layernorm(tape, x, L["conv_ln"]), L["pw1"]))
+            h = batchnorm(tape, dwconv(tape, h, L["dw"]), L["bn"], ops.ACT_SILU)
+            h = dropout(tape, dense(tape, h, L["pw2"]), p, seeds())
+            x = residual(tape, x, h)
+            x = self._ffn_fwd(tape, x, L["ffn2"], p, seeds)
+            x = layernorm(tape, x, L["final_ln"])
+        return x
+
+    @staticmethod
+    def _ffn_fwd(tape, x, F, p, seeds):
+        h = silu(tape, dense(tape, layernorm(tape, x, F["ln"]), F["l1"]))
+        h = dense(tape, dropout(tape, h, p, seeds()), F["l2"])
+        return residual(tape, x, dropout(tape, h, p, seeds()), 0.5)
+
+
+class _VariancePredictorT:
+    def __init__(self, g: ParamGroup, cfg, prefix: str):
+        self.cfg = cfg
+        d, k = cfg.input_dim, cfg.kernel_size
+        self.layers = []
+        for i in range(cfg.n_layers):
+            p = f"{prefix}.convs.{i}"
+            if cfg.depthwise:
+                conv = (WNConv(g, p + ".0", d, d, k, pad=(k - 1) // 2, groups=d), WNConv(g, p + ".1", d, d, 1))
+            else:
+                conv = (Dense(g, p + ".weight", p + ".bias", d, d, k),)
+            self.layers.append((conv, Affine(g, f"{prefix}.norms.{i}", d)))
+        self.linear = Dense(g, prefix + ".linear.weight", prefix + ".linear.bias", d, 1, linear=True)
+
+    def convs(self):
+        return [c for conv, _ in self.layers for c in conv]
+
+    def forward(self, tape: Tape, x: Var, lens32, seeds) -> Var:
+        """x [D, B, L] -> [1, B, L], zero at the padded positions."""
+        for conv, ln in self.layers:
+            h = dense(tape, dwconv(tape, x, conv[0]), conv[1], ops.ACT_RELU) if self.cfg.depthwise else dense(tape, x, conv[0], ops.ACT_RELU)
+            x = dropout(tape, layernorm(tape, h, ln), self.cfg.dropout, seeds())
+        return masked(tape, dense(tape, x, self.linear), lens32)
+
+
+class FastSpeech2Trainer:
+    """``tr = FastSpeech2Trainer(config, stats); losses = tr.training_step(batch)``.
+
+    batch: ``ids [B, L]`` (0 = padding), ``lens [B]``, ``durations [B, L]`` (frames per symbol), ``mel [B, T, n_mels]`` (zero padded,
+    ``T = max sum(durations)``), ``pitch`` / ``energy`` ``[B, L]`` (phone level, normalised), optional ``speakers`` / ``languages`` ``[B]``.
+    """
+
+    _VERSION = "1.0"
+
+    def __init__(self, config: FastSpeech2ModelConfig | None = None, stats: Stats | None = None, training: FastSpeech2TrainingConfig | None = None,
+                 device="cuda:0", seed: int = 1234, lang2id: dict | None = None, speaker2id: dict | None = None, process_group=None):
+        self.config = c = config or FastSpeech2ModelConfig()
+        self.stats = stats or Stats()
+        self.training = training or FastSpeech2TrainingConfig()
+        self.device = torch.device(device)
+        self.lang2id, self.speaker2id = lang2id or {}, speaker2id or {}
+        self.pg = process_group  # None: one GPU; True: the default torch.distributed group; else a group (RCCL under "nccl")
+        if self.device.type != "cuda":
+            raise RuntimeError("FastSpeech2Trainer runs on libevmi_hip (MI355X) only; there is no CPU path")
+        _lib.load()
+        g = self.params = ParamGroup(self.device)
+        d = c.encoder.input_dim
+        self.text_table = Table(g, "text_input_layer.weight", c.n_symbols, d)
+        self.encoder = _ConformerT(g, c.encoder, "encoder")
+        self.speaker_table = Table(g, "speaker_embedding.weight", max(1, c.n_speakers), d) if c.multispeaker else None
+        self.language_table = Table(g, "language_embedding.weight", max(1, c.n_languages), d) if c.multilingual else None
+        vp = c.variance_predictors
+        self.duration_predictor = _VariancePredictorT(g, vp.duration, "duration_predictor")
+        self.pitch_predictor = _VariancePredictorT(g, vp.pitch, "pitch_predictor")
+        self.energy_predictor = _VariancePredictorT(g, vp.energy, "energy_predictor")
+        self.pitch_table = Table(g, "pitch_embedding.weight", vp.pitch.n_bins, d)
+        self.energy_table = Table(g, "energy_embedding.weight", vp.energy.n_bins, d)
+        self.decoder = _ConformerT(g, c.decoder, "decoder")
+        self.mel_linear = Dense(g, "mel_linear.weight", "mel_linear.bias", c.decoder.input_dim, c.n_mels, linear=True)
+        self.postnet = []
+        if c.use_postnet:
+            dims = [c.n_mels] + [c.postnet_channels] * (c.postnet_layers - 1) + [c.n_mels]
+            for i in range(c.postnet_layers):
+                p = f"postnet.convolutions.{i}"
+                self.postnet.append((Dense(g, p + ".0.weight", p + ".0.bias", dims[i], dims[i + 1], c.postnet_kernel), Affine(g, p + ".1", dims[i + 1], batchnorm=True)))
+        g.finalize()
+        self.inv_freq = (1.0 / (10000 ** (torch.arange(0.0, d, 2.0) / d))).to(self.device)
+        lin = lambda st, n: torch.linspace(st.norm_min, st.norm_max, n - 1).to(self.device)
+        self.pitch_bins, self.energy_bins = lin(self.stats.pitch, vp.pitch.n_bins), lin(self.stats.energy, vp.energy.n_bins)
+        self._wn = [cv for vpred in (self.duration_predictor, self.pitch_predictor, self.energy_predictor) for cv in vpred.convs() if isinstance(cv, WNConv)]
+        self._bn = self.encoder.batchnorms() + self.decoder.batchnorms() + [bn for _, bn in self.postnet]
+        self.global_step = 0
+        self._seed = seed
+        self._grad_norm = torch.zeros(1, device=self.device)
+        self.init_random(seed)
+
+    # -- parameters ---------------------------------------------------------------------------------------------------
+    def init_random(self, seed: int = 1234):
+        """torch-like initial values under a fixed seed (there is no network for checkpoints)."""
+        gen = torch.Generator().manual_seed(seed)
+        sd = {}
+        for name, shape, _ in self.params._specs:
+            if name.endswith("weight_g") or (len(shape) == 1 and name.endswith(".weight")):
+                sd[name] = torch.ones(shape)
+            elif name.endswith("bias"):
+                sd[name] = torch.zeros(shape)
+            else:
+                fan_in = max(1, math.prod(shape[1:])) if len(shape) > 1 else shape[0]
+                sd[name] = torch.randn(shape, generator=gen) / fan_in ** 0.5
+        self.load_state_dict(sd, strict=False)
+
+    def load_state_dict(self, sd: dict, strict: bool = True):
+        names = set(self.params.names())
+        for name in names:
+            if name in sd:
+                self.params.load(name, sd[name])
+            elif strict:
+                raise KeyError(f"missing parameter {name}")
+        for bn in self._bn:
+            if bn.prefix + ".running_mean" in sd:
+                bn.running_mean.copy_(sd[bn.prefix + ".running_mean"])
+                bn.running_var.copy_(sd[bn.prefix + ".running_var"])
+        for cv in self._wn:
+            cv._w = None
+        return self
+
+    def state_dict(self) -> dict:
+        """Exactly what ``everyvoice_amd.fs2.FastSpeech2.load_state_dict`` (and the oracle module) take."""
+        sd = self.params.state_dict()
+        for bn in self._bn:
+            sd[bn.prefix + ".running_mean"] = bn.running_mean.clone()
+            sd[bn.prefix + ".running_var"] = bn.running_var.clone()
+            sd[bn.prefix + ".num_batches_tracked"] = torch.tensor(bn.batches)
+        sd["position_embedding.inv_freq"] = self.inv_freq.clone()
+        sd["pitch_bins"], sd["energy_bins"] = self.pitch_bins.clone(), self.energy_bins.clone()
+        return sd
+
+    def checkpoint(self) -> dict:
+        """Lightning-shaped: state_dict, optimiser state, JSON-only hyper_parameters, model_info (tests/test_model.py:85-151)."""
+        g = self.params
+        return {"state_dict": {k: v.cpu() for k, v in self.state_dict().items()},
+                "optimizer_states": [{"m": g.m.cpu(), "v": g.v.cpu(), "step": g.step}],
+                "global_step": self.global_step,
+                "hyper_parameters": {"config": asdict(self.config), "stats": asdict(self.stats), "training": asdict(self.training),
+                                     "lang2id": dict(self.lang2id), "speaker2id": dict(self.speaker2id)},
+                "model_info": {"name": "FastSpeech2", "version": self._VERSION}}
+
+    def load_checkpoint(self, ckpt: dict):
+        info = ckpt.get("model_info", {})
+        if info.get("name") != "FastSpeech2":
+            raise TypeError(f"Wrong model type ({info.get('name')}), we are expecting a 'FastSpeech2' model")
+        self.load_state_dict(ckpt["state_dict"])
+        for bn in self._bn:
+            bn.batches = int(ckpt["state_dict"].get(bn.prefix + ".num_batches_tracked", 0))
+        o = ckpt["optimizer_states"][0]
+        self.params.m.copy_(o["m"])
+        self.params.v.copy_(o["v"])
+        self.params.step = int(o["step"])
+        self.global_step = int(ckpt["global_step"])
+        return self
+
+    # -- schedule -----------------------------------------------------------------------------------------------------
+    def learning_rate(self, step: int) -> float:
+        """Noam: linear warm-up to ``learning_rate`` at ``warmup_steps``, then inverse square root decay."""
+        o = self.training.optimizer
+        w = max(1, o.warmup_steps)
+        return o.learning_rate * w ** 0.5 * min(step ** -0.5, step * w ** -1.5)
+
+    # -- the step -------------------------------------------------------------------------------------------------------
+    def forward_backward(self, batch: dict) -> dict:
+        """Forward in training mode + every loss + backward; gradients are left in ``self.params.grad``."""
+        lib, dev, c, tr = _lib.load(), self.device, self.config, self.training
+        ids = batch["ids"].to(dev, torch.int32).contiguous()
+        lens = batch["lens"].to(dev, torch.int32).contiguous()
+        B, L = ids.shape
+        D = c.encoder.input_dim
+        n_tok = float(batch["lens"].sum())
+        pad = torch.arange(L, device=dev)[None, :] >= lens[:, None]
+        dur = batch["durations"].to(dev, torch.int32).clamp_min(0).masked_fill(pad, 0).contiguous()
+        cum = torch.cumsum(dur, 1, dtype=torch.int32).contiguous()
+        mel_lens_host = batch["durations"].clamp_min(0).masked_fill(torch.arange(L)[None, :] >= batch["lens"][:, None], 0).sum(1)
+        mel_lens = mel_lens_host.to(dev, torch.int32).contiguous()
+        T = int(mel_lens_host.max())
+        n_frames = float(mel_lens_host.sum())
+        mel_t = batch["mel"].to(dev, torch.float32)[:, :T].permute(2, 0, 1).contiguous()  # [n_mels, B, T]
+        pitch_t = batch["pitch"].to(dev, torch.float32).masked_fill(pad, 0.0).contiguous()
+        energy_t = batch["energy"].to(dev, torch.float32).masked_fill(pad, 0.0).contiguous()
+        log_d_t = torch.log(dur.float() + 1.0).contiguous()
+
+        self.params.zero_grad()
+        for cv in self._wn:
+            cv.materialize()
+        tape = Tape()
+        counter = [0]
+
+        def seeds(n=1):
+            counter[0] += n
+            return (self._seed * 1000003 + self.global_step) * 4096 + counter[0] - n
+
+        emb = torch.empty(D, B, L, device=dev, dtype=torch.float32)
+        _chk(lib.evmi_fs2_embed_f32(ids.data_ptr(), lens.data_ptr(), self.text_table.data().data_ptr(), self.inv_freq.data_ptr(), emb.data_ptr(),
+                                    B, L, D, _s(emb)), "evmi_fs2_embed_f32")
+        x0 = Var(emb)
+        tape.record(lambda: x0.grad is not None and _chk(lib.evmi_fs2_embed_bwd_f32(
+            x0.grad.data_ptr(), ids.data_ptr(), lens.data_ptr(), self.text_table.grad().data_ptr(), self.text_table.rows, B, L, D, 0, _s(emb)), "evmi_fs2_embed_bwd_f32"))
+        x = self.encoder.forward(tape, x0, lens, seeds)
+
+        for table, key in ((self.speaker_table, "speakers"), (self.language_table, "languages")):
+            if table is not None:
+                if batch.get(key) is None:
+                    raise ValueError(f"this model needs `{key}` ids [B]")
+                x = self._add_item_embedding(tape, x, table, batch[key].to(dev, torch.int32).contiguous(), lens)
+
+        losses = {}
+        w = tr.duration_loss_weight
+        losses["duration"] = mse_loss(tape, self.duration_predictor.forward(tape, x, lens, seeds), log_d_t.view(1, B, L), n_tok, w)
+        losses["pitch"] = mse_loss(tape, self.pitch_predictor.forward(tape, x, lens, seeds), pitch_t.view(1, B, L), n_tok, tr.pitch_loss_weight)
+        x = self._add_bucket_embedding(tape, x, pitch_t, self.pitch_bins, self.pitch_table)
+        losses["energy"] = mse_loss(tape, self.energy_predictor.forward(tape, x, lens, seeds), energy_t.view(1, B, L), n_tok, tr.energy_loss_weight)
+        x = self._add_bucket_embedding(tape, x, energy_t, self.energy_bins, self.energy_table)
+
+        frames = torch.empty(D, B, T, device=dev, dtype=torch.float32)
+        _chk(lib.evmi_length_regulate_cbt_f32(x.data.data_ptr(), cum.data_ptr(), frames.data_ptr(), D, B, L, T, _s(frames)), "evmi_length_regulate_cbt_f32")
+        _chk(lib.evmi_fs2_add_posemb_f32(frames.data_ptr(), mel_lens.data_ptr(), self.inv_freq.data_ptr(), B, T, D, _s(frames)), "evmi_fs2_add_posemb_f32")
+        f = Var(frames)
+        x_enc = x
+
+        def lr_bwd():
+            if f.grad is None:
+                return
+            dfr = ops.mask_cols_(f.grad, mel_lens)  # the positional sinusoid is constant; padded frames were zeroed
+            dx = torch.empty(D, B, L, device=dev, dtype=torch.float32)
+            _chk(lib.evmi_length_regulate_bwd_cbt_f32(dfr.data_ptr(), cum.data_ptr(), dx.data_ptr(), D, B, L, T, _s(dx)), "evmi_length_regulate_bwd_cbt_f32")
+            x_enc.accumulate(dx)
+
+        tape.record(lr_bwd)
+        y = self.decoder.forward(tape, f, mel_lens, seeds)
+        mel = masked(tape, dense(tape, y, self.mel_linear), mel_lens)
+        n_el = n_frames * c.n_mels
+        losses["mel"] = mse_loss(tape, mel, mel_t, n_el, tr.mel_loss_weight)
+        if self.postnet:
+            h = mel
+            for i, (conv, bn) in enumerate(self.postnet):
+                h = batchnorm(tape, dense(tape, h, conv), bn, ops.ACT_TANH if i < len(self.postnet) - 1 else ops.ACT_NONE)
+            post = masked(tape, residual(tape, mel, h), mel_lens)
+            losses["postnet"] = mse_loss(tape, post, mel_t, n_el, tr.postnet_loss_weight)
+        tape.backward()
+        for cv in self._wn:
+            cv.finish_grads()
+        total = torch.zeros(1, device=dev)
+        for v in losses.values():
+            ops.axpby(1.0, total, 1.0, v, out=total)
+        losses["total"] = total
+        return losses
+
+    def _add_item_embedding(self, tape, x: Var, table: Table, item_ids, lens):
+        lib = _lib.load()
+        D, B, L = x.data.shape
+        out = x.data.clone()
+        _chk(lib.evmi_fs2_add_item_embedding_f32(out.data_ptr(), item_ids.data_ptr(), lens.data_ptr(), table.data().data_ptr(), B, L, D, _s(out)),
+             "evmi_fs2_add_item_embedding_f32")
+        y = Var(out)
+
+        def bwd():
+            if y.grad is None:
+                return
+            _chk(lib.evmi_fs2_item_embedding_bwd_f32(y.grad.data_ptr(), item_ids.data_ptr(), lens.data_ptr(), table.grad().data_ptr(), table.rows, B, L, D, _s(out)),
+                 "evmi_fs2_item_embedding_bwd_f32")
+            x.accumulate(y.grad)
+
+        tape.record(bwd)
+        return y
+
+    def _add_bucket_embedding(self, tape, x: Var, values, bins, table: Table):
+        lib = _lib.load()
+        D, B, L = x.data.shape
+        out = x.data.clone()
+        _chk(lib.evmi_fs2_bucket_embed_add_f32(out.data_ptr(), values.data_ptr(), bins.data_ptr(), table.data().data_ptr(), table.rows, B, L, D, 1.0, _s(out)),
+             "evmi_fs2_bucket_embed_add_f32")
+        y = Var(out)
+
+        def bwd():
+            if y.grad is None:
+                return
+            idx = torch.empty(B, L, device=out.device, dtype=torch.int32)
+            _chk(lib.evmi_fs2_bucket_embed_bwd_f32(y.grad.data_ptr(), values.data_ptr(), bins.data_ptr(), table.grad().data_ptr(), idx.data_ptr(), table.rows,
+                                                   B, L, D, 1.0, _s(out)), "evmi_fs2_bucket_embed_bwd_f32")
+            x.accumulate(y.grad)
+
+        tape.record(bwd)
+        return y
+
+    def training_step(self, batch: dict) -> dict:
+        """One optimiser step; returns the losses as device scalars (no host synchronisation inside the step)."""
+        from .hifigan import allreduce_mean_
+        losses = self.forward_backward(batch)
+        if self.pg is not None:  # data parallel: utterances are sharded across ranks, gradients averaged
+            allreduce_mean_(self.params.grad, self.pg if self.pg is not True else None, lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
+        g = self.params
+        clip = self.training.gradient_clip_val
+        if clip is not None:
+            # g *= min(1, clip / (||g|| + 1e-6)), the norm staying on the device (torch.nn.utils.clip_grad_norm_)
+            ops.scalar_reduce(1, g.grad, None, self._grad_norm, p=0.0)
+            ops.elementwise(ops.EW_CLIP_SCALE, g.grad, None, self._grad_norm, out=g.grad, p0=float(clip))
+        self.global_step += 1
+        o = self.training.optimizer
+        g.adamw(self.learning_rate(self.global_step), tuple(o.betas), o.eps, o.weight_decay)
+        for cv in self._wn:
+            cv._w = None
+        return losses

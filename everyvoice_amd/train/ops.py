@@ -180,10 +180,19 @@ def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bo
     return bool(_lib.load().evmi_conv1d_cbt_f32_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups))
 
 
-def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, lrelu_slope=None):
-    """x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out] (leaky-relu applied in the epilogue when a slope is given)."""
+_ACT_EW = {ACT_SILU: 13, ACT_RELU: 14, ACT_TANH: EW_TANH}
+
+
+def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, lrelu_slope=None, act=ACT_NONE):
+    """x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out] (leaky-relu applied in the epilogue when a slope is given;
+    ``act``: one of the other epilogue activations)."""
     cin, B, t_in = x.shape
     cout, cin_g, k = w.shape
+    if act != ACT_NONE:
+        if CONV_BACKEND["fwd"] == "mfma" and mfma_conv_supported(B, cin, t_in, cout, conv_out_len(t_in, k, stride, pad, dil), k, stride, dil, groups):
+            return conv1d_mfma(x, w, bias, stride, pad, dil, groups, act=act)
+        y = conv1d_fwd(x, w, bias, stride, pad, dil, groups)
+        return elementwise(_ACT_EW[act], y, out=y)
     if CONV_BACKEND["fwd"] == "mfma" and mfma_conv_supported(B, cin, t_in, cout, conv_out_len(t_in, k, stride, pad, dil), k, stride, dil, groups):
         if lrelu_slope is None:
             return conv1d_mfma(x, w, bias, stride, pad, dil, groups)
@@ -223,7 +232,7 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
             _chk(lib.evmi_conv1d_wgrad_cbt_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
                                                k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_f32")
         else:
-            col, _ = unfold(x, k, stride, pad, dil)
+            col = x if (k == 1 and stride == 1 and pad == 0) else unfold(x, k, stride, pad, dil)[0]
             beta = 1.0 if accumulate else 0.0
             kg = cin_g * k
             # dW_g [cout_g, kg] (+)= dY_g [cout_g, N] . col_g^T
@@ -363,3 +372,118 @@ def stft_frames_bwd(dfr, B, T, n_fft, hop):
     dx = torch.empty(B, T, device=dfr.device, dtype=torch.float32)
     _chk(_lib.load().evmi_stft_frames_f32(dfr.data_ptr(), dx.data_ptr(), B, T, n_fft, hop, 1, _s(dfr)), "evmi_stft_frames_f32")
     return dx
+
+
+# ---- FastSpeech2 training operators (csrc/fs2_train_ops.hip) -----------------------------------------------------------
+EW_SILU, EW_RELU, EW_GLU, EW_SILU_BWD, EW_RELU_BWD, EW_CLIP_SCALE = 13, 14, 15, 18, 19, 20
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    y = torch.empty_like(x)
+    _chk(_lib.load().evmi_layernorm_cbt_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1] * x.shape[2],
+                                            eps, _s(x)), "evmi_layernorm_cbt_f32")
+    return y
+
+
+def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5):
+    """dx; dgamma / dbeta are accumulated into."""
+    lib = _lib.load()
+    C, N = x.shape[0], x.shape[1] * x.shape[2]
+    n = lib.evmi_layernorm_bwd_cbt_f32_ws_elems(C, N)
+    ws = WS.get("ln_bwd", n, x.device)
+    dx = torch.empty_like(x)
+    _chk(lib.evmi_layernorm_bwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                        ws.data_ptr(), n, C, N, eps, 0, _s(x)), "evmi_layernorm_bwd_cbt_f32")
+    return dx
+
+
+def batchnorm_fwd(x, gamma, beta, running_mean, running_var, act=ACT_NONE, eps=1e-5, momentum=0.1):
+    C, N = x.shape[0], x.shape[1] * x.shape[2]
+    y = torch.empty_like(x)
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    _chk(_lib.load().evmi_batchnorm_fwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                _lib.ptr(running_mean), _lib.ptr(running_var), C, N, eps, momentum, act, _s(x)), "evmi_batchnorm_fwd_cbt_f32")
+    return y, mean, rstd
+
+
+def batchnorm_bwd(x, gamma, beta, mean, rstd, dy, dgamma, dbeta, act=ACT_NONE):
+    dx = torch.empty_like(x)
+    _chk(_lib.load().evmi_batchnorm_bwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
+                                                dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), x.shape[0], x.shape[1] * x.shape[2], act, _s(x)),
+         "evmi_batchnorm_bwd_cbt_f32")
+    return dx
+
+
+def dwconv_fwd(x, w, bias, k):
+    y = torch.empty_like(x)
+    C, B, T = x.shape
+    _chk(_lib.load().evmi_dwconv1d_cbt_f32(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), y.data_ptr(), C, B, T, k, (k - 1) // 2, 0, _s(x)), "evmi_dwconv1d_cbt_f32")
+    return y
+
+
+def dwconv_bwd(x, w, dy, dw, db, k, need_dx=True):
+    C, B, T = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    _chk(_lib.load().evmi_dwconv1d_bwd_cbt_f32(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _lib.ptr(dx), dw.data_ptr(), db.data_ptr(), C, B, T, k,
+                                               (k - 1) // 2, _s(x)), "evmi_dwconv1d_bwd_cbt_f32")
+    return dx
+
+
+def dropout(x, p, seed):
+    y = torch.empty_like(x)
+    _chk(_lib.load().evmi_dropout_f32(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _s(x)), "evmi_dropout_f32")
+    return y
+
+
+def glu_bwd(p, dy):
+    dp = torch.empty_like(p)
+    _chk(_lib.load().evmi_glu_bwd_f32(p.data_ptr(), dy.data_ptr(), dp.data_ptr(), dy.numel(), _s(p)), "evmi_glu_bwd_f32")
+    return dp
+
+
+def mask_cols_(x, lens32):
+    C, B, T = x.shape
+    _chk(_lib.load().evmi_mask_cols_f32(x.data_ptr(), lens32.data_ptr(), C, B, T, _s(x)), "evmi_mask_cols_f32")
+    return x
+
+
+def attention_train_fwd(qkv, lens32, heads, p=0.0, seed=0):
+    """Multi-head self-attention that keeps the probabilities: qkv [3D, B, T] -> (out [D, B, T], saved).  Two batched GEMMs
+    per head around the masked softmax rows (+ attention dropout, as torch.nn.MultiheadAttention applies it)."""
+    lib = _lib.load()
+    D3, B, T = qkv.shape
+    D = D3 // 3
+    dh = D // heads
+    out = torch.empty(D, B, T, device=qkv.device, dtype=torch.float32)
+    saved = []
+    BT = B * T
+    for h in range(heads):
+        q, kk, v = qkv[h * dh:(h + 1) * dh], qkv[D + h * dh:D + (h + 1) * dh], qkv[2 * D + h * dh:2 * D + (h + 1) * dh]
+        P = torch.empty(B, T, T, device=qkv.device, dtype=torch.float32)
+        gemm_groups(q, kk, P, B, T, T, dh, BT, BT, T, T, T, T * T, ta=True, alpha=dh ** -0.5)
+        Pd = torch.empty_like(P) if p > 0 else None
+        _chk(lib.evmi_softmax_rows_f32(P.data_ptr(), _lib.ptr(Pd), lens32.data_ptr(), B, T, T, p, seed + h, _s(qkv)), "evmi_softmax_rows_f32")
+        gemm_groups(v, Pd if Pd is not None else P, out[h * dh:(h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T, tb=True)
+        saved.append((P, Pd))
+    return out, saved
+
+
+def attention_train_bwd(qkv, saved, dout, heads, p=0.0, seed=0):
+    lib = _lib.load()
+    D3, B, T = qkv.shape
+    D = D3 // 3
+    dh = D // heads
+    BT = B * T
+    dqkv = torch.empty_like(qkv)
+    for h in range(heads):
+        q, kk, v = qkv[h * dh:(h + 1) * dh], qkv[D + h * dh:D + (h + 1) * dh], qkv[2 * D + h * dh:2 * D + (h + 1) * dh]
+        do = dout[h * dh:(h + 1) * dh]
+        P, Pd = saved[h]
+        gemm_groups(do, Pd if Pd is not None else P, dqkv[2 * D + h * dh:2 * D + (h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T)  # dV = dO . Pd
+        dP = WS.get("attn_dP", B * T * T, qkv.device).view(B, T, T)
+        gemm_groups(do, v, dP, B, T, T, dh, BT, BT, T, T, T, T * T, ta=True)                                                          # dP = dO^T . V
+        _chk(lib.evmi_softmax_bwd_rows_f32(P.data_ptr(), dP.data_ptr(), B * T, T, dh ** -0.5, p, seed + h, _s(qkv)), "evmi_softmax_bwd_rows_f32")
+        gemm_groups(kk, dP, dqkv[h * dh:(h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T, tb=True)                                   # dQ = K . dS^T
+        gemm_groups(q, dP, dqkv[D + h * dh:D + (h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T)                                     # dK = Q . dS
+    return dqkv

@@ -355,6 +355,56 @@ int evmi_monotonic_align_f32(const float* value_dev, const int* mel_lens_dev, co
                              int* path_dev, int* dur_dev, unsigned char* scratch_dev, int B, int T, int L,
                              void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * FastSpeech2 training (BASELINE config 3): backward and training-mode operators,
+ * channel-major fp32 x[c][b][t].  The reference gets these from PyTorch autograd inside the absent
+ * submodule FastSpeech2_lightning (driver contract: everyvoice/base_cli/helpers.py:173-195).  Dense
+ * layers use evmi_conv1d_cbt_f32 / evmi_conv1d_dgrad_cbt_f32 / evmi_conv1d_wgrad_cbt_f32 (k = 1).
+ * ------------------------------------------------------------------------------------------ */
+/* LayerNorm over channels, backward: dx (+)= ..., dgamma += sum_cols dy * xhat, dbeta += sum_cols dy (C <= 256).
+ * ws: evmi_layernorm_bwd_cbt_f32_ws_elems floats (per-workgroup partial sums, reduced in a fixed order). */
+long long evmi_layernorm_bwd_cbt_f32_ws_elems(int C, long long n_cols);
+int evmi_layernorm_bwd_cbt_f32(const float* x_dev, const float* gamma_dev, const float* dy_dev, float* dx_dev,
+                               float* dgamma_dev, float* dbeta_dev, float* ws_dev, long long ws_elems, int C,
+                               long long n_cols, float eps, int accumulate_dx, void* stream);
+/* BatchNorm1d in training mode over every column of a channel row, followed by act (0 none, 2 SiLU, 4 tanh):
+ * writes the batch mean / 1/sqrt(var + eps) [C] and, when given, updates the running statistics (unbiased variance). */
+int evmi_batchnorm_fwd_cbt_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
+                               float* mean_dev, float* rstd_dev, float* running_mean_dev, float* running_var_dev,
+                               int C, long long n_cols, float eps, float momentum, int act, void* stream);
+/* dx = ..., dgamma += ..., dbeta += ... through act and the batch statistics. */
+int evmi_batchnorm_bwd_cbt_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, const float* mean_dev,
+                               const float* rstd_dev, const float* dy_dev, float* dx_dev, float* dgamma_dev,
+                               float* dbeta_dev, int C, long long n_cols, int act, void* stream);
+/* Depthwise convolution backward: dx (NULL = skip), dw [C][k] += ..., db [C] += ... (dw NULL = skip both). */
+int evmi_dwconv1d_bwd_cbt_f32(const float* x_dev, const float* w_dev, const float* dy_dev, float* dx_dev, float* dw_dev,
+                              float* db_dev, int C, int B, int T, int k, int pad, void* stream);
+/* scores [B][Tq][Tk] -> softmax over the keys tk < lens[b] in place (0 beyond); with p > 0 also
+ * dropped = dropout(probabilities, p) from the counter-based generator keyed by `seed`. */
+int evmi_softmax_rows_f32(float* scores_dev, float* dropped_dev, const int* lens_dev, int B, int Tq, int Tk, float p,
+                          unsigned long long seed, void* stream);
+/* In place on dprobs: dS = scale * P * (dPm - sum_k P * dPm), dPm = dprobs through the same dropout mask. */
+int evmi_softmax_bwd_rows_f32(const float* probs_dev, float* dprobs_dev, long long rows, int Tk, float scale, float p,
+                              unsigned long long seed, void* stream);
+/* GLU over two halves p = [a; b] of n_half elements each: dp = [dy * sigmoid(b); dy * a * sigmoid'(b)]. */
+int evmi_glu_bwd_f32(const float* p_dev, const float* dy_dev, float* dp_dev, long long n_half, void* stream);
+/* y[i] = keep(seed, i) ? x[i] / (1 - p) : 0 ; calling it on a gradient with the same seed is the backward. */
+int evmi_dropout_f32(const float* x_dev, float* y_dev, long long n, float p, unsigned long long seed, void* stream);
+/* Embedding backward: dtable[ids[b][l]][c] += dx[c][b][l] for l < lens[b], ids != skip_id (padding_idx).  One thread per
+ * (table row, channel) adds its tokens in order: bitwise reproducible, no atomics.  `rows` = rows of the table. */
+int evmi_fs2_embed_bwd_f32(const float* dx_dev, const int* ids_dev, const int* lens_dev, float* dtable_dev, int rows,
+                           int B, int L, int D, int skip_id, void* stream);
+/* idx_ws: B*L ints of scratch (the bucket of every position, pads included as the forward adds there too). */
+int evmi_fs2_bucket_embed_bwd_f32(const float* dx_dev, const float* values_dev, const float* bins_dev,
+                                  float* dtable_dev, int* idx_ws_dev, int n_bins, int B, int L, int D, float control,
+                                  void* stream);
+int evmi_fs2_item_embedding_bwd_f32(const float* dx_dev, const int* ids_dev, const int* lens_dev, float* dtable_dev,
+                                    int rows, int B, int L, int D, void* stream);
+/* Length regulator backward in this layout: dx[c][b][l] = sum of dframes[c][b][t] over the token's frames
+ * (cum = inclusive cumulative durations, as evmi_length_regulate_cbt_f32 takes them). */
+int evmi_length_regulate_bwd_cbt_f32(const float* dframes_dev, const int* cum_dev, float* dx_dev, int C, int B, int L,
+                                     int T, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -268,3 +268,50 @@ def randomize_norm_stats_(model: nn.Module, gen: torch.Generator):
             m.running_var.copy_(torch.rand(m.num_features, generator=gen) * 0.5 + 0.75)
             m.weight.data.copy_(torch.rand(m.num_features, generator=gen) * 0.5 + 0.75)
             m.bias.data.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+
+
+def training_losses_ref(model: FastSpeech2Ref, batch: dict, weights: dict | None = None) -> dict:
+    """Teacher-forced training forward with torch autograd (``model.train()`` decides dropout / BatchNorm mode):
+    ground-truth durations through the length regulator, ground-truth pitch / energy into the embeddings, MSE on
+    log-durations / pitch / energy over the unpadded symbols and on mel / postnet mel over the unpadded frames;
+    weights = FastSpeech2TrainingConfig defaults of the reference's schema (mel 1, postnet 1, pitch / energy / duration 0.1).
+    PARITY UNPINNED like the rest of this file (the training step lives in the absent submodule)."""
+    w = {"mel": 1.0, "postnet": 1.0, "pitch": 0.1, "energy": 0.1, "duration": 0.1}
+    w.update(weights or {})
+    ids, lens, durations = batch["ids"], batch["lens"], batch["durations"]
+    B, L = ids.shape
+    pad = torch.arange(L)[None, :] >= lens[:, None]
+    x = model.text_input_layer(ids) + model.position_embedding(L)[None]
+    x = x.masked_fill(pad[..., None], 0.0)
+    x, _ = model.encoder(x, lens)
+    if model.speaker_embedding is not None:
+        x = x + model.speaker_embedding(batch["speakers"])[:, None, :].masked_fill(pad[..., None], 0.0)
+    if model.language_embedding is not None:
+        x = x + model.language_embedding(batch["languages"])[:, None, :].masked_fill(pad[..., None], 0.0)
+    durations = durations.clamp_min(0).masked_fill(pad, 0)
+    pitch_t, energy_t = batch["pitch"].masked_fill(pad, 0.0), batch["energy"].masked_fill(pad, 0.0)
+    n_tok = lens.sum()
+    losses = {}
+    log_d = model.duration_predictor(x, pad)
+    losses["duration"] = w["duration"] * ((log_d - torch.log(durations.float() + 1.0)) ** 2).sum() / n_tok
+    pitch = model.pitch_predictor(x, pad)
+    losses["pitch"] = w["pitch"] * ((pitch - pitch_t) ** 2).sum() / n_tok
+    x = x + model.pitch_embedding(torch.bucketize(pitch_t, model.pitch_bins))
+    energy = model.energy_predictor(x, pad)
+    losses["energy"] = w["energy"] * ((energy - energy_t) ** 2).sum() / n_tok
+    x = x + model.energy_embedding(torch.bucketize(energy_t, model.energy_bins))
+    mel_lens = durations.sum(1)
+    T = int(mel_lens.max())
+    frames = torch.stack([F.pad(torch.repeat_interleave(x[b], durations[b], dim=0), (0, 0, 0, T - int(mel_lens[b]))) for b in range(B)])
+    fpad = torch.arange(T)[None, :] >= mel_lens[:, None]
+    y = (frames + model.position_embedding(T)[None]).masked_fill(fpad[..., None], 0.0)
+    y, _ = model.decoder(y, mel_lens)
+    mel = model.mel_linear(y).masked_fill(fpad[..., None], 0.0)
+    target = batch["mel"][:, :T]
+    n_el = mel_lens.sum() * mel.shape[2]
+    losses["mel"] = w["mel"] * ((mel - target) ** 2).sum() / n_el
+    if model.postnet is not None:
+        post = (mel + model.postnet(mel)).masked_fill(fpad[..., None], 0.0)
+        losses["postnet"] = w["postnet"] * ((post - target) ** 2).sum() / n_el
+    losses["total"] = sum(losses.values())
+    return losses

@@ -1,0 +1,335 @@
+"""FastSpeech2 training (csrc/fs2_train_ops.hip + train/fs2.py) against torch-CPU autograd of the oracle module.
+
+Operator tests compare each backward kernel with torch autograd of the same op (fp32, tolerance 2e-4 of the tensor's largest
+entry: only the summation order differs).  The step test loads the trainer's parameters into ``oracle.fs2_ref.FastSpeech2Ref``
+in ``train()`` mode (dropout 0 so both sides see the same network; BatchNorm on batch statistics), runs
+``training_losses_ref`` + ``backward()`` and checks every loss, every parameter gradient, the BatchNorm running statistics and
+the parameters after one clipped AdamW step.  Gradient tolerance 2e-3 (L2, relative): 8 conformer layers of fp32 re-association.
+"""
+
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.fs2_ref import FastSpeech2ConfigRef, FastSpeech2Ref, training_losses_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, want, rel=2e-4):
+    scale = float(want.abs().max()) + 1e-12
+    err = float((got.cpu() - want).abs().max())
+    assert err <= rel * scale, f"err {err:.3e} vs scale {scale:.3e}"
+
+
+def _l2close(got, want, rel, name=""):
+    num = float((got.cpu().reshape(-1) - want.reshape(-1)).norm())
+    den = float(want.norm()) + 1e-8
+    floor = 1e-6 * want.numel() ** 0.5  # gradients that are exactly zero in exact arithmetic (a bias in front of BatchNorm) are noise on both sides
+    assert num <= rel * den + floor, f"{name}: |diff| {num:.3e} vs |want| {den:.3e}"
+
+
+def _cbt(x):  # [B, C, T] -> [C, B, T]
+    return x.permute(1, 0, 2).contiguous()
+
+
+# ---- operators -----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,B,T", [(64, 3, 37), (256, 2, 130), (10, 1, 5)])
+def test_layernorm_backward(cuda_device, C, B, T):
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(C + T)
+    x = torch.randn(B, C, T, generator=g, requires_grad=True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_()
+    beta = torch.randn(C, generator=g).requires_grad_()
+    dy = torch.randn(B, C, T, generator=g)
+    y = F.layer_norm(x.transpose(1, 2), (C,), gamma, beta).transpose(1, 2)
+    y.backward(dy)
+    dev = cuda_device
+    dgamma = torch.full((C,), 1.0, device=dev)  # accumulated into: start from a known non-zero value
+    dbeta = torch.full((C,), -2.0, device=dev)
+    dx = ops.layernorm_bwd(_cbt(x.detach()).to(dev), gamma.detach().to(dev), _cbt(dy).to(dev), dgamma, dbeta)
+    _close(dx.cpu().permute(1, 0, 2), x.grad)
+    _close(dgamma.cpu() - 1.0, gamma.grad)
+    _close(dbeta.cpu() + 2.0, beta.grad)
+
+
+@pytest.mark.parametrize("act", [0, 2, 4])
+def test_batchnorm_train_forward_backward(cuda_device, act):
+    from everyvoice_amd.train import ops
+
+    C, B, T = 24, 3, 50
+    g = torch.Generator().manual_seed(act)
+    x = (torch.randn(B, C, T, generator=g) * 2 + 0.5).requires_grad_()
+    bn = torch.nn.BatchNorm1d(C).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    dev = cuda_device
+    rm, rv = bn.running_mean.clone().to(dev), bn.running_var.clone().to(dev)
+    z = bn(x)
+    y = F.silu(z) if act == 2 else (torch.tanh(z) if act == 4 else z)
+    dy = torch.randn(B, C, T, generator=g)
+    y.backward(dy)
+    gam, bet = bn.weight.detach().to(dev), bn.bias.detach().to(dev)
+    out, mean, rstd = ops.batchnorm_fwd(_cbt(x.detach()).to(dev), gam, bet, rm, rv, act)
+    _close(out.cpu().permute(1, 0, 2), y.detach())
+    _close(rm, bn.running_mean, 1e-5)
+    _close(rv, bn.running_var, 1e-5)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    dx = ops.batchnorm_bwd(_cbt(x.detach()).to(dev), gam, bet, mean, rstd, _cbt(dy).to(dev), dg, db, act)
+    _close(dx.cpu().permute(1, 0, 2), x.grad)
+    _close(dg, bn.weight.grad)
+    _close(db, bn.bias.grad)
+
+
+@pytest.mark.parametrize("k", [3, 9])
+def test_depthwise_conv_backward(cuda_device, k):
+    from everyvoice_amd.train import ops
+
+    C, B, T = 20, 3, 41
+    g = torch.Generator().manual_seed(k)
+    x = torch.randn(B, C, T, generator=g, requires_grad=True)
+    w = torch.randn(C, 1, k, generator=g, requires_grad=True)
+    b = torch.randn(C, generator=g, requires_grad=True)
+    y = F.conv1d(x, w, b, padding=(k - 1) // 2, groups=C)
+    dy = torch.randn(B, C, T, generator=g)
+    y.backward(dy)
+    dev = cuda_device
+    got = ops.dwconv_fwd(_cbt(x.detach()).to(dev), w.detach().to(dev), b.detach().to(dev), k)
+    _close(got.cpu().permute(1, 0, 2), y.detach())
+    dw, db = torch.zeros(C, 1, k, device=dev), torch.zeros(C, device=dev)
+    dx = ops.dwconv_bwd(_cbt(x.detach()).to(dev), w.detach().to(dev), _cbt(dy).to(dev), dw, db, k)
+    _close(dx.cpu().permute(1, 0, 2), x.grad)
+    _close(dw, w.grad)
+    _close(db, b.grad)
+
+
+@pytest.mark.parametrize("D,H,B,T", [(64, 2, 3, 29), (256, 2, 2, 70)])
+def test_attention_training_forward_backward(cuda_device, D, H, B, T):
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(D + T)
+    qkv = torch.randn(B, 3 * D, T, generator=g, requires_grad=True)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    lens[0] = T
+    dh = D // H
+    q, k, v = [t.reshape(B, H, dh, T) for t in qkv.split(D, dim=1)]
+    s = torch.einsum("bhdq,bhdk->bhqk", q, k) * dh ** -0.5
+    s = s.masked_fill((torch.arange(T)[None, :] >= lens[:, None])[:, None, None, :], float("-inf"))
+    o = torch.einsum("bhqk,bhdk->bhdq", torch.softmax(s, -1), v).reshape(B, D, T)
+    do = torch.randn(B, D, T, generator=g)
+    o.backward(do)
+    dev = cuda_device
+    x = _cbt(qkv.detach()).to(dev)
+    lens32 = lens.to(dev, torch.int32)
+    out, saved = ops.attention_train_fwd(x, lens32, H)
+    _close(out.cpu().permute(1, 0, 2), o.detach())
+    # the inference kernel (fused, fp32 matrix cores) computes the same thing
+    from everyvoice_amd import _lib
+    fused = torch.empty_like(out)
+    _lib.check(_lib.load().evmi_attention_cbt_f32(x.data_ptr(), lens32.data_ptr(), fused.data_ptr(), B, T, D, H, torch.cuda.current_stream().cuda_stream), "attention")
+    _close(fused.cpu(), out.cpu())
+    dqkv = ops.attention_train_bwd(x, saved, _cbt(do).to(dev), H)
+    _close(dqkv.cpu().permute(1, 0, 2), qkv.grad)
+
+
+def test_attention_dropout_mask_is_consistent(cuda_device):
+    """With p > 0: kept probabilities are scaled by 1/(1-p), the kept fraction is about 1-p, and the backward uses the same
+    mask (checked through linearity: <dqkv, e> equals the directional derivative of <out, dout>)."""
+    from everyvoice_amd.train import ops
+
+    D, H, B, T, p = 64, 2, 2, 48, 0.3
+    g = torch.Generator().manual_seed(3)
+    dev = cuda_device
+    x = torch.randn(3 * D, B, T, generator=g).to(dev)
+    lens32 = torch.tensor([T, T - 7], dtype=torch.int32, device=dev)
+    out, saved = ops.attention_train_fwd(x, lens32, H, p, seed=99)
+    P, Pd = saved[0]
+    kept = (Pd > 0).float().sum() / (P > 0).float().sum()
+    assert abs(float(kept) - (1 - p)) < 0.03
+    sel = Pd > 0
+    _close(Pd[sel].cpu(), (P[sel] / (1 - p)).cpu(), 1e-6)
+    out2, _ = ops.attention_train_fwd(x, lens32, H, p, seed=99)
+    assert torch.equal(out, out2)  # same seed, same mask
+    do = torch.randn(D, B, T, generator=g).to(dev)
+    dqkv = ops.attention_train_bwd(x, saved, do, H, p, seed=99)
+    e = torch.randn(3 * D, B, T, generator=g).to(dev)
+    eps = 1e-2
+    op, _ = ops.attention_train_fwd(x + eps * e, lens32, H, p, seed=99)
+    om, _ = ops.attention_train_fwd(x - eps * e, lens32, H, p, seed=99)
+    fd = float(((op - om) * do).double().sum()) / (2 * eps)
+    an = float((dqkv * e).double().sum())
+    assert abs(fd - an) <= 2e-2 * max(1.0, abs(an)), (fd, an)
+
+
+def test_glu_silu_relu_dropout(cuda_device):
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(0)
+    dev = cuda_device
+    p = torch.randn(2 * 16, 3, 21, generator=g, requires_grad=True)
+    dy = torch.randn(16, 3, 21, generator=g)
+    F.glu(p, dim=0).backward(dy)
+    _close(ops.glu_bwd(p.detach().to(dev), dy.to(dev)), p.grad)
+    z = torch.randn(1000, generator=g, requires_grad=True)
+    dz = torch.randn(1000, generator=g)
+    F.silu(z).backward(dz)
+    _close(ops.elementwise(ops.EW_SILU_BWD, dz.to(dev), z.detach().to(dev)), z.grad)
+    x = torch.randn(100000, generator=g).to(dev)
+    y = ops.dropout(x, 0.25, 7)
+    kept = y != 0
+    assert abs(float(kept.float().mean()) - 0.75) < 0.01
+    _close(y[kept].cpu(), (x[kept] / 0.75).cpu(), 1e-6)
+    assert torch.equal(y, ops.dropout(x, 0.25, 7)) and not torch.equal(y, ops.dropout(x, 0.25, 8))
+
+
+# ---- the whole step ------------------------------------------------------------------------------------------------------
+def _ref_cfg(dropout=0.0, speakers=0):
+    c = FastSpeech2ConfigRef.small()
+    c.encoder.dropout = c.decoder.dropout = dropout
+    c.duration.dropout = c.pitch.dropout = c.energy.dropout = dropout
+    c.n_speakers = speakers
+    return c
+
+
+def _trainer(ref_cfg, cuda_device, seed=11, **kw):
+    from everyvoice_amd.train.fs2 import FastSpeech2Trainer
+    from tests.test_gpu_fs2 import _product_config
+
+    cfg = _product_config(ref_cfg)
+    for enc, rc in ((cfg.encoder, ref_cfg.encoder), (cfg.decoder, ref_cfg.decoder)):
+        enc.dropout = rc.dropout
+    for name in ("duration", "pitch", "energy"):
+        getattr(cfg.variance_predictors, name).dropout = getattr(ref_cfg, name).dropout
+    if ref_cfg.n_speakers:
+        cfg.multispeaker, cfg.n_speakers = True, ref_cfg.n_speakers
+    tr = FastSpeech2Trainer(cfg, device=cuda_device, seed=seed, **kw)
+    g = torch.Generator().manual_seed(seed)
+    sd = tr.state_dict()
+    for n in tr.params.names():  # livelier than the default init: biases, norms and weight-norm gains that matter
+        if n.endswith("bias"):
+            sd[n] = torch.randn(sd[n].shape, generator=g) * 0.05
+        elif n.endswith("weight_g") or (sd[n].dim() == 1 and n.endswith(".weight")):
+            sd[n] = torch.rand(sd[n].shape, generator=g) * 0.5 + 0.75
+    tr.load_state_dict(sd)
+    return tr
+
+
+def _train_batch(ref_cfg, B, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(max(1, L // 2), L + 1, (B,), generator=g)
+    lens[0] = L
+    pad = torch.arange(L)[None] >= lens[:, None]
+    ids = torch.randint(1, ref_cfg.n_symbols, (B, L), generator=g).masked_fill(pad, 0)
+    durs = torch.randint(0, 5, (B, L), generator=g)
+    durs[:, 0] += 1
+    durs = durs.masked_fill(pad, 0)
+    mel_lens = durs.sum(1)
+    T = int(mel_lens.max())
+    mel = torch.randn(B, T, ref_cfg.n_mels, generator=g)
+    mel = mel.masked_fill((torch.arange(T)[None] >= mel_lens[:, None])[..., None], 0.0)
+    batch = dict(ids=ids, lens=lens, durations=durs, mel=mel, pitch=torch.randn(B, L, generator=g), energy=torch.randn(B, L, generator=g))
+    if ref_cfg.n_speakers:
+        batch["speakers"] = torch.randint(0, ref_cfg.n_speakers, (B,), generator=g)
+    return batch
+
+
+def _oracle_from(tr, ref_cfg):
+    ref = FastSpeech2Ref(ref_cfg).train()
+    sd = {k: v.detach().cpu() for k, v in tr.state_dict().items()}
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not missing and not unexpected, (missing, unexpected)
+    return ref
+
+
+@pytest.mark.parametrize("B,L,speakers", [(3, 14, 0), (2, 23, 3)])
+def test_training_step_losses_gradients_and_update(cuda_device, B, L, speakers):
+    ref_cfg = _ref_cfg(0.0, speakers)
+    tr = _trainer(ref_cfg, cuda_device)
+    batch = _train_batch(ref_cfg, B, L, seed=L)
+    ref = _oracle_from(tr, ref_cfg)
+    want = training_losses_ref(ref, batch)
+    want["total"].backward()
+    got = tr.forward_backward(batch)
+    for k, v in want.items():
+        assert float(got[k]) == pytest.approx(float(v), rel=2e-4), k
+    grads = tr.params.gradients()
+    named = dict(ref.named_parameters())
+    assert set(grads) == set(named)
+    for name, p in named.items():
+        want_g = p.grad if p.grad is not None else torch.zeros_like(p)
+        _l2close(grads[name], want_g, 2e-3, name)
+    for name, buf in ref.named_buffers():
+        if name.endswith("running_mean") or name.endswith("running_var"):
+            _close(tr.state_dict()[name], buf, 1e-4)
+
+    # one optimiser step: clip_grad_norm_(1.0) + AdamW at the Noam learning rate of step 1
+    o = tr.training.optimizer
+    # a bias in front of BatchNorm has a zero gradient in exact arithmetic: Adam turns the rounding noise into +-lr steps
+    noise = {n for n, p in named.items() if p.grad is None or float(p.grad.norm()) < 1e-5 * p.numel() ** 0.5}
+    assert all(n.endswith(".bias") for n in noise) and len(noise) <= 2 * ref_cfg.encoder.layers + ref_cfg.postnet_layers
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), tr.training.gradient_clip_val)
+    opt = torch.optim.AdamW(ref.parameters(), lr=tr.learning_rate(1), betas=tuple(o.betas), eps=o.eps, weight_decay=o.weight_decay)
+    opt.step()
+    tr2 = _trainer(ref_cfg, cuda_device)
+    tr2.training_step(batch)
+    sd = tr2.state_dict()
+    for name, p in ref.named_parameters():
+        if name in noise:
+            continue
+        # Adam's first step moves every entry by ~lr * sign(g): single entries whose gradient is numerically zero may differ in sign
+        diff = (sd[name].cpu() - p.detach()).abs()
+        assert float((diff > 1e-6 + 2e-3 * tr.learning_rate(1)).float().mean()) < 0.01, name
+
+
+def test_noam_schedule(cuda_device):
+    tr = _trainer(_ref_cfg(), cuda_device)
+    o = tr.training.optimizer
+    assert tr.learning_rate(o.warmup_steps) == pytest.approx(o.learning_rate)
+    assert tr.learning_rate(1) == pytest.approx(o.learning_rate / o.warmup_steps)
+    assert tr.learning_rate(4 * o.warmup_steps) == pytest.approx(o.learning_rate / 2)
+
+
+def test_training_reduces_the_loss_and_inference_loads_the_result(cuda_device):
+    from everyvoice_amd.fs2 import FastSpeech2
+    from everyvoice_amd.train.fs2 import FastSpeech2TrainingConfig, NoamOptimizerConfig
+
+    ref_cfg = _ref_cfg(0.1)  # with dropout on
+    tr = _trainer(ref_cfg, cuda_device, training=FastSpeech2TrainingConfig(optimizer=NoamOptimizerConfig(learning_rate=2e-3, warmup_steps=5)))
+    batch = _train_batch(ref_cfg, 4, 16, seed=2)
+    first = float(tr.training_step(batch)["total"])
+    for _ in range(25):
+        last = float(tr.training_step(batch)["total"])
+    assert math.isfinite(last) and last < 0.7 * first, (first, last)
+    model = FastSpeech2(tr.config, device=cuda_device).load_state_dict(tr.state_dict())
+    mel, post, dur, pitch, energy, mel_lens = model(batch["ids"], batch["lens"], durations=batch["durations"])
+    assert torch.isfinite(post).all() and post.shape[0] == 4 and int(mel_lens.max()) == post.shape[1]
+    # the same state in the oracle (eval mode: running statistics) gives the same mel
+    ref = FastSpeech2Ref(ref_cfg).eval()
+    ref.load_state_dict({k: v.cpu() for k, v in tr.state_dict().items()}, strict=False)
+    want = ref(batch["ids"], batch["lens"], durations=batch["durations"])
+    _close(post, want[1], 5e-4)
+
+
+def test_checkpoint_resume_is_bitwise(cuda_device):
+    ref_cfg = _ref_cfg(0.1)
+    batch = _train_batch(ref_cfg, 2, 12, seed=4)
+    a = _trainer(ref_cfg, cuda_device)
+    a.training_step(batch)
+    ck = a.checkpoint()
+    assert ck["model_info"] == {"name": "FastSpeech2", "version": "1.0"}
+    import json
+    json.dumps(ck["hyper_parameters"])  # JSON-only, path-free
+    a.training_step(batch)
+    b = _trainer(ref_cfg, cuda_device).load_checkpoint(ck)
+    b.training_step(batch)
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:  # every reduction of the step has a fixed order (no atomics): resuming is bitwise
+        assert torch.equal(sa[k], sb[k]), k
+    with pytest.raises(TypeError, match="Wrong model type"):
+        b.load_checkpoint({"model_info": {"name": "HiFiGAN"}})
