@@ -107,7 +107,8 @@ SYMBOLS = {
     "evmi_layernorm_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_longlong, C.c_int, C.c_longlong, C.c_float, C.c_int, C.c_void_p]),
     "evmi_batchnorm_fwd_cbt_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "evmi_batchnorm_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
-    "evmi_dwconv1d_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_void_p]),
+    "evmi_dwconv1d_bwd_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 3),
+    "evmi_dwconv1d_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_longlong] + [C.c_int] * 5 + [C.c_void_p]),
     "evmi_softmax_rows_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_softmax_bwd_rows_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_glu_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),

@@ -38,82 +38,108 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // ---- LayerNorm backward --------------------------------------------------------------------------------------------
-// Same decomposition as the forward (64 columns x 4 channel slices).  part[blk][0][c] = sum_cols dy * xhat,
-// part[blk][1][c] = sum_cols dy for the workgroup's 64 columns.
-template <int CPT>
-__global__ __launch_bounds__(256) void layernorm_bwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                               const float* __restrict__ dy, float* __restrict__ dx,
-                                                               float* __restrict__ part, int C, long long N, float eps,
-                                                               int accumulate) {
-  __shared__ float red[4][4][64];
+// Workgroup = 64 columns x SL channel slices (one wave per slice): every thread keeps x and dy of its slice of one
+// column in registers (one read of each, one write of dx).  part[blk][0][c] = sum over the 64 columns of dy * xhat,
+// part[blk][1][c] = sum of dy: reduced afterwards in a fixed order.  SL = 8 keeps the slices at 32 channels for
+// C = 256 (two 32-float register arrays: no spills, two workgroups per CU).
+template <int CPT, int SL>
+__global__ __launch_bounds__(64 * SL) void layernorm_bwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ dy, float* __restrict__ dx,
+                                                                   float* __restrict__ part, int C, long long N, float eps,
+                                                                   int accumulate) {
+  __shared__ float red[4][SL][64];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const long long n = (long long)blockIdx.x * 64 + lane;
   const bool live = n < N;
-  const int per = (C + 3) >> 2, c0 = slice * per, c1 = min(C, c0 + per);
-  float v[CPT], g[CPT];
+  const int per = (C + SL - 1) / SL, c0 = slice * per, c1 = min(C, c0 + per);
+  float v[CPT], d[CPT];
   float s = 0.f;
+  const float* xp = x + (long long)c0 * N + n;
+  const float* dp = dy + (long long)c0 * N + n;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = c0 + i;
-    v[i] = (live && c < c1) ? x[(long long)c * N + n] : 0.f;
+    const bool on = live && c0 + i < c1;
+    v[i] = on ? xp[(long long)i * N] : 0.f;
+    d[i] = on ? dp[(long long)i * N] : 0.f;
     s += v[i];
   }
   red[0][slice][lane] = s;
   __syncthreads();
-  const float mean = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
-  float q = 0.f;
+  float mean = 0.f;
+#pragma unroll
+  for (int q = 0; q < SL; ++q) mean += red[0][q][lane];
+  mean /= (float)C;
+  float qs = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const float d = (c0 + i < c1) ? v[i] - mean : 0.f;
-    q = fmaf(d, d, q);
+    const float t = (c0 + i < c1) ? v[i] - mean : 0.f;
+    qs = fmaf(t, t, qs);
   }
-  red[1][slice][lane] = q;
+  red[1][slice][lane] = qs;
   __syncthreads();
-  const float var = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
-  const float rstd = 1.f / sqrtf(var + eps);
+  float var = 0.f;
+#pragma unroll
+  for (int q = 0; q < SL; ++q) var += red[1][q][lane];
+  const float rstd = 1.f / sqrtf(var / (float)C + eps);
   float s1 = 0.f, s2 = 0.f;
   float* pg = part + (long long)blockIdx.x * 2 * C;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     const int c = c0 + i;
     const bool on = c < c1;
-    const float d = (live && on) ? dy[(long long)c * N + n] : 0.f;
     v[i] = on ? (v[i] - mean) * rstd : 0.f;  // xhat
-    g[i] = on ? d * gamma[c] : 0.f;
-    s1 += g[i];
-    s2 = fmaf(g[i], v[i], s2);
-    const float a = wave_sum(d * v[i]), b = wave_sum(d);
+    const float a = wave_sum(d[i] * v[i]), b = wave_sum(d[i]);
     if (on && lane == 0) {
       pg[c] = a;
       pg[C + c] = b;
     }
+    d[i] = on ? d[i] * gamma[c] : 0.f;  // dy * gamma
+    s1 += d[i];
+    s2 = fmaf(d[i], v[i], s2);
   }
   red[2][slice][lane] = s1;
   red[3][slice][lane] = s2;
   __syncthreads();
-  const float m1 = (red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane]) / (float)C;
-  const float m2 = (red[3][0][lane] + red[3][1][lane] + red[3][2][lane] + red[3][3][lane]) / (float)C;
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < SL; ++q) {
+    m1 += red[2][q][lane];
+    m2 += red[3][q][lane];
+  }
+  m1 /= (float)C;
+  m2 /= (float)C;
   if (!live) return;
+  float* op = dx + (long long)c0 * N + n;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const int c = c0 + i;
-    if (c < c1) {
-      const float r = rstd * (g[i] - m1 - v[i] * m2);
-      float* dst = dx + (long long)c * N + n;
+    if (c0 + i < c1) {
+      const float r = rstd * (d[i] - m1 - v[i] * m2);
+      float* dst = op + (long long)i * N;
       *dst = accumulate ? *dst + r : r;
     }
   }
 }
 
-// out0[c] += sum_blk part[blk][0][c]; out1[c] += sum_blk part[blk][1][c]   (fixed order)
-__global__ void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out0, float* __restrict__ out1, int C,
-                                       int nblk) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C) return;
+// out0[c] += sum_blk part[blk][0][c]; out1[c] += sum_blk part[blk][1][c]: 16 channels x 16 segments of the partial list per
+// workgroup, segment sums combined in a fixed order
+__global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ part, float* __restrict__ out0,
+                                                             float* __restrict__ out1, int C, int nblk) {
+  __shared__ double sh[16][17];
+  const int ch = threadIdx.x & 15, seg = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + ch;
+  const int per = (nblk + 15) / 16;
   double acc = 0.0;
-  for (int b = 0; b < nblk; ++b) acc += (double)part[(long long)b * 2 * C + i];
-  float* dst = i < C ? out0 + i : out1 + (i - C);
-  *dst += (float)acc;
+  if (i < 2 * C)
+    for (int b = seg * per; b < min(nblk, (seg + 1) * per); ++b) acc += (double)part[(long long)b * 2 * C + i];
+  sh[seg][ch] = acc;
+  __syncthreads();
+  if (seg == 0 && i < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][ch];
+    float* dst = i < C ? out0 + i : out1 + (i - C);
+    *dst += (float)t;
+  }
 }
 
 // ---- BatchNorm1d, training mode --------------------------------------------------------------------------------------
@@ -217,38 +243,48 @@ __global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* 
 }
 
 constexpr int DW_KMAX = 32;
-// dw[c][j] += sum_{b,t} x[c][b][t + j - pad] * dy[c][b][t] ; db[c] += sum dy : one workgroup per channel
-__global__ __launch_bounds__(256) void dwconv_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           float* __restrict__ dw, float* __restrict__ db, int B, int T, int k,
-                                                           int pad) {
+// part[c][b][j] = sum_t x[c][b][t + j - pad] * dy[c][b][t] (j < k), part[c][b][k] = sum_t dy : one workgroup per (c, b) row
+__global__ __launch_bounds__(256) void dwconv_bwd_dw_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                   float* __restrict__ part, int B, int T, int k, int pad) {
   __shared__ double sh[4];
-  const int c = blockIdx.x;
-  const long long N = (long long)B * T;
-  const float* xr = x + (long long)c * N;
-  const float* dr = dy + (long long)c * N;
+  const int b = blockIdx.x, c = blockIdx.y;
+  const float* xr = x + ((long long)c * B + b) * T;
+  const float* dr = dy + ((long long)c * B + b) * T;
   float acc[DW_KMAX];
 #pragma unroll
   for (int j = 0; j < DW_KMAX; ++j) acc[j] = 0.f;
   float sb = 0.f;
-  for (long long i = threadIdx.x; i < N; i += 256) {
-    const int t = (int)(i % T);
-    const float d = dr[i];
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float d = dr[t];
     sb += d;
 #pragma unroll
     for (int j = 0; j < DW_KMAX; ++j) {
       const int ti = t + j - pad;
-      if (j < k && ti >= 0 && ti < T) acc[j] = fmaf(xr[i - t + ti], d, acc[j]);
+      if (j < k && ti >= 0 && ti < T) acc[j] = fmaf(xr[ti], d, acc[j]);
     }
   }
+  float* pr = part + ((long long)c * B + b) * (k + 1);
 #pragma unroll
   for (int j = 0; j < DW_KMAX; ++j) {
     if (j < k) {
       const double tot = block_sum((double)acc[j], sh);
-      if (threadIdx.x == 0) dw[c * k + j] += (float)tot;
+      if (threadIdx.x == 0) pr[j] = (float)tot;
     }
   }
   const double tb = block_sum((double)sb, sh);
-  if (threadIdx.x == 0 && db) db[c] += (float)tb;
+  if (threadIdx.x == 0) pr[k] = (float)tb;
+}
+
+// dw[c][j] += sum_b part[c][b][j] ; db[c] += sum_b part[c][b][k]   (fixed order)
+__global__ void dwconv_bwd_dw_final_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int C, int B,
+                                           int k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * (k + 1)) return;
+  const int c = i / (k + 1), j = i - c * (k + 1);
+  double acc = 0.0;
+  for (int b = 0; b < B; ++b) acc += (double)part[((long long)c * B + b) * (k + 1) + j];
+  if (j < k) dw[c * k + j] += (float)acc;
+  else if (db) db[c] += (float)acc;
 }
 
 // ---- attention rows ------------------------------------------------------------------------------------------------
@@ -319,22 +355,35 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 // ---- embeddings, backward ------------------------------------------------------------------------------------------
 // One thread per (table row, channel) walks the tokens in order and adds the ones that map to its row: a fixed order
 // of additions (bitwise reproducible, unlike a scatter with atomics); the row test is wave-uniform (scalar loads).
-// mode 0: text embedding   row = ids[b][l] for l < lens[b], ids != skip_id
-// mode 2: variance buckets row = precomputed bucket index of every position (the forward adds everywhere, pads included)
+// text embedding: row = ids[b][l] for l < lens[b], ids != skip_id;  variance buckets: ids = precomputed bucket index of
+// every position, lens = NULL (the forward adds everywhere, pads included).  Row indices are staged through LDS.
+constexpr int TABLE_CHUNK = 4096;
 __global__ __launch_bounds__(256) void fs2_table_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ ids,
-                                                           const int* __restrict__ lens, const float* __restrict__ values,
-                                                           const float* __restrict__ bins, float* __restrict__ dtable, int n_bins,
-                                                           int B, int L, int D, int skip_id, float control, int mode) {
+                                                           const int* __restrict__ lens, float* __restrict__ dtable, int B, int L,
+                                                           int D, int skip_id) {
+  __shared__ int sid[TABLE_CHUNK];
   const int r = blockIdx.x;
   const int c = blockIdx.y * 256 + threadIdx.x;
-  const long long N = (long long)B * L;
+  const int N = B * L;
   const float* row = dx + (long long)(c < D ? c : 0) * N;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const int len = mode == 0 ? min(lens[b], L) : L;
-    for (int l = 0; l < len; ++l) {
-      const int id = ids[b * L + l];
-      if (id == r && id != skip_id) acc += row[(long long)b * L + l];
+  for (int base = 0; base < N; base += TABLE_CHUNK) {
+    const int cnt = min(TABLE_CHUNK, N - base);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+      const int n = base + i, b = n / L, l = n - b * L;
+      const int id = ids[n];
+      sid[i] = (lens && l >= lens[b]) || id == skip_id ? -1 : id;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < cnt; i0 += 64) {  // 64 tokens per ballot; matches are added in token order (wave-uniform loop)
+      unsigned long long m = __ballot(i0 + lane < cnt && sid[i0 + lane] == r);
+      while (m) {
+        const int j = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        acc += row[base + i0 + j];
+      }
     }
   }
   if (c < D) dtable[(long long)r * D + c] += acc;
@@ -401,11 +450,10 @@ int evmi_layernorm_bwd_cbt_f32(const float* x, const float* gamma, const float* 
   if (ws_elems < evmi_layernorm_bwd_cbt_f32_ws_elems(C, n_cols)) return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
   const unsigned nblk = (unsigned)((n_cols + 63) / 64);
-  const int per = (C + 3) / 4;
-  if (per <= 16) hipLaunchKernelGGL(layernorm_bwd_cbt_kernel<16>, dim3(nblk), dim3(256), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
-  else hipLaunchKernelGGL(layernorm_bwd_cbt_kernel<64>, dim3(nblk), dim3(256), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
+  if (C <= 64) hipLaunchKernelGGL((layernorm_bwd_cbt_kernel<16, 4>), dim3(nblk), dim3(256), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
+  else hipLaunchKernelGGL((layernorm_bwd_cbt_kernel<32, 8>), dim3(nblk), dim3(512), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
   EVMI_LAUNCH_CHECK("layernorm_bwd_cbt");
-  hipLaunchKernelGGL(colsum_partials_kernel, dim3(blocks_for(2 * C)), dim3(256), 0, s, ws, dgamma, dbeta, C, (int)nblk);
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, dgamma, dbeta, C, (int)nblk);
   EVMI_LAUNCH_CHECK("colsum_partials");
   return EVMI_OK;
 }
@@ -434,8 +482,10 @@ int evmi_batchnorm_bwd_cbt_f32(const float* x, const float* gamma, const float* 
   return EVMI_OK;
 }
 
-int evmi_dwconv1d_bwd_cbt_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int C, int B, int T,
-                              int k, int pad, void* stream) {
+long long evmi_dwconv1d_bwd_cbt_f32_ws_elems(int C, int B, int k) { return (long long)C * B * (k + 1); }
+
+int evmi_dwconv1d_bwd_cbt_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, float* ws,
+                              long long ws_elems, int C, int B, int T, int k, int pad, void* stream) {
   if (!x || !w || !dy) return fail(EVMI_ERR_INVALID_ARG, "dwconv_bwd: null pointer");
   if (C < 1 || B < 1 || T < 1 || k < 1 || k > DW_KMAX) return fail(EVMI_ERR_INVALID_ARG, "dwconv_bwd: 1 <= k <= 32 and a non-empty input required");
   hipStream_t s = (hipStream_t)stream;
@@ -444,8 +494,11 @@ int evmi_dwconv1d_bwd_cbt_f32(const float* x, const float* w, const float* dy, f
     EVMI_LAUNCH_CHECK("dwconv_bwd_dx");
   }
   if (dw) {
-    hipLaunchKernelGGL(dwconv_bwd_dw_kernel, dim3(C), dim3(256), 0, s, x, dy, dw, db, B, T, k, pad);
-    EVMI_LAUNCH_CHECK("dwconv_bwd_dw");
+    if (!ws || ws_elems < evmi_dwconv1d_bwd_cbt_f32_ws_elems(C, B, k)) return fail(EVMI_ERR_INVALID_ARG, "dwconv_bwd: workspace missing or too small");
+    hipLaunchKernelGGL(dwconv_bwd_dw_partial_kernel, dim3(B, C), dim3(256), 0, s, x, dy, ws, B, T, k, pad);
+    EVMI_LAUNCH_CHECK("dwconv_bwd_dw_partial");
+    hipLaunchKernelGGL(dwconv_bwd_dw_final_kernel, dim3(blocks_for((long long)C * (k + 1))), dim3(256), 0, s, ws, dw, db, C, B, k);
+    EVMI_LAUNCH_CHECK("dwconv_bwd_dw_final");
   }
   return EVMI_OK;
 }
@@ -488,8 +541,8 @@ int evmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned lo
 int evmi_fs2_embed_bwd_f32(const float* dx, const int* ids, const int* lens, float* dtable, int rows, int B, int L, int D, int skip_id,
                            void* stream) {
   if (!dx || !ids || !lens || !dtable || rows < 1 || B < 1 || L < 1 || D < 1) return fail(EVMI_ERR_INVALID_ARG, "fs2_embed_bwd: bad arguments");
-  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(rows, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, ids, lens, nullptr, nullptr,
-                     dtable, 0, B, L, D, skip_id, 1.f, 0);
+  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(rows, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, ids, lens, dtable, B, L, D,
+                     skip_id);
   EVMI_LAUNCH_CHECK("fs2_embed_bwd");
   return EVMI_OK;
 }
@@ -502,8 +555,7 @@ int evmi_fs2_bucket_embed_bwd_f32(const float* dx, const float* values, const fl
   hipLaunchKernelGGL(fs2_bucket_index_kernel, dim3(blocks_for((long long)B * L)), dim3(256), 0, s, values, bins, idx_ws, B * L, n_bins, control);
   EVMI_LAUNCH_CHECK("fs2_bucket_index");
   // the text-embedding walk over precomputed indices: every position counts (lens = NULL -> full rows), no skipped id
-  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(n_bins, (D + 255) / 256), dim3(256), 0, s, dx, idx_ws, nullptr, nullptr, nullptr, dtable, 0, B,
-                     L, D, -1, 1.f, 2);
+  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(n_bins, (D + 255) / 256), dim3(256), 0, s, dx, idx_ws, nullptr, dtable, B, L, D, -1);
   EVMI_LAUNCH_CHECK("fs2_bucket_embed_bwd");
   return EVMI_OK;
 }

@@ -425,8 +425,11 @@ def dwconv_fwd(x, w, bias, k):
 def dwconv_bwd(x, w, dy, dw, db, k, need_dx=True):
     C, B, T = x.shape
     dx = torch.empty_like(x) if need_dx else None
-    _chk(_lib.load().evmi_dwconv1d_bwd_cbt_f32(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _lib.ptr(dx), dw.data_ptr(), db.data_ptr(), C, B, T, k,
-                                               (k - 1) // 2, _s(x)), "evmi_dwconv1d_bwd_cbt_f32")
+    lib = _lib.load()
+    n = lib.evmi_dwconv1d_bwd_cbt_f32_ws_elems(C, B, k)
+    ws = WS.get("dw_bwd", n, x.device)
+    _chk(lib.evmi_dwconv1d_bwd_cbt_f32(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _lib.ptr(dx), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, C, B, T, k,
+                                       (k - 1) // 2, _s(x)), "evmi_dwconv1d_bwd_cbt_f32")
     return dx
 
 

@@ -376,9 +376,12 @@ int evmi_batchnorm_fwd_cbt_f32(const float* x_dev, const float* gamma_dev, const
 int evmi_batchnorm_bwd_cbt_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, const float* mean_dev,
                                const float* rstd_dev, const float* dy_dev, float* dx_dev, float* dgamma_dev,
                                float* dbeta_dev, int C, long long n_cols, int act, void* stream);
-/* Depthwise convolution backward: dx (NULL = skip), dw [C][k] += ..., db [C] += ... (dw NULL = skip both). */
+/* Depthwise convolution backward: dx (NULL = skip), dw [C][k] += ..., db [C] += ... (dw NULL = skip both; otherwise
+ * ws: evmi_dwconv1d_bwd_cbt_f32_ws_elems floats of per-(channel, item) partial sums, reduced in a fixed order). */
+long long evmi_dwconv1d_bwd_cbt_f32_ws_elems(int C, int B, int k);
 int evmi_dwconv1d_bwd_cbt_f32(const float* x_dev, const float* w_dev, const float* dy_dev, float* dx_dev, float* dw_dev,
-                              float* db_dev, int C, int B, int T, int k, int pad, void* stream);
+                              float* db_dev, float* ws_dev, long long ws_elems, int C, int B, int T, int k, int pad,
+                              void* stream);
 /* scores [B][Tq][Tk] -> softmax over the keys tk < lens[b] in place (0 beyond); with p > 0 also
  * dropped = dropout(probabilities, p) from the counter-based generator keyed by `seed`. */
 int evmi_softmax_rows_f32(float* scores_dev, float* dropped_dev, const int* lens_dev, int B, int Tq, int Tk, float p,

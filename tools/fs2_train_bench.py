@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""FastSpeech2 training on one GPU: BASELINE config 3 (LJSpeech-shaped synthetic batch of 32, default model), steps / s."""
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import torch  # noqa: E402
+
+from fs2_bench import forward_flops, synthetic_batch  # noqa: E402
+
+
+def training_batch(B=32, seed=1234, n_mels=80):
+    ids, lens, durs, T_i = synthetic_batch(B, seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    T = int(T_i.max())
+    mel = torch.randn(B, T, n_mels, generator=g).masked_fill((torch.arange(T)[None] >= T_i[:, None])[..., None], 0.0)
+    L = ids.shape[1]
+    return dict(ids=ids, lens=lens, durations=durs, mel=mel, pitch=torch.randn(B, L, generator=g), energy=torch.randn(B, L, generator=g)), T_i
+
+
+def main():
+    from everyvoice_amd.train.fs2 import FastSpeech2Trainer
+
+    dev = torch.device("cuda:0")
+    B = int(os.environ.get("EVMI_FS2_B", "32"))
+    tr = FastSpeech2Trainer(device=dev)
+    batch, T_i = training_batch(B)
+    print(f"parameters {tr.params.numel():,}")
+    for _ in range(2):
+        losses = tr.training_step(batch)
+    torch.cuda.synchronize()
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    t0 = time.perf_counter()
+    for _ in range(n):
+        losses = tr.training_step(batch)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    fl = 3.0 * forward_flops(batch["lens"], T_i, batch["ids"].shape[1], int(T_i.max()), B)  # backward = 2 x forward (dx and dw of every product)
+    print(f"step {dt*1e3:.1f} ms -> {1/dt:.2f} steps/s, {int(T_i.sum())/dt/1e6:.3f} M mel frames/s; algorithmic {fl/1e12:.2f} TFLOP per step -> "
+          f"{fl/dt/1e12:.1f} TFLOP/s; losses { {k: round(float(v), 4) for k, v in losses.items()} }")
+
+
+if __name__ == "__main__":
+    main()
