@@ -337,6 +337,68 @@ def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
             "realtime_factor": round(world * frames * 256 / 22050.0 * steps / elapsed, 1)}
 
 
+def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
+    """BASELINE config 3: FastSpeech2 feature-prediction training, LJSpeech-shaped synthetic batch of 32 per GPU, default model
+    (17.7 M parameters), teacher-forced step = forward + 5 losses + backward + clipped Noam AdamW; data parallel with one RCCL
+    all-reduce of the flat gradient buffer when N > 1.  fp32 storage and fp32 matrix-core arithmetic (>= the bf16 the config
+    names).  Algorithmic FLOPs = 3 x the forward's (dx and dw of every product)."""
+    import torch
+
+    from everyvoice_amd.train.fs2 import FastSpeech2Trainer
+    sys.path.insert(0, str(ROOT / "tools"))
+    from fs2_bench import forward_flops
+    from fs2_train_bench import training_batch
+
+    tr = FastSpeech2Trainer(device=dev, process_group=True if use_dist else None)
+    batch, t_i = training_batch(32, 1234 + rank)
+    out = {}
+
+    def step():
+        out["losses"] = tr.training_step(batch)
+
+    steps, warmup = 10, 3
+    elapsed = timed_region(step, steps, warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    flops = 3.0 * forward_flops(batch["lens"], t_i, int(batch["ids"].shape[1]), int(t_i.max()), 32)
+    tflops = flops * steps / elapsed / 1e12
+    return {"metric": "fastspeech2_train_steps_per_sec_bs32", "value": round(steps / elapsed, 3), "unit": "steps/s",
+            "ms_per_step": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": warmup, "batch_per_gpu": 32, "global_batch": 32 * world,
+            "frames_per_sec": round(world * int(t_i.sum()) * steps / elapsed, 1), "scaling": "weak", "dtype": "f32",
+            "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient buffer)" if world > 1 else ""),
+            "params": tr.params.numel(), "last_losses": {k: round(float(v), 4) for k, v in out["losses"].items()},
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.0, "unit": "TFLOP/s", "frac": round(tflops / 157.0, 4),
+                         "traffic": None, "flop_per_step": flops, "scope": "whole step (forward + backward + optimiser)"}}
+
+
+def cpu_baseline_fs2_train(cores: int, batch: int = 8) -> dict:
+    import torch
+
+    from oracle.fs2_ref import FastSpeech2Ref, training_losses_ref
+    sys.path.insert(0, str(ROOT / "tools"))
+    from fs2_train_bench import training_batch
+
+    torch.manual_seed(1234)
+    torch.set_num_threads(cores)
+    ref = FastSpeech2Ref().train()
+    full, t_i = training_batch(32, 1234)
+    L = int(full["lens"][:batch].max())
+    b = {k: (v[:batch, :L] if v.dim() >= 2 and k != "mel" else v[:batch]) for k, v in full.items()}
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-4)
+
+    def step():
+        opt.zero_grad()
+        training_losses_ref(ref, b)["total"].backward()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    step()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch / 32.0 / dt, 4), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/fs2_ref.py training step (torch autograd + clipping + AdamW) on the first {batch} utterances of the bench batch, "
+                      f"{cores} threads: {dt:.2f} s; scaled to 32 utterances per step"}
+
+
 def main(argv=None) -> int:
     args = parse_args(argv)
     import torch
@@ -386,6 +448,7 @@ def main(argv=None) -> int:
     if not args.no_train:
         train = train_leg(args, dev, rank, world, use_dist, barrier, max_reduce)
     fs2 = None if args.no_fs2 else fs2_leg(args, dev, rank, world, barrier, max_reduce)
+    fs2_train = None if args.no_fs2 else fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce)
 
     result = None
     if rank == 0:
@@ -430,6 +493,7 @@ def main(argv=None) -> int:
             result["train"] = train
         if fs2 is not None:
             result["fs2"] = fs2
+            result["fs2_train"] = fs2_train
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_batch)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
@@ -438,6 +502,7 @@ def main(argv=None) -> int:
                 train["cpu_baseline"] = cpu_baseline_train(cores)
             if fs2 is not None:
                 fs2["cpu_baseline"] = cpu_baseline_fs2(cores)
+                fs2_train["cpu_baseline"] = cpu_baseline_fs2_train(cores)
     if use_dist:
         import torch.distributed as dist
 

@@ -333,3 +333,31 @@ def test_checkpoint_resume_is_bitwise(cuda_device):
         assert torch.equal(sa[k], sb[k]), k
     with pytest.raises(TypeError, match="Wrong model type"):
         b.load_checkpoint({"model_info": {"name": "HiFiGAN"}})
+
+
+def test_data_parallel_path_on_rccl_world_of_one(cuda_device):
+    """The N > 1 code path (RCCL all-reduce of the flat gradient buffer + 1/world scaling) on a one-rank "nccl" group equals the
+    single-GPU step bit for bit."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    ref_cfg = _ref_cfg(0.1)
+    batch = _train_batch(ref_cfg, 2, 12, seed=9)
+    plain = _trainer(ref_cfg, cuda_device)
+    plain.training_step(batch)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_device)
+    try:
+        dp = _trainer(ref_cfg, cuda_device, process_group=True)
+        dp.training_step(batch)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    sa, sb = plain.state_dict(), dp.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
