@@ -117,6 +117,10 @@ SYMBOLS = {
     "evmi_fs2_bucket_embed_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "evmi_fs2_item_embedding_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_length_regulate_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "evmi_forward_sum_grad_f32_ws_elems": (C.c_longlong, [C.c_int] * 3),
+    "evmi_forward_sum_grad_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_longlong] + [C.c_int] * 3 + [C.c_float, C.c_float, C.c_void_p]),
+    "evmi_align_attention_bwd_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
+    "evmi_align_qk_grad_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
     "evmi_dgrad_weights_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "evmi_gemm_batched_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
     "evmi_unfold_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),

@@ -25,9 +25,12 @@ __global__ void fs2_embed_kernel(const int* __restrict__ ids, const int* __restr
   const int l = (int)(i % L), b = (int)((i / L) % B), c = (int)(i / ((long long)L * B));
   float v = 0.f;
   if (l < lens[b]) {
-    const int h = D / 2;
-    const float ang = (float)l * inv_freq[c < h ? c : c - h];
-    v = table[(long long)ids[b * L + l] * D + c] + (c < h ? sinf(ang) : cosf(ang));
+    v = table[(long long)ids[b * L + l] * D + c];
+    if (inv_freq) {  // NULL: the bare symbol embedding (the aligner's keys)
+      const int h = D / 2;
+      const float ang = (float)l * inv_freq[c < h ? c : c - h];
+      v += c < h ? sinf(ang) : cosf(ang);
+    }
   }
   out[i] = v;
 }
@@ -257,7 +260,7 @@ extern "C" {
 
 int evmi_fs2_embed_f32(const int* ids_dev, const int* lens_dev, const float* table_dev, const float* inv_freq_dev, float* out_dev,
                        int B, int L, int D, void* stream) {
-  EVMI_NONNULL(ids_dev && lens_dev && table_dev && inv_freq_dev && out_dev, "fs2_embed");
+  EVMI_NONNULL(ids_dev && lens_dev && table_dev && out_dev, "fs2_embed");  // inv_freq NULL: no positional term
   if (B <= 0 || L <= 0 || D <= 0 || (D & 1)) return fail(EVMI_ERR_INVALID_ARG, "fs2_embed: shape");
   hipLaunchKernelGGL(fs2_embed_kernel, grid1d((long long)D * B * L), dim3(256), 0, (hipStream_t)stream, ids_dev, lens_dev, table_dev,
                      inv_freq_dev, out_dev, B, L, D);

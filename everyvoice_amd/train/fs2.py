@@ -51,6 +51,9 @@ class FastSpeech2TrainingConfig:
     pitch_loss_weight: float = 0.1
     energy_loss_weight: float = 0.1
     duration_loss_weight: float = 0.1
+    attn_ctc_loss_weight: float = 0.1
+    attn_bin_loss_weight: float = 0.1
+    attn_bin_loss_warmup_epochs: int = 100
     gradient_clip_val: float | None = 1.0
 
 
@@ -320,6 +323,42 @@ class _VariancePredictorT:
         return masked(tape, dense(tape, x, self.linear), lens32)
 
 
+class _AlignerT:
+    """The aligner of ``learn_alignment: true`` (Badlani et al. 2021; FastPitch ``ConvAttention``): keys = the symbol embeddings
+    through Conv(k=3) - ReLU - Conv(k=1), queries = the target mel through Conv(k=3) - ReLU - Conv(1) - ReLU - Conv(1), scores
+    ``-temperature * ||q - k||^2`` with the beta-binomial prior (A9) added in the log domain.  PARITY UNPINNED (absent submodule)."""
+
+    n_att, temperature = 80, 0.0005
+
+    def __init__(self, g: ParamGroup, d_text: int, n_mels: int):
+        name = lambda side, i: (f"attention.{side}_proj.{i}.conv.weight", f"attention.{side}_proj.{i}.conv.bias")
+        self.key = [Dense(g, *name("key", 0), d_text, 2 * d_text, 3), Dense(g, *name("key", 2), 2 * d_text, self.n_att, 1)]
+        self.query = [Dense(g, *name("query", 0), n_mels, 2 * n_mels, 3), Dense(g, *name("query", 2), 2 * n_mels, n_mels, 1),
+                      Dense(g, *name("query", 4), n_mels, self.n_att, 1)]
+
+    def forward(self, tape: Tape, text_emb: Var, mel: Var, prior, text_lens32, mel_lens32, n_frames: float, ctc_weight: float, bin_weight: float):
+        """-> (losses dict, hard durations [B, L] int32).  Records the backward of both losses into the projections / embedding."""
+        from ..heavy import maximum_path
+        k = dense(tape, dense(tape, text_emb, self.key[0], ops.ACT_RELU), self.key[1])
+        q = dense(tape, dense(tape, dense(tape, mel, self.query[0], ops.ACT_RELU), self.query[1], ops.ACT_RELU), self.query[2])
+        soft, logprob = ops.align_attention_fwd(q.data, k.data, prior, text_lens32, self.temperature)
+        hard, dur = maximum_path(ops.elementwise(16, soft), mel_lens32, text_lens32)  # monotonic search over log(soft): no gradient
+        ctc, dlogprob = ops.forward_sum_loss_and_grad(logprob, text_lens32, mel_lens32, ctc_weight)
+        from ..heavy import binarization_loss
+        losses = {"attn_ctc": ctc}
+        if bin_weight > 0.0:
+            losses["attn_bin"] = (binarization_loss(hard, soft) * bin_weight).reshape(1)
+
+        def bwd():
+            dq, dk = ops.align_attention_bwd(q.data, k.data, soft, logprob, prior, hard if bin_weight > 0.0 else None, dlogprob, text_lens32,
+                                             self.temperature, bin_weight / n_frames)
+            q.accumulate(dq)
+            k.accumulate(dk)
+
+        tape.record(bwd)
+        return losses, dur.to(torch.int32), hard
+
+
 class FastSpeech2Trainer:
     """``tr = FastSpeech2Trainer(config, stats); losses = tr.training_step(batch)``.
 
@@ -343,6 +382,7 @@ class FastSpeech2Trainer:
         g = self.params = ParamGroup(self.device)
         d = c.encoder.input_dim
         self.text_table = Table(g, "text_input_layer.weight", c.n_symbols, d)
+        self.aligner = _AlignerT(g, d, c.n_mels) if c.learn_alignment else None
         self.encoder = _ConformerT(g, c.encoder, "encoder")
         self.speaker_table = Table(g, "speaker_embedding.weight", max(1, c.n_speakers), d) if c.multispeaker else None
         self.language_table = Table(g, "language_embedding.weight", max(1, c.n_languages), d) if c.multilingual else None
@@ -367,6 +407,8 @@ class FastSpeech2Trainer:
         self._wn = [cv for vpred in (self.duration_predictor, self.pitch_predictor, self.energy_predictor) for cv in vpred.convs() if isinstance(cv, WNConv)]
         self._bn = self.encoder.batchnorms() + self.decoder.batchnorms() + [bn for _, bn in self.postnet]
         self.global_step = 0
+        self.current_epoch = 0  # the driver advances it; only the binarisation-loss warm-up reads it
+        self._prior = None
         self._seed = seed
         self._grad_norm = torch.zeros(1, device=self.device)
         self.init_random(seed)
@@ -453,16 +495,15 @@ class FastSpeech2Trainer:
         D = c.encoder.input_dim
         n_tok = float(batch["lens"].sum())
         pad = torch.arange(L, device=dev)[None, :] >= lens[:, None]
-        dur = batch["durations"].to(dev, torch.int32).clamp_min(0).masked_fill(pad, 0).contiguous()
-        cum = torch.cumsum(dur, 1, dtype=torch.int32).contiguous()
-        mel_lens_host = batch["durations"].clamp_min(0).masked_fill(torch.arange(L)[None, :] >= batch["lens"][:, None], 0).sum(1)
+        learn = self.aligner is not None
+        if learn:  # durations come out of the aligner below; the frame counts are the data's
+            mel_lens_host = batch["mel_lens"].to("cpu", torch.int64)
+        else:
+            mel_lens_host = batch["durations"].to("cpu").clamp_min(0).masked_fill(torch.arange(L)[None, :] >= batch["lens"].to("cpu")[:, None], 0).sum(1)
         mel_lens = mel_lens_host.to(dev, torch.int32).contiguous()
         T = int(mel_lens_host.max())
         n_frames = float(mel_lens_host.sum())
         mel_t = batch["mel"].to(dev, torch.float32)[:, :T].permute(2, 0, 1).contiguous()  # [n_mels, B, T]
-        pitch_t = batch["pitch"].to(dev, torch.float32).masked_fill(pad, 0.0).contiguous()
-        energy_t = batch["energy"].to(dev, torch.float32).masked_fill(pad, 0.0).contiguous()
-        log_d_t = torch.log(dur.float() + 1.0).contiguous()
 
         self.params.zero_grad()
         for cv in self._wn:
@@ -474,12 +515,32 @@ class FastSpeech2Trainer:
             counter[0] += n
             return (self._seed * 1000003 + self.global_step) * 4096 + counter[0] - n
 
-        emb = torch.empty(D, B, L, device=dev, dtype=torch.float32)
-        _chk(lib.evmi_fs2_embed_f32(ids.data_ptr(), lens.data_ptr(), self.text_table.data().data_ptr(), self.inv_freq.data_ptr(), emb.data_ptr(),
-                                    B, L, D, _s(emb)), "evmi_fs2_embed_f32")
-        x0 = Var(emb)
-        tape.record(lambda: x0.grad is not None and _chk(lib.evmi_fs2_embed_bwd_f32(
-            x0.grad.data_ptr(), ids.data_ptr(), lens.data_ptr(), self.text_table.grad().data_ptr(), self.text_table.rows, B, L, D, 0, _s(emb)), "evmi_fs2_embed_bwd_f32"))
+        def embed(with_position: bool) -> Var:
+            e = torch.empty(D, B, L, device=dev, dtype=torch.float32)
+            _chk(lib.evmi_fs2_embed_f32(ids.data_ptr(), lens.data_ptr(), self.text_table.data().data_ptr(), self.inv_freq.data_ptr() if with_position else 0,
+                                        e.data_ptr(), B, L, D, _s(e)), "evmi_fs2_embed_f32")
+            v = Var(e)
+            tape.record(lambda: v.grad is not None and _chk(lib.evmi_fs2_embed_bwd_f32(
+                v.grad.data_ptr(), ids.data_ptr(), lens.data_ptr(), self.text_table.grad().data_ptr(), self.text_table.rows, B, L, D, 0, _s(e)), "evmi_fs2_embed_bwd_f32"))
+            return v
+
+        losses = {}
+        if learn:
+            epochs = max(1, tr.attn_bin_loss_warmup_epochs)
+            bin_w = tr.attn_bin_loss_weight * min(self.current_epoch / epochs, 1.0)
+            prior = batch.get("attn_prior")
+            prior = None if prior is None else prior.to(dev, torch.float64)[:, :T, :L].contiguous()
+            align_losses, dur, self.last_alignment = self.aligner.forward(tape, embed(False), Var(mel_t, needs_grad=False), prior, lens, mel_lens, n_frames,
+                                                                          tr.attn_ctc_loss_weight, bin_w)
+            losses.update(align_losses)
+        else:
+            dur = batch["durations"].to(dev, torch.int32).clamp_min(0).masked_fill(pad, 0).contiguous()
+        cum = torch.cumsum(dur, 1, dtype=torch.int32).contiguous()
+        log_d_t = torch.log(dur.float() + 1.0).contiguous()
+        pitch_t = self._phone_level(batch, "pitch", cum, dur, pad, T)
+        energy_t = self._phone_level(batch, "energy", cum, dur, pad, T)
+
+        x0 = embed(True)
         x = self.encoder.forward(tape, x0, lens, seeds)
 
         for table, key in ((self.speaker_table, "speakers"), (self.language_table, "languages")):
@@ -488,7 +549,6 @@ class FastSpeech2Trainer:
                     raise ValueError(f"this model needs `{key}` ids [B]")
                 x = self._add_item_embedding(tape, x, table, batch[key].to(dev, torch.int32).contiguous(), lens)
 
-        losses = {}
         w = tr.duration_loss_weight
         losses["duration"] = mse_loss(tape, self.duration_predictor.forward(tape, x, lens, seeds), log_d_t.view(1, B, L), n_tok, w)
         losses["pitch"] = mse_loss(tape, self.pitch_predictor.forward(tape, x, lens, seeds), pitch_t.view(1, B, L), n_tok, tr.pitch_loss_weight)
@@ -529,6 +589,18 @@ class FastSpeech2Trainer:
             ops.axpby(1.0, total, 1.0, v, out=total)
         losses["total"] = total
         return losses
+
+    def _phone_level(self, batch, key, cum, dur, pad, T):
+        """Phone-level variance targets [B, L]: given as such (``pitch``), or frame-level (``pitch_frames`` [B, T]) averaged over
+        each symbol's frames -- ``average_data_by_durations``, everyvoice/preprocessor/preprocessor.py:287-300 (1e-7 for zero frames)."""
+        dev = self.device
+        if key in batch:
+            return batch[key].to(dev, torch.float32).masked_fill(pad, 0.0).contiguous()
+        fr = batch[key + "_frames"].to(dev, torch.float32)[:, :T].contiguous()
+        B, L = dur.shape
+        sums = torch.empty(B, L, device=dev, dtype=torch.float32)
+        _chk(_lib.load().evmi_length_regulate_bwd_cbt_f32(fr.data_ptr(), cum.data_ptr(), sums.data_ptr(), 1, B, L, T, _s(fr)), "evmi_length_regulate_bwd_cbt_f32")
+        return torch.where(dur > 0, sums / dur.clamp_min(1), torch.full_like(sums, 1e-7)).masked_fill(pad, 0.0).contiguous()
 
     def _add_item_embedding(self, tape, x: Var, table: Table, item_ids, lens):
         lib = _lib.load()

@@ -490,3 +490,50 @@ def attention_train_bwd(qkv, saved, dout, heads, p=0.0, seed=0):
         gemm_groups(kk, dP, dqkv[h * dh:(h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T, tb=True)                                   # dQ = K . dS^T
         gemm_groups(q, dP, dqkv[D + h * dh:D + (h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T)                                     # dK = Q . dS
     return dqkv
+
+
+# ---- alignment learning, training side (csrc/align_train_ops.hip) -------------------------------------------------------
+def forward_sum_loss_and_grad(logprob, text_lens32, mel_lens32, weight, blank_logprob=-1.0):
+    """(weight * mean over the batch of the per-item CTC forward-sum losses [device scalar], d that / d logprob [B, T, L])."""
+    lib = _lib.load()
+    B, T, L = logprob.shape
+    n = lib.evmi_forward_sum_grad_f32_ws_elems(B, T, L)
+    ws = WS.get("ctc", n, logprob.device)
+    per_item = torch.empty(B, device=logprob.device, dtype=torch.float32)
+    grad = torch.empty_like(logprob)
+    _chk(lib.evmi_forward_sum_grad_f32(logprob.data_ptr(), text_lens32.data_ptr(), mel_lens32.data_ptr(), per_item.data_ptr(), grad.data_ptr(),
+                                       ws.data_ptr(), n, B, T, L, blank_logprob, weight, _s(logprob)), "evmi_forward_sum_grad_f32")
+    loss = torch.empty(1, device=logprob.device, dtype=torch.float32)
+    scalar_reduce(2, per_item, None, loss, scale=weight / B)
+    return loss, grad
+
+
+def align_attention_fwd(q, k, prior, text_lens32, temperature):
+    """q [A, B, T], k [A, B, L] (projected mel / text), prior [B, T, L] float64 or None -> (soft, logprob) [B, T, L]."""
+    A, B, T = q.shape
+    L = k.shape[2]
+    soft = torch.empty(B, T, L, device=q.device, dtype=torch.float32)
+    logprob = torch.empty_like(soft)
+    _chk(_lib.load().evmi_align_attention_f32(q.data_ptr(), k.data_ptr(), _lib.ptr(prior), text_lens32.data_ptr(), soft.data_ptr(), logprob.data_ptr(),
+                                              A, B, T, L, temperature, _s(q)), "evmi_align_attention_f32")
+    return soft, logprob
+
+
+def align_attention_bwd(q, k, soft, logprob, prior, hard, dlogprob, text_lens32, temperature, bin_scale):
+    """-> (dq [A, B, T], dk [A, B, L])"""
+    lib = _lib.load()
+    A, B, T = q.shape
+    L = k.shape[2]
+    dev = q.device
+    da = torch.empty(B, T, L, device=dev, dtype=torch.float32)
+    rs = torch.empty(B, T, device=dev, dtype=torch.float32)
+    cs = torch.empty(B, L, device=dev, dtype=torch.float32)
+    _chk(lib.evmi_align_attention_bwd_f32(soft.data_ptr(), logprob.data_ptr(), _lib.ptr(prior), _lib.ptr(hard), _lib.ptr(dlogprob), text_lens32.data_ptr(),
+                                          da.data_ptr(), rs.data_ptr(), cs.data_ptr(), B, T, L, bin_scale, _s(q)), "evmi_align_attention_bwd_f32")
+    dq = torch.empty_like(q)
+    dk = torch.empty_like(k)
+    gemm_groups(k, da, dq, B, A, T, L, B * L, L, B * T, L, T * L, T, tb=True)  # K_b . da_b^T
+    gemm_groups(q, da, dk, B, A, L, T, B * T, L, B * L, T, T * L, L)           # Q_b . da_b
+    _chk(lib.evmi_align_qk_grad_f32(q.data_ptr(), rs.data_ptr(), dq.data_ptr(), A, B * T, -2.0 * temperature, _s(q)), "evmi_align_qk_grad_f32")
+    _chk(lib.evmi_align_qk_grad_f32(k.data_ptr(), cs.data_ptr(), dk.data_ptr(), A, B * L, -2.0 * temperature, _s(q)), "evmi_align_qk_grad_f32")
+    return dq, dk

@@ -296,7 +296,7 @@ int evmi_adamw_f32(float* p_dev, const float* g_dev, float* m_dev, float* v_dev,
  * (synthesize_helper).  Linear / pointwise / postnet convolutions go through evmi_conv1d_cbt_f32.
  * ------------------------------------------------------------------------------------------ */
 /* out[c][b][l] = l < lens[b] ? table[ids[b][l]][c] + pe(l, c) : 0, pe = cat(sin(l*inv_freq), cos(l*inv_freq))
- * (`position_embedding.inv_freq` [D/2] is the tensor everyvoice/tests/data/test.ckpt holds). */
+ * (`position_embedding.inv_freq` [D/2] is the tensor everyvoice/tests/data/test.ckpt holds); inv_freq NULL = no pe term. */
 int evmi_fs2_embed_f32(const int* ids_dev, const int* lens_dev, const float* table_dev,
                        const float* inv_freq_dev, float* out_dev, int B, int L, int D, void* stream);
 /* x[c][b][t] = t < lens[b] ? x + pe(t, c) : 0   (decoder input). */
@@ -407,6 +407,24 @@ int evmi_fs2_item_embedding_bwd_f32(const float* dx_dev, const int* ids_dev, con
  * (cum = inclusive cumulative durations, as evmi_length_regulate_cbt_f32 takes them). */
 int evmi_length_regulate_bwd_cbt_f32(const float* dframes_dev, const int* cum_dev, float* dx_dev, int C, int B, int L,
                                      int T, void* stream);
+
+/* Alignment learning, backward side (F5).  CTC forward-sum loss per item AND grad [B][T][L] = weight / (B * L_b) * d loss_b /
+ * d logprob (softmax row - state occupancy; zero outside the item's frames / tokens; zero_infinity).
+ * ws: evmi_forward_sum_grad_f32_ws_elems floats (the stored alpha lattice and per-frame normalisers). */
+long long evmi_forward_sum_grad_f32_ws_elems(int B, int T, int L);
+int evmi_forward_sum_grad_f32(const float* logprob_dev, const int* text_lens_dev, const int* mel_lens_dev,
+                              float* loss_per_item_dev, float* grad_dev, float* ws_dev, long long ws_elems, int B, int T,
+                              int L, float blank_logprob, float weight, void* stream);
+/* Backward of evmi_align_attention_f32 down to the distance scores: da [B][T][L] from the CTC gradient dlogprob (or NULL) and
+ * the binarisation loss on `hard` (or NULL; bin_scale = weight / number of hard cells); also rowsum [B][T] = sum_l da and
+ * colsum [B][L] = sum_t da.  prior as given to the forward (or NULL). */
+int evmi_align_attention_bwd_f32(const float* soft_dev, const float* logprob_dev, const double* prior_dev, const int* hard_dev,
+                                 const float* dlogprob_dev, const int* text_lens_dev, float* da_dev, float* rowsum_dev,
+                                 float* colsum_dev, int B, int T, int L, float bin_scale, void* stream);
+/* In place m[c][n] = coef * (x[c][n] * sums[n] - m[c][n]) over A rows of BN columns: finishes dq (m = K . da^T, coef = -2 temp)
+ * and dk (m = Q . da, coef = -2 temp with the sign folded: dk = 2 temp (m - k * colsum)). */
+int evmi_align_qk_grad_f32(const float* x_dev, const float* sums_dev, float* m_dev, int A, long long BN, float coef,
+                           void* stream);
 
 #ifdef __cplusplus
 }

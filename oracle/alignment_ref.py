@@ -42,3 +42,29 @@ def forward_sum_loss_ref(attn_logprob, text_lens, mel_lens, blank_logprob: float
 def binarization_loss_ref(hard, soft):
     """-mean log soft attention on the cells of the hard (monotonic) alignment."""
     return -torch.log(torch.clamp(soft[hard == 1], min=1e-12)).sum() / hard.sum()
+
+
+class AlignerRef(torch.nn.Module):
+    """FastPitch ``ConvAttention``: key / query projections in front of ``alignment_attention_ref`` (parameter names as there:
+    ``key_proj.{0,2}.conv``, ``query_proj.{0,2,4}.conv``)."""
+
+    def __init__(self, d_text: int, n_mels: int, n_att: int = 80, temperature: float = 0.0005):
+        super().__init__()
+        conv = lambda cin, cout, k: _ConvNormRef(cin, cout, k)
+        self.key_proj = torch.nn.Sequential(conv(d_text, 2 * d_text, 3), torch.nn.ReLU(), conv(2 * d_text, n_att, 1))
+        self.query_proj = torch.nn.Sequential(conv(n_mels, 2 * n_mels, 3), torch.nn.ReLU(), conv(2 * n_mels, n_mels, 1), torch.nn.ReLU(),
+                                              conv(n_mels, n_att, 1))
+        self.temperature = temperature
+
+    def forward(self, mel, text_emb, text_lens, prior=None):
+        """mel [B, n_mels, T], text_emb [B, D, L] -> (soft, logprob) [B, T, L]"""
+        return alignment_attention_ref(self.query_proj(mel), self.key_proj(text_emb), text_lens, prior, self.temperature)
+
+
+class _ConvNormRef(torch.nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.conv = torch.nn.Conv1d(cin, cout, k, padding=(k - 1) // 2)
+
+    def forward(self, x):
+        return self.conv(x)

@@ -270,17 +270,42 @@ def randomize_norm_stats_(model: nn.Module, gen: torch.Generator):
             m.bias.data.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
 
 
-def training_losses_ref(model: FastSpeech2Ref, batch: dict, weights: dict | None = None) -> dict:
+def training_losses_ref(model: FastSpeech2Ref, batch: dict, weights: dict | None = None, aligner=None, hard=None) -> dict:
     """Teacher-forced training forward with torch autograd (``model.train()`` decides dropout / BatchNorm mode):
     ground-truth durations through the length regulator, ground-truth pitch / energy into the embeddings, MSE on
     log-durations / pitch / energy over the unpadded symbols and on mel / postnet mel over the unpadded frames;
     weights = FastSpeech2TrainingConfig defaults of the reference's schema (mel 1, postnet 1, pitch / energy / duration 0.1).
     PARITY UNPINNED like the rest of this file (the training step lives in the absent submodule)."""
-    w = {"mel": 1.0, "postnet": 1.0, "pitch": 0.1, "energy": 0.1, "duration": 0.1}
+    w = {"mel": 1.0, "postnet": 1.0, "pitch": 0.1, "energy": 0.1, "duration": 0.1, "attn_ctc": 0.1, "attn_bin": 0.0}
     w.update(weights or {})
-    ids, lens, durations = batch["ids"], batch["lens"], batch["durations"]
+    ids, lens = batch["ids"], batch["lens"]
     B, L = ids.shape
     pad = torch.arange(L)[None, :] >= lens[:, None]
+    losses = {}
+    if aligner is not None:
+        # learn_alignment: soft attention between the target mel and the bare symbol embeddings, hard path by monotonic search
+        # (no gradient), durations = frames per symbol; CTC forward-sum + binarisation losses (oracle/alignment_ref.py)
+        from .alignment_ref import binarization_loss_ref, forward_sum_loss_ref
+        from .mas_ref import maximum_path_batch_ref
+        mel_lens_in = batch["mel_lens"]
+        Tm = int(mel_lens_in.max())
+        soft, logprob = aligner(batch["mel"][:, :Tm].transpose(1, 2), model.text_input_layer(ids).masked_fill(pad[..., None], 0.0).transpose(1, 2), lens,
+                                batch.get("attn_prior"))
+        if hard is None:
+            hard, _ = maximum_path_batch_ref(torch.log(soft.detach()).numpy(), mel_lens_in.numpy(), lens.numpy())
+            hard = torch.from_numpy(hard)
+        durations = hard.sum(1).long()
+        losses["attn_ctc"] = w["attn_ctc"] * forward_sum_loss_ref(logprob, lens, mel_lens_in)
+        if w["attn_bin"] > 0:
+            losses["attn_bin"] = w["attn_bin"] * binarization_loss_ref(hard, soft)
+        cum = torch.cumsum(durations, 1)
+        def phone_level(key):  # average_data_by_durations (preprocessor.py:287-300): mean over the symbol's frames, 1e-7 for none
+            fr = F.pad(torch.cumsum(batch[key + "_frames"][:, :Tm], 1), (1, 0))
+            sums = torch.gather(fr, 1, cum) - torch.gather(fr, 1, cum - durations)
+            return torch.where(durations > 0, sums / durations.clamp_min(1), torch.full_like(sums, 1e-7))
+        batch = dict(batch, durations=durations, pitch=phone_level("pitch") if "pitch" not in batch else batch["pitch"],
+                     energy=phone_level("energy") if "energy" not in batch else batch["energy"])
+    durations = batch["durations"]
     x = model.text_input_layer(ids) + model.position_embedding(L)[None]
     x = x.masked_fill(pad[..., None], 0.0)
     x, _ = model.encoder(x, lens)
@@ -291,7 +316,6 @@ def training_losses_ref(model: FastSpeech2Ref, batch: dict, weights: dict | None
     durations = durations.clamp_min(0).masked_fill(pad, 0)
     pitch_t, energy_t = batch["pitch"].masked_fill(pad, 0.0), batch["energy"].masked_fill(pad, 0.0)
     n_tok = lens.sum()
-    losses = {}
     log_d = model.duration_predictor(x, pad)
     losses["duration"] = w["duration"] * ((log_d - torch.log(durations.float() + 1.0)) ** 2).sum() / n_tok
     pitch = model.pitch_predictor(x, pad)

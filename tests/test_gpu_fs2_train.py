@@ -197,11 +197,12 @@ def _ref_cfg(dropout=0.0, speakers=0):
     return c
 
 
-def _trainer(ref_cfg, cuda_device, seed=11, **kw):
+def _trainer(ref_cfg, cuda_device, seed=11, learn_alignment=False, **kw):
     from everyvoice_amd.train.fs2 import FastSpeech2Trainer
     from tests.test_gpu_fs2 import _product_config
 
     cfg = _product_config(ref_cfg)
+    cfg.learn_alignment = learn_alignment
     for enc, rc in ((cfg.encoder, ref_cfg.encoder), (cfg.decoder, ref_cfg.decoder)):
         enc.dropout = rc.dropout
     for name in ("duration", "pitch", "energy"):
@@ -361,3 +362,122 @@ def test_data_parallel_path_on_rccl_world_of_one(cuda_device):
     sa, sb = plain.state_dict(), dp.state_dict()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+# ---- alignment learning (learn_alignment: true, the reference's default) -------------------------------------------------------
+def test_forward_sum_loss_gradient(cuda_device):
+    from everyvoice_amd.train import ops
+    from oracle.alignment_ref import forward_sum_loss_ref
+
+    g = torch.Generator().manual_seed(21)
+    B, T, L = 3, 40, 9
+    text_lens, mel_lens = torch.tensor([9, 5, 7]), torch.tensor([40, 22, 31])
+    lp = (torch.randn(B, T, L, generator=g) * 2).requires_grad_()
+    want = 0.1 * forward_sum_loss_ref(lp, text_lens, mel_lens)
+    want.backward()
+    dev = cuda_device
+    loss, grad = ops.forward_sum_loss_and_grad(lp.detach().to(dev), text_lens.to(dev, torch.int32), mel_lens.to(dev, torch.int32), 0.1)
+    assert float(loss) == pytest.approx(float(want), rel=2e-5)
+    _close(grad, lp.grad, 2e-4)
+    # an item with fewer frames than symbols is infeasible: zero loss and zero gradient (zero_infinity)
+    loss2, grad2 = ops.forward_sum_loss_and_grad(lp.detach().to(dev), torch.tensor([9, 5, 7], dtype=torch.int32, device=dev),
+                                                 torch.tensor([40, 3, 31], dtype=torch.int32, device=dev), 1.0)
+    assert torch.isfinite(loss2).all() and float(grad2[1].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("with_prior", [True, False])
+def test_alignment_attention_backward(cuda_device, with_prior):
+    from everyvoice_amd.heavy import BetaBinomialInterpolator, maximum_path
+    from everyvoice_amd.train import ops
+    from oracle.alignment_ref import alignment_attention_ref, binarization_loss_ref, forward_sum_loss_ref
+
+    g = torch.Generator().manual_seed(5)
+    A, B, T, L = 12, 2, 26, 7
+    text_lens, mel_lens = torch.tensor([7, 5]), torch.tensor([26, 17])
+    q = torch.randn(B, A, T, generator=g, requires_grad=True)
+    k = torch.randn(B, A, L, generator=g, requires_grad=True)
+    dev = cuda_device
+    prior = None
+    if with_prior:
+        interp = BetaBinomialInterpolator(device=dev)
+        prior = torch.zeros(B, T, L, dtype=torch.float64)
+        for b in range(B):
+            prior[b, : mel_lens[b], : text_lens[b]] = interp(int(mel_lens[b]), int(text_lens[b])).cpu()
+    temp = 0.05
+    soft, logprob = alignment_attention_ref(q, k, text_lens, prior, temp)
+    tl, ml = text_lens.to(dev, torch.int32), mel_lens.to(dev, torch.int32)
+    qd, kd = _cbt(q.detach()).to(dev), _cbt(k.detach()).to(dev)
+    pd = None if prior is None else prior.to(dev)
+    soft_g, logprob_g = ops.align_attention_fwd(qd, kd, pd, tl, temp)
+    _close(soft_g, soft.detach())
+    hard, dur = maximum_path(torch.log(soft_g), ml, tl)
+    hard_c = hard.cpu()
+    loss = 0.3 * forward_sum_loss_ref(logprob, text_lens, mel_lens) + 0.7 * binarization_loss_ref(hard_c, soft)
+    loss.backward()
+    _, dlogprob = ops.forward_sum_loss_and_grad(logprob_g, tl, ml, 0.3)
+    dq, dk = ops.align_attention_bwd(qd, kd, soft_g, logprob_g, pd, hard, dlogprob, tl, temp, 0.7 / float(mel_lens.sum()))
+    _l2close(dq.cpu().permute(1, 0, 2), q.grad, 1e-3, "dq")
+    _l2close(dk.cpu().permute(1, 0, 2), k.grad, 1e-3, "dk")
+
+
+def _align_batch(ref_cfg, B, L, seed, dev):
+    from everyvoice_amd.heavy import BetaBinomialInterpolator
+
+    batch = _train_batch(ref_cfg, B, L, seed)
+    mel_lens = batch["durations"].sum(1)
+    T = int(mel_lens.max())
+    g = torch.Generator().manual_seed(seed + 100)
+    interp = BetaBinomialInterpolator(device=dev)
+    prior = torch.zeros(B, T, L, dtype=torch.float64)
+    for b in range(B):
+        prior[b, : mel_lens[b], : batch["lens"][b]] = interp(int(mel_lens[b]), int(batch["lens"][b])).cpu()
+    out = dict(ids=batch["ids"], lens=batch["lens"], mel=batch["mel"], mel_lens=mel_lens, attn_prior=prior,
+               pitch_frames=torch.randn(B, T, generator=g), energy_frames=torch.randn(B, T, generator=g))
+    return out
+
+
+def test_training_step_with_alignment_learning(cuda_device):
+    """learn_alignment: true -- the aligner's soft attention, the hard path (monotonic search), durations and frame-averaged
+    pitch / energy targets derived from it, CTC + binarisation losses and every gradient (aligner projections included)."""
+    from oracle.alignment_ref import AlignerRef
+
+    ref_cfg = _ref_cfg(0.0)
+    tr = _trainer(ref_cfg, cuda_device, learn_alignment=True)
+    tr.current_epoch = 50  # half of the binarisation warm-up: weight 0.05
+    batch = _align_batch(ref_cfg, 3, 10, seed=6, dev=cuda_device)
+    sd = {k: v.detach().cpu() for k, v in tr.state_dict().items()}
+    ref = FastSpeech2Ref(ref_cfg).train()
+    ref.load_state_dict({k: v for k, v in sd.items() if not k.startswith("attention.")}, strict=True)
+    aligner = AlignerRef(ref_cfg.encoder.input_dim, ref_cfg.n_mels)
+    aligner.load_state_dict({k[len("attention."):]: v for k, v in sd.items() if k.startswith("attention.")}, strict=True)
+    got = tr.forward_backward(batch)
+    hard_gpu = tr.last_alignment.cpu()
+    want = training_losses_ref(ref, batch, weights={"attn_bin": 0.05}, aligner=aligner)
+    want_hard = training_losses_ref(ref, batch, weights={"attn_bin": 0.05}, aligner=aligner, hard=hard_gpu)
+    assert float(want_hard["total"]) == pytest.approx(float(want["total"]), rel=1e-6)  # the oracle's own search finds the same path
+    want["total"].backward()
+    assert set(got) == set(want)
+    for k, v in want.items():
+        assert float(got[k]) == pytest.approx(float(v), rel=2e-4), k
+    grads = tr.params.gradients()
+    named = dict(ref.named_parameters())
+    named.update({"attention." + n: p for n, p in aligner.named_parameters()})
+    assert set(grads) == set(named)
+    for name, p in named.items():
+        want_g = p.grad if p.grad is not None else torch.zeros_like(p)
+        _l2close(grads[name], want_g, 2e-3, name)
+
+
+def test_alignment_learning_trains(cuda_device):
+    from everyvoice_amd.train.fs2 import FastSpeech2TrainingConfig, NoamOptimizerConfig
+
+    ref_cfg = _ref_cfg(0.1)
+    tr = _trainer(ref_cfg, cuda_device, learn_alignment=True,
+                  training=FastSpeech2TrainingConfig(optimizer=NoamOptimizerConfig(learning_rate=2e-3, warmup_steps=5)))
+    batch = _align_batch(ref_cfg, 4, 12, seed=3, dev=cuda_device)
+    first = tr.training_step(batch)
+    for _ in range(20):
+        last = tr.training_step(batch)
+    assert float(last["total"]) < 0.8 * float(first["total"])
+    assert float(last["attn_ctc"]) <= float(first["attn_ctc"]) * 1.001
+    assert int(tr.last_alignment.sum()) == int(batch["mel_lens"].sum())  # one symbol per frame
