@@ -339,7 +339,8 @@ def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
 
 def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     """BASELINE config 3: FastSpeech2 feature-prediction training, LJSpeech-shaped synthetic batch of 32 per GPU, default model
-    (17.7 M parameters), teacher-forced step = forward + 5 losses + backward + clipped Noam AdamW; data parallel with one RCCL
+    (learn_alignment on: aligner + monotonic search + CTC loss inside the step), step = forward + losses + backward + clipped
+    Noam AdamW; data parallel with one RCCL
     all-reduce of the flat gradient buffer when N > 1.  fp32 storage and fp32 matrix-core arithmetic (>= the bf16 the config
     names).  Algorithmic FLOPs = 3 x the forward's (dx and dw of every product)."""
     import torch
@@ -349,8 +350,8 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     from fs2_bench import forward_flops
     from fs2_train_bench import training_batch
 
-    tr = FastSpeech2Trainer(device=dev, process_group=True if use_dist else None)
-    batch, t_i = training_batch(32, 1234 + rank)
+    tr = FastSpeech2Trainer(device=dev, process_group=True if use_dist else None)  # default config: learn_alignment on
+    batch, t_i = training_batch(32, 1234 + rank, device=dev)
     out = {}
 
     def step():
@@ -379,7 +380,7 @@ def cpu_baseline_fs2_train(cores: int, batch: int = 8) -> dict:
     torch.manual_seed(1234)
     torch.set_num_threads(cores)
     ref = FastSpeech2Ref().train()
-    full, t_i = training_batch(32, 1234)
+    full, t_i = training_batch(32, 1234, learn_alignment=False)  # the CPU sample uses given durations (no aligner): a lower bound on its work
     L = int(full["lens"][:batch].max())
     b = {k: (v[:batch, :L] if v.dim() >= 2 and k != "mel" else v[:batch]) for k, v in full.items()}
     opt = torch.optim.AdamW(ref.parameters(), lr=1e-4)

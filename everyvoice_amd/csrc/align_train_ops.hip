@@ -23,72 +23,82 @@ __device__ __forceinline__ float lae(float a, float b) {
   return m + log1pf(expf(-fabsf(a - b)));
 }
 
-// loss[b] = -log p(target) / L_b ; grad[b][t][l] = scale[b] * (softmax row - state occupancy), scale = weight / (B * L_b)
-// alpha_ws [B][T][2L+1], lse_ws [B][T]
-__global__ __launch_bounds__(256) void forward_sum_grad_kernel(const float* __restrict__ logprob, const int* __restrict__ text_lens,
-                                                              const int* __restrict__ mel_lens, float* __restrict__ loss,
-                                                              float* __restrict__ grad, float* __restrict__ alpha_ws,
-                                                              float* __restrict__ lse_ws, int B, int T, int L, float blank_logprob,
-                                                              float weight) {
-  extern __shared__ float sm[];  // [L + 1] normalised row, 2 x [2L + 1] alpha / beta, [8] scratch
+// lse[b][t] = logsumexp over [blank, tokens < L_b] of frame t: one wave per frame
+__global__ __launch_bounds__(256) void forward_sum_lse_kernel(const float* __restrict__ logprob, const int* __restrict__ text_lens,
+                                                             const int* __restrict__ mel_lens, float* __restrict__ lse, int B, int T, int L,
+                                                             float blank_logprob) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long long)B * T) return;
+  const int b = (int)(row / T), t = (int)(row - (long long)b * T);
+  if (t >= mel_lens[b]) return;
+  const int Lb = min(text_lens[b], L);
+  const float* r = logprob + row * L;
+  float m = blank_logprob;
+  for (int l = lane; l < Lb; l += 64) m = fmaxf(m, r[l]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  float s = lane == 0 ? expf(blank_logprob - m) : 0.f;
+  for (int l = lane; l < Lb; l += 64) s += expf(r[l] - m);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) lse[row] = m + logf(s);
+}
+
+// loss[b] = -log p(target) / L_b ; grad[b][t][l] = scale[b] * (softmax row - state occupancy), scale = weight / (B * L_b).
+// One workgroup of 512 threads per item, NS states of the extended target per thread; every thread fetches the emission of
+// its own states one frame ahead, so a frame costs one barrier (double-buffered lattice column in LDS).
+// alpha_ws [B][T][2L+1], lse [B][T] from the kernel above.
+constexpr int CTC_THREADS = 512;
+template <int NS>
+__global__ __launch_bounds__(CTC_THREADS) void forward_sum_grad_kernel(const float* __restrict__ logprob, const int* __restrict__ text_lens,
+                                                                      const int* __restrict__ mel_lens, float* __restrict__ loss,
+                                                                      float* __restrict__ grad, float* __restrict__ alpha_ws,
+                                                                      const float* __restrict__ lse_ws, int B, int T, int L,
+                                                                      float blank_logprob, float weight) {
+  extern __shared__ float sm[];  // 2 x [2L + 1] lattice columns
   const int b = blockIdx.x, tid = threadIdx.x;
   const int Lb = min(text_lens[b], L), Tb = min(mel_lens[b], T), S = 2 * Lb + 1;
   const int SW = 2 * L + 1;
-  float* lp = sm;
-  float* buf0 = lp + (L + 1);
-  float* buf1 = buf0 + SW;
-  float* red = buf1 + SW;
+  float* buf0 = sm;
+  float* buf1 = sm + SW;
   float* gb = grad + (long long)b * T * L;
-  for (long long i = tid; i < (long long)T * L; i += 256) gb[i] = 0.f;
+  for (long long i = tid; i < (long long)T * L; i += CTC_THREADS) gb[i] = 0.f;
   if (Lb <= 0 || Tb <= 0) { if (tid == 0) loss[b] = 0.f; return; }
   float* aw = alpha_ws + (long long)b * T * SW;
-  float* lw = lse_ws + (long long)b * T;
-
-  auto load_row = [&](int t, bool store_lse) {  // lp[0] = blank, lp[l + 1] = token l, log-softmax over these L_b + 1 classes
-    const float* row = logprob + ((long long)b * T + t) * L;
-    float lse;
-    if (store_lse) {
-      float m = blank_logprob;
-      for (int l = tid; l < Lb; l += 256) m = fmaxf(m, row[l]);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-      if ((tid & 63) == 0) red[tid >> 6] = m;
-      __syncthreads();
-      m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-      __syncthreads();
-      float s = tid == 0 ? expf(blank_logprob - m) : 0.f;
-      for (int l = tid; l < Lb; l += 256) s += expf(row[l] - m);
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-      if ((tid & 63) == 0) red[tid >> 6] = s;
-      __syncthreads();
-      lse = m + logf(red[0] + red[1] + red[2] + red[3]);
-      __syncthreads();
-      if (tid == 0) lw[t] = lse;
-    } else {
-      lse = lw[t];
-    }
-    if (tid == 0) lp[0] = blank_logprob - lse;
-    for (int l = tid; l < Lb; l += 256) lp[l + 1] = row[l] - lse;
-    __syncthreads();
+  const float* lw = lse_ws + (long long)b * T;
+  const float* lpb = logprob + (long long)b * T * L;
+  auto emission = [&](int t, int st) {  // normalised log-probability of state st's label at frame t
+    const float raw = (st & 1) ? lpb[(long long)t * L + ((st - 1) >> 1)] : blank_logprob;
+    return raw - lw[t];
   };
-
+  float y[NS], yn[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int st = tid + j * CTC_THREADS;
+    y[j] = st < S ? emission(0, st) : 0.f;
+    yn[j] = (st < S && Tb > 1) ? emission(1, st) : 0.f;
+  }
   for (int t = 0; t < Tb; ++t) {  // alpha
-    load_row(t, true);
     float* cur = (t & 1) ? buf1 : buf0;
     const float* prev = (t & 1) ? buf0 : buf1;
-    for (int st = tid; st < S; st += 256) {
-      const int lab = (st & 1) ? (st + 1) / 2 : 0;
-      float a;
-      if (t == 0) a = st < 2 ? 0.f : -INFINITY;
-      else {
-        a = prev[st];
-        if (st >= 1) a = lae(a, prev[st - 1]);
-        if ((st & 1) && st >= 3) a = lae(a, prev[st - 2]);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int st = tid + j * CTC_THREADS;
+      if (st < S) {
+        float a;
+        if (t == 0) a = st < 2 ? 0.f : -INFINITY;
+        else {
+          a = prev[st];
+          if (st >= 1) a = lae(a, prev[st - 1]);
+          if ((st & 1) && st >= 3) a = lae(a, prev[st - 2]);
+        }
+        a += y[j];
+        cur[st] = a;
+        aw[(long long)t * SW + st] = a;
+        y[j] = yn[j];
+        if (t + 2 < Tb) yn[j] = emission(t + 2, st);
       }
-      a += lp[lab];
-      cur[st] = a;
-      aw[(long long)t * SW + st] = a;
     }
     __syncthreads();
   }
@@ -99,26 +109,41 @@ __global__ __launch_bounds__(256) void forward_sum_grad_kernel(const float* __re
   if (ll == -INFINITY) return;  // zero_infinity: no gradient either
   const float scale = weight / ((float)B * (float)Lb);
 
+  float al[NS], aln[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int st = tid + j * CTC_THREADS;
+    y[j] = st < S ? emission(Tb - 1, st) : 0.f;
+    yn[j] = (st < S && Tb > 1) ? emission(Tb - 2, st) : 0.f;
+    al[j] = st < S ? aw[(long long)(Tb - 1) * SW + st] : 0.f;
+    aln[j] = (st < S && Tb > 1) ? aw[(long long)(Tb - 2) * SW + st] : 0.f;
+  }
   for (int t = Tb - 1; t >= 0; --t) {  // beta (emission at t included, like alpha) + gradient of frame t
-    load_row(t, false);
     float* cur = (t & 1) ? buf1 : buf0;
     const float* nxt = (t & 1) ? buf0 : buf1;
-    for (int st = tid; st < S; st += 256) {
-      const int lab = (st & 1) ? (st + 1) / 2 : 0;
-      float v;
-      if (t == Tb - 1) v = st >= S - 2 ? 0.f : -INFINITY;
-      else {
-        v = nxt[st];
-        if (st + 1 < S) v = lae(v, nxt[st + 1]);
-        if ((st & 1) && st + 2 < S) v = lae(v, nxt[st + 2]);
-      }
-      v += lp[lab];
-      cur[st] = v;
-      if (st & 1) {  // token l = (st - 1) / 2: one state per token
-        const int l = (st - 1) >> 1;
-        const float y = lp[lab];
-        const float occ = expf(aw[(long long)t * SW + st] + v - y - ll);
-        gb[(long long)t * L + l] = scale * (expf(y) - occ);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int st = tid + j * CTC_THREADS;
+      if (st < S) {
+        float v;
+        if (t == Tb - 1) v = st >= S - 2 ? 0.f : -INFINITY;
+        else {
+          v = nxt[st];
+          if (st + 1 < S) v = lae(v, nxt[st + 1]);
+          if ((st & 1) && st + 2 < S) v = lae(v, nxt[st + 2]);
+        }
+        v += y[j];
+        cur[st] = v;
+        if (st & 1) {  // token l = (st - 1) / 2: one state per token
+          const float occ = expf(al[j] + v - y[j] - ll);
+          gb[(long long)t * L + ((st - 1) >> 1)] = scale * (expf(y[j]) - occ);
+        }
+        y[j] = yn[j];
+        al[j] = aln[j];
+        if (t >= 2) {
+          yn[j] = emission(t - 2, st);
+          aln[j] = aw[(long long)(t - 2) * SW + st];
+        }
       }
     }
     __syncthreads();
@@ -210,10 +235,21 @@ int evmi_forward_sum_grad_f32(const float* logprob, const int* text_lens, const 
   if (!logprob || !text_lens || !mel_lens || !loss_per_item || !grad || !ws) return fail(EVMI_ERR_INVALID_ARG, "forward_sum_grad: null pointer");
   if (B <= 0 || T <= 0 || L <= 0) return fail(EVMI_ERR_INVALID_ARG, "forward_sum_grad: shape");
   if (ws_elems < evmi_forward_sum_grad_f32_ws_elems(B, T, L)) return fail(EVMI_ERR_INVALID_ARG, "forward_sum_grad: workspace too small");
-  const size_t lds = (size_t)((L + 1) + 2 * (2 * L + 1) + 8) * sizeof(float);
-  if (lds > 64 * 1024) return fail(EVMI_ERR_UNSUPPORTED, "forward_sum_grad: too many tokens");
-  hipLaunchKernelGGL(forward_sum_grad_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, logprob, text_lens, mel_lens, loss_per_item, grad,
-                     ws, ws + (long long)B * T * (2 * L + 1), B, T, L, blank_logprob, weight);
+  const size_t lds = (size_t)(2 * (2 * L + 1)) * sizeof(float);
+  if (2 * L + 1 > 4 * CTC_THREADS) return fail(EVMI_ERR_UNSUPPORTED, "forward_sum_grad: more than 1023 tokens");
+  hipStream_t s = (hipStream_t)stream;
+  float* lse = ws + (long long)B * T * (2 * L + 1);
+  hipLaunchKernelGGL(forward_sum_lse_kernel, dim3((unsigned)(((long long)B * T + 3) / 4)), dim3(256), 0, s, logprob, text_lens, mel_lens, lse, B, T, L,
+                     blank_logprob);
+  EVMI_LAUNCH_CHECK("forward_sum_lse");
+  const int ns = (2 * L + 1 + CTC_THREADS - 1) / CTC_THREADS;
+#define EVMI_CTC(NSV)                                                                                                                    \
+  hipLaunchKernelGGL(forward_sum_grad_kernel<NSV>, dim3(B), dim3(CTC_THREADS), lds, s, logprob, text_lens, mel_lens, loss_per_item, grad, ws, \
+                     lse, B, T, L, blank_logprob, weight)
+  if (ns == 1) EVMI_CTC(1);
+  else if (ns == 2) EVMI_CTC(2);
+  else EVMI_CTC(4);
+#undef EVMI_CTC
   EVMI_LAUNCH_CHECK("forward_sum_grad");
   return EVMI_OK;
 }

@@ -12,13 +12,23 @@ import torch  # noqa: E402
 from fs2_bench import forward_flops, synthetic_batch  # noqa: E402
 
 
-def training_batch(B=32, seed=1234, n_mels=80):
+def training_batch(B=32, seed=1234, n_mels=80, learn_alignment=True, device="cuda:0"):
+    """learn_alignment (the reference's default): mel + frame counts + beta-binomial priors + frame-level pitch / energy, the
+    durations come out of the aligner; otherwise durations and phone-level targets are part of the batch."""
     ids, lens, durs, T_i = synthetic_batch(B, seed)
     g = torch.Generator().manual_seed(seed + 1)
     T = int(T_i.max())
     mel = torch.randn(B, T, n_mels, generator=g).masked_fill((torch.arange(T)[None] >= T_i[:, None])[..., None], 0.0)
     L = ids.shape[1]
-    return dict(ids=ids, lens=lens, durations=durs, mel=mel, pitch=torch.randn(B, L, generator=g), energy=torch.randn(B, L, generator=g)), T_i
+    if not learn_alignment:
+        return dict(ids=ids, lens=lens, durations=durs, mel=mel, pitch=torch.randn(B, L, generator=g), energy=torch.randn(B, L, generator=g)), T_i
+    from everyvoice_amd.heavy import BetaBinomialInterpolator
+    interp = BetaBinomialInterpolator(device=device)
+    prior = torch.zeros(B, T, L, dtype=torch.float64)
+    for b in range(B):
+        prior[b, : T_i[b], : lens[b]] = interp(int(T_i[b]), int(lens[b])).cpu()
+    return dict(ids=ids, lens=lens, mel=mel, mel_lens=T_i, attn_prior=prior.to(device), pitch_frames=torch.randn(B, T, generator=g),
+                energy_frames=torch.randn(B, T, generator=g)), T_i
 
 
 def main():
@@ -26,8 +36,10 @@ def main():
 
     dev = torch.device("cuda:0")
     B = int(os.environ.get("EVMI_FS2_B", "32"))
-    tr = FastSpeech2Trainer(device=dev)
-    batch, T_i = training_batch(B)
+    from everyvoice_amd.fs2 import FastSpeech2ModelConfig
+    learn = os.environ.get("EVMI_FS2_LEARN_ALIGNMENT", "1") == "1"
+    tr = FastSpeech2Trainer(FastSpeech2ModelConfig(learn_alignment=learn), device=dev)
+    batch, T_i = training_batch(B, learn_alignment=learn, device=dev)
     print(f"parameters {tr.params.numel():,}")
     for _ in range(2):
         losses = tr.training_step(batch)
