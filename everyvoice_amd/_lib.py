@@ -82,10 +82,12 @@ SYMBOLS = {
     ),
     "evmi_gemm_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "evmi_conv1d_cbt_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
+    "evmi_conv1d_cbt_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
     "evmi_conv1d_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 6),
     "evmi_conv1d_cbt_f32_supported": (C.c_int, [C.c_int] * 9),
     "evmi_conv1d_dgrad_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv1d_dgrad_cbt_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
+    "evmi_conv1d_dgrad_cbt_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
     "evmi_conv1d_wgrad_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv1d_wgrad_cbt_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 11 + [C.c_void_p]),
     "evmi_fs2_embed_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),

@@ -57,6 +57,12 @@ struct ConvF32Args {
   int n_out_min;  // planning: shortest phase (most items per tile); 0 = n_out
   long long wf_phase_stride;
   int ph_pad[8], ph_nout[8], ph_off[8];
+  // bf16-operand mode (BF kernels): K runs over blocks of 16 channels at one tap; LDS still holds fp32 rows, the consumer
+  // gathers 8 channels per lane, rounds them to bf16 and feeds v_mfma_f32_32x32x16_bf16 (fp32 accumulation)
+  int bf;       // 1 = bf16 operands
+  int cblocks;  // ceil(cin_g / 16): 16-channel blocks of the weight fragments
+  int tj, nch;  // taps per step and steps per channel step (long kernels are split over the ring steps)
+  int xcd_remap;  // 1 = XCD-aware tile order (EVMI_F32_XCD=0 switches it off for A/B runs)
   int ablate;   // timing experiments only (EVMI_F32_ABLATE): 1 no input loads, 2 no weight loads, 4 no MFMA
   long long* tl;  // timing experiments only (EVMI_F32_TL): s_memtime stamps of workgroup (0, 0), [step][wave][4]
 };
@@ -135,7 +141,119 @@ __global__ __launch_bounds__(256) void wfrag_dgrad_kernel(const float* __restric
   }
 }
 
-template <int BM, int BN, int WM, int WN, int KS>
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// bf16 fragments (v_mfma_f32_32x32x16_bf16 A operand): one 1 KB fragment per (m-block, 16-channel block, tap); lane
+// (mi = lane & 31, kh = lane >> 5) holds the 8 channels cb*16 + kh*8 + 0..7 of row mb*32 + mi as four 32-bit words:
+//   wfb[(((g*MB + mb)*CB + cb)*k + j)*256 + lane*4 + q] = bf16x2(w[.][cb*16 + kh*8 + 2q][j], w[.][.. + 2q + 1][j])
+// grid (CB, groups*MB)
+__global__ __launch_bounds__(256) void wfrag_bf16_kernel(const float* __restrict__ w, unsigned* __restrict__ wf, int cout_g,
+                                                         int cin_g, int k, int MB, int CB) {
+  const int cb = blockIdx.x, gmb = blockIdx.y;
+  const int g = gmb / MB, mb = gmb - g * MB;
+  unsigned* dst = wf + ((long long)gmb * CB + cb) * k * 256;
+  for (int e = threadIdx.x; e < k * 256; e += 256) {
+    const int j = e >> 8, ln = (e >> 2) & 63, q = e & 3;
+    const int m = mb * 32 + (ln & 31), ci = cb * 16 + (ln >> 5) * 8 + 2 * q;
+    float lo = 0.f, hi = 0.f;
+    if (m < cout_g) {
+      const float* wr = w + (long long)(g * cout_g + m) * cin_g * k + j;
+      if (ci < cin_g) lo = wr[(long long)ci * k];
+      if (ci + 1 < cin_g) hi = wr[(long long)(ci + 1) * k];
+    }
+    dst[e] = pack_bf16x2(lo, hi);
+  }
+}
+
+// bf16 fragments of the polyphase input-gradient convolutions (see wfrag_dgrad_kernel): rows = x channels, K = dy channels.
+// MB = ceil(cin_g / 32), CB = ceil(cout_g / 16); grid (CB, groups*MB, phases)
+__global__ __launch_bounds__(256) void wfrag_dgrad_bf16_kernel(const float* __restrict__ w, unsigned* __restrict__ wfd, int cout_g,
+                                                               int cin_g, int k, int stride, int M, int MB, int CB,
+                                                               long long phase_stride) {
+  const int cb = blockIdx.x, gmb = blockIdx.y, phi = blockIdx.z;
+  const int g = gmb / MB, mb = gmb - g * MB;
+  const int m_phi = (k - phi + stride - 1) / stride, lead = M - m_phi;
+  unsigned* dst = wfd + phi * phase_stride + ((long long)gmb * CB + cb) * M * 256;
+  for (int e = threadIdx.x; e < M * 256; e += 256) {
+    const int m = e >> 8, ln = (e >> 2) & 63, q = e & 3;
+    const int ci = mb * 32 + (ln & 31), co = cb * 16 + (ln >> 5) * 8 + 2 * q;
+    float lo = 0.f, hi = 0.f;
+    if (ci < cin_g && m >= lead) {
+      const int j = phi + stride * (m_phi - 1 - (m - lead));
+      if (co < cout_g) lo = w[((long long)(g * cout_g + co) * cin_g + ci) * k + j];
+      if (co + 1 < cout_g) hi = w[((long long)(g * cout_g + co + 1) * cin_g + ci) * k + j];
+    }
+    dst[e] = pack_bf16x2(lo, hi);
+  }
+}
+
+// One K block (16 channels at one tap) of a wave tile in bf16-operand mode: A fragments are 16-byte LDS reads, B fragments
+// 8 fp32 reads (8 channel rows of the staged window at this lane's column) rounded to bf16.
+template <int MT, int NT>
+struct BfRaw {
+  bf16x8 a[MT];
+  float x[NT][8];
+};
+template <int MT, int NT>
+__device__ __forceinline__ void bf_load(BfRaw<MT, NT>& f, const float* __restrict__ sm, const int (&abase)[MT], const int (&xbase)[NT],
+                                        int off_a, int off_x, int xrow) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) f.a[mt] = *reinterpret_cast<const bf16x8*>(sm + abase[mt] + off_a);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const float* col = sm + xbase[nt] + off_x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.x[nt][i] = col[i * xrow];
+  }
+}
+// K blocks [q_lo, q_hi) of a staged step (tjc taps per 16-channel block).  The LDS reads of block q+1 are issued before the
+// MFMAs of block q and converted after them, so the matrix pipe runs while the next operands arrive (one loop, no early
+// exits: the accumulators stay in place).  The block after the last one re-reads the last (in-bounds, unused).
+template <int MT, int NT>
+__device__ __forceinline__ void bf_consume(const float* __restrict__ sm, const int (&abase)[MT], const int (&xbase)[NT], int base,
+                                           int q_lo, int q_hi, int tjc, int j0, int d, int xrow, f32x16 (&acc)[MT][NT]) {
+  if (q_lo >= q_hi) return;
+  int cb = q_lo / tjc, jj = q_lo - cb * tjc;
+  int off_a = base + q_lo * 256;
+  int off_x = base + cb * 16 * xrow + (j0 + jj) * d;
+  BfRaw<MT, NT> nx;
+  bf_load(nx, sm, abase, xbase, off_a, off_x, xrow);
+  bf16x8 fa[MT], fb[NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) fa[mt] = nx.a[mt];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fb[nt][i] = (bf16_t)nx.x[nt][i];
+#pragma unroll 2
+  for (int q = q_lo; q < q_hi; ++q) {
+    if (q + 1 < q_hi) {  // scalar bookkeeping only
+      ++jj; off_a += 256; off_x += d;
+      if (jj == tjc) { jj = 0; off_x += 16 * xrow - tjc * d; }
+    }
+    bf_load(nx, sm, abase, xbase, off_a, off_x, xrow);
+    __builtin_amdgcn_sched_barrier(0);  // all LDS reads of block q+1 are in flight before the MFMAs of block q issue
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) fa[mt] = nx.a[mt];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fb[nt][i] = (bf16_t)nx.x[nt][i];
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int KS, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a) {
   constexpr int NTHREADS = 256;
   static_assert(WM * WN * KS == 4, "four waves");
@@ -145,13 +263,27 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
+
+  // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (private L2s); give every XCD a
+  // contiguous range of the (m-tile major) tile list instead, so the workgroups that share weight fragments share an L2
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd_remap) {
+    const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+    if (nwg >= 16) {
+      const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+      const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+      by = L / gridDim.x;
+      bx = L - by * gridDim.x;
+    }
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ks = wave / (WM * WN), wmn = wave % (WM * WN), wm = wmn / WN, wn = wmn % WN;
   const int kh = lane >> 5, ln = lane & 31;
-  const int g = blockIdx.y / a.mtiles_per_group, mt_idx = blockIdx.y % a.mtiles_per_group;
+  const int g = by / a.mtiles_per_group, mt_idx = by % a.mtiles_per_group;
   const int co0 = g * a.cout_g + mt_idx * BM;
   const int k = a.k, s = a.stride, d = a.dil, xrow = a.xrow, ps = a.ps, pieces = a.pieces;
-  const int nqa_pad = (ps * k + 3) & ~3;      // fragments per m-block per slot (whole 1 KB quads)
+  const int nblk_step = ps >> 3;              // BF: 16-channel blocks per channel step
+  const int nqa_pad = BF ? nblk_step * a.tj * 4 : (ps * k + 3) & ~3;  // 256-byte units per m-block per slot (whole 1 KB quads)
   const int a_floats = MBT * nqa_pad * 64;    // weight part of a slot
   const int halo = (k - 1) * d + 1;
   const int gap = max(halo - s, 0);  // extra columns between the staged segments of consecutive items
@@ -160,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   if (n_out <= 0) return;  // a phase without outputs
   const float* wf_ = a.wf + (long long)ph * a.wf_phase_stride;
   const long long n_total = (long long)a.B * n_out;
-  const long long n0 = (long long)blockIdx.x * BN;
+  const long long n0 = (long long)bx * BN;
   if (n0 >= n_total) return;  // tiles past a (shorter) phase
   const int b_first = (int)(n0 / n_out);
   const int to_first = (int)(n0 - (long long)b_first * n_out);
@@ -178,16 +310,16 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
       const int bb = (int)(n / n_out);
       col_b[nt] = bb;
       col_to[nt] = (int)(n - (long long)bb * n_out);
-      xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * gap;
+      xbase[nt] = a_floats + kh * (BF ? 8 : 1) * xrow + c * s + (bb - b_first) * gap;
     } else {
       col_b[nt] = -1;
       col_to[nt] = 0;
-      xbase[nt] = a_floats + kh * xrow;  // finite staged data; the column is never stored
+      xbase[nt] = a_floats + kh * (BF ? 8 : 1) * xrow;  // finite staged data; the column is never stored
     }
   }
   int abase[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) abase[mt] = (wm * MT + mt) * nqa_pad * 64 + lane;
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = (wm * MT + mt) * nqa_pad * 64 + (BF ? lane * 4 : lane);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -223,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
     lds_barrier();
   }
 
-  const int nsteps = (a.pairs + ps - 1) / ps;
+  const int nsteps = ((a.pairs + ps - 1) / ps) * (BF ? a.nch : 1);
   if (a.ablate) {  // experiments read uninitialised LDS otherwise
     for (int v = tid; v < a.nst * a.stage; v += NTHREADS) smem[v] = 0.f;
     lds_barrier();
@@ -232,15 +364,21 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   // ---- loader: every wave brings its share of the operands of step t -> ring slot t%3 (LDS-direct, no registers).
   // Weights: the 1 KB quads of the step round-robin over the waves (SGPR base + lane offset addressing);
   // inputs: rows round-robin over the waves.  Returns the number of loads this wave issued. ----
-  const long long mb_stride = (long long)a.pairs * k * 64;
+  const long long mb_stride = BF ? (long long)a.cblocks * k * 256 : (long long)a.pairs * k * 64;
   const float* wf_tile = wf_ + (long long)(g * a.mblocks + mt_idx * MBT) * mb_stride;
   const int mb_last = a.mblocks - 1 - mt_idx * MBT;  // m-blocks past the group re-read the last one (never stored)
   const unsigned lane16 = lane * 16;
   auto issue = [&](int t, int slot) -> int {
-    const int c0 = t * 2 * ps;
+    const int tc = BF ? t / a.nch : t;   // channel step; BF: tap chunk t % nch of it
+    const int c0 = tc * 2 * ps;
     const int cbcur = min(2 * ps, a.cin_g - c0);
     const int pairs_cur = (cbcur + 1) >> 1;
-    const int nquads = (pairs_cur * k + 3) >> 2;  // whole quads: the tail fragments belong to the next step (or the slack)
+    const int nblk_cur = (cbcur + 15) >> 4;
+    const int j0 = BF ? (t - tc * a.nch) * a.tj : 0;
+    // f32: whole quads, the tail fragments belong to the next step (or the slack); BF: one 1 KB fragment per (block, tap)
+    const int nquads = BF ? nblk_cur * min(a.tj, k - j0) : (pairs_cur * k + 3) >> 2;
+    const long long a_step = BF ? ((long long)tc * nblk_step * k + j0) * 256 : (long long)t * ps * k * 64;
+    const int nrows = BF ? 16 * nblk_cur : 2 * pairs_cur;
     float* sa = smem + slot * a.stage;
     float* sx = sa + a_floats;
     int issued = 0;
@@ -248,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
       int u = wave;  // unit = (m-block, quad), round-robin over the four waves
 #pragma unroll
       for (int mbi = 0; mbi < MBT; ++mbi) {
-        const char* src = reinterpret_cast<const char*>(wf_tile + min(mbi, mb_last) * mb_stride + (long long)t * ps * k * 64);
+        const char* src = reinterpret_cast<const char*>(wf_tile + min(mbi, mb_last) * mb_stride + a_step);
         float* dst = sa + mbi * nqa_pad * 64;
         for (; u < nquads; u += 4) {
           lds_direct_b128(reinterpret_cast<const float*>(src + (size_t)u * 1024 + lane16), dst + u * 256);
@@ -260,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
     if (!(a.ablate & 1)) {
       const float* xr = xgrp + (long long)(c0 + wave) * ch_stride;
       float* dstrow = sx + wave * xrow;
-      for (int r = wave; r < 2 * pairs_cur; r += 4) {
+      for (int r = wave; r < nrows; r += 4) {
         const bool zero_row = r >= cbcur;
 #pragma unroll
         for (int pi = 0; pi < F32_PMAX; ++pi) {
@@ -284,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
   for (int t = 0; t < nsteps; ++t) {
     slot = slot + 1 == nst ? 0 : slot + 1;       // t % nst
     const int slot_ahead = slot == 0 ? nst - 1 : slot - 1;  // (t + nst - 1) % nst: the slot step t-1 just released
-    const bool stamp = a.tl && blockIdx.x == 0 && blockIdx.y == 0 && t < 24;
+    const bool stamp = a.tl && bx == 0 && by == 0 && t < 24;
     long long* tl = a.tl + (t * 4 + wave) * 4;
     if (stamp && lane == 0) tl[0] = __builtin_readcyclecounter();
     wait_vmcnt_le(n_next);  // step t has landed (this wave's part); step t+1 may still be in flight
@@ -295,6 +433,14 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
       n_next = nst == 3 ? issued : 0;  // two slots: the step just issued is the next one consumed: wait for all of it
     }
     if (stamp && lane == 0) tl[2] = __builtin_readcyclecounter();
+    if (BF) {
+      const int tc = t / a.nch, j0 = (t - tc * a.nch) * a.tj, tjc = min(a.tj, k - j0);
+      const int nkb = ((min(2 * ps, a.cin_g - tc * 2 * ps) + 15) >> 4) * tjc;
+      const int q_lo = KS == 1 ? 0 : (ks * nkb) / KS, q_hi = KS == 1 ? nkb : ((ks + 1) * nkb) / KS;
+      if (!(a.ablate & 4)) bf_consume<MT, NT>(smem, abase, xbase, slot * a.stage, q_lo, q_hi, tjc, j0, d, xrow, acc);
+      if (stamp && lane == 0) tl[3] = __builtin_readcyclecounter();
+      continue;
+    }
     const int cbcur = min(2 * ps, a.cin_g - t * 2 * ps);
     const int nq_all = ((cbcur + 1) >> 1) * k;
     const int q_lo = KS == 1 ? 0 : (ks * nq_all) / KS;
@@ -415,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
 // step is then KS times longer than a step of the shared kernel above for the same LDS (the per-step barrier + load
 // issue phase was what limited these tiles: timeline stamps), and the load issue of one wave overlaps the
 // MFMAs of the waves of the other co-resident workgroup.
-template <int BM, int BNW, int NWN, int KS>
+template <int BM, int BNW, int NWN, int KS, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Args a) {
   static_assert(NWN * KS == 4, "four waves");
   constexpr int MT = BM / 32, NT = BNW / 32;
@@ -425,13 +571,27 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
+
+  // XCD-aware tile order: the dispatcher deals workgroups round-robin over the 8 XCDs (private L2s); give every XCD a
+  // contiguous range of the (m-tile major) tile list instead, so the workgroups that share weight fragments share an L2
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd_remap) {
+    const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+    if (nwg >= 16) {
+      const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+      const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+      by = L / gridDim.x;
+      bx = L - by * gridDim.x;
+    }
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ks = wave / NWN, wn = wave % NWN;
   const int kh = lane >> 5, ln = lane & 31;
-  const int g = blockIdx.y / a.mtiles_per_group, mt_idx = blockIdx.y % a.mtiles_per_group;
+  const int g = by / a.mtiles_per_group, mt_idx = by % a.mtiles_per_group;
   const int co0 = g * a.cout_g + mt_idx * BM;
   const int k = a.k, s = a.stride, d = a.dil, xrow = a.xrow, ps = a.ps, pieces = a.pieces;
-  const int nqa_pad = (ps * k + 3) & ~3;
+  const int nblk_step = ps >> 3;
+  const int nqa_pad = BF ? nblk_step * a.tj * 4 : (ps * k + 3) & ~3;
   const int a_floats = MBT * nqa_pad * 64;
   const int halo = (k - 1) * d + 1;
   const int gap = max(halo - s, 0);  // extra columns between the staged segments of consecutive items
@@ -440,8 +600,8 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
   if (n_out <= 0) return;  // a phase without outputs
   const float* wf_ = a.wf + (long long)ph * a.wf_phase_stride;
   const long long n_total = (long long)a.B * n_out;
-  if ((long long)blockIdx.x * BN >= n_total) return;  // tiles past a (shorter) phase
-  const long long n0 = (long long)blockIdx.x * BN + wn * BNW;  // first column of this wave
+  if ((long long)bx * BN >= n_total) return;  // tiles past a (shorter) phase
+  const long long n0 = (long long)bx * BN + wn * BNW;  // first column of this wave
   const bool wave_live = n0 < n_total;
   const int b_first = wave_live ? (int)(n0 / n_out) : 0;
   const int to_first = wave_live ? (int)(n0 - (long long)b_first * n_out) : 0;
@@ -459,16 +619,16 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
       const int bb = (int)(n / n_out);
       col_b[nt] = bb;
       col_to[nt] = (int)(n - (long long)bb * n_out);
-      xbase[nt] = a_floats + kh * xrow + c * s + (bb - b_first) * gap;
+      xbase[nt] = a_floats + kh * (BF ? 8 : 1) * xrow + c * s + (bb - b_first) * gap;
     } else {
       col_b[nt] = -1;
       col_to[nt] = 0;
-      xbase[nt] = a_floats + kh * xrow;
+      xbase[nt] = a_floats + kh * (BF ? 8 : 1) * xrow;
     }
   }
   int abase[MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) abase[mt] = mt * nqa_pad * 64 + lane;
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = mt * nqa_pad * 64 + (BF ? lane * 4 : lane);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -504,22 +664,27 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
-  const int nsteps = (a.pairs + ps - 1) / ps;
-  const long long mb_stride = (long long)a.pairs * k * 64;
+  const int nsteps = ((a.pairs + ps - 1) / ps) * (BF ? a.nch : 1);
+  const long long mb_stride = BF ? (long long)a.cblocks * k * 256 : (long long)a.pairs * k * 64;
   const float* wf_tile = wf_ + (long long)(g * a.mblocks + mt_idx * MBT) * mb_stride;
   const int mb_last = a.mblocks - 1 - mt_idx * MBT;
   const unsigned lane16 = lane * 16;
   auto issue = [&](int t, int slot) -> int {
-    const int c0 = t * 2 * ps;
+    const int tc = BF ? t / a.nch : t;
+    const int c0 = tc * 2 * ps;
     const int cbcur = min(2 * ps, a.cin_g - c0);
     const int pairs_cur = (cbcur + 1) >> 1;
-    const int nquads = (pairs_cur * k + 3) >> 2;
+    const int nblk_cur = (cbcur + 15) >> 4;
+    const int j0 = BF ? (t - tc * a.nch) * a.tj : 0;
+    const int nquads = BF ? nblk_cur * min(a.tj, k - j0) : (pairs_cur * k + 3) >> 2;
+    const long long a_step = BF ? ((long long)tc * nblk_step * k + j0) * 256 : (long long)t * ps * k * 64;
+    const int nrows = BF ? 16 * nblk_cur : 2 * pairs_cur;
     float* sa = wsm + slot * a.stage;
     float* sx = sa + a_floats;
     int issued = 0;
 #pragma unroll
     for (int mbi = 0; mbi < MBT; ++mbi) {
-      const char* src = reinterpret_cast<const char*>(wf_tile + min(mbi, mb_last) * mb_stride + (long long)t * ps * k * 64);
+      const char* src = reinterpret_cast<const char*>(wf_tile + min(mbi, mb_last) * mb_stride + a_step);
       float* dst = sa + mbi * nqa_pad * 64;
       for (int u = 0; u < nquads; ++u) {
         lds_direct_b128(reinterpret_cast<const float*>(src + (size_t)u * 1024 + lane16), dst + u * 256);
@@ -528,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
     }
     const float* xr = xgrp + (long long)c0 * ch_stride;
     float* dstrow = sx;
-    for (int r = 0; r < 2 * pairs_cur; ++r) {
+    for (int r = 0; r < nrows; ++r) {
       const bool zero_row = r >= cbcur;
 #pragma unroll
       for (int pi = 0; pi < F32_PMAX; ++pi) {
@@ -550,6 +715,13 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
       // the next step of this wave goes to the other slot (its previous contents were consumed one iteration ago)
       const int n_next = t + KS < nsteps ? issue(t + KS, slot ^ 1) : 0;
       wait_vmcnt_le(n_next);  // step t has landed; step t + KS may still be in flight
+      if (BF) {
+        const int tc = t / a.nch, j0 = (t - tc * a.nch) * a.tj, tjc = min(a.tj, k - j0);
+        const int nkb = ((min(2 * ps, a.cin_g - tc * 2 * ps) + 15) >> 4) * tjc;
+        bf_consume<MT, NT>(wsm, abase, xbase, slot * a.stage, 0, nkb, tjc, j0, d, xrow, acc);
+        slot ^= 1;
+        continue;
+      }
       const int cbcur = min(2 * ps, a.cin_g - t * 2 * ps);
       const int nq = ((cbcur + 1) >> 1) * k;
       int j = 0;
@@ -683,7 +855,9 @@ static int pick_tile(const ConvF32Args& a, int groups) {
 
 static long long wfrag_elems(int c_out, int c_in, int k, int groups) {
   const int cout_g = c_out / groups, cin_g = c_in / groups;
-  return (long long)groups * ((cout_g + 31) / 32) * ((cin_g + 1) / 2) * k * 64 + 4 * 64;  // + slack: the loader reads whole quads
+  const long long f32 = (long long)groups * ((cout_g + 31) / 32) * ((cin_g + 1) / 2) * k * 64 + 4 * 64;  // + slack: the loader reads whole quads
+  const long long bf = (long long)groups * ((cout_g + 31) / 32) * ((cin_g + 15) / 16) * k * 256;  // bf16 fragments (32-bit words)
+  return std::max(f32, bf);
 }
 
 struct F32Plan { int ti; size_t lds; dim3 grid; bool wp; };
@@ -694,6 +868,8 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   if ((long long)a.B * a.t_in >= (1LL << 29)) return "B*t_in >= 2^29";
   a.mblocks = (a.cout_g + 31) / 32;
   a.pairs = (a.cin_g + 1) / 2;
+  a.cblocks = (a.cin_g + 15) / 16;
+  a.tj = a.k; a.nch = 1;
   const int halo = (a.k - 1) * a.dil + 1;
   auto xrow_of = [&](int bn) {
     const int nmin = a.n_out_min > 0 ? a.n_out_min : a.n_out;
@@ -702,12 +878,20 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   };
   static const bool use_wp = env_int("EVMI_F32_WP", 1) != 0;  // wave-private rings for the K-split tiles (A/B switch)
   int ti = pick_tile(a, groups);
+  if (a.bf) {
+    const int ft = env_int("EVMI_BF_TILE", -1);
+    if (ft >= 0 && ft < kNumTiles) ti = ft;
+  }
   // wave-private rings (K-split tiles): every wave stages only its own column slice, but a workgroup holds 8 slots:
   // taken where one step of one wave fits 1/8 of the LDS budget; long kernels (the 41-tap scale-discriminator layers)
   // keep the shared ring
   auto wp_fits = [&](int t) {
     if (!use_wp || kTiles[t].ks <= 1) return false;
     const int xr = xrow_of(kTiles[t].bn / (4 / kTiles[t].ks));
+    if (a.bf) {  // one 16-channel block with all its taps per wave step
+      const size_t stb = (size_t)((kTiles[t].bm / 32) * a.k * 256 + 16 * xr + 4) * sizeof(float);
+      return xr <= 64 * F32_PMAX && 8 * stb <= 78 * 1024;
+    }
     const size_t st1 = (size_t)(((kTiles[t].bm / 32) * ((a.k + 3) & ~3) * 64 + 2 * xr + 2 * xr + 3) & ~3) * sizeof(float);
     return xr <= 64 * F32_PMAX && 8 * st1 <= 78 * 1024;
   };
@@ -719,6 +903,47 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   a.xrow = xrow_of(wp ? bn / (4 / ks) : bn);
   a.pieces = (a.xrow + 63) / 64;
   if (a.pieces > F32_PMAX) return "input span too large (very short rows with a long kernel)";
+  if (a.bf && a.cin_g < 16) return "fewer than 16 channels per group";  // half-empty K blocks: the fp32 kernel is faster
+  if (a.bf) {
+    // bf16-operand steps: ps = 8 * (16-channel blocks per step); long kernels split their taps over ring steps (tj per step)
+    auto stage_bf = [&](int ps, int tj) { return ((bm / 32) * (ps / 8) * tj * 256 + 2 * ps * a.xrow + 4) & ~3; };
+    auto lds_bf = [&](int ps, int tj, int nst) { return (size_t)(wp ? 8 : nst) * stage_bf(ps, tj) * sizeof(float); };
+    const size_t two_wg = 78 * 1024, one_wg = 160 * 1024;
+    int ps = 8, tj = a.k, nst = 2;
+    if (lds_bf(8, a.k, 2) <= two_wg) {
+      const int ps_cap = std::min(64, ((a.pairs + 7) / 8) * 8);
+      // deepen the step while it fits two workgroups per CU; K-split tiles want at least two K blocks per wave and step
+      while (ps * 2 <= ps_cap && lds_bf(ps * 2, a.k, 2) <= two_wg && (wp ? (a.pairs + 2 * ps - 1) / (2 * ps) >= ks : (ps < 16 || (ps / 8) * a.k < 2 * ks)))
+        ps *= 2;
+      if (!wp && lds_bf(ps, a.k, 3) <= two_wg) nst = 3;
+    } else if (!wp && env_int("EVMI_BF_CHUNK", 0)) {  // tap-chunked steps re-stage the input window per chunk: measured slower than fp32
+      const size_t budget = lds_bf(8, 1, 2) <= two_wg ? two_wg : one_wg;
+      while (tj > 1 && lds_bf(8, tj, 2) > budget) --tj;
+      if (lds_bf(8, tj, 2) > budget) return "LDS budget";
+      const int nch = (a.k + tj - 1) / tj;
+      tj = (a.k + nch - 1) / nch;  // balanced chunks
+    } else {
+      return "LDS budget";
+    }
+    {  // tuning overrides (experiments)
+      const int fps = env_int("EVMI_BF_PS", 0), fnst = env_int("EVMI_BF_NST", 0);
+      if (fps >= 8 && fps % 8 == 0 && tj == a.k) ps = std::min(fps, ((a.pairs + 7) / 8) * 8);
+      if (!wp && (fnst == 2 || fnst == 3)) nst = fnst;
+    }
+    a.ps = ps; a.tj = tj; a.nch = (a.k + tj - 1) / tj; a.nst = nst;
+    a.stage = stage_bf(ps, tj);
+    size_t lds = lds_bf(ps, tj, nst);
+    lds = std::max(lds, (size_t)(ks - 1) * bm * bn * sizeof(float));
+    lds = std::max(lds, (size_t)a.pieces * 64 * sizeof(int));
+    if (lds > one_wg) return "LDS budget";
+    pl.wp = wp;
+    const long long n_total = (long long)a.B * a.n_out;
+    if ((n_total + bn - 1) / bn > 0x7fffffffLL || groups * a.mtiles_per_group > 65535 || groups * a.mblocks > 65535) return "grid limits";
+    pl.ti = ti;
+    pl.lds = lds;
+    pl.grid = dim3((unsigned)((n_total + bn - 1) / bn), groups * a.mtiles_per_group, 1);
+    return nullptr;
+  }
   auto stage_floats = [&](int ps) {
     return ((bm / 32) * ((ps * a.k + 3) & ~3) * 64 + 2 * ps * a.xrow + 2 * a.xrow + 3) & ~3;  // + slack for the read-ahead past a step
   };
@@ -761,6 +986,8 @@ static int dispatch_conv_f32(ConvF32Args a, const F32Plan& pl, hipStream_t strea
   grid.z = a.phases;
   const int bm = kTiles[ti].bm, bn = kTiles[ti].bn, ks = kTiles[ti].ks;
   a.ablate = env_int("EVMI_F32_ABLATE", 0);
+  static const int xcd_remap = env_int("EVMI_F32_XCD", 1);
+  a.xcd_remap = xcd_remap;
   a.tl = nullptr;
   const bool want_tl = env_int("EVMI_F32_TL", 0) != 0;
   if (want_tl) {
@@ -768,24 +995,34 @@ static int dispatch_conv_f32(ConvF32Args a, const F32Plan& pl, hipStream_t strea
     EVMI_HIP_CHECK(hipMemsetAsync(a.tl, 0, 24 * 4 * 4 * sizeof(long long), stream));
   }
 
-  static thread_local size_t configured[2 * kNumTiles] = {0};
+  static thread_local size_t configured[4 * kNumTiles] = {0};
+#define EVMI_F32_LAUNCH1(BM, BN, WM, WN, KS, BFM, IDX)                                                             \
+  {                                                                                                                \
+    if (lds > configured[IDX]) {                                                                                   \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_cbt_f32_mfma_kernel<BM, BN, WM, WN, KS, BFM>,           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
+      configured[IDX] = lds;                                                                                       \
+    }                                                                                                              \
+    hipLaunchKernelGGL((conv_cbt_f32_mfma_kernel<BM, BN, WM, WN, KS, BFM>), grid, dim3(256), lds, stream, a);      \
+  }
 #define EVMI_F32_LAUNCH(BM, BN, WM, WN, KS, IDX)                                                                   \
   {                                                                                                                \
-    if (lds > configured[IDX]) {                                                                                   \
-      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_cbt_f32_mfma_kernel<BM, BN, WM, WN, KS>,                \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-      configured[IDX] = lds;                                                                                       \
-    }                                                                                                              \
-    hipLaunchKernelGGL((conv_cbt_f32_mfma_kernel<BM, BN, WM, WN, KS>), grid, dim3(256), lds, stream, a);           \
+    if (a.bf) EVMI_F32_LAUNCH1(BM, BN, WM, WN, KS, true, IDX + 2 * kNumTiles)                                      \
+    else EVMI_F32_LAUNCH1(BM, BN, WM, WN, KS, false, IDX)                                                          \
   }
-#define EVMI_F32_LAUNCH_WP(BM, BNW, NWN, KS, IDX)                                                                   \
+#define EVMI_F32_LAUNCH_WP1(BM, BNW, NWN, KS, BFM, IDX)                                                            \
   {                                                                                                                \
     if (lds > configured[IDX]) {                                                                                   \
-      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_cbt_f32_mfma_wp_kernel<BM, BNW, NWN, KS>,               \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_cbt_f32_mfma_wp_kernel<BM, BNW, NWN, KS, BFM>,          \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
       configured[IDX] = lds;                                                                                       \
     }                                                                                                              \
-    hipLaunchKernelGGL((conv_cbt_f32_mfma_wp_kernel<BM, BNW, NWN, KS>), grid, dim3(256), lds, stream, a);          \
+    hipLaunchKernelGGL((conv_cbt_f32_mfma_wp_kernel<BM, BNW, NWN, KS, BFM>), grid, dim3(256), lds, stream, a);     \
+  }
+#define EVMI_F32_LAUNCH_WP(BM, BNW, NWN, KS, IDX)                                                                  \
+  {                                                                                                                \
+    if (a.bf) EVMI_F32_LAUNCH_WP1(BM, BNW, NWN, KS, true, IDX + 2 * kNumTiles)                                     \
+    else EVMI_F32_LAUNCH_WP1(BM, BNW, NWN, KS, false, IDX)                                                         \
   }
   if (pl.wp) {
     switch (ti) {
@@ -804,7 +1041,9 @@ static int dispatch_conv_f32(ConvF32Args a, const F32Plan& pl, hipStream_t strea
     }
   }
 #undef EVMI_F32_LAUNCH_WP
+#undef EVMI_F32_LAUNCH_WP1
 #undef EVMI_F32_LAUNCH
+#undef EVMI_F32_LAUNCH1
   EVMI_LAUNCH_CHECK("conv_cbt_f32_mfma");
   if (want_tl) {  // stamps of workgroup (0,0): per step and wave: arrive, past barrier, loads issued, MFMAs done (100 MHz ticks)
     long long h[24 * 4 * 4];
@@ -842,8 +1081,12 @@ int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, lon
   const long long wf_total = wfrag_elems(a.cout_g * groups, a.cin_g * groups, a.k, groups);
   if (!wfrag_ws || wfrag_ws_elems < wf_total || (reinterpret_cast<uintptr_t>(wfrag_ws) & 15))
     return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_f32_mfma: weight-fragment workspace missing, too small or unaligned");
-  hipLaunchKernelGGL(wfrag_kernel, dim3(a.pairs, groups * a.mblocks), dim3(256), 0, stream, w, wfrag_ws, a.cout_g, a.cin_g,
-                     a.k, a.mblocks, a.pairs);
+  if (a.bf)
+    hipLaunchKernelGGL(wfrag_bf16_kernel, dim3(a.cblocks, groups * a.mblocks), dim3(256), 0, stream, w,
+                       reinterpret_cast<unsigned*>(wfrag_ws), a.cout_g, a.cin_g, a.k, a.mblocks, a.cblocks);
+  else
+    hipLaunchKernelGGL(wfrag_kernel, dim3(a.pairs, groups * a.mblocks), dim3(256), 0, stream, w, wfrag_ws, a.cout_g, a.cin_g,
+                       a.k, a.mblocks, a.pairs);
   a.wf = wfrag_ws;
   a.phases = 1; a.wf_phase_stride = 0;
   a.ph_pad[0] = a.pad; a.ph_nout[0] = a.n_out; a.ph_off[0] = a.out_offset;
@@ -853,7 +1096,8 @@ int launch_conv_cbt_f32_mfma(ConvF32Args a, const float* w, float* wfrag_ws, lon
 // Input gradient of y = conv1d(x, w, stride, pad, dil, groups): dx [c_in][B][t_in] from dy [c_out][B][t_out], all phases in
 // one launch (grid.z).  Strided layers must not be dilated.
 static const char* plan_dgrad(int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
-                              ConvF32Args& a, F32Plan& pl) {
+                              ConvF32Args& a, F32Plan& pl, int bf = 0) {
+  a.bf = bf;
   if (groups <= 0 || c_in <= 0 || c_out <= 0 || c_in % groups || c_out % groups) return "bad shape";
   if (stride > 1 && dil != 1) return "strided and dilated";
   if (stride > 8) return "stride above 8";
@@ -884,17 +1128,21 @@ static const char* plan_dgrad(int B, int c_in, int t_in, int c_out, int t_out, i
 }
 
 int launch_conv_dgrad_f32_mfma(const float* dy, const float* w, float* dx, float* ws, long long ws_elems, int B, int c_in, int t_in,
-                               int c_out, int t_out, int k, int stride, int pad, int dil, int groups, hipStream_t stream) {
+                               int c_out, int t_out, int k, int stride, int pad, int dil, int groups, hipStream_t stream, int bf = 0) {
   ConvF32Args a = {};
   F32Plan pl;
-  if (const char* why = plan_dgrad(B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups, a, pl))
+  if (const char* why = plan_dgrad(B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups, a, pl, bf))
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_dgrad_f32_mfma: ") + why);
   const long long per_phase = wfrag_elems(c_in, c_out, a.k, groups);  // dy channels in, x channels out
   if (!ws || ws_elems < per_phase * a.phases || (reinterpret_cast<uintptr_t>(ws) & 15))
     return fail(EVMI_ERR_INVALID_ARG, "conv_dgrad_f32_mfma: workspace missing, too small or unaligned");
   if (a.pairs > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_dgrad_f32_mfma: grid limits");
-  hipLaunchKernelGGL(wfrag_dgrad_kernel, dim3(a.pairs, groups * a.mblocks, a.phases), dim3(256), 0, stream, w, ws, c_out / groups,
-                     c_in / groups, k, stride, a.k, a.mblocks, a.pairs, per_phase);
+  if (bf)
+    hipLaunchKernelGGL(wfrag_dgrad_bf16_kernel, dim3(a.cblocks, groups * a.mblocks, a.phases), dim3(256), 0, stream, w,
+                       reinterpret_cast<unsigned*>(ws), c_out / groups, c_in / groups, k, stride, a.k, a.mblocks, a.cblocks, per_phase);
+  else
+    hipLaunchKernelGGL(wfrag_dgrad_kernel, dim3(a.pairs, groups * a.mblocks, a.phases), dim3(256), 0, stream, w, ws, c_out / groups,
+                       c_in / groups, k, stride, a.k, a.mblocks, a.pairs, per_phase);
   a.x = dy; a.y = dx; a.wf = ws; a.wf_phase_stride = per_phase;
   return dispatch_conv_f32(a, pl, stream);
 }
@@ -939,7 +1187,22 @@ int evmi_conv1d_dgrad_cbt_f32(const float* dy_dev, const float* w_dev, float* dx
                                     (hipStream_t)stream);
 }
 
-int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
+int evmi_conv1d_dgrad_cbt_bf16(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems, int B,
+                               int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
+                               void* stream) {
+  if (!dy_dev || !w_dev || !dx_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16: null pointer");
+  {  // shapes the bf16-operand staging does not fit run on the fp32 matrix cores
+    ConvF32Args a = {};
+    F32Plan pl;
+    if (plan_dgrad(B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups, a, pl, 1))
+      return launch_conv_dgrad_f32_mfma(dy_dev, w_dev, dx_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, t_out, k, stride, pad, dil,
+                                        groups, (hipStream_t)stream, 0);
+  }
+  return launch_conv_dgrad_f32_mfma(dy_dev, w_dev, dx_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups,
+                                    (hipStream_t)stream, 1);
+}
+
+static int conv1d_cbt_any(int bf, const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
                         float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
                         int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups, int out_stride,
                         int out_offset, int accumulate, int act, float act_param, void* stream) {
@@ -960,7 +1223,29 @@ int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bia
   a.out_stride = out_stride; a.out_offset = out_offset; a.accumulate = accumulate; a.mtiles_per_group = 1;
   a.act = act; a.act_param = act_param;
   if (act < 0 || act > 4 || (act && accumulate)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_f32: activation (0..4, not with accumulate)");
+  if (bf) {  // shapes the bf16-operand staging does not fit run on the fp32 matrix cores
+    ConvF32Args probe = a;
+    probe.bf = 1;
+    F32Plan pl;
+    if (plan_conv_f32(probe, groups, pl) == nullptr) a.bf = 1;
+  }
   return launch_conv_cbt_f32_mfma(a, w_dev, wfrag_ws_dev, wfrag_ws_elems, groups, (hipStream_t)stream);
+}
+
+int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
+                        float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
+                        int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups, int out_stride,
+                        int out_offset, int accumulate, int act, float act_param, void* stream) {
+  return conv1d_cbt_any(0, x_dev, w_dev, bias_dev, y_dev, wfrag_ws_dev, wfrag_ws_elems, B, c_in, t_in, c_out, t_out_total, n_out, k,
+                        stride, pad, dil, groups, out_stride, out_offset, accumulate, act, act_param, stream);
+}
+
+int evmi_conv1d_cbt_bf16(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
+                         float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
+                         int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups, int out_stride,
+                         int out_offset, int accumulate, int act, float act_param, void* stream) {
+  return conv1d_cbt_any(1, x_dev, w_dev, bias_dev, y_dev, wfrag_ws_dev, wfrag_ws_elems, B, c_in, t_in, c_out, t_out_total, n_out, k,
+                        stride, pad, dil, groups, out_stride, out_offset, accumulate, act, act_param, stream);
 }
 
 }  // extern "C"

@@ -117,9 +117,10 @@ def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=No
     lib = _lib.load()
     wf_elems = lib.evmi_conv1d_cbt_f32_ws_elems(B, cin, cout, t_conv if n_out is None else n_out, k, groups)
     wf = WS.get("wfrag", wf_elems, x.device)
-    _chk(lib.evmi_conv1d_cbt_f32(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), wf.data_ptr(), wf_elems, B, cin, t_in, cout,
-                                         out.shape[2], t_conv if n_out is None else n_out, k, stride, pad, dil, groups,
-                                         out_stride, out_offset, int(accumulate), act, float(act_param), _s(x)), "evmi_conv1d_cbt_f32")
+    fn = lib.evmi_conv1d_cbt_bf16 if CONV_BACKEND["operands"] == "bf16" else lib.evmi_conv1d_cbt_f32
+    _chk(fn(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), wf.data_ptr(), wf_elems, B, cin, t_in, cout,
+            out.shape[2], t_conv if n_out is None else n_out, k, stride, pad, dil, groups,
+            out_stride, out_offset, int(accumulate), act, float(act_param), _s(x)), "evmi_conv1d_cbt")
     return out
 
 
@@ -144,8 +145,9 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
     if ws_elems > 0:  # every phase in one launch, weight fragments straight from w
         ws = WS.get("wfrag", ws_elems, dy.device)
         dx = (torch.zeros if k < stride else torch.empty)(cin, B, t_in, device=dy.device, dtype=torch.float32)
-        _chk(lib.evmi_conv1d_dgrad_cbt_f32(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
-                                           k, stride, pad, dil, groups, _s(dy)), "evmi_conv1d_dgrad_cbt_f32")
+        fn = lib.evmi_conv1d_dgrad_cbt_bf16 if CONV_BACKEND["operands"] == "bf16" else lib.evmi_conv1d_dgrad_cbt_f32
+        _chk(fn(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
+                k, stride, pad, dil, groups, _s(dy)), "evmi_conv1d_dgrad_cbt")
         return dx
     if stride == 1:
         wt = WS.get("wt", cin * (cout // groups) * k, dy.device)
@@ -172,7 +174,9 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
 # "mfma": the hand-written fp32 matrix-core kernels; "gemm": unfold + rocBLAS (A/B and reference variant).
 # wgrad "auto": implicit GEMM for grouped layers (2-5x over unfold + per-group GEMMs), unfold + ONE library GEMM for dense
 # ones, where rocBLAS is still 1.2-1.8x ahead of conv_wgrad_f32_mfma.hip (tools/bench_f32wgrad.py): 83.6 -> 79.4 ms/step.
-CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma", "wgrad": "auto"}
+# "operands": "f32" = exact fp32 fmaf chains on the fp32-input matrix cores; "bf16" = the same kernels round both operands to
+# bf16 on their way into v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 tensors in HBM, fp32 master weights).
+CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma", "wgrad": "auto", "operands": "f32"}
 
 
 def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bool:

@@ -231,6 +231,18 @@ long long evmi_conv1d_dgrad_cbt_f32_ws_elems(int B, int c_in, int t_in, int c_ou
 int evmi_conv1d_dgrad_cbt_f32(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev,
                               long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k,
                               int stride, int pad, int dil, int groups, void* stream);
+/* bf16-operand variants of the two calls above (same arguments, same workspaces, fp32 tensors in HBM, fp32 accumulation):
+ * the kernels round both operands to bf16 on their way into v_mfma_f32_32x32x16_bf16 -- the mixed-precision ("bf16
+ * autocast") counterpart of the exact fp32 path; results differ from it by the operand rounding (2^-9 relative per
+ * operand).  Shapes whose staging does not fit the 16-channel K blocks of this mode run the fp32 kernels. */
+int evmi_conv1d_cbt_bf16(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
+                         float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
+                         int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups,
+                         int out_stride, int out_offset, int accumulate, int act, float act_param,
+                         void* stream);
+int evmi_conv1d_dgrad_cbt_bf16(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev,
+                               long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k,
+                               int stride, int pad, int dil, int groups, void* stream);
 /* Weight gradient of the same convolution as an implicit GEMM on the fp32 matrix cores (no unfold):
  *   dw[co][ci][j] (+)= sum_{b,to} dy[co][b][to] * x[ci][b][to*stride + j*dil - pad]
  * x [c_in][B][t_in], dy [c_out][B][n_out], dw [c_out][c_in/groups][k]; `ws_dev`: 16-byte aligned scratch of

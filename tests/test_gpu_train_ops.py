@@ -258,6 +258,62 @@ def test_conv1d_dgrad_fused_phases(cuda_device, case):
     assert float((bct(dx.cpu()) - x.grad).abs().max()) <= 2e-5 * scale + 1e-6, case
 
 
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.fixture
+def bf16_operands():
+    from everyvoice_amd.train import ops
+
+    ops.CONV_BACKEND["operands"] = "bf16"
+    yield
+    ops.CONV_BACKEND["operands"] = "f32"
+
+
+@pytest.mark.parametrize("c", MFMA_CONVS)
+@pytest.mark.parametrize("T", [101, 700])
+def test_conv1d_bf16_operands_fwd(cuda_device, bf16_operands, c, T):
+    """bf16-operand mode: both operands rounded to bf16 (nearest even), products accumulated in fp32 -- so the oracle is the
+    fp32 convolution of the ROUNDED operands and only the summation order differs (same tolerance as the fp32 test)."""
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(T + 7)
+    B = 3
+    x = torch.randn(B, c["cin"], T, generator=g)
+    w = torch.randn(c["cout"], c["cin"] // c["groups"], c["k"], generator=g) * 0.2
+    b = torch.randn(c["cout"], generator=g)
+    # GEMV / outer-product shapes and groups of fewer than 16 channels stay on the exact fp32 kernels
+    direct = c["cout"] <= 4 or c["cin"] // c["groups"] < 16 or (c["k"] > 32 and c["groups"] > 1)
+    xr, wr = (x, w) if direct else (_bf(x), _bf(w))
+    want = F.conv1d(xr, wr, b, c["stride"], c["pad"], c["dil"], c["groups"])
+    got = ops.conv1d_mfma(cbt(x).to(cuda_device), w.to(cuda_device), b.to(cuda_device), c["stride"], c["pad"], c["dil"], c["groups"])
+    torch.testing.assert_close(bct(got.cpu()), want, rtol=1e-4, atol=3e-5)
+    # and within the operand-rounding distance of the exact convolution (2^-9 per operand, random signs)
+    exact = F.conv1d(x, w, b, c["stride"], c["pad"], c["dil"], c["groups"])
+    assert float((bct(got.cpu()) - exact).norm() / exact.norm()) < 6e-3
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv1d_bf16_operands_dgrad(cuda_device, bf16_operands, case):
+    from everyvoice_amd.train import ops
+
+    B, T, cin, cout, k, s, p, d, groups = case
+    g = torch.Generator().manual_seed(T * 3 + k + 1)
+    x = torch.randn(B, cin, T, generator=g, requires_grad=True)
+    w = torch.randn(cout, cin // groups, k, generator=g) * 0.2
+    dy = torch.randn(F.conv1d(x, w, None, s, p, d, groups).shape, generator=g)
+    # shapes outside the bf16 staging (GEMV / outer products, fewer than 16 channels per group) run the exact fp32 kernels
+    F.conv1d(x, _bf(w), None, s, p, d, groups).backward(_bf(dy))
+    g_bf = x.grad.clone()
+    x.grad = None
+    F.conv1d(x, w, None, s, p, d, groups).backward(dy)
+    dx = bct(ops.conv1d_bwd_data_mfma(cbt(dy).to(cuda_device), w.to(cuda_device), T, s, p, d, groups).cpu())
+    scale = float(x.grad.abs().max())
+    err = min(float((dx - g_bf).abs().max()), float((dx - x.grad).abs().max()))
+    assert err <= 2e-5 * scale + 1e-6, case
+
+
 def test_conv_kernels_edge_shapes(cuda_device):
     """Single item, single output position, output length 1 per item with many items, channels not a multiple of anything."""
     from everyvoice_amd.train import ops

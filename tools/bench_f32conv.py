@@ -34,7 +34,7 @@ import os
 flt = os.environ.get("F32_LAYERS", "")
 if flt:
     SHAPES = [sh for sh in SHAPES if any(f in sh[0] for f in flt.split(","))]
-print(f"{'layer':32s} {'GFLOP':>8s} | {'mfma ms':>8s} {'TF/s':>7s} | {'gemm ms':>8s} {'TF/s':>7s}")
+print(f"{'layer':32s} {'GFLOP':>8s} | {'mfma ms':>8s} {'TF/s':>7s} | {'bf16 ms':>8s} {'TF/s':>7s} | {'gemm ms':>8s} {'TF/s':>7s}")
 for name, cin, cout, k, s, p, d, g, b, t in SHAPES:
     x = torch.randn(cin, b, t, device=dev)
     w = torch.randn(cout, cin // g, k, device=dev) * 0.1
@@ -42,8 +42,9 @@ for name, cin, cout, k, s, p, d, g, b, t in SHAPES:
     t_out = ops.conv_out_len(t, k, s, p, d)
     fl = 2.0 * b * t_out * cout * (cin // g) * k
     res = {}
-    for backend in ("mfma", "gemm"):
-        ops.CONV_BACKEND["fwd"] = backend
+    for backend in ("mfma", "bf16", "gemm"):
+        ops.CONV_BACKEND["fwd"] = "mfma" if backend == "bf16" else backend
+        ops.CONV_BACKEND["operands"] = "bf16" if backend == "bf16" else "f32"
         for _ in range(2):
             ops.conv1d_fwd(x, w, bias, s, p, d, g)
         torch.cuda.synchronize()
@@ -52,4 +53,4 @@ for name, cin, cout, k, s, p, d, g, b, t in SHAPES:
             ops.conv1d_fwd(x, w, bias, s, p, d, g)
         torch.cuda.synchronize()
         res[backend] = (time.perf_counter() - t0) / 5 * 1e3
-    print(f"{name:32s} {fl/1e9:8.2f} | {res['mfma']:8.3f} {fl/res['mfma']/1e9:7.1f} | {res['gemm']:8.3f} {fl/res['gemm']/1e9:7.1f}")
+    print(f"{name:32s} {fl/1e9:8.2f} | {res['mfma']:8.3f} {fl/res['mfma']/1e9:7.1f} | {res['bf16']:8.3f} {fl/res['bf16']/1e9:7.1f} | {res['gemm']:8.3f} {fl/res['gemm']/1e9:7.1f}")

@@ -11,7 +11,8 @@ from everyvoice_amd.spectral import MelSpectrogram  # noqa: E402
 from everyvoice_amd.train import ops  # noqa: E402
 from everyvoice_amd.train.hifigan import HiFiGANTrainer  # noqa: E402
 
-ops.CONV_BACKEND.update(fwd="mfma", dgrad="mfma")
+import os
+ops.CONV_BACKEND.update(fwd="mfma", dgrad="mfma", operands=os.environ.get("OPERANDS", "f32"))
 dev = torch.device("cuda:0")
 B, S = 16, 8192
 g = torch.Generator().manual_seed(1234)
@@ -26,12 +27,12 @@ stats = defaultdict(lambda: [0, 0.0, 0.0])
 orig = ops.conv1d_mfma
 
 
-def timed(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=None, out_stride=1, out_offset=0, accumulate=False):
+def timed(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=None, out_stride=1, out_offset=0, accumulate=False, **kw):
     cin, Bx, t_in = x.shape
     cout, cin_g, k = w.shape
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    r = orig(x, w, bias, stride, pad, dil, groups, out, n_out, out_stride, out_offset, accumulate)
+    r = orig(x, w, bias, stride, pad, dil, groups, out, n_out, out_stride, out_offset, accumulate, **kw)
     e1.record()
     e1.synchronize()
     n = r.shape[2] if n_out is None else n_out
