@@ -83,6 +83,10 @@ SYMBOLS = {
     "evmi_gemm_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "evmi_conv1d_cbt_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
     "evmi_conv1d_cbt_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
+    "evmi_conv1d_cbt_bf16pk": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
+    "evmi_conv1d_cbt_bf16pk_ws_elems": (C.c_longlong, [C.c_int] * 10),
+    "evmi_conv1d_dgrad_cbt_bf16pk": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
+    "evmi_conv1d_dgrad_cbt_bf16pk_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv1d_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 6),
     "evmi_conv1d_cbt_f32_supported": (C.c_int, [C.c_int] * 9),
     "evmi_conv1d_dgrad_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 10),

@@ -1,0 +1,576 @@
+// bf16-operand implicit-GEMM 1-D convolution for the channel-major training layout, on a PACKED copy of the input.
+//
+//   y[co][b][to*os + oo] (+)= act(bias[co] + sum_{ci in group} sum_{j<k} bf16(w[co][ci][j]) * bf16(x[ci][b][to*s + j*d - p]))
+//
+// The fp32 tensors stay [C][B][T] in HBM (fp32 master weights, fp32 activations, fp32 accumulation).  What changes against
+// conv_cbt_f32_mfma.hip is how the operands reach v_mfma_f32_32x32x16_bf16, whose B operand wants 8 consecutive K values per
+// lane for ONE column -- 8 channels of one time step, which are B*T floats apart in the channel-major layout:
+//
+//  * pack_x_kernel (one read of x, half a write): xp[g][octet][b][u] = 16-byte unit of the 8 channels 8*octet..+7 of group g
+//    at padded position u (u = t + PL; zeros in the padding and in channels past the group), every item a segment of Tp
+//    units.  A tile's input window -- several short items or a slice of a long one, taps, strides and padding included --
+//    is then ONE contiguous range of units per octet row: all loads are full 1 KB global_load_lds_dwordx4, no masks, no
+//    per-lane tables, and a B fragment is one ds_read_b128 at (column * stride + tap * dilation).
+//  * K runs over "halves" h = (octet, tap) in that order; one MFMA K block = halves (2q, 2q+1): the lanes of the lower
+//    half-wave take half 2q, the upper ones half 2q+1 (an odd tail is zero weights).  So any group width that is a multiple
+//    of 8 channels fills the K blocks exactly (the grouped 41-tap layers of the scale discriminators have 8..64).
+//  * wfrag_pk_kernel re-lays the weights per call as 1 KB A fragments [m-block][K block][lane][8 bf16].
+//  * LDS ring of 2-3 slots per workgroup (weights + window rows of a step), LDS-direct loads one or two steps ahead, one
+//    barrier per step; every wave owns a 64x64 / 32x64 / 32x32 accumulator tile.  Tiles are XCD-ordered (m-tile major).
+//  * The input gradient of a strided layer runs its polyphase components in one launch (grid.z), as in the fp32 kernel.
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+#include "conv_cbt_direct.h"
+
+namespace evmi {
+
+struct ConvPkArgs {
+  const uint4* xp;     // packed input [groups][octs][B][Tp] units (+ slack)
+  const uint4* wf;     // fragments [phase][groups*mblocks][kblocks][64] units
+  const float* bias;   // [c_out] or nullptr
+  float* y;            // [c_out][B][t_out_total]
+  int B, Tp, t_out_total;
+  int cout_g, k, stride, dil;
+  int octs, kblocks;   // ceil(cin_g / 8), ceil(octs * k / 2)
+  int kb_step;         // K blocks per ring step
+  int rows_step;       // octet rows a step may span
+  int xrow, pieces;    // LDS row stride in units (= 64 * pieces)
+  int nst;             // ring slots
+  int mblocks, mtiles_per_group;
+  int out_stride, accumulate, act;
+  float act_param;
+  int phases;
+  long long wf_phase_stride;  // units
+  int ph_shift[8], ph_nout[8], ph_off[8];
+  int xcd_remap;
+  int ablate;  // timing experiments (EVMI_PK_ABLATE): 1 no window loads, 2 no weight loads, 4 no MFMA loop, 8 no stores
+};
+
+template <int ACT>
+__device__ __forceinline__ float pk_act(float v, float p) {
+  if (ACT == 1) return v > 0.f ? v : v * p;
+  if (ACT == 2) return v / (1.f + expf(-v));
+  if (ACT == 3) return fmaxf(v, 0.f);
+  if (ACT == 4) return tanhf(v);
+  return v;
+}
+template <class F>
+__device__ __forceinline__ void pk_with_act(int act, F&& body) {
+  switch (act) {
+    case 1: body(std::integral_constant<int, 1>{}); break;
+    case 2: body(std::integral_constant<int, 2>{}); break;
+    case 3: body(std::integral_constant<int, 3>{}); break;
+    case 4: body(std::integral_constant<int, 4>{}); break;
+    default: body(std::integral_constant<int, 0>{}); break;
+  }
+}
+
+typedef __attribute__((address_space(3))) uint4 lds_u4_t;
+typedef __attribute__((address_space(1))) const uint4 glb_u4_t;
+__device__ __forceinline__ void pk_lds_direct(const uint4* g, uint4* l) {
+  __builtin_amdgcn_global_load_lds((glb_u4_t*)g, (lds_u4_t*)l, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pk_bf16x2(float lo, float hi) {
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  bf2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// x [groups*cin_g][B][t_in] fp32 -> xp [groups][octs][B][Tp] units; unit (g, o, b, u) = channels g*cin_g + 8o..8o+7 at t = u - PL.
+// grid (ceil(Tp / 256), B, groups*octs): one thread per unit, consecutive threads consecutive u (coalesced reads of 8 channel
+// rows, 16-byte writes); no index divisions.
+__global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ x, uint4* __restrict__ xp, int cin_g, int octs, int B,
+                                                     int t_in, int Tp, int PL) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  if (u >= Tp) return;
+  const int b = blockIdx.y, go = blockIdx.z;
+  const int g = go / octs, o = go - g * octs;
+  const int t = u - PL;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  if (t >= 0 && t < t_in) {
+    const float* src = x + ((long long)(g * cin_g + o * 8) * B + b) * t_in + t;
+    const long long cs = (long long)B * t_in;
+    const int nch = min(8, cin_g - o * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < nch) v[i] = src[i * cs];
+  }
+  uint4 out;
+  out.x = pk_bf16x2(v[0], v[1]);
+  out.y = pk_bf16x2(v[2], v[3]);
+  out.z = pk_bf16x2(v[4], v[5]);
+  out.w = pk_bf16x2(v[6], v[7]);
+  xp[((long long)go * B + b) * Tp + u] = out;
+}
+
+// A fragments.  mode 0 (forward): rows = output channels of w [c_out][cin_g][k], K channels = input channels, tap j.
+// mode 1 (input gradient, phase phi of `stride`): rows = INPUT channels, K channels = output channels, M taps per phase
+// (phases with fewer taps zero padded in front), tap m -> j = phi + stride * (m_phi - 1 - (m - lead)): see wfrag_dgrad_kernel.
+// wf[ph][(g*MB + mb)][q][lane] (uint4): lane (mi = lane & 31, kh = lane >> 5), half h = 2q + kh = (octet, tap).
+// grid (kblocks, groups*MB, phases), 256 threads = 64 lanes x 4 words
+__global__ __launch_bounds__(256) void wfrag_pk_kernel(const float* __restrict__ w, unsigned* __restrict__ wf, int rows_g, int kch_g, int kt,
+                                                       int MB, int octs, int kblocks, int mode, int k_full, int stride,
+                                                       long long phase_stride_words) {
+  const int q = blockIdx.x, gmb = blockIdx.y, phi = blockIdx.z;
+  const int g = gmb / MB, mb = gmb - g * MB;
+  const int lane = threadIdx.x >> 2, wd = threadIdx.x & 3;
+  const int mi = lane & 31, kh = lane >> 5;
+  const int h = 2 * q + kh;
+  const int o = h / kt, j = h - o * kt;
+  const int row = mb * 32 + mi;
+  float v[2] = {0.f, 0.f};
+  if (o < octs && row < rows_g) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int kc = o * 8 + 2 * wd + e;
+      if (kc >= kch_g) continue;
+      if (mode == 0) {
+        v[e] = w[((long long)(g * rows_g + row) * kch_g + kc) * kt + j];
+      } else {  // rows_g = cin_g (x channels), kch_g = cout_g (dy channels), w [c_out][cin_g][k_full]
+        const int m_phi = (k_full - phi + stride - 1) / stride, lead = kt - m_phi;
+        if (j >= lead) {
+          const int jj = phi + stride * (m_phi - 1 - (j - lead));
+          v[e] = w[((long long)(g * kch_g + kc) * rows_g + row) * k_full + jj];
+        }
+      }
+    }
+  }
+  wf[phi * phase_stride_words + (((long long)gmb * kblocks + q) * 64 + lane) * 4 + wd] = pk_bf16x2(v[0], v[1]);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
+  static_assert(WM * WN == 4, "four waves");
+  constexpr int MT = BM / (WM * 32), NT = BN / (WN * 32), MBT = BM / 32;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int kh = lane >> 5, ln = lane & 31;
+
+  unsigned bx = blockIdx.x, by = blockIdx.y;
+  if (a.xcd_remap) {  // every XCD (private L2) takes a contiguous range of the m-tile-major tile list
+    const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
+    if (nwg >= 16) {
+      const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+      const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+      by = L / gridDim.x;
+      bx = L - by * gridDim.x;
+    }
+  }
+  const int g = by / a.mtiles_per_group, mt_idx = by % a.mtiles_per_group;
+  const int co0 = g * a.cout_g + mt_idx * BM;
+  const int k = a.k, s = a.stride, d = a.dil, xrow = a.xrow, pieces = a.pieces, kbs = a.kb_step;
+  const int ph = blockIdx.z;
+  const int n_out = a.ph_nout[ph], shift = a.ph_shift[ph], out_off = a.ph_off[ph];
+  if (n_out <= 0) return;
+  const long long n_total = (long long)a.B * n_out;
+  const long long n0 = (long long)bx * BN;
+  if (n0 >= n_total) return;
+  const int b_first = (int)(n0 / n_out);
+  const int to_first = (int)(n0 - (long long)b_first * n_out);
+  const int m_valid = min(BM, a.cout_g - mt_idx * BM);
+  const long long plane = (long long)a.B * a.Tp;  // units per octet row
+  const uint4* xwin = a.xp + (long long)g * a.octs * plane + (long long)b_first * a.Tp + (long long)to_first * s + shift;
+  const int a_units = MBT * kbs * 64;
+  const int stage = a_units + a.rows_step * xrow;
+
+  int colu[NT], col_b[NT], col_to[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = (wn * NT + nt) * 32 + ln;
+    const long long n = n0 + c;
+    if (n < n_total) {
+      const int bb = (int)(n / n_out);
+      col_b[nt] = bb;
+      col_to[nt] = (int)(n - (long long)bb * n_out);
+      colu[nt] = a_units + (bb - b_first) * a.Tp + (col_to[nt] - to_first) * s;
+    } else {
+      col_b[nt] = -1;
+      col_to[nt] = 0;
+      colu[nt] = a_units;  // staged data; the column is never stored
+    }
+  }
+  int abase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) abase[mt] = (wm * MT + mt) * kbs * 64 + lane;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nsteps = (a.kblocks + kbs - 1) / kbs;
+  const uint4* wf_tile = a.wf + (long long)ph * a.wf_phase_stride + (long long)(g * a.mblocks + mt_idx * MBT) * a.kblocks * 64;
+  const int mb_last = a.mblocks - 1 - mt_idx * MBT;  // m-blocks past the group re-read the last one (never stored)
+  const int halves = a.octs * k;
+
+  // ---- loader: the 1 KB units of step t (weight fragments, then window pieces) round-robin over the four waves ----
+  auto issue = [&](int t, int slot) -> int {
+    const int q0 = t * kbs;
+    const int nq = min(kbs, a.kblocks - q0);
+    uint4* sa = smem + slot * stage;
+    uint4* sx = sa + a_units;
+    int issued = 0;
+    int u = wave;
+    if (!(a.ablate & 2))
+#pragma unroll
+    for (int mbi = 0; mbi < MBT; ++mbi) {
+      const uint4* src = wf_tile + ((long long)min(mbi, mb_last) * a.kblocks + q0) * 64 + lane;
+      uint4* dst = sa + mbi * kbs * 64;
+      for (; u < nq; u += 4) {
+        pk_lds_direct(src + u * 64, dst + u * 64);
+        ++issued;
+      }
+      u -= nq;
+    }
+    const int o_lo = (2 * q0) / k;
+    const int o_hi = min(a.octs - 1, (2 * (q0 + nq) - 1) / k);
+    const int nunits = (o_hi - o_lo + 1) * pieces;
+    if (!(a.ablate & 1))
+    for (; u < nunits; u += 4) {
+      const int r = u / pieces, pi = u - r * pieces;
+      pk_lds_direct(xwin + (long long)(o_lo + r) * plane + pi * 64 + lane, sx + r * xrow + pi * 64);
+      ++issued;
+    }
+    return issued;
+  };
+
+  int n_next = 0;
+  const int nst = a.nst;
+  issue(0, 0);
+  if (nst == 3 && nsteps > 1) n_next = issue(1, 1);
+
+  int slot = -1;
+  for (int t = 0; t < nsteps; ++t) {
+    slot = slot + 1 == nst ? 0 : slot + 1;
+    const int slot_ahead = slot == 0 ? nst - 1 : slot - 1;
+    wait_vmcnt_le(n_next);  // step t has landed (this wave's part); step t+1 may still be in flight
+    lds_barrier();          // ... everyone's part; the slot about to be refilled was last read in step t-1
+    {
+      const int issued = t + nst - 1 < nsteps ? issue(t + nst - 1, slot_ahead) : 0;
+      n_next = nst == 3 ? issued : 0;
+    }
+    const int q0 = t * kbs;
+    const int nq = min(kbs, a.kblocks - q0);
+    const int o_lo = (2 * q0) / k;
+    const uint4* sm = smem + slot * stage;
+    // halves (2q, 2q+1) -> (octet, tap); kept incrementally
+    int h0 = 2 * q0;
+    int o0 = h0 / k, j0 = h0 - o0 * k;
+    int o1 = o0, j1 = j0 + 1;
+    if (j1 >= k) { j1 -= k; ++o1; }
+    auto lane_off = [&]() -> int {
+      const int off0 = (o0 - o_lo) * xrow + j0 * d;
+      const int off1 = h0 + 1 < halves ? (o1 - o_lo) * xrow + j1 * d : off0;  // odd tail: zero weights, any staged unit
+      return kh ? off1 : off0;
+    };
+    auto advance = [&]() {
+      h0 += 2;
+      j0 += 2;
+      while (j0 >= k) { j0 -= k; ++o0; }
+      j1 += 2;
+      while (j1 >= k) { j1 -= k; ++o1; }
+    };
+    bf16x8 fa[MT], fb[NT], na[MT], nb[NT];
+    auto load = [&](bf16x8 (&da)[MT], bf16x8 (&db)[NT], int qi) {
+      const int lo = lane_off();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) da[mt] = *reinterpret_cast<const bf16x8*>(sm + abase[mt] + qi * 64);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) db[nt] = *reinterpret_cast<const bf16x8*>(sm + colu[nt] + lo);
+    };
+    load(fa, fb, 0);
+    if (!(a.ablate & 4))
+    for (int qi = 0; qi < nq; ++qi) {
+      if (qi + 1 < nq) advance();  // past the end: re-read the last block (in-bounds, unused)
+      load(na, nb, min(qi + 1, nq - 1));
+      __builtin_amdgcn_sched_barrier(0);  // the LDS reads of block qi+1 are in flight before the MFMAs of block qi issue
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = na[mt];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[nt] = nb[nt];
+    }
+  }
+
+  // ---- epilogue: D layout: lane column = output position, registers = output channels ----
+  if (a.ablate & 8) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
+    if (sacc == 12345.678f) a.y[0] = sacc;
+    return;
+  }
+  pk_with_act(a.act, [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (col_b[nt] < 0) continue;
+      float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (m >= m_valid) continue;
+          const int co = co0 + m;
+          float v = acc[mt][nt][r];
+          if (a.bias) v += a.bias[co];
+          v = pk_act<ACT>(v, a.act_param);
+          float* dst = ycol + (long long)co * a.B * a.t_out_total;
+          *dst = a.accumulate ? *dst + v : v;
+        }
+      }
+    }
+  });
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+struct PkTile { int bm, bn; };
+static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}};
+constexpr int kNumPkTiles = sizeof(kPkTiles) / sizeof(kPkTiles[0]);
+
+static int pk_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+struct PkPlan {
+  int ti;
+  size_t lds;
+  dim3 grid;
+  int PL;                  // left padding of the packed items (units)
+  long long xp_units;      // packed input incl. slack
+  long long wf_units;      // fragments, all phases
+  int cin_g, t_in, groups;
+};
+
+static long long round_up_ll(long long v, long long m) { return (v + m - 1) / m * m; }
+
+// Fills the geometry of `a` (phases must be set: ph_nout, ph_off and the per-phase padding in ph_shift) and the plan.
+static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const int* ph_pad, PkPlan& pl) {
+  if (cin_g <= 0 || a.cout_g <= 0 || a.k <= 0 || a.stride <= 0 || a.dil <= 0 || a.B <= 0 || t_in <= 0) return "bad shape";
+  if (cin_g < 8) return "fewer than 8 channels per group";
+  if (a.cout_g <= 4) return "direct-kernel shape";
+  a.octs = (cin_g + 7) / 8;
+  a.kblocks = (a.octs * a.k + 1) / 2;
+  a.mblocks = (a.cout_g + 31) / 32;
+  int PL = 0, n_max = 0, n_min = 0;
+  for (int p = 0; p < a.phases; ++p) PL = std::max(PL, ph_pad[p]);
+  long long ext = (long long)PL + t_in;
+  for (int p = 0; p < a.phases; ++p) {
+    a.ph_shift[p] = PL - ph_pad[p];
+    if (a.ph_nout[p] <= 0) continue;
+    ext = std::max<long long>(ext, (long long)a.ph_shift[p] + (long long)(a.ph_nout[p] - 1) * a.stride + (long long)(a.k - 1) * a.dil + 1);
+    n_max = std::max(n_max, a.ph_nout[p]);
+    n_min = n_min == 0 ? a.ph_nout[p] : std::min(n_min, a.ph_nout[p]);
+  }
+  if (n_max <= 0) return "no outputs";
+  if (ext > (1 << 24)) return "row too long";
+  a.Tp = (int)ext;
+  const long long n_total = (long long)a.B * n_max;
+  auto blocks = [&](int i) {
+    return ((n_total + kPkTiles[i].bn - 1) / kPkTiles[i].bn) * ((a.cout_g + kPkTiles[i].bm - 1) / kPkTiles[i].bm) * groups;
+  };
+  static const long long want = pk_env_int("EVMI_PK_WANT", 512);  // two workgroups per CU: one's epilogue / load waits overlap the other's MFMAs
+  int ti;
+  if (a.cout_g > 64) ti = blocks(0) >= want ? 0 : (blocks(1) >= want ? 1 : 2);
+  else if (a.cout_g > 32) ti = blocks(1) >= want ? 1 : 2;
+  else ti = 3;
+  const int forced = pk_env_int("EVMI_PK_TILE", -1);
+  if (forced >= 0 && forced < kNumPkTiles) ti = forced;
+  const size_t two_wg = 78 * 1024, one_wg = 160 * 1024;
+  for (;; ++ti) {  // narrower tiles while the staged window does not fit
+    if (ti >= kNumPkTiles) return "LDS budget";
+    const int bm = kPkTiles[ti].bm, bn = kPkTiles[ti].bn;
+    const int items_max = (int)std::min<long long>(a.B, (bn + n_min - 2) / n_min + 1);
+    // tile column c of item bb sits at unit c*s + (bb - b_first) * (Tp - n_out*s) of the window (+ tap * dilation)
+    const long long gap = std::max<long long>(0, (long long)a.Tp - (long long)n_min * a.stride);
+    const long long win = (long long)(bn - 1) * a.stride + (items_max - 1) * gap + (long long)(a.k - 1) * a.dil + 1;
+    if (win > 64 * 24) { if (ti == kNumPkTiles - 1) return "input window too long"; continue; }
+    a.pieces = (int)((win + 63) / 64);
+    a.xrow = a.pieces * 64;
+    auto rows_of = [&](int kbs) { return std::min(a.octs, (2 * kbs + a.k - 2) / a.k + 1); };
+    auto lds_of = [&](int kbs, int nst) { return (size_t)nst * ((bm / 32) * kbs * 64 + rows_of(kbs) * a.xrow) * 16; };
+    if (lds_of(1, 2) > one_wg) { if (ti == kNumPkTiles - 1) return "LDS budget"; continue; }
+    // deepest step (K blocks) that leaves two workgroups per CU; three slots when they fit at that depth
+    int kbs = 1, nst = 2;
+    const size_t budget = lds_of(1, 2) <= two_wg ? two_wg : one_wg;
+    const int kbs_cap = std::min(a.kblocks, pk_env_int("EVMI_PK_KBS_CAP", 16));
+    while (kbs < kbs_cap && lds_of(kbs + 1, 2) <= budget) ++kbs;
+    if (lds_of(std::max(1, kbs * 2 / 3), 3) <= budget && kbs >= 3) { nst = 3; kbs = std::max(1, kbs * 2 / 3); }
+    const int fk = pk_env_int("EVMI_PK_KBS", 0), fn = pk_env_int("EVMI_PK_NST", 0);
+    if (fn == 2 || fn == 3) nst = fn;
+    if (fk > 0) kbs = std::min(fk, a.kblocks);
+    while (kbs > 1 && lds_of(kbs, nst) > one_wg) --kbs;
+    if (lds_of(kbs, nst) > one_wg) return "LDS budget";
+    a.kb_step = kbs;
+    a.rows_step = rows_of(kbs);
+    a.nst = nst;
+    a.mtiles_per_group = (a.cout_g + bm - 1) / bm;
+    pl.lds = lds_of(kbs, nst);
+    if ((n_total + bn - 1) / bn > 0x7fffffffLL || groups * a.mtiles_per_group > 65535 || groups * a.mblocks > 65535) return "grid limits";
+    pl.grid = dim3((unsigned)((n_total + bn - 1) / bn), groups * a.mtiles_per_group, a.phases);
+    break;
+  }
+  pl.ti = ti;
+  pl.PL = PL;
+  pl.cin_g = cin_g; pl.t_in = t_in; pl.groups = groups;
+  // slack: the last window piece of the last tile reads up to 63 units past its window, rows of the last octet included
+  pl.xp_units = (long long)groups * a.octs * a.B * a.Tp + (long long)a.xrow + 64;
+  a.wf_phase_stride = (long long)groups * a.mblocks * a.kblocks * 64;
+  pl.wf_units = a.wf_phase_stride * a.phases;
+  if (pl.xp_units >= (1LL << 31)) return "packed input too large";
+  if (a.B > 65535 || groups * a.octs > 65535) return "grid limits (pack)";
+  return nullptr;
+}
+
+static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float* w, float* ws, long long ws_elems, int wmode,
+                     int rows_g, int kch_g, int k_full, int stride_full, hipStream_t stream) {
+  const long long need = (pl.xp_units + pl.wf_units) * 4;
+  if (!ws || ws_elems < need || (reinterpret_cast<uintptr_t>(ws) & 15))
+    return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_bf16_pk: workspace missing, too small or unaligned");
+  uint4* xp = reinterpret_cast<uint4*>(ws);
+  uint4* wf = xp + pl.xp_units;
+  if (a.B > 65535 || pl.groups * a.octs > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_bf16_pk: grid limits (pack)");
+  hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((a.Tp + 255) / 256), a.B, pl.groups * a.octs), dim3(256), 0, stream, x, xp, pl.cin_g,
+                     a.octs, a.B, pl.t_in, a.Tp, pl.PL);
+  hipLaunchKernelGGL(wfrag_pk_kernel, dim3(a.kblocks, pl.groups * a.mblocks, a.phases), dim3(256), 0, stream, w,
+                     reinterpret_cast<unsigned*>(wf), rows_g, kch_g, a.k, a.mblocks, a.octs, a.kblocks, wmode, k_full, stride_full,
+                     a.wf_phase_stride * 4);
+  a.xp = xp;
+  a.wf = wf;
+  static const int xcd_remap = pk_env_int("EVMI_F32_XCD", 1);
+  a.xcd_remap = xcd_remap;
+  a.ablate = pk_env_int("EVMI_PK_ABLATE", 0);
+  const size_t lds = pl.lds;
+  static thread_local size_t configured[kNumPkTiles] = {0};
+#define EVMI_PK_LAUNCH(BM, BN, WM, WN, IDX)                                                                              \
+  {                                                                                                                      \
+    if (lds > configured[IDX]) {                                                                                         \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pk_kernel<BM, BN, WM, WN>,                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+      configured[IDX] = lds;                                                                                             \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((conv_pk_kernel<BM, BN, WM, WN>), pl.grid, dim3(256), lds, stream, a);                            \
+  }
+  switch (pl.ti) {
+    case 0: EVMI_PK_LAUNCH(128, 128, 2, 2, 0) break;
+    case 1: EVMI_PK_LAUNCH(64, 128, 1, 4, 1) break;
+    case 2: EVMI_PK_LAUNCH(64, 64, 2, 2, 2) break;
+    default: EVMI_PK_LAUNCH(32, 128, 1, 4, 3) break;
+  }
+#undef EVMI_PK_LAUNCH
+  EVMI_LAUNCH_CHECK("conv_cbt_bf16_pk");
+  return EVMI_OK;
+}
+
+static const char* plan_fwd_pk(ConvPkArgs& a, PkPlan& pl, int B, int c_in, int t_in, int c_out, int t_out_total, int n_out, int k, int stride,
+                               int pad, int dil, int groups, int out_stride, int out_offset) {
+  if (groups <= 0 || c_in % groups || c_out % groups) return "groups";
+  if (pad < 0) return "negative padding";
+  a.B = B; a.t_out_total = t_out_total; a.cout_g = c_out / groups; a.k = k; a.stride = stride; a.dil = dil;
+  a.out_stride = out_stride; a.phases = 1;
+  a.ph_nout[0] = n_out; a.ph_off[0] = out_offset;
+  const int ph_pad[1] = {pad};
+  return plan_pk(a, c_in / groups, t_in, groups, ph_pad, pl);
+}
+
+// dx [c_in][B][t_in] from dy [c_out][B][t_out]: min(stride, k) polyphase stride-1 convolutions of dy in one launch
+static const char* plan_dgrad_pk(ConvPkArgs& a, PkPlan& pl, int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad,
+                                 int dil, int groups) {
+  if (groups <= 0 || c_in <= 0 || c_out <= 0 || c_in % groups || c_out % groups) return "bad shape";
+  if (stride > 1 && dil != 1) return "strided and dilated";
+  if (stride > 8) return "stride above 8";
+  const int phases = std::min(stride, k), M = (k + stride - 1) / stride;
+  a.B = B; a.t_out_total = t_in; a.cout_g = c_in / groups; a.k = M; a.stride = 1; a.dil = stride == 1 ? dil : 1;
+  a.out_stride = stride; a.phases = phases; a.accumulate = 0; a.bias = nullptr; a.act = 0;
+  int ph_pad[8];
+  for (int phi = 0; phi < phases; ++phi) {
+    if (stride == 1) {
+      ph_pad[0] = dil * (k - 1) - pad; a.ph_nout[0] = t_in; a.ph_off[0] = 0;
+    } else {
+      const int num = pad - phi;  // first q with stride*q + phi - pad >= 0
+      const int q0 = num > 0 ? (num + stride - 1) / stride : 0;
+      const int q_hi = (t_in - 1 + pad - phi) >= 0 ? (t_in - 1 + pad - phi) / stride : -1;
+      ph_pad[phi] = (M - 1) - q0;
+      a.ph_nout[phi] = std::max(0, q_hi - q0 + 1);
+      a.ph_off[phi] = stride * q0 + phi - pad;
+    }
+    if (ph_pad[phi] < 0) return "negative phase padding";
+  }
+  return plan_pk(a, c_out / groups, t_out, groups, ph_pad, pl);
+}
+
+}  // namespace evmi
+
+using namespace evmi;
+
+extern "C" {
+
+/* Floats of workspace the packed bf16 convolution needs (packed input + weight fragments); 0 = shape not taken by it. */
+long long evmi_conv1d_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil,
+                                          int groups) {
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (plan_fwd_pk(a, pl, B, c_in, t_in, c_out, n_out, n_out, k, stride, pad, dil, groups, 1, 0)) return 0;
+  return (pl.xp_units + pl.wf_units) * 4;
+}
+
+int evmi_conv1d_cbt_bf16pk(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev,
+                           long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out_total, int n_out, int k, int stride,
+                           int pad, int dil, int groups, int out_stride, int out_offset, int accumulate, int act, float act_param,
+                           void* stream) {
+  if (!x_dev || !w_dev || !y_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk: null pointer");
+  if (act < 0 || act > 4 || (act && accumulate)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk: activation (0..4, not with accumulate)");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_fwd_pk(a, pl, B, c_in, t_in, c_out, t_out_total, n_out, k, stride, pad, dil, groups, out_stride, out_offset))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk: ") + why);
+  a.bias = bias_dev; a.y = y_dev; a.accumulate = accumulate; a.act = act; a.act_param = act_param;
+  return launch_pk(a, pl, x_dev, w_dev, ws_dev, ws_elems, 0, c_out / groups, c_in / groups, k, stride, (hipStream_t)stream);
+}
+
+long long evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil,
+                                                int groups) {
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (plan_dgrad_pk(a, pl, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups)) return 0;
+  return (pl.xp_units + pl.wf_units) * 4;
+}
+
+int evmi_conv1d_dgrad_cbt_bf16pk(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems, int B,
+                                 int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
+                                 void* stream) {
+  if (!dy_dev || !w_dev || !dx_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk: null pointer");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_dgrad_pk(a, pl, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk: ") + why);
+  a.y = dx_dev;
+  return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -115,6 +115,15 @@ def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=No
     if out is None:
         out = torch.empty(cout, B, t_conv, device=x.device, dtype=torch.float32)
     lib = _lib.load()
+    if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"]:
+        n_eff = t_conv if n_out is None else n_out
+        pk_elems = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t_in, cout, n_eff, k, stride, pad, dil, groups)
+        if pk_elems > 0:  # packed bf16 copy of x + A fragments (conv_cbt_bf16_pk.hip)
+            ws = WS.get("pk", pk_elems, x.device)
+            _chk(lib.evmi_conv1d_cbt_bf16pk(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in,
+                                            cout, out.shape[2], n_eff, k, stride, pad, dil, groups, out_stride, out_offset,
+                                            int(accumulate), act, float(act_param), _s(x)), "evmi_conv1d_cbt_bf16pk")
+            return out
     wf_elems = lib.evmi_conv1d_cbt_f32_ws_elems(B, cin, cout, t_conv if n_out is None else n_out, k, groups)
     wf = WS.get("wfrag", wf_elems, x.device)
     fn = lib.evmi_conv1d_cbt_bf16 if CONV_BACKEND["operands"] == "bf16" else lib.evmi_conv1d_cbt_f32
@@ -141,6 +150,14 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
     _, cin_g, k = w.shape
     cin = cin_g * groups
     lib = _lib.load()
+    if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"]:
+        pk_elems = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+        if pk_elems > 0:
+            ws = WS.get("pk", pk_elems, dy.device)
+            dx = (torch.zeros if k < stride else torch.empty)(cin, B, t_in, device=dy.device, dtype=torch.float32)
+            _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout,
+                                                  t_out, k, stride, pad, dil, groups, _s(dy)), "evmi_conv1d_dgrad_cbt_bf16pk")
+            return dx
     ws_elems = lib.evmi_conv1d_dgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
     if ws_elems > 0:  # every phase in one launch, weight fragments straight from w
         ws = WS.get("wfrag", ws_elems, dy.device)
@@ -176,7 +193,9 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
 # ones, where rocBLAS is still 1.2-1.8x ahead of conv_wgrad_f32_mfma.hip (tools/bench_f32wgrad.py): 83.6 -> 79.4 ms/step.
 # "operands": "f32" = exact fp32 fmaf chains on the fp32-input matrix cores; "bf16" = the same kernels round both operands to
 # bf16 on their way into v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 tensors in HBM, fp32 master weights).
-CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma", "wgrad": "auto", "operands": "f32"}
+# "packed": bf16 operands go through the packed-input kernel (conv_cbt_bf16_pk.hip) where it takes the shape; False = always the
+# in-LDS rounding variant of the fp32 kernels (A/B switch).
+CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma", "wgrad": "auto", "operands": "f32", "packed": True}
 
 
 def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bool:

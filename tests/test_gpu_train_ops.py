@@ -283,12 +283,21 @@ def test_conv1d_bf16_operands_fwd(cuda_device, bf16_operands, c, T):
     x = torch.randn(B, c["cin"], T, generator=g)
     w = torch.randn(c["cout"], c["cin"] // c["groups"], c["k"], generator=g) * 0.2
     b = torch.randn(c["cout"], generator=g)
-    # GEMV / outer-product shapes and groups of fewer than 16 channels stay on the exact fp32 kernels
-    direct = c["cout"] <= 4 or c["cin"] // c["groups"] < 16 or (c["k"] > 32 and c["groups"] > 1)
-    xr, wr = (x, w) if direct else (_bf(x), _bf(w))
+    # GEMV / outer-product shapes and groups of fewer than 8 channels stay on the exact fp32 kernels
+    cin_g, cout_g = c["cin"] // c["groups"], c["cout"] // c["groups"]
+    rounded = c["cout"] > 4 and cout_g > 4 and cin_g >= 8
+    xr, wr = (_bf(x), _bf(w)) if rounded else (x, w)
     want = F.conv1d(xr, wr, b, c["stride"], c["pad"], c["dil"], c["groups"])
     got = ops.conv1d_mfma(cbt(x).to(cuda_device), w.to(cuda_device), b.to(cuda_device), c["stride"], c["pad"], c["dil"], c["groups"])
     torch.testing.assert_close(bct(got.cpu()), want, rtol=1e-4, atol=3e-5)
+    # strided output grid + accumulation (the polyphase placement of input gradients)
+    base = torch.randn(c["cout"], B, want.shape[2] * 2 + 1, generator=g)
+    out = base.clone().to(cuda_device)
+    ops.conv1d_mfma(cbt(x).to(cuda_device), w.to(cuda_device), None, c["stride"], c["pad"], c["dil"], c["groups"], out=out,
+                    n_out=want.shape[2], out_stride=2, out_offset=1, accumulate=True)
+    ref = base.clone()
+    ref[:, :, 1::2] += cbt(F.conv1d(xr, wr, None, c["stride"], c["pad"], c["dil"], c["groups"]))
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=3e-5)
     # and within the operand-rounding distance of the exact convolution (2^-9 per operand, random signs)
     exact = F.conv1d(x, w, b, c["stride"], c["pad"], c["dil"], c["groups"])
     assert float((bct(got.cpu()) - exact).norm() / exact.norm()) < 6e-3

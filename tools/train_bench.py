@@ -16,6 +16,8 @@ from everyvoice_amd.train import ops  # noqa: E402
 if os.environ.get("EVMI_CONV_BACKEND"):  # e.g. "mfma,mfma" / "gemm,gemm" / "mfma,gemm"
     parts = os.environ["EVMI_CONV_BACKEND"].split(",")
     ops.CONV_BACKEND.update(fwd=parts[0], dgrad=parts[1], wgrad=parts[2] if len(parts) > 2 else "mfma")
+from everyvoice_amd.train import ops as _ops  # noqa: E402
+_ops.CONV_BACKEND["operands"] = os.environ.get("OPERANDS", "f32")
 dev = torch.device("cuda:0")
 B, S = int(os.environ.get("EVMI_TRAIN_B", "16")), 8192
 g = torch.Generator().manual_seed(1234)
