@@ -53,6 +53,9 @@ def parse_args(argv=None):
     p.add_argument("--profile-passes", type=int, default=3)
     p.add_argument("--no-train", action="store_true", help="skip the GAN-training leg (second half of the metric)")
     p.add_argument("--no-fs2", action="store_true", help="skip the FastSpeech2 feature-prediction inference leg")
+    p.add_argument("--train-precision", default="bf16", choices=["bf16", "f32"],
+                   help="training legs: bf16 convolution operands with fp32 accumulation / master weights (BASELINE config 3 names bf16), "
+                        "or the exact fp32 path; the other one is timed beside it with fewer steps")
     p.add_argument("--train-steps", type=int, default=6)
     p.add_argument("--train-warmup", type=int, default=2)
     return p.parse_args(argv)
@@ -273,16 +276,25 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     g = torch.Generator().manual_seed(1234 + rank)
     y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(dev)
     mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
-    trainer = HiFiGANTrainer(device=dev, process_group=True if use_dist else None)
+    prec = args.train_precision
+    trainer = HiFiGANTrainer(device=dev, process_group=True if use_dist else None, precision=prec)
     losses = {}
 
     def step():
         losses.update(trainer.training_step(mel, y))
 
     elapsed = timed_region(step, args.train_steps, args.train_warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    # the other precision beside it (same trainer object, fewer steps)
+    other = "f32" if prec == "bf16" else "bf16"
+    trainer.precision = other
+    elapsed_other = timed_region(step, 3, 1, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    trainer.precision = prec
     flop_per_step = 25.8e6 * B * S  # per GPU
     tflops = flop_per_step * args.train_steps / elapsed / 1e12
-    roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.0, "unit": "TFLOP/s", "frac": round(tflops / 157.0, 4),
+    # bf16 mode: forward and input-gradient convolutions on the bf16 matrix cores (2.5 PFLOP/s dense), weight gradients still on
+    # the fp32 ones (157 TFLOP/s): priced against the bf16 peak, the stricter denominator
+    peak = MFMA_PEAK_TFLOPS_BF16 if prec == "bf16" else 157.0
+    roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
             "traffic": None, "flop_per_step_per_gpu": flop_per_step, "scope": "whole training step"}
     pmc_files = sorted((ROOT / "profiles").glob("*train_pmc_summary.json"))
     if pmc_files:  # recorded rocprofv3 --pmc passes (tools/gpu_profile_train.sh): the kernel with the most HBM reads per step
@@ -304,7 +316,8 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
         "global_batch": B * world,
         "segment_samples": S,
         "scaling": "weak",
-        "dtype": "f32",
+        "dtype": prec,
+        "other_precision": {"dtype": other, "value": round(3 / elapsed_other, 3), "unit": "steps/s", "ms_per_step": round(elapsed_other / 3 * 1e3, 2), "steps": 3},
         "parallelism": f"dp{world}" + (" (RCCL all-reduce of 2 flat gradient buffers per step)" if world > 1 else ""),
         "params": {"generator": trainer.g_params.numel(), "discriminators": trainer.d_params.numel()},
         "last_losses": {k: round(v, 4) for k, v in losses.items()},
@@ -350,7 +363,8 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     from fs2_bench import forward_flops
     from fs2_train_bench import training_batch
 
-    tr = FastSpeech2Trainer(device=dev, process_group=True if use_dist else None)  # default config: learn_alignment on
+    prec = args.train_precision
+    tr = FastSpeech2Trainer(device=dev, process_group=True if use_dist else None, precision=prec)  # default config: learn_alignment on
     batch, t_i = training_batch(32, 1234 + rank, device=dev)
     out = {}
 
@@ -359,14 +373,20 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
 
     steps, warmup = 10, 3
     elapsed = timed_region(step, steps, warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    other = "f32" if prec == "bf16" else "bf16"
+    tr.precision = other
+    elapsed_other = timed_region(step, 3, 1, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    tr.precision = prec
     flops = 3.0 * forward_flops(batch["lens"], t_i, int(batch["ids"].shape[1]), int(t_i.max()), 32)
     tflops = flops * steps / elapsed / 1e12
+    peak = MFMA_PEAK_TFLOPS_BF16 if prec == "bf16" else 157.0
     return {"metric": "fastspeech2_train_steps_per_sec_bs32", "value": round(steps / elapsed, 3), "unit": "steps/s",
             "ms_per_step": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": warmup, "batch_per_gpu": 32, "global_batch": 32 * world,
-            "frames_per_sec": round(world * int(t_i.sum()) * steps / elapsed, 1), "scaling": "weak", "dtype": "f32",
+            "frames_per_sec": round(world * int(t_i.sum()) * steps / elapsed, 1), "scaling": "weak", "dtype": prec,
+            "other_precision": {"dtype": other, "value": round(3 / elapsed_other, 3), "unit": "steps/s", "ms_per_step": round(elapsed_other / 3 * 1e3, 2), "steps": 3},
             "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient buffer)" if world > 1 else ""),
             "params": tr.params.numel(), "last_losses": {k: round(float(v), 4) for k, v in out["losses"].items()},
-            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.0, "unit": "TFLOP/s", "frac": round(tflops / 157.0, 4),
+            "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
                          "traffic": None, "flop_per_step": flops, "scope": "whole step (forward + backward + optimiser)"}}
 
 

@@ -369,7 +369,11 @@ class FastSpeech2Trainer:
     _VERSION = "1.0"
 
     def __init__(self, config: FastSpeech2ModelConfig | None = None, stats: Stats | None = None, training: FastSpeech2TrainingConfig | None = None,
-                 device="cuda:0", seed: int = 1234, lang2id: dict | None = None, speaker2id: dict | None = None, process_group=None):
+                 device="cuda:0", seed: int = 1234, lang2id: dict | None = None, speaker2id: dict | None = None, process_group=None,
+                 precision: str = "f32"):
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision: 'f32' or 'bf16' (bf16 operands of the dense layers, fp32 accumulation / master weights)")
+        self.precision = precision
         self.config = c = config or FastSpeech2ModelConfig()
         self.stats = stats or Stats()
         self.training = training or FastSpeech2TrainingConfig()
@@ -642,7 +646,12 @@ class FastSpeech2Trainer:
     def training_step(self, batch: dict) -> dict:
         """One optimiser step; returns the losses as device scalars (no host synchronisation inside the step)."""
         from .hifigan import allreduce_mean_
-        losses = self.forward_backward(batch)
+        prev = ops.CONV_BACKEND["operands"]
+        ops.CONV_BACKEND["operands"] = self.precision
+        try:
+            losses = self.forward_backward(batch)
+        finally:
+            ops.CONV_BACKEND["operands"] = prev
         if self.pg is not None:  # data parallel: utterances are sharded across ranks, gradients averaged (SURVEY.md 8e)
             allreduce_mean_(self.params.grad, self.pg if self.pg is not True else None, lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
         g = self.params

@@ -280,7 +280,12 @@ class HiFiGANTrainer:
     """Generator + MPD + MSD with two AdamW optimisers; ``training_step`` is one full GAN step."""
 
     def __init__(self, config: HiFiGANConfig | None = None, device="cuda:0", lr=2e-4, betas=(0.8, 0.99), eps=1e-8,
-                 weight_decay=0.01, seed=1234, process_group=None, reconstruction_loss="mel", stft_loss_weight=45.0):
+                 weight_decay=0.01, seed=1234, process_group=None, reconstruction_loss="mel", stft_loss_weight=45.0,
+                 precision="f32"):
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision: 'f32' (exact fp32 arithmetic) or 'bf16' (bf16 convolution operands, fp32 accumulation, "
+                             "fp32 master weights and activations: the mixed-precision counterpart of Lightning's bf16-mixed)")
+        self.precision = precision
         self.config = config or HiFiGANConfig()
         self.device = torch.device(device)
         self.opt = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -459,6 +464,14 @@ class HiFiGANTrainer:
     # -- one GAN step -----------------------------------------------------------------------------------------
     def training_step(self, mel_bct: torch.Tensor, audio_bct: torch.Tensor) -> dict:
         """mel [B, n_mels, T/hop], audio [B, 1, T] on the device.  Returns the scalar losses (python floats)."""
+        prev = ops.CONV_BACKEND["operands"]
+        ops.CONV_BACKEND["operands"] = self.precision
+        try:
+            return self._training_step(mel_bct, audio_bct)
+        finally:
+            ops.CONV_BACKEND["operands"] = prev
+
+    def _training_step(self, mel_bct: torch.Tensor, audio_bct: torch.Tensor) -> dict:
         dev = self.device
         B = audio_bct.shape[0]
         y = audio_bct.to(torch.float32).reshape(1, B, -1).contiguous()  # [B,1,T] and [1,B,T] are the same bytes

@@ -34,13 +34,11 @@ def training_batch(B=32, seed=1234, n_mels=80, learn_alignment=True, device="cud
 def main():
     from everyvoice_amd.train.fs2 import FastSpeech2Trainer
 
-    from everyvoice_amd.train import ops as _ops  # noqa: E402
-_ops.CONV_BACKEND["operands"] = os.environ.get("OPERANDS", "f32")
-dev = torch.device("cuda:0")
+    dev = torch.device("cuda:0")
     B = int(os.environ.get("EVMI_FS2_B", "32"))
     from everyvoice_amd.fs2 import FastSpeech2ModelConfig
     learn = os.environ.get("EVMI_FS2_LEARN_ALIGNMENT", "1") == "1"
-    tr = FastSpeech2Trainer(FastSpeech2ModelConfig(learn_alignment=learn), device=dev)
+    tr = FastSpeech2Trainer(FastSpeech2ModelConfig(learn_alignment=learn), device=dev, precision=os.environ.get("OPERANDS", "f32"))
     batch, T_i = training_batch(B, learn_alignment=learn, device=dev)
     print(f"parameters {tr.params.numel():,}")
     for _ in range(2):

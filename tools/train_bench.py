@@ -23,7 +23,7 @@ B, S = int(os.environ.get("EVMI_TRAIN_B", "16")), 8192
 g = torch.Generator().manual_seed(1234)
 y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(dev)
 mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
-tr = HiFiGANTrainer(device=dev)
+tr = HiFiGANTrainer(device=dev, precision=os.environ.get("OPERANDS", "f32"))
 for i in range(2):
     out = tr.training_step(mel, y)
 torch.cuda.synchronize()
