@@ -92,6 +92,8 @@ SYMBOLS = {
     "evmi_conv1d_dgrad_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv1d_dgrad_cbt_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
     "evmi_conv1d_dgrad_cbt_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
+    "evmi_conv1d_wgrad_cbt_bf16pk_ws_elems": (C.c_longlong, [C.c_int] * 10),
+    "evmi_conv1d_wgrad_cbt_bf16pk": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 11 + [C.c_void_p]),
     "evmi_conv1d_wgrad_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv1d_wgrad_cbt_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 11 + [C.c_void_p]),
     "evmi_fs2_embed_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),

@@ -25,12 +25,14 @@
 
 #include "common.h"
 #include "conv_cbt_direct.h"
+#include "conv_pk_common.h"
 
 namespace evmi {
 
 struct ConvPkArgs {
   const uint4* xp;     // packed input [groups][octs][B][Tp] units (+ slack)
   const uint4* wf;     // fragments [phase][groups*mblocks][kblocks][64] units
+  const int2* tab;     // per K block: window offsets (units) of its two halves, relative to the first octet row of its step
   const float* bias;   // [c_out] or nullptr
   float* y;            // [c_out][B][t_out_total]
   int B, Tp, t_out_total;
@@ -69,49 +71,6 @@ __device__ __forceinline__ void pk_with_act(int act, F&& body) {
   }
 }
 
-typedef __attribute__((address_space(3))) uint4 lds_u4_t;
-typedef __attribute__((address_space(1))) const uint4 glb_u4_t;
-__device__ __forceinline__ void pk_lds_direct(const uint4* g, uint4* l) {
-  __builtin_amdgcn_global_load_lds((glb_u4_t*)g, (lds_u4_t*)l, 16, 0, 0);
-}
-
-__device__ __forceinline__ unsigned pk_bf16x2(float lo, float hi) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  bf2 v;
-  v[0] = (__bf16)lo;
-  v[1] = (__bf16)hi;
-  return __builtin_bit_cast(unsigned, v);
-}
-
-// x [groups*cin_g][B][t_in] fp32 -> xp [groups][octs][B][Tp] units; unit (g, o, b, u) = channels g*cin_g + 8o..8o+7 at t = u - PL.
-// grid (ceil(Tp / 256), B, groups*octs): one thread per unit, consecutive threads consecutive u (coalesced reads of 8 channel
-// rows, 16-byte writes); no index divisions.
-__global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ x, uint4* __restrict__ xp, int cin_g, int octs, int B,
-                                                     int t_in, int Tp, int PL) {
-  const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= Tp) return;
-  const int b = blockIdx.y, go = blockIdx.z;
-  const int g = go / octs, o = go - g * octs;
-  const int t = u - PL;
-  float v[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = 0.f;
-  if (t >= 0 && t < t_in) {
-    const float* src = x + ((long long)(g * cin_g + o * 8) * B + b) * t_in + t;
-    const long long cs = (long long)B * t_in;
-    const int nch = min(8, cin_g - o * 8);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < nch) v[i] = src[i * cs];
-  }
-  uint4 out;
-  out.x = pk_bf16x2(v[0], v[1]);
-  out.y = pk_bf16x2(v[2], v[3]);
-  out.z = pk_bf16x2(v[4], v[5]);
-  out.w = pk_bf16x2(v[6], v[7]);
-  xp[((long long)go * B + b) * Tp + u] = out;
-}
-
 // A fragments.  mode 0 (forward): rows = output channels of w [c_out][cin_g][k], K channels = input channels, tap j.
 // mode 1 (input gradient, phase phi of `stride`): rows = INPUT channels, K channels = output channels, M taps per phase
 // (phases with fewer taps zero padded in front), tap m -> j = phi + stride * (m_phi - 1 - (m - lead)): see wfrag_dgrad_kernel.
@@ -119,8 +78,13 @@ __global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ x
 // grid (kblocks, groups*MB, phases), 256 threads = 64 lanes x 4 words
 __global__ __launch_bounds__(256) void wfrag_pk_kernel(const float* __restrict__ w, unsigned* __restrict__ wf, int rows_g, int kch_g, int kt,
                                                        int MB, int octs, int kblocks, int mode, int k_full, int stride,
-                                                       long long phase_stride_words) {
+                                                       long long phase_stride_words, int2* __restrict__ tab, int kb_step, int xrow, int dil) {
   const int q = blockIdx.x, gmb = blockIdx.y, phi = blockIdx.z;
+  if (gmb == 0 && phi == 0 && threadIdx.x == 0) {  // offsets of the K block's halves in the staged window of its ring step
+    const int o_lo = (2 * (q / kb_step) * kb_step) / kt;
+    const int h0 = 2 * q, h1 = h0 + 1 < octs * kt ? h0 + 1 : h0;  // odd tail: zero weights, any staged unit
+    tab[q] = make_int2((h0 / kt - o_lo) * xrow + (h0 % kt) * dil, (h1 / kt - o_lo) * xrow + (h1 % kt) * dil);
+  }
   const int g = gmb / MB, mb = gmb - g * MB;
   const int lane = threadIdx.x >> 2, wd = threadIdx.x & 3;
   const int mi = lane & 31, kh = lane >> 5;
@@ -216,7 +180,6 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
   const int nsteps = (a.kblocks + kbs - 1) / kbs;
   const uint4* wf_tile = a.wf + (long long)ph * a.wf_phase_stride + (long long)(g * a.mblocks + mt_idx * MBT) * a.kblocks * 64;
   const int mb_last = a.mblocks - 1 - mt_idx * MBT;  // m-blocks past the group re-read the last one (never stored)
-  const int halves = a.octs * k;
 
   // ---- loader: the 1 KB units of step t (weight fragments, then window pieces) round-robin over the four waves ----
   auto issue = [&](int t, int slot) -> int {
@@ -268,46 +231,49 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     const int nq = min(kbs, a.kblocks - q0);
     const int o_lo = (2 * q0) / k;
     const uint4* sm = smem + slot * stage;
-    // halves (2q, 2q+1) -> (octet, tap); kept incrementally
-    int h0 = 2 * q0;
-    int o0 = h0 / k, j0 = h0 - o0 * k;
-    int o1 = o0, j1 = j0 + 1;
-    if (j1 >= k) { j1 -= k; ++o1; }
-    auto lane_off = [&]() -> int {
-      const int off0 = (o0 - o_lo) * xrow + j0 * d;
-      const int off1 = h0 + 1 < halves ? (o1 - o_lo) * xrow + j1 * d : off0;  // odd tail: zero weights, any staged unit
-      return kh ? off1 : off0;
-    };
-    auto advance = [&]() {
-      h0 += 2;
-      j0 += 2;
-      while (j0 >= k) { j0 -= k; ++o0; }
-      j1 += 2;
-      while (j1 >= k) { j1 -= k; ++o1; }
-    };
-    bf16x8 fa[MT], fb[NT], na[MT], nb[NT];
-    auto load = [&](bf16x8 (&da)[MT], bf16x8 (&db)[NT], int qi) {
-      const int lo = lane_off();
+    // wave-uniform table reads through the constant address space: scalar loads (s_load), which leave vmcnt -- the
+    // counter the LDS-direct ring is tracked with -- alone
+    typedef __attribute__((address_space(4))) const int cint_t;
+    cint_t* tbw = (cint_t*)(a.tab + q0);
+    auto tb_at = [&](int qi) { return make_int2(tbw[2 * qi], tbw[2 * qi + 1]); };
+    bf16x8 fa[2][MT], fb[2][NT], na[2][MT], nb[2][NT];
+    auto load = [&](bf16x8 (&da)[MT], bf16x8 (&db)[NT], int qi, int2 e) {
+      const int lo = kh ? e.y : e.x;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) da[mt] = *reinterpret_cast<const bf16x8*>(sm + abase[mt] + qi * 64);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) db[nt] = *reinterpret_cast<const bf16x8*>(sm + colu[nt] + lo);
     };
-    load(fa, fb, 0);
-    if (!(a.ablate & 4))
-    for (int qi = 0; qi < nq; ++qi) {
-      if (qi + 1 < nq) advance();  // past the end: re-read the last block (in-bounds, unused)
-      load(na, nb, min(qi + 1, nq - 1));
-      __builtin_amdgcn_sched_barrier(0);  // the LDS reads of block qi+1 are in flight before the MFMAs of block qi issue
+    auto mma = [&](const bf16x8 (&da)[MT], const bf16x8 (&db)[NT]) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[mt], db[nt], acc[mt][nt], 0, 0, 0);
+    };
+    // Two K blocks per iteration: the LDS reads of blocks qi+2, qi+3 are in flight before the MFMAs of qi, qi+1 issue, and the
+    // table entries of the iteration after that are fetched one iteration early (past the end: re-reads of the last block,
+    // in-bounds and unused).
+    load(fa[0], fb[0], 0, tb_at(0));
+    load(fa[1], fb[1], min(1, nq - 1), tb_at(min(1, nq - 1)));
+    int2 e0 = tb_at(min(2, nq - 1)), e1 = tb_at(min(3, nq - 1));
+    if (!(a.ablate & 4))
+    for (int qi = 0; qi < nq; qi += 2) {
+      const int2 f0 = tb_at(min(qi + 4, nq - 1)), f1 = tb_at(min(qi + 5, nq - 1));
+      load(na[0], nb[0], min(qi + 2, nq - 1), e0);
+      load(na[1], nb[1], min(qi + 3, nq - 1), e1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(fa[0], fb[0]);
+      if (qi + 1 < nq) mma(fa[1], fb[1]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) fa[mt] = na[mt];
+      for (int u = 0; u < 2; ++u) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) fb[nt] = nb[nt];
+        for (int mt = 0; mt < MT; ++mt) fa[u][mt] = na[u][mt];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) fb[u][nt] = nb[u][nt];
+      }
+      e0 = f0;
+      e1 = f1;
     }
   }
 
@@ -418,7 +384,7 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     // deepest step (K blocks) that leaves two workgroups per CU; three slots when they fit at that depth
     int kbs = 1, nst = 2;
     const size_t budget = lds_of(1, 2) <= two_wg ? two_wg : one_wg;
-    const int kbs_cap = std::min(a.kblocks, pk_env_int("EVMI_PK_KBS_CAP", 16));
+    const int kbs_cap = std::min(a.kblocks, pk_env_int("EVMI_PK_KBS_CAP", 32));
     while (kbs < kbs_cap && lds_of(kbs + 1, 2) <= budget) ++kbs;
     if (lds_of(std::max(1, kbs * 2 / 3), 3) <= budget && kbs >= 3) { nst = 3; kbs = std::max(1, kbs * 2 / 3); }
     const int fk = pk_env_int("EVMI_PK_KBS", 0), fn = pk_env_int("EVMI_PK_NST", 0);
@@ -441,7 +407,7 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
   // slack: the last window piece of the last tile reads up to 63 units past its window, rows of the last octet included
   pl.xp_units = (long long)groups * a.octs * a.B * a.Tp + (long long)a.xrow + 64;
   a.wf_phase_stride = (long long)groups * a.mblocks * a.kblocks * 64;
-  pl.wf_units = a.wf_phase_stride * a.phases;
+  pl.wf_units = a.wf_phase_stride * a.phases + ((long long)a.kblocks * 8 + 15) / 16;  // + the K-block offset table (int2 each)
   if (pl.xp_units >= (1LL << 31)) return "packed input too large";
   if (a.B > 65535 || groups * a.octs > 65535) return "grid limits (pack)";
   return nullptr;
@@ -459,7 +425,8 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
                      a.octs, a.B, pl.t_in, a.Tp, pl.PL);
   hipLaunchKernelGGL(wfrag_pk_kernel, dim3(a.kblocks, pl.groups * a.mblocks, a.phases), dim3(256), 0, stream, w,
                      reinterpret_cast<unsigned*>(wf), rows_g, kch_g, a.k, a.mblocks, a.octs, a.kblocks, wmode, k_full, stride_full,
-                     a.wf_phase_stride * 4);
+                     a.wf_phase_stride * 4, reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases), a.kb_step, a.xrow, a.dil);
+  a.tab = reinterpret_cast<const int2*>(wf + a.wf_phase_stride * a.phases);
   a.xp = xp;
   a.wf = wf;
   static const int xcd_remap = pk_env_int("EVMI_F32_XCD", 1);

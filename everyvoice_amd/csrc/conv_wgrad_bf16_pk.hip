@@ -1,0 +1,339 @@
+// Weight gradient of the 1-D convolution with bf16 operands (fp32 accumulation), on PACKED copies of x and dy:
+//
+//   dw[co][ci][j] (+)= sum_{b, to} bf16(dy[co][b][to]) * bf16(x[ci][b][to*s + j*d - p])
+//
+// GEMM view: M = output channels, N = input channels (one tap j per accumulator tile), K = the flattened (item, position)
+// index.  Both operands come from the packed layout of conv_pk_common.h -- 16-byte units of 8 channels at one position -- in
+// which the K index runs ACROSS units: exactly the case of gfx950's transposing LDS read.  ds_read_b64_tr_b16 hands every lane
+// 4 consecutive positions of ONE channel out of a [position][channel] image, so the LDS image of both operands is a plain
+// copy of the packed rows (1 KB LDS-direct loads, no masks), and the stride / dilation of the convolution is just the
+// per-lane address of the x read (row stride of the transposed block = s units, tap offset = j*d units).
+//
+//  * dy is packed with every item padded to Tq positions (a multiple of 16, zeros behind the n_out valid ones) and x with items
+//    of exactly Tq*s positions (PL = pad zeros in front): then position f = b*Tq + to of dy pairs with unit f*s + j*d of x for
+//    EVERY item -- the K loop runs over one flat index, K steps span short items freely, and the zero tail of dy cancels
+//    whatever the x window holds there.
+//  * Workgroup = 64 output channels x 64 input channels x TG taps (accumulators: TG tiles of 32x32 per wave, 2x2 waves);
+//    the x window of a K step is staged once and serves all TG taps.  Long kernels split their taps over grid.x.
+//  * Split-K over grid.z with partial tiles added in a fixed order by wgrad_pk_reduce_kernel (deterministic).
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+
+#include "common.h"
+#include "conv_pk_common.h"
+
+namespace evmi {
+
+struct WgradPkArgs {
+  const uint4* dyp;   // [groups][octs_y][B*Tq] units (+ slack)
+  const uint4* xp;    // [groups][octs_x][B*Tq*s] units (+ slack)
+  float* out;         // dw [c_out][cin_g][k] (splits == 1) or partial tiles [splits][c_out][cin_g][k]
+  int cout_g, cin_g, k, stride, dil;
+  int octs_y, octs_x;
+  long long plane_y, plane_x;  // units per octet row
+  int ksteps;          // K steps of KS positions in total
+  int steps_per_split;
+  int tg, ntg;         // taps per workgroup, tap groups
+  int tiles_ci, tiles_co;
+  int xrow, xpieces;   // staged x row: units (64 * pieces)
+  int nst;
+  int accumulate;      // splits == 1 only: dw += instead of =
+  int partial, c_out;  // 1: out is the partial-tile buffer [split][tap][c_out][cin_g]
+  long long split_stride;  // floats between partial copies
+};
+
+constexpr int WG_KS = 64;  // positions per K step (4 MFMA K blocks)
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 lds_read_tr(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+__device__ __forceinline__ bf16x8 join_tr(s16x4 lo, s16x4 hi) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TGMAX>
+__global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int kh = lane >> 5;
+  const int k = a.k, s = a.stride, d = a.dil, tg = a.tg;
+
+  const int tile_ci = blockIdx.x % a.tiles_ci, tgi = blockIdx.x / a.tiles_ci;
+  const int g = blockIdx.y / a.tiles_co, tile_co = blockIdx.y % a.tiles_co;
+  const int j_lo = tgi * tg;
+  const int tgc = min(tg, k - j_lo);  // taps of this group
+  const int split = blockIdx.z;
+  const int t_lo = split * a.steps_per_split, t_hi = min(a.ksteps, t_lo + a.steps_per_split);
+  if (t_lo >= t_hi) return;  // (the reduce pass only reads the splits that exist)
+
+  // octet rows of this tile, clamped to the group (rows past it are staged from the last one and never stored)
+  const int oy0 = tile_co * 8, ox0 = tile_ci * 8;
+  const uint4* dy_g = a.dyp + (long long)g * a.octs_y * a.plane_y;
+  const uint4* x_g = a.xp + (long long)g * a.octs_x * a.plane_x;
+  const int xrow = a.xrow, xpieces = a.xpieces;
+  const int y_units = 8 * WG_KS;
+  const int stage = y_units + 8 * xrow;
+
+  // ---- per-lane addresses of the transposing reads (bytes within a stage) ----
+  // 16-lane group G: kh = G >> 1 (K half of the MFMA operand), hf = G & 1 (which 16 of the 32 channels); lane i of the group
+  // supplies the address of 4 channels (i & 3) of position row (i >> 2) and receives channel i, 4 positions.
+  const int i16 = lane & 15, hf = (lane >> 4) & 1;
+  const int oct_in_blk = 2 * hf + ((i16 & 3) >> 1);
+  const int a_base = (((wm * 4 + oct_in_blk) * WG_KS) + 8 * kh + (i16 >> 2)) * 16 + (i16 & 1) * 8;
+  const int b_base = (y_units + (wn * 4 + oct_in_blk) * xrow + (8 * kh + (i16 >> 2)) * s) * 16 + (i16 & 1) * 8;
+
+  f32x16 acc[TGMAX];
+#pragma unroll
+  for (int j = 0; j < TGMAX; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  auto issue = [&](int t, int slot) -> int {
+    uint4* sy = smem + slot * stage;
+    uint4* sx = sy + y_units;
+    const long long f0 = (long long)t * WG_KS;
+    int issued = 0;
+    int u = wave;
+    for (; u < 8; u += 4) {  // dy: 8 octet rows x 64 units = one 1 KB piece each
+      const int o = min(oy0 + u, a.octs_y - 1);
+      pk_lds_direct(dy_g + (long long)o * a.plane_y + f0 + lane, sy + u * WG_KS);
+      ++issued;
+    }
+    u -= 8;
+    const long long x0 = f0 * s + (long long)j_lo * d;
+    for (; u < 8 * xpieces; u += 4) {
+      const int r = u / xpieces, pi = u - r * xpieces;
+      const int o = min(ox0 + r, a.octs_x - 1);
+      pk_lds_direct(x_g + (long long)o * a.plane_x + x0 + pi * 64 + lane, sx + r * xrow + pi * 64);
+      ++issued;
+    }
+    return issued;
+  };
+
+  const int nst = a.nst;
+  int n_next = 0;
+  issue(t_lo, 0);
+  if (nst == 3 && t_lo + 1 < t_hi) n_next = issue(t_lo + 1, 1);
+  int slot = -1;
+  for (int t = t_lo; t < t_hi; ++t) {
+    slot = slot + 1 == nst ? 0 : slot + 1;
+    const int slot_ahead = slot == 0 ? nst - 1 : slot - 1;
+    wait_vmcnt_le(n_next);
+    lds_barrier();
+    {
+      const int issued = t + nst - 1 < t_hi ? issue(t + nst - 1, slot_ahead) : 0;
+      n_next = nst == 3 ? issued : 0;
+    }
+    const char* sm = reinterpret_cast<const char*>(smem + slot * stage);
+#pragma unroll
+    for (int kb = 0; kb < WG_KS / 16; ++kb) {
+      const char* pa = sm + a_base + kb * 256;
+      const bf16x8 fa = join_tr(lds_read_tr(pa), lds_read_tr(pa + 64));
+      const char* pb = sm + b_base + kb * 16 * s * 16;
+      bf16x8 fb[TGMAX];
+#pragma unroll
+      for (int j = 0; j < TGMAX; ++j)
+        if (j < tgc) {
+          const char* q = pb + j * d * 16;
+          fb[j] = join_tr(lds_read_tr(q), lds_read_tr(q + 4 * s * 16));
+        }
+#pragma unroll
+      for (int j = 0; j < TGMAX; ++j)
+        if (j < tgc) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+    }
+  }
+
+  // ---- store: lane column = input channel, registers = output channels ----
+  const int ci = tile_ci * 64 + wn * 32 + (lane & 31);
+  if (ci >= a.cin_g) return;
+  if (a.partial) {  // partial tiles [split][tap][c_out][cin_g]: consecutive lanes consecutive addresses
+    float* outp = a.out + (long long)split * a.split_stride;
+    const long long tap_stride = (long long)a.c_out * a.cin_g;
+#pragma unroll
+    for (int j = 0; j < TGMAX; ++j) {
+      if (j >= tgc) break;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m >= a.cout_g) continue;
+        outp[(j_lo + j) * tap_stride + (long long)(g * a.cout_g + m) * a.cin_g + ci] = acc[j][r];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TGMAX; ++j) {
+    if (j >= tgc) break;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (m >= a.cout_g) continue;
+      float* dst = a.out + ((long long)(g * a.cout_g + m) * a.cin_g + ci) * k + j_lo + j;
+      *dst = a.accumulate ? *dst + acc[j][r] : acc[j][r];
+    }
+  }
+}
+
+// dw[co][ci][j] (+)= sum over the partial copies [split][j][co][ci], in split order (fixed summation order: bitwise
+// reproducible).  One thread per (j, co, ci) in the partial tiles' order: coalesced reads, one strided write.
+__global__ __launch_bounds__(256) void wgrad_pk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long long rows_ci, int k,
+                                                              int splits, long long split_stride, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // co * cin_g + ci
+  const int j = blockIdx.y;
+  if (i >= rows_ci) return;
+  float acc = 0.f;
+  for (int sidx = 0; sidx < splits; ++sidx) acc += part[sidx * split_stride + j * rows_ci + i];
+  float* dst = dw + i * k + j;
+  *dst = accumulate ? *dst + acc : acc;
+}
+
+struct WgradPkPlan {
+  int Tq, octs_y, octs_x, splits;
+  long long dy_units, x_units, part_elems;
+  size_t lds;
+  dim3 grid;
+  int tgmax;
+};
+
+static int wg_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad,
+                                 int dil, int groups) {
+  if (groups <= 0 || c_in <= 0 || c_out <= 0 || c_in % groups || c_out % groups || k <= 0 || stride <= 0 || dil <= 0 || B <= 0 || n_out <= 0 ||
+      t_in <= 0 || pad < 0)
+    return "bad shape";
+  const int cin_g = c_in / groups, cout_g = c_out / groups;
+  if (cin_g < 32 || cout_g < 32 || cin_g * cout_g < 4096) return "narrow groups (the fp32 implicit-GEMM kernel takes them)";
+  if (stride > 8) return "stride above 8";
+  a.cout_g = cout_g; a.cin_g = cin_g; a.k = k; a.stride = stride; a.dil = dil;
+  pl.octs_y = a.octs_y = (cout_g + 7) / 8;
+  pl.octs_x = a.octs_x = (cin_g + 7) / 8;
+  // item length: a multiple of 16 positions, and Tq*s units of x must hold the padded item and every tap of a valid output
+  long long need = std::max<long long>((long long)pad + t_in, (long long)(n_out - 1) * stride + (long long)(k - 1) * dil + 1);
+  long long Tq = ((long long)n_out + 15) / 16 * 16;
+  // ... and the rows of the packed dy must end on a K-step boundary (the step past the end would read the next row)
+  while (Tq * stride < need || ((long long)B * Tq) % WG_KS) Tq += 16;
+  if (Tq > (1 << 22)) return "row too long";
+  pl.Tq = (int)Tq;
+  a.plane_y = (long long)B * Tq;
+  a.plane_x = (long long)B * Tq * stride;
+  a.ksteps = (int)((a.plane_y + WG_KS - 1) / WG_KS);
+  // taps per workgroup
+  const int tgcap = 8;
+  a.ntg = (k + tgcap - 1) / tgcap;
+  a.tg = (k + a.ntg - 1) / a.ntg;
+  pl.tgmax = a.tg <= 4 ? 4 : 8;
+  a.tiles_ci = (cin_g + 63) / 64;
+  a.tiles_co = (cout_g + 63) / 64;
+  const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;
+  if (xwin > 64 * 12) return "input window too long";
+  a.xpieces = (int)((xwin + 63) / 64);
+  a.xrow = a.xpieces * 64;
+  const size_t stage_bytes = (size_t)(8 * WG_KS + 8 * a.xrow) * 16;
+  a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
+  const int fn = wg_env_int("EVMI_WG_NST", 0);
+  if (fn == 2 || fn == 3) a.nst = fn;
+  pl.lds = a.nst * stage_bytes;
+  if (pl.lds > 160 * 1024) return "LDS budget";
+  const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co * groups;
+  static const long long want = wg_env_int("EVMI_WG_WANT", 512);
+  static const int min_steps = wg_env_int("EVMI_WG_MIN_STEPS", 8);  // K steps per workgroup that pay for its prologue and tile store
+  int splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / min_steps));
+  const int fs = wg_env_int("EVMI_WG_SPLITS", 0);
+  if (fs > 0) splits = std::min(fs, a.ksteps);
+  a.steps_per_split = (a.ksteps + splits - 1) / splits;
+  splits = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;  // no empty splits
+  pl.splits = splits;
+  if ((long long)a.tiles_ci * a.ntg > 0x7fffffffLL || (long long)groups * a.tiles_co > 65535 || splits > 65535) return "grid limits";
+  pl.grid = dim3(a.tiles_ci * a.ntg, groups * a.tiles_co, splits);
+  // slack: the last K step reads up to its full window past the end of the last row
+  pl.dy_units = (long long)groups * a.octs_y * a.plane_y + WG_KS + 64;
+  pl.x_units = (long long)groups * a.octs_x * a.plane_x + (long long)WG_KS * stride + a.xrow + 64;
+  a.split_stride = (long long)c_out * cin_g * k;
+  pl.part_elems = splits > 1 ? a.split_stride * splits : 0;
+  if (B > 65535 || groups * std::max(a.octs_x, a.octs_y) > 65535) return "grid limits (pack)";
+  if (pl.dy_units >= (1LL << 31) || pl.x_units >= (1LL << 31)) return "packed operands too large";
+  return nullptr;
+}
+
+}  // namespace evmi
+
+using namespace evmi;
+
+extern "C" {
+
+/* Floats of workspace (packed dy, packed x, split-K partial tiles); 0 = shape not taken here. */
+long long evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil,
+                                                int groups) {
+  WgradPkArgs a = {};
+  WgradPkPlan pl;
+  if (plan_wgrad_pk(a, pl, B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups)) return 0;
+  return (pl.dy_units + pl.x_units) * 4 + pl.part_elems;
+}
+
+int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in,
+                                 int t_in, int c_out, int n_out, int k, int stride, int pad, int dil, int groups, int accumulate,
+                                 void* stream) {
+  if (!x_dev || !dy_dev || !dw_dev || !ws_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_cbt_bf16pk: null pointer");
+  WgradPkArgs a = {};
+  WgradPkPlan pl;
+  if (const char* why = plan_wgrad_pk(a, pl, B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_wgrad_cbt_bf16pk: ") + why);
+  const long long need = (pl.dy_units + pl.x_units) * 4 + pl.part_elems;
+  if (ws_elems < need || (reinterpret_cast<uintptr_t>(ws_dev) & 15))
+    return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_cbt_bf16pk: workspace too small or unaligned");
+  hipStream_t s = (hipStream_t)stream;
+  uint4* dyp = reinterpret_cast<uint4*>(ws_dev);
+  uint4* xp = dyp + pl.dy_units;
+  float* part = reinterpret_cast<float*>(xp + pl.x_units);
+  const int cin_g = c_in / groups, cout_g = c_out / groups;
+  // the slack behind both packed tensors is read (never used): keep it finite
+  EVMI_HIP_CHECK(hipMemsetAsync(dyp + (pl.dy_units - WG_KS - 64), 0, (size_t)(WG_KS + 64) * 16, s));
+  EVMI_HIP_CHECK(hipMemsetAsync(xp + (long long)groups * a.octs_x * a.plane_x, 0,
+                                (size_t)(pl.x_units - (long long)groups * a.octs_x * a.plane_x) * 16, s));
+  hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((pl.Tq + 255) / 256), B, groups * a.octs_y), dim3(256), 0, s, dy_dev, dyp, cout_g, a.octs_y,
+                     B, n_out, pl.Tq, 0);
+  const int Tpx = pl.Tq * stride;
+  hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((Tpx + 255) / 256), B, groups * a.octs_x), dim3(256), 0, s, x_dev, xp, cin_g, a.octs_x, B,
+                     t_in, Tpx, pad);
+  a.dyp = dyp;
+  a.xp = xp;
+  a.out = pl.splits > 1 ? part : dw_dev;
+  a.accumulate = pl.splits > 1 ? 0 : accumulate;
+  a.partial = pl.splits > 1;
+  a.c_out = c_out;
+  static thread_local size_t configured[2] = {0, 0};
+  const size_t lds = pl.lds;
+  if (pl.tgmax == 4) {
+    if (lds > configured[0]) {
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured[0] = lds;
+    }
+    hipLaunchKernelGGL((wgrad_pk_kernel<4>), pl.grid, dim3(256), lds, s, a);
+  } else {
+    if (lds > configured[1]) {
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured[1] = lds;
+    }
+    hipLaunchKernelGGL((wgrad_pk_kernel<8>), pl.grid, dim3(256), lds, s, a);
+  }
+  EVMI_LAUNCH_CHECK("wgrad_pk_kernel");
+  if (pl.splits > 1) {
+    const long long rows_ci = (long long)c_out * cin_g;
+    hipLaunchKernelGGL(wgrad_pk_reduce_kernel, dim3((unsigned)((rows_ci + 255) / 256), k), dim3(256), 0, s, part, dw_dev, rows_ci, k, pl.splits,
+                       a.split_stride, accumulate);
+    EVMI_LAUNCH_CHECK("wgrad_pk_reduce_kernel");
+  }
+  return EVMI_OK;
+}
+
+}  // extern "C"

@@ -249,8 +249,14 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
     if need_dw:
         dw = dw_out if dw_out is not None else torch.empty_like(w)
         lib = _lib.load()
-        ws_elems = lib.evmi_conv1d_wgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) if (CONV_BACKEND["wgrad"] == "mfma" or (CONV_BACKEND["wgrad"] == "auto" and groups > 1)) else 0
-        if ws_elems > 0:  # implicit GEMM on the fp32 matrix cores (conv_wgrad_f32_mfma.hip)
+        pk_elems = (lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+                    if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"] and CONV_BACKEND["wgrad"] != "gemm" else 0)
+        ws_elems = 0 if pk_elems > 0 else lib.evmi_conv1d_wgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) if (CONV_BACKEND["wgrad"] == "mfma" or (CONV_BACKEND["wgrad"] == "auto" and groups > 1)) else 0
+        if pk_elems > 0:  # bf16 operands: packed dy and x, transposing LDS reads (conv_wgrad_bf16_pk.hip)
+            ws = WS.get("pkw", pk_elems, x.device)
+            _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout, t_out,
+                                                  k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk")
+        elif ws_elems > 0:  # implicit GEMM on the fp32 matrix cores (conv_wgrad_f32_mfma.hip)
             ws = WS.get("wgrad", ws_elems, x.device)
             _chk(lib.evmi_conv1d_wgrad_cbt_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
                                                k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_f32")

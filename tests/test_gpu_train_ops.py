@@ -323,6 +323,47 @@ def test_conv1d_bf16_operands_dgrad(cuda_device, bf16_operands, case):
     assert err <= 2e-5 * scale + 1e-6, case
 
 
+WGRAD_BF16_CASES = [
+    # (B, T, cin, cout, k, stride, pad, dil, groups)
+    (4, 300, 64, 64, 3, 1, 1, 1, 1),
+    (16, 256, 128, 128, 11, 1, 25, 5, 1),     # generator resblock: two tap groups, dilation 5
+    (22, 28, 64, 96, 5, 3, 2, 1, 1),          # period discriminator: stride 3, rows of 10 outputs, ragged channel tile
+    (12, 9, 128, 160, 5, 3, 2, 1, 1),         # rows of 3 outputs: K steps span many items
+    (3, 130, 512, 512, 41, 4, 20, 1, 8),      # scale discriminator: 41 taps in six groups, stride 4, 64 channels per group
+    (5, 64, 72, 104, 7, 2, 3, 1, 1),          # channel counts that are no multiple of 32 / 64
+    (2, 1000, 64, 96, 1, 1, 0, 1, 1),         # pointwise (the FastSpeech2 dense layers)
+    (7, 51, 96, 256, 5, 1, 2, 1, 1),          # odd item count: rows padded to a K-step boundary
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_BF16_CASES)
+def test_conv1d_wgrad_bf16_packed(cuda_device, case):
+    """evmi_conv1d_wgrad_cbt_bf16pk (transposing LDS reads on packed operands) vs torch's weight gradient of the ROUNDED
+    operands: fp32 accumulation of exact bf16 products, only the summation order differs."""
+    from everyvoice_amd import _lib
+
+    B, T, cin, cout, k, s, p, d, groups = case
+    g = torch.Generator().manual_seed(B * 11 + T)
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cout, cin // groups, k, generator=g)
+    n_out = (T + 2 * p - d * (k - 1) - 1) // s + 1
+    dy = torch.randn(B, cout, n_out, generator=g)
+    want = torch.nn.grad.conv1d_weight(_bf(x), w.shape, _bf(dy), s, p, d, groups)
+    lib = _lib.load()
+    ws_elems = lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, T, cout, n_out, k, s, p, d, groups)
+    assert ws_elems > 0, case
+    xd, dyd = cbt(x).to(cuda_device), cbt(dy).to(cuda_device)
+    ws = torch.empty(ws_elems, device=cuda_device)
+    base = torch.randn(w.shape, generator=g)
+    for accumulate in (0, 1):
+        dw = base.clone().to(cuda_device)
+        _lib.check(lib.evmi_conv1d_wgrad_cbt_bf16pk(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, T, cout,
+                                                    n_out, k, s, p, d, groups, accumulate, torch.cuda.current_stream().cuda_stream), "wgrad")
+        ref = want + (base if accumulate else 0)
+        scale = float(want.abs().max())
+        assert float((dw.cpu() - ref).abs().max()) <= 3e-5 * scale + 1e-6, (case, accumulate)
+
+
 def test_conv_kernels_edge_shapes(cuda_device):
     """Single item, single output position, output length 1 per item with many items, channels not a multiple of anything."""
     from everyvoice_amd.train import ops

@@ -101,7 +101,7 @@ def _bf(t):
 
 class _RoundedConv(torch.autograd.Function):
     """The arithmetic of precision="bf16" restated for the oracle: forward and input gradient use bf16-rounded operands
-    (round to nearest even) with fp32 accumulation; the weight gradient stays fp32."""
+    (round to nearest even) with fp32 accumulation; so does the weight gradient where the product's bf16 kernel takes the shape."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, dilation, groups, nd):
@@ -117,7 +117,11 @@ class _RoundedConv(torch.autograd.Function):
         gi = torch.nn.grad.conv1d_input if nd == 1 else torch.nn.grad.conv2d_input
         gw = torch.nn.grad.conv1d_weight if nd == 1 else torch.nn.grad.conv2d_weight
         dx = gi(x.shape, _bf(w), _bf(dy), stride, padding, dilation, groups)
-        dw = gw(x, w.shape, dy, stride, padding, dilation, groups)
+        cin_g, cout_g = w.shape[1], w.shape[0] // groups
+        if cin_g >= 32 and cout_g >= 32 and cin_g * cout_g >= 4096:  # shapes conv_wgrad_bf16_pk.hip takes
+            dw = gw(_bf(x), w.shape, _bf(dy), stride, padding, dilation, groups)
+        else:
+            dw = gw(x, w.shape, dy, stride, padding, dilation, groups)
         db = dy.sum(dim=[0] + list(range(2, dy.dim()))) if has_b else None
         return dx, dw, db, None, None, None, None, None
 
