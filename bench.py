@@ -334,19 +334,26 @@ def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
     sys.path.insert(0, str(ROOT / "tools"))
     from fs2_bench import forward_flops, synthetic_batch
 
-    model = FastSpeech2(device=dev).init_random(1234)
+    prec = args.train_precision
+    model = FastSpeech2(device=dev, precision=prec).init_random(1234)
     ids, lens, durs, t_i = synthetic_batch(32, 1234 + rank)
     ids, lens, durs = ids.to(dev), lens.to(dev), durs.to(dev)
     steps, warmup = 10, 3
     elapsed = timed_region(lambda: model(ids, lens, durations=durs), steps, warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    other = "f32" if prec == "bf16" else "bf16"
+    model.precision = other
+    elapsed_other = timed_region(lambda: model(ids, lens, durations=durs), 3, 1, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    model.precision = prec
     frames = int(t_i.sum())
     flops = forward_flops(lens.cpu(), t_i, int(ids.shape[1]), int(t_i.max()), 32)
     tflops = flops * steps / elapsed / 1e12
-    return {"roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": 157.0, "unit": "TFLOP/s", "frac": round(tflops / 157.0, 4),
+    peak = MFMA_PEAK_TFLOPS_BF16 if prec == "bf16" else 157.0
+    return {"roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
                          "traffic": None, "flop_per_batch": flops, "scope": "whole forward (dense layers on the padded grids)"},
             "metric": "fastspeech2_infer_mel_frames_per_sec", "value": round(world * frames * steps / elapsed, 1), "unit": "frames/s",
             "ms_per_batch": round(elapsed / steps * 1e3, 3), "batch": 32, "max_tokens": int(ids.shape[1]), "frames_per_batch": frames,
-            "dtype": "f32", "steps": steps, "warmup": warmup, "parallelism": f"replicas x{world}",
+            "dtype": prec, "steps": steps, "warmup": warmup, "parallelism": f"replicas x{world}",
+            "other_precision": {"dtype": other, "ms_per_batch": round(elapsed_other / 3 * 1e3, 3), "value": round(world * frames * 3 / elapsed_other, 1), "unit": "frames/s"},
             "realtime_factor": round(world * frames * 256 / 22050.0 * steps / elapsed, 1)}
 
 

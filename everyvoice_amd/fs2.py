@@ -217,7 +217,10 @@ class FastSpeech2:
     """``model = FastSpeech2(config, stats); model.load_state_dict(sd); mel, post, durations, pitch, energy, mel_lens = model(ids, lens)``"""
 
     def __init__(self, config: FastSpeech2ModelConfig | None = None, stats: Stats | None = None, device="cuda:0",
-                 lang2id: dict | None = None, speaker2id: dict | None = None):
+                 lang2id: dict | None = None, speaker2id: dict | None = None, precision: str = "f32"):
+        if precision not in ("f32", "bf16"):
+            raise ValueError("precision: 'f32' (exact fp32 arithmetic) or 'bf16' (bf16 operands of the dense layers, fp32 accumulation)")
+        self.precision = precision
         self.config = config or FastSpeech2ModelConfig()
         self.stats = stats or Stats()
         self.device = torch.device(device)
@@ -359,6 +362,14 @@ class FastSpeech2:
         energy [B, L], mel_lens [B]) on the device."""
         if not self._ready:
             raise RuntimeError("load_state_dict() or init_random() first")
+        prev = ops.CONV_BACKEND["operands"]
+        ops.CONV_BACKEND["operands"] = self.precision
+        try:
+            return self._forward(ids, lens, duration_control, pitch_control, energy_control, durations, speakers, languages)
+        finally:
+            ops.CONV_BACKEND["operands"] = prev
+
+    def _forward(self, ids, lens, duration_control, pitch_control, energy_control, durations, speakers, languages):
         lib, dev, c = _lib.load(), self.device, self.config
         B, L = ids.shape
         if L > c.max_length:

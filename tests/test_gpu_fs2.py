@@ -109,6 +109,38 @@ def test_fs2_default_config(cuda_device):
     _close(got[1].cpu(), want[1], rel=5e-4)
 
 
+def test_fs2_default_config_bf16_operands(cuda_device):
+    """precision="bf16": the dense layers take bf16 operands (fp32 accumulation, fp32 LayerNorm / attention / activations).
+    Against the fp32 oracle with durations given (so the lengths are exact).  The pitch / energy embeddings are made a SMOOTH
+    function of the bin (as trained ones are): a predicted value moved by the operand rounding (1 % of its range = a few of the
+    256 bins) then moves the embedding a little; with the default independent random rows it would swap it for an unrelated
+    unit-variance vector (measured: pitch off by 1e-2, everything behind the embedding by 0.7 -- a property of the random
+    table, not of the arithmetic, which tests/test_gpu_train_ops.py pins per operator).  Tolerance: 5e-2 of each tensor's scale."""
+    from everyvoice_amd.fs2 import FastSpeech2
+
+    ref_cfg = FastSpeech2ConfigRef()
+    torch.manual_seed(3)
+    ref = FastSpeech2Ref(ref_cfg).eval()
+    g = torch.Generator().manual_seed(4)
+    randomize_norm_stats_(ref, g)
+    with torch.no_grad():
+        ramp = torch.linspace(-1.0, 1.0, 256)[:, None]
+        ref.pitch_embedding.weight.copy_(ramp * torch.randn(1, 256, generator=g))
+        ref.energy_embedding.weight.copy_(ramp * torch.randn(1, 256, generator=g))
+    model = FastSpeech2(_product_config(ref_cfg), device=cuda_device, precision="bf16").load_state_dict(ref.state_dict())
+    ids, lens, g = _batch(80, 2, 40, seed=11, lens=[40, 23])
+    durs = torch.randint(2, 9, (2, 40), generator=g)
+    want = ref(ids, lens, durations=durs)
+    got = model(ids, lens, durations=durs)
+    assert torch.equal(got[5].cpu(), want[5])
+    for i in (3, 4, 0, 1):
+        _close(got[i].cpu(), want[i], rel=5e-2)
+    model.precision = "f32"  # the switch is per object and per call: the fp32 path is untouched
+    got32 = model(ids, lens, durations=durs)
+    _close(got32[1].cpu(), want[1], rel=5e-4)
+    assert float((got32[1] - got[1]).abs().max()) > 0.0
+
+
 def test_attention_kernel_alone(cuda_device):
     """evmi_attention_cbt_f32 vs torch scaled-dot-product attention with a key padding mask, ragged lengths, T not a multiple of 32."""
     from everyvoice_amd import _lib
