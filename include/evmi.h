@@ -243,6 +243,32 @@ int evmi_conv1d_cbt_bf16(const float* x_dev, const float* w_dev, const float* bi
 int evmi_conv1d_dgrad_cbt_bf16(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev,
                                long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k,
                                int stride, int pad, int dil, int groups, void* stream);
+/* Packed-input bf16 convolution (csrc/conv_cbt_bf16_pk.hip), the kernel precision="bf16" training and inference use wherever it
+ * takes the shape (at least 8 input channels per group, more than 4 output channels per group): x is first re-laid as
+ * 16-byte units of 8 channels per position with the zero padding materialised (one pass), so that every operand load of the
+ * implicit GEMM is a full 1 KB LDS-direct load and a B fragment one ds_read_b128.  Same arguments as evmi_conv1d_cbt_f32 /
+ * evmi_conv1d_dgrad_cbt_f32; `ws_dev`: 16-byte aligned scratch of the matching *_ws_elems floats (packed input + bf16 weight
+ * fragments + K-block table); *_ws_elems == 0 means "shape not taken here": use the calls above. */
+long long evmi_conv1d_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad,
+                                          int dil, int groups);
+int evmi_conv1d_cbt_bf16pk(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev,
+                           long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out_total, int n_out, int k,
+                           int stride, int pad, int dil, int groups, int out_stride, int out_offset, int accumulate,
+                           int act, float act_param, void* stream);
+long long evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c_out, int t_out, int k, int stride,
+                                                int pad, int dil, int groups);
+int evmi_conv1d_dgrad_cbt_bf16pk(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev,
+                                 long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k, int stride,
+                                 int pad, int dil, int groups, void* stream);
+/* Weight gradient with bf16 operands (csrc/conv_wgrad_bf16_pk.hip): dy and x packed as above, the contraction over
+ * (item, position) fed to the matrix cores through gfx950's transposing LDS read (ds_read_b64_tr_b16), split-K with a
+ * fixed-order reduction (bitwise reproducible).  Takes groups of at least 32 x 32 channels (cin_g * cout_g >= 4096);
+ * *_ws_elems == 0 otherwise (the fp32 implicit-GEMM / GEMM weight gradient below takes those). */
+long long evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride,
+                                                int pad, int dil, int groups);
+int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev,
+                                 long long ws_elems, int B, int c_in, int t_in, int c_out, int n_out, int k, int stride,
+                                 int pad, int dil, int groups, int accumulate, void* stream);
 /* Weight gradient of the same convolution as an implicit GEMM on the fp32 matrix cores (no unfold):
  *   dw[co][ci][j] (+)= sum_{b,to} dy[co][b][to] * x[ci][b][to*stride + j*dil - pad]
  * x [c_in][B][t_in], dy [c_out][B][n_out], dw [c_out][c_in/groups][k]; `ws_dev`: 16-byte aligned scratch of
