@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nsteps = (a.kblocks + kbs - 1) / kbs;
+  const int nsteps = (a.ablate & 16) ? 0 : (a.kblocks + kbs - 1) / kbs;  // (16: timing experiment without the K loop)
   const uint4* wf_tile = a.wf + (long long)ph * a.wf_phase_stride + (long long)(g * a.mblocks + mt_idx * MBT) * a.kblocks * 64;
   const int mb_last = a.mblocks - 1 - mt_idx * MBT;  // m-blocks past the group re-read the last one (never stored)
 
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
 
   int n_next = 0;
   const int nst = a.nst;
-  issue(0, 0);
+  if (nsteps > 0) issue(0, 0);
   if (nst == 3 && nsteps > 1) n_next = issue(1, 1);
 
   int slot = -1;
@@ -386,7 +386,9 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     const size_t budget = lds_of(1, 2) <= two_wg ? two_wg : one_wg;
     const int kbs_cap = std::min(a.kblocks, pk_env_int("EVMI_PK_KBS_CAP", 32));
     while (kbs < kbs_cap && lds_of(kbs + 1, 2) <= budget) ++kbs;
-    if (lds_of(std::max(1, kbs * 2 / 3), 3) <= budget && kbs >= 3) { nst = 3; kbs = std::max(1, kbs * 2 / 3); }
+    // (three slots at 2/3 of the depth measured slower on every layer: the per-step cost -- barrier, scalar bookkeeping, the
+    // un-overlapped first fragment reads -- outweighs the extra step of load latency hidden)
+    if (pk_env_int("EVMI_PK_THREE", 0) && lds_of(std::max(1, kbs * 2 / 3), 3) <= budget && kbs >= 3) { nst = 3; kbs = std::max(1, kbs * 2 / 3); }
     const int fk = pk_env_int("EVMI_PK_KBS", 0), fn = pk_env_int("EVMI_PK_NST", 0);
     if (fn == 2 || fn == 3) nst = fn;
     if (fk > 0) kbs = std::min(fk, a.kblocks);
