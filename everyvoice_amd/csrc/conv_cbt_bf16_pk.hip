@@ -424,7 +424,7 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   uint4* wf = xp + pl.xp_units;
   if (a.B > 65535 || pl.groups * a.octs > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_bf16_pk: grid limits (pack)");
   hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((a.Tp + 255) / 256), a.B, pl.groups * a.octs), dim3(256), 0, stream, x, xp, pl.cin_g,
-                     a.octs, a.B, pl.t_in, a.Tp, pl.PL);
+                     a.octs, a.B, pl.t_in, a.Tp, pl.PL, (int)(pl.xp_units - (long long)pl.groups * a.octs * a.B * a.Tp));
   hipLaunchKernelGGL(wfrag_pk_kernel, dim3(a.kblocks, pl.groups * a.mblocks, a.phases), dim3(256), 0, stream, w,
                      reinterpret_cast<unsigned*>(wf), rows_g, kch_g, a.k, a.mblocks, a.octs, a.kblocks, wmode, k_full, stride_full,
                      a.wf_phase_stride * 4, reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases), a.kb_step, a.xrow, a.dil);

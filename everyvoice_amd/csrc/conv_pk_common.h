@@ -22,12 +22,17 @@ __device__ __forceinline__ unsigned pk_bf16x2(float lo, float hi) {
 
 // x [groups*cin_g][B][t_in] fp32 -> xp [groups][octs][B][Tp] units; unit (g, o, b, u) = channels g*cin_g + 8o..8o+7 at t = u - PL.
 // grid (ceil(Tp / 256), B, groups*octs): one thread per unit, consecutive threads consecutive u (coalesced reads of 8 channel
-// rows, 16-byte writes); no index divisions.
+// rows, 16-byte writes); no index divisions.  The workgroups of the last row also zero `slack_units` units behind the tensor.
 static __global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ x, uint4* __restrict__ xp, int cin_g, int octs, int B,
-                                                     int t_in, int Tp, int PL) {
+                                                     int t_in, int Tp, int PL, int slack_units) {
   const int u = blockIdx.x * 256 + threadIdx.x;
-  if (u >= Tp) return;
   const int b = blockIdx.y, go = blockIdx.z;
+  if (slack_units > 0 && b == B - 1 && go == (int)gridDim.z - 1) {
+    // the units behind the last row are read by the last tiles' window loads (never used): keep them finite
+    uint4* tail = xp + (long long)gridDim.z * B * Tp;
+    for (int i = u; i < slack_units; i += gridDim.x * 256) tail[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (u >= Tp) return;
   const int g = go / octs, o = go - g * octs;
   const int t = u - PL;
   float v[8];

@@ -296,15 +296,12 @@ int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float*
   uint4* xp = dyp + pl.dy_units;
   float* part = reinterpret_cast<float*>(xp + pl.x_units);
   const int cin_g = c_in / groups, cout_g = c_out / groups;
-  // the slack behind both packed tensors is read (never used): keep it finite
-  EVMI_HIP_CHECK(hipMemsetAsync(dyp + (pl.dy_units - WG_KS - 64), 0, (size_t)(WG_KS + 64) * 16, s));
-  EVMI_HIP_CHECK(hipMemsetAsync(xp + (long long)groups * a.octs_x * a.plane_x, 0,
-                                (size_t)(pl.x_units - (long long)groups * a.octs_x * a.plane_x) * 16, s));
+  // (the slack behind both packed tensors is read, never used: the pack kernels zero it)
   hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((pl.Tq + 255) / 256), B, groups * a.octs_y), dim3(256), 0, s, dy_dev, dyp, cout_g, a.octs_y,
-                     B, n_out, pl.Tq, 0);
+                     B, n_out, pl.Tq, 0, (int)(pl.dy_units - (long long)groups * a.octs_y * a.plane_y));
   const int Tpx = pl.Tq * stride;
   hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((Tpx + 255) / 256), B, groups * a.octs_x), dim3(256), 0, s, x_dev, xp, cin_g, a.octs_x, B,
-                     t_in, Tpx, pad);
+                     t_in, Tpx, pad, (int)(pl.x_units - (long long)groups * a.octs_x * a.plane_x));
   a.dyp = dyp;
   a.xp = xp;
   a.out = pl.splits > 1 ? part : dw_dev;
