@@ -221,21 +221,22 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
   for (int t = 0; t < nsteps; ++t) {
     slot = slot + 1 == nst ? 0 : slot + 1;
     const int slot_ahead = slot == 0 ? nst - 1 : slot - 1;
+    const int q0 = t * kbs;
+    const int nq = min(kbs, a.kblocks - q0);
+    // wave-uniform table reads through the constant address space: scalar loads (s_load), which leave vmcnt -- the
+    // counter the LDS-direct ring is tracked with -- alone.  The entries of the step's first four K blocks are fetched
+    // BEFORE the wait for its operands (their latency hides behind it).
+    typedef __attribute__((address_space(4))) const int cint_t;
+    cint_t* tbw = (cint_t*)(a.tab + q0);
+    auto tb_at = [&](int qi) { return make_int2(tbw[2 * qi], tbw[2 * qi + 1]); };
+    const int2 p0 = tb_at(0), p1 = tb_at(min(1, nq - 1)), p2 = tb_at(min(2, nq - 1)), p3 = tb_at(min(3, nq - 1));
     wait_vmcnt_le(n_next);  // step t has landed (this wave's part); step t+1 may still be in flight
     lds_barrier();          // ... everyone's part; the slot about to be refilled was last read in step t-1
     {
       const int issued = t + nst - 1 < nsteps ? issue(t + nst - 1, slot_ahead) : 0;
       n_next = nst == 3 ? issued : 0;
     }
-    const int q0 = t * kbs;
-    const int nq = min(kbs, a.kblocks - q0);
-    const int o_lo = (2 * q0) / k;
     const uint4* sm = smem + slot * stage;
-    // wave-uniform table reads through the constant address space: scalar loads (s_load), which leave vmcnt -- the
-    // counter the LDS-direct ring is tracked with -- alone
-    typedef __attribute__((address_space(4))) const int cint_t;
-    cint_t* tbw = (cint_t*)(a.tab + q0);
-    auto tb_at = [&](int qi) { return make_int2(tbw[2 * qi], tbw[2 * qi + 1]); };
     bf16x8 fa[2][MT], fb[2][NT], na[2][MT], nb[2][NT];
     auto load = [&](bf16x8 (&da)[MT], bf16x8 (&db)[NT], int qi, int2 e) {
       const int lo = kh ? e.y : e.x;
@@ -253,9 +254,9 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     // Two K blocks per iteration: the LDS reads of blocks qi+2, qi+3 are in flight before the MFMAs of qi, qi+1 issue, and the
     // table entries of the iteration after that are fetched one iteration early (past the end: re-reads of the last block,
     // in-bounds and unused).
-    load(fa[0], fb[0], 0, tb_at(0));
-    load(fa[1], fb[1], min(1, nq - 1), tb_at(min(1, nq - 1)));
-    int2 e0 = tb_at(min(2, nq - 1)), e1 = tb_at(min(3, nq - 1));
+    load(fa[0], fb[0], 0, p0);
+    load(fa[1], fb[1], min(1, nq - 1), p1);
+    int2 e0 = p2, e1 = p3;
     if (!(a.ablate & 4))
     for (int qi = 0; qi < nq; qi += 2) {
       const int2 f0 = tb_at(min(qi + 4, nq - 1)), f1 = tb_at(min(qi + 5, nq - 1));

@@ -44,6 +44,10 @@ struct WgradPkArgs {
 };
 
 constexpr int WG_KS = 64;  // positions per K step (4 MFMA K blocks)
+// LDS row stride of the staged dy rows: 64 units + 4 (64 bytes), so that the two octet rows a 16-lane group of the transposing
+// read touches (4 consecutive positions = 64 bytes each) fall on different banks (a stride of 1 KB puts them on the same ones:
+// SQ_LDS_BANK_CONFLICT was 75 % of the LDS cycles); the staged x rows get the same 4 units of padding
+constexpr int WG_YROW = WG_KS + 4;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x4 lds_read_tr(const char* p) {
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   const uint4* dy_g = a.dyp + (long long)g * a.octs_y * a.plane_y;
   const uint4* x_g = a.xp + (long long)g * a.octs_x * a.plane_x;
   const int xrow = a.xrow, xpieces = a.xpieces;
-  const int y_units = 8 * WG_KS;
+  const int y_units = 8 * WG_YROW;
   const int stage = y_units + 8 * xrow;
 
   // ---- per-lane addresses of the transposing reads (bytes within a stage) ----
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   // supplies the address of 4 channels (i & 3) of position row (i >> 2) and receives channel i, 4 positions.
   const int i16 = lane & 15, hf = (lane >> 4) & 1;
   const int oct_in_blk = 2 * hf + ((i16 & 3) >> 1);
-  const int a_base = (((wm * 4 + oct_in_blk) * WG_KS) + 8 * kh + (i16 >> 2)) * 16 + (i16 & 1) * 8;
+  const int a_base = (((wm * 4 + oct_in_blk) * WG_YROW) + 8 * kh + (i16 >> 2)) * 16 + (i16 & 1) * 8;
   const int b_base = (y_units + (wn * 4 + oct_in_blk) * xrow + (8 * kh + (i16 >> 2)) * s) * 16 + (i16 & 1) * 8;
 
   f32x16 acc[TGMAX];
@@ -102,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
     int u = wave;
     for (; u < 8; u += 4) {  // dy: 8 octet rows x 64 units = one 1 KB piece each
       const int o = min(oy0 + u, a.octs_y - 1);
-      pk_lds_direct(dy_g + (long long)o * a.plane_y + f0 + lane, sy + u * WG_KS);
+      pk_lds_direct(dy_g + (long long)o * a.plane_y + f0 + lane, sy + u * WG_YROW);
       ++issued;
     }
     u -= 8;
@@ -237,8 +241,8 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
   const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;
   if (xwin > 64 * 12) return "input window too long";
   a.xpieces = (int)((xwin + 63) / 64);
-  a.xrow = a.xpieces * 64;
-  const size_t stage_bytes = (size_t)(8 * WG_KS + 8 * a.xrow) * 16;
+  a.xrow = a.xpieces * 64 + 4;
+  const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
   a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
   const int fn = wg_env_int("EVMI_WG_NST", 0);
   if (fn == 2 || fn == 3) a.nst = fn;
