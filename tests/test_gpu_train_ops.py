@@ -364,6 +364,49 @@ def test_conv1d_wgrad_bf16_packed(cuda_device, case):
         assert float((dw.cpu() - ref).abs().max()) <= 3e-5 * scale + 1e-6, (case, accumulate)
 
 
+BF16_EDGE_CASES = [
+    # (B, T, cin, cout, k, stride, pad, dil, groups)
+    (1, 7, 8, 7, 3, 1, 1, 1, 1),          # one item, one octet, ragged output rows
+    (1, 1, 16, 10, 1, 1, 0, 1, 1),        # a single position
+    (37, 3, 9, 33, 3, 3, 0, 1, 1),        # output length 1 per item, 37 items, 9 channels (two octets, 7 of them padding)
+    (2, 50, 24, 18, 5, 1, 2, 2, 3),       # three groups of 8 channels, dilation 2
+    (1, 8192, 8, 8, 7, 1, 3, 1, 1),       # one long row: 64 column tiles of one item
+    (3, 40, 40, 24, 2, 3, 0, 1, 1),       # kernel shorter than the stride (one residue class of dx stays zero)
+    (5, 33, 136, 72, 41, 1, 20, 1, 1),    # 41 taps on rows shorter than the kernel
+    (2, 300, 64, 64, 3, 1, 1, 1, 1),
+    (65, 10, 1024, 64, 5, 1, 2, 1, 1),    # many short items, deep contraction (84 ring steps)
+]
+
+
+@pytest.mark.parametrize("case", BF16_EDGE_CASES)
+def test_bf16_packed_kernels_edge_shapes(cuda_device, bf16_operands, case):
+    """Forward, input gradient and weight gradient through ops.conv1d_fwd / conv1d_bwd in bf16-operand mode vs torch on the
+    rounded operands (where a shape falls outside a packed kernel the exact fp32 kernel runs: either oracle may be the match)."""
+    from everyvoice_amd.train import ops
+
+    B, T, cin, cout, k, s, p, d, groups = case
+    g = torch.Generator().manual_seed(B * 13 + T + k)
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cout, cin // groups, k, generator=g) * 0.3
+    b = torch.randn(cout, generator=g)
+    n_out = (T + 2 * p - d * (k - 1) - 1) // s + 1
+    dy = torch.randn(B, cout, n_out, generator=g)
+    xd, wd, dyd = cbt(x).to(cuda_device), w.to(cuda_device), cbt(dy).to(cuda_device)
+    yg = bct(ops.conv1d_fwd(xd, wd, b.to(cuda_device), s, p, d, groups).cpu())
+    dxg, dwg, _ = ops.conv1d_bwd(xd, wd, dyd, s, p, d, groups)
+    dxg, dwg = bct(dxg.cpu()), dwg.cpu()
+
+    def closest(got, cands, tol):
+        errs = [float((got - c).abs().max() / (c.abs().max() + 1e-30)) for c in cands]
+        assert min(errs) <= tol, (case, errs)
+
+    closest(yg, [F.conv1d(_bf(x), _bf(w), b, s, p, d, groups), F.conv1d(x, w, b, s, p, d, groups)], 1e-4)
+    closest(dxg, [torch.nn.grad.conv1d_input(x.shape, _bf(w), _bf(dy), s, p, d, groups),
+                  torch.nn.grad.conv1d_input(x.shape, w, dy, s, p, d, groups)], 1e-4)
+    closest(dwg, [torch.nn.grad.conv1d_weight(_bf(x), w.shape, _bf(dy), s, p, d, groups),
+                  torch.nn.grad.conv1d_weight(x, w.shape, dy, s, p, d, groups)], 1e-4)
+
+
 def test_conv_kernels_edge_shapes(cuda_device):
     """Single item, single output position, output length 1 per item with many items, channels not a multiple of anything."""
     from everyvoice_amd.train import ops
