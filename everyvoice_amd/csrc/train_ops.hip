@@ -449,6 +449,45 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
   for (int i = threadIdx.x; i < N; i += 256) dv[r * N + i] = sc * (dw[r * N + i] - v[r * N + i] * k);
 }
 
+// iSTFTNet head, between conv_post and the inverse STFT (the generator of `istft_layer: true`): a [2H][n] = H log-magnitude rows
+// then H phase rows  ->  s [2H][n] = H real rows then H imaginary rows of exp(a) * exp(i * sin(b)).
+__global__ __launch_bounds__(256) void istft_polar_kernel(const float* __restrict__ a, float* __restrict__ s, int H, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)H * n) return;
+  const float mag = expf(a[i]), ph = sinf(a[(long long)H * n + i]);
+  s[i] = mag * cosf(ph);
+  s[(long long)H * n + i] = mag * sinf(ph);
+}
+// da from ds (same layouts): d log-mag = (dre cos + dim sin) mag;  d phase-pre = mag (-dre sin + dim cos) cos(b)
+__global__ __launch_bounds__(256) void istft_polar_bwd_kernel(const float* __restrict__ a, const float* __restrict__ ds, float* __restrict__ da,
+                                                              int H, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)H * n) return;
+  const long long j = (long long)H * n + i;
+  const float b = a[j], mag = expf(a[i]), ph = sinf(b), c = cosf(ph), sn = sinf(ph);
+  const float dre = ds[i], dim = ds[j];
+  da[i] = (dre * c + dim * sn) * mag;
+  da[j] = mag * (dim * c - dre * sn) * cosf(b);
+}
+// ReflectionPad1d((1, 0)) on rows [rows][T] -> [rows][T + 1]: y[0] = x[1], y[1 + t] = x[t]; bwd = 1: the adjoint (x, y swap roles:
+// `x` receives dx[t] = dy[t + 1] + (t == 1 ? dy[0] : 0) from `y` = dy)
+__global__ __launch_bounds__(256) void reflect_pad_left1_kernel(const float* __restrict__ src, float* __restrict__ dst, long long rows, int T,
+                                                                int bwd) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (!bwd) {
+    if (i >= rows * (T + 1)) return;
+    const long long r = i / (T + 1);
+    const int t = (int)(i - r * (T + 1));
+    dst[i] = src[r * T + (t == 0 ? 1 : t - 1)];
+  } else {
+    if (i >= rows * T) return;
+    const long long r = i / T;
+    const int t = (int)(i - r * T);
+    const float* dy = src + r * (T + 1);
+    dst[i] = dy[t + 1] + (t == 1 ? dy[0] : 0.f);
+  }
+}
+
 // y = x / max(||x||, eps)  (one workgroup; spectral norm's power iteration vectors are <= a few thousand long)
 __global__ __launch_bounds__(1024) void normalize_vec_kernel(const float* __restrict__ x, float* __restrict__ y, int n, float eps) {
   __shared__ float part[16];
@@ -673,6 +712,31 @@ int evmi_weight_norm_bwd_f32(const float* g_dev, const float* v_dev, const float
   EVMI_NONNULL(g_dev && v_dev && norm_dev && dw_dev && dg_dev && dv_dev, "weight_norm_bwd");
   hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g_dev, v_dev, norm_dev, dw_dev, dg_dev, dv_dev, n_per_row);
   EVMI_LAUNCH_CHECK("weight_norm_bwd");
+  return EVMI_OK;
+}
+
+int evmi_istft_polar_f32(const float* a_dev, float* s_dev, int H, long long n, void* stream) {
+  EVMI_NONNULL(a_dev && s_dev, "istft_polar");
+  if (H <= 0 || n <= 0) return fail(EVMI_ERR_INVALID_ARG, "istft_polar: shape");
+  hipLaunchKernelGGL(istft_polar_kernel, grid1d((long long)H * n), dim3(256), 0, (hipStream_t)stream, a_dev, s_dev, H, n);
+  EVMI_LAUNCH_CHECK("istft_polar");
+  return EVMI_OK;
+}
+
+int evmi_istft_polar_bwd_f32(const float* a_dev, const float* ds_dev, float* da_dev, int H, long long n, void* stream) {
+  EVMI_NONNULL(a_dev && ds_dev && da_dev, "istft_polar_bwd");
+  if (H <= 0 || n <= 0) return fail(EVMI_ERR_INVALID_ARG, "istft_polar_bwd: shape");
+  hipLaunchKernelGGL(istft_polar_bwd_kernel, grid1d((long long)H * n), dim3(256), 0, (hipStream_t)stream, a_dev, ds_dev, da_dev, H, n);
+  EVMI_LAUNCH_CHECK("istft_polar_bwd");
+  return EVMI_OK;
+}
+
+int evmi_reflect_pad_left1_f32(const float* src_dev, float* dst_dev, long long rows, int T, int backward, void* stream) {
+  EVMI_NONNULL(src_dev && dst_dev, "reflect_pad_left1");
+  if (rows <= 0 || T < 2) return fail(EVMI_ERR_INVALID_ARG, "reflect_pad_left1: needs at least two positions per row");
+  hipLaunchKernelGGL(reflect_pad_left1_kernel, grid1d(rows * (backward ? T : T + 1)), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev,
+                     rows, T, backward);
+  EVMI_LAUNCH_CHECK("reflect_pad_left1");
   return EVMI_OK;
 }
 

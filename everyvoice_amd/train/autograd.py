@@ -138,3 +138,63 @@ def period_view(tape: Tape, x: Var, period: int) -> Var:
     y = Var(ops.period_view(x.data, period))
     tape.record(lambda: y.grad is not None and x.accumulate(ops.period_view_bwd(y.grad, B, T, period)))
     return y
+
+
+def reflect_pad_left1(tape: Tape, x: Var) -> Var:
+    """torch.nn.ReflectionPad1d((1, 0)): the iSTFTNet head pads one frame in front of conv_post."""
+    y = Var(ops.reflect_pad_left1(x.data))
+    tape.record(lambda: y.grad is not None and x.accumulate(ops.reflect_pad_left1_bwd(y.grad)))
+    return y
+
+
+class ISTFTConstants:
+    """Windowed inverse-DFT basis as transposed-convolution weights [n_fft + 2, 1, n_fft] (real rows then imaginary rows; hann
+    window, 1/N and the factor 2 of the mirrored bins folded in) and the reciprocal window envelope of torch.istft(center=True)."""
+
+    def __init__(self, n_fft: int, hop: int, device):
+        import math
+
+        self.n_fft, self.hop, self.device = n_fft, hop, device
+        H = n_fft // 2 + 1
+        n = torch.arange(n_fft, dtype=torch.float64)
+        win = torch.hann_window(n_fft, dtype=torch.float64)  # periodic, as torch.hann_window's default
+        w = torch.zeros(2 * H, 1, n_fft, dtype=torch.float64)
+        for h in range(H):
+            c = (1.0 if h in (0, n_fft // 2) else 2.0) / n_fft
+            ang = 2.0 * math.pi * h * n / n_fft
+            w[h, 0] = c * torch.cos(ang) * win
+            w[H + h, 0] = -c * torch.sin(ang) * win
+        self.weight = w.to(torch.float32).to(device)
+        self._win_sq = (win * win).to(torch.float32)
+        self._inv_env = {}
+
+    def inv_envelope(self, B: int, frames: int) -> torch.Tensor:
+        key = (B, frames)
+        if key not in self._inv_env:
+            n_fft, hop = self.n_fft, self.hop
+            env = torch.zeros(n_fft + hop * (frames - 1))
+            for t in range(frames):
+                env[t * hop : t * hop + n_fft] += self._win_sq
+            env = env[n_fft // 2 : n_fft // 2 + hop * (frames - 1)]
+            self._inv_env[key] = (1.0 / env).reshape(1, 1, -1).repeat(1, B, 1).contiguous().to(self.device)
+        return self._inv_env[key]
+
+
+def istft(tape: Tape, x: Var, consts: ISTFTConstants) -> Var:
+    """x [n_fft + 2, B, frames] (conv_post output) -> wav [1, B, hop * (frames - 1)] = istft(exp(x_lo) * exp(i sin(x_hi)))."""
+    H = consts.n_fft // 2 + 1
+    _, B, frames = x.data.shape
+    s = ops.istft_polar(x.data, H)
+    inv_env = consts.inv_envelope(B, frames)
+    raw = ops.conv_transpose1d_fwd(s, consts.weight, None, consts.hop, consts.n_fft // 2)
+    y = Var(ops.elementwise(ops.EW_MUL, raw, inv_env))
+
+    def bwd():
+        if y.grad is None:
+            return
+        dyr = ops.elementwise(ops.EW_MUL, y.grad, inv_env)
+        ds, _, _ = ops.conv_transpose1d_bwd(s, consts.weight, dyr, consts.hop, consts.n_fft // 2, need_dx=True, need_dw=False)
+        x.accumulate(ops.istft_polar_bwd(x.data, ds, H))
+
+    tape.record(bwd)
+    return y

@@ -30,8 +30,11 @@ def _to_cbt(x_bct: torch.Tensor) -> torch.Tensor:
 class GeneratorT:
     def __init__(self, cfg: HiFiGANConfig, group: ParamGroup):
         m = cfg.model
-        if m.istft_layer or str(getattr(m.resblock, "value", m.resblock)) != "1":
-            raise NotImplementedError("training path: resblock '1' without the iSTFT head (this round)")
+        if str(getattr(m.resblock, "value", m.resblock)) != "1":
+            raise NotImplementedError("training path: resblock '1' (with or without the iSTFT head) this round")
+        self.istft = bool(m.istft_layer)
+        self._istft_consts = None
+        self._istft_cfg = (cfg.gen_istft_n_fft, cfg.gen_istft_hop_size)
         self.slope = ACTIVATION_SLOPES[m.activation_function]
         ch0, n_mels = m.upsample_initial_channel, cfg.preprocessing.audio.n_mels
         # declaration order = forward order: backward then finishes the flat gradient buffer suffix-first (BucketReducer)
@@ -48,7 +51,7 @@ class GeneratorT:
                     for q, d in enumerate(dils)
                 ])
         self.num_kernels = len(m.resblock_kernel_sizes)
-        self.conv_post = WNConv(group, "conv_post", ch0 >> len(m.upsample_rates), 1, 7, pad=3)
+        self.conv_post = WNConv(group, "conv_post", ch0 >> len(m.upsample_rates), cfg.gen_istft_n_fft + 2 if self.istft else 1, 7, pad=3)
 
     def layers(self):
         out = [self.conv_pre, *self.ups, self.conv_post]
@@ -85,6 +88,12 @@ class GeneratorT:
             x = ag.scale(tape, xs, 1.0 / self.num_kernels)
         hook([self.conv_post])
         x = ag.lrelu(tape, x, 0.01)
+        if self.istft:  # iSTFTNet head: reflection pad -> conv_post (n_fft + 2 channels) -> exp / sin -> inverse STFT
+            if self._istft_consts is None:
+                self._istft_consts = ag.ISTFTConstants(*self._istft_cfg, x.data.device)
+            x = ag.reflect_pad_left1(tape, x)
+            x = ag.conv1d(tape, x, self.conv_post)
+            return ag.istft(tape, x, self._istft_consts)
         x = ag.conv1d(tape, x, self.conv_post)
         return ag.tanh(tape, x)
 

@@ -295,14 +295,16 @@ def conv_transpose1d_fwd(x, w, bias, stride, pad):
     return y
 
 
-def conv_transpose1d_bwd(x, w, dy, stride, pad, need_dx=True, dw_out=None, db_out=None, accumulate=False):
+def conv_transpose1d_bwd(x, w, dy, stride, pad, need_dx=True, dw_out=None, db_out=None, accumulate=False, need_dw=True):
     cin, B, t_in = x.shape
     _, cout, k = w.shape
     t_out = dy.shape[2]
     col, t_chk = unfold(dy, k, stride, pad, 1)  # [Cout*k, B*T_in]
     assert t_chk == t_in
-    dw = dw_out if dw_out is not None else torch.empty_like(w)
-    gemm(x.view(cin, B * t_in), col, dw.view(cin, cout * k), tb=True, beta=1.0 if accumulate else 0.0)
+    dw = None
+    if need_dw:
+        dw = dw_out if dw_out is not None else torch.empty_like(w)
+        gemm(x.view(cin, B * t_in), col, dw.view(cin, cout * k), tb=True, beta=1.0 if accumulate else 0.0)
     db = None
     if db_out is not None:
         db = row_reduce(0, dy, None, db_out, cout, B * t_out, accumulate=accumulate)
@@ -311,6 +313,34 @@ def conv_transpose1d_bwd(x, w, dy, stride, pad, need_dx=True, dw_out=None, db_ou
         dx = torch.empty(cin, B, t_in, device=x.device, dtype=torch.float32)
         gemm(w.reshape(cin, cout * k), col, dx.view(cin, B * t_in))
     return dx, dw, db
+
+
+# ---- iSTFTNet head ---------------------------------------------------------------------------------------------
+def istft_polar(a, H):
+    """a [2H, B, T] (log-magnitude rows, phase rows) -> [2H, B, T] real rows, imaginary rows of exp(a) * exp(i sin(b))."""
+    s = torch.empty_like(a)
+    _chk(_lib.load().evmi_istft_polar_f32(a.data_ptr(), s.data_ptr(), H, a.numel() // (2 * H), _s(a)), "evmi_istft_polar_f32")
+    return s
+
+
+def istft_polar_bwd(a, ds, H):
+    da = torch.empty_like(a)
+    _chk(_lib.load().evmi_istft_polar_bwd_f32(a.data_ptr(), ds.data_ptr(), da.data_ptr(), H, a.numel() // (2 * H), _s(a)), "evmi_istft_polar_bwd_f32")
+    return da
+
+
+def reflect_pad_left1(x):
+    C, B, T = x.shape
+    y = torch.empty(C, B, T + 1, device=x.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_reflect_pad_left1_f32(x.data_ptr(), y.data_ptr(), C * B, T, 0, _s(x)), "evmi_reflect_pad_left1_f32")
+    return y
+
+
+def reflect_pad_left1_bwd(dy):
+    C, B, T1 = dy.shape
+    dx = torch.empty(C, B, T1 - 1, device=dy.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_reflect_pad_left1_f32(dy.data_ptr(), dx.data_ptr(), C * B, T1 - 1, 1, _s(dy)), "evmi_reflect_pad_left1_f32")
+    return dx
 
 
 # ---- activations / pooling / views -------------------------------------------------------------------------

@@ -320,6 +320,14 @@ int evmi_weight_norm_fwd_f32(const float* g_dev, const float* v_dev, float* w_de
 int evmi_weight_norm_bwd_f32(const float* g_dev, const float* v_dev, const float* norm_dev,
                              const float* dw_dev, float* dg_dev, float* dv_dev, int rows,
                              int n_per_row, void* stream);
+/* iSTFTNet head in training (generator with `istft_layer: true`, everyvoice/.schema/everyvoice-spec-to-wav-0.5.json:387-392;
+ * upstream rishikksh20/iSTFTNet-pytorch): between conv_post and the inverse STFT.  a [2H][n]: H log-magnitude rows then H phase
+ * rows; s [2H][n]: real rows then imaginary rows of exp(a) * exp(i sin(b)).  The inverse STFT itself is a transposed
+ * convolution with the windowed inverse-DFT basis (evmi_gemm_f32 + evmi_fold_cbt_f32) and the window-envelope division. */
+int evmi_istft_polar_f32(const float* a_dev, float* s_dev, int H, long long n, void* stream);
+int evmi_istft_polar_bwd_f32(const float* a_dev, const float* ds_dev, float* da_dev, int H, long long n, void* stream);
+/* torch.nn.ReflectionPad1d((1, 0)) on `rows` rows of T samples -> T + 1 (backward = 1: its adjoint, src = dy [rows][T+1]). */
+int evmi_reflect_pad_left1_f32(const float* src_dev, float* dst_dev, long long rows, int T, int backward, void* stream);
 /* y = x / max(||x||, eps) (spectral norm's power iteration). */
 int evmi_normalize_vec_f32(const float* x_dev, float* y_dev, int n, float eps, void* stream);
 /* torch.optim.AdamW step `step` (1-based) on a flat parameter buffer. */

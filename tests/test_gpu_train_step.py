@@ -177,19 +177,41 @@ def test_full_gan_step_bf16_operands_match_rounded_oracle(cuda_device, oracle_mo
         _full_gan_step(cuda_device, oracle_models, "bf16", g_gain=1.0 / 8.0)
 
 
-def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0):
+def test_full_gan_step_istft_generator_matches_oracle(cuda_device, oracle_models):
+    """BASELINE config 5's vocoder: the iSTFTNet head in training (reference test configuration C8C8I: upsampling 8 x 8, then
+    conv_post -> exp / sin -> inverse STFT 16 / 4): the whole GAN step against torch autograd through torch.istft."""
+    _full_gan_step(cuda_device, oracle_models, "f32", istft=True)
+
+
+def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=False):
+    from everyvoice_amd.config import HiFiGANConfig
     from everyvoice_amd.train.hifigan import HiFiGANTrainer
 
-    g_ref, mpd_ref, msd_ref = GeneratorRef().train(), MultiPeriodDiscriminatorRef().train(), MultiScaleDiscriminatorRef().train()
-    for new, old in zip((g_ref, mpd_ref, msd_ref), oracle_models):  # weight-normed modules do not deepcopy
-        new.load_state_dict(old.state_dict())
+    mpd_ref, msd_ref = MultiPeriodDiscriminatorRef().train(), MultiScaleDiscriminatorRef().train()
+    if istft:
+        from oracle.hifigan_ref import HiFiGANModelConfigRef
+
+        torch.manual_seed(77)
+        g_ref = GeneratorRef(HiFiGANModelConfigRef.test_config()).train()
+        with torch.no_grad():  # livelier than N(0, 0.01), short of saturating exp()
+            for n, p in g_ref.named_parameters():
+                if n.endswith("weight_g") and not n.startswith("conv_post"):
+                    p.mul_(2.0)
+        for new, old in zip((mpd_ref, msd_ref), oracle_models[1:]):
+            new.load_state_dict(old.state_dict())
+        config = HiFiGANConfig(model=dict(istft_layer=True, upsample_rates=[8, 8], upsample_kernel_sizes=[16, 16]))
+    else:
+        g_ref = GeneratorRef().train()
+        for new, old in zip((g_ref, mpd_ref, msd_ref), oracle_models):  # weight-normed modules do not deepcopy
+            new.load_state_dict(old.state_dict())
+        config = None
     if g_gain != 1.0:
         with torch.no_grad():
             for n, p in g_ref.named_parameters():
                 if n.endswith("weight_g"):
                     p.mul_(g_gain)
     opt_kw = dict(lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
-    tr = HiFiGANTrainer(device=cuda_device, precision=precision, **opt_kw)
+    tr = HiFiGANTrainer(config, device=cuda_device, precision=precision, **opt_kw)
     tr.load_reference_state(g_ref.state_dict(), mpd_ref.state_dict(), msd_ref.state_dict())
     tr.keep_grads = True
     loss_rel = 2e-4 if precision == "f32" else 2e-3
