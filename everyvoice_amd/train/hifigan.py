@@ -30,8 +30,7 @@ def _to_cbt(x_bct: torch.Tensor) -> torch.Tensor:
 class GeneratorT:
     def __init__(self, cfg: HiFiGANConfig, group: ParamGroup):
         m = cfg.model
-        if str(getattr(m.resblock, "value", m.resblock)) != "1":
-            raise NotImplementedError("training path: resblock '1' (with or without the iSTFT head) this round")
+        self.resblock2 = str(getattr(m.resblock, "value", m.resblock)) == "2"
         self.istft = bool(m.istft_layer)
         self._istft_consts = None
         self._istft_cfg = (cfg.gen_istft_n_fft, cfg.gen_istft_hop_size)
@@ -45,6 +44,10 @@ class GeneratorT:
             c = ch0 >> (i + 1)
             for j, (k, dils) in enumerate(zip(m.resblock_kernel_sizes, m.resblock_dilation_sizes)):
                 n = i * len(m.resblock_kernel_sizes) + j
+                if self.resblock2:  # 2 x [lrelu -> dilated conv] with a residual each (upstream ResBlock2: parameters convs.q)
+                    self.resblocks.append([(WNConv(group, f"resblocks.{n}.convs.{q}", c, c, k, pad=d * (k - 1) // 2, dil=d), None)
+                                           for q, d in enumerate(dils)])
+                    continue
                 self.resblocks.append([
                     (WNConv(group, f"resblocks.{n}.convs1.{q}", c, c, k, pad=d * (k - 1) // 2, dil=d),
                      WNConv(group, f"resblocks.{n}.convs2.{q}", c, c, k, pad=(k - 1) // 2))
@@ -57,14 +60,14 @@ class GeneratorT:
         out = [self.conv_pre, *self.ups, self.conv_post]
         for rb in self.resblocks:
             for c1, c2 in rb:
-                out += [c1, c2]
+                out += [c1] if c2 is None else [c1, c2]
         return out
 
     def stage_layers(self, i):
         out = [self.ups[i]]
         for j in range(self.num_kernels):
             for c1, c2 in self.resblocks[i * self.num_kernels + j]:
-                out += [c1, c2]
+                out += [c1] if c2 is None else [c1, c2]
         return out
 
     def forward(self, tape: ag.Tape, mel: ag.Var, bucket_hook=None) -> ag.Var:
@@ -81,8 +84,11 @@ class GeneratorT:
                 y = x
                 for c1, c2 in self.resblocks[i * self.num_kernels + j]:
                     t = ag.lrelu(tape, y, self.slope)
-                    t = ag.conv1d_lrelu(tape, t, c1, self.slope)
-                    t = ag.conv1d(tape, t, c2)
+                    if c2 is None:
+                        t = ag.conv1d(tape, t, c1)
+                    else:
+                        t = ag.conv1d_lrelu(tape, t, c1, self.slope)
+                        t = ag.conv1d(tape, t, c2)
                     y = ag.add(tape, t, y)
                 xs = y if xs is None else ag.add(tape, xs, y)
             x = ag.scale(tape, xs, 1.0 / self.num_kernels)

@@ -183,6 +183,12 @@ def test_full_gan_step_istft_generator_matches_oracle(cuda_device, oracle_models
     _full_gan_step(cuda_device, oracle_models, "f32", istft=True)
 
 
+def test_full_gan_step_resblock2_generator_matches_oracle(cuda_device, oracle_models):
+    """The "2" resblock option (upstream V3 shape: 256 initial channels, upsampling 8 x 8 x 4, kernels 3 / 5 / 7 with two
+    dilations each): the whole GAN step against the oracle."""
+    _full_gan_step(cuda_device, oracle_models, "f32", istft="v3")
+
+
 def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=False):
     from everyvoice_amd.config import HiFiGANConfig
     from everyvoice_amd.train.hifigan import HiFiGANTrainer
@@ -192,14 +198,16 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
         from oracle.hifigan_ref import HiFiGANModelConfigRef
 
         torch.manual_seed(77)
-        g_ref = GeneratorRef(HiFiGANModelConfigRef.test_config()).train()
+        v3 = dict(resblock="2", upsample_rates=[8, 8, 4], upsample_kernel_sizes=[16, 16, 8], upsample_initial_channel=256,
+                  resblock_kernel_sizes=[3, 5, 7], resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]])
+        g_ref = GeneratorRef(HiFiGANModelConfigRef(**v3) if istft == "v3" else HiFiGANModelConfigRef.test_config()).train()
         with torch.no_grad():  # livelier than N(0, 0.01), short of saturating exp()
             for n, p in g_ref.named_parameters():
                 if n.endswith("weight_g") and not n.startswith("conv_post"):
                     p.mul_(2.0)
         for new, old in zip((mpd_ref, msd_ref), oracle_models[1:]):
             new.load_state_dict(old.state_dict())
-        config = HiFiGANConfig(model=dict(istft_layer=True, upsample_rates=[8, 8], upsample_kernel_sizes=[16, 16]))
+        config = HiFiGANConfig(model=v3 if istft == "v3" else dict(istft_layer=True, upsample_rates=[8, 8], upsample_kernel_sizes=[16, 16]))
     else:
         g_ref = GeneratorRef().train()
         for new, old in zip((g_ref, mpd_ref, msd_ref), oracle_models):  # weight-normed modules do not deepcopy
