@@ -216,7 +216,11 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
       t_in <= 0 || pad < 0)
     return "bad shape";
   const int cin_g = c_in / groups, cout_g = c_out / groups;
-  if (cin_g < 32 || cout_g < 32 || cin_g * cout_g < 4096) return "narrow groups (the fp32 implicit-GEMM kernel takes them)";
+  // half-empty 64 x 64 tiles only pay with many taps to share the staged window (measured: 128->128 k41 g4 0.38 -> 0.26 ms,
+  // but 32->32 k3 0.064 -> 0.089 ms)
+  static const int min_prod = wg_env_int("EVMI_WG_MINPROD", 4096);
+  if (cin_g < 32 || cout_g < 32 || (cin_g * cout_g < min_prod && k < 16))
+    return "narrow groups (the fp32 implicit-GEMM kernel takes them)";
   if (stride > 8) return "stride above 8";
   a.cout_g = cout_g; a.cin_g = cin_g; a.k = k; a.stride = stride; a.dil = dil;
   pl.octs_y = a.octs_y = (cout_g + 7) / 8;

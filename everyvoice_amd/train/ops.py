@@ -287,6 +287,13 @@ def conv_transpose1d_fwd(x, w, bias, stride, pad):
     cin, B, t_in = x.shape
     _, cout, k = w.shape
     t_out = (t_in - 1) * stride - 2 * pad + k
+    if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"] and dgrad_mfma_supported(B, cout, t_out, cin, t_in, k, stride, 1, 1):
+        # a transposed convolution IS the input gradient of the strided convolution with the same weight tensor
+        # (w [c_in, c_out, k] read as [conv c_out][conv c_in][k]): the polyphase packed kernel, one launch
+        y = conv1d_bwd_data_mfma(x, w, t_out, stride, pad, 1, 1)
+        if bias is not None:
+            _chk(_lib.load().evmi_bias_add_rows_f32(y.data_ptr(), bias.data_ptr(), cout, B * t_out, _s(y)), "evmi_bias_add_rows_f32")
+        return y
     col = WS.get("dcol", cout * k * B * t_in, x.device).view(cout * k, B * t_in)
     gemm(w.reshape(cin, cout * k), x.view(cin, B * t_in), col, ta=True)
     y = fold(col, cout, B, t_out, t_in, k, stride, pad, 1)
@@ -299,6 +306,15 @@ def conv_transpose1d_bwd(x, w, dy, stride, pad, need_dx=True, dw_out=None, db_ou
     cin, B, t_in = x.shape
     _, cout, k = w.shape
     t_out = dy.shape[2]
+    if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"] and dgrad_mfma_supported(B, cout, t_out, cin, t_in, k, stride, 1, 1):
+        # the adjoint pair of the above: dx = conv1d(dy, w), dw = weight gradient of that convolution with (input, output
+        # gradient) = (dy, x) -- both in the transposed convolution's own weight layout [c_in, c_out, k]
+        db = row_reduce(0, dy, None, db_out, cout, B * t_out, accumulate=accumulate) if db_out is not None else None
+        dw = None
+        if need_dw:
+            _, dw, _ = conv1d_bwd(dy, w, x, stride, pad, 1, 1, need_dx=False, dw_out=dw_out, accumulate=accumulate)
+        dx = conv1d_fwd(dy, w, None, stride, pad, 1, 1) if need_dx else None
+        return dx, dw, db
     col, t_chk = unfold(dy, k, stride, pad, 1)  # [Cout*k, B*T_in]
     assert t_chk == t_in
     dw = None

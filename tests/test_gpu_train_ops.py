@@ -113,6 +113,32 @@ def test_conv_transpose1d_fwd_bwd(cuda_device, u, k):
     torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("u,k,cin,cout", [(8, 16, 64, 32), (2, 4, 128, 64), (3, 7, 24, 40)])
+def test_conv_transpose1d_bf16_operands(cuda_device, bf16_operands, u, k, cin, cout):
+    """bf16 mode: the transposed convolution runs as the (polyphase, packed) input-gradient kernel of the strided convolution
+    with the same weight tensor, its input gradient as that convolution, its weight gradient as that convolution's."""
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(5)
+    B, T = 3, 41
+    p = (k - u) // 2
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cin, cout, k, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    y = F.conv_transpose1d(_bf(x), _bf(w), b, u, p)
+    dy = torch.randn(y.shape, generator=g)
+    xd, wd, bd, dyd = cbt(x).to(cuda_device), w.to(cuda_device), b.to(cuda_device), cbt(dy).to(cuda_device)
+    yg = ops.conv_transpose1d_fwd(xd, wd, bd, u, p)
+    torch.testing.assert_close(bct(yg.cpu()), y, rtol=1e-4, atol=3e-5)
+    dbuf = torch.zeros(cout, device=cuda_device)
+    dx, dw, db = ops.conv_transpose1d_bwd(xd, wd, dyd, u, p, db_out=dbuf)
+    torch.testing.assert_close(bct(dx.cpu()), F.conv1d(_bf(dy), _bf(w), None, u, p), rtol=1e-4, atol=3e-5)
+    cands = [torch.nn.grad.conv1d_weight(_bf(dy), w.shape, _bf(x), u, p), torch.nn.grad.conv1d_weight(dy, w.shape, x, u, p)]
+    errs = [float((dw.cpu() - c).abs().max() / c.abs().max()) for c in cands]   # bf16 or fp32 weight gradient by shape
+    assert min(errs) <= 1e-4, errs
+    torch.testing.assert_close(db.cpu(), dy.sum(dim=(0, 2)), rtol=1e-4, atol=1e-4)
+
+
 def test_pool_period_view_activations(cuda_device):
     from everyvoice_amd.train import ops
 

@@ -117,13 +117,38 @@ class _RoundedConv(torch.autograd.Function):
         gi = torch.nn.grad.conv1d_input if nd == 1 else torch.nn.grad.conv2d_input
         gw = torch.nn.grad.conv1d_weight if nd == 1 else torch.nn.grad.conv2d_weight
         dx = gi(x.shape, _bf(w), _bf(dy), stride, padding, dilation, groups)
-        cin_g, cout_g = w.shape[1], w.shape[0] // groups
-        if cin_g >= 32 and cout_g >= 32 and cin_g * cout_g >= 4096:  # shapes conv_wgrad_bf16_pk.hip takes
+        if _wgrad_rounded(w.shape[1], w.shape[0] // groups, w.shape[2]):
             dw = gw(_bf(x), w.shape, _bf(dy), stride, padding, dilation, groups)
         else:
             dw = gw(x, w.shape, dy, stride, padding, dilation, groups)
         db = dy.sum(dim=[0] + list(range(2, dy.dim()))) if has_b else None
         return dx, dw, db, None, None, None, None, None
+
+
+def _wgrad_rounded(cin_g, cout_g, k):
+    return cin_g >= 32 and cout_g >= 32 and (cin_g * cout_g >= 4096 or k >= 16)  # shapes conv_wgrad_bf16_pk.hip takes
+
+
+class _RoundedConvT(torch.autograd.Function):
+    """conv_transpose1d in precision="bf16": the input-gradient kernel of the strided convolution with the same weights."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, b is not None)
+        return torch.nn.functional.conv_transpose1d(_bf(x), _bf(w), b, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, has_b = ctx.cfg
+        dx = _ORIG_CONV1D(_bf(dy), _bf(w), None, stride, padding)
+        rd = _wgrad_rounded(w.shape[1], w.shape[0], w.shape[2])
+        dw = torch.nn.grad.conv1d_weight(_bf(dy) if rd else dy, w.shape, _bf(x) if rd else x, stride, padding)
+        return dx, dw, dy.sum(dim=(0, 2)) if has_b else None, None, None
+
+
+_ORIG_CONV1D = F.conv1d
 
 
 class _bf16_operand_oracle:
@@ -151,13 +176,22 @@ class _bf16_operand_oracle:
                 return c2(_bf(x), _bf(w), b, stride, padding, dilation, groups)
             return c2(x, w, b, stride, padding, dilation, groups)
 
-        F.conv1d, F.conv2d = conv1d, conv2d
-        torch.nn.functional.conv1d, torch.nn.functional.conv2d = conv1d, conv2d
+        self.ct = F.conv_transpose1d
+        ct = self.ct
+
+        def conv_transpose1d(x, w, b=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+            s1 = stride[0] if isinstance(stride, (tuple, list)) else stride
+            p1 = padding[0] if isinstance(padding, (tuple, list)) else padding
+            op = output_padding[0] if isinstance(output_padding, (tuple, list)) else output_padding
+            if torch.is_grad_enabled() and groups == 1 and op == 0 and w.shape[0] >= 8 and w.shape[1] > 4:
+                return _RoundedConvT.apply(x, w, b, s1, p1)
+            return ct(x, w, b, stride, padding, output_padding, groups, dilation)
+
+        F.conv1d, F.conv2d, F.conv_transpose1d = conv1d, conv2d, conv_transpose1d
         return self
 
     def __exit__(self, *exc):
-        F.conv1d, F.conv2d = self.c1, self.c2
-        torch.nn.functional.conv1d, torch.nn.functional.conv2d = self.c1, self.c2
+        F.conv1d, F.conv2d, F.conv_transpose1d = self.c1, self.c2, self.ct
 
 
 def test_full_gan_step_matches_oracle(cuda_device, oracle_models):
