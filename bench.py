@@ -264,9 +264,11 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     generator + MPD + MSD, LSGAN + feature matching + 45 x mel L1, two AdamW optimisers), data parallel with one
     RCCL all-reduce per optimiser (discriminator 283 MB, generator 56 MB of fp32 gradients) when N > 1.
     Synthetic segments y = 0.3 * tanh(N(0,1)) [16, 1, 8192] per rank (seed 1234 + rank), mel from the device
-    front-end.  fp32: every convolution's forward, input gradient and weight gradient on the fp32 matrix cores
-    (conv_cbt_f32_mfma.hip, conv_wgrad_f32_mfma.hip).  The roofline object prices the step at SURVEY.md 8(d)'s 25.8 MFLOP per
-    segment sample (12.9 M MAC: D step 6.21 M + G step 6.70 M) against the 157 TFLOP/s fp32 matrix peak."""
+    front-end.  --train-precision bf16 (default): bf16 operands, fp32 accumulation / master weights / activations -- forward,
+    input gradient and weight gradient of every convolution on the packed-input kernels (conv_cbt_bf16_pk.hip,
+    conv_wgrad_bf16_pk.hip); f32: the exact path on the fp32 matrix cores (conv_cbt_f32_mfma.hip, conv_wgrad_f32_mfma.hip);
+    the other one is timed beside it.  The roofline object prices the step at SURVEY.md 8(d)'s 25.8 MFLOP per segment sample
+    (12.9 M MAC: D step 6.21 M + G step 6.70 M) against the dense bf16 MFMA peak (bf16) or the 157 TFLOP/s fp32 matrix peak."""
     import torch
 
     from everyvoice_amd.spectral import MelSpectrogram
@@ -299,11 +301,14 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     pmc_files = sorted((ROOT / "profiles").glob("*train_pmc_summary.json"))
     if pmc_files:  # recorded rocprofv3 --pmc passes (tools/gpu_profile_train.sh): the kernel with the most HBM reads per step
         pmc = json.loads(pmc_files[-1].read_text())
-        name, top = max(pmc.items(), key=lambda kv: kv[1]["fetch_bytes_per_launch"] * kv[1]["launches"])
+        # the kernel with the most active GPU cycles over the profiled steps
+        name, top = max(pmc.items(), key=lambda kv: kv[1].get("active_cycles_per_launch", 0.0) * kv[1]["launches"])
         roof["traffic"] = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in pmc.values()) / 3)
         roof["traffic_source"] = f"profiles/{pmc_files[-1].name}: HBM bytes per step, all kernels (FETCH_SIZE + WRITE_SIZE, raw KiB counters)"
         roof["dominant_kernel"] = {"name": name, "mfma_busy_frac": round(top.get("mfma_busy_frac", 0.0), 4),
-                                   "hbm_bytes_per_launch": round(top["fetch_bytes_per_launch"] + top["write_bytes_per_launch"])}
+                                   "lds_bank_conflict_frac": round(top.get("lds_bank_conflict_frac", 0.0), 4),
+                                   "hbm_bytes_per_launch": round(top["fetch_bytes_per_launch"] + top["write_bytes_per_launch"]),
+                                   "profiled_precision": "bf16" if "pk_kernel" in name else "f32"}
     return {
         "roofline": roof,
         "metric": "hifigan_v1_gan_train_steps_per_sec",
@@ -327,7 +332,8 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
 def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
     """FastSpeech2 feature prediction, inference: text ids -> mel on an LJSpeech-shaped synthetic
     batch (8d C3 shapes: B = 32, L ~ N(99.9, 34) in [12, 187], T ~ 5.67 L, durations given so the length is fixed),
-    default model sizes, random parameters.  fp32 on the fp32 matrix cores.  Replicas only across GPUs."""
+    default model sizes, random parameters; dense layers with bf16 operands (--train-precision, default) or exact fp32, the
+    other timed beside it.  Replicas only across GPUs."""
     import torch
 
     from everyvoice_amd.fs2 import FastSpeech2
@@ -361,8 +367,9 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     """BASELINE config 3: FastSpeech2 feature-prediction training, LJSpeech-shaped synthetic batch of 32 per GPU, default model
     (learn_alignment on: aligner + monotonic search + CTC loss inside the step), step = forward + losses + backward + clipped
     Noam AdamW; data parallel with one RCCL
-    all-reduce of the flat gradient buffer when N > 1.  fp32 storage and fp32 matrix-core arithmetic (>= the bf16 the config
-    names).  Algorithmic FLOPs = 3 x the forward's (dx and dw of every product)."""
+    all-reduce of the flat gradient buffer when N > 1.  --train-precision bf16 (what the config names; default): bf16 operands of
+    the dense layers, fp32 accumulation, master weights and activations; f32: the exact path, timed beside it.
+    Algorithmic FLOPs = 3 x the forward's (dx and dw of every product)."""
     import torch
 
     from everyvoice_amd.train.fs2 import FastSpeech2Trainer
