@@ -229,7 +229,13 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     typedef __attribute__((address_space(4))) const int cint_t;
     cint_t* tbw = (cint_t*)(a.tab + q0);
     auto tb_at = [&](int qi) { return make_int2(tbw[2 * qi], tbw[2 * qi + 1]); };
-    const int2 p0 = tb_at(0), p1 = tb_at(min(1, nq - 1)), p2 = tb_at(min(2, nq - 1)), p3 = tb_at(min(3, nq - 1));
+    // U K blocks per loop iteration.  (U = 4 for the 32x32 wave tiles measured 5 % slower than 2: those tiles read two 1 KB
+    // fragments per MFMA, i.e. they are bound by LDS read bandwidth -- 30 % of it bank conflicts on the short-row layers --
+    // not by the latency of one round trip.)
+    constexpr int U = 2;
+    int2 pe[2 * U];  // table entries of the step's first 2U blocks, fetched BEFORE the wait for its operands
+#pragma unroll
+    for (int u = 0; u < 2 * U; ++u) pe[u] = tb_at(min(u, nq - 1));
     wait_vmcnt_le(n_next);  // step t has landed (this wave's part); step t+1 may still be in flight
     lds_barrier();          // ... everyone's part; the slot about to be refilled was last read in step t-1
     {
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
       n_next = nst == 3 ? issued : 0;
     }
     const uint4* sm = smem + slot * stage;
-    bf16x8 fa[2][MT], fb[2][NT], na[2][MT], nb[2][NT];
+    bf16x8 fa[U][MT], fb[U][NT], na[U][MT], nb[U][NT];
     auto load = [&](bf16x8 (&da)[MT], bf16x8 (&db)[NT], int qi, int2 e) {
       const int lo = kh ? e.y : e.x;
 #pragma unroll
@@ -251,30 +257,31 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[mt], db[nt], acc[mt][nt], 0, 0, 0);
     };
-    // Two K blocks per iteration: the LDS reads of blocks qi+2, qi+3 are in flight before the MFMAs of qi, qi+1 issue, and the
-    // table entries of the iteration after that are fetched one iteration early (past the end: re-reads of the last block,
-    // in-bounds and unused).
-    load(fa[0], fb[0], 0, p0);
-    load(fa[1], fb[1], min(1, nq - 1), p1);
-    int2 e0 = p2, e1 = p3;
+    // U K blocks per iteration: the LDS reads of blocks qi+U .. qi+2U-1 are in flight before the MFMAs of qi .. qi+U-1 issue,
+    // and the table entries of the iteration after that are fetched one iteration early (past the end: re-reads of the last
+    // block, in-bounds and unused).
+#pragma unroll
+    for (int u = 0; u < U; ++u) load(fa[u], fb[u], min(u, nq - 1), pe[u]);
     if (!(a.ablate & 4))
-    for (int qi = 0; qi < nq; qi += 2) {
-      const int2 f0 = tb_at(min(qi + 4, nq - 1)), f1 = tb_at(min(qi + 5, nq - 1));
-      load(na[0], nb[0], min(qi + 2, nq - 1), e0);
-      load(na[1], nb[1], min(qi + 3, nq - 1), e1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(fa[0], fb[0]);
-      if (qi + 1 < nq) mma(fa[1], fb[1]);
+    for (int qi = 0; qi < nq; qi += U) {
+      int2 fe[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) fe[u] = tb_at(min(qi + 2 * U + u, nq - 1));
+#pragma unroll
+      for (int u = 0; u < U; ++u) load(na[u], nb[u], min(qi + U + u, nq - 1), pe[U + u]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < U; ++u)
+        if (u == 0 || qi + u < nq) mma(fa[u], fb[u]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fa[u][mt] = na[u][mt];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) fb[u][nt] = nb[u][nt];
+        pe[U + u] = fe[u];
       }
-      e0 = f0;
-      e1 = f1;
     }
   }
 
