@@ -92,6 +92,8 @@ SYMBOLS = {
     "evmi_conv1d_dgrad_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv1d_dgrad_cbt_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
     "evmi_conv1d_dgrad_cbt_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
+    "evmi_weight_norm_fwd_batched_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_longlong, C.c_longlong, C.c_void_p]),
+    "evmi_weight_norm_bwd_batched_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_longlong, C.c_longlong, C.c_void_p]),
     "evmi_istft_polar_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
     "evmi_istft_polar_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
     "evmi_reflect_pad_left1_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),

@@ -449,6 +449,70 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
   for (int i = threadIdx.x; i < N; i += 256) dv[r * N + i] = sc * (dw[r * N + i] - v[r * N + i] * k);
 }
 
+// Weight norm of MANY layers in one launch (one optimiser's weight-normed convolutions; the per-layer launches were 5-7 us each,
+// ~300 per GAN step).  table [6][L + 1] int64: row_start (prefix sums of the layers' row counts), n_per_row, and the offsets of
+// g / v in the flat parameter buffer, of w in the effective-weight buffer (same for its gradient sink) and of the norms.
+// One workgroup per row; rows [row_lo, row_hi) of the concatenated row list.
+__device__ __forceinline__ int wn_find_layer(const long long* __restrict__ row_start, int L, long long r) {
+  int lo = 0, hi = L - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (row_start[mid] <= r) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void weight_norm_fwd_batched_kernel(const float* __restrict__ flat, float* __restrict__ eff,
+                                                                      float* __restrict__ norms, const long long* __restrict__ tab, int L,
+                                                                      long long row_lo) {
+  __shared__ float part[4];
+  __shared__ float nrm;
+  const long long r = row_lo + blockIdx.x;
+  const int l = wn_find_layer(tab, L, r);
+  const long long lr = r - tab[l];
+  const int N = (int)tab[(L + 1) + l];
+  const float* v = flat + tab[3 * (L + 1) + l] + lr * N;
+  float* w = eff + tab[4 * (L + 1) + l] + lr * N;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) { const float t = v[i]; acc += t * t; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { nrm = sqrtf(part[0] + part[1] + part[2] + part[3]); norms[tab[5 * (L + 1) + l] + lr] = nrm; }
+  __syncthreads();
+  const float sc = flat[tab[2 * (L + 1) + l] + lr] / nrm;
+  for (int i = threadIdx.x; i < N; i += 256) w[i] = v[i] * sc;
+}
+// dg, dv from the effective-weight gradient sink (then zeroed for the next step), same arithmetic as weight_norm_bwd_kernel
+__global__ __launch_bounds__(256) void weight_norm_bwd_batched_kernel(const float* __restrict__ flat, float* __restrict__ grad,
+                                                                      const float* __restrict__ norms, float* __restrict__ dw_eff,
+                                                                      const long long* __restrict__ tab, int L, long long row_lo) {
+  __shared__ float part[4];
+  __shared__ float dot;
+  const long long r = row_lo + blockIdx.x;
+  const int l = wn_find_layer(tab, L, r);
+  const long long lr = r - tab[l];
+  const int N = (int)tab[(L + 1) + l];
+  const long long voff = tab[3 * (L + 1) + l] + lr * N, goff = tab[2 * (L + 1) + l] + lr;
+  const float* v = flat + voff;
+  float* dw = dw_eff + tab[4 * (L + 1) + l] + lr * N;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) acc += dw[i] * v[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const float nr = norms[tab[5 * (L + 1) + l] + lr];
+  if (threadIdx.x == 0) { dot = part[0] + part[1] + part[2] + part[3]; grad[goff] = dot / nr; }
+  __syncthreads();
+  const float sc = flat[goff] / nr, k = dot / (nr * nr);
+  float* dv = grad + voff;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    dv[i] = sc * (dw[i] - v[i] * k);
+    dw[i] = 0.f;
+  }
+}
+
 // iSTFTNet head, between conv_post and the inverse STFT (the generator of `istft_layer: true`): a [2H][n] = H log-magnitude rows
 // then H phase rows  ->  s [2H][n] = H real rows then H imaginary rows of exp(a) * exp(i * sin(b)).
 __global__ __launch_bounds__(256) void istft_polar_kernel(const float* __restrict__ a, float* __restrict__ s, int H, long long n) {
@@ -712,6 +776,26 @@ int evmi_weight_norm_bwd_f32(const float* g_dev, const float* v_dev, const float
   EVMI_NONNULL(g_dev && v_dev && norm_dev && dw_dev && dg_dev && dv_dev, "weight_norm_bwd");
   hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, g_dev, v_dev, norm_dev, dw_dev, dg_dev, dv_dev, n_per_row);
   EVMI_LAUNCH_CHECK("weight_norm_bwd");
+  return EVMI_OK;
+}
+
+int evmi_weight_norm_fwd_batched_f32(const float* flat_dev, float* eff_dev, float* norms_dev, const long long* table_dev, int n_layers,
+                                     long long row_lo, long long row_hi, void* stream) {
+  EVMI_NONNULL(flat_dev && eff_dev && norms_dev && table_dev, "weight_norm_fwd_batched");
+  if (n_layers <= 0 || row_hi <= row_lo || row_hi - row_lo > 0x7fffffffLL) return fail(EVMI_ERR_INVALID_ARG, "weight_norm_fwd_batched: rows");
+  hipLaunchKernelGGL(weight_norm_fwd_batched_kernel, dim3((unsigned)(row_hi - row_lo)), dim3(256), 0, (hipStream_t)stream, flat_dev, eff_dev,
+                     norms_dev, table_dev, n_layers, row_lo);
+  EVMI_LAUNCH_CHECK("weight_norm_fwd_batched");
+  return EVMI_OK;
+}
+
+int evmi_weight_norm_bwd_batched_f32(const float* flat_dev, float* grad_dev, const float* norms_dev, float* dw_eff_dev,
+                                     const long long* table_dev, int n_layers, long long row_lo, long long row_hi, void* stream) {
+  EVMI_NONNULL(flat_dev && grad_dev && norms_dev && dw_eff_dev && table_dev, "weight_norm_bwd_batched");
+  if (n_layers <= 0 || row_hi <= row_lo || row_hi - row_lo > 0x7fffffffLL) return fail(EVMI_ERR_INVALID_ARG, "weight_norm_bwd_batched: rows");
+  hipLaunchKernelGGL(weight_norm_bwd_batched_kernel, dim3((unsigned)(row_hi - row_lo)), dim3(256), 0, (hipStream_t)stream, flat_dev, grad_dev,
+                     norms_dev, dw_eff_dev, table_dev, n_layers, row_lo);
+  EVMI_LAUNCH_CHECK("weight_norm_bwd_batched");
   return EVMI_OK;
 }
 

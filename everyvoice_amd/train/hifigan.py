@@ -20,7 +20,7 @@ from ..config import ACTIVATION_SLOPES, HiFiGANConfig
 from ..spectral import slaney_mel_filterbank, windowed_dft_basis
 from . import autograd as ag
 from . import ops
-from .layers import ParamGroup, SNConv, WNConv, kaiming_uniform_conv_init_
+from .layers import ParamGroup, SNConv, WNBatch, WNConv, kaiming_uniform_conv_init_
 
 
 def _to_cbt(x_bct: torch.Tensor) -> torch.Tensor:
@@ -312,6 +312,8 @@ class HiFiGANTrainer:
         self.msd = [DiscriminatorST(self.d_params, f"msd.discriminators.{i}", spectral=(i == 0)) for i in range(m.msd_layers)]
         self.g_params.finalize()
         self.d_params.finalize()
+        # weight norm of all layers of an optimiser in one launch (forward), one launch per gradient bucket (backward)
+        self._wn_batches = [WNBatch(self.g_params, self.generator.layers()), WNBatch(self.d_params, self.d_layers())]
         self.mel_loss = MelLoss(self.config.preprocessing.audio, self.device)
         if reconstruction_loss not in ("mel", "mrstft", "mel+mrstft"):
             raise ValueError("reconstruction_loss: 'mel' (45 x mel-L1, the upstream default), 'mrstft' or 'mel+mrstft'")
@@ -414,8 +416,15 @@ class HiFiGANTrainer:
                 "model_info": {"name": "HiFiGANGenerator", "version": self._VERSION}}
 
     def _materialize(self, layers):
+        batches = []
         for layer in layers:
-            layer.materialize()
+            b = getattr(layer, "_batch", None)
+            if b is None:
+                layer.materialize()
+            elif b not in batches:
+                batches.append(b)
+        for b in batches:
+            b.materialize()
 
     def _reducer(self, group: ParamGroup):
         """Bucketed all-reduce of one optimiser's flat gradient buffer, overlapped with backward (None on one GPU)."""
@@ -430,8 +439,15 @@ class HiFiGANTrainer:
         turn the effective-weight gradients into parameter gradients and hand the now-final slice of the flat buffer to the
         reducer.  `state["hi"]` is the start of the suffix already handed over."""
         def done():
+            batches = {}
             for layer in layers:
-                layer.finish_grads()
+                b = getattr(layer, "_batch", None)
+                if b is None:
+                    layer.finish_grads()
+                else:
+                    batches.setdefault(id(b), (b, []))[1].append(layer)
+            for b, ls in batches.values():
+                b.finish(ls)
             if reducer is not None:
                 lo = min(group.offset_of(n) for layer in layers for n in layer.param_names())
                 reducer.launch(lo, state["hi"])

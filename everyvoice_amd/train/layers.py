@@ -132,6 +132,64 @@ class WNConv(_ConvBase):
         self._dw.zero_()
 
 
+class WNBatch:
+    """All weight-normed layers of one optimiser: effective weights, norms and gradient sinks live in three flat buffers, so
+    ``materialize`` is ONE launch per optimiser step and ``finish`` one launch per gradient bucket (instead of one per layer)."""
+
+    def __init__(self, group: ParamGroup, layers):
+        from .. import _lib
+
+        self.group = group
+        self.layers = sorted([l for l in layers if isinstance(l, WNConv)], key=lambda l: group.offset_of(l.name + ".weight_g"))
+        L = len(self.layers)
+        rows = [l.wshape[0] for l in self.layers]
+        n = [math.prod(l.wshape[1:]) for l in self.layers]
+        row_start, w_off, norm_off = [0], [0], [0]
+        for r, k in zip(rows, n):
+            row_start.append(row_start[-1] + r)
+            w_off.append(w_off[-1] + (r * k + 3) // 4 * 4)
+            norm_off.append(norm_off[-1] + r)
+        dev = group.device
+        self.eff = torch.zeros(max(w_off[-1], 1), device=dev, dtype=torch.float32)
+        self.dw_eff = torch.zeros_like(self.eff)
+        self.norms = torch.ones(max(norm_off[-1], 1), device=dev, dtype=torch.float32)
+        tab = torch.zeros(6, L + 1, dtype=torch.int64)
+        tab[0] = torch.tensor(row_start)
+        for i, l in enumerate(self.layers):
+            tab[1, i] = n[i]
+            tab[2, i] = group.offset_of(l.name + ".weight_g")
+            tab[3, i] = group.offset_of(l.name + ".weight_v")
+            tab[4, i] = w_off[i]
+            tab[5, i] = norm_off[i]
+            l._w = self.eff[w_off[i] : w_off[i] + rows[i] * n[i]].view(l.wshape)
+            l._dw = self.dw_eff[w_off[i] : w_off[i] + rows[i] * n[i]].view(l.wshape)
+            l._norm = self.norms[norm_off[i] : norm_off[i] + rows[i]]
+            l._batch, l._bi = self, i
+        self.table = tab.to(dev)
+        self.row_start = row_start
+        self._lib = _lib
+
+    def materialize(self):
+        if not self.layers:
+            return
+        g = self.group
+        self._lib.check(self._lib.load().evmi_weight_norm_fwd_batched_f32(g.flat.data_ptr(), self.eff.data_ptr(), self.norms.data_ptr(),
+                                                                       self.table.data_ptr(), len(self.layers), 0, self.row_start[-1],
+                                                                       self._lib.current_stream_ptr(g.device)), "evmi_weight_norm_fwd_batched_f32")
+
+    def finish(self, layers):
+        """Parameter gradients of a gradient bucket's weight-normed layers (a contiguous range in declaration order)."""
+        idx = sorted(l._bi for l in layers if getattr(l, "_batch", None) is self)
+        if not idx:
+            return
+        assert idx == list(range(idx[0], idx[-1] + 1)), "a gradient bucket must be a contiguous layer range"
+        g = self.group
+        self._lib.check(self._lib.load().evmi_weight_norm_bwd_batched_f32(g.flat.data_ptr(), g.grad.data_ptr(), self.norms.data_ptr(),
+                                                                       self.dw_eff.data_ptr(), self.table.data_ptr(), len(self.layers),
+                                                                       self.row_start[idx[0]], self.row_start[idx[-1] + 1],
+                                                                       self._lib.current_stream_ptr(g.device)), "evmi_weight_norm_bwd_batched_f32")
+
+
 class SNConv(_ConvBase):
     """spectral_norm(Conv1d) as torch.nn.utils.spectral_norm: parameter weight_orig, buffers weight_u / weight_v;
     in training mode every forward call runs one power iteration (and therefore sees its own sigma)."""

@@ -320,6 +320,16 @@ int evmi_weight_norm_fwd_f32(const float* g_dev, const float* v_dev, float* w_de
 int evmi_weight_norm_bwd_f32(const float* g_dev, const float* v_dev, const float* norm_dev,
                              const float* dw_dev, float* dg_dev, float* dv_dev, int rows,
                              int n_per_row, void* stream);
+/* torch.nn.utils.weight_norm of all weight-normed convolutions of one optimiser in ONE launch (w = g v / ||v|| per row), and
+ * the matching backward (dg, dv from the gradient of w; the gradient sink is zeroed behind the read).  flat / grad: the
+ * optimiser's flat parameter / gradient buffers; eff / dw_eff: effective weights and their gradient sink (same layout);
+ * table [6][n_layers + 1] int64: row_start prefix sums, n_per_row, offsets of g, v (flat), w (eff), norms; rows [row_lo, row_hi)
+ * of the concatenated row list (a gradient bucket = a contiguous layer range).  Same arithmetic as the per-layer calls. */
+int evmi_weight_norm_fwd_batched_f32(const float* flat_dev, float* eff_dev, float* norms_dev, const long long* table_dev,
+                                     int n_layers, long long row_lo, long long row_hi, void* stream);
+int evmi_weight_norm_bwd_batched_f32(const float* flat_dev, float* grad_dev, const float* norms_dev, float* dw_eff_dev,
+                                     const long long* table_dev, int n_layers, long long row_lo, long long row_hi,
+                                     void* stream);
 /* iSTFTNet head in training (generator with `istft_layer: true`, everyvoice/.schema/everyvoice-spec-to-wav-0.5.json:387-392;
  * upstream rishikksh20/iSTFTNet-pytorch): between conv_post and the inverse STFT.  a [2H][n]: H log-magnitude rows then H phase
  * rows; s [2H][n]: real rows then imaginary rows of exp(a) * exp(i sin(b)).  The inverse STFT itself is a transposed
