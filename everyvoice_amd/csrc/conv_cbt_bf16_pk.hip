@@ -76,39 +76,59 @@ __device__ __forceinline__ void pk_with_act(int act, F&& body) {
 // (phases with fewer taps zero padded in front), tap m -> j = phi + stride * (m_phi - 1 - (m - lead)): see wfrag_dgrad_kernel.
 // wf[ph][(g*MB + mb)][q][lane] (uint4): lane (mi = lane & 31, kh = lane >> 5), half h = 2q + kh = (octet, tap).
 // grid (kblocks, groups*MB, phases), 256 threads = 64 lanes x 4 words
-__global__ __launch_bounds__(256) void wfrag_pk_kernel(const float* __restrict__ w, unsigned* __restrict__ wf, int rows_g, int kch_g, int kt,
-                                                       int MB, int octs, int kblocks, int mode, int k_full, int stride,
-                                                       long long phase_stride_words, int2* __restrict__ tab, int kb_step, int xrow, int dil) {
-  const int q = blockIdx.x, gmb = blockIdx.y, phi = blockIdx.z;
+struct WfragArgs {
+  const float* w;
+  unsigned* wf;
+  int rows_g, kch_g, kt, MB, octs, kblocks, mode, k_full, stride;
+  long long phase_stride_words;
+  int2* tab;
+  int kb_step, xrow, dil;
+  int gx, gy, gz;  // logical grid (kblocks, groups*MB, phases)
+};
+__device__ __forceinline__ void wfrag_pk_block(const WfragArgs& f, int q, int gmb, int phi) {
+  const int kt = f.kt;
   if (gmb == 0 && phi == 0 && threadIdx.x == 0) {  // offsets of the K block's halves in the staged window of its ring step
-    const int o_lo = (2 * (q / kb_step) * kb_step) / kt;
-    const int h0 = 2 * q, h1 = h0 + 1 < octs * kt ? h0 + 1 : h0;  // odd tail: zero weights, any staged unit
-    tab[q] = make_int2((h0 / kt - o_lo) * xrow + (h0 % kt) * dil, (h1 / kt - o_lo) * xrow + (h1 % kt) * dil);
+    const int o_lo = (2 * (q / f.kb_step) * f.kb_step) / kt;
+    const int h0 = 2 * q, h1 = h0 + 1 < f.octs * kt ? h0 + 1 : h0;  // odd tail: zero weights, any staged unit
+    f.tab[q] = make_int2((h0 / kt - o_lo) * f.xrow + (h0 % kt) * f.dil, (h1 / kt - o_lo) * f.xrow + (h1 % kt) * f.dil);
   }
-  const int g = gmb / MB, mb = gmb - g * MB;
+  const int g = gmb / f.MB, mb = gmb - g * f.MB;
   const int lane = threadIdx.x >> 2, wd = threadIdx.x & 3;
   const int mi = lane & 31, kh = lane >> 5;
   const int h = 2 * q + kh;
   const int o = h / kt, j = h - o * kt;
   const int row = mb * 32 + mi;
   float v[2] = {0.f, 0.f};
-  if (o < octs && row < rows_g) {
+  if (o < f.octs && row < f.rows_g) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int kc = o * 8 + 2 * wd + e;
-      if (kc >= kch_g) continue;
-      if (mode == 0) {
-        v[e] = w[((long long)(g * rows_g + row) * kch_g + kc) * kt + j];
+      if (kc >= f.kch_g) continue;
+      if (f.mode == 0) {
+        v[e] = f.w[((long long)(g * f.rows_g + row) * f.kch_g + kc) * kt + j];
       } else {  // rows_g = cin_g (x channels), kch_g = cout_g (dy channels), w [c_out][cin_g][k_full]
-        const int m_phi = (k_full - phi + stride - 1) / stride, lead = kt - m_phi;
+        const int m_phi = (f.k_full - phi + f.stride - 1) / f.stride, lead = kt - m_phi;
         if (j >= lead) {
-          const int jj = phi + stride * (m_phi - 1 - (j - lead));
-          v[e] = w[((long long)(g * kch_g + kc) * rows_g + row) * k_full + jj];
+          const int jj = phi + f.stride * (m_phi - 1 - (j - lead));
+          v[e] = f.w[((long long)(g * f.kch_g + kc) * f.rows_g + row) * f.k_full + jj];
         }
       }
     }
   }
-  wf[phi * phase_stride_words + (((long long)gmb * kblocks + q) * 64 + lane) * 4 + wd] = pk_bf16x2(v[0], v[1]);
+  f.wf[phi * f.phase_stride_words + (((long long)gmb * f.kblocks + q) * 64 + lane) * 4 + wd] = pk_bf16x2(v[0], v[1]);
+}
+// Both preparation passes of a convolution call in ONE launch: blocks [0, n_pack) pack the input, the rest re-lay the weights
+// (the two are independent; at 5-7 us of fixed cost per launch and ~350 convolution calls per GAN step the second launch was
+// 2.5 ms of the step).
+__global__ __launch_bounds__(256) void prep_pk_kernel(PackArgs p, WfragArgs f) {
+  const unsigned n_pack = (unsigned)p.gx * p.gy * p.gz;
+  if (blockIdx.x < n_pack) {
+    pack_x_flat(p, blockIdx.x);
+  } else {
+    const unsigned b = blockIdx.x - n_pack;
+    const unsigned q = b % f.gx, r = b / f.gx;
+    wfrag_pk_block(f, (int)q, (int)(r % f.gy), (int)(r / f.gy));
+  }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
   }
   const int g = by / a.mtiles_per_group, mt_idx = by % a.mtiles_per_group;
   const int co0 = g * a.cout_g + mt_idx * BM;
-  const int k = a.k, s = a.stride, d = a.dil, xrow = a.xrow, pieces = a.pieces, kbs = a.kb_step;
+  const int k = a.k, s = a.stride, xrow = a.xrow, pieces = a.pieces, kbs = a.kb_step;
   const int ph = blockIdx.z;
   const int n_out = a.ph_nout[ph], shift = a.ph_shift[ph], out_off = a.ph_off[ph];
   if (n_out <= 0) return;
@@ -419,7 +439,7 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
   a.wf_phase_stride = (long long)groups * a.mblocks * a.kblocks * 64;
   pl.wf_units = a.wf_phase_stride * a.phases + ((long long)a.kblocks * 8 + 15) / 16;  // + the K-block offset table (int2 each)
   if (pl.xp_units >= (1LL << 31)) return "packed input too large";
-  if (a.B > 65535 || groups * a.octs > 65535) return "grid limits (pack)";
+
   return nullptr;
 }
 
@@ -430,13 +450,17 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
     return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_bf16_pk: workspace missing, too small or unaligned");
   uint4* xp = reinterpret_cast<uint4*>(ws);
   uint4* wf = xp + pl.xp_units;
-  if (a.B > 65535 || pl.groups * a.octs > 65535) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_bf16_pk: grid limits (pack)");
-  hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((a.Tp + 255) / 256), a.B, pl.groups * a.octs), dim3(256), 0, stream, x, xp, pl.cin_g,
-                     a.octs, a.B, pl.t_in, a.Tp, pl.PL, (int)(pl.xp_units - (long long)pl.groups * a.octs * a.B * a.Tp));
-  hipLaunchKernelGGL(wfrag_pk_kernel, dim3(a.kblocks, pl.groups * a.mblocks, a.phases), dim3(256), 0, stream, w,
-                     reinterpret_cast<unsigned*>(wf), rows_g, kch_g, a.k, a.mblocks, a.octs, a.kblocks, wmode, k_full, stride_full,
-                     a.wf_phase_stride * 4, reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases), a.kb_step, a.xrow, a.dil);
-  a.tab = reinterpret_cast<const int2*>(wf + a.wf_phase_stride * a.phases);
+  PackArgs pa = make_pack_args(x, xp, pl.cin_g, a.octs, a.B, pl.t_in, a.Tp, pl.PL,
+                               (int)(pl.xp_units - (long long)pl.groups * a.octs * a.B * a.Tp), pl.groups);
+  WfragArgs fa;
+  fa.w = w; fa.wf = reinterpret_cast<unsigned*>(wf); fa.rows_g = rows_g; fa.kch_g = kch_g; fa.kt = a.k; fa.MB = a.mblocks; fa.octs = a.octs;
+  fa.kblocks = a.kblocks; fa.mode = wmode; fa.k_full = k_full; fa.stride = stride_full; fa.phase_stride_words = a.wf_phase_stride * 4;
+  fa.tab = reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases); fa.kb_step = a.kb_step; fa.xrow = a.xrow; fa.dil = a.dil;
+  fa.gx = a.kblocks; fa.gy = pl.groups * a.mblocks; fa.gz = a.phases;
+  const long long n_prep = (long long)pa.gx * pa.gy * pa.gz + (long long)fa.gx * fa.gy * fa.gz;
+  if (n_prep > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_bf16_pk: grid limits (preparation pass)");
+  hipLaunchKernelGGL(prep_pk_kernel, dim3((unsigned)n_prep), dim3(256), 0, stream, pa, fa);
+  a.tab = fa.tab;
   a.xp = xp;
   a.wf = wf;
   static const int xcd_remap = pk_env_int("EVMI_F32_XCD", 1);

@@ -21,27 +21,31 @@ __device__ __forceinline__ unsigned pk_bf16x2(float lo, float hi) {
 }
 
 // x [groups*cin_g][B][t_in] fp32 -> xp [groups][octs][B][Tp] units; unit (g, o, b, u) = channels g*cin_g + 8o..8o+7 at t = u - PL.
-// grid (ceil(Tp / 256), B, groups*octs): one thread per unit, consecutive threads consecutive u (coalesced reads of 8 channel
-// rows, 16-byte writes); no index divisions.  The workgroups of the last row also zero `slack_units` units behind the tensor.
-static __global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ x, uint4* __restrict__ xp, int cin_g, int octs, int B,
-                                                     int t_in, int Tp, int PL, int slack_units) {
-  const int u = blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y, go = blockIdx.z;
-  if (slack_units > 0 && b == B - 1 && go == (int)gridDim.z - 1) {
-    // the units behind the last row are read by the last tiles' window loads (never used): keep them finite
-    uint4* tail = xp + (long long)gridDim.z * B * Tp;
-    for (int i = u; i < slack_units; i += gridDim.x * 256) tail[i] = make_uint4(0u, 0u, 0u, 0u);
+// Logical grid (ceil(Tp / 256), B, groups*octs): one thread per unit, consecutive threads consecutive u (coalesced reads of 8
+// channel rows, 16-byte writes).  The workgroups of the last row also zero `slack_units` units behind the tensor (read by the
+// last tiles' window loads, never used: kept finite).
+struct PackArgs {
+  const float* x;
+  uint4* xp;
+  int cin_g, octs, B, t_in, Tp, PL, slack_units;
+  int gx, gy, gz;  // logical grid
+};
+__device__ __forceinline__ void pack_x_block(const PackArgs& p, int bx, int b, int go) {
+  const int u = bx * 256 + threadIdx.x;
+  if (p.slack_units > 0 && b == p.B - 1 && go == p.gz - 1) {
+    uint4* tail = p.xp + (long long)p.gz * p.B * p.Tp;
+    for (int i = u; i < p.slack_units; i += p.gx * 256) tail[i] = make_uint4(0u, 0u, 0u, 0u);
   }
-  if (u >= Tp) return;
-  const int g = go / octs, o = go - g * octs;
-  const int t = u - PL;
+  if (u >= p.Tp) return;
+  const int g = go / p.octs, o = go - g * p.octs;
+  const int t = u - p.PL;
   float v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = 0.f;
-  if (t >= 0 && t < t_in) {
-    const float* src = x + ((long long)(g * cin_g + o * 8) * B + b) * t_in + t;
-    const long long cs = (long long)B * t_in;
-    const int nch = min(8, cin_g - o * 8);
+  if (t >= 0 && t < p.t_in) {
+    const float* src = p.x + ((long long)(g * p.cin_g + o * 8) * p.B + b) * p.t_in + t;
+    const long long cs = (long long)p.B * p.t_in;
+    const int nch = min(8, p.cin_g - o * 8);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (i < nch) v[i] = src[i * cs];
@@ -51,8 +55,25 @@ static __global__ __launch_bounds__(256) void pack_x_kernel(const float* __restr
   out.y = pk_bf16x2(v[2], v[3]);
   out.z = pk_bf16x2(v[4], v[5]);
   out.w = pk_bf16x2(v[6], v[7]);
-  xp[((long long)go * B + b) * Tp + u] = out;
+  p.xp[((long long)go * p.B + b) * p.Tp + u] = out;
 }
-
+static inline PackArgs make_pack_args(const float* x, uint4* xp, int cin_g, int octs, int B, int t_in, int Tp, int PL, int slack_units,
+                                      int groups) {
+  PackArgs p;
+  p.x = x; p.xp = xp; p.cin_g = cin_g; p.octs = octs; p.B = B; p.t_in = t_in; p.Tp = Tp; p.PL = PL; p.slack_units = slack_units;
+  p.gx = (Tp + 255) / 256; p.gy = B; p.gz = groups * octs;
+  return p;
+}
+// decode a flat block index into the logical 3-D grid of a pack (x fastest)
+__device__ __forceinline__ void pack_x_flat(const PackArgs& p, unsigned bid) {
+  const unsigned bx = bid % p.gx, r = bid / p.gx;
+  pack_x_block(p, (int)bx, (int)(r % p.gy), (int)(r / p.gy));
+}
+// two packs in one launch (the weight gradient's dy and x): blocks [0, n0) take the first
+static __global__ __launch_bounds__(256) void pack2_kernel(PackArgs p0, PackArgs p1) {
+  const unsigned n0 = (unsigned)p0.gx * p0.gy * p0.gz;
+  if (blockIdx.x < n0) pack_x_flat(p0, blockIdx.x);
+  else pack_x_flat(p1, blockIdx.x - n0);
+}
 
 }  // namespace evmi

@@ -268,7 +268,7 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
   pl.x_units = (long long)groups * a.octs_x * a.plane_x + (long long)WG_KS * stride + a.xrow + 64;
   a.split_stride = (long long)c_out * cin_g * k;
   pl.part_elems = splits > 1 ? a.split_stride * splits : 0;
-  if (B > 65535 || groups * std::max(a.octs_x, a.octs_y) > 65535) return "grid limits (pack)";
+
   if (pl.dy_units >= (1LL << 31) || pl.x_units >= (1LL << 31)) return "packed operands too large";
   return nullptr;
 }
@@ -304,12 +304,15 @@ int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float*
   uint4* xp = dyp + pl.dy_units;
   float* part = reinterpret_cast<float*>(xp + pl.x_units);
   const int cin_g = c_in / groups, cout_g = c_out / groups;
-  // (the slack behind both packed tensors is read, never used: the pack kernels zero it)
-  hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((pl.Tq + 255) / 256), B, groups * a.octs_y), dim3(256), 0, s, dy_dev, dyp, cout_g, a.octs_y,
-                     B, n_out, pl.Tq, 0, (int)(pl.dy_units - (long long)groups * a.octs_y * a.plane_y));
+  // both operands packed in one launch (the slack behind the packed tensors is read, never used: the pack zeroes it)
   const int Tpx = pl.Tq * stride;
-  hipLaunchKernelGGL(pack_x_kernel, dim3((unsigned)((Tpx + 255) / 256), B, groups * a.octs_x), dim3(256), 0, s, x_dev, xp, cin_g, a.octs_x, B,
-                     t_in, Tpx, pad, (int)(pl.x_units - (long long)groups * a.octs_x * a.plane_x));
+  PackArgs py = make_pack_args(dy_dev, dyp, cout_g, a.octs_y, B, n_out, pl.Tq, 0, (int)(pl.dy_units - (long long)groups * a.octs_y * a.plane_y),
+                               groups);
+  PackArgs px = make_pack_args(x_dev, xp, cin_g, a.octs_x, B, t_in, Tpx, pad, (int)(pl.x_units - (long long)groups * a.octs_x * a.plane_x),
+                               groups);
+  const long long n_pack = (long long)py.gx * py.gy * py.gz + (long long)px.gx * px.gy * px.gz;
+  if (n_pack > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv1d_wgrad_cbt_bf16pk: grid limits (pack)");
+  hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)n_pack), dim3(256), 0, s, py, px);
   a.dyp = dyp;
   a.xp = xp;
   a.out = pl.splits > 1 ? part : dw_dev;
