@@ -46,10 +46,64 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
 static thread_local float* g_splitk_ws = nullptr;
 static thread_local size_t g_splitk_cap = 0;
 
+// Matrix-vector products of the spectral-norm power iteration (W up to 1024 x 5120): a library GEMM with N = 1 takes 36-51 us
+// for them; these read W once at memory speed.  y[r] = sum_c W[r][c] x[c]: one workgroup per row.
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ W, const float* __restrict__ x, float* __restrict__ y,
+                                                        int K, int lda) {
+  __shared__ float part[4];
+  const float* row = W + (long long)blockIdx.x * lda;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < K; i += 256) acc = fmaf(row[i], x[i], acc);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) y[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+// y[c] = sum_r W[r][c] u[r]: grid (column blocks of 256, row chunks of GEMV_RC rows) -> partial sums, added in chunk order by
+// the second kernel (fixed order: reproducible)
+constexpr int GEMV_RC = 32;
+__global__ __launch_bounds__(256) void gemv_cols_partial_kernel(const float* __restrict__ W, const float* __restrict__ u,
+                                                                float* __restrict__ part, int rows, int cols, int lda) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int r0 = blockIdx.y * GEMV_RC, r1 = min(rows, r0 + GEMV_RC);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc = fmaf(W[(long long)r * lda + c], u[r], acc);
+  part[(long long)blockIdx.y * cols + c] = acc;
+}
+__global__ __launch_bounds__(256) void gemv_cols_final_kernel(const float* __restrict__ part, float* __restrict__ y, int chunks, int cols) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float acc = 0.f;
+  for (int i = 0; i < chunks; ++i) acc += part[(long long)i * cols + c];
+  y[c] = acc;
+}
+
 // Row-major C[M][N] = alpha * op(A) . op(B) + beta * C;  op(A) is M x K, op(B) is K x N.
 // (row-major C is column-major C^T = op(B)^T . op(A)^T: operands swapped for rocBLAS)
 int gemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
             float beta, float* C, int ldc, hipStream_t s) {
+  if (N == 1 && alpha == 1.f && beta == 0.f && ldb == 1 && ldc == 1 && (long long)M * K >= 4096) {  // matrix-vector products
+    if (!ta) {
+      hipLaunchKernelGGL(gemv_rows_kernel, dim3(M), dim3(256), 0, s, A, B, C, K, lda);
+      EVMI_LAUNCH_CHECK("gemv_rows");
+      return EVMI_OK;
+    }
+    const int chunks = (K + GEMV_RC - 1) / GEMV_RC;  // op(A) = A^T: A is [K][M]
+    const size_t need = (size_t)chunks * M;
+    if (need > g_splitk_cap) {
+      if (g_splitk_ws) (void)hipFree(g_splitk_ws);
+      g_splitk_ws = nullptr;
+      g_splitk_cap = 0;
+      EVMI_HIP_CHECK(hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
+      g_splitk_cap = need;
+    }
+    hipLaunchKernelGGL(gemv_cols_partial_kernel, dim3((M + 255) / 256, chunks), dim3(256), 0, s, A, B, g_splitk_ws, K, M, lda);
+    hipLaunchKernelGGL(gemv_cols_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, g_splitk_ws, C, chunks, M);
+    EVMI_LAUNCH_CHECK("gemv_cols");
+    return EVMI_OK;
+  }
   rocblas_handle h;
   int rc = blas_handle(s, &h);
   if (rc) return rc;
