@@ -49,6 +49,11 @@ struct ConvPkArgs {
   long long wf_phase_stride;  // units
   int ph_shift[8], ph_nout[8], ph_off[8];
   int xcd_remap;
+  // split-K (phases == 1 only): grid.x = column tiles * ksplit; split sp takes the ring steps [sp * steps_per_split, ...) and
+  // stores its raw accumulators to part[sp][c_out][B * n_out]; conv_pk_reduce_kernel adds them in split order + epilogue
+  int ksplit, steps_per_split, ntiles_n;
+  float* part;
+  long long part_stride;
   int ablate;  // timing experiments (EVMI_PK_ABLATE): 1 no window loads, 2 no weight loads, 4 no MFMA loop, 8 no stores
 };
 
@@ -159,6 +164,8 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
   const int n_out = a.ph_nout[ph], shift = a.ph_shift[ph], out_off = a.ph_off[ph];
   if (n_out <= 0) return;
   const long long n_total = (long long)a.B * n_out;
+  const int split = a.ksplit > 1 ? (int)(bx / a.ntiles_n) : 0;
+  if (a.ksplit > 1) bx -= split * a.ntiles_n;
   const long long n0 = (long long)bx * BN;
   if (n0 >= n_total) return;
   const int b_first = (int)(n0 / n_out);
@@ -197,7 +204,9 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nsteps = (a.ablate & 16) ? 0 : (a.kblocks + kbs - 1) / kbs;  // (16: timing experiment without the K loop)
+  const int nsteps_all = (a.ablate & 16) ? 0 : (a.kblocks + kbs - 1) / kbs;  // (16: timing experiment without the K loop)
+  const int t_lo = a.ksplit > 1 ? split * a.steps_per_split : 0;
+  const int nsteps = a.ksplit > 1 ? min(nsteps_all, t_lo + a.steps_per_split) : nsteps_all;  // this workgroup: steps [t_lo, nsteps)
   const uint4* wf_tile = a.wf + (long long)ph * a.wf_phase_stride + (long long)(g * a.mblocks + mt_idx * MBT) * a.kblocks * 64;
   const int mb_last = a.mblocks - 1 - mt_idx * MBT;  // m-blocks past the group re-read the last one (never stored)
 
@@ -234,11 +243,11 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
 
   int n_next = 0;
   const int nst = a.nst;
-  if (nsteps > 0) issue(0, 0);
-  if (nst == 3 && nsteps > 1) n_next = issue(1, 1);
+  if (nsteps > t_lo) issue(t_lo, 0);
+  if (nst == 3 && nsteps > t_lo + 1) n_next = issue(t_lo + 1, 1);
 
   int slot = -1;
-  for (int t = 0; t < nsteps; ++t) {
+  for (int t = t_lo; t < nsteps; ++t) {
     slot = slot + 1 == nst ? 0 : slot + 1;
     const int slot_ahead = slot == 0 ? nst - 1 : slot - 1;
     const int q0 = t * kbs;
@@ -317,6 +326,22 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     if (sacc == 12345.678f) a.y[0] = sacc;
     return;
   }
+  if (a.ksplit > 1) {  // raw partial tile: rows = output channels, columns = the flat (item, position) index (coalesced)
+    float* pp = a.part + (long long)split * a.part_stride;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      if (col_b[nt] < 0) continue;
+      const long long n = n0 + (wn * NT + nt) * 32 + ln;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (m < m_valid) pp[(long long)(co0 + m) * n_total + n] = acc[mt][nt][r];
+        }
+    }
+    return;
+  }
   pk_with_act(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
 #pragma unroll
@@ -341,6 +366,22 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
   });
 }
 
+// y[co][b][to*os + oo] (+)= act(bias + sum over the splits' partial tiles, in split order): one thread per (co, n), n fastest
+__global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a, int c_out, long long n_total) {
+  const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int co = blockIdx.y;
+  if (n >= n_total) return;
+  const int n_out = a.ph_nout[0];
+  float v = 0.f;
+  for (int sp = 0; sp < a.ksplit; ++sp) v += a.part[(long long)sp * a.part_stride + (long long)co * n_total + n];
+  if (a.bias) v += a.bias[co];
+  pk_with_act(a.act, [&](auto act_c) { v = pk_act<decltype(act_c)::value>(v, a.act_param); });
+  const long long bb = n / n_out;
+  const int to = (int)(n - bb * n_out);
+  float* dst = a.y + ((long long)co * a.B + bb) * a.t_out_total + (long long)to * a.out_stride + a.ph_off[0];
+  *dst = a.accumulate ? *dst + v : v;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct PkTile { int bm, bn; };
 static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}};
@@ -359,6 +400,8 @@ struct PkPlan {
   long long xp_units;      // packed input incl. slack
   long long wf_units;      // fragments, all phases
   int cin_g, t_in, groups;
+  long long part_elems;    // split-K partial tiles (floats)
+  int c_out;
 };
 
 static long long round_up_ll(long long v, long long m) { return (v + m - 1) / m * m; }
@@ -390,12 +433,24 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
   };
   static const long long want = pk_env_int("EVMI_PK_WANT", 512);  // two workgroups per CU: one's epilogue / load waits overlap the other's MFMAs
   int ti;
-  if (a.cout_g > 64) ti = blocks(0) >= want ? 0 : (blocks(1) >= want ? 1 : 2);
+  // wide layers on few columns (the 1024-channel discriminator layers: 1.6-2.8 k columns): 128 x 128 tiles -- one LDS read per
+  // MFMA instead of the 64 x 64 tile's two -- fill the CUs only with the contraction split over workgroups
+  static const int allow_split = pk_env_int("EVMI_PK_SPLITK", 1);
+  a.ksplit = 1;
+  if (allow_split && a.phases == 1 && a.cout_g > 64 && blocks(0) < pk_env_int("EVMI_PK_SPLIT_BELOW", 256) && a.kblocks >= 64) {
+    static const int split_want = pk_env_int("EVMI_PK_SPLIT_WANT", 384), split_min_kb = pk_env_int("EVMI_PK_SPLIT_MINKB", 24);
+    int ks = (int)std::min<long long>(8, (split_want + blocks(0) - 1) / blocks(0));
+    while (ks > 1 && a.kblocks / ks < split_min_kb) --ks;
+    a.ksplit = ks;
+  }
+  if (a.ksplit > 1) ti = 0;
+  else if (a.cout_g > 64) ti = blocks(0) >= want ? 0 : (blocks(1) >= want ? 1 : 2);
   else if (a.cout_g > 32) ti = blocks(1) >= want ? 1 : 2;
   else ti = 3;
   const int forced = pk_env_int("EVMI_PK_TILE", -1);
   if (forced >= 0 && forced < kNumPkTiles) ti = forced;
   const size_t two_wg = 78 * 1024, one_wg = 160 * 1024;
+  const int ti_first = ti;
   for (;; ++ti) {  // narrower tiles while the staged window does not fit
     if (ti >= kNumPkTiles) return "LDS budget";
     const int bm = kPkTiles[ti].bm, bn = kPkTiles[ti].bn;
@@ -428,9 +483,20 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     a.mtiles_per_group = (a.cout_g + bm - 1) / bm;
     pl.lds = lds_of(kbs, nst);
     if ((n_total + bn - 1) / bn > 0x7fffffffLL || groups * a.mtiles_per_group > 65535 || groups * a.mblocks > 65535) return "grid limits";
-    pl.grid = dim3((unsigned)((n_total + bn - 1) / bn), groups * a.mtiles_per_group, a.phases);
+    a.ntiles_n = (int)((n_total + bn - 1) / bn);
+    if (a.ksplit > 1 && ti != ti_first) a.ksplit = 1;  // (the wide tile did not fit: no split)
+    if (a.ksplit > 1) {
+      const int nsteps_all = (a.kblocks + kbs - 1) / kbs;
+      a.ksplit = std::min(a.ksplit, nsteps_all);
+      a.steps_per_split = (nsteps_all + a.ksplit - 1) / a.ksplit;
+      a.ksplit = (nsteps_all + a.steps_per_split - 1) / a.steps_per_split;  // no empty splits
+    }
+    pl.grid = dim3((unsigned)(a.ntiles_n * a.ksplit), groups * a.mtiles_per_group, a.phases);
     break;
   }
+  pl.c_out = a.cout_g * groups;
+  a.part_stride = (long long)pl.c_out * n_total;
+  pl.part_elems = a.ksplit > 1 ? a.part_stride * a.ksplit : 0;
   pl.ti = ti;
   pl.PL = PL;
   pl.cin_g = cin_g; pl.t_in = t_in; pl.groups = groups;
@@ -445,11 +511,12 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
 
 static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float* w, float* ws, long long ws_elems, int wmode,
                      int rows_g, int kch_g, int k_full, int stride_full, hipStream_t stream) {
-  const long long need = (pl.xp_units + pl.wf_units) * 4;
+  const long long need = (pl.xp_units + pl.wf_units) * 4 + pl.part_elems;
   if (!ws || ws_elems < need || (reinterpret_cast<uintptr_t>(ws) & 15))
     return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_bf16_pk: workspace missing, too small or unaligned");
   uint4* xp = reinterpret_cast<uint4*>(ws);
   uint4* wf = xp + pl.xp_units;
+  a.part = reinterpret_cast<float*>(wf + pl.wf_units);
   PackArgs pa = make_pack_args(x, xp, pl.cin_g, a.octs, a.B, pl.t_in, a.Tp, pl.PL,
                                (int)(pl.xp_units - (long long)pl.groups * a.octs * a.B * a.Tp), pl.groups);
   WfragArgs fa;
@@ -485,6 +552,11 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   }
 #undef EVMI_PK_LAUNCH
   EVMI_LAUNCH_CHECK("conv_cbt_bf16_pk");
+  if (a.ksplit > 1) {
+    const long long n_total = (long long)a.B * a.ph_nout[0];
+    hipLaunchKernelGGL(conv_pk_reduce_kernel, dim3((unsigned)((n_total + 255) / 256), pl.c_out), dim3(256), 0, stream, a, pl.c_out, n_total);
+    EVMI_LAUNCH_CHECK("conv_pk_reduce");
+  }
   return EVMI_OK;
 }
 
@@ -537,7 +609,7 @@ long long evmi_conv1d_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c_out, 
   ConvPkArgs a = {};
   PkPlan pl;
   if (plan_fwd_pk(a, pl, B, c_in, t_in, c_out, n_out, n_out, k, stride, pad, dil, groups, 1, 0)) return 0;
-  return (pl.xp_units + pl.wf_units) * 4;
+  return (pl.xp_units + pl.wf_units) * 4 + pl.part_elems;
 }
 
 int evmi_conv1d_cbt_bf16pk(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev,
@@ -559,7 +631,7 @@ long long evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c
   ConvPkArgs a = {};
   PkPlan pl;
   if (plan_dgrad_pk(a, pl, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups)) return 0;
-  return (pl.xp_units + pl.wf_units) * 4;
+  return (pl.xp_units + pl.wf_units) * 4 + pl.part_elems;
 }
 
 int evmi_conv1d_dgrad_cbt_bf16pk(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems, int B,
