@@ -301,13 +301,23 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     pmc_files = sorted((ROOT / "profiles").glob("*train_pmc_summary.json"))
     if pmc_files:  # recorded rocprofv3 --pmc passes (tools/gpu_profile_train.sh): the kernel with the most HBM reads per step
         pmc = json.loads(pmc_files[-1].read_text())
-        # the kernel with the most active GPU cycles over the profiled steps
-        name, top = max(pmc.items(), key=lambda kv: kv[1].get("active_cycles_per_launch", 0.0) * kv[1]["launches"])
+        # the kernel FAMILY (template instantiations together) with the most active GPU cycles over the profiled steps
+        fam = defaultdict(lambda: {"cycles": 0.0, "mfma": 0.0, "lds": 0.0, "bytes": 0.0, "launches": 0})
+        for kname, v in pmc.items():
+            f = fam[kname.split("<")[0].replace("evmi::", "")]
+            cyc = v.get("active_cycles_per_launch", 0.0) * v["launches"]
+            f["cycles"] += cyc
+            f["mfma"] += v.get("mfma_busy_frac", 0.0) * cyc
+            f["lds"] += v.get("lds_bank_conflict_frac", 0.0) * cyc
+            f["bytes"] += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
+            f["launches"] += v["launches"]
+        name, top = max(fam.items(), key=lambda kv: kv[1]["cycles"])
         roof["traffic"] = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in pmc.values()) / 3)
         roof["traffic_source"] = f"profiles/{pmc_files[-1].name}: HBM bytes per step, all kernels (FETCH_SIZE + WRITE_SIZE, raw KiB counters)"
-        roof["dominant_kernel"] = {"name": name, "mfma_busy_frac": round(top.get("mfma_busy_frac", 0.0), 4),
-                                   "lds_bank_conflict_frac": round(top.get("lds_bank_conflict_frac", 0.0), 4),
-                                   "hbm_bytes_per_launch": round(top["fetch_bytes_per_launch"] + top["write_bytes_per_launch"]),
+        roof["dominant_kernel"] = {"name": name, "mfma_busy_frac": round(top["mfma"] / max(top["cycles"], 1.0), 4),
+                                   "lds_bank_conflict_frac": round(top["lds"] / max(top["cycles"], 1.0), 4),
+                                   "hbm_bytes_per_launch": round(top["bytes"] / max(top["launches"], 1)),
+                                   "share_of_active_cycles": round(top["cycles"] / max(sum(f["cycles"] for f in fam.values()), 1.0), 4),
                                    "profiled_precision": "bf16" if "pk_kernel" in name else "f32"}
     return {
         "roofline": roof,
