@@ -49,11 +49,12 @@ struct ConvPkArgs {
   long long wf_phase_stride;  // units
   int ph_shift[8], ph_nout[8], ph_off[8];
   int xcd_remap;
-  // split-K (phases == 1 only): grid.x = column tiles * ksplit; split sp takes the ring steps [sp * steps_per_split, ...) and
-  // stores its raw accumulators to part[sp][c_out][B * n_out]; conv_pk_reduce_kernel adds them in split order + epilogue
+  // split-K: grid.x = column tiles * ksplit; split sp takes the ring steps [sp * steps_per_split, ...) and stores its raw
+  // accumulators to part[sp][phase][c_out][part_ld] (part_ld = B * longest phase); conv_pk_reduce_kernel adds them in split
+  // order + epilogue
   int ksplit, steps_per_split, ntiles_n;
   float* part;
-  long long part_stride;
+  long long part_stride, part_ld;
   int ablate;  // timing experiments (EVMI_PK_ABLATE): 1 no window loads, 2 no weight loads, 4 no MFMA loop, 8 no stores
 };
 
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     return;
   }
   if (a.ksplit > 1) {  // raw partial tile: rows = output channels, columns = the flat (item, position) index (coalesced)
-    float* pp = a.part + (long long)split * a.part_stride;
+    float* pp = a.part + ((long long)split * a.phases + ph) * a.part_stride;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       if (col_b[nt] < 0) continue;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (m < m_valid) pp[(long long)(co0 + m) * n_total + n] = acc[mt][nt][r];
+          if (m < m_valid) pp[(long long)(co0 + m) * a.part_ld + n] = acc[mt][nt][r];
         }
     }
     return;
@@ -366,19 +367,20 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
   });
 }
 
-// y[co][b][to*os + oo] (+)= act(bias + sum over the splits' partial tiles, in split order): one thread per (co, n), n fastest
-__global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a, int c_out, long long n_total) {
+// y[co][b][to*os + oo] (+)= act(bias + sum over the splits' partial tiles, in split order): one thread per (co, n), n fastest;
+// grid.z = phase
+__global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a) {
   const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int co = blockIdx.y;
-  if (n >= n_total) return;
-  const int n_out = a.ph_nout[0];
+  const int co = blockIdx.y, ph = blockIdx.z;
+  const int n_out = a.ph_nout[ph];
+  if (n_out <= 0 || n >= (long long)a.B * n_out) return;
   float v = 0.f;
-  for (int sp = 0; sp < a.ksplit; ++sp) v += a.part[(long long)sp * a.part_stride + (long long)co * n_total + n];
+  for (int sp = 0; sp < a.ksplit; ++sp) v += a.part[((long long)sp * a.phases + ph) * a.part_stride + (long long)co * a.part_ld + n];
   if (a.bias) v += a.bias[co];
   pk_with_act(a.act, [&](auto act_c) { v = pk_act<decltype(act_c)::value>(v, a.act_param); });
   const long long bb = n / n_out;
   const int to = (int)(n - bb * n_out);
-  float* dst = a.y + ((long long)co * a.B + bb) * a.t_out_total + (long long)to * a.out_stride + a.ph_off[0];
+  float* dst = a.y + ((long long)co * a.B + bb) * a.t_out_total + (long long)to * a.out_stride + a.ph_off[ph];
   *dst = a.accumulate ? *dst + v : v;
 }
 
@@ -437,7 +439,7 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
   // MFMA instead of the 64 x 64 tile's two -- fill the CUs only with the contraction split over workgroups
   static const int allow_split = pk_env_int("EVMI_PK_SPLITK", 1);
   a.ksplit = 1;
-  if (allow_split && a.phases == 1 && a.cout_g > 64 && blocks(0) < pk_env_int("EVMI_PK_SPLIT_BELOW", 256) && a.kblocks >= 64) {
+  if (allow_split && a.cout_g > 64 && blocks(0) < pk_env_int("EVMI_PK_SPLIT_BELOW", 256) && a.kblocks >= 64) {
     static const int split_want = pk_env_int("EVMI_PK_SPLIT_WANT", 384), split_min_kb = pk_env_int("EVMI_PK_SPLIT_MINKB", 24);
     int ks = (int)std::min<long long>(8, (split_want + blocks(0) - 1) / blocks(0));
     while (ks > 1 && a.kblocks / ks < split_min_kb) --ks;
@@ -495,8 +497,9 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     break;
   }
   pl.c_out = a.cout_g * groups;
+  a.part_ld = n_total;  // B * longest phase
   a.part_stride = (long long)pl.c_out * n_total;
-  pl.part_elems = a.ksplit > 1 ? a.part_stride * a.ksplit : 0;
+  pl.part_elems = a.ksplit > 1 ? a.part_stride * a.ksplit * a.phases : 0;
   pl.ti = ti;
   pl.PL = PL;
   pl.cin_g = cin_g; pl.t_in = t_in; pl.groups = groups;
@@ -553,8 +556,7 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
 #undef EVMI_PK_LAUNCH
   EVMI_LAUNCH_CHECK("conv_cbt_bf16_pk");
   if (a.ksplit > 1) {
-    const long long n_total = (long long)a.B * a.ph_nout[0];
-    hipLaunchKernelGGL(conv_pk_reduce_kernel, dim3((unsigned)((n_total + 255) / 256), pl.c_out), dim3(256), 0, stream, a, pl.c_out, n_total);
+    hipLaunchKernelGGL(conv_pk_reduce_kernel, dim3((unsigned)((a.part_ld + 255) / 256), pl.c_out, a.phases), dim3(256), 0, stream, a);
     EVMI_LAUNCH_CHECK("conv_pk_reduce");
   }
   return EVMI_OK;

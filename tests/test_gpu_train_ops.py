@@ -264,6 +264,8 @@ DGRAD_CASES = [
     (3, 100, 48, 40, 2, 3, 0, 1, 1),         # kernel shorter than the stride: one residue class is never written (stays zero)
     (16, 300, 128, 128, 11, 1, 25, 5, 1),    # dilated stride-1
     (5, 64, 40, 72, 7, 2, 3, 1, 1),
+    (4, 40, 128, 512, 5, 3, 2, 1, 1),        # deep contraction on few columns, three phases: the bf16 kernel splits K over workgroups
+    (2, 33, 256, 1024, 5, 1, 2, 1, 1),       # ... and the stride-1 case (one phase)
 ]
 
 
