@@ -80,6 +80,16 @@ __global__ __launch_bounds__(256) void gemv_cols_final_kernel(const float* __res
   y[c] = acc;
 }
 
+// C[M][N] = alpha * a b^T + beta * C (the rank-one term of the spectral-norm gradient; a library GEMM with K = 1 took 36 us)
+__global__ __launch_bounds__(256) void rank1_update_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, float* __restrict__ C,
+                                                           int N, int ldc, float alpha, float beta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= N) return;
+  float* dst = C + (long long)blockIdx.y * ldc + c;
+  const float t = alpha * a[(long long)blockIdx.y * lda] * b[c];
+  *dst = beta == 0.f ? t : beta * *dst + t;
+}
+
 // Row-major C[M][N] = alpha * op(A) . op(B) + beta * C;  op(A) is M x K, op(B) is K x N.
 // (row-major C is column-major C^T = op(B)^T . op(A)^T: operands swapped for rocBLAS)
 int gemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
@@ -102,6 +112,11 @@ int gemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float* A, 
     hipLaunchKernelGGL(gemv_cols_partial_kernel, dim3((M + 255) / 256, chunks), dim3(256), 0, s, A, B, g_splitk_ws, K, M, lda);
     hipLaunchKernelGGL(gemv_cols_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, g_splitk_ws, C, chunks, M);
     EVMI_LAUNCH_CHECK("gemv_cols");
+    return EVMI_OK;
+  }
+  if (K == 1 && !ta && !tb && M <= 65535 && (long long)M * N >= 4096) {  // outer product
+    hipLaunchKernelGGL(rank1_update_kernel, dim3((N + 255) / 256, M), dim3(256), 0, s, A, lda, B, C, N, ldc, alpha, beta);
+    EVMI_LAUNCH_CHECK("rank1_update");
     return EVMI_OK;
   }
   rocblas_handle h;
