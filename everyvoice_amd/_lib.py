@@ -139,6 +139,7 @@ SYMBOLS = {
     "evmi_unfold_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p]),
     "evmi_fold_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 9 + [C.c_void_p]),
     "evmi_bias_add_rows_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
+    "evmi_lrelu_bwd_rowsum_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_longlong, C.c_float, C.c_int, C.c_void_p]),
     "evmi_row_reduce_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_int, C.c_void_p]),
     "evmi_elementwise_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_void_p]),
     "evmi_scalar_reduce_f32": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_int, C.c_void_p]),

@@ -303,6 +303,31 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict
   }
 }
 
+// Backward of leaky_relu(conv(x)) in one pass over dy: dpre = dy * (y > 0 ? 1 : slope) is written for the convolution's gradient
+// kernels and its row sums (the bias gradient) come out of the same read (same two-stage scheme as row_reduce_kernel).
+__global__ __launch_bounds__(256) void lrelu_bwd_rowsum_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                               float* __restrict__ dpre, float* __restrict__ out, float* __restrict__ part_out,
+                                                               long long N, long long seg, float slope, int accumulate) {
+  __shared__ float part[4];
+  const long long r = blockIdx.x;
+  const long long lo = (long long)blockIdx.y * seg, hi = min(N, lo + seg);
+  float acc = 0.f;
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = dy[r * N + i] * (y[r * N + i] > 0.f ? 1.f : slope);
+    dpre[r * N + i] = v;
+    acc += v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = part[0] + part[1] + part[2] + part[3];
+    if (gridDim.y == 1) out[r] = accumulate ? out[r] + t : t;
+    else part_out[r * gridDim.y + blockIdx.y] = t;
+  }
+}
+
 __global__ void row_reduce_final_kernel(const float* __restrict__ part, float* __restrict__ out, int rows, int nseg,
                                         float scale, int accumulate) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -757,6 +782,28 @@ int evmi_row_reduce_f32(int mode, const float* a_dev, const float* b_dev, float*
   else return fail(EVMI_ERR_INVALID_ARG, "row_reduce: mode");
   if (nseg > 1) hipLaunchKernelGGL(row_reduce_final_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, out_dev, rows, nseg, scale, accumulate);
   EVMI_LAUNCH_CHECK("row_reduce");
+  return EVMI_OK;
+}
+
+int evmi_lrelu_bwd_rowsum_f32(const float* dy_dev, const float* y_dev, float* dpre_dev, float* db_dev, int rows, long long n_per_row,
+                              float slope, int accumulate, void* stream) {
+  EVMI_NONNULL(dy_dev && y_dev && dpre_dev && db_dev, "lrelu_bwd_rowsum");
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int MAXSEG = 64;
+  static thread_local float* part = nullptr;
+  static thread_local long long part_elems = 0;
+  int nseg = 1;
+  if (rows < 512 && n_per_row > 16384) nseg = (int)std::min<long long>(MAXSEG, std::min<long long>((1024 + rows - 1) / rows, (n_per_row + 8191) / 8192));
+  const long long seg = (n_per_row + nseg - 1) / nseg;
+  if (nseg > 1 && part_elems < (long long)rows * nseg) {
+    if (part) EVMI_HIP_CHECK(hipFree(part));
+    part_elems = (long long)rows * MAXSEG;
+    EVMI_HIP_CHECK(hipMalloc((void**)&part, part_elems * sizeof(float)));
+  }
+  hipLaunchKernelGGL(lrelu_bwd_rowsum_kernel, dim3(rows, nseg), dim3(256), 0, s, dy_dev, y_dev, dpre_dev, db_dev, part, n_per_row, seg, slope,
+                     accumulate);
+  if (nseg > 1) hipLaunchKernelGGL(row_reduce_final_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, db_dev, rows, nseg, 1.f, accumulate);
+  EVMI_LAUNCH_CHECK("lrelu_bwd_rowsum");
   return EVMI_OK;
 }
 

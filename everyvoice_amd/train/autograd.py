@@ -69,9 +69,12 @@ def conv1d_lrelu(tape: Tape, x: Var, layer, slope: float, training: bool = True)
     def bwd():
         if y.grad is None:
             return
-        dpre = ops.lrelu_bwd(y.grad, y.data, slope)
+        if layer.frozen:
+            dpre, db_out = ops.lrelu_bwd(y.grad, y.data, slope), None
+        else:  # activation backward and bias gradient in one pass over dy
+            dpre, db_out = ops.lrelu_bwd_rowsum(y.grad, y.data, slope, layer.db_sink(), accumulate=True), None
         dx, _, _ = ops.conv1d_bwd(x.data, w, dpre, layer.stride, layer.pad, layer.dil, layer.groups, need_dx=x.needs_grad,
-                                  dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True, need_dw=not layer.frozen)
+                                  dw_out=dw_sink, db_out=db_out, accumulate=True, need_dw=not layer.frozen)
         if dx is not None:
             x.accumulate(dx)
 

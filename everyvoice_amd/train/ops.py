@@ -364,6 +364,15 @@ def lrelu(x, slope):
     return elementwise(EW_LRELU, x, p0=slope)
 
 
+def lrelu_bwd_rowsum(dy, y, slope, db_out, accumulate=True):
+    """dpre = dy * (y > 0 ? 1 : slope) and db_out (+)= row sums of dpre, in one pass (dy, y: [C, B, T])."""
+    dpre = torch.empty_like(dy)
+    C = dy.shape[0]
+    _chk(_lib.load().evmi_lrelu_bwd_rowsum_f32(dy.data_ptr(), y.data_ptr(), dpre.data_ptr(), db_out.data_ptr(), C, dy.numel() // C, slope,
+                                               int(accumulate), _s(dy)), "evmi_lrelu_bwd_rowsum_f32")
+    return dpre
+
+
 def lrelu_bwd(dy, x, slope):
     return elementwise(EW_LRELU_BWD, dy, x, p0=slope)
 

@@ -295,6 +295,10 @@ int evmi_fold_cbt_f32(const float* dcol_dev, float* dx_dev, int C, int B, int t_
                       int stride, int pad, int dil, int accumulate, void* stream);
 int evmi_bias_add_rows_f32(float* y_dev, const float* bias_dev, int rows, long long n_per_row,
                            void* stream);
+/* Backward of leaky_relu(conv(x)) in one pass over dy [rows][n]: dpre = dy * (y > 0 ? 1 : slope) (the convolution's output
+ * gradient) and db[r] (+)= sum_n dpre[r][n] (its bias gradient), fixed summation order. */
+int evmi_lrelu_bwd_rowsum_f32(const float* dy_dev, const float* y_dev, float* dpre_dev, float* db_dev, int rows,
+                              long long n_per_row, float slope, int accumulate, void* stream);
 /* out[r] (+)= scale * sum_n f;  mode 0: a, 1: a*b, 2: a*a  (bias gradients, per-row dots). */
 int evmi_row_reduce_f32(int mode, const float* a_dev, const float* b_dev, float* out_dev, int rows,
                         long long n_per_row, float scale, int accumulate, void* stream);
