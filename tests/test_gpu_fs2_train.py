@@ -248,6 +248,34 @@ def _oracle_from(tr, ref_cfg):
     return ref
 
 
+def test_training_step_bf16_operands_follow_the_exact_step(cuda_device):
+    """precision="bf16" (BASELINE config 3's dtype): the same step -- same parameters, same batch, dropout off -- with bf16
+    operands in the dense layers' forward, input gradient and weight gradient, against the exact fp32 step of the same trainer
+    class.  The per-operator arithmetic is pinned in test_gpu_train_ops.py (= fp32 product of the rounded operands, 1e-4);
+    here: every loss within 2e-2, the flat gradient within 5 % in norm and cosine >= 0.99 (multi-speaker model, so every
+    embedding path is on it)."""
+    ref_cfg = _ref_cfg(0.0, 3)
+    batch = _train_batch(ref_cfg, 4, 23, seed=5)
+    out = {}
+    for prec in ("f32", "bf16"):
+        from everyvoice_amd.train import ops
+
+        tr = _trainer(ref_cfg, cuda_device, precision=prec)
+        ops.CONV_BACKEND["operands"] = prec  # what training_step does around forward_backward
+        try:
+            losses = tr.forward_backward(batch)
+        finally:
+            ops.CONV_BACKEND["operands"] = "f32"
+        out[prec] = ({k: float(v) for k, v in losses.items()}, tr.params.grad.clone())
+    for k, v in out["f32"][0].items():
+        assert out["bf16"][0][k] == pytest.approx(v, rel=2e-2, abs=1e-4), k
+    g32, g16 = out["f32"][1].double(), out["bf16"][1].double()
+    cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+    ratio = float(g16.norm() / g32.norm())
+    assert cos >= 0.99 and 0.95 <= ratio <= 1.05, (cos, ratio)
+    assert float((g32 - g16).abs().max()) > 0.0  # the bf16 kernels did run
+
+
 @pytest.mark.parametrize("B,L,speakers", [(3, 14, 0), (2, 23, 3)])
 def test_training_step_losses_gradients_and_update(cuda_device, B, L, speakers):
     ref_cfg = _ref_cfg(0.0, speakers)
