@@ -42,7 +42,8 @@ def forward_flops(lens, mel_lens, L_pad, T_pad, B, d=256, f=1024, k=9, heads=2, 
 
 def main():
     dev = torch.device("cuda:0")
-    model = FastSpeech2(device=dev).init_random(1234)
+    import os
+    model = FastSpeech2(device=dev, precision=os.environ.get("OPERANDS", "f32")).init_random(1234)
     ids, lens, durs, T_i = synthetic_batch()
     ids, lens, durs = ids.to(dev), lens.to(dev), durs.to(dev)
     for _ in range(3):
