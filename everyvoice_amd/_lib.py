@@ -110,6 +110,7 @@ SYMBOLS = {
     "evmi_fs2_durations_i32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_float, C.c_void_p]),
     "evmi_length_regulate_cbt_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_attention_cbt_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
+    "evmi_attention_cbt_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_fs2_add_item_embedding_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_void_p]),
     "evmi_attention_prior_f64": (C.c_int, [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_align_attention_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),

@@ -172,7 +172,8 @@ class _Conformer:
             A = L["attn"]
             qkv = _conv(_layernorm(x, A["ln_g"], A["ln_b"]), A["w_in"], A["b_in"])
             att = torch.empty_like(x)
-            _chk(lib.evmi_attention_cbt_f32(qkv.data_ptr(), lens.data_ptr(), att.data_ptr(), B, T, D, self.cfg.heads, _s(x)), "evmi_attention_cbt_f32")
+            attn = lib.evmi_attention_cbt_bf16 if ops.CONV_BACKEND["operands"] == "bf16" else lib.evmi_attention_cbt_f32
+            _chk(attn(qkv.data_ptr(), lens.data_ptr(), att.data_ptr(), B, T, D, self.cfg.heads, _s(x)), "evmi_attention_cbt")
             x = ops.axpby(1.0, x, 1.0, _conv(att, A["w_out"], A["b_out"]))
             Cm = L["conv"]
             p = _conv(_layernorm(x, Cm["ln_g"], Cm["ln_b"]), Cm["w_pw1"], Cm["b_pw1"])

@@ -388,6 +388,10 @@ int evmi_length_regulate_cbt_f32(const float* x_dev, const int* cum_dev, float* 
  * (softmax(Q K^T / sqrt(d_head)) V per head; fp32 matrix cores, online softmax; d_head 32 / 64 / 128). */
 int evmi_attention_cbt_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, int B, int T, int D,
                            int heads, void* stream);
+/* The same with bf16 operands (Q, K, V and the probabilities rounded to bf16; scores, softmax statistics and the output in
+ * fp32): precision="bf16" inference. */
+int evmi_attention_cbt_bf16(const float* qkv_dev, const int* lens_dev, float* out_dev, int B, int T, int D,
+                            int heads, void* stream);
 /* Speaker / language embedding of a multi-speaker / multilingual model: x[c][b][l] += table[ids[b]][c] for l < lens[b]. */
 int evmi_fs2_add_item_embedding_f32(float* x_dev, const int* ids_dev, const int* lens_dev, const float* table_dev,
                                     int B, int L, int D, void* stream);

@@ -161,6 +161,38 @@ def test_attention_kernel_alone(cuda_device):
         torch.testing.assert_close(out.cpu(), want, rtol=2e-5, atol=2e-5)
 
 
+def test_attention_kernel_bf16_operands(cuda_device):
+    """evmi_attention_cbt_bf16 vs torch attention with the SAME roundings restated: q (pre-scaled), k, v and the un-normalised
+    probabilities exp(s - max) rounded to bf16, everything else fp32 (the running maximum of the kernel's online softmax only
+    rescales: the restatement uses the row maximum, so the probabilities may differ by their bf16 rounding -> 1e-2 of the
+    output's scale); and within 2e-2 of the exact attention."""
+    from everyvoice_amd import _lib
+
+    def bf(t):
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    g = torch.Generator().manual_seed(3)
+    for (B, T, D, H) in ((2, 50, 64, 2), (3, 200, 256, 2), (1, 33, 128, 2), (2, 70, 128, 4)):
+        qkv = torch.randn(3 * D, B, T, generator=g)
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        lens[0] = T
+        q, k, v = [t.view(H, D // H, B, T).permute(2, 0, 3, 1) for t in qkv.split(D)]  # [B, H, T, dh]
+        mask = (torch.arange(T)[None] >= lens[:, None])[:, None, None, :]
+        scale = 1.0 / (D // H) ** 0.5
+        exact = ((q @ k.transpose(-1, -2)) * scale).masked_fill(mask, float("-inf")).softmax(-1) @ v
+        s = (bf(q * scale) @ bf(k).transpose(-1, -2)).masked_fill(mask, float("-inf"))
+        p = torch.exp(s - s.amax(-1, keepdim=True))
+        rounded = (bf(p) @ bf(v)) / p.sum(-1, keepdim=True)
+        qd, ld = qkv.to(cuda_device), lens.to(cuda_device, torch.int32)
+        out = torch.empty(D, B, T, device=cuda_device)
+        _lib.check(_lib.load().evmi_attention_cbt_bf16(qd.data_ptr(), ld.data_ptr(), out.data_ptr(), B, T, D, H,
+                                                       torch.cuda.current_stream().cuda_stream), "attention")
+        got = out.cpu().view(H, D // H, B, T).permute(2, 0, 3, 1)
+        sc = float(exact.abs().max())
+        assert float((got - rounded).abs().max()) <= 1e-2 * sc, (B, T, D, H)
+        assert float((got - exact).abs().max()) <= 2e-2 * sc, (B, T, D, H)
+
+
 def test_fs2_against_committed_golden(cuda_device):
     """The committed fixture (inputs, parameters and the oracle's outputs) through the HIP path."""
     import numpy as np
