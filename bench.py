@@ -56,8 +56,8 @@ def parse_args(argv=None):
     p.add_argument("--train-precision", default="bf16", choices=["bf16", "f32"],
                    help="training legs: bf16 convolution operands with fp32 accumulation / master weights (BASELINE config 3 names bf16), "
                         "or the exact fp32 path; the other one is timed beside it with fewer steps")
-    p.add_argument("--train-steps", type=int, default=6)
-    p.add_argument("--train-warmup", type=int, default=2)
+    p.add_argument("--train-steps", type=int, default=10)
+    p.add_argument("--train-warmup", type=int, default=3)
     return p.parse_args(argv)
 
 
