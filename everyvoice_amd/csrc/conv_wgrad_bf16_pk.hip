@@ -185,9 +185,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
 }
 
 // dw[co][ci][j] (+)= sum over the partial copies [split][j][co][ci], in split order (fixed summation order: bitwise
-// reproducible).  One thread per (j, co, ci) in the partial tiles' order: coalesced reads, one strided write.
+// reproducible).  One workgroup per 256 consecutive (co, ci) pairs: the k tap planes are read coalesced (summed over the splits)
+// into LDS and written back as the 256 * k contiguous floats of dw they are.
 __global__ __launch_bounds__(256) void wgrad_pk_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long long rows_ci, int k,
                                                               int splits, long long split_stride, int accumulate) {
+  extern __shared__ float tile[];  // [k][256]
+  const long long base = (long long)blockIdx.x * 256;
+  const long long i = base + threadIdx.x;
+  if (i < rows_ci)
+    for (int j = 0; j < k; ++j) {
+      float acc = 0.f;
+      for (int sidx = 0; sidx < splits; ++sidx) acc += part[sidx * split_stride + j * rows_ci + i];
+      tile[j * 256 + threadIdx.x] = acc;
+    }
+  __syncthreads();
+  const int n_here = (int)min<long long>(256, rows_ci - base);
+  float* dst = dw + base * k;
+  for (int e = threadIdx.x; e < n_here * k; e += 256) {
+    const int p = e / k, j = e - p * k;
+    const float v = tile[j * 256 + p];
+    dst[e] = accumulate ? dst[e] + v : v;
+  }
+}
+
+// the same for small weight tensors reduced over many splits: one thread per (j, co, ci) (k times the workgroups; strided write)
+__global__ __launch_bounds__(256) void wgrad_pk_reduce_planes_kernel(const float* __restrict__ part, float* __restrict__ dw, long long rows_ci,
+                                                                     int k, int splits, long long split_stride, int accumulate) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // co * cin_g + ci
   const int j = blockIdx.y;
   if (i >= rows_ci) return;
@@ -337,8 +360,12 @@ int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float*
   EVMI_LAUNCH_CHECK("wgrad_pk_kernel");
   if (pl.splits > 1) {
     const long long rows_ci = (long long)c_out * cin_g;
-    hipLaunchKernelGGL(wgrad_pk_reduce_kernel, dim3((unsigned)((rows_ci + 255) / 256), k), dim3(256), 0, s, part, dw_dev, rows_ci, k, pl.splits,
-                       a.split_stride, accumulate);
+    if (rows_ci >= 131072)  // enough (co, ci) pairs to fill the chip with one workgroup per 256 of them: coalesced both ways
+      hipLaunchKernelGGL(wgrad_pk_reduce_kernel, dim3((unsigned)((rows_ci + 255) / 256)), dim3(256), (size_t)k * 256 * sizeof(float), s, part,
+                         dw_dev, rows_ci, k, pl.splits, a.split_stride, accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_pk_reduce_planes_kernel, dim3((unsigned)((rows_ci + 255) / 256), k), dim3(256), 0, s, part, dw_dev, rows_ci, k,
+                         pl.splits, a.split_stride, accumulate);
     EVMI_LAUNCH_CHECK("wgrad_pk_reduce_kernel");
   }
   return EVMI_OK;

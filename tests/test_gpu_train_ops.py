@@ -361,6 +361,7 @@ WGRAD_BF16_CASES = [
     (5, 64, 72, 104, 7, 2, 3, 1, 1),          # channel counts that are no multiple of 32 / 64
     (2, 1000, 64, 96, 1, 1, 0, 1, 1),         # pointwise (the FastSpeech2 dense layers)
     (7, 51, 96, 256, 5, 1, 2, 1, 1),          # odd item count: rows padded to a K-step boundary
+    (16, 100, 512, 384, 5, 1, 2, 1, 1),       # 196,608 (co, ci) pairs over three K splits: the LDS-transposing reduce
 ]
 
 
