@@ -90,7 +90,6 @@ __device__ __forceinline__ void with_act(int act, F&& body) {
 
 constexpr int SMALLCO_DIRECT = 4;  // output channels up to which conv_cbt_direct.hip takes the shape
 constexpr int F32_PMAX = 10;  // 64-column pieces of a staged row (xrow <= 640)
-constexpr int F32_NST = 3;    // LDS ring slots (maximum)
 
 __device__ float g_zero_line[64];  // source of the zeros staged for padding / out-of-range columns
 

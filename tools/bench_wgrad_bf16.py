@@ -12,6 +12,9 @@ SHAPES = [
     ("G rb c128 k11 d5", 128, 128, 11, 1, 25, 5, 1, B, 2048),
     ("G rb c64 k7 d3", 64, 64, 7, 1, 9, 3, 1, B, 4096),
     ("G rb c32 k3 d1", 32, 32, 3, 1, 1, 1, 1, B, 8192),
+    ("G rb c32 k7 d3", 32, 32, 7, 1, 9, 3, 1, B, 8192),
+    ("G rb c32 k11 d5", 32, 32, 11, 1, 25, 5, 1, B, 8192),
+    ("G rb c64 k11 d5", 64, 64, 11, 1, 25, 5, 1, B, 4096),
     ("MSD L1 128->128 k41 s2 g4", 128, 128, 41, 2, 20, 1, 4, B, 8192),
     ("MSD L4 512->1024 k41 s4 g16", 512, 1024, 41, 4, 20, 1, 16, B, 512),
     ("MSD L5 1024->1024 k41 g16", 1024, 1024, 41, 1, 20, 1, 16, B, 128),
