@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Headline benchmark: HiFiGAN-V1 generator inference, 22.05 kHz audio samples / second.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK /
+WORLD_SIZE in the environment), or started bare -- then this process, WITHOUT touching the GPU, starts that launcher as a
+child (one rank per GPU over RCCL), relays rank 0's JSON line and exits with the children's return code (the one-command
+form of the reference's `everyvoice train ... --devices N --strategy ddp`, base_cli/interfaces.py:84-97,
+base_cli/helpers.py:252-270).
 
 Workload (BASELINE.json configs[1]): mel = clamp(N(-5, 2^2), -11.5129, 2.0) of
 shape [32, 80, 768] per GPU, seed 1234 + rank, already resident in HBM; weights N(0, 0.01) upstream
@@ -23,6 +29,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from collections import defaultdict
@@ -56,9 +64,70 @@ def parse_args(argv=None):
     p.add_argument("--train-precision", default="bf16", choices=["bf16", "f32"],
                    help="training legs: bf16 convolution operands with fp32 accumulation / master weights (BASELINE config 3 names bf16), "
                         "or the exact fp32 path; the other one is timed beside it with fewer steps")
-    p.add_argument("--train-steps", type=int, default=10)
-    p.add_argument("--train-warmup", type=int, default=3)
+    p.add_argument("--train-steps", type=int, default=50)
+    p.add_argument("--train-warmup", type=int, default=10)
+    p.add_argument("--selftest-cpu", action="store_true",
+                   help="launcher self-test: ranks rendezvous over gloo on the CPU, time a dummy step and report the rank count "
+                        "(tests/test_bench_dist.py; measures nothing)")
     return p.parse_args(argv)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n: int, argv: list[str]) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks as children of this process through
+    torch.distributed.run (never os.exec*: this also has to work under rocprofv3), pass their stderr through, relay the
+    JSON line rank 0 prints and return the children's exit code.  This process never initialises the GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(Path(__file__).resolve()), *argv]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"bench.py: the {n}-rank launch failed (rc {proc.returncode}, JSON line {'present' if line else 'missing'})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
+def selftest_cpu(args, rank: int, world: int) -> int:
+    """The launcher path with the GPU legs replaced by a sleep: rendezvous, barrier / max-over-ranks timing, one JSON line."""
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    ones = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(ones)
+
+    def max_reduce(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed = timed_region(lambda: time.sleep(0.002 * (rank + 1)), args.steps, args.warmup, lambda: None,
+                           dist.barrier if world > 1 else (lambda: None), max_reduce)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "selftest_cpu", "value": world * args.steps / elapsed, "n_gpus": world, "ranks_seen": int(ones.item()),
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3}))
+    return 0
 
 
 def dist_env():
@@ -291,6 +360,14 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     trainer.precision = other
     elapsed_other = timed_region(step, 3, 1, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     trainer.precision = prec
+    # BASELINE config 4 as written names the multi-resolution STFT loss: the same step with it added to the 45 x mel-L1 term
+    del trainer
+    trainer_mr = HiFiGANTrainer(device=dev, process_group=True if use_dist else None, precision=prec, reconstruction_loss="mel+mrstft")
+    losses_mr = {}
+    n_mr = max(3, args.train_steps // 5)
+    elapsed_mr = timed_region(lambda: losses_mr.update(trainer_mr.training_step(mel, y)), n_mr, 2, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    params = {"generator": trainer_mr.g_params.numel(), "discriminators": trainer_mr.d_params.numel()}
+    del trainer_mr
     flop_per_step = 25.8e6 * B * S  # per GPU
     tflops = flop_per_step * args.train_steps / elapsed / 1e12
     # bf16 mode: forward and input-gradient convolutions on the bf16 matrix cores (2.5 PFLOP/s dense), weight gradients still on
@@ -333,8 +410,10 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
         "scaling": "weak",
         "dtype": prec,
         "other_precision": {"dtype": other, "value": round(3 / elapsed_other, 3), "unit": "steps/s", "ms_per_step": round(elapsed_other / 3 * 1e3, 2), "steps": 3},
-        "parallelism": f"dp{world}" + (" (RCCL all-reduce of 2 flat gradient buffers per step)" if world > 1 else ""),
-        "params": {"generator": trainer.g_params.numel(), "discriminators": trainer.d_params.numel()},
+        "with_mrstft_loss": {"reconstruction_loss": "mel+mrstft", "value": round(n_mr / elapsed_mr, 3), "unit": "steps/s",
+                             "ms_per_step": round(elapsed_mr / n_mr * 1e3, 2), "steps": n_mr, "g_stft": round(losses_mr.get("g_stft", 0.0), 4)},
+        "parallelism": f"dp{world}" + (" (RCCL all-reduce of 2 flat gradient buffers per step, bucketed, overlapped with backward)" if world > 1 else ""),
+        "params": params,
         "last_losses": {k: round(v, 4) for k, v in losses.items()},
     }
 
@@ -445,14 +524,18 @@ def cpu_baseline_fs2_train(cores: int, batch: int = 8) -> dict:
 
 
 def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
-    import torch
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus, argv)  # before anything touches the GPU
     rank, local_rank, world = dist_env()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE={world})", file=sys.stderr)
-            return 2
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        return 2
+    if args.selftest_cpu:
+        return selftest_cpu(args, rank, world)
+    import torch
+
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the product path has no CPU fallback", file=sys.stderr)
         return 2
@@ -473,9 +556,14 @@ def main(argv=None) -> int:
             t = torch.tensor([x], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
+
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)  # the rank count RCCL itself sees
+        rccl_ranks = int(ones.item())
     else:
         barrier = lambda: None  # noqa: E731
         max_reduce = lambda x: x  # noqa: E731
+        rccl_ranks = 0
 
     model = upstream_init_generator(args.precision).to(dev).eval()
     mel = synthetic_mel(args.batch, args.frames, 1234 + rank).to(dev)
@@ -488,6 +576,14 @@ def main(argv=None) -> int:
 
     elapsed = timed_region(step, args.steps, args.warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     value = world * samples_per_step * args.steps / elapsed
+    # the other arithmetic beside it (the reference computes in fp32; bf16 operands with fp32 accumulation are SURVEY 8(d) C2's contract)
+    other = "f32" if args.precision == "bf16" else "bf16"
+    model_o = upstream_init_generator(other).to(dev).eval()
+    n_other = max(2, args.steps // 5)
+    elapsed_o = timed_region(lambda: model_o.generator(mel), n_other, 1, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    other_precision = {"dtype": other, "value": round(world * samples_per_step * n_other / elapsed_o, 1), "unit": "samples/s",
+                       "ms_per_step": round(elapsed_o / n_other * 1e3, 3), "steps": n_other}
+    del model_o
 
     train = None
     if not args.no_train:
@@ -532,8 +628,11 @@ def main(argv=None) -> int:
             },
             "whole_job_tflops": round(value * flops_per_sample / 1e12, 2),
             "realtime_factor": round(value / 22050.0, 1),
+            "other_precision": other_precision,
             "roofline": roof,
         }
+        if use_dist:
+            result["rccl_ranks"] = rccl_ranks
         if train is not None:
             result["train"] = train
         if fs2 is not None:

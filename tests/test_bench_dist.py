@@ -119,3 +119,25 @@ def test_dist_env_and_roofline_aggregation(monkeypatch):
     assert abs(roof["achieved"] - 2e9 / 2e-3 / 1e12) < 1e-2  # algorithmic FLOP per launch / mean duration
     assert roof["peak"] == 2500.0 and roof["bound"] == "mfma"
     assert abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-3
+
+
+def test_bare_multi_gpu_command_launches_its_own_ranks(monkeypatch, capfd):
+    """`python bench.py --gpus 2` with no launcher in the environment: the parent starts two ranks through
+    torch.distributed.run, relays rank 0's JSON line and returns the children's exit code (--selftest-cpu replaces the GPU
+    legs by a sleep and RCCL by gloo; the launcher path is the one the GPU run takes)."""
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    rc = bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--selftest-cpu"])
+    out = capfd.readouterr().out
+    assert rc == 0, out
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["steps"] == 3
+    assert line["ms_per_step"] >= 4.0 * 0.9  # the slower rank (2 x 2 ms) sets the time
+
+
+def test_rank_count_mismatch_is_a_hard_error(monkeypatch, capfd):
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    assert bench.main(["--gpus", "8", "--selftest-cpu"]) == 2
+    assert "WORLD_SIZE=4" in capfd.readouterr().err
