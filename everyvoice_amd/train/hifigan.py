@@ -108,9 +108,9 @@ class DiscriminatorPT:
     def __init__(self, group: ParamGroup, prefix: str, period: int):
         self.period = period
         chans = [1, 32, 128, 512, 1024]
-        self.convs = [WNConv(group, f"{prefix}.convs.{i}", chans[i], chans[i + 1], 5, stride=3, pad=2) for i in range(4)]
-        self.convs.append(WNConv(group, f"{prefix}.convs.4", 1024, 1024, 5, pad=2))
-        self.conv_post = WNConv(group, f"{prefix}.conv_post", 1024, 1, 3, pad=1)
+        self.convs = [WNConv(group, f"{prefix}.convs.{i}", chans[i], chans[i + 1], 5, stride=3, pad=2, conv2d=True) for i in range(4)]
+        self.convs.append(WNConv(group, f"{prefix}.convs.4", 1024, 1024, 5, pad=2, conv2d=True))
+        self.conv_post = WNConv(group, f"{prefix}.conv_post", 1024, 1, 3, pad=1, conv2d=True)
 
     def layers(self):
         return [*self.convs, self.conv_post]

@@ -20,12 +20,18 @@ class ParamGroup:
     def __init__(self, device):
         self.device = device
         self._specs = []  # (name, shape, offset)
+        self._export = {}  # name -> shape in an exported state dict, where it differs
         self._n = 0
         self.flat = self.grad = self.m = self.v = None
         self.step = 0
 
-    def declare(self, name: str, shape) -> int:
+    def declare(self, name: str, shape, export_shape=None) -> int:
+        """``export_shape``: the tensor shape upstream stores under this name when it differs from the one the kernels use
+        (the period discriminators' Conv2d((k, 1)) weights are [c_out, c_in, k, 1] upstream, [c_out, c_in, k] here)."""
         n = math.prod(shape)
+        if export_shape is not None:
+            assert math.prod(export_shape) == n
+            self._export[name] = tuple(export_shape)
         self._specs.append((name, tuple(shape), self._n))
         self._n += (n + 3) // 4 * 4  # keep every tensor 16-byte aligned
         return len(self._specs) - 1
@@ -58,7 +64,8 @@ class ParamGroup:
         return sum(math.prod(s[1]) for s in self._specs)
 
     def state_dict(self):
-        return {name: self._view(self.flat, i).detach().clone() for i, (name, _, _) in enumerate(self._specs)}
+        return {name: self._view(self.flat, i).detach().clone().reshape(self._export.get(name, shape))
+                for i, (name, shape, _) in enumerate(self._specs)}
 
     def gradients(self):
         return {name: self._view(self.grad, i) for i, (name, _, _) in enumerate(self._specs)}
@@ -77,8 +84,9 @@ class ParamGroup:
 class _ConvBase:
     transposed = False
 
-    def __init__(self, group: ParamGroup, name, cin, cout, k, stride=1, pad=0, dil=1, groups=1, transposed=False):
+    def __init__(self, group: ParamGroup, name, cin, cout, k, stride=1, pad=0, dil=1, groups=1, transposed=False, conv2d=False):
         self.group, self.name = group, name
+        self.conv2d = conv2d  # upstream module is Conv2d((k, 1)): exported tensors carry the trailing unit axis
         self.cin, self.cout, self.k = cin, cout, k
         self.stride, self.pad, self.dil, self.groups = stride, pad, dil, groups
         self.transposed = transposed
@@ -110,8 +118,8 @@ class WNConv(_ConvBase):
     def __init__(self, group, name, cin, cout, k, **kw):
         super().__init__(group, name, cin, cout, k, **kw)
         rows = self.wshape[0]
-        self.i_g = group.declare(name + ".weight_g", (rows, 1, 1))
-        self.i_v = group.declare(name + ".weight_v", self.wshape)
+        self.i_g = group.declare(name + ".weight_g", (rows, 1, 1), (rows, 1, 1, 1) if self.conv2d else None)
+        self.i_v = group.declare(name + ".weight_v", self.wshape, (*self.wshape, 1) if self.conv2d else None)
         self._w = self._norm = None
 
     def materialize(self):

@@ -120,3 +120,25 @@ def test_reference_test_config_ref_matches_host_config():
     mine = HiFiGANConfig(model=dict(istft_layer=True, upsample_rates=[8, 8], upsample_kernel_sizes=[16, 16])).model
     for f in ("upsample_rates", "upsample_kernel_sizes", "resblock_kernel_sizes", "resblock_dilation_sizes", "mpd_layers"):
         assert getattr(ref, f) == getattr(mine, f)
+
+
+def test_trainer_state_dict_loads_strictly_into_the_upstream_modules():
+    """A checkpoint trained here must resume upstream: every exported tensor has upstream's name AND shape -- the period
+    discriminators are Conv2d((k, 1)) there (weight_v [c_out, c_in, k, 1], weight_g [c_out, 1, 1, 1]), Conv1d on the period
+    view here.  Host-only: constructing the trainer and exporting / importing its state runs no kernel."""
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+    from oracle.hifigan_ref import MultiPeriodDiscriminatorRef, MultiScaleDiscriminatorRef
+
+    tr = HiFiGANTrainer(device="cpu")
+    sd = tr.state_dict()
+    strip = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}  # noqa: E731
+    g, mpd, msd = GeneratorRef(), MultiPeriodDiscriminatorRef(), MultiScaleDiscriminatorRef()
+    for mod, pre in ((g, "generator."), (mpd, "mpd."), (msd, "msd.")):
+        res = mod.load_state_dict(strip(pre), strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+    assert sd["mpd.discriminators.0.convs.1.weight_v"].shape == (128, 32, 5, 1)
+    assert sd["mpd.discriminators.0.convs.1.weight_g"].shape == (128, 1, 1, 1)
+    # and back: the upstream-shaped tensors load into a fresh trainer bit for bit
+    tr2 = HiFiGANTrainer(device="cpu", seed=7)
+    tr2.load_checkpoint(tr.checkpoint())
+    assert torch.equal(tr2.d_params.flat, tr.d_params.flat) and torch.equal(tr2.g_params.flat, tr.g_params.flat)
