@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void attention_cbt_kernel(const float* __restr
     }
   }
   if (!qlive) return;
-  const float inv = 1.f / l_run;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;  // an item of length 0 has no keys: its rows are zeros, not NaN
   float* o = out + ((long long)(h * DH) * B + b) * T + tq;
 #pragma unroll
   for (int i = 0; i < DH / 32; ++i)
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void attention_cbt_bf16_kernel(const float* __
     }
   }
   if (!qlive) return;
-  const float inv = 1.f / l_run;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;  // an item of length 0 has no keys: its rows are zeros, not NaN
   float* o = out + ((long long)(h * DH) * B + b) * T + tq;
 #pragma unroll
   for (int i = 0; i < DH / 32; ++i)

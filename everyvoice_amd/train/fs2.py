@@ -515,9 +515,19 @@ class FastSpeech2Trainer:
         tape = Tape()
         counter = [0]
 
+        world, rank = 1, 0
+        if self.pg is not None:
+            import torch.distributed as dist
+
+            grp = self.pg if self.pg is not True else None
+            world, rank = dist.get_world_size(grp), dist.get_rank(grp)
+
         def seeds(n=1):
+            """Counter-based dropout seeds: distinct per (seed, step, rank, draw) -- every data-parallel rank masks its shard
+            independently, as per-process RNG streams do under DDP."""
             counter[0] += n
-            return (self._seed * 1000003 + self.global_step) * 4096 + counter[0] - n
+            assert counter[0] < 65536, "more dropout draws in one step than the seed layout reserves"
+            return ((((self._seed * 1000003 + self.global_step) * world + rank) << 16) | (counter[0] - n)) & 0x7FFFFFFFFFFFFFFF
 
         def embed(with_position: bool) -> Var:
             e = torch.empty(D, B, L, device=dev, dtype=torch.float32)

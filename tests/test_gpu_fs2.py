@@ -273,6 +273,43 @@ def test_multispeaker_multilingual_and_checkpoint_roundtrip(cuda_device):
         FastSpeech2.from_checkpoint({**ckpt, "model_info": {"name": "FastSpeech2", "version": "9.0"}}, device=cuda_device)
 
 
+def test_config5_multispeaker_fs2_into_hop512_istft_vocoder(cuda_device):
+    """BASELINE config 5 end to end at its own model size: multi-speaker FastSpeech2 (default 256-dim conformers, 4 speakers)
+    -> iSTFTNet vocoder with upsampling 8 x 8 x 2 and iSTFT(16, 4) = hop 512 (44.1 kHz), against the oracle chain in fp32;
+    the bf16 path within its relative-L2 bound."""
+    from everyvoice_amd.fs2 import FastSpeech2
+    from oracle.hifigan_ref import HiFiGANModelConfigRef
+    from tests.helpers import make_ref_generator, rel_l2
+    from tests.test_gpu_generator import _product_from_ref
+
+    cfg = FastSpeech2ConfigRef()
+    cfg.n_speakers = 4
+    torch.manual_seed(21)
+    ref = FastSpeech2Ref(cfg).eval()
+    randomize_norm_stats_(ref, torch.Generator().manual_seed(22))
+    pc = _product_config(cfg)
+    pc.multispeaker, pc.n_speakers = True, 4
+    fs2 = FastSpeech2(pc, device=cuda_device, speaker2id={f"s{i}": i for i in range(4)}).load_state_dict(ref.state_dict())
+    ids, lens, g = _batch(cfg.n_symbols, 3, 37, seed=9)
+    durs = torch.randint(1, 5, (3, 37), generator=g)
+    spk = torch.tensor([2, 0, 3])
+    want = ref(ids, lens, durations=durs, speakers=spk)
+    got = fs2(ids, lens, durations=durs, speakers=spk)
+    assert torch.equal(got[5].cpu(), want[5])
+    _close(got[1].cpu(), want[1])
+    voc_ref = make_ref_generator(HiFiGANModelConfigRef(istft_layer=True, upsample_rates=[8, 8, 2], upsample_kernel_sizes=[16, 16, 4]), seed=99)
+    mel_ref_bct = want[1].detach().transpose(1, 2).contiguous()  # [B, 80, T]
+    with torch.no_grad():
+        wav_want = voc_ref(mel_ref_bct)
+    assert wav_want.shape[-1] == 512 * mel_ref_bct.shape[-1]
+    mel_got = got[1].transpose(1, 2).contiguous()
+    wav32 = _product_from_ref(voc_ref, cuda_device, "f32")(mel_got).cpu()
+    assert wav32.shape == wav_want.shape
+    assert float((wav32 - wav_want).abs().max()) <= 1e-3 * max(1.0, float(wav_want.abs().max()))  # mel 2e-4 of its scale, through the vocoder
+    wav16 = _product_from_ref(voc_ref, cuda_device, "bf16")(mel_got).cpu()
+    assert torch.isfinite(wav16).all() and rel_l2(wav16, wav_want) <= 3e-2
+
+
 def test_fs2_edge_cases(cuda_device):
     """One token, zero durations for some tokens, an all-zero item next to a normal one, max_length guard, duration_control."""
     from everyvoice_amd.fs2 import FastSpeech2

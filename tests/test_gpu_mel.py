@@ -51,6 +51,35 @@ def test_batched_random_audio(cuda_device, B, S):
     torch.testing.assert_close(torch.log(torch.clamp(lin, min=1e-5)), want_log, rtol=0, atol=LOGMEL_ATOL)
 
 
+@pytest.mark.parametrize("B,S", [(1, 16384), (3, 11000), (16, 8192)])
+def test_config5_front_end_44k_nfft2048_hop512(cuda_device, B, S):
+    """BASELINE config 5's STFT contract (AudioConfig with 44.1 kHz, n_fft = win = 2048, hop 512, f_max 8000): the magnitude
+    tile of 1025 bins does not fit the LDS next to the audio segment, so the kernel walks the bins in chunks."""
+    from everyvoice_amd.spectral import MelSpectrogram
+
+    g = torch.Generator().manual_seed(S)
+    audio = 0.3 * torch.tanh(torch.randn(B, S, generator=g))
+    tr = MelSpectrogram(2048, 2048, 512, 44100, 80, 0, 8000)
+    got_log, got_energy, got_mag = tr(audio.to(cuda_device), log=True, return_energy=True, return_magnitude=True)
+    want_log = mel_ref.mel_spectrogram_ref(audio, sr=44100, n_fft=2048, win=2048, hop=512)
+    assert got_log.shape == want_log.shape == (B, 80, 1 + S // 512)
+    assert float((got_log.cpu() - want_log).abs().max()) <= LOGMEL_ATOL
+    torch.testing.assert_close(got_mag.cpu(), mel_ref.magnitude_spectrogram_ref(audio, 2048, 2048, 512), rtol=1e-3, atol=4e-4)
+    np.testing.assert_allclose(got_energy.cpu().numpy(), np.linalg.norm(want_log.numpy(), axis=1), rtol=2e-4)
+
+
+def test_many_mel_bands_on_a_short_fft(cuda_device):
+    """n_fft 256 / hop 64 with 128 mel bands: the per-frame log-mel scratch (32 x 129 words) is larger than the audio tile."""
+    from everyvoice_amd.spectral import MelSpectrogram
+
+    audio = 0.3 * torch.tanh(torch.randn(2, 5000, generator=torch.Generator().manual_seed(1)))
+    tr = MelSpectrogram(256, 256, 64, 22050, 128, 0, 8000)
+    got, energy = tr(audio.to(cuda_device), log=True, return_energy=True)
+    want = mel_ref.mel_spectrogram_ref(audio, n_fft=256, win=256, hop=64, n_mels=128)
+    assert float((got.cpu() - want).abs().max()) <= LOGMEL_ATOL
+    np.testing.assert_allclose(energy.cpu().numpy(), np.linalg.norm(want.numpy(), axis=1), rtol=2e-4)
+
+
 def test_silence_and_edges(cuda_device):
     from everyvoice_amd.spectral import MelSpectrogram
 

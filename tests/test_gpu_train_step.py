@@ -217,13 +217,35 @@ def test_full_gan_step_istft_generator_matches_oracle(cuda_device, oracle_models
     _full_gan_step(cuda_device, oracle_models, "f32", istft=True)
 
 
+def test_full_gan_step_at_bench_size_matches_oracle(cuda_device, oracle_models):
+    """BASELINE config 4 at its own size: 16 segments of 8192 samples per GPU -- the shape bench.py times, where the planner
+    picks the 128 x 128 split-K tiles and the one-launch polyphase input gradients -- whole step against the CPU oracle in fp32."""
+    _full_gan_step(cuda_device, oracle_models, "f32", B=16, S=8192)
+
+
+def test_full_gan_step_at_bench_size_bf16_operands(cuda_device, oracle_models):
+    """The timed configuration itself (bs 16 x 8192, precision="bf16") against the oracle with the same roundings restated."""
+    with _bf16_operand_oracle():
+        _full_gan_step(cuda_device, oracle_models, "bf16", g_gain=1.0 / 8.0, B=16, S=8192)
+
+
+def test_full_gan_step_config5_vocoder_matches_oracle(cuda_device, oracle_models):
+    """BASELINE config 5's vocoder as a whole GAN step: 44.1 kHz front-end (n_fft 2048, hop 512) for the mel input and the
+    45 x mel-L1 term, generator upsampling 8 x 8 x 2 + iSTFT(16, 4) = hop 512."""
+    _full_gan_step(cuda_device, oracle_models, "f32", istft="c5", B=2, S=4096)
+
+
 def test_full_gan_step_resblock2_generator_matches_oracle(cuda_device, oracle_models):
     """The "2" resblock option (upstream V3 shape: 256 initial channels, upsampling 8 x 8 x 4, kernels 3 / 5 / 7 with two
     dilations each): the whole GAN step against the oracle."""
     _full_gan_step(cuda_device, oracle_models, "f32", istft="v3")
 
 
-def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=False):
+C5_AUDIO = dict(input_sampling_rate=44100, output_sampling_rate=44100, n_fft=2048, fft_window_size=2048, fft_hop_size=512)
+C5_MEL = dict(sr=44100, n_fft=2048, win=2048, hop=512)
+
+
+def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=False, B=2, S=2048):
     from everyvoice_amd.config import HiFiGANConfig
     from everyvoice_amd.train.hifigan import HiFiGANTrainer
 
@@ -234,14 +256,16 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
         torch.manual_seed(77)
         v3 = dict(resblock="2", upsample_rates=[8, 8, 4], upsample_kernel_sizes=[16, 16, 8], upsample_initial_channel=256,
                   resblock_kernel_sizes=[3, 5, 7], resblock_dilation_sizes=[[1, 2], [2, 6], [3, 12]])
-        g_ref = GeneratorRef(HiFiGANModelConfigRef(**v3) if istft == "v3" else HiFiGANModelConfigRef.test_config()).train()
+        c5 = dict(istft_layer=True, upsample_rates=[8, 8, 2], upsample_kernel_sizes=[16, 16, 4])  # x 4 (iSTFT hop) = hop 512
+        model_kw = v3 if istft == "v3" else c5 if istft == "c5" else dict(istft_layer=True, upsample_rates=[8, 8], upsample_kernel_sizes=[16, 16])
+        g_ref = GeneratorRef(HiFiGANModelConfigRef(**model_kw)).train()
         with torch.no_grad():  # livelier than N(0, 0.01), short of saturating exp()
             for n, p in g_ref.named_parameters():
                 if n.endswith("weight_g") and not n.startswith("conv_post"):
                     p.mul_(2.0)
         for new, old in zip((mpd_ref, msd_ref), oracle_models[1:]):
             new.load_state_dict(old.state_dict())
-        config = HiFiGANConfig(model=v3 if istft == "v3" else dict(istft_layer=True, upsample_rates=[8, 8], upsample_kernel_sizes=[16, 16]))
+        config = HiFiGANConfig(model=model_kw, preprocessing=dict(audio=C5_AUDIO) if istft == "c5" else {})
     else:
         g_ref = GeneratorRef().train()
         for new, old in zip((g_ref, mpd_ref, msd_ref), oracle_models):  # weight-normed modules do not deepcopy
@@ -259,9 +283,10 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
     loss_rel = 2e-4 if precision == "f32" else 2e-3
 
     gen = torch.Generator().manual_seed(11)
-    B, S = 2, 2048
     y = 0.3 * torch.tanh(torch.randn(B, 1, S, generator=gen))
-    mel = mel_ref.mel_spectrogram_ref(y.squeeze(1))[:, :, : S // 256]
+    mel_kw = C5_MEL if istft == "c5" else {}
+    hop = mel_kw.get("hop", 256)
+    mel = mel_ref.mel_spectrogram_ref(y.squeeze(1), **mel_kw)[:, :, : S // hop]
 
     # ---- oracle step (jik876 training loop order: D step, then G step) ----
     opt_g = torch.optim.AdamW(g_ref.parameters(), **opt_kw)
@@ -276,8 +301,8 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
     d_grads.update({"msd." + k: v.grad.clone() for k, v in msd_ref.named_parameters()})
     opt_d.step()
     opt_g.zero_grad()
-    lm_y = mel_ref.mel_spectrogram_ref(y.squeeze(1))
-    lm_g = mel_ref.mel_spectrogram_ref(y_hat.squeeze(1))
+    lm_y = mel_ref.mel_spectrogram_ref(y.squeeze(1), **mel_kw)
+    lm_g = mel_ref.mel_spectrogram_ref(y_hat.squeeze(1), **mel_kw)
     loss_mel = F.l1_loss(lm_y, lm_g) * 45
     _, g1, fr1, fg1 = mpd_ref(y, y_hat)
     _, g2, fr2, fg2 = msd_ref(y, y_hat)
