@@ -16,9 +16,14 @@ $(BUILD)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/evmi.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -L/opt/rocm/lib -lrocblas -Wl,-rpath,/opt/rocm/lib -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(OBJS) -o $@
+
+# tuning variants of the inference convolution (tools/sweep_conv.py): NOT part of the product library
+BENCHLIB   := tools/microbench/libevmi_bench.so
+bench-kernels: $(LIB)
+	$(HIPCC) $(HIPFLAGS) -Itools/microbench -shared tools/microbench/bench_kernels.hip -Leveryvoice_amd -levmi_hip -Wl,-rpath,'$$ORIGIN/../../everyvoice_amd' -o $(BENCHLIB)
 
 clean:
 	rm -rf $(BUILD) $(LIB)
 
-.PHONY: all clean
+.PHONY: all clean bench-kernels

@@ -123,6 +123,8 @@ SYMBOLS = {
     "evmi_batchnorm_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
     "evmi_dwconv1d_bwd_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 3),
     "evmi_dwconv1d_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_longlong] + [C.c_int] * 5 + [C.c_void_p]),
+    "evmi_mha_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
+    "evmi_mha_bwd_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_softmax_rows_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_softmax_bwd_rows_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_glu_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
@@ -150,6 +152,11 @@ SYMBOLS = {
     "evmi_weight_norm_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
     "evmi_weight_norm_bwd_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "evmi_normalize_vec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "evmi_optimizer_step_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_longlong] + [C.c_float] * 5 + [C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "evmi_transpose_bct_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "evmi_counter_add_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "evmi_spectral_norm_grad_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
+    "evmi_ratio_accumulate_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     "evmi_adamw_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_float] * 5 + [C.c_int, C.c_void_p]),
     "evmi_generator_create": (C.c_int, [C.POINTER(GeneratorConfig), C.c_int, C.POINTER(C.c_void_p)]),
     "evmi_generator_destroy": (None, [C.c_void_p]),

@@ -1,0 +1,342 @@
+// Multi-head self-attention for TRAINING (SURVEY.md 8a F2 / 8b evmi_mha_{fwd,bwd}): flash-style forward that keeps only the
+// per-query log-sum-exp, and a backward that recomputes the probabilities from it -- no [B][T][T] tensor exists in either pass.
+//
+//   qkv [3D][B][T] channel-major (q rows, k rows, v rows; head h owns channels h*DH .. h*DH+DH-1), lens [B] (key padding mask)
+//   forward : S = scale * Q K^T ; P = softmax_keys(S) ; Pd = dropout(P) ; O = Pd V           -> out [D][B][T], lse [B][H][T]
+//   backward: D_q = <dO_q, O_q> ; dPd = dO V^T ; dS = P * (mask/(1-p) * dPd - D) ;
+//             dQ = scale * dS K ; dK = scale * dS^T Q ; dV = Pd^T dO                          -> dqkv [3D][B][T]
+//
+// Attention dropout (torch.nn.MultiheadAttention applies it to the normalised probabilities) uses the counter-based generator
+// of fs2_train_ops.hip: element ((b * T + q) * T + k) of the stream seeded with seed + h, so the backward regenerates the mask.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).  Both passes use the transposed-problem trick of
+// the inference kernel (fs2_ops.hip): computing S^T = K Q^T leaves a score tile as lane = query, registers = keys, which is
+// exactly the B-operand layout of the next product over the keys (step r contracts the two keys the half-waves hold in register
+// r), so probabilities and score gradients never leave the registers.
+//   * dq kernel : one wave owns 32 queries (Q^T and dO^T in registers), walks the key tiles (K, V staged in LDS).
+//   * dkv kernel: one wave owns 32 keys (K^T and V^T in registers), walks the query tiles (Q, dO, lse, D staged in LDS).
+// Each (query, key) tile is therefore recomputed twice in the backward; in exchange every output element has ONE writer and a
+// fixed summation order: the gradients are bitwise reproducible (the checkpoint / resume test relies on that).
+#include "common.h"
+
+namespace evmi {
+
+__device__ __forceinline__ float attn_uniform01(unsigned long long seed, unsigned long long i) {
+  unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;  // splitmix64, as fs2_train_ops.hip: uniform01
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+constexpr int AT_LD = 33;  // staged rows are read both along and across: odd stride
+
+// register r of a 32x32 accumulator <-> row index within the tile, for half-wave kh
+__device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+// stage a [DH][32] tile of a channel-major [DH][B][T] slice starting at column t0 (zeros past T)
+template <int DH>
+__device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, long long N, int t0, int T, int tid) {
+  for (int v = tid; v < DH * 32; v += 256) {
+    const int d = v >> 5, tt = v & 31;
+    dst[d * AT_LD + tt] = t0 + tt < T ? src[(long long)d * N + t0 + tt] : 0.f;
+  }
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------------
+// grid (ceil(T / 128), H, B), 256 threads: every wave owns 32 queries
+template <int DH>
+__global__ __launch_bounds__(256) void attention_train_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+                                                                 float* __restrict__ out, float* __restrict__ lse, int B, int T, int D,
+                                                                 float scale, float p_drop, unsigned long long seed) {
+  __shared__ float Ks[DH * AT_LD];
+  __shared__ float Vs[DH * AT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int len = min(lens[b], T);
+  const long long N = (long long)B * T;
+  const float* q = qkv + ((long long)(h * DH) * B + b) * T;
+  const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
+  const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
+  const int tq = blockIdx.x * 128 + wave * 32 + ln;
+  const bool qlive = tq < T;
+  float qreg[DH / 2];
+#pragma unroll
+  for (int s = 0; s < DH / 2; ++s) qreg[s] = qlive ? q[(long long)(2 * s + kh) * N + tq] * scale : 0.f;
+  f32x16 acc[DH / 32];
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
+
+  for (int k0 = 0; k0 < len; k0 += 32) {
+    __syncthreads();
+    stage_tile<DH>(Ks, kg, N, k0, T, tid);
+    stage_tile<DH>(Vs, vg, N, k0, T, tid);
+    __syncthreads();
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH / 2; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * s + kh) * AT_LD + ln], qreg[s], st, 0, 0, 0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (k0 + acc_row(r, kh) >= len) st[r] = -INFINITY;
+      mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);  // finite: every processed tile has a valid key
+    const float corr = expf(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st[r] = expf(st[r] - m_new);
+      ps += st[r];  // the normaliser sums the probabilities BEFORE dropout
+      if (p_drop > 0.f)
+        st[r] = attn_uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? st[r] * keep : 0.f;
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * corr + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] *= corr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(i * 32 + ln) * AT_LD + acc_row(r, kh)], st[r], acc[i], 0, 0, 0);
+    }
+  }
+  if (!qlive) return;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;  // an item of length 0 has no keys: zero rows
+  float* o = out + ((long long)(h * DH) * B + b) * T + tq;
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(long long)(i * 32 + acc_row(r, kh)) * N] = acc[i][r] * inv;
+  if (kh == 0) lse[((long long)b * H + h) * T + tq] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;  // +inf: exp(s - lse) = 0
+}
+
+// ---- backward, step 0: D[b][h][t] = sum_d dO[d][b][t] * O[d][b][t] ---------------------------------------------------------
+__global__ void attention_rowdot_kernel(const float* __restrict__ o, const float* __restrict__ d_o, float* __restrict__ dsum, int B, int T,
+                                        int H, int DH) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * H * T) return;
+  const int t = (int)(i % T), h = (int)((i / T) % H), b = (int)(i / ((long long)T * H));
+  const long long N = (long long)B * T;
+  const long long base = ((long long)(h * DH) * B + b) * T + t;
+  float acc = 0.f;
+  for (int d = 0; d < DH; ++d) acc = fmaf(o[base + d * N], d_o[base + d * N], acc);
+  dsum[i] = acc;
+}
+
+// ---- backward, dQ: grid (ceil(T / 128), H, B); every wave owns 32 queries and walks the key tiles -----------------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attention_train_dq_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+                                                                const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                                const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
+                                                                int D, float scale, float p_drop, unsigned long long seed) {
+  __shared__ float Ks[DH * AT_LD];
+  __shared__ float Vs[DH * AT_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int len = min(lens[b], T);
+  const long long N = (long long)B * T;
+  const float* q = qkv + ((long long)(h * DH) * B + b) * T;
+  const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
+  const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
+  const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
+  const int tq = blockIdx.x * 128 + wave * 32 + ln;
+  const bool qlive = tq < T;
+  float qreg[DH / 2], doreg[DH / 2];
+#pragma unroll
+  for (int s = 0; s < DH / 2; ++s) {
+    qreg[s] = qlive ? q[(long long)(2 * s + kh) * N + tq] * scale : 0.f;
+    doreg[s] = qlive ? dog[(long long)(2 * s + kh) * N + tq] : 0.f;
+  }
+  const float my_lse = qlive ? lse[((long long)b * H + h) * T + tq] : INFINITY;
+  const float my_d = qlive ? dsum[((long long)b * H + h) * T + tq] : 0.f;
+  const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
+  f32x16 acc[DH / 32];
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  for (int k0 = 0; k0 < len; k0 += 32) {
+    __syncthreads();
+    stage_tile<DH>(Ks, kg, N, k0, T, tid);
+    stage_tile<DH>(Vs, vg, N, k0, T, tid);
+    __syncthreads();
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH / 2; ++s) {
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * s + kh) * AT_LD + ln], qreg[s], st, 0, 0, 0);   // S^T  = K Q^T
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(2 * s + kh) * AT_LD + ln], doreg[s], dp, 0, 0, 0);  // dPd^T = V dO^T
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + acc_row(r, kh);
+      const float pr = key < len ? expf(st[r] - my_lse) : 0.f;
+      float g = dp[r];
+      if (p_drop > 0.f) g = attn_uniform01(seed + h, row_base + (unsigned long long)key) >= p_drop ? g * keep : 0.f;
+      st[r] = pr * (g - my_d);  // dS^T as it lies: lane = query, register = key
+    }
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)  // dQ^T [d][query] += K^T [d][key] dS^T [key][query]
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(i * 32 + ln) * AT_LD + acc_row(r, kh)], st[r], acc[i], 0, 0, 0);
+  }
+  if (!qlive) return;
+  float* o = dqkv + ((long long)(h * DH) * B + b) * T + tq;
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(long long)(i * 32 + acc_row(r, kh)) * N] = acc[i][r] * scale;
+}
+
+// ---- backward, dK and dV: grid (ceil(T / 128), H, B); every wave owns 32 keys and walks the query tiles ---------------------
+template <int DH>
+__global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+                                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                                 const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
+                                                                 int D, float scale, float p_drop, unsigned long long seed) {
+  __shared__ float Qs[DH * AT_LD];
+  __shared__ float Os[DH * AT_LD];
+  __shared__ float lse_s[32], d_s[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int len = min(lens[b], T);
+  const long long N = (long long)B * T;
+  const float* qg = qkv + ((long long)(h * DH) * B + b) * T;
+  const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
+  const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
+  const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
+  const int tk = blockIdx.x * 128 + wave * 32 + ln;
+  const bool klive = tk < len;  // padded keys receive no probability mass: zero gradients
+  float kreg[DH / 2], vreg[DH / 2];
+#pragma unroll
+  for (int s = 0; s < DH / 2; ++s) {
+    kreg[s] = klive ? kg[(long long)(2 * s + kh) * N + tk] * scale : 0.f;
+    vreg[s] = klive ? vg[(long long)(2 * s + kh) * N + tk] : 0.f;
+  }
+  const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  f32x16 acck[DH / 32], accv[DH / 32];
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acck[i][r] = accv[i][r] = 0.f;
+  const bool block_live = blockIdx.x * 128 < len;  // uniform per workgroup
+
+  for (int q0 = 0; q0 < T && block_live; q0 += 32) {
+    __syncthreads();
+    stage_tile<DH>(Qs, qg, N, q0, T, tid);
+    stage_tile<DH>(Os, dog, N, q0, T, tid);
+    if (tid < 32) {
+      const bool in = q0 + tid < T;
+      lse_s[tid] = in ? lse[((long long)b * H + h) * T + q0 + tid] : INFINITY;
+      d_s[tid] = in ? dsum[((long long)b * H + h) * T + q0 + tid] : 0.f;
+    }
+    __syncthreads();
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH / 2; ++s) {
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(2 * s + kh) * AT_LD + ln], kreg[s], st, 0, 0, 0);  // S   = Q K^T : lane = key, registers = queries
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[(2 * s + kh) * AT_LD + ln], vreg[s], dp, 0, 0, 0);  // dPd = dO V^T
+    }
+    f32x16 pd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = acc_row(r, kh);
+      const int tq = q0 + qi;
+      const float pr = (klive && tq < T) ? expf(st[r] - lse_s[qi]) : 0.f;
+      float mk = 1.f;
+      if (p_drop > 0.f) mk = attn_uniform01(seed + h, ((unsigned long long)b * T + (unsigned long long)min(tq, T - 1)) * T + (unsigned long long)min(tk, T - 1)) >= p_drop ? keep : 0.f;
+      pd[r] = pr * mk;                        // Pd   : the dropped-out probabilities that multiplied V
+      st[r] = pr * (dp[r] * mk - d_s[qi]);    // dS
+    }
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qi = acc_row(r, kh);
+        accv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[(i * 32 + ln) * AT_LD + qi], pd[r], accv[i], 0, 0, 0);  // dV^T += dO^T Pd
+        acck[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(i * 32 + ln) * AT_LD + qi], st[r], acck[i], 0, 0, 0);  // dK^T += Q^T dS
+      }
+  }
+  if (tk >= T) return;
+  float* dk = dqkv + ((long long)(D + h * DH) * B + b) * T + tk;
+  float* dv = dqkv + ((long long)(2 * D + h * DH) * B + b) * T + tk;
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dk[(long long)(i * 32 + acc_row(r, kh)) * N] = acck[i][r] * scale;
+      dv[(long long)(i * 32 + acc_row(r, kh)) * N] = accv[i][r];
+    }
+}
+
+}  // namespace evmi
+
+using namespace evmi;
+
+extern "C" {
+
+int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
+                     float p_drop, unsigned long long seed, void* stream) {
+  if (!qkv_dev || !lens_dev || !out_dev || !lse_dev) return fail(EVMI_ERR_INVALID_ARG, "mha_fwd: null pointer");
+  if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads || p_drop < 0.f || p_drop >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "mha_fwd: shape / dropout");
+  if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "mha_fwd: grid limits");
+  const int dh = D / heads;
+  const float scale = 1.f / sqrtf((float)dh);
+  const dim3 grid((T + 127) / 128, heads, B);
+  hipStream_t s = (hipStream_t)stream;
+#define EVMI_MHA_FWD(DH) hipLaunchKernelGGL(attention_train_fwd_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, scale, p_drop, seed)
+  if (dh == 128) EVMI_MHA_FWD(128);
+  else if (dh == 64) EVMI_MHA_FWD(64);
+  else if (dh == 32) EVMI_MHA_FWD(32);
+  else return fail(EVMI_ERR_UNSUPPORTED, "mha_fwd: head dimension must be 32, 64 or 128");
+#undef EVMI_MHA_FWD
+  EVMI_LAUNCH_CHECK("mha_fwd");
+  return EVMI_OK;
+}
+
+int evmi_mha_bwd_f32(const float* qkv_dev, const int* lens_dev, const float* out_dev, const float* dout_dev, const float* lse_dev,
+                     float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop, unsigned long long seed,
+                     void* stream) {
+  if (!qkv_dev || !lens_dev || !out_dev || !dout_dev || !lse_dev || !dsum_dev || !dqkv_dev) return fail(EVMI_ERR_INVALID_ARG, "mha_bwd: null pointer");
+  if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads || p_drop < 0.f || p_drop >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "mha_bwd: shape / dropout");
+  if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "mha_bwd: grid limits");
+  const int dh = D / heads;
+  const float scale = 1.f / sqrtf((float)dh);
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)B * heads * T;
+  hipLaunchKernelGGL(attention_rowdot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out_dev, dout_dev, dsum_dev, B, T, heads, dh);
+  const dim3 grid((T + 127) / 128, heads, B);
+#define EVMI_MHA_BWD(DH)                                                                                                          \
+  {                                                                                                                               \
+    hipLaunchKernelGGL(attention_train_dq_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev,      \
+                       dqkv_dev, B, T, D, scale, p_drop, seed);                                                                   \
+    hipLaunchKernelGGL(attention_train_dkv_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev,     \
+                       dqkv_dev, B, T, D, scale, p_drop, seed);                                                                   \
+  }
+  if (dh == 128) EVMI_MHA_BWD(128)
+  else if (dh == 64) EVMI_MHA_BWD(64)
+  else if (dh == 32) EVMI_MHA_BWD(32)
+  else return fail(EVMI_ERR_UNSUPPORTED, "mha_bwd: head dimension must be 32, 64 or 128");
+#undef EVMI_MHA_BWD
+  EVMI_LAUNCH_CHECK("mha_bwd");
+  return EVMI_OK;
+}
+
+}  // extern "C"

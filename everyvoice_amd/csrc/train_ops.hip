@@ -5,31 +5,19 @@
 //     fwd     Y[C_out][B*T_out]   = W[C_out][C_in*k] . col[C_in*k][B*T_out]
 //     dgrad   dcol[C_in*k][B*T_out] = W^T . dY          -> fold back (col2im)
 //     wgrad   dW[C_out][C_in*k]   = dY . col^T          (the batch is part of the GEMM's K dimension)
-// and audio [B,1,T] / logits are the same bytes in CBT and in torch's BCT.  The GEMMs go to rocBLAS
-// (plain library GEMMs); everything around them (unfold / fold, activations, pooling, padding, losses,
-// weight / spectral norm, AdamW) is hand-written here.  First-version training path: correctness and
-// the full step first; the inference path's implicit-GEMM MFMA kernels replace the unfold + GEMM pairs
-// layer by layer in later rounds.
-#include <rocblas/rocblas.h>
-
+// and audio [B,1,T] / logits are the same bytes in CBT and in torch's BCT.  The plain GEMMs that remain (the A/B "gemm"
+// convolution backend, loss DFTs, the fp32 dense weight-gradient fallback) run on this library's own fp32 matrix-core GEMM
+// (gemm_f32.hip); everything around them (unfold / fold, activations, pooling, padding, losses, weight / spectral norm, the
+// optimisers) is hand-written here.  No BLAS library is linked.
 #include <algorithm>
+#include <map>
 
 #include "common.h"
 
 namespace evmi {
 
-// ---- rocBLAS plumbing ------------------------------------------------------------------------------
-static thread_local rocblas_handle g_blas = nullptr;
-
-static int blas_handle(hipStream_t s, rocblas_handle* out) {
-  if (!g_blas) {
-    if (rocblas_create_handle(&g_blas) != rocblas_status_success) return fail(EVMI_ERR_HIP, "rocblas_create_handle failed");
-    rocblas_set_pointer_mode(g_blas, rocblas_pointer_mode_host);
-  }
-  if (rocblas_set_stream(g_blas, s) != rocblas_status_success) return fail(EVMI_ERR_HIP, "rocblas_set_stream failed");
-  *out = g_blas;
-  return EVMI_OK;
-}
+int launch_gemm_f32(bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, long long sa, const float* B, int ldb,
+                    long long sb, float beta, float* C, int ldc, long long sc, int batch, hipStream_t s);
 
 // out[i] = beta * out[i] + sum_s part[s][i]   (split-K partial sums; out is [M][ldc], part is [S][M][N])
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int M, int N, int ldc, int S,
@@ -43,8 +31,22 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
   *o = beta == 0.f ? acc : beta * *o + acc;
 }
 
-static thread_local float* g_splitk_ws = nullptr;
-static thread_local size_t g_splitk_cap = 0;
+// Scratch for partial sums, one buffer per (thread, stream): launches on different streams may overlap on the device.  It only
+// grows (hipMalloc outside stream order): warm every shape up before capturing a HIP graph.
+struct SplitKWs { float* ptr = nullptr; size_t cap = 0; };
+static thread_local std::map<hipStream_t, SplitKWs> g_splitk;
+static int splitk_ws(hipStream_t s, size_t need, float** out) {
+  SplitKWs& w = g_splitk[s];
+  if (need > w.cap) {
+    if (w.ptr) (void)hipFree(w.ptr);
+    w.ptr = nullptr;
+    w.cap = 0;
+    EVMI_HIP_CHECK(hipMalloc((void**)&w.ptr, need * sizeof(float)));
+    w.cap = need;
+  }
+  *out = w.ptr;
+  return EVMI_OK;
+}
 
 // Matrix-vector products of the spectral-norm power iteration (W up to 1024 x 5120): a library GEMM with N = 1 takes 36-51 us
 // for them; these read W once at memory speed.  y[r] = sum_c W[r][c] x[c]: one workgroup per row.
@@ -91,7 +93,6 @@ __global__ __launch_bounds__(256) void rank1_update_kernel(const float* __restri
 }
 
 // Row-major C[M][N] = alpha * op(A) . op(B) + beta * C;  op(A) is M x K, op(B) is K x N.
-// (row-major C is column-major C^T = op(B)^T . op(A)^T: operands swapped for rocBLAS)
 int gemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float* A, int lda, const float* B, int ldb,
             float beta, float* C, int ldc, hipStream_t s) {
   if (N == 1 && alpha == 1.f && beta == 0.f && ldb == 1 && ldc == 1 && (long long)M * K >= 4096) {  // matrix-vector products
@@ -101,16 +102,10 @@ int gemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float* A, 
       return EVMI_OK;
     }
     const int chunks = (K + GEMV_RC - 1) / GEMV_RC;  // op(A) = A^T: A is [K][M]
-    const size_t need = (size_t)chunks * M;
-    if (need > g_splitk_cap) {
-      if (g_splitk_ws) (void)hipFree(g_splitk_ws);
-      g_splitk_ws = nullptr;
-      g_splitk_cap = 0;
-      EVMI_HIP_CHECK(hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
-      g_splitk_cap = need;
-    }
-    hipLaunchKernelGGL(gemv_cols_partial_kernel, dim3((M + 255) / 256, chunks), dim3(256), 0, s, A, B, g_splitk_ws, K, M, lda);
-    hipLaunchKernelGGL(gemv_cols_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, g_splitk_ws, C, chunks, M);
+    float* ws = nullptr;
+    if (int rc = splitk_ws(s, (size_t)chunks * M, &ws)) return rc;
+    hipLaunchKernelGGL(gemv_cols_partial_kernel, dim3((M + 255) / 256, chunks), dim3(256), 0, s, A, B, ws, K, M, lda);
+    hipLaunchKernelGGL(gemv_cols_final_kernel, dim3((M + 255) / 256), dim3(256), 0, s, ws, C, chunks, M);
     EVMI_LAUNCH_CHECK("gemv_cols");
     return EVMI_OK;
   }
@@ -119,47 +114,26 @@ int gemm_rm(bool ta, bool tb, int M, int N, int K, float alpha, const float* A, 
     EVMI_LAUNCH_CHECK("rank1_update");
     return EVMI_OK;
   }
-  rocblas_handle h;
-  int rc = blas_handle(s, &h);
-  if (rc) return rc;
   // Weight-gradient shapes: a small [M][N] output reduced over a very long K (= batch * time).  A single GEMM
-  // puts that on a handful of workgroups; split K into equal slabs as a strided-batched GEMM and add the slabs.
+  // puts that on a handful of workgroups; split K into equal slabs (a batched GEMM into partial tiles) and add the slabs in order.
   if (K >= 8192 && (long long)M * N <= (1ll << 21)) {
     int S = K / 4096;
     if (S > 128) S = 128;
     const int kc = K / S, tail = K - kc * S;
     const int slabs = S + (tail ? 1 : 0);
-    const size_t need = (size_t)slabs * M * N;
-    if (need > g_splitk_cap) {
-      if (g_splitk_ws) (void)hipFree(g_splitk_ws);
-      g_splitk_ws = nullptr;
-      g_splitk_cap = 0;
-      EVMI_HIP_CHECK(hipMalloc((void**)&g_splitk_ws, need * sizeof(float)));
-      g_splitk_cap = need;
-    }
-    const float zero = 0.f;
+    float* ws = nullptr;
+    if (int rc = splitk_ws(s, (size_t)slabs * M * N, &ws)) return rc;
     const long long sa = ta ? (long long)kc * lda : kc;  // advance of op(A) along K
     const long long sb = tb ? kc : (long long)kc * ldb;
-    rocblas_status st = rocblas_sgemm_strided_batched(
-        h, tb ? rocblas_operation_transpose : rocblas_operation_none, ta ? rocblas_operation_transpose : rocblas_operation_none,
-        N, M, kc, &alpha, B, ldb, sb, A, lda, sa, &zero, g_splitk_ws, N, (long long)M * N, S);
-    if (st != rocblas_status_success) return fail(EVMI_ERR_HIP, "rocblas_sgemm_strided_batched failed: " + std::to_string((int)st));
-    if (tail) {
-      st = rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
-                         ta ? rocblas_operation_transpose : rocblas_operation_none, N, M, tail, &alpha, B + sb * S, ldb,
-                         A + sa * S, lda, &zero, g_splitk_ws + (size_t)S * M * N, N);
-      if (st != rocblas_status_success) return fail(EVMI_ERR_HIP, "rocblas_sgemm (split-K tail) failed");
-    }
+    if (int rc = launch_gemm_f32(ta, tb, M, N, kc, alpha, A, lda, sa, B, ldb, sb, 0.f, ws, N, (long long)M * N, S, s)) return rc;
+    if (tail)
+      if (int rc = launch_gemm_f32(ta, tb, M, N, tail, alpha, A + sa * S, lda, 0, B + sb * S, ldb, 0, 0.f, ws + (size_t)S * M * N, N, 0, 1, s)) return rc;
     const long long n = (long long)M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g_splitk_ws, C, M, N, ldc, slabs, beta);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ws, C, M, N, ldc, slabs, beta);
     EVMI_LAUNCH_CHECK("splitk_reduce");
     return EVMI_OK;
   }
-  const rocblas_status st = rocblas_sgemm(h, tb ? rocblas_operation_transpose : rocblas_operation_none,
-                                          ta ? rocblas_operation_transpose : rocblas_operation_none, N, M, K, &alpha, B,
-                                          ldb, A, lda, &beta, C, ldc);
-  if (st != rocblas_status_success) return fail(EVMI_ERR_HIP, "rocblas_sgemm failed: " + std::to_string((int)st));
-  return EVMI_OK;
+  return launch_gemm_f32(ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, s);
 }
 
 // Same, `batch` independent problems at fixed element strides (grouped convolutions: one problem per group).
@@ -173,14 +147,7 @@ int gemm_rm_batched(bool ta, bool tb, int M, int N, int K, float alpha, const fl
     }
     return EVMI_OK;
   }
-  rocblas_handle h;
-  int rc = blas_handle(s, &h);
-  if (rc) return rc;
-  const rocblas_status st = rocblas_sgemm_strided_batched(
-      h, tb ? rocblas_operation_transpose : rocblas_operation_none, ta ? rocblas_operation_transpose : rocblas_operation_none, N,
-      M, K, &alpha, B, ldb, sb, A, lda, sa, &beta, C, ldc, sc, batch);
-  if (st != rocblas_status_success) return fail(EVMI_ERR_HIP, "rocblas_sgemm_strided_batched failed: " + std::to_string((int)st));
-  return EVMI_OK;
+  return launch_gemm_f32(ta, tb, M, N, K, alpha, A, lda, sa, B, ldb, sb, beta, C, ldc, sc, batch, s);
 }
 
 // ---- unfold / fold ------------------------------------------------------------------------------------
@@ -347,6 +314,8 @@ __global__ void row_reduce_final_kernel(const float* __restrict__ part, float* _
 //   13: y = silu(a)                         14: y = relu(a)                        15: y = a * sigmoid(b)  (GLU)
 //   20: y = a * min(1, p0 / (sqrt(c[0]) + 1e-6))   (gradient-norm clipping, c[0] = sum of squares on the device)
 //   18: y = a * silu'(b)                    19: y = b > 0 ? a : 0  (ReLU backward from the output)
+//   23: y = p0 (fill)
+//   21: y = a / c[0]  (device scalar)        22: op 17 with p0 / (sqrt(c[0]) sqrt(c[1])) as the first coefficient (device scalars)
 //   16: y = log(a)                          17: y = p0 * (a - b) + p1 * sign(a - b) / a   (d/da of the two STFT-loss terms, a = |Y^|, b = |Y|)
 template <int OP>
 __global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
@@ -374,6 +343,13 @@ __global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__
   else if (OP == 18) { const float z = b[i], sg = 1.f / (1.f + expf(-z)); r = a[i] * sg * (1.f + z * (1.f - sg)); }
   else if (OP == 19) r = b[i] > 0.f ? a[i] : 0.f;
   else if (OP == 20) r = a[i] * fminf(1.f, p0 / (sqrtf(c[0]) + 1e-6f));
+  else if (OP == 21) r = a[i] / c[0];
+  else if (OP == 23) r = p0;
+  else if (OP == 22) {  // op 17 with its first coefficient p0 / (||a - b|| ||b||) formed from the squared norms c[0], c[1] on the device
+    const float nd = sqrtf(c[0]), ny = sqrtf(c[1]);
+    const float k0 = nd > 0.f ? p0 / (nd * ny) : 0.f;
+    r = k0 * (a[i] - b[i]) + p1 * (a[i] > b[i] ? 1.f : (a[i] < b[i] ? -1.f : 0.f)) / a[i];
+  }
   else r = p0 * (a[i] - b[i]) + p1 * (a[i] > b[i] ? 1.f : (a[i] < b[i] ? -1.f : 0.f)) / a[i];
   y[i] = r;
 }
@@ -681,6 +657,61 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   p[i] = pv - (lr / bc1) * mv / denom;
 }
 
+// One step of Adam / AdamW / RMSprop on a flat buffer (torch.optim semantics, amsgrad / momentum / centered off), the optimiser
+// union the reference's training config allows (everyvoice/.schema/everyvoice-spec-to-wav-0.5.json:434-622).
+//   kind 0 AdamW: decoupled decay p *= 1 - lr wd;  kind 1 Adam: g += wd p (L2);  kind 2 RMSprop: v = a v + (1-a) g^2, p -= lr g / (sqrt(v) + eps)
+// The 1-based step number comes from a device counter when `step_dev` is given (so a captured HIP graph replays correctly);
+// clip > 0 clamps the updated parameters to [-clip, clip] (WGAN weight clipping, wgan_clip_value).
+__global__ void optimizer_step_kernel(int kind, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                      float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps, float wd,
+                                      int step, const int* __restrict__ step_dev, float clip) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float pv = p[i], gv = g[i];
+  if (kind == 2) {
+    gv = fmaf(wd, pv, gv);
+    const float vv = beta1 * v[i] + (1.f - beta1) * gv * gv;  // beta1 carries RMSprop's alpha
+    v[i] = vv;
+    pv -= lr * gv / (sqrtf(vv) + eps);
+  } else {
+    const float st = (float)(step_dev ? *step_dev : step);
+    const float bc1 = 1.f - powf(beta1, st), bc2 = 1.f - powf(beta2, st);
+    if (kind == 0) pv *= 1.f - lr * wd;
+    else gv = fmaf(wd, pv, gv);
+    const float mv = beta1 * m[i] + (1.f - beta1) * gv;
+    const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    pv -= (lr / bc1) * mv / (sqrtf(vv) / sqrtf(bc2) + eps);
+  }
+  if (clip > 0.f) pv = fminf(fmaxf(pv, -clip), clip);
+  p[i] = pv;
+}
+__global__ void counter_add_kernel(int* c, int delta) { *c += delta; }
+// out[c][b][t] = in[b][c][t]  (torch's [B, C, T] batch to the channel-major training layout; rows of T stay contiguous)
+__global__ void transpose_bct_cbt_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int C, int T, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int t = (int)(i % T);
+  const long long r = i / T;
+  const int b = (int)(r % B), c = (int)(r / B);
+  out[i] = in[((long long)b * C + c) * T + t];
+}
+
+// Spectral-norm pieces with the scale sigma left on the device (no host round trip in the step):
+//   sn_grad: gW[r][c] += dw[r][c] / sigma - (dot / sigma^2) * u[r] * v[c]      (dot = <dw, W>, sigma = u^T W v)
+__global__ void sn_grad_kernel(float* __restrict__ gW, const float* __restrict__ dw, const float* __restrict__ u,
+                               const float* __restrict__ v, const float* __restrict__ sigma, const float* __restrict__ dot, int cols,
+                               long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sg = *sigma;
+  const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+  gW[i] += dw[i] / sg - (*dot / (sg * sg)) * u[r] * v[c];
+}
+// out[0] += w * sqrt(c[0] / c[1])   (the spectral-convergence term of the multi-resolution STFT loss from its two squared norms)
+__global__ void ratio_acc_kernel(float* out, const float* c, float w) { out[0] += c[1] > 0.f ? w * sqrtf(c[0] / c[1]) : 0.f; }
+
 static inline dim3 grid1d(long long n, int block = 256) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace evmi
@@ -765,16 +796,12 @@ int evmi_row_reduce_f32(int mode, const float* a_dev, const float* b_dev, float*
   hipStream_t s = (hipStream_t)stream;
   // few long rows: split every row into segments so the chip is busy (two passes, fixed summation order)
   constexpr int MAXSEG = 64;
-  static thread_local float* part = nullptr;
-  static thread_local long long part_elems = 0;
+  float* part = nullptr;
   int nseg = 1;
   if (rows < 512 && n_per_row > 16384) nseg = (int)std::min<long long>(MAXSEG, std::min<long long>((1024 + rows - 1) / rows, (n_per_row + 8191) / 8192));
   const long long seg = (n_per_row + nseg - 1) / nseg;
-  if (nseg > 1 && part_elems < (long long)rows * nseg) {
-    if (part) EVMI_HIP_CHECK(hipFree(part));
-    part_elems = (long long)rows * MAXSEG;
-    EVMI_HIP_CHECK(hipMalloc((void**)&part, part_elems * sizeof(float)));
-  }
+  if (nseg > 1)
+    if (int rc = splitk_ws(s, (size_t)rows * MAXSEG, &part)) return rc;
   const dim3 grid(rows, nseg);
   if (mode == 0) hipLaunchKernelGGL(row_reduce_kernel<0>, grid, dim3(256), 0, s, a_dev, b_dev, out_dev, part, n_per_row, seg, scale, accumulate);
   else if (mode == 1) hipLaunchKernelGGL(row_reduce_kernel<1>, grid, dim3(256), 0, s, a_dev, b_dev, out_dev, part, n_per_row, seg, scale, accumulate);
@@ -790,16 +817,12 @@ int evmi_lrelu_bwd_rowsum_f32(const float* dy_dev, const float* y_dev, float* dp
   EVMI_NONNULL(dy_dev && y_dev && dpre_dev && db_dev, "lrelu_bwd_rowsum");
   hipStream_t s = (hipStream_t)stream;
   constexpr int MAXSEG = 64;
-  static thread_local float* part = nullptr;
-  static thread_local long long part_elems = 0;
+  float* part = nullptr;
   int nseg = 1;
   if (rows < 512 && n_per_row > 16384) nseg = (int)std::min<long long>(MAXSEG, std::min<long long>((1024 + rows - 1) / rows, (n_per_row + 8191) / 8192));
   const long long seg = (n_per_row + nseg - 1) / nseg;
-  if (nseg > 1 && part_elems < (long long)rows * nseg) {
-    if (part) EVMI_HIP_CHECK(hipFree(part));
-    part_elems = (long long)rows * MAXSEG;
-    EVMI_HIP_CHECK(hipMalloc((void**)&part, part_elems * sizeof(float)));
-  }
+  if (nseg > 1)
+    if (int rc = splitk_ws(s, (size_t)rows * MAXSEG, &part)) return rc;
   hipLaunchKernelGGL(lrelu_bwd_rowsum_kernel, dim3(rows, nseg), dim3(256), 0, s, dy_dev, y_dev, dpre_dev, db_dev, part, n_per_row, seg, slope,
                      accumulate);
   if (nseg > 1) hipLaunchKernelGGL(row_reduce_final_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, db_dev, rows, nseg, 1.f, accumulate);
@@ -813,7 +836,7 @@ int evmi_elementwise_f32(int op, const float* a_dev, const float* b_dev, const f
   hipStream_t s = (hipStream_t)stream;
 #define EW(OPN) case OPN: hipLaunchKernelGGL(ew_kernel<OPN>, grid1d(n), dim3(256), 0, s, a_dev, b_dev, c_dev, y_dev, n, p0, p1); break;
   switch (op) {
-    EW(0) EW(1) EW(2) EW(3) EW(4) EW(5) EW(6) EW(7) EW(8) EW(9) EW(10) EW(11) EW(12) EW(13) EW(14) EW(15) EW(16) EW(17) EW(18) EW(19) EW(20)
+    EW(0) EW(1) EW(2) EW(3) EW(4) EW(5) EW(6) EW(7) EW(8) EW(9) EW(10) EW(11) EW(12) EW(13) EW(14) EW(15) EW(16) EW(17) EW(18) EW(19) EW(20) EW(21) EW(22) EW(23)
     default: return fail(EVMI_ERR_INVALID_ARG, "elementwise: unknown op");
   }
 #undef EW
@@ -826,9 +849,10 @@ int evmi_scalar_reduce_f32(int mode, const float* a_dev, const float* b_dev, flo
                            float p, int accumulate, void* stream) {
   EVMI_NONNULL(a_dev && out_dev, "scalar_reduce");
   hipStream_t s = (hipStream_t)stream;
-  static thread_local double* part = nullptr;
   constexpr int MAXB = 1024;
-  if (!part) EVMI_HIP_CHECK(hipMalloc((void**)&part, MAXB * sizeof(double)));
+  float* part_f = nullptr;
+  if (int rc = splitk_ws(s, 2 * MAXB, &part_f)) return rc;
+  double* part = reinterpret_cast<double*>(part_f);
   int nb = (int)((n + 256 * 8 - 1) / (256 * 8));
   if (nb < 1) nb = 1;
   if (nb > MAXB) nb = MAXB;
@@ -944,6 +968,47 @@ int evmi_normalize_vec_f32(const float* x_dev, float* y_dev, int n, float eps, v
   EVMI_NONNULL(x_dev && y_dev, "normalize_vec");
   hipLaunchKernelGGL(normalize_vec_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x_dev, y_dev, n, eps);
   EVMI_LAUNCH_CHECK("normalize_vec");
+  return EVMI_OK;
+}
+
+int evmi_optimizer_step_f32(int kind, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, int step, const int* step_dev, float clip, void* stream) {
+  EVMI_NONNULL(p_dev && g_dev && v_dev && (kind == 2 || m_dev), "optimizer_step");
+  if (kind < 0 || kind > 2) return fail(EVMI_ERR_INVALID_ARG, "optimizer_step: kind (0 AdamW, 1 Adam, 2 RMSprop)");
+  hipLaunchKernelGGL(optimizer_step_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, kind, p_dev, g_dev, m_dev, v_dev, n, lr, beta1,
+                     beta2, eps, weight_decay, step, step_dev, clip);
+  EVMI_LAUNCH_CHECK("optimizer_step");
+  return EVMI_OK;
+}
+
+int evmi_transpose_bct_cbt_f32(const float* in_dev, float* out_dev, int B, int C, int T, void* stream) {
+  EVMI_NONNULL(in_dev && out_dev, "transpose_bct_cbt");
+  const long long n = (long long)B * C * T;
+  hipLaunchKernelGGL(transpose_bct_cbt_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev, B, C, T, n);
+  EVMI_LAUNCH_CHECK("transpose_bct_cbt");
+  return EVMI_OK;
+}
+
+int evmi_counter_add_i32(int* counter_dev, int delta, void* stream) {
+  EVMI_NONNULL(counter_dev, "counter_add");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter_dev, delta);
+  EVMI_LAUNCH_CHECK("counter_add");
+  return EVMI_OK;
+}
+
+int evmi_spectral_norm_grad_f32(float* gw_dev, const float* dw_dev, const float* u_dev, const float* v_dev, const float* sigma_dev,
+                                const float* dot_dev, int rows, int cols, void* stream) {
+  EVMI_NONNULL(gw_dev && dw_dev && u_dev && v_dev && sigma_dev && dot_dev, "spectral_norm_grad");
+  const long long n = (long long)rows * cols;
+  hipLaunchKernelGGL(sn_grad_kernel, grid1d(n), dim3(256), 0, (hipStream_t)stream, gw_dev, dw_dev, u_dev, v_dev, sigma_dev, dot_dev, cols, n);
+  EVMI_LAUNCH_CHECK("spectral_norm_grad");
+  return EVMI_OK;
+}
+
+int evmi_ratio_accumulate_f32(float* out_dev, const float* sq_dev, float weight, void* stream) {
+  EVMI_NONNULL(out_dev && sq_dev, "ratio_accumulate");
+  hipLaunchKernelGGL(ratio_acc_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out_dev, sq_dev, weight);
+  EVMI_LAUNCH_CHECK("ratio_accumulate");
   return EVMI_OK;
 }
 

@@ -117,7 +117,7 @@ def add(tape: Tape, a: Var, b: Var) -> Var:
         if y.grad is None:
             return
         a.accumulate(y.grad)
-        b.accumulate(y.grad.clone() if a.needs_grad and a.grad is y.grad else y.grad)
+        b.accumulate(ops.copy(y.grad) if a.needs_grad and a.grad is y.grad else y.grad)
 
     tape.record(bwd)
     return y

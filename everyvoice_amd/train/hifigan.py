@@ -6,16 +6,29 @@ two optimisers, ``gan_type = "original"`` (LSGAN):
     D step:  loss_d = sum_i mean((1 - D_i(y))^2) + mean(D_i(y_hat.detach())^2)            -> AdamW(D)
     G step:  loss_g = sum_i mean((1 - D_i(y_hat))^2) + 2 * sum L1(fmaps) + 45 * L1(logmel(y), logmel(y_hat)) -> AdamW(G)
 
+``gan_type = "wgan"`` (critic losses mean D(y_hat) - mean D(y) / -mean D(y_hat), weight clipping to +-wgan_clip_value after
+the critic's optimiser step), ``generator_warmup_steps`` (the first steps train the generator on the reconstruction loss
+alone) and the optimiser union Adam / AdamW / RMSprop are the options the reference's training schema freezes
+(everyvoice/.schema/everyvoice-spec-to-wav-0.5.json:434-622); their arithmetic inside the absent submodule is restated from
+the published algorithms (parity unpinned, like the rest of the model code).
+
 Layer structure and state-dict names follow upstream (jik876 HiFi-GAN generator / MPD / MSD; the first MSD scale
 is spectral-normalised), see oracle/hifigan_ref.py for the pins.  All arithmetic runs in libevmi_hip kernels
 (fp32, channel-major activations); torch owns memory and, for data parallel training, the RCCL all-reduce of
 the two flat gradient buffers.
+
+Execution: the step makes no host round trip until its losses are read (spectral-norm scales, loss norms and the optimisers'
+step counters stay on the device).  The eight discriminators -- and the three MRF branches of every generator stage -- are
+independent chains of small kernels: each runs on its own HIP stream (fork / join around them, forward and backward), and with
+fixed segment shapes the whole step is captured once into a HIP graph and replayed (``use_graph``), so launch-bound layers of
+different discriminators overlap on the device instead of queueing behind each other.
 """
 
 from __future__ import annotations
 
 import torch
 
+from .. import _lib
 from ..config import ACTIVATION_SLOPES, HiFiGANConfig
 from ..spectral import slaney_mel_filterbank, windowed_dft_basis
 from . import autograd as ag
@@ -25,6 +38,63 @@ from .layers import ParamGroup, SNConv, WNBatch, WNConv, kaiming_uniform_conv_in
 
 def _to_cbt(x_bct: torch.Tensor) -> torch.Tensor:
     return x_bct.permute(1, 0, 2).contiguous()  # layout change only (memory plumbing)
+
+
+class Branches:
+    """Fork / join of independent chains onto side HIP streams.  ``run(fns)``: fn i runs on stream i (mod the pool), ordered
+    after everything already queued on the current stream; the current stream continues after all of them.  Work queued
+    this way is captured into a HIP graph like any other (the fork / join events become graph edges)."""
+
+    def __init__(self, device, n: int, enabled: bool = True):
+        self.device = torch.device(device)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(n)] if (enabled and self.device.type == "cuda") else []
+
+    def run(self, fns) -> None:
+        if not self.streams or len(fns) < 2:
+            for fn in fns:
+                fn()
+            return
+        main = torch.cuda.current_stream(self.device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        used = self.streams[: min(len(fns), len(self.streams))]
+        for st in used:
+            st.wait_event(fork)
+        for i, fn in enumerate(fns):
+            with torch.cuda.stream(used[i % len(used)]):
+                fn()
+        for st in used:
+            main.wait_stream(st)
+
+
+def parallel_section(tape: ag.Tape, branches: Branches, fns):
+    """fns[i](sub_tape) -> result.  Every fn records on its own tape and runs on its own stream; the recorded backward runs the
+    sub-tapes the same way.  Inputs shared between branches must enter them as separate leaf Vars (see ``fan_out``)."""
+    subs = [ag.Tape() for _ in fns]
+    results = [None] * len(fns)
+
+    def fwd(i):
+        def go():
+            results[i] = fns[i](subs[i])
+        return go
+
+    branches.run([fwd(i) for i in range(len(fns))])
+    tape.record(lambda: branches.run([sub.backward for sub in subs]))
+    return results
+
+
+def fan_out(tape: ag.Tape, x: ag.Var, n: int):
+    """n leaf Vars over x's data, one per parallel branch; their gradients are added into x (in branch order) after the
+    branches' backward has been joined.  Call BEFORE ``parallel_section`` (the tape runs in reverse)."""
+    leaves = [ag.Var(x.data, needs_grad=x.needs_grad) for _ in range(n)]
+
+    def gather():
+        for leaf in leaves:
+            if leaf.grad is not None:
+                x.accumulate(leaf.grad)
+
+    tape.record(gather)
+    return leaves
 
 
 class GeneratorT:
@@ -70,8 +140,20 @@ class GeneratorT:
                 out += [c1] if c2 is None else [c1, c2]
         return out
 
-    def forward(self, tape: ag.Tape, mel: ag.Var, bucket_hook=None) -> ag.Var:
-        """`bucket_hook(layers)` is called before the forward of each group of layers whose parameters form one gradient bucket."""
+    def _mrf_branch(self, tape: ag.Tape, y: ag.Var, i: int, j: int) -> ag.Var:
+        for c1, c2 in self.resblocks[i * self.num_kernels + j]:
+            t = ag.lrelu(tape, y, self.slope)
+            if c2 is None:
+                t = ag.conv1d(tape, t, c1)
+            else:
+                t = ag.conv1d_lrelu(tape, t, c1, self.slope)
+                t = ag.conv1d(tape, t, c2)
+            y = ag.add(tape, t, y)
+        return y
+
+    def forward(self, tape: ag.Tape, mel: ag.Var, bucket_hook=None, branches: Branches | None = None) -> ag.Var:
+        """`bucket_hook(layers)` is called before the forward of each group of layers whose parameters form one gradient bucket.
+        ``branches``: the MRF branches of a stage (kernel sizes 3 / 7 / 11: independent residual chains) run side by side."""
         hook = bucket_hook or (lambda layers: None)
         hook([self.conv_pre])
         x = ag.conv1d(tape, mel, self.conv_pre)
@@ -79,18 +161,14 @@ class GeneratorT:
             hook(self.stage_layers(i))
             x = ag.lrelu(tape, x, self.slope)
             x = ag.conv_transpose1d(tape, x, up)
-            xs = None
-            for j in range(self.num_kernels):
-                y = x
-                for c1, c2 in self.resblocks[i * self.num_kernels + j]:
-                    t = ag.lrelu(tape, y, self.slope)
-                    if c2 is None:
-                        t = ag.conv1d(tape, t, c1)
-                    else:
-                        t = ag.conv1d_lrelu(tape, t, c1, self.slope)
-                        t = ag.conv1d(tape, t, c2)
-                    y = ag.add(tape, t, y)
-                xs = y if xs is None else ag.add(tape, xs, y)
+            if branches is not None and branches.streams and self.num_kernels > 1:
+                leaves = fan_out(tape, x, self.num_kernels)
+                ys = parallel_section(tape, branches, [(lambda sub, j=j: self._mrf_branch(sub, leaves[j], i, j)) for j in range(self.num_kernels)])
+            else:
+                ys = [self._mrf_branch(tape, x, i, j) for j in range(self.num_kernels)]
+            xs = ys[0]
+            for y in ys[1:]:
+                xs = ag.add(tape, xs, y)
             x = ag.scale(tape, xs, 1.0 / self.num_kernels)
         hook([self.conv_post])
         x = ag.lrelu(tape, x, 0.01)
@@ -199,7 +277,7 @@ class MultiResolutionSTFTLoss:
     """Multi-resolution STFT loss (spectral convergence + log-magnitude L1, mean over the resolutions; Yamamoto et al. 2020) --
     the selectable alternative to the 45 x mel-L1 term that BASELINE.json's config 4 names.  Same GEMM
     formulation as MelLoss: frames -> windowed DFT (cos | sin) -> sqrt(re^2 + im^2 + eps).  The two Frobenius norms of the
-    spectral-convergence term are read back to the host (one sync per resolution)."""
+    spectral-convergence term stay on the device (the loss and its gradient kernels read them there)."""
 
     def __init__(self, device, resolutions=((1024, 120, 600), (2048, 240, 1200), (512, 50, 240)), eps=1e-7):
         self.eps, self.res = eps, []
@@ -226,14 +304,14 @@ class MultiResolutionSTFTLoss:
             my, _, _ = self._mag(y_bt, n_fft, hop, nb, cos, sin)
             mg, re, im = self._mag(yhat_bt, n_fft, hop, nb, cos, sin)
             n = mg.numel()
-            sq = torch.zeros(2, device=mg.device)
+            sq = torch.empty(2, device=mg.device)
             ops.scalar_reduce(1, ops.axpby(1.0, mg, -1.0, my), None, sq[0:1], p=0.0)   # ||mg - my||^2
             ops.scalar_reduce(1, my, None, sq[1:2], p=0.0)                              # ||my||^2
-            nd, ny = (float(v) ** 0.5 for v in sq.tolist())
-            loss_out += w * nd / ny
+            _lib.check(_lib.load().evmi_ratio_accumulate_f32(loss_out.data_ptr(), sq.data_ptr(), w, _lib.current_stream_ptr(mg.device)),
+                       "evmi_ratio_accumulate_f32")                                     # loss += w ||mg - my|| / ||my||
             ops.scalar_reduce(0, ops.elementwise(16, mg), ops.elementwise(16, my), loss_out, scale=w / n, accumulate=True)
             # d/dmg: spectral convergence (mg - my) / (||mg - my|| ||my||), log-magnitude sign(mg - my) / (n mg)
-            dmag = ops.elementwise(17, mg, my, p0=w / (nd * ny) if nd > 0 else 0.0, p1=w / n)
+            dmag = ops.elementwise(ops.EW_STFT_GRAD_DEV, mg, my, sq, p0=w, p1=w / n)
             dre = ops.elementwise(ops.EW_MUL_DIV, dmag, re, mg)
             dim = ops.elementwise(ops.EW_MUL_DIV, dmag, im, mg)
             dfr = torch.empty(n_fft, dre.shape[1], device=dre.device)
@@ -292,18 +370,27 @@ class BucketReducer:
 
 
 class HiFiGANTrainer:
-    """Generator + MPD + MSD with two AdamW optimisers; ``training_step`` is one full GAN step."""
+    """Generator + MPD + MSD with two optimisers; ``training_step`` is one full GAN step."""
+
+    LOSS_KEYS = ("d", "g_adv", "g_fm", "g_mel", "g_stft")
 
     def __init__(self, config: HiFiGANConfig | None = None, device="cuda:0", lr=2e-4, betas=(0.8, 0.99), eps=1e-8,
                  weight_decay=0.01, seed=1234, process_group=None, reconstruction_loss="mel", stft_loss_weight=45.0,
-                 precision="f32"):
+                 precision="f32", optimizer="adamw", alpha=0.99, gan_type="original", wgan_clip_value=0.01,
+                 generator_warmup_steps=0, use_graph=False, parallel_streams=True):
         if precision not in ("f32", "bf16"):
             raise ValueError("precision: 'f32' (exact fp32 arithmetic) or 'bf16' (bf16 convolution operands, fp32 accumulation, "
                              "fp32 master weights and activations: the mixed-precision counterpart of Lightning's bf16-mixed)")
+        if optimizer not in ParamGroup.OPTIMIZERS:
+            raise ValueError(f"optimizer: one of {sorted(ParamGroup.OPTIMIZERS)} (AdamOptimizer / AdamWOptimizer / RMSOptimizer of the reference's config)")
+        if gan_type not in ("original", "wgan"):
+            raise ValueError("gan_type: 'original' (least-squares GAN, the default) or 'wgan'")
         self.precision = precision
         self.config = config or HiFiGANConfig()
         self.device = torch.device(device)
         self.opt = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.optimizer, self.alpha = optimizer, alpha
+        self.gan_type, self.wgan_clip_value, self.generator_warmup_steps = gan_type, float(wgan_clip_value), int(generator_warmup_steps)
         self.pg = process_group
         self.g_params, self.d_params = ParamGroup(self.device), ParamGroup(self.device)
         self.generator = GeneratorT(self.config, self.g_params)
@@ -329,10 +416,21 @@ class HiFiGANTrainer:
         self.global_step = 0
         self.keep_grads = False  # tests: keep copies of both gradient buffers of the last step
         self.last_grads = {}
+        # one stream per discriminator (the MRF branches of the generator reuse the first few)
+        self.branches = Branches(self.device, len(self.mpd) + len(self.msd), enabled=parallel_streams)
+        n_d = len(self.mpd) + len(self.msd)
+        self._loss_buf = torch.zeros(len(self.LOSS_KEYS), device=self.device)      # d, g_adv, g_fm, g_mel, g_stft
+        self._slots = torch.zeros(3, n_d, device=self.device)                      # per-discriminator partial d / g_adv / g_fm
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self._graphs, self._graph_warm = {}, {}
+        self._graph_failed = None
 
     # -- state ------------------------------------------------------------------------------------------
     def d_layers(self):
         return [layer for d in [*self.mpd, *self.msd] for layer in d.layers()]
+
+    def discriminators(self):
+        return [*self.mpd, *self.msd]
 
     def load_reference_state(self, gen_sd=None, mpd_sd=None, msd_sd=None):
         """Load upstream-named state dicts (weight_g / weight_v / weight_orig / bias, SN buffers weight_u / weight_v)."""
@@ -361,7 +459,8 @@ class HiFiGANTrainer:
 
     def state_dict(self) -> dict:
         """Reference layout of the ``HiFiGAN`` LightningModule: ``generator.*``, ``mpd.*``, ``msd.*`` with the upstream
-        parameter names (weight_g / weight_v, and weight_orig + weight_u / weight_v buffers of the spectral-norm scale)."""
+        parameter names AND shapes (weight_g / weight_v, Conv2d((k, 1)) tensors for the period discriminators, and
+        weight_orig + weight_u / weight_v buffers of the spectral-norm scale)."""
         sd = {"generator." + k: v.cpu() for k, v in self.g_params.state_dict().items()}
         sd.update({k: v.cpu() for k, v in self.d_params.state_dict().items()})
         for layer in self.d_layers():
@@ -378,7 +477,8 @@ class HiFiGANTrainer:
             "hyper_parameters": {"config": self.config.model_dump(mode="json")},
             "model_info": {"name": "HiFiGAN", "version": self._VERSION},
             "optimizer_states": [
-                {"evmi_flat_adamw": {"group": name, "step": grp.step, "exp_avg": grp.m.cpu(), "exp_avg_sq": grp.v.cpu(), **self.opt}}
+                {"evmi_flat_adamw": {"group": name, "step": grp.step, "exp_avg": grp.m.cpu(), "exp_avg_sq": grp.v.cpu(),
+                                     "optimizer": self.optimizer, "alpha": self.alpha, **self.opt}}
                 for name, grp in (("generator", self.g_params), ("discriminators", self.d_params))],
         }
 
@@ -405,7 +505,7 @@ class HiFiGANTrainer:
                 grp = self.g_params if st["group"] == "generator" else self.d_params
                 grp.m.copy_(st["exp_avg"].to(self.device))
                 grp.v.copy_(st["exp_avg_sq"].to(self.device))
-                grp.step = int(st["step"])
+                grp.set_step(int(st["step"]))
         return self
 
     def export_generator_checkpoint(self) -> dict:
@@ -434,10 +534,17 @@ class HiFiGANTrainer:
                              lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
 
     @staticmethod
-    def _bucket_hook(tape, group: ParamGroup, layers, reducer, state):
-        """Record, BEFORE the forward of `layers`, the closure that backward runs AFTER all of their gradient closures:
-        turn the effective-weight gradients into parameter gradients and hand the now-final slice of the flat buffer to the
-        reducer.  `state["hi"]` is the start of the suffix already handed over."""
+    def _bucket_range(group: ParamGroup, layers):
+        """[lo, hi) of the flat buffers that the parameters of `layers` (a contiguous run in declaration order) occupy."""
+        names = [n for layer in layers for n in layer.param_names()]
+        lo = min(group.offset_of(n) for n in names)
+        hi = max(group.offset_of(n) + (group.gradient(group._index[n]).numel() + 3) // 4 * 4 for n in names)
+        return lo, hi
+
+    def _bucket_hook(self, tape, group: ParamGroup, layers, reducer):
+        """Record, BEFORE the forward of `layers`, the closure that backward runs AFTER all of their gradient closures: turn
+        the effective-weight gradients into parameter gradients and hand the now-final slice of the flat gradient buffer to the
+        reducer (on whatever stream this bucket's backward ran on)."""
         def done():
             batches = {}
             for layer in layers:
@@ -449,142 +556,315 @@ class HiFiGANTrainer:
             for b, ls in batches.values():
                 b.finish(ls)
             if reducer is not None:
-                lo = min(group.offset_of(n) for layer in layers for n in layer.param_names())
-                reducer.launch(lo, state["hi"])
-                state["hi"] = lo
+                reducer.launch(*self._bucket_range(group, layers))
         tape.record(done)
 
-    # -- discriminators on one waveform ----------------------------------------------------------------------
-    def _discriminate(self, tape, audio: ag.Var, training=True):
-        logits, fmaps = [], []
-        for d in self.mpd:
-            o, f = d.forward(tape, audio, training)
-            logits.append(o)
-            fmaps.append(f)
-        x = audio
-        for i, d in enumerate(self.msd):
-            if i > 0:
-                x = ag.avgpool4s2(tape, x)
-            o, f = d.forward(tape, x, training)
-            logits.append(o)
-            fmaps.append(f)
-        return logits, fmaps
+    # -- discriminators --------------------------------------------------------------------------------------
+    def _scale_inputs(self, tape, audio: ag.Var):
+        """Inputs of the scale discriminators: the waveform and its AvgPool1d(4, 2, 2) pyramid."""
+        xs = [audio]
+        for _ in self.msd[1:]:
+            xs.append(ag.avgpool4s2(tape, xs[-1]))
+        return xs
 
-    def _discriminate_pair(self, tape, y: torch.Tensor, y_hat: torch.Tensor, reducer=None, state=None):
-        """Discriminator step: real and generated waveforms as ONE batch of 2B items (columns of the same GEMMs), so
-        every convolution, its input gradient and its weight gradient run once over twice the columns.  The
-        spectral-norm scale discriminator keeps the reference's two forward calls: each call runs its own power
-        iteration and sees its own sigma.  Returns [(logits Var, "pair" | "real" | "fake")]."""
-        pair = ag.Var(torch.cat([y, y_hat], dim=1), needs_grad=False)
-        outs = []
-        for d in self.mpd:
-            self._bucket_hook(tape, self.d_params, d.layers(), reducer, state)
-            outs.append((d.forward(tape, pair)[0], "pair"))
-        x = pair
-        for i, d in enumerate(self.msd):
-            if i > 0:
-                x = ag.avgpool4s2(tape, x)
-            self._bucket_hook(tape, self.d_params, d.layers(), reducer, state)
-            if any(isinstance(layer, SNConv) for layer in d.layers()):
-                outs.append((d.forward(tape, ag.Var(y, needs_grad=False))[0], "real"))
-                outs.append((d.forward(tape, ag.Var(y_hat, needs_grad=False))[0], "fake"))
+    def _discriminate(self, tape, audio: ag.Var, training=True):
+        """All eight discriminators on one waveform, side by side on their streams -> (logits, feature maps)."""
+        xs = self._scale_inputs(tape, audio)
+        mpd_in = fan_out(tape, audio, len(self.mpd) + 1)  # + the first scale, which also reads the waveform itself
+        ins = [*mpd_in[: len(self.mpd)], mpd_in[-1], *[fan_out(tape, x, 1)[0] for x in xs[1:]]]
+        ds = self.discriminators()
+        outs = parallel_section(tape, self.branches, [(lambda sub, i=i: ds[i].forward(sub, ins[i], training)) for i in range(len(ds))])
+        return [o for o, _ in outs], [f for _, f in outs]
+
+    def _logit_loss(self, logits, grad, target_real: bool, n: int, slot, sign=1.0):
+        """One term of an adversarial loss on a logits tensor: accumulates the value into `slot`, writes d loss / d logits.
+        original: mean((logit - target)^2), target 1 (real) or 0 (generated).  wgan: -/+ mean(logit)."""
+        if self.gan_type == "wgan":
+            sc = (-1.0 if target_real else 1.0) * sign / n
+            ops.scalar_reduce(2, logits, None, slot, scale=sc, accumulate=True)
+            ops.elementwise(ops.EW_FILL, logits, out=grad, p0=sc)
+        else:
+            tgt = 1.0 if target_real else 0.0
+            ops.scalar_reduce(1, logits, None, slot, scale=1.0 / n, p=tgt, accumulate=True)
+            ops.elementwise(ops.EW_SQ_GRAD, logits, out=grad, p0=1.0 / n, p1=tgt)
+
+    def _d_branch(self, tape, i: int, d, pair: ag.Var, y: torch.Tensor, y_hat: torch.Tensor, reducer):
+        """Discriminator step of one discriminator: forward on real + generated, its loss terms (into slot i), backward later.
+        Real and generated waveforms run as ONE batch of 2B items (columns of the same GEMMs); the spectral-norm scale keeps
+        the reference's two forward calls: each call runs its own power iteration and sees its own sigma."""
+        self._bucket_hook(tape, self.d_params, d.layers(), reducer)
+        slot = self._slots[0, i : i + 1]
+        if any(isinstance(layer, SNConv) for layer in d.layers()):
+            outs = [(d.forward(tape, ag.Var(y, needs_grad=False))[0], "real"), (d.forward(tape, ag.Var(y_hat, needs_grad=False))[0], "fake")]
+        else:
+            outs = [(d.forward(tape, pair)[0], "pair")]
+        for o, kind in outs:
+            o.grad = torch.empty_like(o.data)
+            if kind == "pair":  # real items first, generated items second along the batch axis ((item, column) for the period view)
+                n, h = o.data.numel() // 2, o.data.shape[1] // 2
+                self._logit_loss(o.data[:, :h], o.grad[:, :h], True, n, slot)
+                self._logit_loss(o.data[:, h:], o.grad[:, h:], False, n, slot)
             else:
-                outs.append((d.forward(tape, x)[0], "pair"))
-        return outs
+                self._logit_loss(o.data, o.grad, kind == "real", o.data.numel(), slot)
+
+    def _g_branch(self, tape, i: int, d, x_real: ag.Var, x_fake: ag.Var, adversarial: bool):
+        """Generator step through one (frozen) discriminator: feature maps of the real waveform, logits + feature maps of the
+        generated one, adversarial and feature-matching terms (into slots i) with their gradients."""
+        _, fr_list = d.forward(tape, x_real)
+        dg, fg_list = d.forward(tape, x_fake)
+        if not adversarial:
+            return
+        n = dg.data.numel()
+        dg.grad = torch.empty_like(dg.data)
+        # original: mean((1 - D(y_hat))^2); wgan: -mean(D(y_hat))  (= the "real" form of the critic term)
+        self._logit_loss(dg.data, dg.grad, True, n, self._slots[1, i : i + 1])
+        for fr, fg in zip(fr_list, fg_list):
+            n = fg.data.numel()
+            ops.scalar_reduce(0, fg.data, fr.data, self._slots[2, i : i + 1], scale=2.0 / n, accumulate=True)
+            fg.accumulate(ops.elementwise(ops.EW_SIGN_DIFF, fg.data, fr.data, p0=2.0 / n))
 
     # -- one GAN step -----------------------------------------------------------------------------------------
-    def training_step(self, mel_bct: torch.Tensor, audio_bct: torch.Tensor) -> dict:
-        """mel [B, n_mels, T/hop], audio [B, 1, T] on the device.  Returns the scalar losses (python floats)."""
+    def training_step(self, mel_bct: torch.Tensor, audio_bct: torch.Tensor, sync: bool = True):
+        """mel [B, n_mels, T/hop], audio [B, 1, T] on the device.  Returns the scalar losses: python floats (ONE device-to-host
+        read at the end of the step), or with ``sync=False`` a device tensor in LOSS_KEYS order (no host synchronisation)."""
         prev = ops.CONV_BACKEND["operands"]
         ops.CONV_BACKEND["operands"] = self.precision
         try:
-            return self._training_step(mel_bct, audio_bct)
+            if self.use_graph and self._graph_failed is None:
+                buf = self._graph_step(mel_bct, audio_bct)
+            else:
+                buf = self._eager_step(mel_bct, audio_bct)
         finally:
             ops.CONV_BACKEND["operands"] = prev
+        self.global_step += 1
+        if not sync:
+            return buf
+        vals = buf.tolist()
+        out = dict(zip(self.LOSS_KEYS, vals))
+        out["g_total"] = out["g_adv"] + out["g_fm"] + out["g_mel"] + out["g_stft"]
+        return out
 
-    def _training_step(self, mel_bct: torch.Tensor, audio_bct: torch.Tensor) -> dict:
-        dev = self.device
+    def _opt_kw(self):
+        return dict(name=self.optimizer, alpha=self.alpha, **self.opt)
+
+    def _eager_step(self, mel_bct, audio_bct):
+        warm = self.global_step < self.generator_warmup_steps
+        ctx = self._phase_generator_forward(mel_bct, audio_bct)
+        if not warm:
+            d_red = self._reducer(self.d_params)
+            self._phase_d_backward(ctx, d_red)
+            if d_red is not None:
+                d_red.launch(0, min(self.d_params.offset_of(n) for n in self.d_params.names()))  # alignment padding in front, if any
+                d_red.finish()
+            self._phase_d_update(ctx)
+        g_red = self._reducer(self.g_params)
+        ctx["g_reducer"][0] = g_red
+        self._phase_g_backward(ctx, adversarial=not warm)
+        if g_red is not None:
+            g_red.launch(0, min(self.g_params.offset_of(n) for n in self.g_params.names()))
+            g_red.finish()
+        self._phase_g_update(ctx)
+        return self._loss_buf
+
+    # ---- the phases of a step (each one a stretch without communication: what a HIP graph captures) ----
+    def _phase_generator_forward(self, mel_bct, audio_bct):
         B = audio_bct.shape[0]
-        y = audio_bct.to(torch.float32).reshape(1, B, -1).contiguous()  # [B,1,T] and [1,B,T] are the same bytes
-        mel = _to_cbt(mel_bct.to(torch.float32))
+        y = audio_bct.to(torch.float32).reshape(1, B, -1)  # [B,1,T] and [1,B,T] are the same bytes
+        if not y.is_contiguous():
+            y = ops.copy(y.contiguous())
+        mel = _to_cbt_kernel(mel_bct.to(torch.float32))  # [B, C, T] -> [C, B, T]: layout change only
+        ops.fill_(self._loss_buf, 0.0)
+        ops.fill_(self._slots, 0.0)
         g_layers, d_layers = self.generator.layers(), self.d_layers()
         self._materialize(g_layers)
         self._materialize(d_layers)
-        losses = {k: torch.zeros(1, device=dev) for k in ("d", "g_adv", "g_fm", "g_mel", "g_stft")}
-
-        # ---- generator forward (tape kept for the generator step) ----
         g_tape = ag.Tape()
-        g_reducer, g_state = self._reducer(self.g_params), {"hi": self.g_params.grad.numel()}
-        y_hat = self.generator.forward(g_tape, ag.Var(mel, needs_grad=False),
-                                       lambda layers: self._bucket_hook(g_tape, self.g_params, layers, g_reducer, g_state))
+        g_reducer = [None]  # filled in before the generator's backward (the reducer object is created per phase)
+        y_hat = self.generator.forward(
+            g_tape, ag.Var(mel, needs_grad=False),
+            lambda layers: self._bucket_hook_late(g_tape, self.g_params, layers, g_reducer), branches=self.branches)
+        return dict(B=B, y=y, y_hat=y_hat, g_tape=g_tape, g_reducer=g_reducer, d_layers=d_layers)
 
-        # ---- discriminator step ----
+    def _bucket_hook_late(self, tape, group, layers, reducer_box):
+        """As `_bucket_hook`, with the reducer looked up when backward runs (the generator's tape is recorded long before it)."""
+        def done():
+            batches = {}
+            for layer in layers:
+                b = getattr(layer, "_batch", None)
+                if b is None:
+                    layer.finish_grads()
+                else:
+                    batches.setdefault(id(b), (b, []))[1].append(layer)
+            for b, ls in batches.values():
+                b.finish(ls)
+            if reducer_box[0] is not None:
+                reducer_box[0].launch(*self._bucket_range(group, layers))
+        tape.record(done)
+
+    def _phase_d_backward(self, ctx, reducer):
+        """Discriminator step up to its gradients: the eight discriminators side by side."""
+        y, y_hat, B = ctx["y"], ctx["y_hat"], ctx["B"]
         self.d_params.zero_grad()
-        for layer in d_layers:
+        for layer in ctx["d_layers"]:
             layer.frozen = False
+        T = y.shape[-1]
+        pair_t = torch.empty(1, 2 * B, T, device=self.device, dtype=torch.float32)
+        ops.copy(y, out=pair_t[:, :B])
+        ops.copy(y_hat.data, out=pair_t[:, B:])  # y_hat.detach()
         d_tape = ag.Tape()
-        d_reducer, d_state = self._reducer(self.d_params), {"hi": self.d_params.grad.numel()}
-        for o, kind in self._discriminate_pair(d_tape, y, y_hat.data, d_reducer, d_state):  # y_hat.detach()
-            if kind == "pair":  # real items first, generated items second along the batch axis
-                n, h = o.data.numel() // 2, o.data.shape[1] // 2  # period discriminators: the batch axis is (item, column)
-                o.grad = torch.empty_like(o.data)
-                parts = ((o.data[:, :h], o.grad[:, :h], 1.0), (o.data[:, h:], o.grad[:, h:], 0.0))
-            else:
-                n = o.data.numel()
-                o.grad = torch.empty_like(o.data)
-                parts = ((o.data, o.grad, 1.0 if kind == "real" else 0.0),)
-            for logits, grad, target in parts:
-                ops.scalar_reduce(1, logits, None, losses["d"], scale=1.0 / n, p=target, accumulate=True)
-                ops.elementwise(ops.EW_SQ_GRAD, logits, out=grad, p0=1.0 / n, p1=target)
-        d_tape.backward()  # every discriminator's bucket is finished (and its all-reduce launched) as backward leaves it
-        if d_reducer is not None:
-            d_reducer.launch(0, d_state["hi"])  # alignment padding in front of the first parameter, if any
-            d_reducer.finish()
+        pair = ag.Var(pair_t, needs_grad=False)
+        pairs = [pair]
+        for _ in self.msd[1:]:
+            pairs.append(ag.avgpool4s2(d_tape, pairs[-1]))
+        ds = self.discriminators()
+        ins = [pair] * len(self.mpd) + pairs
+
+        def branch(i):
+            return lambda sub: self._d_branch(sub, i, ds[i], ins[i], y, y_hat.data, reducer)
+
+        parallel_section(d_tape, self.branches, [branch(i) for i in range(len(ds))])
+        d_tape.backward()  # every discriminator's bucket is finished (and its all-reduce launched) as its stream leaves it
+        ops.scalar_reduce(2, self._slots[0], None, self._loss_buf[0:1])
         if self.keep_grads:
             self.last_grads["d"] = {k: v.clone() for k, v in self.d_params.gradients().items()}
-        self.d_params.adamw(**self.opt)
-        self._materialize(d_layers)  # the generator step sees the updated discriminators
 
-        # ---- generator step ----
+    def _phase_d_update(self, ctx):
+        self.d_params.optimizer_step(clip=self.wgan_clip_value if self.gan_type == "wgan" else 0.0, **self._opt_kw())
+        self._materialize(ctx["d_layers"])  # the generator step sees the updated discriminators
+
+    def _phase_g_backward(self, ctx, adversarial=True):
+        y, y_hat, B = ctx["y"], ctx["y_hat"], ctx["B"]
         self.g_params.zero_grad()
-        for layer in d_layers:
+        for layer in ctx["d_layers"]:
             layer.frozen = True  # gradients flow through the discriminators to y_hat only
-        gd_tape = ag.Tape()
         y_hat_in = ag.Var(y_hat.data)  # boundary between the discriminator tape and the generator tape
-        _, fmaps_r = self._discriminate(gd_tape, ag.Var(y, needs_grad=False))
-        fake_logits, fmaps_g = self._discriminate(gd_tape, y_hat_in)
-        for dg in fake_logits:
-            n = dg.data.numel()
-            ops.scalar_reduce(1, dg.data, None, losses["g_adv"], scale=1.0 / n, p=1.0, accumulate=True)
-            dg.grad = ops.elementwise(ops.EW_SQ_GRAD, dg.data, p0=1.0 / n, p1=1.0)
-        for fr_list, fg_list in zip(fmaps_r, fmaps_g):
-            for fr, fg in zip(fr_list, fg_list):
-                n = fg.data.numel()
-                ops.scalar_reduce(0, fg.data, fr.data, losses["g_fm"], scale=2.0 / n, accumulate=True)
-                fg.accumulate(ops.elementwise(ops.EW_SIGN_DIFF, fg.data, fr.data, p0=2.0 / n))
-        gd_tape.backward()
-        for layer in d_layers:
-            if isinstance(layer, SNConv):
-                layer._calls.clear()  # frozen: no parameter gradients from this pass
+        if adversarial:
+            gd_tape = ag.Tape()
+            real = ag.Var(y, needs_grad=False)
+            xs_r = self._scale_inputs(gd_tape, real)
+            xs_f = self._scale_inputs(gd_tape, y_hat_in)
+            n_p = len(self.mpd)
+            fake_leaves = fan_out(gd_tape, y_hat_in, n_p + 1)
+            ins_r = [real] * (n_p + 1) + xs_r[1:]
+            ins_f = [*fake_leaves[:n_p], fake_leaves[-1], *[fan_out(gd_tape, x, 1)[0] for x in xs_f[1:]]]
+            ds = self.discriminators()
+
+            def branch(i):
+                return lambda sub: self._g_branch(sub, i, ds[i], ins_r[i], ins_f[i], True)
+
+            parallel_section(gd_tape, self.branches, [branch(i) for i in range(len(ds))])
+            gd_tape.backward()
+            ops.scalar_reduce(2, self._slots[1], None, self._loss_buf[1:2])
+            ops.scalar_reduce(2, self._slots[2], None, self._loss_buf[2:3])
+            for layer in ctx["d_layers"]:
+                if isinstance(layer, SNConv):
+                    layer._calls.clear()  # frozen: no parameter gradients from this pass
+        total = None
         if "mel" in self.reconstruction_loss.split("+"):
-            total = self.mel_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), 45.0, losses["g_mel"]).view(1, B, -1)
-        else:
-            total = torch.zeros(1, B, y.shape[-1], device=dev)
+            total = self.mel_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), 45.0, self._loss_buf[3:4]).view(1, B, -1)
         if self.stft_loss is not None:
-            d_stft = self.stft_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), self.stft_loss_weight, losses["g_stft"])
-            total = ops.axpby(1.0, total, 1.0, d_stft.view(1, B, -1))
+            d_stft = self.stft_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), self.stft_loss_weight, self._loss_buf[4:5]).view(1, B, -1)
+            total = d_stft if total is None else ops.axpby(1.0, total, 1.0, d_stft, out=total)
         if y_hat_in.grad is not None:
-            total = ops.axpby(1.0, total, 1.0, y_hat_in.grad)
+            total = ops.axpby(1.0, total, 1.0, y_hat_in.grad, out=total)
         y_hat.grad = total
-        g_tape.backward()  # buckets: conv_post, the four upsampling stages, conv_pre
-        if g_reducer is not None:
-            g_reducer.launch(0, g_state["hi"])
-            g_reducer.finish()
+        ctx["g_tape"].backward()  # buckets: conv_post, the upsampling stages, conv_pre
         if self.keep_grads:
             self.last_grads["g"] = {k: v.clone() for k, v in self.g_params.gradients().items()}
             self.last_grads["y_hat"] = y_hat.data.clone()
-        self.g_params.adamw(**self.opt)
-        self.global_step += 1
-        out = {k: float(v.item()) for k, v in losses.items()}
-        out["g_total"] = out["g_adv"] + out["g_fm"] + out["g_mel"] + out["g_stft"]
+
+    def _phase_g_update(self, ctx):
+        self.g_params.optimizer_step(**self._opt_kw())
+
+    # ---- HIP-graph execution of the step ----------------------------------------------------------------------------
+    GRAPH_WARMUP_STEPS = 2
+
+    def _graph_step(self, mel_bct, audio_bct):
+        """Fixed-shape steps (vocoder segments are: batch x vocoder_segment_size) run as HIP graph replays: the first steps at a
+        shape run eagerly (workspaces grow, kernel attributes are set), the next one is captured -- on one GPU as ONE graph,
+        under data parallelism as three (up to the discriminators' gradients | their update and the generator's backward | the
+        generator's update) with the two gradient all-reduces issued between them -- and every later step replays.
+        Any failure while capturing falls back to eager execution for good (``_graph_failed`` holds the reason)."""
+        warm = self.global_step < self.generator_warmup_steps
+        key = (tuple(mel_bct.shape), tuple(audio_bct.shape), self.precision, warm, self.keep_grads)
+        entry = self._graphs.get(key)
+        if entry is None:
+            n = self._graph_warm.get(key, 0)
+            if n < self.GRAPH_WARMUP_STEPS or self.keep_grads:
+                self._graph_warm[key] = n + 1
+                return self._eager_step(mel_bct, audio_bct)
+            try:
+                entry = self._capture(key, mel_bct, audio_bct, warm)
+            except Exception as e:  # noqa: BLE001 -- whatever the runtime objected to: the eager path is always available
+                self._graph_failed = f"{type(e).__name__}: {e}"
+                torch.cuda.synchronize(self.device)
+                return self._eager_step(mel_bct, audio_bct)
+            self._graphs[key] = entry
+        ops.copy(mel_bct.to(torch.float32).contiguous(), out=entry["mel"])
+        ops.copy(audio_bct.to(torch.float32).contiguous(), out=entry["audio"])
+        graphs = entry["graphs"]
+        graphs[0].replay()
+        if len(graphs) > 1:
+            self._allreduce_whole(self.d_params)
+            graphs[1].replay()
+            self._allreduce_whole(self.g_params)
+            graphs[2].replay()
+        # the host-side step counters follow the device-side ones the graph increments
+        if not warm:
+            self.d_params.step += 1
+        self.g_params.step += 1
+        return self._loss_buf
+
+    def _allreduce_whole(self, group: ParamGroup):
+        if self.pg is not None:
+            allreduce_mean_(group.grad, self.pg if self.pg is not True else None, lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
+
+    def _capture(self, key, mel_bct, audio_bct, warm):
+        mel_s = mel_bct.to(torch.float32).contiguous().clone()
+        audio_s = audio_bct.to(torch.float32).contiguous().clone()
+        steps = (self.g_params.step, self.d_params.step)
+        torch.cuda.synchronize(self.device)
+        pool = torch.cuda.graph_pool_handle()
+        graphs = []
+        ctx = {}
+
+        def cap(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                fn()
+            graphs.append(g)
+
+        def part_a():
+            ctx.update(self._phase_generator_forward(mel_s, audio_s))
+            if not warm:
+                self._phase_d_backward(ctx, None)
+
+        def part_b():
+            if not warm:
+                self._phase_d_update(ctx)
+            self._phase_g_backward(ctx, adversarial=not warm)
+
+        def part_c():
+            self._phase_g_update(ctx)
+
+        if self.pg is None:
+            cap(lambda: (part_a(), part_b(), part_c()))
+        else:
+            cap(part_a)
+            cap(part_b)
+            cap(part_c)
+        ctx.clear()
+        # capturing does not execute: the host-side counters the phases bumped are put back (replay bumps them again)
+        self.g_params.step, self.d_params.step = steps
+        return dict(graphs=graphs, mel=mel_s, audio=audio_s)
+
+
+def _to_cbt_kernel(x_bct: torch.Tensor) -> torch.Tensor:
+    """[B, C, T] -> [C, B, T] with library copy kernels (one strided row-block copy per item: layout change only)."""
+    B, C, T = x_bct.shape
+    out = torch.empty(C, B, T, device=x_bct.device, dtype=torch.float32)
+    if x_bct.is_cuda:
+        _lib.check(_lib.load().evmi_transpose_bct_cbt_f32(x_bct.contiguous().data_ptr(), out.data_ptr(), B, C, T, _lib.current_stream_ptr(x_bct.device)),
+                   "evmi_transpose_bct_cbt_f32")
         return out
+    return x_bct.permute(1, 0, 2).contiguous()

@@ -41,6 +41,7 @@ class ParamGroup:
         self.grad = torch.zeros_like(self.flat)
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
+        self.step_dev = torch.zeros(1, device=self.device, dtype=torch.int32)  # the step counter the optimiser kernel reads
         self._index = {name: i for i, (name, _, _) in enumerate(self._specs)}
 
     def _view(self, buf, i):
@@ -74,11 +75,32 @@ class ParamGroup:
         self._view(self.flat, self._index[name]).copy_(value.to(self.device, torch.float32).reshape(self._specs[self._index[name]][1]))
 
     def zero_grad(self):
-        self.grad.zero_()
+        ops.fill_(self.grad, 0.0)
+
+    def set_step(self, step: int):
+        self.step = int(step)
+        self.step_dev.fill_(self.step)
+
+    OPTIMIZERS = {"adamw": 0, "adam": 1, "rms": 2}
+
+    def optimizer_step(self, name="adamw", lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, alpha=0.99, clip=0.0):
+        """One step of the configured optimiser (the reference's union: AdamOptimizer / AdamWOptimizer / RMSOptimizer,
+        everyvoice/.schema/everyvoice-spec-to-wav-0.5.json:434-622) over the flat buffer; ``clip`` > 0 clamps the updated
+        parameters (WGAN).  The step number lives on the device, so a captured HIP graph of the step replays correctly."""
+        from .. import _lib
+
+        kind = self.OPTIMIZERS[name]
+        self.step += 1
+        lib = _lib.load()
+        st = _lib.current_stream_ptr(self.flat.device)
+        _lib.check(lib.evmi_counter_add_i32(self.step_dev.data_ptr(), 1, st), "evmi_counter_add_i32")
+        b1, b2 = (alpha, 0.0) if kind == 2 else betas
+        _lib.check(lib.evmi_optimizer_step_f32(kind, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                               self.flat.numel(), lr, b1, b2, eps, weight_decay, self.step, self.step_dev.data_ptr(),
+                                               float(clip), st), "evmi_optimizer_step_f32")
 
     def adamw(self, lr, betas, eps, weight_decay):
-        self.step += 1
-        ops.adamw_step(self.flat, self.grad, self.m, self.v, lr, betas, eps, weight_decay, self.step)
+        self.optimizer_step("adamw", lr, betas, eps, weight_decay)
 
 
 class _ConvBase:
@@ -108,7 +130,7 @@ class _ConvBase:
         """Gradient wrt the EFFECTIVE weight accumulates here during backward; ``finish_grads`` maps it to the
         stored parameters (g, v) or weight_orig."""
         if self._dw is None:
-            self._dw = torch.zeros(self.wshape, device=self.group.device, dtype=torch.float32)
+            self._dw = ops.zeros(*self.wshape, device=self.group.device)
         return self._dw
 
 
@@ -137,7 +159,7 @@ class WNConv(_ConvBase):
             return
         ops.weight_norm_bwd(self.group.data(self.i_g), self.group.data(self.i_v), self._norm, self._dw,
                             self.group.gradient(self.i_g), self.group.gradient(self.i_v))
-        self._dw.zero_()
+        ops.fill_(self._dw, 0.0)
 
 
 class WNBatch:
@@ -225,28 +247,28 @@ class SNConv(_ConvBase):
             tmp_u = torch.empty(h, device=W.device)
             ops.gemm(Wm, self.v.view(wdt, 1), tmp_u.view(h, 1))            # W v
             ops.normalize_vec(tmp_u, self.u)
-        u, v = self.u.clone(), self.v.clone()
+        u, v = ops.copy(self.u), ops.copy(self.v)
         wv = torch.empty(h, device=W.device)
         ops.gemm(Wm, v.view(wdt, 1), wv.view(h, 1))
-        sigma_t = torch.empty(1, device=W.device)
-        ops.row_reduce(1, u, wv, sigma_t, 1, h)                            # sigma = u . (W v)
-        sigma = float(sigma_t.item())
-        w = ops.elementwise(ops.EW_SCALE, W, p0=1.0 / sigma)
-        dw = torch.zeros(self.wshape, device=W.device)
+        sigma = torch.empty(1, device=W.device)
+        ops.row_reduce(1, u, wv, sigma, 1, h)                              # sigma = u . (W v), left on the device
+        w = ops.elementwise(ops.EW_DIV_SCALAR, W, c=sigma)
+        dw = ops.zeros(*self.wshape, device=W.device)
         self._calls.append((sigma, u, v, dw))
         return w, dw
 
     def finish_grads(self):
+        from .. import _lib
+
         W = self.group.data(self.i_w)
         gW = self.group.gradient(self.i_w)
         h, wdt = self.wshape[0], math.prod(self.wshape[1:])
         for sigma, u, v, dw in self._calls:
-            # d weight_orig += dw / sigma - (<dw, W> / sigma^2) u v^T
+            # d weight_orig += dw / sigma - (<dw, W> / sigma^2) u v^T   (sigma and the inner product stay on the device)
             dot = torch.empty(1, device=W.device)
             ops.scalar_reduce(2, ops.elementwise(ops.EW_MUL, dw, W), None, dot)
-            coef = -float(dot.item()) / (sigma * sigma)
-            ops.axpby(1.0, gW, 1.0 / sigma, dw, out=gW)
-            ops.gemm(u.view(h, 1), v.view(1, wdt), gW.view(h, wdt), alpha=coef, beta=1.0)
+            _lib.check(_lib.load().evmi_spectral_norm_grad_f32(gW.data_ptr(), dw.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(),
+                                                               dot.data_ptr(), h, wdt, _lib.current_stream_ptr(W.device)), "evmi_spectral_norm_grad_f32")
         self._calls.clear()
 
 

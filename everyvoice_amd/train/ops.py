@@ -1,7 +1,7 @@
 """Training-time operators on libevmi_hip (fp32, channel-major "CBT" activations [C, B, T]).
 
 Thin host wrappers: torch allocates device memory and provides the stream, every arithmetic step is a
-libevmi_hip call (unfold / fold / activation / loss / norm kernels, rocBLAS sgemm for the plain GEMMs).
+libevmi_hip call (convolution / unfold / fold / activation / loss / norm kernels, the library's own fp32 GEMM for plain products).
 Forward functions return what their backward needs; nothing here uses torch autograd or torch math.
 """
 
@@ -25,16 +25,21 @@ def _chk(rc: int, what: str) -> None:
 
 
 class Workspace:
-    """Grow-only scratch buffers keyed by role (unfold matrices are large and short-lived)."""
+    """Grow-only scratch buffers keyed by (role, stream): launches on different HIP streams may overlap on the device, so every
+    stream has its own (unfold matrices, packed operands and weight fragments are large and short-lived).  They are grown
+    with plain allocations outside any graph capture: run every shape once eagerly before capturing."""
 
     def __init__(self):
-        self._bufs: dict[str, torch.Tensor] = {}
+        self._bufs: dict[tuple, torch.Tensor] = {}
 
     def get(self, key: str, numel: int, device) -> torch.Tensor:
-        buf = self._bufs.get(key)
+        k = (key, _lib.current_stream_ptr(device) if device.type == "cuda" else 0)
+        buf = self._bufs.get(k)
         if buf is None or buf.numel() < numel or buf.device != device:
-            buf = torch.empty(max(numel, 1), device=device, dtype=torch.float32)
-            self._bufs[key] = buf
+            if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"workspace {key!r} would have to grow during graph capture: warm the step up eagerly first")
+            buf = torch.empty(max(numel, 1) * 5 // 4, device=device, dtype=torch.float32)
+            self._bufs[k] = buf
         return buf[:numel]
 
 
@@ -79,8 +84,7 @@ def fold(dcol, C, B, t_in, t_out, k, stride, pad, dil, out=None, accumulate=Fals
     if out is None:
         out = torch.empty(C, B, t_in, device=dcol.device, dtype=torch.float32)
     if k == 1 and stride == 1 and pad == 0 and not accumulate:
-        out.view(-1).copy_(dcol.reshape(-1))
-        return out
+        return copy(dcol.reshape(-1), out=out.view(-1)).view(C, B, t_in)
     _chk(_lib.load().evmi_fold_cbt_f32(dcol.data_ptr(), out.data_ptr(), C, B, t_in, t_out, k, stride, pad, dil, int(accumulate), _s(out)), "evmi_fold_cbt_f32")
     return out
 
@@ -90,6 +94,23 @@ def elementwise(op, a, b=None, c=None, out=None, p0=0.0, p1=0.0):
         out = torch.empty_like(a)
     _chk(_lib.load().evmi_elementwise_f32(op, a.data_ptr(), _lib.ptr(b), _lib.ptr(c), out.data_ptr(), a.numel(), p0, p1, _s(a)), "evmi_elementwise_f32")
     return out
+
+
+EW_DIV_SCALAR, EW_STFT_GRAD_DEV, EW_FILL = 21, 22, 23
+
+
+def fill_(x, value=0.0):
+    """x[:] = value with a library kernel (x contiguous)."""
+    return elementwise(EW_FILL, x, out=x, p0=value)
+
+
+def copy(x, out=None):
+    """A contiguous copy made by a library kernel (the step issues no torch copy / fill kernels)."""
+    return elementwise(EW_SCALE, x, out=out, p0=1.0)
+
+
+def zeros(*shape, device):
+    return fill_(torch.empty(*shape, device=device, dtype=torch.float32))
 
 
 def row_reduce(mode, a, b, out, rows, n_per_row, scale=1.0, accumulate=False):
@@ -154,14 +175,14 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
         pk_elems = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
         if pk_elems > 0:
             ws = WS.get("pk", pk_elems, dy.device)
-            dx = (torch.zeros if k < stride else torch.empty)(cin, B, t_in, device=dy.device, dtype=torch.float32)
+            dx = zeros(cin, B, t_in, device=dy.device) if k < stride else torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
             _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout,
                                                   t_out, k, stride, pad, dil, groups, _s(dy)), "evmi_conv1d_dgrad_cbt_bf16pk")
             return dx
     ws_elems = lib.evmi_conv1d_dgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
     if ws_elems > 0:  # every phase in one launch, weight fragments straight from w
         ws = WS.get("wfrag", ws_elems, dy.device)
-        dx = (torch.zeros if k < stride else torch.empty)(cin, B, t_in, device=dy.device, dtype=torch.float32)
+        dx = zeros(cin, B, t_in, device=dy.device) if k < stride else torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
         fn = lib.evmi_conv1d_dgrad_cbt_bf16 if CONV_BACKEND["operands"] == "bf16" else lib.evmi_conv1d_dgrad_cbt_f32
         _chk(fn(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
                 k, stride, pad, dil, groups, _s(dy)), "evmi_conv1d_dgrad_cbt")
@@ -172,7 +193,7 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
         dx = torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
         return conv1d_mfma(dy, wt.view(cin, cout // groups, k), None, 1, dil * (k - 1) - pad, dil, groups, out=dx, n_out=t_in)
     assert dil == 1, "strided convolutions of this model are not dilated"
-    dx = torch.zeros(cin, B, t_in, device=dy.device, dtype=torch.float32)
+    dx = zeros(cin, B, t_in, device=dy.device)
     for phi in range(min(stride, k)):
         M = (k - phi + stride - 1) // stride
         q0 = max(0, -((phi - pad) // stride))          # first q with stride*q + phi - pad >= 0
@@ -188,9 +209,9 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
     return dx
 
 
-# "mfma": the hand-written fp32 matrix-core kernels; "gemm": unfold + rocBLAS (A/B and reference variant).
+# "mfma": the hand-written fp32 matrix-core convolution kernels; "gemm": unfold + the plain fp32 GEMM (A/B and reference variant).
 # wgrad "auto": implicit GEMM for grouped layers (2-5x over unfold + per-group GEMMs), unfold + ONE library GEMM for dense
-# ones, where rocBLAS is still 1.2-1.8x ahead of conv_wgrad_f32_mfma.hip (tools/bench_f32wgrad.py): 83.6 -> 79.4 ms/step.
+# ones in fp32 mode (one long-K product, split over K).
 # "operands": "f32" = exact fp32 fmaf chains on the fp32-input matrix cores; "bf16" = the same kernels round both operands to
 # bf16 on their way into v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 tensors in HBM, fp32 master weights).
 # "packed": bf16 operands go through the packed-input kernel (conv_cbt_bf16_pk.hip) where it takes the shape; False = always the
@@ -536,43 +557,25 @@ def mask_cols_(x, lens32):
 
 
 def attention_train_fwd(qkv, lens32, heads, p=0.0, seed=0):
-    """Multi-head self-attention that keeps the probabilities: qkv [3D, B, T] -> (out [D, B, T], saved).  Two batched GEMMs
-    per head around the masked softmax rows (+ attention dropout, as torch.nn.MultiheadAttention applies it)."""
-    lib = _lib.load()
+    """Multi-head self-attention in training mode (evmi_mha_fwd_f32, flash-style): qkv [3D, B, T] -> (out [D, B, T], saved).
+    Only the per-query log-sum-exp is kept for the backward; attention dropout as torch.nn.MultiheadAttention applies it
+    (on the normalised probabilities), mask regenerated from (seed + head, element index) in the backward."""
     D3, B, T = qkv.shape
     D = D3 // 3
-    dh = D // heads
     out = torch.empty(D, B, T, device=qkv.device, dtype=torch.float32)
-    saved = []
-    BT = B * T
-    for h in range(heads):
-        q, kk, v = qkv[h * dh:(h + 1) * dh], qkv[D + h * dh:D + (h + 1) * dh], qkv[2 * D + h * dh:2 * D + (h + 1) * dh]
-        P = torch.empty(B, T, T, device=qkv.device, dtype=torch.float32)
-        gemm_groups(q, kk, P, B, T, T, dh, BT, BT, T, T, T, T * T, ta=True, alpha=dh ** -0.5)
-        Pd = torch.empty_like(P) if p > 0 else None
-        _chk(lib.evmi_softmax_rows_f32(P.data_ptr(), _lib.ptr(Pd), lens32.data_ptr(), B, T, T, p, seed + h, _s(qkv)), "evmi_softmax_rows_f32")
-        gemm_groups(v, Pd if Pd is not None else P, out[h * dh:(h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T, tb=True)
-        saved.append((P, Pd))
-    return out, saved
+    lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
+    _chk(_lib.load().evmi_mha_fwd_f32(qkv.data_ptr(), lens32.data_ptr(), out.data_ptr(), lse.data_ptr(), B, T, D, heads, float(p), int(seed),
+                                      _s(qkv)), "evmi_mha_fwd_f32")
+    return out, (out, lse, lens32)
 
 
 def attention_train_bwd(qkv, saved, dout, heads, p=0.0, seed=0):
-    lib = _lib.load()
+    out, lse, lens32 = saved
     D3, B, T = qkv.shape
-    D = D3 // 3
-    dh = D // heads
-    BT = B * T
     dqkv = torch.empty_like(qkv)
-    for h in range(heads):
-        q, kk, v = qkv[h * dh:(h + 1) * dh], qkv[D + h * dh:D + (h + 1) * dh], qkv[2 * D + h * dh:2 * D + (h + 1) * dh]
-        do = dout[h * dh:(h + 1) * dh]
-        P, Pd = saved[h]
-        gemm_groups(do, Pd if Pd is not None else P, dqkv[2 * D + h * dh:2 * D + (h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T)  # dV = dO . Pd
-        dP = WS.get("attn_dP", B * T * T, qkv.device).view(B, T, T)
-        gemm_groups(do, v, dP, B, T, T, dh, BT, BT, T, T, T, T * T, ta=True)                                                          # dP = dO^T . V
-        _chk(lib.evmi_softmax_bwd_rows_f32(P.data_ptr(), dP.data_ptr(), B * T, T, dh ** -0.5, p, seed + h, _s(qkv)), "evmi_softmax_bwd_rows_f32")
-        gemm_groups(kk, dP, dqkv[h * dh:(h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T, tb=True)                                   # dQ = K . dS^T
-        gemm_groups(q, dP, dqkv[D + h * dh:D + (h + 1) * dh], B, dh, T, T, BT, T, BT, T, T * T, T)                                     # dK = Q . dS
+    dsum = torch.empty_like(lse)
+    _chk(_lib.load().evmi_mha_bwd_f32(qkv.data_ptr(), lens32.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dsum.data_ptr(),
+                                      dqkv.data_ptr(), B, T, D3 // 3, heads, float(p), int(seed), _s(qkv)), "evmi_mha_bwd_f32")
     return dqkv
 
 

@@ -199,7 +199,7 @@ double evmi_generator_macs_per_sample(const evmi_generator* g);
  *   fwd  Y[C_out][B*T_out] = W[C_out][C_in*k] . col      dgrad  dcol = W^T . dY -> fold
  *   wgrad dW = dY . col^T
  * ------------------------------------------------------------------------------------------ */
-/* Row-major C[M][N] = alpha * op(A)[M][K] . op(B)[K][N] + beta * C   (rocBLAS sgemm underneath). */
+/* Row-major C[M][N] = alpha * op(A)[M][K] . op(B)[K][N] + beta * C   (own fp32 matrix-core kernel, csrc/gemm_f32.hip; no BLAS library is linked). */
 int evmi_gemm_f32(int trans_a, int trans_b, int M, int N, int K, float alpha, const float* a_dev,
                   int lda, const float* b_dev, int ldb, float beta, float* c_dev, int ldc,
                   void* stream);
@@ -344,6 +344,24 @@ int evmi_istft_polar_bwd_f32(const float* a_dev, const float* ds_dev, float* da_
 int evmi_reflect_pad_left1_f32(const float* src_dev, float* dst_dev, long long rows, int T, int backward, void* stream);
 /* y = x / max(||x||, eps) (spectral norm's power iteration). */
 int evmi_normalize_vec_f32(const float* x_dev, float* y_dev, int n, float eps, void* stream);
+/* One optimiser step on a flat parameter buffer: kind 0 torch.optim.AdamW, 1 torch.optim.Adam (L2 weight decay), 2
+ * torch.optim.RMSprop (beta1 = alpha; m unused) -- the optimiser union of the reference's training config
+ * (everyvoice/.schema/everyvoice-spec-to-wav-0.5.json:434-622).  `step` is the 1-based step number, read from
+ * step_dev[0] instead when given (HIP-graph replay); clip > 0 clamps the updated parameters to +-clip (gan_type "wgan",
+ * wgan_clip_value, same schema :573-605). */
+int evmi_optimizer_step_f32(int kind, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
+                            float clip, void* stream);
+/* out[c][b][t] = in[b][c][t]: a torch [B, C, T] batch into the channel-major layout of the training kernels. */
+int evmi_transpose_bct_cbt_f32(const float* in_dev, float* out_dev, int B, int C, int T, void* stream);
+/* counter[0] += delta (the device-side step counters of the optimisers). */
+int evmi_counter_add_i32(int* counter_dev, int delta, void* stream);
+/* torch.nn.utils.spectral_norm backward with sigma and <dw, W> left on the device:
+ * gw[r][c] += dw[r][c] / sigma - (dot / sigma^2) u[r] v[c]. */
+int evmi_spectral_norm_grad_f32(float* gw_dev, const float* dw_dev, const float* u_dev, const float* v_dev,
+                                const float* sigma_dev, const float* dot_dev, int rows, int cols, void* stream);
+/* out[0] += weight * sqrt(sq[0] / sq[1]): the spectral-convergence term of the multi-resolution STFT loss. */
+int evmi_ratio_accumulate_f32(float* out_dev, const float* sq_dev, float weight, void* stream);
 /* torch.optim.AdamW step `step` (1-based) on a flat parameter buffer. */
 int evmi_adamw_f32(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
@@ -446,6 +464,18 @@ long long evmi_dwconv1d_bwd_cbt_f32_ws_elems(int C, int B, int k);
 int evmi_dwconv1d_bwd_cbt_f32(const float* x_dev, const float* w_dev, const float* dy_dev, float* dx_dev, float* dw_dev,
                               float* db_dev, float* ws_dev, long long ws_elems, int C, int B, int T, int k, int pad,
                               void* stream);
+/* Multi-head self-attention in TRAINING mode (csrc/attention_train.hip; the reference reaches torch.nn.MultiheadAttention
+ * through torchaudio's Conformer inside the absent submodule FastSpeech2_lightning; SURVEY.md 8b names evmi_mha_{fwd,bwd}).
+ * qkv [3D][B][T] channel-major, lens [B] = key padding mask.  Forward: out [D][B][T] and the per-query log-sum-exp
+ * lse [B][heads][T] -- the only thing the backward needs besides its inputs (the probabilities are recomputed tile by tile;
+ * attention dropout p regenerates its mask from (seed + head, (b * T + q) * T + k) of the counter-based generator that
+ * evmi_dropout_f32 uses).  Backward: dqkv [3D][B][T] from d out; dsum [B][heads][T] is scratch.  fp32 matrix cores, one
+ * writer per output element, fixed summation order (bitwise reproducible). */
+int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
+                     float p_drop, unsigned long long seed, void* stream);
+int evmi_mha_bwd_f32(const float* qkv_dev, const int* lens_dev, const float* out_dev, const float* dout_dev,
+                     const float* lse_dev, float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop,
+                     unsigned long long seed, void* stream);
 /* scores [B][Tq][Tk] -> softmax over the keys tk < lens[b] in place (0 beyond); with p > 0 also
  * dropped = dropout(probabilities, p) from the counter-based generator keyed by `seed`. */
 int evmi_softmax_rows_f32(float* scores_dev, float* dropped_dev, const int* lens_dev, int B, int Tq, int Tk, float p,

@@ -235,6 +235,99 @@ def test_full_gan_step_config5_vocoder_matches_oracle(cuda_device, oracle_models
     _full_gan_step(cuda_device, oracle_models, "f32", istft="c5", B=2, S=4096)
 
 
+def test_full_gan_step_wgan_rmsprop_clipping_matches_oracle(cuda_device, oracle_models):
+    """gan_type "wgan" (everyvoice-spec-to-wav-0.5.json:573-605): critic losses mean D(y_hat) - mean D(y) and -mean D(y_hat),
+    RMSprop on both sides, critic weights clipped to +-wgan_clip_value after its step -- against torch autograd + torch.optim.RMSprop."""
+    _full_gan_step(cuda_device, oracle_models, "f32", gan_type="wgan")
+
+
+def test_step_without_side_streams_is_bitwise_the_same(cuda_device):
+    """The fork / join of the discriminators and MRF branches onto side streams changes the schedule, not the arithmetic."""
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(8)
+    B, S = 2, 2048
+    y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device)
+    mel = torch.randn(B, 80, S // 256, generator=g).to(cuda_device)
+    outs, sds = [], []
+    for par in (True, False):
+        tr = HiFiGANTrainer(device=cuda_device, seed=5, parallel_streams=par)
+        outs.append([tr.training_step(mel, y) for _ in range(2)])
+        sds.append(tr.state_dict())
+    assert outs[0] == outs[1]
+    for k in sds[0]:
+        assert torch.equal(sds[0][k], sds[1][k]), k
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_graph_replay_equals_eager_steps(cuda_device, precision):
+    """use_graph=True: two eager warm-up steps, one captured, then replays -- five steps end bitwise where five eager steps do
+    (same kernels, same order per tensor; the optimisers' step counters live on the device)."""
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(18)
+    B, S = 2, 2048
+    ys = [(0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device) for _ in range(5)]
+    mels = [torch.randn(B, 80, S // 256, generator=g).to(cuda_device) for _ in range(5)]
+    res = {}
+    for graph in (False, True):
+        tr = HiFiGANTrainer(device=cuda_device, seed=5, precision=precision, use_graph=graph)
+        losses = [tr.training_step(m, y) for m, y in zip(mels, ys)]
+        if graph:
+            assert tr._graph_failed is None, tr._graph_failed
+            assert len(tr._graphs) == 1
+        res[graph] = (losses, tr.state_dict(), tr.checkpoint()["optimizer_states"])
+    assert res[True][0] == res[False][0]
+    for k in res[False][1]:
+        assert torch.equal(res[False][1][k], res[True][1][k]), k
+    for a, b in zip(res[False][2], res[True][2]):
+        assert a["evmi_flat_adamw"]["step"] == b["evmi_flat_adamw"]["step"] == 5
+        assert torch.equal(a["evmi_flat_adamw"]["exp_avg_sq"], b["evmi_flat_adamw"]["exp_avg_sq"])
+
+
+def test_generator_warmup_steps_train_the_generator_alone(cuda_device):
+    """generator_warmup_steps (same schema): during the warm-up the discriminators are neither stepped nor consulted -- the
+    generator follows the reconstruction loss only; afterwards the full GAN step runs."""
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(28)
+    y = (0.3 * torch.tanh(torch.randn(2, 1, 2048, generator=g))).to(cuda_device)
+    mel = torch.randn(2, 80, 8, generator=g).to(cuda_device)
+    tr = HiFiGANTrainer(device=cuda_device, seed=5, generator_warmup_steps=2)
+    d0, g0 = tr.d_params.flat.clone(), tr.g_params.flat.clone()
+    out = tr.training_step(mel, y)
+    assert out["d"] == 0.0 and out["g_adv"] == 0.0 and out["g_fm"] == 0.0 and out["g_mel"] > 0
+    assert torch.equal(tr.d_params.flat, d0) and not torch.equal(tr.g_params.flat, g0) and tr.d_params.step == 0
+    tr.training_step(mel, y)
+    out = tr.training_step(mel, y)  # third step: past the warm-up
+    assert out["d"] > 0 and out["g_adv"] > 0 and out["g_fm"] > 0 and not torch.equal(tr.d_params.flat, d0) and tr.d_params.step == 1
+
+
+@pytest.mark.parametrize("name", ["adam", "adamw", "rms"])
+def test_optimizer_kernel_matches_torch_optim(cuda_device, name):
+    """The flat-buffer optimiser kernel against torch.optim.{Adam, AdamW, RMSprop} over three steps (weight decay on)."""
+    from everyvoice_amd.train.layers import ParamGroup
+
+    g = torch.Generator().manual_seed(1)
+    grp = ParamGroup(cuda_device)
+    grp.declare("w", (257,))
+    grp.finalize()
+    w0 = torch.randn(257, generator=g)
+    grp.load("w", w0)
+    ref = torch.nn.Parameter(w0.clone())
+    kw = dict(lr=1e-2, eps=1e-8, weight_decay=0.05)
+    opt = {"adam": lambda: torch.optim.Adam([ref], betas=(0.8, 0.99), **kw), "adamw": lambda: torch.optim.AdamW([ref], betas=(0.8, 0.99), **kw),
+           "rms": lambda: torch.optim.RMSprop([ref], alpha=0.9, **kw)}[name]()
+    for _ in range(3):
+        gr = torch.randn(257, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        grp.gradient(0).copy_(gr.to(cuda_device))
+        grp.optimizer_step(name, lr=1e-2, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.05, alpha=0.9)
+    torch.testing.assert_close(grp.data(0).cpu(), ref.detach(), rtol=2e-5, atol=2e-6)
+    assert grp.step == 3 and int(grp.step_dev.item()) == 3
+
+
 def test_full_gan_step_resblock2_generator_matches_oracle(cuda_device, oracle_models):
     """The "2" resblock option (upstream V3 shape: 256 initial channels, upsampling 8 x 8 x 4, kernels 3 / 5 / 7 with two
     dilations each): the whole GAN step against the oracle."""
@@ -245,7 +338,7 @@ C5_AUDIO = dict(input_sampling_rate=44100, output_sampling_rate=44100, n_fft=204
 C5_MEL = dict(sr=44100, n_fft=2048, win=2048, hop=512)
 
 
-def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=False, B=2, S=2048):
+def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=False, B=2, S=2048, gan_type="original", **trainer_kw):
     from everyvoice_amd.config import HiFiGANConfig
     from everyvoice_amd.train.hifigan import HiFiGANTrainer
 
@@ -277,7 +370,10 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
                 if n.endswith("weight_g"):
                     p.mul_(g_gain)
     opt_kw = dict(lr=2e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=0.01)
-    tr = HiFiGANTrainer(config, device=cuda_device, precision=precision, **opt_kw)
+    wgan = gan_type == "wgan"
+    if wgan:  # critic losses, RMSprop (the optimiser WGAN is defined with), weight clipping
+        trainer_kw = dict(gan_type="wgan", optimizer="rms", alpha=0.99, wgan_clip_value=0.01, **trainer_kw)
+    tr = HiFiGANTrainer(config, device=cuda_device, precision=precision, **opt_kw, **trainer_kw)
     tr.load_reference_state(g_ref.state_dict(), mpd_ref.state_dict(), msd_ref.state_dict())
     tr.keep_grads = True
     loss_rel = 2e-4 if precision == "f32" else 2e-3
@@ -289,17 +385,28 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
     mel = mel_ref.mel_spectrogram_ref(y.squeeze(1), **mel_kw)[:, :, : S // hop]
 
     # ---- oracle step (jik876 training loop order: D step, then G step) ----
-    opt_g = torch.optim.AdamW(g_ref.parameters(), **opt_kw)
-    opt_d = torch.optim.AdamW(list(mpd_ref.parameters()) + list(msd_ref.parameters()), **opt_kw)
+    d_params_ref = list(mpd_ref.parameters()) + list(msd_ref.parameters())
+    if wgan:
+        rms = dict(lr=2e-4, alpha=0.99, eps=1e-8, weight_decay=0.01)
+        opt_g, opt_d = torch.optim.RMSprop(g_ref.parameters(), **rms), torch.optim.RMSprop(d_params_ref, **rms)
+    else:
+        opt_g, opt_d = torch.optim.AdamW(g_ref.parameters(), **opt_kw), torch.optim.AdamW(d_params_ref, **opt_kw)
     y_hat = g_ref(mel)
     opt_d.zero_grad()
     r1, g1, _, _ = mpd_ref(y, y_hat.detach())
     r2, g2, _, _ = msd_ref(y, y_hat.detach())
-    loss_d = discriminator_loss_ref(r1, g1) + discriminator_loss_ref(r2, g2)
+    if wgan:
+        loss_d = sum(gg.mean() - rr.mean() for rr, gg in zip(r1 + r2, g1 + g2))
+    else:
+        loss_d = discriminator_loss_ref(r1, g1) + discriminator_loss_ref(r2, g2)
     loss_d.backward()
     d_grads = {"mpd." + k: v.grad.clone() for k, v in mpd_ref.named_parameters()}
     d_grads.update({"msd." + k: v.grad.clone() for k, v in msd_ref.named_parameters()})
     opt_d.step()
+    if wgan:
+        with torch.no_grad():
+            for prm in d_params_ref:
+                prm.clamp_(-0.01, 0.01)
     opt_g.zero_grad()
     lm_y = mel_ref.mel_spectrogram_ref(y.squeeze(1), **mel_kw)
     lm_g = mel_ref.mel_spectrogram_ref(y_hat.squeeze(1), **mel_kw)
@@ -307,7 +414,7 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
     _, g1, fr1, fg1 = mpd_ref(y, y_hat)
     _, g2, fr2, fg2 = msd_ref(y, y_hat)
     loss_fm = feature_loss_ref(fr1, fg1) + feature_loss_ref(fr2, fg2)
-    loss_adv = generator_loss_ref(g1) + generator_loss_ref(g2)
+    loss_adv = -sum(gg.mean() for gg in g1 + g2) if wgan else generator_loss_ref(g1) + generator_loss_ref(g2)
     (loss_adv + loss_fm + loss_mel).backward()
     g_grads = {k: v.grad.clone() for k, v in g_ref.named_parameters()}
     opt_g.step()
@@ -343,6 +450,17 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
     for name, want in g_grads.items():
         _grad_close(name, tr.last_grads["g"][name].cpu(), want)
     # updated parameters after AdamW on both sides
+    if wgan:  # RMSprop's first step is lr * g / (sqrt(0.01 g^2) + eps) = 10 lr sign(g); the clipped critic is compared exactly below
+        sd_d = tr.d_params.state_dict()
+        ref_d = {**{"mpd." + k: v for k, v in mpd_ref.state_dict().items()}, **{"msd." + k: v for k, v in msd_ref.state_dict().items()}}
+        for k, got in sd_d.items():  # the trainer's parameters (the spectral-norm buffers are not among them)
+            got, want = got.cpu().reshape(ref_d[k].shape), ref_d[k]
+            assert float(got.abs().max()) <= 0.01 + 1e-7, k                       # wgan_clip_value
+            assert float(((got - want).abs() > 2.2e-3).float().mean()) < 0.02, k  # entries whose tiny gradient changed sign: +-10 lr
+        sd_g = tr.g_params.state_dict()
+        for k, v in g_ref.state_dict().items():
+            _params_close(k, sd_g[k].cpu(), v, g_grads.get(k), lr=2e-3)
+        return
     sd_g = tr.g_params.state_dict()
     for k, v in g_ref.state_dict().items():
         _params_close(k, sd_g[k].cpu(), v, g_grads.get(k))

@@ -12,7 +12,11 @@ import torch  # noqa: E402,F401  (initialises the HIP runtime the same way the p
 
 from everyvoice_amd import _lib  # noqa: E402
 
-lib = _lib.load()
+_lib.load()  # the product library first (the bench library links against it)
+_bench = Path(__file__).resolve().parent / "microbench" / "libevmi_bench.so"
+if not _bench.exists():
+    sys.exit("build the tuning variants first: make bench-kernels")
+lib = C.CDLL(str(_bench))
 lib.evmi_bench_variant_name.restype = C.c_char_p
 lib.evmi_bench_conv_tc.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                    C.POINTER(C.c_float), C.POINTER(C.c_double)]
