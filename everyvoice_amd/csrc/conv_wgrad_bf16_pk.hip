@@ -239,9 +239,9 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
       t_in <= 0 || pad < 0)
     return "bad shape";
   const int cin_g = c_in / groups, cout_g = c_out / groups;
-  // half-empty 64 x 64 tiles only pay with many taps to share the staged window (measured: 128->128 k41 g4 0.38 -> 0.26 ms,
-  // but 32->32 k3 0.064 -> 0.089 ms)
-  static const int min_prod = wg_env_int("EVMI_WG_MINPROD", 4096);
+  // half-empty 64 x 64 tiles pay most with many taps sharing the staged window (128->128 k41 g4 0.38 -> 0.26 ms); the 32 x 32
+  // layers of the generator's last stage (k 3 / 7 / 11: 0.09 ms here) still beat the fp32 unfold + GEMM route (0.15 ms)
+  static const int min_prod = wg_env_int("EVMI_WG_MINPROD", 1024);
   if (cin_g < 32 || cout_g < 32 || (cin_g * cout_g < min_prod && k < 16))
     return "narrow groups (the fp32 implicit-GEMM kernel takes them)";
   if (stride > 8) return "stride above 8";

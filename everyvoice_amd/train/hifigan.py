@@ -161,7 +161,7 @@ class GeneratorT:
             hook(self.stage_layers(i))
             x = ag.lrelu(tape, x, self.slope)
             x = ag.conv_transpose1d(tape, x, up)
-            if branches is not None and branches.streams and self.num_kernels > 1:
+            if branches is not None and self.num_kernels > 1:  # (also without side streams: same summation order either way)
                 leaves = fan_out(tape, x, self.num_kernels)
                 ys = parallel_section(tape, branches, [(lambda sub, j=j: self._mrf_branch(sub, leaves[j], i, j)) for j in range(self.num_kernels)])
             else:
@@ -418,12 +418,16 @@ class HiFiGANTrainer:
         self.last_grads = {}
         # one stream per discriminator (the MRF branches of the generator reuse the first few)
         self.branches = Branches(self.device, len(self.mpd) + len(self.msd), enabled=parallel_streams)
+        self._stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         n_d = len(self.mpd) + len(self.msd)
         self._loss_buf = torch.zeros(len(self.LOSS_KEYS), device=self.device)      # d, g_adv, g_fm, g_mel, g_stft
         self._slots = torch.zeros(3, n_d, device=self.device)                      # per-discriminator partial d / g_adv / g_fm
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self._graphs, self._graph_warm = {}, {}
         self._graph_failed = None
+        import os
+
+        self.phase_times = {} if os.environ.get("EVMI_PHASE_TIMES") else None
 
     # -- state ------------------------------------------------------------------------------------------
     def d_layers(self):
@@ -630,10 +634,19 @@ class HiFiGANTrainer:
         prev = ops.CONV_BACKEND["operands"]
         ops.CONV_BACKEND["operands"] = self.precision
         try:
-            if self.use_graph and self._graph_failed is None:
-                buf = self._graph_step(mel_bct, audio_bct)
-            else:
+            if self.device.type != "cuda":
                 buf = self._eager_step(mel_bct, audio_bct)
+            else:
+                # the step always runs on the trainer's own stream -- eagerly, while capturing and when replaying -- so that the
+                # per-stream scratch buffers grown by the eager warm-up are the ones the captured graph uses
+                caller = torch.cuda.current_stream(self.device)
+                self._stream.wait_stream(caller)
+                with torch.cuda.stream(self._stream):
+                    if self.use_graph and self._graph_failed is None:
+                        buf = self._graph_step(mel_bct, audio_bct)
+                    else:
+                        buf = self._eager_step(mel_bct, audio_bct)
+                caller.wait_stream(self._stream)
         finally:
             ops.CONV_BACKEND["operands"] = prev
         self.global_step += 1
@@ -649,21 +662,38 @@ class HiFiGANTrainer:
 
     def _eager_step(self, mel_bct, audio_bct):
         warm = self.global_step < self.generator_warmup_steps
+        marks = []
+
+        def mark(name):  # EVMI_PHASE_TIMES=1: device time of every phase of the step (HIP events on the step's stream)
+            if self.phase_times is not None:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(torch.cuda.current_stream(self.device))
+                marks.append((name, ev))
+
+        mark("start")
         ctx = self._phase_generator_forward(mel_bct, audio_bct)
+        mark("generator forward")
         if not warm:
             d_red = self._reducer(self.d_params)
             self._phase_d_backward(ctx, d_red)
             if d_red is not None:
                 d_red.launch(0, min(self.d_params.offset_of(n) for n in self.d_params.names()))  # alignment padding in front, if any
                 d_red.finish()
+            mark("discriminator step: forward + backward")
             self._phase_d_update(ctx)
+            mark("discriminator update + weight norm")
         g_red = self._reducer(self.g_params)
         ctx["g_reducer"][0] = g_red
         self._phase_g_backward(ctx, adversarial=not warm)
         if g_red is not None:
             g_red.launch(0, min(self.g_params.offset_of(n) for n in self.g_params.names()))
             g_red.finish()
+        mark("generator step: discriminators + losses + generator backward")
         self._phase_g_update(ctx)
+        mark("generator update")
+        if marks:
+            marks[-1][1].synchronize()
+            self.phase_times = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks, marks[1:])}
         return self._loss_buf
 
     # ---- the phases of a step (each one a stretch without communication: what a HIP graph captures) ----
@@ -811,8 +841,8 @@ class HiFiGANTrainer:
             graphs[2].replay()
         # the host-side step counters follow the device-side ones the graph increments
         if not warm:
-            self.d_params.step += 1
-        self.g_params.step += 1
+            self.d_params._step += 1
+        self.g_params._step += 1
         return self._loss_buf
 
     def _allreduce_whole(self, group: ParamGroup):
@@ -830,7 +860,7 @@ class HiFiGANTrainer:
 
         def cap(fn):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, pool=pool, stream=self._stream, capture_error_mode="thread_local"):
                 fn()
             graphs.append(g)
 
@@ -855,7 +885,7 @@ class HiFiGANTrainer:
             cap(part_c)
         ctx.clear()
         # capturing does not execute: the host-side counters the phases bumped are put back (replay bumps them again)
-        self.g_params.step, self.d_params.step = steps
+        self.g_params._step, self.d_params._step = steps
         return dict(graphs=graphs, mel=mel_s, audio=audio_s)
 
 

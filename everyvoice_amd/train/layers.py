@@ -22,8 +22,8 @@ class ParamGroup:
         self._specs = []  # (name, shape, offset)
         self._export = {}  # name -> shape in an exported state dict, where it differs
         self._n = 0
-        self.flat = self.grad = self.m = self.v = None
-        self.step = 0
+        self.flat = self.grad = self.m = self.v = self.step_dev = None
+        self._step = 0
 
     def declare(self, name: str, shape, export_shape=None) -> int:
         """``export_shape``: the tensor shape upstream stores under this name when it differs from the one the kernels use
@@ -77,9 +77,20 @@ class ParamGroup:
     def zero_grad(self):
         ops.fill_(self.grad, 0.0)
 
+    @property
+    def step(self) -> int:
+        """Optimiser steps taken.  The optimiser kernel reads the DEVICE copy (``step_dev``); assigning here (checkpoint
+        restore) sets both, the step itself only bumps the host mirror next to the device-side increment it launches."""
+        return self._step
+
+    @step.setter
+    def step(self, value: int):
+        self._step = int(value)
+        if self.step_dev is not None:
+            self.step_dev.fill_(self._step)
+
     def set_step(self, step: int):
-        self.step = int(step)
-        self.step_dev.fill_(self.step)
+        self.step = step
 
     OPTIMIZERS = {"adamw": 0, "adam": 1, "rms": 2}
 
@@ -90,13 +101,13 @@ class ParamGroup:
         from .. import _lib
 
         kind = self.OPTIMIZERS[name]
-        self.step += 1
+        self._step += 1
         lib = _lib.load()
         st = _lib.current_stream_ptr(self.flat.device)
         _lib.check(lib.evmi_counter_add_i32(self.step_dev.data_ptr(), 1, st), "evmi_counter_add_i32")
         b1, b2 = (alpha, 0.0) if kind == 2 else betas
         _lib.check(lib.evmi_optimizer_step_f32(kind, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                               self.flat.numel(), lr, b1, b2, eps, weight_decay, self.step, self.step_dev.data_ptr(),
+                                               self.flat.numel(), lr, b1, b2, eps, weight_decay, self._step, self.step_dev.data_ptr(),
                                                float(clip), st), "evmi_optimizer_step_f32")
 
     def adamw(self, lr, betas, eps, weight_decay):

@@ -216,7 +216,15 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
 # bf16 on their way into v_mfma_f32_32x32x16_bf16 (fp32 accumulation, fp32 tensors in HBM, fp32 master weights).
 # "packed": bf16 operands go through the packed-input kernel (conv_cbt_bf16_pk.hip) where it takes the shape; False = always the
 # in-LDS rounding variant of the fp32 kernels (A/B switch).
-CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma", "wgrad": "auto", "operands": "f32", "packed": True}
+CONV_BACKEND = {"fwd": "mfma", "dgrad": "mfma", "wgrad": "mfma", "operands": "f32", "packed": True}
+
+
+def wgrad_takes_bf16(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) -> bool:
+    """True where precision="bf16" computes this layer's weight gradient from bf16-rounded operands (conv_wgrad_bf16_pk.hip takes
+    the shape); narrower groups keep exact fp32 operands.  The ONE statement of that rule: tests restating the arithmetic for
+    the oracle ask here instead of copying the predicate."""
+    return (CONV_BACKEND["packed"] and CONV_BACKEND["wgrad"] != "gemm"
+            and _lib.load().evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) > 0)
 
 
 def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bool:

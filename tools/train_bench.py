@@ -23,9 +23,11 @@ B, S = int(os.environ.get("EVMI_TRAIN_B", "16")), 8192
 g = torch.Generator().manual_seed(1234)
 y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(dev)
 mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
-tr = HiFiGANTrainer(device=dev, precision=os.environ.get("OPERANDS", "f32"))
-for i in range(2):
+tr = HiFiGANTrainer(device=dev, precision=os.environ.get("OPERANDS", "f32"), use_graph=os.environ.get("GRAPH", "0") == "1",
+                    parallel_streams=os.environ.get("STREAMS", "1") == "1")
+for i in range(4):
     out = tr.training_step(mel, y)
+print("graph:", len(tr._graphs), tr._graph_failed)
 torch.cuda.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 t0 = time.perf_counter()
@@ -34,4 +36,6 @@ for i in range(n):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
 print(f"step {dt*1e3:.1f} ms -> {1/dt:.2f} steps/s; losses {out}")
+if tr.phase_times:
+    print("phases (ms):", tr.phase_times)
 print(f"G params {tr.g_params.numel():,}  D params {tr.d_params.numel():,}")
