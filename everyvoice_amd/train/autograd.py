@@ -46,13 +46,14 @@ class Tape:
 def conv1d(tape: Tape, x: Var, layer, training: bool = True) -> Var:
     """``layer`` supplies hyper-parameters, bias, the effective weight and the sink of its gradient."""
     w, dw_sink = layer.effective(training)
+    db_sink = layer.call_db_sink()
     y = Var(ops.conv1d_fwd(x.data, w, layer.bias_data(), layer.stride, layer.pad, layer.dil, layer.groups))
 
     def bwd():
         if y.grad is None:
             return
         dx, _, _ = ops.conv1d_bwd(x.data, w, y.grad, layer.stride, layer.pad, layer.dil, layer.groups, need_dx=x.needs_grad,
-                                  dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True, need_dw=not layer.frozen)
+                                  dw_out=dw_sink, db_out=db_sink, accumulate=True, need_dw=not layer.frozen)
         if dx is not None:
             x.accumulate(dx)
 
@@ -64,6 +65,7 @@ def conv1d_lrelu(tape: Tape, x: Var, layer, slope: float, training: bool = True)
     """leaky_relu(conv1d(x)) with the activation in the convolution's epilogue: the pre-activation is never stored; the
     backward takes its sign from the output (same sign for slope > 0)."""
     w, dw_sink = layer.effective(training)
+    db_sink = layer.call_db_sink()
     y = Var(ops.conv1d_fwd(x.data, w, layer.bias_data(), layer.stride, layer.pad, layer.dil, layer.groups, lrelu_slope=slope))
 
     def bwd():
@@ -72,7 +74,7 @@ def conv1d_lrelu(tape: Tape, x: Var, layer, slope: float, training: bool = True)
         if layer.frozen:
             dpre, db_out = ops.lrelu_bwd(y.grad, y.data, slope), None
         else:  # activation backward and bias gradient in one pass over dy
-            dpre, db_out = ops.lrelu_bwd_rowsum(y.grad, y.data, slope, layer.db_sink(), accumulate=True), None
+            dpre, db_out = ops.lrelu_bwd_rowsum(y.grad, y.data, slope, db_sink, accumulate=True), None
         dx, _, _ = ops.conv1d_bwd(x.data, w, dpre, layer.stride, layer.pad, layer.dil, layer.groups, need_dx=x.needs_grad,
                                   dw_out=dw_sink, db_out=db_out, accumulate=True, need_dw=not layer.frozen)
         if dx is not None:

@@ -48,23 +48,38 @@ class Branches:
     def __init__(self, device, n: int, enabled: bool = True):
         self.device = torch.device(device)
         self.streams = [torch.cuda.Stream(self.device) for _ in range(n)] if (enabled and self.device.type == "cuda") else []
+        self.timing = None  # a list: every fork / join appends the (start, end) events of its branches (diagnostics)
 
     def run(self, fns) -> None:
-        if not self.streams or len(fns) < 2:
-            for fn in fns:
+        self.run_indexed(list(enumerate(fns)))
+
+    def run_indexed(self, items) -> None:
+        """items: (stream index, fn) in HOST issue order; fn runs on stream (index mod pool size)."""
+        if not self.streams or len(items) < 2:
+            for _, fn in items:
                 fn()
             return
         main = torch.cuda.current_stream(self.device)
         fork = torch.cuda.Event()
         fork.record(main)
-        used = self.streams[: min(len(fns), len(self.streams))]
+        used = self.streams[: min(max(j for j, _ in items) + 1, len(self.streams))]
         for st in used:
             st.wait_event(fork)
-        for i, fn in enumerate(fns):
+        evs = []
+        for i, fn in items:
             with torch.cuda.stream(used[i % len(used)]):
+                if self.timing is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 fn()
+                if self.timing is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    evs.append((e0, e1))
         for st in used:
             main.wait_stream(st)
+        if self.timing is not None:
+            self.timing.append(evs)
 
 
 def parallel_section(tape: ag.Tape, branches: Branches, fns):
@@ -417,17 +432,20 @@ class HiFiGANTrainer:
         self.keep_grads = False  # tests: keep copies of both gradient buffers of the last step
         self.last_grads = {}
         # one stream per discriminator (the MRF branches of the generator reuse the first few)
-        self.branches = Branches(self.device, len(self.mpd) + len(self.msd), enabled=parallel_streams)
+        self.branches = Branches(self.device, 2 * (len(self.mpd) + len(self.msd)) + 2, enabled=parallel_streams)
         self._stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         n_d = len(self.mpd) + len(self.msd)
         self._loss_buf = torch.zeros(len(self.LOSS_KEYS), device=self.device)      # d, g_adv, g_fm, g_mel, g_stft
-        self._slots = torch.zeros(3, n_d, device=self.device)                      # per-discriminator partial d / g_adv / g_fm
+        self._slots = torch.zeros(4, n_d, device=self.device)                      # per-discriminator partial d / g_adv / g_fm / d (generated call of the spectral-norm scale)
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self._graphs, self._graph_warm = {}, {}
         self._graph_failed = None
         import os
 
         self.phase_times = {} if os.environ.get("EVMI_PHASE_TIMES") else None
+        self.branch_times = None
+        if self.phase_times is not None:
+            self.branches.timing = []
 
     # -- state ------------------------------------------------------------------------------------------
     def d_layers(self):
@@ -592,32 +610,40 @@ class HiFiGANTrainer:
             ops.scalar_reduce(1, logits, None, slot, scale=1.0 / n, p=tgt, accumulate=True)
             ops.elementwise(ops.EW_SQ_GRAD, logits, out=grad, p0=1.0 / n, p1=tgt)
 
-    def _d_branch(self, tape, i: int, d, pair: ag.Var, y: torch.Tensor, y_hat: torch.Tensor, reducer):
-        """Discriminator step of one discriminator: forward on real + generated, its loss terms (into slot i), backward later.
-        Real and generated waveforms run as ONE batch of 2B items (columns of the same GEMMs); the spectral-norm scale keeps
-        the reference's two forward calls: each call runs its own power iteration and sees its own sigma."""
-        self._bucket_hook(tape, self.d_params, d.layers(), reducer)
-        slot = self._slots[0, i : i + 1]
-        if any(isinstance(layer, SNConv) for layer in d.layers()):
-            outs = [(d.forward(tape, ag.Var(y, needs_grad=False))[0], "real"), (d.forward(tape, ag.Var(y_hat, needs_grad=False))[0], "fake")]
-        else:
-            outs = [(d.forward(tape, pair)[0], "pair")]
-        for o, kind in outs:
-            o.grad = torch.empty_like(o.data)
-            if kind == "pair":  # real items first, generated items second along the batch axis ((item, column) for the period view)
-                n, h = o.data.numel() // 2, o.data.shape[1] // 2
-                self._logit_loss(o.data[:, :h], o.grad[:, :h], True, n, slot)
-                self._logit_loss(o.data[:, h:], o.grad[:, h:], False, n, slot)
-            else:
-                self._logit_loss(o.data, o.grad, kind == "real", o.data.numel(), slot)
+    def _sn_layers(self):
+        return [layer for layer in self.d_layers() if isinstance(layer, SNConv)]
 
-    def _g_branch(self, tape, i: int, d, x_real: ag.Var, x_fake: ag.Var, adversarial: bool):
-        """Generator step through one (frozen) discriminator: feature maps of the real waveform, logits + feature maps of the
-        generated one, adversarial and feature-matching terms (into slots i) with their gradients."""
-        _, fr_list = d.forward(tape, x_real)
-        dg, fg_list = d.forward(tape, x_fake)
-        if not adversarial:
-            return
+    def _prepare_spectral_norm(self, n_calls: int):
+        """Power iterations + effective weights of the spectral-norm scale's next forward calls, every layer on its own stream:
+        ~8 small dependent launches per layer and call that would otherwise sit in front of each of its convolutions."""
+        layers = self._sn_layers()
+        self.branches.run([(lambda l=l: l.prepare(n_calls)) for l in layers])
+
+    def _d_losses(self, o: ag.Var, kind: str, slot):
+        o.grad = torch.empty_like(o.data)
+        if kind == "pair":  # real items first, generated items second along the batch axis ((item, column) for the period view)
+            n, h = o.data.numel() // 2, o.data.shape[1] // 2
+            self._logit_loss(o.data[:, :h], o.grad[:, :h], True, n, slot)
+            self._logit_loss(o.data[:, h:], o.grad[:, h:], False, n, slot)
+        else:
+            self._logit_loss(o.data, o.grad, kind == "real", o.data.numel(), slot)
+
+    def _d_branch(self, tape, i: int, d, pair: ag.Var, reducer):
+        """Discriminator step of one weight-normed discriminator: real and generated waveforms as ONE batch of 2B items (columns
+        of the same GEMMs), its loss terms (into slot i); the recorded backward ends with its gradient bucket."""
+        self._bucket_hook(tape, self.d_params, d.layers(), reducer)
+        self._d_losses(d.forward(tape, pair)[0], "pair", self._slots[0, i : i + 1])
+
+    def _d_branch_sn(self, tape, i: int, d, audio: torch.Tensor, kind: str):
+        """One of the two forward calls of the spectral-norm scale (each sees its own power iteration): a chain of its own."""
+        self._d_losses(d.forward(tape, ag.Var(audio, needs_grad=False))[0], kind, self._slots[3 if kind == "fake" else 0, i : i + 1])
+
+    def _g_forward(self, tape, d, x: ag.Var):
+        return d.forward(tape, x)
+
+    def _g_losses(self, i: int, real, fake):
+        """Adversarial and feature-matching terms of one discriminator (into slots i) with their gradients."""
+        (_, fr_list), (dg, fg_list) = real, fake
         n = dg.data.numel()
         dg.grad = torch.empty_like(dg.data)
         # original: mean((1 - D(y_hat))^2); wgan: -mean(D(y_hat))  (= the "real" form of the critic term)
@@ -693,6 +719,9 @@ class HiFiGANTrainer:
         mark("generator update")
         if marks:
             marks[-1][1].synchronize()
+            if self.branches.timing:
+                self.branch_times = [[round(a.elapsed_time(b), 3) for a, b in sec] for sec in self.branches.timing]
+                self.branches.timing.clear()
             self.phase_times = {b[0]: round(a[1].elapsed_time(b[1]), 3) for a, b in zip(marks, marks[1:])}
         return self._loss_buf
 
@@ -732,11 +761,12 @@ class HiFiGANTrainer:
         tape.record(done)
 
     def _phase_d_backward(self, ctx, reducer):
-        """Discriminator step up to its gradients: the eight discriminators side by side."""
+        """Discriminator step up to its gradients: the discriminators side by side, the spectral-norm scale's two calls too."""
         y, y_hat, B = ctx["y"], ctx["y_hat"], ctx["B"]
         self.d_params.zero_grad()
         for layer in ctx["d_layers"]:
             layer.frozen = False
+        self._prepare_spectral_norm(2)  # real call, then generated call
         T = y.shape[-1]
         pair_t = torch.empty(1, 2 * B, T, device=self.device, dtype=torch.float32)
         ops.copy(y, out=pair_t[:, :B])
@@ -748,13 +778,19 @@ class HiFiGANTrainer:
             pairs.append(ag.avgpool4s2(d_tape, pairs[-1]))
         ds = self.discriminators()
         ins = [pair] * len(self.mpd) + pairs
-
-        def branch(i):
-            return lambda sub: self._d_branch(sub, i, ds[i], ins[i], y, y_hat.data, reducer)
-
-        parallel_section(d_tape, self.branches, [branch(i) for i in range(len(ds))])
+        fns = []
+        for i, d in enumerate(ds):
+            if any(isinstance(layer, SNConv) for layer in d.layers()):
+                # its bucket closes on the main stream once both chains' backward has been joined
+                self._bucket_hook(d_tape, self.d_params, d.layers(), reducer)
+                fns.append(lambda sub, i=i, d=d: self._d_branch_sn(sub, i, d, y, "real"))
+                fns.append(lambda sub, i=i, d=d: self._d_branch_sn(sub, i, d, y_hat.data, "fake"))
+            else:
+                fns.append(lambda sub, i=i, d=d: self._d_branch(sub, i, d, ins[i], reducer))
+        parallel_section(d_tape, self.branches, fns)
         d_tape.backward()  # every discriminator's bucket is finished (and its all-reduce launched) as its stream leaves it
         ops.scalar_reduce(2, self._slots[0], None, self._loss_buf[0:1])
+        ops.scalar_reduce(2, self._slots[3], None, self._loss_buf[0:1], accumulate=True)
         if self.keep_grads:
             self.last_grads["d"] = {k: v.clone() for k, v in self.d_params.gradients().items()}
 
@@ -762,13 +798,25 @@ class HiFiGANTrainer:
         self.d_params.optimizer_step(clip=self.wgan_clip_value if self.gan_type == "wgan" else 0.0, **self._opt_kw())
         self._materialize(ctx["d_layers"])  # the generator step sees the updated discriminators
 
+    def _recon_grad(self, y, y_hat_t, B):
+        """Reconstruction losses (45 x mel-L1 and / or the multi-resolution STFT loss) and their gradient wrt y_hat [1, B, T]."""
+        total = None
+        if "mel" in self.reconstruction_loss.split("+"):
+            total = self.mel_loss.loss_and_grad(y.view(B, -1), y_hat_t.view(B, -1), 45.0, self._loss_buf[3:4]).view(1, B, -1)
+        if self.stft_loss is not None:
+            d_stft = self.stft_loss.loss_and_grad(y.view(B, -1), y_hat_t.view(B, -1), self.stft_loss_weight, self._loss_buf[4:5]).view(1, B, -1)
+            total = d_stft if total is None else ops.axpby(1.0, total, 1.0, d_stft, out=total)
+        return total
+
     def _phase_g_backward(self, ctx, adversarial=True):
         y, y_hat, B = ctx["y"], ctx["y_hat"], ctx["B"]
         self.g_params.zero_grad()
         for layer in ctx["d_layers"]:
             layer.frozen = True  # gradients flow through the discriminators to y_hat only
         y_hat_in = ag.Var(y_hat.data)  # boundary between the discriminator tape and the generator tape
+        recon = [None]
         if adversarial:
+            self._prepare_spectral_norm(2)  # real call, then generated call
             gd_tape = ag.Tape()
             real = ag.Var(y, needs_grad=False)
             xs_r = self._scale_inputs(gd_tape, real)
@@ -778,23 +826,32 @@ class HiFiGANTrainer:
             ins_r = [real] * (n_p + 1) + xs_r[1:]
             ins_f = [*fake_leaves[:n_p], fake_leaves[-1], *[fan_out(gd_tape, x, 1)[0] for x in xs_f[1:]]]
             ds = self.discriminators()
+            nd = len(ds)
+            # generated-waveform chains on streams 0 .. nd-1 (their backward too), real-waveform chains (forward only) and the
+            # reconstruction loss on the streams after them; the spectral-norm scale hands out its real call first
+            res_r, res_f = [None] * nd, [None] * nd
 
-            def branch(i):
-                return lambda sub: self._g_branch(sub, i, ds[i], ins_r[i], ins_f[i], True)
+            def fwd_real(i):
+                return lambda sub: res_r.__setitem__(i, self._g_forward(sub, ds[i], ins_r[i]))
 
-            parallel_section(gd_tape, self.branches, [branch(i) for i in range(len(ds))])
+            def fwd_fake(i):
+                return lambda sub: res_f.__setitem__(i, self._g_forward(sub, ds[i], ins_f[i]))
+
+            sn_first = [i for i, d in enumerate(ds) if any(isinstance(l, SNConv) for l in d.layers())]
+            order_fake = [fwd_fake(i) for i in range(nd)]
+            order_real = [fwd_real(i) for i in range(nd)]
+            # host order decides which prepared spectral-norm call a chain receives: issue the real chains of those scales first
+            self._ordered_section(gd_tape, order_fake, order_real + [lambda sub: recon.__setitem__(0, self._recon_grad(y, y_hat.data, B))], first=[nd + i for i in sn_first])
+            self.branches.run([(lambda i=i: self._g_losses(i, res_r[i], res_f[i])) for i in range(nd)])
             gd_tape.backward()
             ops.scalar_reduce(2, self._slots[1], None, self._loss_buf[1:2])
             ops.scalar_reduce(2, self._slots[2], None, self._loss_buf[2:3])
             for layer in ctx["d_layers"]:
                 if isinstance(layer, SNConv):
                     layer._calls.clear()  # frozen: no parameter gradients from this pass
-        total = None
-        if "mel" in self.reconstruction_loss.split("+"):
-            total = self.mel_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), 45.0, self._loss_buf[3:4]).view(1, B, -1)
-        if self.stft_loss is not None:
-            d_stft = self.stft_loss.loss_and_grad(y.view(B, -1), y_hat.data.view(B, -1), self.stft_loss_weight, self._loss_buf[4:5]).view(1, B, -1)
-            total = d_stft if total is None else ops.axpby(1.0, total, 1.0, d_stft, out=total)
+            total = recon[0]
+        else:
+            total = self._recon_grad(y, y_hat.data, B)
         if y_hat_in.grad is not None:
             total = ops.axpby(1.0, total, 1.0, y_hat_in.grad, out=total)
         y_hat.grad = total
@@ -802,6 +859,14 @@ class HiFiGANTrainer:
         if self.keep_grads:
             self.last_grads["g"] = {k: v.clone() for k, v in self.g_params.gradients().items()}
             self.last_grads["y_hat"] = y_hat.data.clone()
+
+    def _ordered_section(self, tape, fns_a, fns_b, first=()):
+        """A parallel section over fns_a + fns_b (branch j on stream j) whose HOST issue order starts with the indices in `first`."""
+        fns = list(fns_a) + list(fns_b)
+        subs = [ag.Tape() for _ in fns]
+        order = list(first) + [j for j in range(len(fns)) if j not in first]
+        self.branches.run_indexed([(j, (lambda j=j: fns[j](subs[j]))) for j in order])
+        tape.record(lambda: self.branches.run_indexed([(j, subs[j].backward) for j in range(len(fns))]))
 
     def _phase_g_update(self, ctx):
         self.g_params.optimizer_step(**self._opt_kw())

@@ -137,6 +137,10 @@ class _ConvBase:
     def db_sink(self):
         return self.group.gradient(self.i_bias)
 
+    def call_db_sink(self):
+        """Bias-gradient sink of the forward call `effective` just served (weight-normed layers: the parameter gradient itself)."""
+        return self.group.gradient(self.i_bias)
+
     def _shared_sink(self):
         """Gradient wrt the EFFECTIVE weight accumulates here during backward; ``finish_grads`` maps it to the
         stored parameters (g, v) or weight_orig."""
@@ -233,7 +237,13 @@ class WNBatch:
 
 class SNConv(_ConvBase):
     """spectral_norm(Conv1d) as torch.nn.utils.spectral_norm: parameter weight_orig, buffers weight_u / weight_v;
-    in training mode every forward call runs one power iteration (and therefore sees its own sigma)."""
+    in training mode every forward call runs one power iteration (and therefore sees its own sigma).
+
+    The effective weights depend on (weight_orig, u) only, not on activations: ``prepare(n)`` runs the power iterations of the
+    next n forward calls ahead of time (each layer's chain of small matrix-vector kernels is independent of the other layers',
+    so the trainer runs them side by side, off the convolutions' critical path); ``effective`` then hands them out in order.
+    Every call owns its weight- and bias-gradient buffers, so two calls (real / generated waveform) may run their backward on
+    different streams; ``finish_grads`` adds them into the parameter gradients in call order."""
 
     def __init__(self, group, name, cin, cout, k, **kw):
         super().__init__(group, name, cin, cout, k, **kw)
@@ -241,45 +251,79 @@ class SNConv(_ConvBase):
         h, wdt = self.wshape[0], math.prod(self.wshape[1:])
         self.u = torch.zeros(h, device=group.device)
         self.v = torch.zeros(wdt, device=group.device)
-        self._calls = []  # (sigma tensor [1], u, v, dw buffer) per forward call of this step
+        self._calls = []  # (sigma tensor [1], u, v, dw buffer, db buffer) per forward call of this step
+        self._ready = []  # prepared, not yet handed out
+        self._call_db = None
 
     def materialize(self):
         pass  # the effective weight depends on the power-iteration state: computed per forward call
 
-    def effective(self, training=True):
-        """One forward call: (one power iteration in training mode,) sigma = u^T W v, w = W / sigma."""
+    def _iterate(self, u_prev, training):
+        """One forward call's (w, sigma, u, v) from the state u_prev: one power iteration in training mode."""
         W = self.group.data(self.i_w)
         h, wdt = self.wshape[0], math.prod(self.wshape[1:])
         Wm = W.view(h, wdt)
+        dev = W.device
+        sigma = torch.empty(1, device=dev)
         if training:
-            tmp_v = torch.empty(wdt, device=W.device)
-            ops.gemm(Wm, self.u.view(h, 1), tmp_v.view(wdt, 1), ta=True)   # W^T u
-            ops.normalize_vec(tmp_v, self.v)
-            tmp_u = torch.empty(h, device=W.device)
-            ops.gemm(Wm, self.v.view(wdt, 1), tmp_u.view(h, 1))            # W v
-            ops.normalize_vec(tmp_u, self.u)
-        u, v = ops.copy(self.u), ops.copy(self.v)
-        wv = torch.empty(h, device=W.device)
-        ops.gemm(Wm, v.view(wdt, 1), wv.view(h, 1))
-        sigma = torch.empty(1, device=W.device)
-        ops.row_reduce(1, u, wv, sigma, 1, h)                              # sigma = u . (W v), left on the device
+            tmp_v = torch.empty(wdt, device=dev)
+            ops.gemm(Wm, u_prev.view(h, 1), tmp_v.view(wdt, 1), ta=True)   # W^T u
+            v = ops.normalize_vec(tmp_v, torch.empty(wdt, device=dev))
+            wv = torch.empty(h, device=dev)
+            ops.gemm(Wm, v.view(wdt, 1), wv.view(h, 1))                     # W v
+            u = ops.normalize_vec(wv, torch.empty(h, device=dev))
+        else:
+            u, v = u_prev, self.v
+            wv = torch.empty(h, device=dev)
+            ops.gemm(Wm, v.view(wdt, 1), wv.view(h, 1))
+        ops.row_reduce(1, u, wv, sigma, 1, h)                               # sigma = u . (W v), left on the device
         w = ops.elementwise(ops.EW_DIV_SCALAR, W, c=sigma)
-        dw = ops.zeros(*self.wshape, device=W.device)
-        self._calls.append((sigma, u, v, dw))
+        return w, sigma, u, v
+
+    def prepare(self, n_calls: int, training=True):
+        """Power iterations + effective weights of the next `n_calls` forward calls (the buffers end at the last call's state)."""
+        u = self.u
+        v = self.v
+        for _ in range(n_calls):
+            w, sigma, u, v = self._iterate(u, training)
+            self._ready.append((w, sigma, u, v))
+        if training and n_calls:
+            ops.copy(u, out=self.u)
+            ops.copy(v, out=self.v)
+
+    def effective(self, training=True):
+        """One forward call: (one power iteration in training mode,) sigma = u^T W v, w = W / sigma."""
+        if not self._ready:
+            self.prepare(1, training)
+        w, sigma, u, v = self._ready.pop(0)
+        dw = db = None
+        if not self.frozen:
+            dw = ops.zeros(*self.wshape, device=w.device)
+            db = ops.zeros(self.cout, device=w.device)
+        self._calls.append((sigma, u, v, dw, db))
+        self._call_db = db
         return w, dw
+
+    def call_db_sink(self):
+        """Bias-gradient sink of the forward call `effective` just served (read right after it)."""
+        return self._call_db
 
     def finish_grads(self):
         from .. import _lib
 
         W = self.group.data(self.i_w)
         gW = self.group.gradient(self.i_w)
+        gb = self.group.gradient(self.i_bias)
         h, wdt = self.wshape[0], math.prod(self.wshape[1:])
-        for sigma, u, v, dw in self._calls:
+        for sigma, u, v, dw, db in self._calls:
+            if dw is None:
+                continue
             # d weight_orig += dw / sigma - (<dw, W> / sigma^2) u v^T   (sigma and the inner product stay on the device)
             dot = torch.empty(1, device=W.device)
             ops.scalar_reduce(2, ops.elementwise(ops.EW_MUL, dw, W), None, dot)
             _lib.check(_lib.load().evmi_spectral_norm_grad_f32(gW.data_ptr(), dw.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(),
                                                                dot.data_ptr(), h, wdt, _lib.current_stream_ptr(W.device)), "evmi_spectral_norm_grad_f32")
+            ops.axpby(1.0, gb, 1.0, db, out=gb)
         self._calls.clear()
 
 

@@ -38,4 +38,7 @@ dt = (time.perf_counter() - t0) / n
 print(f"step {dt*1e3:.1f} ms -> {1/dt:.2f} steps/s; losses {out}")
 if tr.phase_times:
     print("phases (ms):", tr.phase_times)
+    for sec in tr.branch_times or []:
+        if len(sec) > 3:
+            print("  branches (ms):", sec)
 print(f"G params {tr.g_params.numel():,}  D params {tr.d_params.numel():,}")
