@@ -80,6 +80,10 @@ SYMBOLS = {
         C.c_int,
         [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p],
     ),
+    "evmi_mel_spectrogram_ragged_f32": (
+        C.c_int,
+        [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p],
+    ),
     "evmi_gemm_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "evmi_conv1d_cbt_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
     "evmi_conv1d_cbt_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
@@ -153,6 +157,9 @@ SYMBOLS = {
     "evmi_weight_norm_bwd_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "evmi_normalize_vec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "evmi_optimizer_step_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_longlong] + [C.c_float] * 5 + [C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "evmi_loudness_lkfs_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
+    "evmi_loudness_scratch_elems": (C.c_longlong, [C.c_int] * 4),
+    "evmi_peak_normalize_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "evmi_transpose_bct_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "evmi_counter_add_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "evmi_spectral_norm_grad_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),

@@ -9,7 +9,7 @@ int launch_conv1d_f32(const float*, const float*, const float*, const float*, fl
 int launch_conv_transpose1d_f32(const float*, const float*, const float*, float*, int, int, int, int, int,
                                 int, int, float, hipStream_t);
 int launch_mel_frontend(const float*, const float*, const float*, float*, float*, float*, int, int, int, int, int,
-                        int, int, int, int, hipStream_t);
+                        int, int, int, int, hipStream_t, const int* lens);
 }  // namespace evmi
 
 using namespace evmi;
@@ -58,7 +58,19 @@ int evmi_mel_spectrogram_f32(const float* audio_dev, const float* dft_basis_dev,
     return fail(EVMI_ERR_INVALID_ARG, "mel_spectrogram: bad shape");
   const int n_frames = 1 + n_samples / hop;
   return launch_mel_frontend(audio_dev, dft_basis_dev, mel_basis_dev, mel_dev, energy_dev, mag_dev, B, n_samples,
-                             n_frames, n_fft, hop, n_bins_padded, n_fft / 2 + 1, n_mels, apply_log, (hipStream_t)stream);
+                             n_frames, n_fft, hop, n_bins_padded, n_fft / 2 + 1, n_mels, apply_log, (hipStream_t)stream, nullptr);
+}
+
+int evmi_mel_spectrogram_ragged_f32(const float* audio_dev, const int* lens_dev, const float* dft_basis_dev, const float* mel_basis_dev,
+                                    float* mel_dev, float* energy_dev, float* mag_dev, int B, int n_samples_max, int n_fft, int hop,
+                                    int n_bins_padded, int n_mels, int apply_log, void* stream) {
+  if (!audio_dev || !lens_dev || !dft_basis_dev || !mel_basis_dev || !mel_dev)
+    return fail(EVMI_ERR_INVALID_ARG, "mel_spectrogram_ragged: null pointer");
+  if (B <= 0 || n_samples_max <= 0 || n_mels <= 0 || n_bins_padded % 16 || n_bins_padded < n_fft / 2 + 1)
+    return fail(EVMI_ERR_INVALID_ARG, "mel_spectrogram_ragged: bad shape");
+  const int n_frames = 1 + n_samples_max / hop;
+  return launch_mel_frontend(audio_dev, dft_basis_dev, mel_basis_dev, mel_dev, energy_dev, mag_dev, B, n_samples_max,
+                             n_frames, n_fft, hop, n_bins_padded, n_fft / 2 + 1, n_mels, apply_log, (hipStream_t)stream, lens_dev);
 }
 
 }  // extern "C"

@@ -37,8 +37,8 @@ constexpr int MEL_ROWS_PER_THREAD = 8;  // n_mels <= 16 * 8
 
 __global__ __launch_bounds__(MEL_THREADS) void mel_frontend_kernel(
     const float* __restrict__ audio, const float* __restrict__ basis_ri, const float* __restrict__ melb,
-    float* __restrict__ out, float* __restrict__ energy, float* __restrict__ mag_out, int n_samples, int n_frames,
-    int n_fft, int hop, int nb_pad, int n_bins, int n_mels, int apply_log, int chunk_tiles) {
+    float* __restrict__ out, float* __restrict__ energy, float* __restrict__ mag_out, int n_samples_max, int n_frames,
+    int n_fft, int hop, int nb_pad, int n_bins, int n_mels, int apply_log, int chunk_tiles, const int* __restrict__ lens) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int seg = (MEL_FRAMES - 1) * hop + n_fft;           // audio samples a block needs
   float* As = reinterpret_cast<float*>(smem);                // skewed: index s + s / hop
@@ -50,7 +50,10 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_frontend_kernel(
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * MEL_FRAMES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* ab = audio + (long long)b * n_samples;
+  // ragged batches: item b holds lens[b] samples of its n_samples_max-long row and reflects at ITS end; frames past its own
+  // 1 + lens[b] / hop are computed from whatever follows (finite) and are the caller's to ignore
+  const int n_samples = lens ? max(min(lens[b], n_samples_max), n_fft / 2 + 1) : n_samples_max;
+  const float* ab = audio + (long long)b * n_samples_max;
   const int pad = n_fft / 2;
 
   for (int s = tid; s < seg; s += MEL_THREADS) {
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(MEL_THREADS) void mel_frontend_kernel(
 
 int launch_mel_frontend(const float* audio, const float* basis_ri, const float* melb, float* out, float* energy,
                         float* mag_out, int B, int n_samples, int n_frames, int n_fft, int hop, int nb_pad,
-                        int n_bins, int n_mels, int apply_log, hipStream_t s) {
+                        int n_bins, int n_mels, int apply_log, hipStream_t s, const int* lens) {
   if (n_fft % hop || n_fft % 2 || hop <= 0) return fail(EVMI_ERR_UNSUPPORTED, "mel: n_fft must be a multiple of hop");
   if (n_samples <= n_fft / 2) return fail(EVMI_ERR_INVALID_ARG, "mel: reflect padding needs n_samples > n_fft/2");
   if (n_mels > MEL_ROWS_PER_THREAD * (MEL_THREADS / 32)) return fail(EVMI_ERR_UNSUPPORTED, "mel: n_mels > 128");
@@ -168,7 +171,7 @@ int launch_mel_frontend(const float* audio, const float* basis_ri, const float* 
   }
   dim3 grid((n_frames + MEL_FRAMES - 1) / MEL_FRAMES, B);
   hipLaunchKernelGGL(mel_frontend_kernel, grid, dim3(MEL_THREADS), lds, s, audio, basis_ri, melb, out, energy, mag_out,
-                     n_samples, n_frames, n_fft, hop, nb_pad, n_bins, n_mels, apply_log, chunk_tiles);
+                     n_samples, n_frames, n_fft, hop, nb_pad, n_bins, n_mels, apply_log, chunk_tiles, lens);
   EVMI_LAUNCH_CHECK("mel_frontend");
   return EVMI_OK;
 }

@@ -1,0 +1,152 @@
+// Audio gating of the preprocessor on the device: integrated loudness of every utterance of a batch, the
+// quantity behind the reference's "audio_empty" gate (everyvoice/preprocessor/preprocessor.py:177-185:
+// torchaudio.transforms.Loudness(sr)(audio) < -36 LUFS or NaN -> skipped).
+//
+// torchaudio.functional.loudness restated (ITU-R BS.1770-4; torchaudio is not in this image: parity unpinned, checked against
+// the numpy restatement in oracle/preprocess_ref.py):
+//   K-weighting: treble_biquad(+4 dB, 1500 Hz, Q = 1/sqrt 2) then highpass_biquad(38 Hz, Q = 0.5), each lfilter(clamp=True)
+//   400 ms blocks, 75 % overlap: z[block] = mean(y^2);  l[block] = -0.691 + 10 log10(sum_ch g_ch z_ch)   (g = 1 for the first
+//   three channels); absolute gate l > -70; relative gate l > (-0.691 + 10 log10(sum_ch g_ch mean_gated z_ch)) - 10;
+//   LKFS = -0.691 + 10 log10(sum_ch g_ch mean_{both gates} z_ch).
+// The two biquads are a sequential recurrence per (utterance, channel): one thread each (a batch of utterances runs its
+// recurrences side by side: ~240 k dependent steps for 11 s of audio, milliseconds per batch); block means and the gating run
+// one workgroup per utterance.
+#include "common.h"
+
+namespace evmi {
+
+struct Biquad { float b0, b1, b2, a1, a2; };
+
+// y2[item][ch][t] = (K-weighted x)^2 ; x [items][channels][t_max] (zero padded), lens [items]
+__global__ void kweight_square_kernel(const float* __restrict__ x, const int* __restrict__ lens, float* __restrict__ y2, int items,
+                                      int channels, int t_max, Biquad s1, Biquad s2) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= items * channels) return;
+  const int n = min(lens[idx / channels], t_max);
+  const float* xs = x + (long long)idx * t_max;
+  float* ys = y2 + (long long)idx * t_max;
+  float x1 = 0.f, x2 = 0.f, y1 = 0.f, yy2 = 0.f;  // stage 1 state
+  float u1 = 0.f, u2 = 0.f, v1 = 0.f, v2 = 0.f;   // stage 2 state
+  for (int t = 0; t < n; ++t) {
+    const float xv = xs[t];
+    float y = s1.b0 * xv + s1.b1 * x1 + s1.b2 * x2 - s1.a1 * y1 - s1.a2 * yy2;
+    x2 = x1; x1 = xv; yy2 = y1; y1 = y;           // the recurrence runs on the unclamped output; the clamp applies to what leaves the filter
+    y = fminf(fmaxf(y, -1.f), 1.f);
+    float v = s2.b0 * y + s2.b1 * u1 + s2.b2 * u2 - s2.a1 * v1 - s2.a2 * v2;
+    u2 = u1; u1 = y; v2 = v1; v1 = v;
+    v = fminf(fmaxf(v, -1.f), 1.f);
+    ys[t] = v * v;
+  }
+}
+
+// one workgroup per utterance: block means (per channel), both gates, LKFS.  scratch: [items][channels][max_blocks]
+__global__ __launch_bounds__(256) void loudness_gate_kernel(const float* __restrict__ y2, const int* __restrict__ lens, float* __restrict__ zbuf,
+                                                            float* __restrict__ lkfs, int channels, int t_max, int gate, int step, int max_blocks) {
+  const int item = blockIdx.x;
+  const int n = min(lens[item], t_max);
+  const int nb = n >= gate ? (n - gate) / step + 1 : 0;
+  float* z = zbuf + (long long)item * channels * max_blocks;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c = 0; c < channels; ++c) {
+    const float* ys = y2 + ((long long)item * channels + c) * t_max;
+    for (int b = wave; b < nb; b += 4) {  // one wave per block
+      float acc = 0.f;
+      for (int t = lane; t < gate; t += 64) acc += ys[(long long)b * step + t];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+      if (lane == 0) z[c * max_blocks + b] = acc / (float)gate;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (nb == 0) { lkfs[item] = NAN; return; }
+  const float bias = -0.691f;
+  auto pass = [&](float thresh_abs, float thresh_rel, bool use_rel, float& out_energy) {
+    int count = 0;
+    float sums[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < nb; ++b) {
+      float e = 0.f;
+      for (int c = 0; c < channels; ++c) e += (c < 3 ? 1.f : 1.41f) * z[c * max_blocks + b];
+      const float l = bias + 10.f * log10f(e);
+      if (l > thresh_abs && (!use_rel || l > thresh_rel)) {
+        ++count;
+        for (int c = 0; c < channels; ++c) sums[c] += z[c * max_blocks + b];
+      }
+    }
+    float e = 0.f;
+    for (int c = 0; c < channels; ++c) e += (c < 3 ? 1.f : 1.41f) * (sums[c] / (float)count);  // count 0 -> NaN, as torchaudio
+    out_energy = e;
+  };
+  float e1, e2;
+  pass(-70.f, 0.f, false, e1);
+  const float gamma_rel = bias + 10.f * log10f(e1) - 10.f;
+  pass(-70.f, gamma_rel, true, e2);
+  lkfs[item] = bias + 10.f * log10f(e2);
+}
+
+// dst[b][t] = scale[b] * src[b][t] for t < lens[b], 0 beyond (peak normalisation to 0.95 with the per-utterance peak on the device)
+__global__ void peak_normalize_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ lens, int t_max, float target) {
+  __shared__ float part[4];
+  const int item = blockIdx.x;
+  const int n = min(lens[item], t_max);
+  const float* xs = src + (long long)item * t_max;
+  float* ys = dst + (long long)item * t_max;
+  float mx = 0.f;
+  for (int t = threadIdx.x; t < n; t += 256) mx = fmaxf(mx, fabsf(xs[t]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+  for (int t = threadIdx.x; t < t_max; t += 256) ys[t] = t < n ? xs[t] / mx * target : 0.f;  // (x / max|x|) * 0.95, the reference's two steps
+}
+
+}  // namespace evmi
+
+using namespace evmi;
+
+static Biquad normalized(double b0, double b1, double b2, double a0, double a1, double a2) {
+  return Biquad{(float)(b0 / a0), (float)(b1 / a0), (float)(b2 / a0), (float)(a1 / a0), (float)(a2 / a0)};
+}
+
+extern "C" {
+
+int evmi_loudness_lkfs_f32(const float* x_dev, const int* lens_dev, float* y2_scratch_dev, float* z_scratch_dev, float* lkfs_dev, int items,
+                           int channels, int t_max, int sample_rate, void* stream) {
+  if (!x_dev || !lens_dev || !y2_scratch_dev || !z_scratch_dev || !lkfs_dev) return fail(EVMI_ERR_INVALID_ARG, "loudness: null pointer");
+  if (items <= 0 || channels <= 0 || channels > 5 || t_max <= 0 || sample_rate <= 0) return fail(EVMI_ERR_INVALID_ARG, "loudness: shape");
+  const double pi = 3.14159265358979323846;
+  // treble_biquad(gain 4 dB, 1500 Hz, Q 1/sqrt 2)
+  double w0 = 2.0 * pi * 1500.0 / sample_rate, alpha = sin(w0) / 2.0 / (1.0 / sqrt(2.0)), A = exp(4.0 / 40.0 * log(10.0));
+  double t1 = 2.0 * sqrt(A) * alpha, t2 = (A - 1.0) * cos(w0), t3 = (A + 1.0) * cos(w0);
+  const Biquad s1 = normalized(A * ((A + 1.0) + t2 + t1), -2.0 * A * ((A - 1.0) + t3), A * ((A + 1.0) + t2 - t1), (A + 1.0) - t2 + t1,
+                               2.0 * ((A - 1.0) - t3), (A + 1.0) - t2 - t1);
+  // highpass_biquad(38 Hz, Q 0.5)
+  w0 = 2.0 * pi * 38.0 / sample_rate;
+  alpha = sin(w0) / 2.0 / 0.5;
+  const Biquad s2 = normalized((1.0 + cos(w0)) / 2.0, -1.0 - cos(w0), (1.0 + cos(w0)) / 2.0, 1.0 + alpha, -2.0 * cos(w0), 1.0 - alpha);
+  const int gate = (int)llround(0.4 * sample_rate), step = (int)(gate * (1.0 - 0.75));
+  const int max_blocks = t_max >= gate ? (t_max - gate) / step + 1 : 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int n = items * channels;
+  hipLaunchKernelGGL(kweight_square_kernel, dim3((n + 63) / 64), dim3(64), 0, s, x_dev, lens_dev, y2_scratch_dev, items, channels, t_max, s1, s2);
+  hipLaunchKernelGGL(loudness_gate_kernel, dim3(items), dim3(256), 0, s, y2_scratch_dev, lens_dev, z_scratch_dev, lkfs_dev, channels, t_max, gate, step,
+                     max_blocks);
+  EVMI_LAUNCH_CHECK("loudness");
+  return EVMI_OK;
+}
+
+long long evmi_loudness_scratch_elems(int items, int channels, int t_max, int sample_rate) {
+  const int gate = (int)llround(0.4 * sample_rate), step = (int)(gate * (1.0 - 0.75));
+  const int max_blocks = t_max >= gate ? (t_max - gate) / (step > 0 ? step : 1) + 1 : 1;
+  return (long long)items * channels * max_blocks;
+}
+
+int evmi_peak_normalize_f32(const float* src_dev, float* dst_dev, const int* lens_dev, int items, int t_max, float target, void* stream) {
+  if (!src_dev || !dst_dev || !lens_dev || items <= 0 || t_max <= 0) return fail(EVMI_ERR_INVALID_ARG, "peak_normalize: arguments");
+  hipLaunchKernelGGL(peak_normalize_kernel, dim3(items), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev, lens_dev, t_max, target);
+  EVMI_LAUNCH_CHECK("peak_normalize");
+  return EVMI_OK;
+}
+
+}  // extern "C"

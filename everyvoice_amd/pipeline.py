@@ -3,9 +3,13 @@ the reference's preprocessor for the features computed on the GPU (spec, energy,
 and the synthesis writers (PCM-16 wav, ``[n_mels, T]`` spec) with the reference's file naming.
 
 Mirrors (paths relative to the reference):
-  process_audio            everyvoice/preprocessor/preprocessor.py:131-218  (channel / length gates, peak normalise to
-                           0.95, truncate to a multiple of the hop; the LUFS gate, SoX effects and resampling are the
-                           reference's CPU steps and are not reproduced: inputs must already be at the target rate)
+  process_audio            everyvoice/preprocessor/preprocessor.py:131-218  (channel / length gates, the -36 LUFS "audio_empty"
+                           gate, the default SoX effect "channels 1" (mix-down), resampling, peak normalise to 0.95, truncate
+                           to a multiple of the hop).  Loudness, resampling and normalisation run on the device
+                           (csrc/preprocess_ops.hip; torchaudio's algorithms restated, parity unpinned: torchaudio is not in
+                           the image); other SoX effect chains are not reproduced
+  preprocess / .config-lock  preprocessor.py:974-1082 (what the lock records, when a run refuses to continue)
+  compute_stats / normalize_stats  preprocessor.py:378-490 (dataset statistics of energy / pitch -> Stats, files rewritten normalised)
   create_path naming       everyvoice/preprocessor/preprocessor.py:502-508, 529-533, 633-639
                            ``<save_dir>/<kind>/<basename>--<speaker>--<language>--<kind-file>``
   average_data_by_durations  everyvoice/preprocessor/preprocessor.py:287-300 (host loop, as in the reference)
@@ -17,7 +21,10 @@ File IO and per-utterance scalars stay on the host (they are IO-bound plumbing);
 
 from __future__ import annotations
 
+import json
+import math
 import wave
+from glob import glob
 from pathlib import Path
 
 import numpy as np
@@ -71,8 +78,76 @@ def feature_path(save_dir, kind: str, basename: str, speaker: str, language: str
     return Path(save_dir) / kind / SEP.join([basename, speaker, language, fn])
 
 
-def process_audio(wav_path, cfg: AudioConfig, normalize: bool = True):
-    """(audio [S'], sr) with S' a multiple of the hop, or (None, reason) when the file is skipped."""
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """The polyphase windowed-sinc filter bank of torchaudio.functional.resample (defaults: sinc_interp_hann): ``new`` filters of
+    ``2 * width + orig`` taps applied at stride ``orig`` -> (kernel [new, 1, taps] float32, width, orig, new), rates reduced
+    by their gcd.  Built in float64 on the host, as torchaudio does; the convolution itself runs on the device."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    taps = np.arange(-width, width + orig, dtype=np.float64)[None, :] / orig
+    t = (np.arange(0, -new, -1, dtype=np.float64)[:, None] / new + taps) * base
+    t = np.clip(t, -lowpass_filter_width, lowpass_filter_width)
+    window = np.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    with np.errstate(invalid="ignore", divide="ignore"):
+        sinc = np.where(t == 0, 1.0, np.sin(t) / t)
+    return torch.from_numpy((sinc * window * (base / orig)).astype(np.float32))[:, None, :].contiguous(), width, orig, new
+
+
+_RESAMPLE_KERNELS: dict = {}
+
+
+def resample(audio: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
+    """[B, S] (device) -> [B, ceil(new * S / orig)]: torchaudio.functional.resample as ONE strided convolution on the device
+    (evmi_conv1d_f32: exact fp32 fmaf chains) with the filter bank above (preprocessor.py:196-198)."""
+    from . import _lib
+
+    if orig_freq == new_freq:
+        return audio
+    if not audio.is_cuda:
+        raise RuntimeError("everyvoice_amd.pipeline.resample computes on the GPU only (no CPU fallback)")
+    key = (int(orig_freq), int(new_freq), audio.device)
+    if key not in _RESAMPLE_KERNELS:
+        k, width, orig, new = sinc_resample_kernel(orig_freq, new_freq)
+        _RESAMPLE_KERNELS[key] = (k.to(audio.device), width, orig, new)
+    kernel, width, orig, new = _RESAMPLE_KERNELS[key]
+    x = audio.to(torch.float32)
+    B, S = x.shape
+    xp = torch.nn.functional.pad(x, (width, width + orig)).contiguous()  # (memory plumbing: the zero margin of the filter)
+    taps = kernel.shape[-1]
+    frames = (xp.shape[1] - taps) // orig + 1
+    y = torch.empty(B, new, frames, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().evmi_conv1d_f32(xp.data_ptr(), kernel.data_ptr(), 0, 0, y.data_ptr(), B, 1, xp.shape[1], new, taps, orig, 0, 1, 1,
+                                           1.0, 1.0, 0, _lib.current_stream_ptr(x.device)), "evmi_conv1d_f32")
+    return y.transpose(1, 2).reshape(B, -1)[:, : math.ceil(new * S / orig)].contiguous()
+
+
+def loudness(audio: torch.Tensor, lens: torch.Tensor, sample_rate: int) -> torch.Tensor:
+    """Integrated loudness (LKFS) of a zero-padded batch [items, channels, t_max] with lengths [items] -> [items] on the device
+    (torchaudio.transforms.Loudness restated: K-weighting, 400 ms blocks, absolute / relative gates)."""
+    from . import _lib
+
+    if not audio.is_cuda:
+        raise RuntimeError("everyvoice_amd.pipeline.loudness computes on the GPU only (no CPU fallback)")
+    x = audio.to(torch.float32).contiguous()
+    items, channels, t_max = x.shape
+    lib = _lib.load()
+    lens32 = lens.to(x.device, torch.int32).contiguous()
+    y2 = torch.empty_like(x)
+    z = torch.empty(max(1, lib.evmi_loudness_scratch_elems(items, channels, t_max, sample_rate)), device=x.device, dtype=torch.float32)
+    out = torch.empty(items, device=x.device, dtype=torch.float32)
+    _lib.check(lib.evmi_loudness_lkfs_f32(x.data_ptr(), lens32.data_ptr(), y2.data_ptr(), z.data_ptr(), out.data_ptr(), items, channels, t_max,
+                                          int(sample_rate), _lib.current_stream_ptr(x.device)), "evmi_loudness_lkfs_f32")
+    return out
+
+
+LOUDNESS_GATE_LKFS = -36.0  # preprocessor.py:180: "a conservative threshold"
+
+
+def gate_audio(wav_path, cfg: AudioConfig):
+    """The host-side gates of process_audio (file IO and counts): -> (audio [channels, S], sr) or (None, reason)."""
     audio, sr, seconds = load_wav(wav_path)
     if audio.shape[0] > 2:
         return None, "multichannel_files"
@@ -80,18 +155,67 @@ def process_audio(wav_path, cfg: AudioConfig, normalize: bool = True):
         return None, "audio_too_long"
     if seconds < cfg.min_audio_length:
         return None, "audio_too_short"
-    if sr != cfg.input_sampling_rate:
-        raise NotImplementedError(f"{wav_path}: {sr} Hz; resampling is the reference's CPU step (expected {cfg.input_sampling_rate})")
-    if audio.shape[0] == 2:
-        audio = audio.mean(0, keepdim=True)  # sox "channels 1" (the reference's default effect)
-    peak = float(audio.abs().max())
-    if not np.isfinite(peak) or peak == 0.0:
-        return None, "audio_empty"
+    return audio, sr
+
+
+def process_audio_batch(wavs: list[torch.Tensor], sr: int, cfg: AudioConfig, device, normalize: bool = True, resample_rate: int | None = None):
+    """The device part of process_audio for a batch of gated utterances at one source rate: loudness gate -> mix-down -> resample
+    -> peak normalise -> truncate to a multiple of the hop.  wavs: [channels_i, S_i] host tensors.
+    -> (audio [n, t_max] on the device, lens [n] python ints (multiples of the hop), kept indices, {reason: count})."""
+    from . import _lib
+
+    counters: dict[str, int] = {}
+    n = len(wavs)
+    if n == 0:
+        return None, [], [], counters
+    target_sr = resample_rate or sr
+    kept_idx = []
+    keep_mask = torch.ones(n, dtype=torch.bool)
+    # loudness is measured on the file as loaded (all its channels, original rate), before any effect
+    for ch in sorted({w.shape[0] for w in wavs}):
+        idx = [i for i, w in enumerate(wavs) if w.shape[0] == ch]
+        t_max = max(wavs[i].shape[1] for i in idx)
+        batch = torch.zeros(len(idx), ch, t_max)
+        for j, i in enumerate(idx):
+            batch[j, :, : wavs[i].shape[1]] = wavs[i]
+        lk = loudness(batch.to(device), torch.tensor([wavs[i].shape[1] for i in idx]), sr).cpu()
+        for j, i in enumerate(idx):
+            if torch.isnan(lk[j]) or float(lk[j]) < LOUDNESS_GATE_LKFS:
+                keep_mask[i] = False
+                counters["audio_empty"] = counters.get("audio_empty", 0) + 1
+    kept_idx = [i for i in range(n) if keep_mask[i]]
+    if not kept_idx:
+        return None, [], [], counters
+    t_max = max(wavs[i].shape[1] for i in kept_idx)
+    mono = torch.zeros(len(kept_idx), t_max)
+    for j, i in enumerate(kept_idx):
+        mono[j, : wavs[i].shape[1]] = wavs[i].mean(0)  # SoX "channels 1" (the reference's default effect): the channels' mean
+    x = mono.to(device)
+    lens = [wavs[i].shape[1] for i in kept_idx]
+    if target_sr != sr:
+        x = resample(x, sr, target_sr)
+        g = math.gcd(sr, target_sr)
+        lens = [math.ceil((target_sr // g) * L / (sr // g)) for L in lens]
     if normalize:
-        audio = audio / peak * 0.95
-    audio = audio.squeeze(0)
-    n = audio.numel() // cfg.fft_hop_size * cfg.fft_hop_size
-    return audio[:n], sr
+        y = torch.empty_like(x)
+        lens_t = torch.tensor(lens, dtype=torch.int32, device=x.device)
+        _lib.check(_lib.load().evmi_peak_normalize_f32(x.data_ptr(), y.data_ptr(), lens_t.data_ptr(), x.shape[0], x.shape[1], 0.95,
+                                                       _lib.current_stream_ptr(x.device)), "evmi_peak_normalize_f32")
+        x = y
+    lens = [L // cfg.fft_hop_size * cfg.fft_hop_size for L in lens]
+    return x, lens, kept_idx, counters
+
+
+def process_audio(wav_path, cfg: AudioConfig, normalize: bool = True, device="cuda:0", resample_rate: int | None = None):
+    """(audio [S'] on the host, sr) with S' a multiple of the hop, or (None, reason) when the file is skipped
+    (everyvoice/preprocessor/preprocessor.py:131-218)."""
+    audio, info = gate_audio(wav_path, cfg)
+    if audio is None:
+        return None, info
+    x, lens, kept, counters = process_audio_batch([audio], info, cfg, torch.device(device), normalize, resample_rate or cfg.input_sampling_rate)
+    if not kept:
+        return None, next(iter(counters))
+    return x[0, : lens[0]].cpu(), resample_rate or cfg.input_sampling_rate
 
 
 def average_data_by_durations(data: torch.Tensor, durations) -> torch.Tensor:
@@ -104,12 +228,17 @@ def average_data_by_durations(data: torch.Tensor, durations) -> torch.Tensor:
     return torch.tensor(out, dtype=torch.float32)
 
 
-class GpuPreprocessor:
-    """spec + energy (+ normalised audio) of a list of wavs, in the reference's on-disk layout."""
+class ConfigLockMismatch(RuntimeError):
+    """The preprocessed directory was written with another configuration (or an interrupted run): refuse to mix outputs."""
 
-    def __init__(self, cfg: AudioConfig | None = None, device="cuda:0"):
+
+class GpuPreprocessor:
+    """spec + energy (+ normalised audio) of a list of wavs, in the reference's on-disk layout, several utterances per launch."""
+
+    def __init__(self, cfg: AudioConfig | None = None, device="cuda:0", batch_items: int = 32):
         self.cfg = cfg or AudioConfig()
         self.device = torch.device(device)
+        self.batch_items = batch_items
         self.transform = MelSpectrogram(self.cfg.n_fft, self.cfg.fft_window_size, self.cfg.fft_hop_size,
                                         self.cfg.input_sampling_rate, self.cfg.n_mels, self.cfg.f_min, self.cfg.f_max)
         self.counters: dict[str, int] = {}
@@ -121,23 +250,109 @@ class GpuPreprocessor:
         n = x.shape[-1] // self.cfg.fft_hop_size
         return mel[..., :n].contiguous(), energy[..., :n].contiguous()
 
-    def process(self, items: list[dict], save_dir) -> list[dict]:
-        """items: dicts with ``basename``, ``speaker``, ``language``, ``wav``.  Returns the items that were kept."""
+    # -- .config-lock (preprocessor.py:974-1082) ----------------------------------------------------------------------
+    def get_config_lock(self, in_progress: bool = True) -> dict:
+        return {"info": "This file has the configuration that was used to preprocess files. Do not edit.",
+                "status": "in progress" if in_progress else "completed",
+                "preprocessing.audio": self.cfg.model_dump(mode="json"), "preprocessing.source_data": {}, "text": {}}
+
+    def save_config_lock(self, save_dir, in_progress: bool):
+        save_dir = Path(save_dir)
+        save_dir.mkdir(parents=True, exist_ok=True)
+        lock = save_dir / ".config-lock"
+        if lock.exists():
+            lock.chmod(0o666)
+        with open(lock, "w", encoding="utf8") as f:
+            json.dump(self.get_config_lock(in_progress), f, indent=2, ensure_ascii=False)
+            f.write("\n")
+        lock.chmod(0o444)  # read-only: discourages edits
+
+    def config_lock_has_conflicts(self, save_dir) -> bool:
+        lock = Path(save_dir) / ".config-lock"
+        try:
+            saved = json.loads(lock.read_text(encoding="utf8"))
+        except FileNotFoundError:
+            return False
+        except json.JSONDecodeError:
+            return True
+        if saved.get("status") != "completed":  # an interrupted run's partial results cannot be trusted
+            return True
+        return saved.get("preprocessing.audio") != self.get_config_lock()["preprocessing.audio"] or saved.get("text") != {}
+
+    def process(self, items: list[dict], save_dir, overwrite: bool = False) -> list[dict]:
+        """items: dicts with ``basename``, ``speaker``, ``language``, ``wav``.  Returns the items that were kept.  Utterances are
+        gated on the host (file IO), then run through the device pipeline in ragged batches of ``batch_items``: loudness gate,
+        mix-down, resampling to input_sampling_rate, peak normalisation, STFT -> mel -> log + energy in ONE launch per batch."""
+        if self.config_lock_has_conflicts(save_dir) and not overwrite:
+            raise ConfigLockMismatch(f"{save_dir}/.config-lock records another audio configuration or an interrupted run; "
+                                     "preprocess into a new directory or pass overwrite=True")
+        self.save_config_lock(save_dir, in_progress=True)
         kept = []
         sr_tag, spec_fn = self.cfg.input_sampling_rate, f"spec-{self.cfg.input_sampling_rate}-{self.cfg.spec_type}.pt"
+        hop = self.cfg.fft_hop_size
+        pending: dict[int, list] = {}  # source sampling rate -> [(item, audio)]
+
+        def flush(sr):
+            group = pending.pop(sr, [])
+            if not group:
+                return
+            x, lens, kept_idx, counters = process_audio_batch([a for _, a in group], sr, self.cfg, self.device, True, sr_tag)
+            for k, v in counters.items():
+                self.counters[k] = self.counters.get(k, 0) + v
+            if not kept_idx:
+                return
+            t_max = max(lens)
+            x = x[:, :t_max].contiguous()
+            mel, energy = self.transform(x, log=True, return_energy=True, lens=torch.tensor(lens, dtype=torch.int32))
+            x_host, mel_host, energy_host = x.cpu(), mel.cpu(), energy.cpu()
+            for j, i in enumerate(kept_idx):
+                it = group[i][0]
+                ids = (it["basename"], it.get("speaker", "default"), it.get("language", "default"))
+                n, frames = lens[j], lens[j] // hop
+                save_wav(x_host[j, :n], feature_path(save_dir, "audio", *ids, f"audio-{sr_tag}.wav"), sr_tag, self.cfg.target_bit_depth)
+                save_tensor(mel_host[j, :, :frames].clone(), feature_path(save_dir, "spec", *ids, spec_fn))
+                save_tensor(energy_host[j, :frames].clone(), feature_path(save_dir, "energy", *ids, "energy.pt"))
+                self.counters["processed_files"] = self.counters.get("processed_files", 0) + 1
+                kept.append(dict(it, frames=frames, samples=n))
+
         for it in items:
-            audio, info = process_audio(it["wav"], self.cfg)
+            audio, info = gate_audio(it["wav"], self.cfg)
             if audio is None:
                 self.counters[info] = self.counters.get(info, 0) + 1
                 continue
-            mel, energy = self.features(audio)
-            ids = (it["basename"], it.get("speaker", "default"), it.get("language", "default"))
-            save_wav(audio, feature_path(save_dir, "audio", *ids, f"audio-{sr_tag}.wav"), sr_tag, self.cfg.target_bit_depth)
-            save_tensor(mel, feature_path(save_dir, "spec", *ids, spec_fn))
-            save_tensor(energy, feature_path(save_dir, "energy", *ids, "energy.pt"))
-            self.counters["processed_files"] = self.counters.get("processed_files", 0) + 1
-            kept.append(dict(it, frames=mel.shape[1], samples=audio.numel()))
+            pending.setdefault(info, []).append((it, audio))
+            if len(pending[info]) >= self.batch_items:
+                flush(info)
+        for sr in list(pending):
+            flush(sr)
+        self.save_config_lock(save_dir, in_progress=False)
         return kept
+
+    # -- dataset statistics (preprocessor.py:378-490) -------------------------------------------------------------------
+    def compute_stats(self, save_dir, energy: bool = True, pitch: bool = True):
+        """(energy Scaler, pitch Scaler) over every saved ``energy/*energy*`` / ``pitch/*pitch*`` tensor (None where disabled)."""
+        out = []
+        for kind, on in (("energy", energy), ("pitch", pitch)):
+            sc = None
+            if on:
+                sc = Scaler()
+                for path in sorted(glob(str(Path(save_dir) / f"{kind}/**/*{kind}*"), recursive=True)):
+                    sc.append(torch.load(path, weights_only=True).to(self.device))
+            out.append(sc)
+        return tuple(out)
+
+    def normalize_stats(self, save_dir, energy_scaler, pitch_scaler) -> dict:
+        """Standardise every saved energy / pitch tensor with the dataset statistics and return them as the ``stats`` dict that
+        becomes FastSpeech2's ``Stats(pitch=StatsInfo(...), energy=StatsInfo(...))`` (tests/model_stubs.py:50-57)."""
+        stats = {}
+        for kind, sc in (("energy", energy_scaler), ("pitch", pitch_scaler)):
+            if not sc or not len(sc):
+                continue
+            st = sc.calculate_stats()
+            for path in sorted(glob(str(Path(save_dir) / f"{kind}/**/*{kind}*"), recursive=True)):
+                save_tensor(sc.normalize(torch.load(path, weights_only=True).to(self.device)), path)
+            stats[kind] = st
+        return stats
 
 
 def synthesize_from_spec(spec: torch.Tensor, vocoder, out_dir, basename: str, speaker: str = "default",
@@ -228,3 +443,112 @@ def synthesize_from_text(ids: torch.Tensor, lens: torch.Tensor, fs2, vocoder, ou
             rec["wav"] = p
         results.append(rec)
     return results
+
+
+class PredictionWriter:
+    """A prediction writer of the reference's synthesis (``base_cli/prediction_writing_callback.py:14-41``): one per output format;
+    ``get_filename(basename, speaker, language)`` = ``<save_dir>/<basename>--<speaker>--<language>[--ckpt=<step>]--<file_extension>``,
+    ``last_file_written`` is what the demo hands back (``demo/app.py:107-108``)."""
+
+    def __init__(self, save_dir: Path, file_extension: str, global_step: int = 0, include_global_step_in_filename: bool = False):
+        self.file_extension = file_extension
+        self.global_step = f"ckpt={global_step}"
+        self.save_dir = Path(save_dir)
+        self.sep = SEP
+        self.include_global_step_in_filename = include_global_step_in_filename
+        self.save_dir.mkdir(parents=True, exist_ok=True)
+        self.last_file_written = None
+
+    def get_filename(self, basename: str, speaker: str, language: str) -> str:
+        parts = [basename, speaker, language, self.file_extension]
+        if self.include_global_step_in_filename:
+            parts.insert(-1, self.global_step)
+        path = self.save_dir / self.sep.join(parts)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        return str(path)
+
+
+def synthesize_helper(model, texts: list, language: str | None, speaker: str | None, duration_control: float | None, global_step: int, output_type,
+                      text_representation=None, accelerator: str = "auto", devices: str = "1", device=None, batch_size: int = 16, num_workers: int = 0,
+                      filelist=None, filelist_data=None, output_dir: Path = Path("synthesis_output"), teacher_forcing_directory: Path | None = None,
+                      vocoder_model=None, vocoder_config=None, vocoder_global_step: int | None = None, style_reference=None, return_scores: bool = False,
+                      text_to_ids=None):
+    """``fs2.cli.synthesize.synthesize_helper`` (call site ``everyvoice/demo/app.py:84-106``, same keyword names) for the path this
+    library accelerates: texts -> symbol ids -> FastSpeech2 -> (vocoder) -> files through per-format writers.
+    Returns ``(config, device, predictions, callbacks)`` with ``callbacks`` keyed by output format ("wav", "spec").
+
+    ``texts`` are strings mapped to ids by ``text_to_ids`` (the reference's TextProcessor: CPU string work, out of scope) or already
+    lists / tensors of symbol ids; ``filelist_data`` rows (dicts with basename / ids / speaker / language) replace ``texts``.
+    ``teacher_forcing_directory``: read ``duration/<basename>--<speaker>--<language>--duration.pt`` from there and synthesise with
+    those durations -- how the spectrograms for vocoder matching are produced (docs/guides/finetune.md:18-43)."""
+    formats = [getattr(f, "value", f) for f in (output_type if isinstance(output_type, (list, tuple)) else [output_type])]
+    unsupported = [f for f in formats if f not in ("wav", "spec")]
+    if unsupported:
+        raise NotImplementedError(f"output formats {unsupported}: textgrid / readalong outputs belong to the reference's text front-end (out of scope)")
+    dev = torch.device(device) if device is not None else model.device
+    output_dir = Path(output_dir)
+    sr = vocoder_config.preprocessing.audio.output_sampling_rate if vocoder_config is not None else 22050
+    in_sr = vocoder_config.preprocessing.audio.input_sampling_rate if vocoder_config is not None else 22050
+    hop_out = (vocoder_config.preprocessing.audio.fft_hop_size * (sr // in_sr)) if vocoder_config is not None else 256
+    callbacks = {}
+    if "wav" in formats:
+        if vocoder_model is None:
+            raise ValueError("output_type 'wav' needs a vocoder_model")
+        callbacks["wav"] = PredictionWriter(output_dir / "wav", "pred.wav", vocoder_global_step or 0, include_global_step_in_filename=False)
+    if "spec" in formats:
+        callbacks["spec"] = PredictionWriter(output_dir / "synthesized_spec", f"spec-pred-{in_sr}-mel-librosa.pt", global_step)
+    rows = []
+    if filelist_data is not None:
+        rows = [dict(r) for r in filelist_data]
+    else:
+        for i, t in enumerate(texts):
+            ids = text_to_ids(t) if isinstance(t, str) else t
+            if isinstance(t, str) and text_to_ids is None:
+                raise ValueError("synthesize_helper: pass text_to_ids (text -> symbol ids) or symbol ids; text processing is host-side string work")
+            rows.append({"basename": f"utt-{i:04d}" if not isinstance(t, str) else "".join(c if c.isalnum() else "-" for c in t)[:20] or f"utt-{i:04d}",
+                         "ids": ids, "speaker": speaker, "language": language})
+    predictions = []
+    for lo in range(0, len(rows), batch_size):
+        chunk = rows[lo : lo + batch_size]
+        lens = torch.tensor([len(r["ids"]) for r in chunk])
+        ids = torch.zeros(len(chunk), int(lens.max()), dtype=torch.long)
+        for j, r in enumerate(chunk):
+            ids[j, : lens[j]] = torch.as_tensor(r["ids"], dtype=torch.long)
+        kw = {}
+        spk = [r.get("speaker") or speaker or "default" for r in chunk]
+        lang = [r.get("language") or language or "default" for r in chunk]
+        if getattr(model, "speaker2id", None) and getattr(model.config, "multispeaker", False):
+            kw["speakers"] = torch.tensor([model.speaker2id[s] for s in spk])
+        if getattr(model, "lang2id", None) and getattr(model.config, "multilingual", False):
+            kw["languages"] = torch.tensor([model.lang2id[x] for x in lang])
+        if teacher_forcing_directory is not None:
+            durs = torch.zeros_like(ids)
+            for j, r in enumerate(chunk):
+                d = torch.load(Path(teacher_forcing_directory) / "duration" / SEP.join([r["basename"], spk[j], lang[j], "duration.pt"]), weights_only=True)
+                durs[j, : lens[j]] = d[: lens[j]].long()
+            kw["durations"] = durs
+        _, post, durations, _, _, mel_lens = model(ids, lens, duration_control=1.0 if duration_control is None else duration_control, **kw)
+        wav = vocoder_model(post.transpose(1, 2).contiguous()) if "wav" in formats else None
+        for j, r in enumerate(chunk):
+            T = int(mel_lens[j])
+            rec = {"basename": r["basename"], "speaker": spk[j], "language": lang[j], "frames": T, "durations": durations[j, : int(lens[j])].cpu()}
+            if "spec" in formats:
+                path = callbacks["spec"].get_filename(r["basename"], spk[j], lang[j])
+                save_tensor(post[j, :T].transpose(0, 1).contiguous(), path)
+                callbacks["spec"].last_file_written = rec["spec"] = path
+            if wav is not None:
+                path = callbacks["wav"].get_filename(r["basename"], spk[j], lang[j])
+                save_wav(wav[j, 0, : T * hop_out], path, sr)
+                callbacks["wav"].last_file_written = rec["wav"] = path
+            predictions.append(rec)
+    return model.config, dev, predictions, callbacks
+
+
+def generate_teacher_forced_specs(model, filelist_data: list[dict], preprocessed_dir, global_step: int = 0, batch_size: int = 16):
+    """Vocoder matching, step 1 (docs/guides/finetune.md:18-43: ``everyvoice synthesize from-text ... -O spec
+    --teacher-forcing-directory <preprocessed>``): the feature-prediction network's spectrogram of every training utterance under its
+    ground-truth durations, written next to the real features as ``synthesized_spec/...--spec-pred-<sr>-mel-librosa.pt`` -- what
+    ``training.finetune: true`` then feeds the vocoder (dataset.SpecDataset)."""
+    _, _, preds, callbacks = synthesize_helper(model, [], None, None, 1.0, global_step, ["spec"], filelist_data=filelist_data,
+                                               output_dir=Path(preprocessed_dir), teacher_forcing_directory=Path(preprocessed_dir), batch_size=batch_size)
+    return preds

@@ -79,7 +79,10 @@ class MelSpectrogram:
             self._dev[device] = (self._basis_host.to(device), self._mel_host.to(device))
         return self._dev[device]
 
-    def __call__(self, audio: torch.Tensor, log: bool = False, return_energy: bool = False, return_magnitude: bool = False):
+    def __call__(self, audio: torch.Tensor, log: bool = False, return_energy: bool = False, return_magnitude: bool = False,
+                 lens: torch.Tensor | None = None):
+        """``lens`` [B] (int32, device): a ragged batch -- rows of ``audio`` are zero-padded utterances; item b is transformed as if
+        alone (reflection at its own end), its valid frames are the first ``1 + lens[b] // hop`` of its row."""
         if not audio.is_cuda:
             raise RuntimeError("everyvoice_amd.spectral computes on the GPU only (no CPU fallback)")
         squeeze = audio.dim() == 1
@@ -92,12 +95,21 @@ class MelSpectrogram:
         mag = torch.empty(B, self.n_fft // 2 + 1, frames, device=x.device, dtype=torch.float32) if return_magnitude else None
         lib = _lib.load()
         with torch.cuda.device(x.device):
-            _lib.check(
-                lib.evmi_mel_spectrogram_f32(x.data_ptr(), basis.data_ptr(), melb.data_ptr(), mel.data_ptr(), _lib.ptr(energy),
-                                             _lib.ptr(mag), B, S, self.n_fft, self.hop, self.nb_pad, self.n_mels, int(log),
-                                             _lib.current_stream_ptr(x.device)),
-                "evmi_mel_spectrogram_f32",
-            )
+            if lens is not None:
+                lens = lens.to(x.device, torch.int32).contiguous()
+                _lib.check(
+                    lib.evmi_mel_spectrogram_ragged_f32(x.data_ptr(), lens.data_ptr(), basis.data_ptr(), melb.data_ptr(), mel.data_ptr(),
+                                                        _lib.ptr(energy), _lib.ptr(mag), B, S, self.n_fft, self.hop, self.nb_pad, self.n_mels,
+                                                        int(log), _lib.current_stream_ptr(x.device)),
+                    "evmi_mel_spectrogram_ragged_f32",
+                )
+            else:
+                _lib.check(
+                    lib.evmi_mel_spectrogram_f32(x.data_ptr(), basis.data_ptr(), melb.data_ptr(), mel.data_ptr(), _lib.ptr(energy),
+                                                 _lib.ptr(mag), B, S, self.n_fft, self.hop, self.nb_pad, self.n_mels, int(log),
+                                                 _lib.current_stream_ptr(x.device)),
+                    "evmi_mel_spectrogram_f32",
+                )
         shape = tuple(audio.shape[:-1])
         outs = [mel[0] if squeeze else mel.reshape(shape + mel.shape[1:])]
         if return_energy:

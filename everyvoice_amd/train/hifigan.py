@@ -537,6 +537,18 @@ class HiFiGANTrainer:
                 "hyper_parameters": {"config": self.config.model_dump(mode="json")},
                 "model_info": {"name": "HiFiGANGenerator", "version": self._VERSION}}
 
+    def generate(self, mel_bct: torch.Tensor) -> torch.Tensor:
+        """The generator alone with the current training weights (validation / synthesis during training): mel [B, n_mels, F]
+        -> wav [B, 1, F * hop], no tape kept."""
+        prev = ops.CONV_BACKEND["operands"]
+        ops.CONV_BACKEND["operands"] = self.precision
+        try:
+            self._materialize(self.generator.layers())
+            y = self.generator.forward(ag.Tape(), ag.Var(_to_cbt_kernel(mel_bct.to(self.device, torch.float32)), needs_grad=False))
+        finally:
+            ops.CONV_BACKEND["operands"] = prev
+        return y.data.view(mel_bct.shape[0], 1, -1)  # [1, B, T] and [B, 1, T] are the same bytes
+
     def _materialize(self, layers):
         batches = []
         for layer in layers:

@@ -112,6 +112,13 @@ int evmi_mel_spectrogram_f32(const float* audio_dev, const float* dft_basis_dev,
                              const float* mel_basis_dev, float* mel_dev, float* energy_dev,
                              float* mag_dev, int B, int n_samples, int n_fft, int hop,
                              int n_bins_padded, int n_mels, int apply_log, void* stream);
+/* The same transform on a RAGGED batch -- how the batched preprocessor packs several utterances into one launch (SURVEY.md 8f
+ * N2): audio [B][n_samples_max] zero padded, lens [B]; item b reflects at its own end and its frames 0 .. lens[b] / hop are
+ * exactly what evmi_mel_spectrogram_f32 gives for that utterance alone (later frames of its row are padding: ignore them). */
+int evmi_mel_spectrogram_ragged_f32(const float* audio_dev, const int* lens_dev, const float* dft_basis_dev,
+                                    const float* mel_basis_dev, float* mel_dev, float* energy_dev, float* mag_dev, int B,
+                                    int n_samples_max, int n_fft, int hop, int n_bins_padded, int n_mels, int apply_log,
+                                    void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * HiFiGAN / iSTFTNet generator — replaces the forward of `hfgl.utils.HiFiGANGenerator` /
@@ -366,6 +373,21 @@ int evmi_ratio_accumulate_f32(float* out_dev, const float* sq_dev, float weight,
 int evmi_adamw_f32(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr,
                    float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Audio gating of the preprocessor (everyvoice/preprocessor/preprocessor.py:131-218).
+ * evmi_loudness_lkfs_f32: integrated loudness (ITU-R BS.1770-4 as torchaudio.transforms.Loudness computes it: K-weighting
+ * biquads, 400 ms blocks at 75 % overlap, absolute -70 and relative -10 LU gates) of `items` zero-padded utterances
+ * x [items][channels][t_max] with lens [items]; the reference skips a file when the value is NaN or below -36
+ * (preprocessor.py:177-185).  Scratch: y2 [items * channels * t_max] floats, z [evmi_loudness_scratch_elems(...)] floats.
+ * evmi_peak_normalize_f32: dst = src / max|src| * target per utterance (preprocessor.py:199-201, target 0.95), zeros past lens.
+ * Resampling (preprocessor.py:196-198, torchaudio.functional.resample) is evmi_conv1d_f32 with the windowed-sinc polyphase
+ * kernel built by the host (everyvoice_amd/pipeline.py: sinc_resample_kernel). */
+int evmi_loudness_lkfs_f32(const float* x_dev, const int* lens_dev, float* y2_scratch_dev, float* z_scratch_dev,
+                           float* lkfs_dev, int items, int channels, int t_max, int sample_rate, void* stream);
+long long evmi_loudness_scratch_elems(int items, int channels, int t_max, int sample_rate);
+int evmi_peak_normalize_f32(const float* src_dev, float* dst_dev, const int* lens_dev, int items, int t_max, float target,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * FastSpeech2 feature-prediction forward path, channel-major fp32 x[c][b][t].

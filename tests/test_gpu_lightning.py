@@ -1,0 +1,147 @@
+"""The module contract on the GPU: ``train_base_command`` with the real classes (HiFiGAN over the libevmi_hip trainer, the data
+module over a GPU-preprocessed directory), checkpoint -> resume, the FastSpeech2 module's checkpoint conventions, and the
+vocoder-matching loop (teacher-forced spectrograms -> ``training.finetune``).  Reference pins: base_cli/helpers.py:173-375,
+tests/test_model.py:85-151, 302-313; docs/guides/finetune.md:18-43; demo/app.py:84-106."""
+
+import json
+import wave
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_wav(path, x, sr=22050):
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(sr)
+        w.writeframes(np.clip(np.round(np.asarray(x) * 32767), -32768, 32767).astype("<i2").tobytes())
+
+
+@pytest.fixture()
+def dataset(tmp_path, cuda_device):
+    from everyvoice_amd import pipeline
+    from everyvoice_amd.config import HiFiGANConfig
+
+    gen = torch.Generator().manual_seed(0)
+    items = []
+    for i, n in enumerate([40000, 30000, 52000, 25000, 36000, 45000]):
+        _write_wav(tmp_path / f"u{i}.wav", 0.3 * torch.tanh(torch.randn(n, generator=gen)).numpy())
+        items.append(dict(basename=f"u{i}", speaker="default", language="default", wav=tmp_path / f"u{i}.wav"))
+    kept = pipeline.GpuPreprocessor(device=cuda_device).process(items, tmp_path / "pre")
+    rows = ["basename|speaker|language"] + [f"{k['basename']}|default|default" for k in kept]
+    (tmp_path / "train.psv").write_text("\n".join(rows) + "\n")
+    (tmp_path / "val.psv").write_text("\n".join(rows[:3]) + "\n")
+    cfg = HiFiGANConfig(preprocessing=dict(save_dir=tmp_path / "pre"),
+                        training=dict(training_filelist=tmp_path / "train.psv", validation_filelist=tmp_path / "val.psv", batch_size=2, train_data_workers=0,
+                                      max_steps=4, val_check_interval=2, save_top_k_ckpts=1, logger=dict(save_dir=tmp_path / "logs", name="exp")))
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg.model_dump(mode="json")))
+    return tmp_path, cfg, kept
+
+
+def test_train_base_command_trains_checkpoints_and_resumes(dataset, cuda_device):
+    from everyvoice_amd.config import HiFiGANConfig
+    from everyvoice_amd.dataset import HiFiGANDataModule
+    from everyvoice_amd.lightning import HiFiGAN, train_base_command
+
+    root, cfg, _ = dataset
+    calls = []
+    m = train_base_command(HiFiGANConfig, HiFiGANDataModule, HiFiGAN, "validation/mel_spec_error", [], root / "cfg.json", accelerator="gpu", devices="1",
+                           nodes=1, strategy="ddp", gradient_clip_val=None, calls=calls)
+    assert m.global_step == 4 and [c[1] for c in calls if c[0] == "validate"] == [2, 4]
+    assert m.logged["training/gen/loss_total"] > 0 and m.logged["validation/mel_spec_error"] > 0
+    run = next((root / "logs" / "exp" / "base").iterdir())
+    ck = torch.load(run / "checkpoints" / "last.ckpt", weights_only=True)
+    assert ck["model_info"] == {"name": "HiFiGAN", "version": "1.0"} and ck["global_step"] == 4
+    json.dumps(ck["hyper_parameters"])
+    assert "training_filelist" not in ck["hyper_parameters"]["config"]["training"]
+    # resume: weights, optimiser moments and step counters come back; training continues to the new max_steps
+    m2 = train_base_command(HiFiGANConfig, HiFiGANDataModule, HiFiGAN, "validation/mel_spec_error",
+                            [f"training.finetune_checkpoint={json.dumps(str(run / 'checkpoints' / 'last.ckpt'))}", "training.max_steps=6"], root / "cfg.json",
+                            accelerator="gpu", devices="1")
+    assert m2.global_step == 6 and m2.trainer_.g_params.step == 6 and int(m2.trainer_.g_params.step_dev.item()) == 6
+    # the module classes load each other's files only when they are theirs
+    from everyvoice_amd.lightning import FastSpeech2
+
+    with pytest.raises(TypeError, match=r"Wrong model type \(HiFiGAN\), we are expecting a 'FastSpeech2' model"):
+        FastSpeech2.load_from_checkpoint(run / "checkpoints" / "last.ckpt")
+
+
+def test_fastspeech2_module_contract_and_vocoder_matching_loop(dataset, cuda_device, tmp_path):
+    from everyvoice_amd import pipeline
+    from everyvoice_amd.config import HiFiGANConfig
+    from everyvoice_amd.dataset import HiFiGANDataModule, SpecDataset
+    from everyvoice_amd.fs2 import FastSpeech2 as FastSpeech2Infer
+    from everyvoice_amd.fs2 import ConformerConfig, FastSpeech2ModelConfig, Stats, StatsInfo, VariancePredictorConfig, VariancePredictors
+    from everyvoice_amd.lightning import FastSpeech2, FastSpeech2Config
+    from everyvoice_amd.vocoder import HiFiGANGenerator
+
+    root, cfg, kept = dataset
+    conf = ConformerConfig(layers=2, heads=2, input_dim=64, feedforward_dim=128, conv_kernel_size=5)
+    vp = VariancePredictorConfig(n_layers=2, kernel_size=3, input_dim=64, n_bins=16)
+    mc = FastSpeech2ModelConfig(encoder=conf, decoder=ConformerConfig(**conf.__dict__), n_symbols=20, n_mels=80, postnet_channels=32,
+                                variance_predictors=VariancePredictors(energy=vp, duration=VariancePredictorConfig(**vp.__dict__), pitch=VariancePredictorConfig(**vp.__dict__)),
+                                learn_alignment=False)
+    stats = Stats(pitch=StatsInfo(min=0, max=1, std=2, mean=3, norm_min=-2, norm_max=2), energy=StatsInfo(min=7, max=8, std=9, mean=10, norm_min=-2, norm_max=2))
+    model = FastSpeech2(FastSpeech2Config(model=mc), stats=stats, lang2id={"foo": 0, "bar": 1}, speaker2id={"baz": 0, "qux": 1}, device=cuda_device, precision="f32")
+    assert model.hparams.config is model.config
+    g = torch.Generator().manual_seed(3)
+    L = 12
+    ids = torch.randint(1, 20, (2, L), generator=g)
+    durs = torch.randint(1, 4, (2, L), generator=g)
+    T = int(durs.sum(1).max())
+    batch = dict(ids=ids, lens=torch.tensor([L, L]), durations=durs, mel=torch.randn(2, T, 80, generator=g), pitch=torch.randn(2, L, generator=g),
+                 energy=torch.randn(2, L, generator=g))
+    first = model.training_step(batch, 0)
+    for _ in range(3):
+        last = model.training_step(batch, 0)
+    assert last["total"] < first["total"] and model.global_step == 4
+    path = tmp_path / "fs2.ckpt"
+    model.save_checkpoint(path)
+    ck = torch.load(path, weights_only=True)
+    json.dumps(ck["hyper_parameters"])  # JSON-only (tests/test_model.py:85-151)
+    assert ck["model_info"] == {"name": "FastSpeech2", "version": "1.0"} and ck["hyper_parameters"]["speaker2id"] == {"baz": 0, "qux": 1}
+    again = FastSpeech2.load_from_checkpoint(path, device=cuda_device, precision="f32")
+    assert again.global_step == 4 and again.stats.pitch.norm_max == 2 and again.lang2id == {"foo": 0, "bar": 1}
+    for k, v in model.state_dict().items():
+        assert torch.equal(v.cpu(), again.state_dict()[k].cpu()), k
+
+    # vocoder matching: teacher-forced spectrograms of the training utterances under their durations -> finetune dataset
+    infer = FastSpeech2Infer(mc, device=cuda_device).load_state_dict(model.state_dict())
+    rows = []
+    for k in kept[:3]:
+        n_tok = 10
+        d = torch.full((n_tok,), k["frames"] // n_tok)
+        d[-1] += k["frames"] - int(d.sum())
+        pipeline.save_tensor(d, pipeline.feature_path(root / "pre", "duration", k["basename"], "default", "default", "duration.pt"))
+        rows.append(dict(basename=k["basename"], speaker="default", language="default", ids=torch.randint(1, 20, (n_tok,), generator=g)))
+    preds = pipeline.generate_teacher_forced_specs(infer, rows, root / "pre", global_step=4)
+    for p, k in zip(preds, kept[:3]):
+        assert Path(p["spec"]).name == f"{k['basename']}--default--default--spec-pred-22050-mel-librosa.pt"
+        assert torch.load(p["spec"]).shape == (80, k["frames"])  # same frame count as the real features: the crop offsets line up
+    cfg.training.finetune = True
+    dm = HiFiGANDataModule(cfg)
+    assert sorted(x["basename"] for x in dm.train_dataset) == sorted(k["basename"] for k in kept[:3])
+    spec, audio, _, spec_real = SpecDataset(dm.train_dataset, cfg, use_segments=True)[0]
+    assert spec.shape == spec_real.shape == (80, 32) and not torch.equal(spec, spec_real)
+
+    # synthesize_helper with the reference's keyword surface: ids -> FastSpeech2 -> vocoder -> wav + spec files via the writers
+    voc = HiFiGANGenerator(HiFiGANConfig(), precision="bf16").to(cuda_device).eval()
+    infer.duration_predictor.b_lin.fill_(1.0)  # a few frames per token instead of the zeros a random predictor gives
+    config, device, predictions, callbacks = pipeline.synthesize_helper(
+        model=infer, style_reference=None, vocoder_model=voc, vocoder_config=HiFiGANConfig(), texts=[[3, 4, 5, 6, 7, 8], [9, 2, 2, 5]], language=None,
+        accelerator="gpu", devices="1", device=cuda_device, global_step=4, vocoder_global_step=7, output_type=("spec", "wav"), text_representation="characters",
+        output_dir=tmp_path / "out", speaker=None, duration_control=1.0, filelist=None, filelist_data=None, teacher_forcing_directory=None, batch_size=16,
+        num_workers=1)
+    assert config is infer.config and len(predictions) == 2 and set(callbacks) == {"spec", "wav"}
+    assert callbacks["wav"].last_file_written == predictions[-1]["wav"] and Path(predictions[0]["wav"]).name == "utt-0000--default--default--pred.wav"
+    for p in predictions:
+        with wave.open(p["wav"]) as w:
+            assert w.getframerate() == 22050 and w.getnframes() == p["frames"] * 256
+        assert torch.load(p["spec"]).shape == (80, p["frames"])
+    with pytest.raises(NotImplementedError, match="textgrid"):
+        pipeline.synthesize_helper(infer, [[1, 2]], None, None, 1.0, 0, ["textgrid"], vocoder_model=voc)

@@ -20,7 +20,7 @@ def _write_wav(path, x, sr=22050, ch=1):
         w.writeframes(pcm.tobytes())
 
 
-def test_wav_round_trip_and_gates(tmp_path, golden_dir):
+def test_wav_round_trip_and_host_gates(tmp_path, golden_dir):
     g = np.load(golden_dir / "mel_anchor.npz")
     pcm = g["pcm"]
     p = tmp_path / "a.wav"
@@ -29,21 +29,47 @@ def test_wav_round_trip_and_gates(tmp_path, golden_dir):
     assert sr == 22050 and audio.shape == (1, len(pcm)) and abs(sec - len(pcm) / 22050) < 1e-9
     assert np.array_equal(np.round(audio[0].numpy() * 32768).astype(np.int16), pcm)  # bit-exact PCM decode
     cfg = AudioConfig()
-    out, sr2 = pipeline.process_audio(p, cfg)
-    assert out.numel() % 256 == 0 and len(pcm) - out.numel() < 256  # test_preprocessing.py:356-383 invariant
-    assert abs(float(out.abs().max()) - 0.95) < 1e-6
-    pipeline.save_wav(out, tmp_path / "sub" / "o.wav", sr2)
+    got, sr2 = pipeline.gate_audio(p, cfg)
+    assert sr2 == 22050 and torch.equal(got, audio)
+    pipeline.save_wav(audio[0] * 0.5, tmp_path / "sub" / "o.wav", sr2)
     back, _, _ = pipeline.load_wav(tmp_path / "sub" / "o.wav")
-    assert float((back[0] - out).abs().max()) <= 1.0 / 32768 + 1e-7
-    # gates (test_preprocessing.py:109-160): too short, too long, > 2 channels, empty
+    assert float((back[0] - audio[0] * 0.5).abs().max()) <= 1.0 / 32768 + 1e-7
+    # host gates (test_preprocessing.py:109-160): too short, too long, > 2 channels
     _write_wav(tmp_path / "short.wav", np.zeros(2000) + 0.1)
-    assert pipeline.process_audio(tmp_path / "short.wav", cfg) == (None, "audio_too_short")
+    assert pipeline.gate_audio(tmp_path / "short.wav", cfg) == (None, "audio_too_short")
     _write_wav(tmp_path / "long.wav", np.zeros(22050 * 12) + 0.1)
-    assert pipeline.process_audio(tmp_path / "long.wav", cfg) == (None, "audio_too_long")
+    assert pipeline.gate_audio(tmp_path / "long.wav", cfg) == (None, "audio_too_long")
     _write_wav(tmp_path / "multi.wav", np.zeros(22050 * 4) + 0.1, ch=4)
-    assert pipeline.process_audio(tmp_path / "multi.wav", cfg) == (None, "multichannel_files")
-    _write_wav(tmp_path / "zeros.wav", np.zeros(22050))
-    assert pipeline.process_audio(tmp_path / "zeros.wav", cfg) == (None, "audio_empty")
+    assert pipeline.gate_audio(tmp_path / "multi.wav", cfg) == (None, "multichannel_files")
+
+
+def test_resample_filter_bank_and_config_lock(tmp_path):
+    from oracle.preprocess_ref import sinc_kernel_ref
+
+    for orig, new in ((44100, 22050), (48000, 22050), (16000, 22050)):
+        k, width, o, n = pipeline.sinc_resample_kernel(orig, new)
+        kr, wr, o_r, n_r = sinc_kernel_ref(orig, new)
+        assert (width, o, n) == (wr, o_r, n_r) and k.shape == kr.shape == (n, 1, 2 * width + o)
+        torch.testing.assert_close(k, kr, rtol=0, atol=1e-7)
+    # .config-lock (preprocessor.py:974-1082): written read-only, "in progress" while running; a later run with another audio
+    # configuration, or after an interrupted run, is refused
+    pre = pipeline.GpuPreprocessor(AudioConfig(), device="cpu")
+    assert not pre.config_lock_has_conflicts(tmp_path)
+    pre.save_config_lock(tmp_path, in_progress=True)
+    lock = tmp_path / ".config-lock"
+    import json
+    import stat
+
+    saved = json.loads(lock.read_text())
+    assert saved["status"] == "in progress" and saved["preprocessing.audio"]["n_fft"] == 1024 and "Do not edit" in saved["info"]
+    assert not (lock.stat().st_mode & stat.S_IWUSR)
+    assert pre.config_lock_has_conflicts(tmp_path)  # interrupted run
+    pre.save_config_lock(tmp_path, in_progress=False)
+    assert not pre.config_lock_has_conflicts(tmp_path)
+    other = pipeline.GpuPreprocessor(AudioConfig(n_fft=2048, fft_window_size=2048, fft_hop_size=512), device="cpu")
+    assert other.config_lock_has_conflicts(tmp_path)
+    with pytest.raises(pipeline.ConfigLockMismatch):
+        other.process([], tmp_path)
 
 
 def test_paths_and_phone_average(tmp_path):
@@ -83,3 +109,87 @@ def test_preprocess_then_copy_synthesis(tmp_path, golden_dir, cuda_device):
     assert out.name == "LJ010-0008--default--default--pred.wav"
     y, sr, _ = pipeline.load_wav(out)
     assert sr == 22050 and y.shape == (1, spec.shape[1] * 256)
+
+
+@pytest.mark.gpu
+def test_process_audio_gates_and_normalisation(tmp_path, golden_dir, cuda_device):
+    g = np.load(golden_dir / "mel_anchor.npz")
+    pcm = g["pcm"]
+    p = tmp_path / "a.wav"
+    _write_wav(p, pcm.astype(np.float32) / 32767.0)
+    cfg = AudioConfig()
+    out, sr2 = pipeline.process_audio(p, cfg, device=cuda_device)
+    assert out.numel() % 256 == 0 and len(pcm) - out.numel() < 256  # test_preprocessing.py:356-383 invariant
+    assert abs(float(out.abs().max()) - 0.95) < 1e-6 and sr2 == 22050
+    _write_wav(tmp_path / "zeros.wav", np.zeros(22050))
+    assert pipeline.process_audio(tmp_path / "zeros.wav", cfg, device=cuda_device) == (None, "audio_empty")
+    _write_wav(tmp_path / "quiet.wav", 1e-3 * np.sin(np.arange(22050) * 0.1))  # about -63 LUFS: below the -36 gate
+    assert pipeline.process_audio(tmp_path / "quiet.wav", cfg, device=cuda_device) == (None, "audio_empty")
+
+
+@pytest.mark.gpu
+def test_loudness_and_resampling_match_the_restated_torchaudio(cuda_device):
+    from oracle.preprocess_ref import loudness_ref, resample_ref
+
+    gen = torch.Generator().manual_seed(5)
+    items = [0.3 * torch.tanh(torch.randn(1, 30000, generator=gen)), 0.02 * torch.randn(1, 22050, generator=gen),
+             torch.sin(torch.arange(40000) * 0.05)[None] * torch.linspace(0, 1, 40000)[None]]
+    t_max = max(x.shape[1] for x in items)
+    batch = torch.zeros(len(items), 1, t_max)
+    for i, x in enumerate(items):
+        batch[i, :, : x.shape[1]] = x
+    got = pipeline.loudness(batch.to(cuda_device), torch.tensor([x.shape[1] for x in items]), 22050).cpu()
+    for i, x in enumerate(items):
+        assert float(got[i]) == pytest.approx(loudness_ref(x, 22050), abs=2e-3), i  # dB
+    stereo = torch.stack([items[0][0, :22050], 0.5 * items[1][0]])[None]
+    got2 = pipeline.loudness(stereo.to(cuda_device), torch.tensor([22050]), 22050).cpu()
+    assert float(got2[0]) == pytest.approx(loudness_ref(stereo[0], 22050), abs=2e-3)
+    for orig, new in ((44100, 22050), (48000, 22050), (16000, 22050)):
+        x = 0.3 * torch.tanh(torch.randn(2, 12345, generator=gen))
+        want = resample_ref(x, orig, new)
+        out = pipeline.resample(x.to(cuda_device), orig, new).cpu()
+        assert out.shape == want.shape
+        torch.testing.assert_close(out, want, rtol=0, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_batched_preprocessing_equals_one_by_one_and_dataset_statistics(tmp_path, cuda_device):
+    """N2: several utterances of different lengths (and one at 44.1 kHz, one stereo) per launch give exactly the files the
+    one-utterance path writes; then compute_stats / normalize_stats (A8) over the energy files."""
+    from oracle import mel_ref
+
+    gen = torch.Generator().manual_seed(9)
+    items = []
+    for i, (n, sr, ch) in enumerate([(30000, 22050, 1), (12000, 22050, 1), (45000, 22050, 2), (50000, 44100, 1), (9000, 22050, 1)]):
+        x = 0.3 * torch.tanh(torch.randn(n * ch, generator=gen)).numpy()
+        _write_wav(tmp_path / f"u{i}.wav", x, sr=sr, ch=ch)
+        items.append(dict(basename=f"u{i}", speaker="default", language="default", wav=tmp_path / f"u{i}.wav"))
+    _write_wav(tmp_path / "silent.wav", np.zeros(22050))
+    items.append(dict(basename="silent", speaker="default", language="default", wav=tmp_path / "silent.wav"))
+    batched = pipeline.GpuPreprocessor(device=cuda_device, batch_items=8)
+    kept = batched.process(items, tmp_path / "b")
+    single = pipeline.GpuPreprocessor(device=cuda_device, batch_items=1)
+    kept1 = single.process(items, tmp_path / "s")
+    assert [k["basename"] for k in kept] and sorted(k["basename"] for k in kept) == sorted(k["basename"] for k in kept1) == [f"u{i}" for i in range(5)]
+    assert batched.counters == single.counters and batched.counters["audio_empty"] == 1 and batched.counters["processed_files"] == 5
+    for k in kept:
+        for kind, fn in (("spec", "spec-22050-mel-librosa.pt"), ("energy", "energy.pt")):
+            a = torch.load(tmp_path / "b" / kind / f"{k['basename']}--default--default--{fn}")
+            b = torch.load(tmp_path / "s" / kind / f"{k['basename']}--default--default--{fn}")
+            assert torch.equal(a, b), (k["basename"], kind)
+        wa, _, _ = pipeline.load_wav(tmp_path / "b" / "audio" / f"{k['basename']}--default--default--audio-22050.wav")
+        wb, _, _ = pipeline.load_wav(tmp_path / "s" / "audio" / f"{k['basename']}--default--default--audio-22050.wav")
+        assert torch.equal(wa, wb) and wa.shape[1] == k["samples"] == k["frames"] * 256
+        spec = torch.load(tmp_path / "b" / "spec" / f"{k['basename']}--default--default--spec-22050-mel-librosa.pt")
+        assert float((spec - mel_ref.mel_spectrogram_ref(wa[0], truncate=True)).abs().max()) <= 3e-3  # (the saved wav is PCM-16 quantised)
+    assert (tmp_path / "b" / ".config-lock").exists()
+    # dataset statistics of the energy files, then their standardisation in place
+    es, ps = batched.compute_stats(tmp_path / "b", pitch=True)
+    assert len(es) == 5 and len(ps) == 0
+    allv = torch.cat([torch.load(p) for p in sorted((tmp_path / "b" / "energy").iterdir())])
+    stats = batched.normalize_stats(tmp_path / "b", es, ps)
+    assert set(stats) == {"energy"} and stats["energy"]["sample_size"] == 5
+    assert stats["energy"]["mean"] == pytest.approx(float(allv.mean()), rel=1e-5) and stats["energy"]["std"] == pytest.approx(float(allv.std()), rel=1e-5)
+    normed = torch.cat([torch.load(p) for p in sorted((tmp_path / "b" / "energy").iterdir())])
+    assert abs(float(normed.mean())) < 1e-4 and float(normed.std()) == pytest.approx(1.0, rel=1e-4)
+    assert stats["energy"]["norm_min"] == pytest.approx(float(normed.min()), rel=1e-4)
