@@ -157,6 +157,10 @@ SYMBOLS = {
     "evmi_weight_norm_bwd_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "evmi_normalize_vec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "evmi_optimizer_step_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_longlong] + [C.c_float] * 5 + [C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
+    "evmi_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "evmi_comm_init_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int]),
+    "evmi_comm_destroy": (C.c_int, [C.c_void_p]),
+    "evmi_allreduce_bucket": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p]),
     "evmi_loudness_lkfs_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_loudness_scratch_elems": (C.c_longlong, [C.c_int] * 4),
     "evmi_peak_normalize_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),

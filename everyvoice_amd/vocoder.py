@@ -140,12 +140,24 @@ class Generator(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     # -- native object ----------------------------------------------------------------------------
-    def _ensure_native(self, device: torch.device):
+    def _new_handle(self, device_index: int):
         lib = _lib.load()
-        if self._handle is None:
-            h = C.c_void_p()
-            _lib.check(lib.evmi_generator_create(C.byref(self._c_cfg), device.index or 0, C.byref(h)), "evmi_generator_create")
-            object.__setattr__(self, "_handle", h)
+        old = self.__dict__.get("_handle")
+        if old is not None:
+            lib.evmi_generator_destroy(old)
+        h = C.c_void_p()
+        _lib.check(lib.evmi_generator_create(C.byref(self._c_cfg), device_index, C.byref(h)), "evmi_generator_create")
+        object.__setattr__(self, "_handle", h)
+        object.__setattr__(self, "_handle_device", device_index)
+        self._uploaded_version = None
+
+    def _ensure_native(self, device: torch.device):
+        """The native object (weights in kernel layouts + workspace) lives on ONE device: it is created for the device of the
+        first input and re-created -- weights uploaded again -- when the module is used on another one."""
+        lib = _lib.load()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        if self._handle is None or self.__dict__.get("_handle_device") != index:
+            self._new_handle(index)
         ver = self._weights_version()
         if self._uploaded_version != ver:
             for name, p in self.named_parameters():
@@ -154,7 +166,8 @@ class Generator(nn.Module):
                     lib.evmi_generator_set_weight(self._handle, name.encode(), host.data_ptr(), host.numel()),
                     f"evmi_generator_set_weight({name})",
                 )
-            _lib.check(lib.evmi_generator_finalize(self._handle), "evmi_generator_finalize")
+            with torch.cuda.device(index):  # finalize uploads to the handle's device: the caller's current device is left alone
+                _lib.check(lib.evmi_generator_finalize(self._handle), "evmi_generator_finalize")
             self._uploaded_version = ver
         return lib
 
@@ -174,12 +187,17 @@ class Generator(nn.Module):
         return h * self.config.gen_istft_hop_size if self.config.model.istft_layer else h
 
     def macs_per_sample(self) -> float:
+        """Multiply-accumulates per output sample of this configuration (host arithmetic: a throw-away native object when the
+        module has not run yet, so asking does not pin the module to a device)."""
         lib = _lib.load()
-        if self._handle is None:
-            h = C.c_void_p()
-            _lib.check(lib.evmi_generator_create(C.byref(self._c_cfg), 0, C.byref(h)), "evmi_generator_create")
-            object.__setattr__(self, "_handle", h)
-        return float(lib.evmi_generator_macs_per_sample(self._handle))
+        if self._handle is not None:
+            return float(lib.evmi_generator_macs_per_sample(self._handle))
+        h = C.c_void_p()
+        _lib.check(lib.evmi_generator_create(C.byref(self._c_cfg), 0, C.byref(h)), "evmi_generator_create")
+        try:
+            return float(lib.evmi_generator_macs_per_sample(h))
+        finally:
+            lib.evmi_generator_destroy(h)
 
     def _check_input(self, mel: torch.Tensor) -> torch.Tensor:
         if not mel.is_cuda:

@@ -375,6 +375,17 @@ int evmi_adamw_f32(float* p_dev, const float* g_dev, float* m_dev, float* v_dev,
 
 
 /* ------------------------------------------------------------------------------------------
+ * Data-parallel gradient exchange (what Lightning's DDP strategy does for the reference,
+ * base_cli/helpers.py:252-270: --devices N --strategy ddp): RCCL all-reduce of one contiguous fp32 bucket of a flat gradient
+ * buffer, in place, summed over the ranks and scaled (1 / world for a mean) on `stream`.  One process per GPU; rank 0 makes the
+ * 128-byte id and hands it to the others over any side channel.  RCCL is resolved at run time (a copy already in the process,
+ * else librccl.so): EVMI_ERR_UNSUPPORTED when there is none. */
+int evmi_comm_unique_id(void* id_out_128_bytes);
+int evmi_comm_init_rank(void** comm_out, int world, const void* id_128_bytes, int rank);
+int evmi_comm_destroy(void* comm);
+int evmi_allreduce_bucket(void* comm, float* grad_dev, long long n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Audio gating of the preprocessor (everyvoice/preprocessor/preprocessor.py:131-218).
  * evmi_loudness_lkfs_f32: integrated loudness (ITU-R BS.1770-4 as torchaudio.transforms.Loudness computes it: K-weighting
  * biquads, 400 ms blocks at 75 % overlap, absolute -70 and relative -10 LU gates) of `items` zero-padded utterances

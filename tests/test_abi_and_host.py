@@ -37,6 +37,8 @@ def test_generator_object_without_gpu():
     """create / weight_info / macs are host-only: safe without a device."""
     g = Generator(HiFiGANConfig())
     assert g.macs_per_sample() == 1_199_424.0  # SURVEY.md §6: HiFi-GAN V1 MAC per output sample
+    assert g._handle is None  # asking for the MAC count does not pin the module to a device
+    g._new_handle(0)  # (creating the native object is host-only too)
     lib = _lib.load()
     n = lib.evmi_generator_num_weights(g._handle)
     names = []

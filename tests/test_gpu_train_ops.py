@@ -455,3 +455,28 @@ def test_conv_kernels_edge_shapes(cuda_device):
         dx, dw, _ = ops.conv1d_bwd(xd, wd, dyd, s, p, d, groups)
         torch.testing.assert_close(bct(dx.cpu()), x.grad, rtol=1e-4, atol=1e-5)
         torch.testing.assert_close(dw.cpu(), w.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_allreduce_bucket_c_abi_on_a_world_of_one(cuda_device):
+    """evmi_allreduce_bucket (the C-ABI form of the data-parallel gradient exchange): RCCL resolved at run time, a one-rank
+    communicator, sum + scale in place on the caller's stream.  (N > 1 needs N GPUs; the torch.distributed path is covered by
+    the gloo tests and the one-rank "nccl" tests.)"""
+    import ctypes as C
+
+    from everyvoice_amd import _lib
+
+    lib = _lib.load()
+    uid = C.create_string_buffer(128)
+    _lib.check(lib.evmi_comm_unique_id(uid), "evmi_comm_unique_id")
+    comm = C.c_void_p()
+    torch.cuda.set_device(cuda_device)
+    _lib.check(lib.evmi_comm_init_rank(C.byref(comm), 1, uid, 0), "evmi_comm_init_rank")
+    try:
+        g = torch.arange(1000, dtype=torch.float32, device=cuda_device)
+        _lib.check(lib.evmi_allreduce_bucket(comm, g[100:].data_ptr(), 900, 0.5, _lib.current_stream_ptr(cuda_device)), "evmi_allreduce_bucket")
+        torch.cuda.synchronize()
+        want = torch.arange(1000, dtype=torch.float32)
+        want[100:] *= 0.5
+        assert torch.equal(g.cpu(), want)
+    finally:
+        _lib.check(lib.evmi_comm_destroy(comm), "evmi_comm_destroy")
