@@ -103,6 +103,9 @@ SYMBOLS = {
     "evmi_reflect_pad_left1_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
     "evmi_conv1d_wgrad_cbt_bf16pk_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv1d_wgrad_cbt_bf16pk": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 11 + [C.c_void_p]),
+    "evmi_conv1d_cbt_bf16pk_fused": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 12 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "evmi_conv1d_dgrad_cbt_bf16pk_fused": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "evmi_conv1d_wgrad_cbt_bf16pk_fused": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 11 + [C.c_float, C.c_void_p, C.c_float, C.c_void_p]),
     "evmi_conv1d_wgrad_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv1d_wgrad_cbt_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 11 + [C.c_void_p]),
     "evmi_fs2_embed_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 3 + [C.c_void_p]),
@@ -128,6 +131,8 @@ SYMBOLS = {
     "evmi_dwconv1d_bwd_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 3),
     "evmi_dwconv1d_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_longlong] + [C.c_int] * 5 + [C.c_void_p]),
     "evmi_mha_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
+    "evmi_mha_fwd_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
+    "evmi_mha_bwd_bf16": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_mha_bwd_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_softmax_rows_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_softmax_bwd_rows_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_ulonglong, C.c_void_p]),

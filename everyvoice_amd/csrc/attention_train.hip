@@ -286,6 +286,325 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
     }
 }
 
+
+// ==== bf16-operand variants (precision = "bf16": what BASELINE config 3 names) =================================================
+// Same structure on v_mfma_f32_32x32x16_bf16: Q / K / V / dO, the probabilities and the score gradients are rounded to bf16 on
+// their way into the matrix cores; scores, softmax statistics, D and every accumulator stay fp32.  A contraction over the head
+// dimension reads 8 consecutive channels per lane, so its LDS operand is staged [position][channel]; a contraction over the keys
+// (queries) of a tile takes its k slots in the order the half-waves already hold the score tile's registers -- slot (half, e) of
+// block kb is position 16 kb + 8 (e >> 2) + 4 half + (e & 3) -- so P^T / dS^T feed it straight from registers and the other
+// operand is staged [channel][position] (two 8-byte reads).  Tiles that take part in both kinds of product are staged twice.
+constexpr int ATB_PD = 8;  // bf16 row padding
+
+template <int DH>
+__device__ __forceinline__ void stage_tile_bf16(bf16_t* __restrict__ x_pc, bf16_t* __restrict__ x_cp, const float* __restrict__ src, long long N,
+                                                int t0, int T, int tid) {
+  constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
+  for (int v = tid; v < DH * 32; v += 256) {
+    const int d = v >> 5, tt = v & 31;
+    const bf16_t val = (bf16_t)(t0 + tt < T ? src[(long long)d * N + t0 + tt] : 0.f);
+    if (x_pc) x_pc[tt * LP + d] = val;
+    if (x_cp) x_cp[d * LC + tt] = val;
+  }
+}
+// the same in two phases: the global loads of the NEXT tile are issued into registers before the current tile's products, the
+// conversion + LDS stores happen at the top of the next iteration (the loads' latency hides behind the matrix work)
+template <int DH>
+__device__ __forceinline__ void tile_fetch(float (&r)[DH / 8], const float* __restrict__ src, long long N, int t0, int T, int tid) {
+#pragma unroll
+  for (int i = 0; i < DH / 8; ++i) {
+    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
+    r[i] = t0 + tt < T ? src[(long long)d * N + t0 + tt] : 0.f;
+  }
+}
+template <int DH>
+__device__ __forceinline__ void tile_commit(const float (&r)[DH / 8], bf16_t* __restrict__ x_pc, bf16_t* __restrict__ x_cp, int tid) {
+  constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
+#pragma unroll
+  for (int i = 0; i < DH / 8; ++i) {
+    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
+    const bf16_t val = (bf16_t)r[i];
+    if (x_pc) x_pc[tt * LP + d] = val;
+    if (x_cp) x_cp[d * LC + tt] = val;
+  }
+}
+
+// A operand of a contraction over the tile's positions: lane (channel row, half) takes positions 16 kb + 4 half + {0..3} and + 8
+__device__ __forceinline__ bf16x8 load_pos_slots(const bf16_t* __restrict__ row, int kb, int kh) {
+  const bf16x4 lo = *reinterpret_cast<const bf16x4*>(row + 16 * kb + 4 * kh);
+  const bf16x4 hi = *reinterpret_cast<const bf16x4*>(row + 16 * kb + 4 * kh + 8);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+                                                                      float* __restrict__ out, float* __restrict__ lse, int B, int T, int D,
+                                                                      float scale, float p_drop, unsigned long long seed) {
+  constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * LP];   // [key][channel]
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[DH * LC];   // [channel][key]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int len = min(lens[b], T);
+  const long long N = (long long)B * T;
+  const float* q = qkv + ((long long)(h * DH) * B + b) * T;
+  const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
+  const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
+  const int tq = blockIdx.x * 128 + wave * 32 + ln;
+  const bool qlive = tq < T;
+  bf16x8 qreg[DH / 16];
+#pragma unroll
+  for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qreg[s][e] = (bf16_t)(qlive ? q[(long long)(16 * s + 8 * kh + e) * N + tq] * scale : 0.f);
+  f32x16 acc[DH / 32];
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
+
+  float kf[DH / 8], vf[DH / 8];
+  if (len > 0) {
+    tile_fetch<DH>(kf, kg, N, 0, T, tid);
+    tile_fetch<DH>(vf, vg, N, 0, T, tid);
+  }
+  for (int k0 = 0; k0 < len; k0 += 32) {
+    __syncthreads();
+    tile_commit<DH>(kf, Ks, nullptr, tid);
+    tile_commit<DH>(vf, nullptr, Vs, tid);
+    __syncthreads();
+    if (k0 + 32 < len) {
+      tile_fetch<DH>(kf, kg, N, k0 + 32, T, tid);
+      tile_fetch<DH>(vf, vg, N, k0 + 32, T, tid);
+    }
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s)
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Ks[ln * LP + 16 * s + 8 * kh]), qreg[s], st, 0, 0, 0);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (k0 + acc_row(r, kh) >= len) st[r] = -INFINITY;
+      mx = fmaxf(mx, st[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float corr = expf(m_run - m_new);
+    float ps = 0.f;
+    bf16x8 pb[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float pr = expf(st[r] - m_new);
+      ps += pr;
+      if (p_drop > 0.f) pr = attn_uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? pr * keep : 0.f;
+      pb[r >> 3][r & 7] = (bf16_t)pr;
+    }
+    ps += __shfl_xor(ps, 32, 64);
+    l_run = l_run * corr + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] *= corr;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_pos_slots(&Vs[(i * 32 + ln) * LC], kb, kh), pb[kb], acc[i], 0, 0, 0);
+    }
+  }
+  if (!qlive) return;
+  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+  float* o = out + ((long long)(h * DH) * B + b) * T + tq;
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(long long)(i * 32 + acc_row(r, kh)) * N] = acc[i][r] * inv;
+  if (kh == 0) lse[((long long)b * H + h) * T + tq] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_train_dq_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+                                                                     const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                                     const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
+                                                                     int D, float scale, float p_drop, unsigned long long seed) {
+  constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * LP];   // [key][channel]: S^T = K Q^T
+  __shared__ __attribute__((aligned(16))) bf16_t Kt[DH * LC];   // [channel][key]: dQ^T += K^T dS^T
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[32 * LP];   // [key][channel]: dPd^T = V dO^T
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int len = min(lens[b], T);
+  const long long N = (long long)B * T;
+  const float* q = qkv + ((long long)(h * DH) * B + b) * T;
+  const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
+  const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
+  const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
+  const int tq = blockIdx.x * 128 + wave * 32 + ln;
+  const bool qlive = tq < T;
+  bf16x8 qreg[DH / 16], doreg[DH / 16];
+#pragma unroll
+  for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long long off = (long long)(16 * s + 8 * kh + e) * N + tq;
+      qreg[s][e] = (bf16_t)(qlive ? q[off] * scale : 0.f);
+      doreg[s][e] = (bf16_t)(qlive ? dog[off] : 0.f);
+    }
+  const float my_lse = qlive ? lse[((long long)b * H + h) * T + tq] : INFINITY;
+  const float my_d = qlive ? dsum[((long long)b * H + h) * T + tq] : 0.f;
+  const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
+  f32x16 acc[DH / 32];
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  float kf[DH / 8], vf[DH / 8];
+  if (len > 0) {
+    tile_fetch<DH>(kf, kg, N, 0, T, tid);
+    tile_fetch<DH>(vf, vg, N, 0, T, tid);
+  }
+  for (int k0 = 0; k0 < len; k0 += 32) {
+    __syncthreads();
+    tile_commit<DH>(kf, Ks, Kt, tid);
+    tile_commit<DH>(vf, Vs, nullptr, tid);
+    __syncthreads();
+    if (k0 + 32 < len) {
+      tile_fetch<DH>(kf, kg, N, k0 + 32, T, tid);
+      tile_fetch<DH>(vf, vg, N, k0 + 32, T, tid);
+    }
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Ks[ln * LP + 16 * s + 8 * kh]), qreg[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Vs[ln * LP + 16 * s + 8 * kh]), doreg[s], dp, 0, 0, 0);
+    }
+    bf16x8 dsb[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = k0 + acc_row(r, kh);
+      const float pr = key < len ? expf(st[r] - my_lse) : 0.f;
+      float g = dp[r];
+      if (p_drop > 0.f) g = attn_uniform01(seed + h, row_base + (unsigned long long)key) >= p_drop ? g * keep : 0.f;
+      dsb[r >> 3][r & 7] = (bf16_t)(pr * (g - my_d));
+    }
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_pos_slots(&Kt[(i * 32 + ln) * LC], kb, kh), dsb[kb], acc[i], 0, 0, 0);
+  }
+  if (!qlive) return;
+  float* o = dqkv + ((long long)(h * DH) * B + b) * T + tq;
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(long long)(i * 32 + acc_row(r, kh)) * N] = acc[i][r] * scale;
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void attention_train_dkv_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+                                                                      const float* __restrict__ d_o, const float* __restrict__ lse,
+                                                                      const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
+                                                                      int D, float scale, float p_drop, unsigned long long seed) {
+  constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[32 * LP];   // [query][channel]
+  __shared__ __attribute__((aligned(16))) bf16_t Qt[DH * LC];   // [channel][query]
+  __shared__ __attribute__((aligned(16))) bf16_t Os[32 * LP];   // dO [query][channel]
+  __shared__ __attribute__((aligned(16))) bf16_t Ot[DH * LC];   // dO [channel][query]
+  __shared__ float lse_s[32], d_s[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
+  const int len = min(lens[b], T);
+  const long long N = (long long)B * T;
+  const float* qg = qkv + ((long long)(h * DH) * B + b) * T;
+  const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
+  const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
+  const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
+  const int tk = blockIdx.x * 128 + wave * 32 + ln;
+  const bool klive = tk < len;
+  bf16x8 kreg[DH / 16], vreg[DH / 16];
+#pragma unroll
+  for (int s = 0; s < DH / 16; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long long off = (long long)(16 * s + 8 * kh + e) * N + tk;
+      kreg[s][e] = (bf16_t)(klive ? kg[off] * scale : 0.f);
+      vreg[s][e] = (bf16_t)(klive ? vg[off] : 0.f);
+    }
+  const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  f32x16 acck[DH / 32], accv[DH / 32];
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acck[i][r] = accv[i][r] = 0.f;
+  const bool block_live = blockIdx.x * 128 < len;
+
+  float qf[DH / 8], of[DH / 8];
+  if (block_live) {
+    tile_fetch<DH>(qf, qg, N, 0, T, tid);
+    tile_fetch<DH>(of, dog, N, 0, T, tid);
+  }
+  for (int q0 = 0; q0 < T && block_live; q0 += 32) {
+    __syncthreads();
+    tile_commit<DH>(qf, Qs, Qt, tid);
+    tile_commit<DH>(of, Os, Ot, tid);
+    if (tid < 32) {
+      const bool in = q0 + tid < T;
+      lse_s[tid] = in ? lse[((long long)b * H + h) * T + q0 + tid] : INFINITY;
+      d_s[tid] = in ? dsum[((long long)b * H + h) * T + q0 + tid] : 0.f;
+    }
+    __syncthreads();
+    if (q0 + 32 < T) {
+      tile_fetch<DH>(qf, qg, N, q0 + 32, T, tid);
+      tile_fetch<DH>(of, dog, N, q0 + 32, T, tid);
+    }
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < DH / 16; ++s) {
+      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Qs[ln * LP + 16 * s + 8 * kh]), kreg[s], st, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Os[ln * LP + 16 * s + 8 * kh]), vreg[s], dp, 0, 0, 0);
+    }
+    bf16x8 pdb[2], dsb[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qi = acc_row(r, kh);
+      const int tq = q0 + qi;
+      const float pr = (klive && tq < T) ? expf(st[r] - lse_s[qi]) : 0.f;
+      float mk = 1.f;
+      if (p_drop > 0.f) mk = attn_uniform01(seed + h, ((unsigned long long)b * T + (unsigned long long)min(tq, T - 1)) * T + (unsigned long long)min(tk, T - 1)) >= p_drop ? keep : 0.f;
+      pdb[r >> 3][r & 7] = (bf16_t)(pr * mk);
+      dsb[r >> 3][r & 7] = (bf16_t)(pr * (dp[r] * mk - d_s[qi]));
+    }
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        accv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_pos_slots(&Ot[(i * 32 + ln) * LC], kb, kh), pdb[kb], accv[i], 0, 0, 0);
+        acck[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_pos_slots(&Qt[(i * 32 + ln) * LC], kb, kh), dsb[kb], acck[i], 0, 0, 0);
+      }
+  }
+  if (tk >= T) return;
+  float* dk = dqkv + ((long long)(D + h * DH) * B + b) * T + tk;
+  float* dv = dqkv + ((long long)(2 * D + h * DH) * B + b) * T + tk;
+#pragma unroll
+  for (int i = 0; i < DH / 32; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dk[(long long)(i * 32 + acc_row(r, kh)) * N] = acck[i][r] * scale;
+      dv[(long long)(i * 32 + acc_row(r, kh)) * N] = accv[i][r];
+    }
+}
+
 }  // namespace evmi
 
 using namespace evmi;
@@ -308,6 +627,53 @@ int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, 
   else return fail(EVMI_ERR_UNSUPPORTED, "mha_fwd: head dimension must be 32, 64 or 128");
 #undef EVMI_MHA_FWD
   EVMI_LAUNCH_CHECK("mha_fwd");
+  return EVMI_OK;
+}
+
+int evmi_mha_fwd_bf16(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
+                      float p_drop, unsigned long long seed, void* stream) {
+  if (!qkv_dev || !lens_dev || !out_dev || !lse_dev) return fail(EVMI_ERR_INVALID_ARG, "mha_fwd_bf16: null pointer");
+  if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads || p_drop < 0.f || p_drop >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "mha_fwd_bf16: shape / dropout");
+  if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "mha_fwd_bf16: grid limits");
+  const int dh = D / heads;
+  const float scale = 1.f / sqrtf((float)dh);
+  const dim3 grid((T + 127) / 128, heads, B);
+  hipStream_t s = (hipStream_t)stream;
+#define EVMI_MHA_FWD(DH) hipLaunchKernelGGL(attention_train_fwd_bf16_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, scale, p_drop, seed)
+  if (dh == 128) EVMI_MHA_FWD(128);
+  else if (dh == 64) EVMI_MHA_FWD(64);
+  else if (dh == 32) EVMI_MHA_FWD(32);
+  else return fail(EVMI_ERR_UNSUPPORTED, "mha_fwd_bf16: head dimension must be 32, 64 or 128");
+#undef EVMI_MHA_FWD
+  EVMI_LAUNCH_CHECK("mha_fwd_bf16");
+  return EVMI_OK;
+}
+
+int evmi_mha_bwd_bf16(const float* qkv_dev, const int* lens_dev, const float* out_dev, const float* dout_dev, const float* lse_dev,
+                      float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop, unsigned long long seed,
+                      void* stream) {
+  if (!qkv_dev || !lens_dev || !out_dev || !dout_dev || !lse_dev || !dsum_dev || !dqkv_dev) return fail(EVMI_ERR_INVALID_ARG, "mha_bwd_bf16: null pointer");
+  if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads || p_drop < 0.f || p_drop >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "mha_bwd_bf16: shape / dropout");
+  if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "mha_bwd_bf16: grid limits");
+  const int dh = D / heads;
+  const float scale = 1.f / sqrtf((float)dh);
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = (long long)B * heads * T;
+  hipLaunchKernelGGL(attention_rowdot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out_dev, dout_dev, dsum_dev, B, T, heads, dh);
+  const dim3 grid((T + 127) / 128, heads, B);
+#define EVMI_MHA_BWD(DH)                                                                                                          \
+  {                                                                                                                               \
+    hipLaunchKernelGGL(attention_train_dq_bf16_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev, \
+                       dqkv_dev, B, T, D, scale, p_drop, seed);                                                                   \
+    hipLaunchKernelGGL(attention_train_dkv_bf16_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev,\
+                       dqkv_dev, B, T, D, scale, p_drop, seed);                                                                   \
+  }
+  if (dh == 128) EVMI_MHA_BWD(128)
+  else if (dh == 64) EVMI_MHA_BWD(64)
+  else if (dh == 32) EVMI_MHA_BWD(32)
+  else return fail(EVMI_ERR_UNSUPPORTED, "mha_bwd_bf16: head dimension must be 32, 64 or 128");
+#undef EVMI_MHA_BWD
+  EVMI_LAUNCH_CHECK("mha_bwd_bf16");
   return EVMI_OK;
 }
 

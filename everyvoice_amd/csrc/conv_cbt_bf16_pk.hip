@@ -56,6 +56,13 @@ struct ConvPkArgs {
   float* part;
   long long part_stride, part_ld;
   int ablate;  // timing experiments (EVMI_PK_ABLATE): 1 no window loads, 2 no weight loads, 4 no MFMA loop, 8 no stores
+  // fused epilogue tail, in this order: v = act(acc + bias); v *= (out_mask > 0 ? 1 : out_mask_slope); v += res
+  //   out_mask: a tensor of y's shape -- the INPUT of the leaky ReLU in front of the convolution whose input gradient this
+  //             launch computes (the activation backward without a separate pass);  res: a tensor of y's shape added to the
+  //             result (the residual connection in a forward pass, the skip path's gradient in a backward pass)
+  const float* out_mask;
+  float out_mask_slope;
+  const float* res;
 };
 
 template <int ACT>
@@ -360,6 +367,8 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
           if (a.bias) v += a.bias[co];
           v = pk_act<ACT>(v, a.act_param);
           float* dst = ycol + (long long)co * a.B * a.t_out_total;
+          if (a.out_mask) v *= a.out_mask[dst - a.y] > 0.f ? 1.f : a.out_mask_slope;
+          if (a.res) v += a.res[dst - a.y];
           *dst = a.accumulate ? *dst + v : v;
         }
       }
@@ -381,6 +390,8 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a) {
   const long long bb = n / n_out;
   const int to = (int)(n - bb * n_out);
   float* dst = a.y + ((long long)co * a.B + bb) * a.t_out_total + (long long)to * a.out_stride + a.ph_off[ph];
+  if (a.out_mask) v *= a.out_mask[dst - a.y] > 0.f ? 1.f : a.out_mask_slope;
+  if (a.res) v += a.res[dst - a.y];
   *dst = a.accumulate ? *dst + v : v;
 }
 
@@ -512,8 +523,14 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
   return nullptr;
 }
 
+struct PkInputFusion {  // what the pack applies to the input on its way in (see PackArgs)
+  float pre_slope = 1.f;
+  const float* mask = nullptr;
+  float mask_slope = 1.f;
+};
+
 static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float* w, float* ws, long long ws_elems, int wmode,
-                     int rows_g, int kch_g, int k_full, int stride_full, hipStream_t stream) {
+                     int rows_g, int kch_g, int k_full, int stride_full, hipStream_t stream, PkInputFusion in = PkInputFusion()) {
   const long long need = (pl.xp_units + pl.wf_units) * 4 + pl.part_elems;
   if (!ws || ws_elems < need || (reinterpret_cast<uintptr_t>(ws) & 15))
     return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_bf16_pk: workspace missing, too small or unaligned");
@@ -522,6 +539,7 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   a.part = reinterpret_cast<float*>(wf + pl.wf_units);
   PackArgs pa = make_pack_args(x, xp, pl.cin_g, a.octs, a.B, pl.t_in, a.Tp, pl.PL,
                                (int)(pl.xp_units - (long long)pl.groups * a.octs * a.B * a.Tp), pl.groups);
+  pa.pre_slope = in.pre_slope; pa.mask = in.mask; pa.mask_slope = in.mask_slope;
   WfragArgs fa;
   fa.w = w; fa.wf = reinterpret_cast<unsigned*>(wf); fa.rows_g = rows_g; fa.kch_g = kch_g; fa.kt = a.k; fa.MB = a.mblocks; fa.octs = a.octs;
   fa.kblocks = a.kblocks; fa.mode = wmode; fa.k_full = k_full; fa.stride = stride_full; fa.phase_stride_words = a.wf_phase_stride * 4;
@@ -628,6 +646,24 @@ int evmi_conv1d_cbt_bf16pk(const float* x_dev, const float* w_dev, const float* 
   return launch_pk(a, pl, x_dev, w_dev, ws_dev, ws_elems, 0, c_out / groups, c_in / groups, k, stride, (hipStream_t)stream);
 }
 
+/* The same with the fusions of a residual block's forward: the input passes through leaky_relu(., pre_slope) while it is packed
+ * (pre_slope 1 = none) and `residual` [c_out][B][t_out_total] (may be NULL) is added behind the activation. */
+int evmi_conv1d_cbt_bf16pk_fused(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev,
+                                 long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out_total, int n_out, int k, int stride,
+                                 int pad, int dil, int groups, int act, float act_param, float pre_slope, const float* residual_dev,
+                                 void* stream) {
+  if (!x_dev || !w_dev || !y_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_fused: null pointer");
+  if (act < 0 || act > 4) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_fused: activation");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_fwd_pk(a, pl, B, c_in, t_in, c_out, t_out_total, n_out, k, stride, pad, dil, groups, 1, 0))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk_fused: ") + why);
+  a.bias = bias_dev; a.y = y_dev; a.accumulate = 0; a.act = act; a.act_param = act_param; a.res = residual_dev;
+  PkInputFusion in;
+  in.pre_slope = pre_slope;
+  return launch_pk(a, pl, x_dev, w_dev, ws_dev, ws_elems, 0, c_out / groups, c_in / groups, k, stride, (hipStream_t)stream, in);
+}
+
 long long evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil,
                                                 int groups) {
   ConvPkArgs a = {};
@@ -646,6 +682,28 @@ int evmi_conv1d_dgrad_cbt_bf16pk(const float* dy_dev, const float* w_dev, float*
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk: ") + why);
   a.y = dx_dev;
   return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream);
+}
+
+/* Input gradient with the fusions of a backward pass: dy is multiplied by (dy_mask > 0 ? 1 : dy_mask_slope) while it is packed
+ * (dy_mask = the OUTPUT of the leaky ReLU behind the convolution: its backward; NULL = none); the result is multiplied by
+ * (dx_mask > 0 ? 1 : dx_mask_slope) (dx_mask = the INPUT of the leaky ReLU in front of the convolution; NULL = none) and
+ * `residual` [c_in][B][t_in] is added (the skip path's gradient; NULL = none).  pre_slope applies leaky_relu to the packed input
+ * itself (a transposed convolution run as an input-gradient kernel: ConvTranspose(leaky_relu(x))). */
+int evmi_conv1d_dgrad_cbt_bf16pk_fused(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems, int B,
+                                       int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
+                                       float pre_slope, const float* dy_mask_dev, float dy_mask_slope, const float* dx_mask_dev,
+                                       float dx_mask_slope, const float* residual_dev, void* stream) {
+  if (!dy_dev || !w_dev || !dx_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_fused: null pointer");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_dgrad_pk(a, pl, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk_fused: ") + why);
+  if ((dx_mask_dev || residual_dev) && k < stride)
+    return fail(EVMI_ERR_UNSUPPORTED, "conv1d_dgrad_cbt_bf16pk_fused: positions no phase writes would miss the residual");
+  a.y = dx_dev; a.out_mask = dx_mask_dev; a.out_mask_slope = dx_mask_slope; a.res = residual_dev;
+  PkInputFusion in;
+  in.pre_slope = pre_slope; in.mask = dy_mask_dev; in.mask_slope = dy_mask_slope;
+  return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream, in);
 }
 
 }  // extern "C"

@@ -24,11 +24,17 @@ __device__ __forceinline__ unsigned pk_bf16x2(float lo, float hi) {
 // Logical grid (ceil(Tp / 256), B, groups*octs): one thread per unit, consecutive threads consecutive u (coalesced reads of 8
 // channel rows, 16-byte writes).  The workgroups of the last row also zero `slack_units` units behind the tensor (read by the
 // last tiles' window loads, never used: kept finite).
+// Fused on the way in: pre_slope != 1 packs leaky_relu(x, pre_slope) (the activation in front of a convolution: no separate
+// pass, no activated copy in HBM); mask != nullptr packs x * (mask > 0 ? 1 : mask_slope) (a gradient through the leaky ReLU
+// whose OUTPUT is `mask`: the activation backward folded into the pack of dy).
 struct PackArgs {
   const float* x;
   uint4* xp;
   int cin_g, octs, B, t_in, Tp, PL, slack_units;
   int gx, gy, gz;  // logical grid
+  float pre_slope;
+  const float* mask;
+  float mask_slope;
 };
 __device__ __forceinline__ void pack_x_block(const PackArgs& p, int bx, int b, int go) {
   const int u = bx * 256 + threadIdx.x;
@@ -49,6 +55,16 @@ __device__ __forceinline__ void pack_x_block(const PackArgs& p, int bx, int b, i
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       if (i < nch) v[i] = src[i * cs];
+    if (p.pre_slope != 1.f) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.pre_slope;
+    }
+    if (p.mask) {
+      const float* ms = p.mask + (src - p.x);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (i < nch) v[i] *= ms[i * cs] > 0.f ? 1.f : p.mask_slope;
+    }
   }
   uint4 out;
   out.x = pk_bf16x2(v[0], v[1]);
@@ -62,6 +78,7 @@ static inline PackArgs make_pack_args(const float* x, uint4* xp, int cin_g, int 
   PackArgs p;
   p.x = x; p.xp = xp; p.cin_g = cin_g; p.octs = octs; p.B = B; p.t_in = t_in; p.Tp = Tp; p.PL = PL; p.slack_units = slack_units;
   p.gx = (Tp + 255) / 256; p.gy = B; p.gz = groups * octs;
+  p.pre_slope = 1.f; p.mask = nullptr; p.mask_slope = 1.f;
   return p;
 }
 // decode a flat block index into the logical 3-D grid of a pack (x fastest)

@@ -311,9 +311,29 @@ long long evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c
   return (pl.dy_units + pl.x_units) * 4 + pl.part_elems;
 }
 
+static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in,
+                         int c_out, int n_out, int k, int stride, int pad, int dil, int groups, int accumulate, float x_pre_slope,
+                         const float* dy_mask_dev, float dy_mask_slope, void* stream);
+
 int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in,
                                  int t_in, int c_out, int n_out, int k, int stride, int pad, int dil, int groups, int accumulate,
                                  void* stream) {
+  return wgrad_pk_impl(x_dev, dy_dev, dw_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups, accumulate, 1.f,
+                       nullptr, 1.f, stream);
+}
+
+/* The same with the operands transformed while they are packed: x -> leaky_relu(x, x_pre_slope) (the activation in front of the
+ * convolution, never materialised) and dy -> dy * (dy_mask > 0 ? 1 : dy_mask_slope) (the backward of the leaky ReLU behind it). */
+int evmi_conv1d_wgrad_cbt_bf16pk_fused(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B,
+                                       int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil, int groups,
+                                       int accumulate, float x_pre_slope, const float* dy_mask_dev, float dy_mask_slope, void* stream) {
+  return wgrad_pk_impl(x_dev, dy_dev, dw_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups, accumulate,
+                       x_pre_slope, dy_mask_dev, dy_mask_slope, stream);
+}
+
+static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in,
+                         int c_out, int n_out, int k, int stride, int pad, int dil, int groups, int accumulate, float x_pre_slope,
+                         const float* dy_mask_dev, float dy_mask_slope, void* stream) {
   if (!x_dev || !dy_dev || !dw_dev || !ws_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_cbt_bf16pk: null pointer");
   WgradPkArgs a = {};
   WgradPkPlan pl;
@@ -333,6 +353,8 @@ int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float*
                                groups);
   PackArgs px = make_pack_args(x_dev, xp, cin_g, a.octs_x, B, t_in, Tpx, pad, (int)(pl.x_units - (long long)groups * a.octs_x * a.plane_x),
                                groups);
+  px.pre_slope = x_pre_slope;
+  py.mask = dy_mask_dev; py.mask_slope = dy_mask_slope;
   const long long n_pack = (long long)py.gx * py.gy * py.gz + (long long)px.gx * px.gy * px.gz;
   if (n_pack > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv1d_wgrad_cbt_bf16pk: grid limits (pack)");
   hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)n_pack), dim3(256), 0, s, py, px);

@@ -71,14 +71,51 @@ def conv1d_lrelu(tape: Tape, x: Var, layer, slope: float, training: bool = True)
     def bwd():
         if y.grad is None:
             return
-        if layer.frozen:
-            dpre, db_out = ops.lrelu_bwd(y.grad, y.data, slope), None
+        if layer.frozen:  # input gradient only: the activation's backward rides in the pack of dy
+            if x.needs_grad:
+                x.accumulate(ops.conv1d_fused_dgrad(y.grad, w, x.data.shape[2], layer.stride, layer.pad, layer.dil, layer.groups, dy_mask=y.data,
+                                                    dy_mask_slope=slope, x_for_fallback=x.data))
+            return
         else:  # activation backward and bias gradient in one pass over dy
             dpre, db_out = ops.lrelu_bwd_rowsum(y.grad, y.data, slope, db_sink, accumulate=True), None
         dx, _, _ = ops.conv1d_bwd(x.data, w, dpre, layer.stride, layer.pad, layer.dil, layer.groups, need_dx=x.needs_grad,
                                   dw_out=dw_sink, db_out=db_out, accumulate=True, need_dw=not layer.frozen)
         if dx is not None:
             x.accumulate(dx)
+
+    tape.record(bwd)
+    return y
+
+
+def resblock_pair(tape: Tape, x: Var, c1, c2, slope: float, training: bool = True) -> Var:
+    """x + conv2(leaky_relu(conv1(leaky_relu(x)))) -- one residual pair of a HiFi-GAN ResBlock1 -- with the activations and the
+    residual taken into the convolutions' packs and epilogues (ops.conv1d_fused_*): forward = 2 convolution calls; backward =
+    bias row sums + 2 weight gradients + 2 input gradients, the second of which delivers the pair's complete input gradient
+    (activation backward and skip path included).  SURVEY.md 8b names this fusion evmi_resblock1_fused_{fwd,bwd}."""
+    w1, dw1 = c1.effective(training)
+    db1 = c1.call_db_sink()
+    w2, dw2 = c2.effective(training)
+    db2 = c2.call_db_sink()
+    t = ops.conv1d_fused_fwd(x.data, w1, c1.bias_data(), c1.stride, c1.pad, c1.dil, c1.groups, act=ops.ACT_LRELU, act_param=slope, pre_slope=slope)
+    y = Var(ops.conv1d_fused_fwd(t, w2, c2.bias_data(), c2.stride, c2.pad, c2.dil, c2.groups, residual=x.data))
+
+    def bwd():
+        dy = y.grad
+        if dy is None:
+            return
+        C2, N2 = dy.shape[0], dy.shape[1] * dy.shape[2]
+        if not c2.frozen:
+            ops.row_reduce(0, dy, None, db2, C2, N2, accumulate=True)
+            ops.conv1d_fused_wgrad(t, w2.shape, dy, dw2, c2.stride, c2.pad, c2.dil, c2.groups)
+        dt = ops.conv1d_fused_dgrad(dy, w2, t.shape[2], c2.stride, c2.pad, c2.dil, c2.groups, x_for_fallback=t)
+        if c1.frozen:
+            dpre = ops.lrelu_bwd(dt, t, slope)
+        else:  # backward of the activation between the two convolutions + conv1's bias gradient, one pass
+            dpre = ops.lrelu_bwd_rowsum(dt, t, slope, db1, accumulate=True)
+            ops.conv1d_fused_wgrad(x.data, w1.shape, dpre, dw1, c1.stride, c1.pad, c1.dil, c1.groups, x_pre_slope=slope)
+        if x.needs_grad:
+            x.accumulate(ops.conv1d_fused_dgrad(dpre, w1, x.data.shape[2], c1.stride, c1.pad, c1.dil, c1.groups, dx_mask=x.data, dx_mask_slope=slope,
+                                                residual=dy, x_for_fallback=x.data))
 
     tape.record(bwd)
     return y

@@ -342,14 +342,26 @@ class _AlignerT:
         k = dense(tape, dense(tape, text_emb, self.key[0], ops.ACT_RELU), self.key[1])
         q = dense(tape, dense(tape, dense(tape, mel, self.query[0], ops.ACT_RELU), self.query[1], ops.ACT_RELU), self.query[2])
         soft, logprob = ops.align_attention_fwd(q.data, k.data, prior, text_lens32, self.temperature)
+        # The CTC forward-sum loss and its gradient (one workgroup per utterance walking the frames: ~2 ms of latency, a fraction of
+        # the chip) are only needed when backward reaches the aligner: they run on a side stream beside the variance adaptor and
+        # the decoder, and the aligner's backward waits for them.
+        main = torch.cuda.current_stream(logprob.device)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(logprob.device)
+        fork, done = torch.cuda.Event(), torch.cuda.Event()
+        fork.record(main)
+        self._side.wait_event(fork)
+        with torch.cuda.stream(self._side):
+            ctc, dlogprob = ops.forward_sum_loss_and_grad(logprob, text_lens32, mel_lens32, ctc_weight)
+            done.record(self._side)
         hard, dur = maximum_path(ops.elementwise(16, soft), mel_lens32, text_lens32)  # monotonic search over log(soft): no gradient
-        ctc, dlogprob = ops.forward_sum_loss_and_grad(logprob, text_lens32, mel_lens32, ctc_weight)
         from ..heavy import binarization_loss
         losses = {"attn_ctc": ctc}
         if bin_weight > 0.0:
             losses["attn_bin"] = (binarization_loss(hard, soft) * bin_weight).reshape(1)
 
         def bwd():
+            torch.cuda.current_stream(logprob.device).wait_event(done)
             dq, dk = ops.align_attention_bwd(q.data, k.data, soft, logprob, prior, hard if bin_weight > 0.0 else None, dlogprob, text_lens32,
                                              self.temperature, bin_weight / n_frames)
             q.accumulate(dq)

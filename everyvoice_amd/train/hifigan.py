@@ -116,6 +116,7 @@ class GeneratorT:
     def __init__(self, cfg: HiFiGANConfig, group: ParamGroup):
         m = cfg.model
         self.resblock2 = str(getattr(m.resblock, "value", m.resblock)) == "2"
+        self.fused_pairs = True  # residual pairs as ag.resblock_pair (False: the unfused op sequence, for A/B tests)
         self.istft = bool(m.istft_layer)
         self._istft_consts = None
         self._istft_cfg = (cfg.gen_istft_n_fft, cfg.gen_istft_hop_size)
@@ -157,6 +158,9 @@ class GeneratorT:
 
     def _mrf_branch(self, tape: ag.Tape, y: ag.Var, i: int, j: int) -> ag.Var:
         for c1, c2 in self.resblocks[i * self.num_kernels + j]:
+            if c2 is not None and self.fused_pairs:
+                y = ag.resblock_pair(tape, y, c1, c2, self.slope)
+                continue
             t = ag.lrelu(tape, y, self.slope)
             if c2 is None:
                 t = ag.conv1d(tape, t, c1)
@@ -801,6 +805,8 @@ class HiFiGANTrainer:
                 fns.append(lambda sub, i=i, d=d: self._d_branch(sub, i, d, ins[i], reducer))
         parallel_section(d_tape, self.branches, fns)
         d_tape.backward()  # every discriminator's bucket is finished (and its all-reduce launched) as its stream leaves it
+        for layer in self._sn_layers():
+            layer.release()  # every stream has been joined: the prepared spectral-norm tensors may go
         ops.scalar_reduce(2, self._slots[0], None, self._loss_buf[0:1])
         ops.scalar_reduce(2, self._slots[3], None, self._loss_buf[0:1], accumulate=True)
         if self.keep_grads:
@@ -861,6 +867,7 @@ class HiFiGANTrainer:
             for layer in ctx["d_layers"]:
                 if isinstance(layer, SNConv):
                     layer._calls.clear()  # frozen: no parameter gradients from this pass
+                    layer.release()
             total = recon[0]
         else:
             total = self._recon_grad(y, y_hat.data, B)

@@ -253,6 +253,7 @@ class SNConv(_ConvBase):
         self.v = torch.zeros(wdt, device=group.device)
         self._calls = []  # (sigma tensor [1], u, v, dw buffer, db buffer) per forward call of this step
         self._ready = []  # prepared, not yet handed out
+        self._held = []   # everything prepare() allocated, kept alive until release(): see prepare()
         self._call_db = None
 
     def materialize(self):
@@ -282,11 +283,16 @@ class SNConv(_ConvBase):
 
     def prepare(self, n_calls: int, training=True):
         """Power iterations + effective weights of the next `n_calls` forward calls (the buffers end at the last call's state)."""
+        # The tensors made here are allocated on the CURRENT stream but consumed by convolutions on other streams (the
+        # discriminator's chains).  The caching allocator hands a freed block back to its allocation stream at once, so dropping
+        # the last reference while a consumer stream still reads it would let the next allocation here overwrite live data:
+        # they stay referenced in `_held` until the trainer calls release() behind the join that ends the phase.
         u = self.u
         v = self.v
         for _ in range(n_calls):
             w, sigma, u, v = self._iterate(u, training)
             self._ready.append((w, sigma, u, v))
+            self._held.append((w, sigma, u, v))
         if training and n_calls:
             ops.copy(u, out=self.u)
             ops.copy(v, out=self.v)
@@ -307,6 +313,10 @@ class SNConv(_ConvBase):
     def call_db_sink(self):
         """Bias-gradient sink of the forward call `effective` just served (read right after it)."""
         return self._call_db
+
+    def release(self):
+        """Drop the prepared tensors (call once every stream that used them has been joined)."""
+        self._held.clear()
 
     def finish_grads(self):
         from .. import _lib

@@ -155,6 +155,76 @@ def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=No
 
 
 
+# ---- fused forms (packed bf16 kernels take the neighbours of a convolution into their pack / epilogue; every other path runs
+# the same arithmetic as separate passes, so callers use ONE signature whatever kernel serves the shape) --------------------
+def _packed() -> bool:
+    return CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"]
+
+
+def conv1d_fused_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, act=ACT_NONE, act_param=0.0, pre_slope=1.0, residual=None):
+    """y = act(conv(leaky_relu(x, pre_slope)) + bias) + residual."""
+    cin, B, t_in = x.shape
+    cout, _, k = w.shape
+    t_out = conv_out_len(t_in, k, stride, pad, dil)
+    lib = _lib.load()
+    if _packed() and CONV_BACKEND["fwd"] == "mfma":
+        pk = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+        if pk > 0:
+            y = torch.empty(cout, B, t_out, device=x.device, dtype=torch.float32)
+            ws = WS.get("pk", pk, x.device)
+            _chk(lib.evmi_conv1d_cbt_bf16pk_fused(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), y.data_ptr(), ws.data_ptr(), pk, B, cin, t_in, cout, t_out,
+                                                  t_out, k, stride, pad, dil, groups, act, float(act_param), float(pre_slope), _lib.ptr(residual),
+                                                  _s(x)), "evmi_conv1d_cbt_bf16pk_fused")
+            return y
+    xa = x if pre_slope == 1.0 else lrelu(x, pre_slope)
+    y = conv1d_fwd(xa, w, bias, stride, pad, dil, groups, lrelu_slope=act_param if act == ACT_LRELU else None, act=act if act != ACT_LRELU else ACT_NONE)
+    return y if residual is None else axpby(1.0, y, 1.0, residual, out=y)
+
+
+def conv1d_fused_dgrad(dy, w, t_in, stride=1, pad=0, dil=1, groups=1, dy_mask=None, dy_mask_slope=1.0, dx_mask=None, dx_mask_slope=1.0,
+                       residual=None, x_for_fallback=None):
+    """dx = conv_input_grad(dy * lrelu'(dy_mask)) * lrelu'(dx_mask) + residual  (lrelu'(m) = 1 where m > 0, else the slope)."""
+    cout, B, t_out = dy.shape
+    _, cin_g, k = w.shape
+    cin = cin_g * groups
+    lib = _lib.load()
+    if _packed() and CONV_BACKEND["dgrad"] == "mfma" and not ((dx_mask is not None or residual is not None) and k < stride):
+        pk = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+        if pk > 0:
+            dx = zeros(cin, B, t_in, device=dy.device) if k < stride else torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
+            ws = WS.get("pk", pk, dy.device)
+            _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_fused(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk, B, cin, t_in, cout, t_out, k, stride,
+                                                        pad, dil, groups, 1.0, _lib.ptr(dy_mask), float(dy_mask_slope), _lib.ptr(dx_mask),
+                                                        float(dx_mask_slope), _lib.ptr(residual), _s(dy)), "evmi_conv1d_dgrad_cbt_bf16pk_fused")
+            return dx
+    dpre = dy if dy_mask is None else lrelu_bwd(dy, dy_mask, dy_mask_slope)
+    x_dummy = x_for_fallback if x_for_fallback is not None else torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
+    dx, _, _ = conv1d_bwd(x_dummy, w, dpre, stride, pad, dil, groups, need_dx=True, need_dw=False)
+    if dx_mask is not None:
+        dx = lrelu_bwd(dx, dx_mask, dx_mask_slope)
+    return dx if residual is None else axpby(1.0, dx, 1.0, residual, out=dx)
+
+
+def conv1d_fused_wgrad(x, w_shape, dy, dw_out, stride=1, pad=0, dil=1, groups=1, x_pre_slope=1.0, accumulate=True):
+    """dw (+)= conv_weight_grad(leaky_relu(x, x_pre_slope), dy)."""
+    cin, B, t_in = x.shape
+    cout, _, k = w_shape
+    t_out = dy.shape[2]
+    lib = _lib.load()
+    if _packed() and CONV_BACKEND["wgrad"] != "gemm":
+        pk = lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+        if pk > 0:
+            ws = WS.get("pkw", pk, x.device)
+            _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk_fused(x.data_ptr(), dy.data_ptr(), dw_out.data_ptr(), ws.data_ptr(), pk, B, cin, t_in, cout, t_out, k,
+                                                        stride, pad, dil, groups, int(accumulate), float(x_pre_slope), 0, 1.0, _s(x)),
+                 "evmi_conv1d_wgrad_cbt_bf16pk_fused")
+            return dw_out
+    xa = x if x_pre_slope == 1.0 else lrelu(x, x_pre_slope)
+    w_dummy = dw_out  # (only its shape is read on this path)
+    conv1d_bwd(xa, w_dummy, dy, stride, pad, dil, groups, need_dx=False, dw_out=dw_out, accumulate=accumulate)
+    return dw_out
+
+
 def dgrad_mfma_supported(B, cin, t_in, cout, t_out, k, stride, dil, groups) -> bool:
     """The input gradient runs as stride-1 convolutions of dy (c_out channels) with at most ceil(k / stride) taps."""
     if stride > 1 and dil != 1:
@@ -572,8 +642,9 @@ def attention_train_fwd(qkv, lens32, heads, p=0.0, seed=0):
     D = D3 // 3
     out = torch.empty(D, B, T, device=qkv.device, dtype=torch.float32)
     lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
-    _chk(_lib.load().evmi_mha_fwd_f32(qkv.data_ptr(), lens32.data_ptr(), out.data_ptr(), lse.data_ptr(), B, T, D, heads, float(p), int(seed),
-                                      _s(qkv)), "evmi_mha_fwd_f32")
+    lib = _lib.load()
+    fn = lib.evmi_mha_fwd_bf16 if CONV_BACKEND["operands"] == "bf16" else lib.evmi_mha_fwd_f32
+    _chk(fn(qkv.data_ptr(), lens32.data_ptr(), out.data_ptr(), lse.data_ptr(), B, T, D, heads, float(p), int(seed), _s(qkv)), "evmi_mha_fwd")
     return out, (out, lse, lens32)
 
 
@@ -582,8 +653,10 @@ def attention_train_bwd(qkv, saved, dout, heads, p=0.0, seed=0):
     D3, B, T = qkv.shape
     dqkv = torch.empty_like(qkv)
     dsum = torch.empty_like(lse)
-    _chk(_lib.load().evmi_mha_bwd_f32(qkv.data_ptr(), lens32.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dsum.data_ptr(),
-                                      dqkv.data_ptr(), B, T, D3 // 3, heads, float(p), int(seed), _s(qkv)), "evmi_mha_bwd_f32")
+    lib = _lib.load()
+    fn = lib.evmi_mha_bwd_bf16 if CONV_BACKEND["operands"] == "bf16" else lib.evmi_mha_bwd_f32
+    _chk(fn(qkv.data_ptr(), lens32.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dsum.data_ptr(), dqkv.data_ptr(), B, T, D3 // 3, heads,
+            float(p), int(seed), _s(qkv)), "evmi_mha_bwd")
     return dqkv
 
 

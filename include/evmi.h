@@ -276,6 +276,25 @@ long long evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c
 int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev,
                                  long long ws_elems, int B, int c_in, int t_in, int c_out, int n_out, int k, int stride,
                                  int pad, int dil, int groups, int accumulate, void* stream);
+/* The packed bf16 convolution kernels with a residual block's neighbours fused in (no separate activation / add passes, no
+ * activated copies in HBM) -- the training-side counterpart of SURVEY.md 8b's evmi_resblock1_fused_{fwd,bwd}:
+ *   forward   y = act(conv(leaky_relu(x, pre_slope)) + bias) + residual
+ *   dgrad     dx = conv_input_grad(dy * lrelu'(dy_mask)) * lrelu'(dx_mask) + residual        (lrelu'(m) = m > 0 ? 1 : slope;
+ *             dy_mask = the output of the activation behind the convolution, dx_mask = the input of the one in front of it)
+ *   wgrad     dw (+)= conv_weight_grad(leaky_relu(x, x_pre_slope), dy * lrelu'(dy_mask))
+ * Masks / residual may be NULL, slopes 1 = none; shapes and workspaces as the unfused entry points. */
+int evmi_conv1d_cbt_bf16pk_fused(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev,
+                                 long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out_total, int n_out, int k,
+                                 int stride, int pad, int dil, int groups, int act, float act_param, float pre_slope,
+                                 const float* residual_dev, void* stream);
+int evmi_conv1d_dgrad_cbt_bf16pk_fused(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems,
+                                       int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil,
+                                       int groups, float pre_slope, const float* dy_mask_dev, float dy_mask_slope,
+                                       const float* dx_mask_dev, float dx_mask_slope, const float* residual_dev, void* stream);
+int evmi_conv1d_wgrad_cbt_bf16pk_fused(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems,
+                                       int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil,
+                                       int groups, int accumulate, float x_pre_slope, const float* dy_mask_dev,
+                                       float dy_mask_slope, void* stream);
 /* Weight gradient of the same convolution as an implicit GEMM on the fp32 matrix cores (no unfold):
  *   dw[co][ci][j] (+)= sum_{b,to} dy[co][b][to] * x[ci][b][to*stride + j*dil - pad]
  * x [c_in][B][t_in], dy [c_out][B][n_out], dw [c_out][c_in/groups][k]; `ws_dev`: 16-byte aligned scratch of
@@ -509,6 +528,13 @@ int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, 
 int evmi_mha_bwd_f32(const float* qkv_dev, const int* lens_dev, const float* out_dev, const float* dout_dev,
                      const float* lse_dev, float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop,
                      unsigned long long seed, void* stream);
+/* The same two passes with bf16 operands (precision "bf16", BASELINE config 3): Q / K / V / dO, the probabilities and the score
+ * gradients are rounded to bf16 into v_mfma_f32_32x32x16_bf16; scores, softmax statistics and accumulators are fp32. */
+int evmi_mha_fwd_bf16(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
+                      float p_drop, unsigned long long seed, void* stream);
+int evmi_mha_bwd_bf16(const float* qkv_dev, const int* lens_dev, const float* out_dev, const float* dout_dev,
+                      const float* lse_dev, float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop,
+                      unsigned long long seed, void* stream);
 /* scores [B][Tq][Tk] -> softmax over the keys tk < lens[b] in place (0 beyond); with p > 0 also
  * dropped = dropout(probabilities, p) from the counter-based generator keyed by `seed`. */
 int evmi_softmax_rows_f32(float* scores_dev, float* dropped_dev, const int* lens_dev, int B, int Tq, int Tk, float p,

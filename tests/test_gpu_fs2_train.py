@@ -152,6 +152,42 @@ def test_attention_training_forward_backward(cuda_device, D, H, B, T):
     assert torch.equal(again, dqkv)  # one writer per element, fixed summation order
 
 
+@pytest.mark.parametrize("D,H,B,T,p", [(256, 2, 2, 300, 0.0), (64, 2, 3, 70, 0.2), (128, 2, 2, 947, 0.1)])
+def test_attention_training_bf16_operands(cuda_device, D, H, B, T, p):
+    """evmi_mha_{fwd,bwd}_bf16: Q / K / V / dO, probabilities and score gradients rounded to bf16 into the matrix cores, fp32
+    statistics and accumulation -- against torch autograd in fp32 with the same dropout mask: output within 1e-2 of its scale,
+    every gradient block (dq, dk, dv) cosine >= 0.999 and norm within 1 %."""
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(D + T)
+    dev = cuda_device
+    qkv = torch.randn(B, 3 * D, T, generator=g, requires_grad=True)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    lens[0] = T
+    keep = None
+    if p > 0:
+        ones = torch.ones(B * T * T, device=dev)
+        keep = torch.stack([(ops.dropout(ones, p, 7 + h) > 0).float().view(B, T, T) for h in range(H)], dim=1).cpu()
+    o = _attention_ref(qkv, lens, H, keep, p)
+    do = torch.randn(B, D, T, generator=g)
+    o.backward(do)
+    x, lens32 = _cbt(qkv.detach()).to(dev), lens.to(dev, torch.int32)
+    ops.CONV_BACKEND["operands"] = "bf16"
+    try:
+        out, saved = ops.attention_train_fwd(x, lens32, H, p, seed=7)
+        dqkv = ops.attention_train_bwd(x, saved, _cbt(do).to(dev), H, p, seed=7)
+        again = ops.attention_train_bwd(x, saved, _cbt(do).to(dev), H, p, seed=7)
+    finally:
+        ops.CONV_BACKEND["operands"] = "f32"
+    assert torch.equal(dqkv, again)
+    _close(out.cpu().permute(1, 0, 2), o.detach(), 1e-2)
+    got = dqkv.cpu().permute(1, 0, 2)
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        a, w = got[:, sl].double().flatten(), qkv.grad[:, sl].double().flatten()
+        cos, ratio = float(torch.dot(a, w) / (a.norm() * w.norm())), float(a.norm() / w.norm())
+        assert cos >= 0.999 and 0.99 <= ratio <= 1.01, (name, cos, ratio)
+
+
 def test_attention_dropout_matches_torch_with_the_same_mask(cuda_device):
     """With p > 0: the mask is element ((b T + q) T + k) of the counter-based stream seeded with seed + head -- the same
     stream evmi_dropout_f32 draws from, so the test reads the mask back through it -- applied to the normalised probabilities

@@ -265,6 +265,28 @@ def test_step_without_side_streams_is_bitwise_the_same(cuda_device):
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_fused_residual_pairs_equal_the_unfused_sequence(cuda_device, precision):
+    """ag.resblock_pair (activations in the packs, residual and activation backward in the epilogues) against the op-by-op
+    sequence lrelu -> conv -> lrelu -> conv -> add: the same roundings in the same order, so two steps end bitwise equal -- in
+    bf16 through the fused kernels, in f32 through the fall-back that runs the same passes separately."""
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(8)
+    B, S = 2, 2048
+    y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device)
+    mel = torch.randn(B, 80, S // 256, generator=g).to(cuda_device)
+    outs, sds = [], []
+    for fused in (True, False):
+        tr = HiFiGANTrainer(device=cuda_device, seed=5, precision=precision)
+        tr.generator.fused_pairs = fused
+        outs.append([tr.training_step(mel, y) for _ in range(2)])
+        sds.append(tr.state_dict())
+    assert outs[0] == outs[1]
+    for k in sds[0]:
+        assert torch.equal(sds[0][k], sds[1][k]), k
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
 def test_graph_replay_equals_eager_steps(cuda_device, precision):
     """use_graph=True: two eager warm-up steps, one captured, then replays -- five steps end bitwise where five eager steps do
     (same kernels, same order per tensor; the optimisers' step counters live on the device)."""
