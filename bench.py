@@ -354,6 +354,11 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     def step():
         losses.update(trainer.training_step(mel, y))
 
+    from everyvoice_amd.train import autograd as ag
+
+    ag.activation_elements(reset=True)
+    step()  # (eager: the graph is captured on a later warm-up step) -- counts the activations one step creates
+    act_elems = ag.activation_elements(reset=True)
     elapsed = timed_region(step, args.train_steps, args.train_warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     # the other precision beside it (same trainer object, fewer steps)
     other = "f32" if prec == "bf16" else "bf16"
@@ -374,8 +379,15 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     # bf16 mode: forward and input-gradient convolutions on the bf16 matrix cores (2.5 PFLOP/s dense), weight gradients still on
     # the fp32 ones (157 TFLOP/s): priced against the bf16 peak, the stricter denominator
     peak = MFMA_PEAK_TFLOPS_BF16 if prec == "bf16" else 157.0
+    n_params = params["generator"] + params["discriminators"]
+    # algorithmic HBM bytes of one step in the fp32 storage the tape uses: every activation written once and read once going
+    # forward, read once more + its gradient written and read going backward (5 passes); every parameter: weight norm (3),
+    # three forward reads, weight-gradient write, weight-norm backward (5), optimiser (7 streams) -- 19 passes
+    algorithmic_bytes = 4 * (5 * act_elems + 19 * n_params)
     roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
-            "traffic": None, "flop_per_step_per_gpu": flop_per_step, "scope": "whole training step"}
+            "traffic": None, "flop_per_step_per_gpu": flop_per_step, "scope": "whole training step",
+            "algorithmic_bytes_per_step": algorithmic_bytes, "activation_elements_per_step": act_elems,
+            "algorithmic_hbm_gbs": round(algorithmic_bytes * args.train_steps / elapsed / 1e9, 1)}
     pmc_files = sorted((ROOT / "profiles").glob("*train_pmc_summary.json"))
     if pmc_files:  # recorded rocprofv3 --pmc passes (tools/gpu_profile_train.sh): the kernel with the most HBM reads per step
         pmc = json.loads(pmc_files[-1].read_text())
@@ -390,7 +402,9 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
             f["bytes"] += (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"]
             f["launches"] += v["launches"]
         name, top = max(fam.items(), key=lambda kv: kv[1]["cycles"])
-        roof["traffic"] = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in pmc.values()) / 3)
+        steps_profiled = json.loads(pmc_files[-1].with_suffix(".meta.json").read_text())["steps"] if pmc_files[-1].with_suffix(".meta.json").exists() else 3
+        roof["traffic"] = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in pmc.values()) / steps_profiled)
+        roof["traffic_over_algorithmic"] = round(roof["traffic"] / algorithmic_bytes, 2)
         roof["traffic_source"] = f"profiles/{pmc_files[-1].name}: HBM bytes per step, all kernels (FETCH_SIZE + WRITE_SIZE, raw KiB counters)"
         roof["dominant_kernel"] = {"name": name, "mfma_busy_frac": round(top["mfma"] / max(top["cycles"], 1.0), 4),
                                    "lds_bank_conflict_frac": round(top["lds"] / max(top["cycles"], 1.0), 4),
@@ -580,7 +594,7 @@ def main(argv=None) -> int:
     # the other arithmetic beside it (the reference computes in fp32; bf16 operands with fp32 accumulation are SURVEY 8(d) C2's contract)
     other = "f32" if args.precision == "bf16" else "bf16"
     model_o = upstream_init_generator(other).to(dev).eval()
-    n_other = max(2, args.steps // 5)
+    n_other = 2
     elapsed_o = timed_region(lambda: model_o.generator(mel), n_other, 1, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     other_precision = {"dtype": other, "value": round(world * samples_per_step * n_other / elapsed_o, 1), "unit": "samples/s",
                        "ms_per_step": round(elapsed_o / n_other * 1e3, 3), "steps": n_other}

@@ -13,6 +13,18 @@ import torch
 from . import ops
 
 
+_ACTIVATION_ELEMS = [0]
+
+
+def activation_elements(reset: bool = False) -> int:
+    """Elements of every activation tensor (Var) created since the last reset: what bench.py prices a step's algorithmic HBM
+    traffic with (each activation written once and read once forward; read once more, its gradient written and read, backward)."""
+    n = _ACTIVATION_ELEMS[0]
+    if reset:
+        _ACTIVATION_ELEMS[0] = 0
+    return n
+
+
 class Var:
     __slots__ = ("data", "grad", "needs_grad")
 
@@ -20,6 +32,7 @@ class Var:
         self.data = data
         self.grad = None
         self.needs_grad = needs_grad
+        _ACTIVATION_ELEMS[0] += data.numel()
 
     def accumulate(self, g: torch.Tensor) -> None:
         if not self.needs_grad:

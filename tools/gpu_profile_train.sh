@@ -4,6 +4,7 @@ TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+export OPERANDS=${OPERANDS:-bf16} GRAPH=${GRAPH:-0} STREAMS=${STREAMS:-1}
 CMD="python3 $R/tools/train_bench.py 1"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_fetch -o p -- $CMD > $OUT/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_write -o p -- $CMD > $OUT/${TAG}_pmc_write.log 2>&1

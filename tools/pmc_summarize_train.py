@@ -47,6 +47,11 @@ for name in sorted(fetch, key=lambda n: -fetch[n].get("FETCH_SIZE", 0)):
     out[name] = e
 dst = ROOT / "profiles" / f"{tag}_pmc_summary.json"
 json.dump(out, open(dst, "w"), indent=1)
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5  # tools/train_bench.py 1: four warm-up steps + one timed
+total = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in out.values())
+json.dump({"steps": steps, "hbm_bytes_per_step": total / steps, "launches_per_step": sum(v["launches"] for v in out.values()) / steps},
+          open(dst.with_suffix(".meta.json"), "w"))
+print(f"steps {steps}: {total / steps / 1e9:.2f} GB of HBM traffic per step (raw counters)")
 for k, v in list(out.items())[:12]:
     print(k[:70], {kk: (round(vv, 4) if isinstance(vv, float) and vv < 10 else round(vv)) for kk, vv in v.items()})
 print("->", dst)
