@@ -9,6 +9,8 @@ namespace evmi {
 // ABL: ablation bits for the micro-benchmark only (tools/sweep_conv.py); 0 in the product table.
 //   1 = no weight streaming after step 0   2 = activation tile loaded for chunk 0 only
 //   4 = no epilogue                        8 = no MFMA (data movement only)
+//   64 = activation tile of the NEXT channel chunk prefetched into registers during the current chunk's taps (round 2: measured
+//        0.665 vs 0.600 ms on c128/k11 -- 20 more live VGPRs and the extra address arithmetic cost more than the exposed load)
 template <int CIN_, int KC_, int BM_, int BN_, int WM_, int WN_, int KS_, int TAPS_, int MAXDIL_, int ABL_ = 0, int OCC_ = 0>
 struct ConvTcCfg {
   static constexpr int CIN = CIN_, KC = KC_, BM = BM_, BN = BN_, WM = WM_, WN = WN_, KS = KS_,
@@ -28,6 +30,10 @@ struct ConvTcCfg {
   static constexpr int A_PER_THREAD = (A_VECS + NTHREADS - 1) / NTHREADS;
   // every tap group is full and divides evenly over the threads: no per-vector guards needed
   static constexpr bool A_EXACT = (KS % TAPS == 0) && (A_VECS % NTHREADS == 0);
+  // activation tile of the NEXT chunk kept in flight in registers while the current chunk's taps run
+  static constexpr int X_VECS_MAX = R_MAX * (KC / 8);
+  static constexpr int X_PER_THREAD = (X_VECS_MAX + NTHREADS - 1) / NTHREADS;
+  static constexpr bool X_PREFETCH = (ABL & 64) != 0;
   static constexpr size_t LDS_MAIN = size_t(R_MAX * XS + NABUF * A_TILE) * 2;
   static constexpr size_t LDS_OUT = size_t(BN) * OS * 2;
   static constexpr size_t LDS = LDS_MAIN > LDS_OUT ? LDS_MAIN : LDS_OUT;
@@ -96,12 +102,51 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
   const int rows_needed = C::BN + (C::KS - 1) * a.dil;
   const float pre = a.pre_slope;
 
+  // Variant (ABL bit 64): the activation rows of chunk c + 1 are requested (global -> registers) right after chunk c's first
+  // barrier and written to LDS at the chunk boundary, so their latency runs under chunk c's tap steps.  Not in the product
+  // table: slower than the synchronous load on every shape measured (see the bit's description above).
+  bf16x8 xreg[C::X_PER_THREAD];
+  const int x_nvec = rows_needed * (C::KC / 8);
+  auto x_prefetch = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < C::X_PER_THREAD; ++i) {
+      const int v = tid + i * C::NTHREADS;
+      const int row = v / (C::KC / 8), c8 = v % (C::KC / 8);
+      const int rr = r0 - a.pad + row;
+      bf16x8 val;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) val[e] = (bf16_t)0.f;
+      if (v < x_nvec && rr >= 0 && rr < a.t_in) val = *reinterpret_cast<const bf16x8*>(xb + (long long)rr * C::CIN + chunk * C::KC + c8 * 8);
+      xreg[i] = val;
+    }
+  };
+  auto x_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < C::X_PER_THREAD; ++i) {
+      const int v = tid + i * C::NTHREADS;
+      if (v >= x_nvec) continue;
+      const int row = v / (C::KC / 8), c8 = v % (C::KC / 8);
+      bf16x8 val = xreg[i];
+      if (pre != 1.f) {  // slope in [0, 1]: lrelu(x) = max(x, slope * x)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)val[e];
+          val[e] = (bf16_t)fmaxf(f, f * pre);
+        }
+      }
+      *reinterpret_cast<bf16x8*>(Xs + row * C::XS + c8 * 8) = val;
+    }
+  };
+
   a_prefetch(0);
+  if (C::X_PREFETCH) x_prefetch(0);
 #pragma unroll 1
   for (int chunk = 0; chunk < C::NCHUNK; ++chunk) {
     if (chunk > 0) __syncthreads();  // everyone is done reading the previous X chunk
     // ---- activation tile: rows [r0 - pad, r0 - pad + rows_needed) x channels [chunk*KC, +KC)
-    if (!(C::ABL & 2) || chunk == 0) {
+    if (C::X_PREFETCH) {
+      x_commit();
+    } else if (!(C::ABL & 2) || chunk == 0) {
       const int nvec = rows_needed * (C::KC / 8);
       for (int v = tid; v < nvec; v += C::NTHREADS) {
         const int i = v / (C::KC / 8), c8 = v % (C::KC / 8);
@@ -129,6 +174,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
       if (!(C::ABL & 1) || step == 0) a_commit(step);
       __syncthreads();
       if (step + 1 < C::NSTEP && !(C::ABL & 1)) a_prefetch(step + 1);
+      if (C::X_PREFETCH && grp == 0 && chunk + 1 < C::NCHUNK) x_prefetch(chunk + 1);
       const bf16_t* Ab = As + ((C::ABL & 1) ? 0 : (step & (C::NABUF - 1))) * C::A_TILE;
       {
         const bf16_t* Arow = Ab + (wm * C::MT * 32 + (lane & 31)) * C::AS + (lane >> 5) * 8;

@@ -101,6 +101,68 @@ __global__ void peak_normalize_kernel(const float* __restrict__ src, float* __re
   for (int t = threadIdx.x; t < t_max; t += 256) ys[t] = t < n ? xs[t] / mx * target : 0.f;  // (x / max|x|) * 0.95, the reference's two steps
 }
 
+// ---- frame-level F0 ------------------------------------------------------------------------------------
+// The reference calls pyworld (dio + stonemask, third-party C, fp64) on the CPU; that estimator is NOT reproduced.  This is a
+// normalised-autocorrelation tracker with the same interface -- one value per hop at t = f * hop, 0 for unvoiced frames, search
+// range [f0_floor, f0_ceil] = WORLD's defaults [71, 800] Hz -- so that FastSpeech2's pitch targets can be made on the device:
+//   r(lag) = sum_n x[n] x[n + lag] / sqrt(sum_n x[n]^2 * sum_n x[n + lag]^2)      n over a window of `win` samples centred on the frame
+//   best   = the SMALLEST lag whose r is a local maximum >= 0.85 * max_lag r (guards against picking a multiple of the period)
+//   voiced = r(best) >= threshold;  f0 = sr / (best + parabolic offset)
+// One workgroup per (frame, item); lags are spread over the threads, the window is staged once in LDS.
+__global__ __launch_bounds__(256) void pitch_acf_kernel(const float* __restrict__ audio, const int* __restrict__ lens, float* __restrict__ f0,
+                                                        int t_max, int n_frames, int hop, int sr, int win, int lag_lo, int lag_hi, float threshold) {
+  extern __shared__ float sm[];
+  float* xs = sm;                       // win + lag_hi + 1 samples starting at the window's first sample
+  float* r = xs + win + lag_hi + 2;     // r[lag - lag_lo + 1] with one guard entry on each side
+  const int f = blockIdx.x, b = blockIdx.y;
+  const int n = min(lens[b], t_max);
+  const int start = f * hop - win / 2;
+  const int span = win + lag_hi + 1;
+  const float* ab = audio + (long long)b * t_max;
+  for (int i = threadIdx.x; i < span; i += 256) {
+    const int g = start + i;
+    xs[i] = (g >= 0 && g < n) ? ab[g] : 0.f;
+  }
+  __syncthreads();
+  __shared__ float e0s;
+  if (threadIdx.x == 0) {
+    float e = 0.f;
+    for (int i = 0; i < win; ++i) e = fmaf(xs[i], xs[i], e);
+    e0s = e;
+  }
+  __syncthreads();
+  const float e0 = e0s;
+  const int nl = lag_hi - lag_lo + 3;  // lags lag_lo - 1 .. lag_hi + 1
+  for (int li = threadIdx.x; li < nl; li += 256) {
+    const int lag = lag_lo - 1 + li;
+    float c = 0.f, e1 = 0.f;
+    for (int i = 0; i < win; ++i) {
+      const float y = xs[i + lag];
+      c = fmaf(xs[i], y, c);
+      e1 = fmaf(y, y, e1);
+    }
+    const float den = sqrtf(e0 * e1);
+    r[li] = den > 1e-12f ? c / den : 0.f;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float rmax = 0.f;
+  for (int li = 1; li < nl - 1; ++li) rmax = fmaxf(rmax, r[li]);
+  float out = 0.f;
+  if (f * hop < n + hop && rmax >= threshold) {
+    for (int li = 1; li < nl - 1; ++li) {
+      if (r[li] >= 0.85f * rmax && r[li] >= r[li - 1] && r[li] >= r[li + 1]) {
+        const float a = r[li - 1], c0 = r[li], d = r[li + 1];
+        const float den = a - 2.f * c0 + d;
+        const float off = fabsf(den) > 1e-12f ? 0.5f * (a - d) / den : 0.f;
+        out = (float)sr / ((float)(lag_lo - 1 + li) + fminf(fmaxf(off, -0.5f), 0.5f));
+        break;
+      }
+    }
+  }
+  f0[(long long)b * n_frames + f] = out;
+}
+
 }  // namespace evmi
 
 using namespace evmi;
@@ -140,6 +202,21 @@ long long evmi_loudness_scratch_elems(int items, int channels, int t_max, int sa
   const int gate = (int)llround(0.4 * sample_rate), step = (int)(gate * (1.0 - 0.75));
   const int max_blocks = t_max >= gate ? (t_max - gate) / (step > 0 ? step : 1) + 1 : 1;
   return (long long)items * channels * max_blocks;
+}
+
+int evmi_pitch_acf_f32(const float* audio_dev, const int* lens_dev, float* f0_dev, int items, int t_max, int hop, int sample_rate, float f0_floor,
+                       float f0_ceil, float threshold, void* stream) {
+  if (!audio_dev || !lens_dev || !f0_dev || items <= 0 || t_max <= 0 || hop <= 0 || sample_rate <= 0 || f0_floor <= 0.f || f0_ceil <= f0_floor)
+    return fail(EVMI_ERR_INVALID_ARG, "pitch_acf: arguments");
+  const int lag_lo = (int)floorf((float)sample_rate / f0_ceil), lag_hi = (int)ceilf((float)sample_rate / f0_floor);
+  const int win = 2 * lag_hi;  // two periods of the lowest pitch
+  const int n_frames = t_max / hop + 1;
+  const size_t lds = ((size_t)(win + lag_hi + 2) + (size_t)(lag_hi - lag_lo + 3)) * sizeof(float);
+  if (lag_lo < 2 || lds > 64 * 1024 || items > 65535) return fail(EVMI_ERR_UNSUPPORTED, "pitch_acf: search range");
+  hipLaunchKernelGGL(pitch_acf_kernel, dim3(n_frames, items), dim3(256), lds, (hipStream_t)stream, audio_dev, lens_dev, f0_dev, t_max, n_frames, hop,
+                     sample_rate, win, lag_lo, lag_hi, threshold);
+  EVMI_LAUNCH_CHECK("pitch_acf");
+  return EVMI_OK;
 }
 
 int evmi_peak_normalize_f32(const float* src_dev, float* dst_dev, const int* lens_dev, int items, int t_max, float target, void* stream) {

@@ -143,6 +143,35 @@ def loudness(audio: torch.Tensor, lens: torch.Tensor, sample_rate: int) -> torch
     return out
 
 
+def extract_pitch(audio: torch.Tensor, lens: torch.Tensor | None, hop: int, sample_rate: int, f0_floor: float = 71.0, f0_ceil: float = 800.0,
+                  voicing_threshold: float = 0.5, interpolate: bool = True) -> torch.Tensor:
+    """Frame-level pitch [items, S // hop + 1] (Hz) of a zero-padded batch [items, t_max] on the device -- the interface and the
+    post-processing of ``Preprocessor.extract_pitch`` (preprocessor.py:244-285: unvoiced frames -> NaN -> linear interpolation
+    across them, an utterance without any voiced frame -> zeros), with a normalised-autocorrelation estimator in place of
+    pyworld's dio + stonemask (third-party CPU DSP, not reproduced: the VALUES differ from the reference's, the format does not)."""
+    from . import _lib
+
+    if not audio.is_cuda:
+        raise RuntimeError("everyvoice_amd.pipeline.extract_pitch computes on the GPU only (no CPU fallback)")
+    x = audio.to(torch.float32).reshape(-1, audio.shape[-1]).contiguous()
+    items, t_max = x.shape
+    lens32 = (torch.full((items,), t_max) if lens is None else lens).to(x.device, torch.int32).contiguous()
+    f0 = torch.empty(items, t_max // hop + 1, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().evmi_pitch_acf_f32(x.data_ptr(), lens32.data_ptr(), f0.data_ptr(), items, t_max, hop, int(sample_rate), float(f0_floor),
+                                              float(f0_ceil), float(voicing_threshold), _lib.current_stream_ptr(x.device)), "evmi_pitch_acf_f32")
+    if not interpolate:
+        return f0
+    out = f0.cpu().numpy().astype(np.float64)  # (per-utterance 1-D interpolation over a few hundred frames: host plumbing, as in the reference)
+    for i in range(items):
+        n = int(lens32[i]) // hop + 1
+        row = out[i, :n]
+        voiced = row > 0
+        if voiced.any():
+            row[~voiced] = np.interp(np.nonzero(~voiced)[0], np.nonzero(voiced)[0], row[voiced])
+        out[i, n:] = 0.0
+    return torch.from_numpy(out.astype(np.float32)).to(x.device)
+
+
 LOUDNESS_GATE_LKFS = -36.0  # preprocessor.py:180: "a conservative threshold"
 
 
@@ -235,10 +264,11 @@ class ConfigLockMismatch(RuntimeError):
 class GpuPreprocessor:
     """spec + energy (+ normalised audio) of a list of wavs, in the reference's on-disk layout, several utterances per launch."""
 
-    def __init__(self, cfg: AudioConfig | None = None, device="cuda:0", batch_items: int = 32):
+    def __init__(self, cfg: AudioConfig | None = None, device="cuda:0", batch_items: int = 32, pitch: bool = True):
         self.cfg = cfg or AudioConfig()
         self.device = torch.device(device)
         self.batch_items = batch_items
+        self.pitch = pitch  # also write pitch/<...>--pitch.pt (FastSpeech2's pitch targets; this library's own estimator, see extract_pitch)
         self.transform = MelSpectrogram(self.cfg.n_fft, self.cfg.fft_window_size, self.cfg.fft_hop_size,
                                         self.cfg.input_sampling_rate, self.cfg.n_mels, self.cfg.f_min, self.cfg.f_max)
         self.counters: dict[str, int] = {}
@@ -304,6 +334,7 @@ class GpuPreprocessor:
             t_max = max(lens)
             x = x[:, :t_max].contiguous()
             mel, energy = self.transform(x, log=True, return_energy=True, lens=torch.tensor(lens, dtype=torch.int32))
+            pitch_host = extract_pitch(x, torch.tensor(lens), hop, sr_tag).cpu() if self.pitch else None
             x_host, mel_host, energy_host = x.cpu(), mel.cpu(), energy.cpu()
             for j, i in enumerate(kept_idx):
                 it = group[i][0]
@@ -312,6 +343,8 @@ class GpuPreprocessor:
                 save_wav(x_host[j, :n], feature_path(save_dir, "audio", *ids, f"audio-{sr_tag}.wav"), sr_tag, self.cfg.target_bit_depth)
                 save_tensor(mel_host[j, :, :frames].clone(), feature_path(save_dir, "spec", *ids, spec_fn))
                 save_tensor(energy_host[j, :frames].clone(), feature_path(save_dir, "energy", *ids, "energy.pt"))
+                if pitch_host is not None:
+                    save_tensor(pitch_host[j, :frames].clone(), feature_path(save_dir, "pitch", *ids, "pitch.pt"))
                 self.counters["processed_files"] = self.counters.get("processed_files", 0) + 1
                 kept.append(dict(it, frames=frames, samples=n))
 

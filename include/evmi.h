@@ -418,6 +418,13 @@ int evmi_loudness_lkfs_f32(const float* x_dev, const int* lens_dev, float* y2_sc
 long long evmi_loudness_scratch_elems(int items, int channels, int t_max, int sample_rate);
 int evmi_peak_normalize_f32(const float* src_dev, float* dst_dev, const int* lens_dev, int items, int t_max, float target,
                             void* stream);
+/* Frame-level F0 for FastSpeech2's pitch targets (call site everyvoice/preprocessor/preprocessor.py:244-285).
+ * The reference's estimator is pyworld's dio + stonemask (third-party CPU code) and is NOT reproduced: this is a
+ * normalised-autocorrelation tracker with the same interface -- f0 [items][t_max / hop + 1] in Hz at t = f * hop, 0 where
+ * unvoiced, search range [f0_floor, f0_ceil] (WORLD's defaults are 71 and 800 Hz).  The NaN-interpolation over unvoiced
+ * frames that follows in the reference is host-side in everyvoice_amd/pipeline.py: extract_pitch. */
+int evmi_pitch_acf_f32(const float* audio_dev, const int* lens_dev, float* f0_dev, int items, int t_max, int hop,
+                       int sample_rate, float f0_floor, float f0_ceil, float threshold, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * FastSpeech2 feature-prediction forward path, channel-major fp32 x[c][b][t].

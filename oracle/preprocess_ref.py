@@ -83,3 +83,36 @@ def loudness_ref(waveform: torch.Tensor, sample_rate: int) -> float:
         gated = gated & (loud > gamma_rel)
         ef = (e * gated).sum(1) / gated.sum()
         return float(bias + 10 * np.log10((g[:, 0] * ef).sum()))
+
+
+def pitch_acf_ref(audio: np.ndarray, hop: int, sr: int, f0_floor: float = 71.0, f0_ceil: float = 800.0, threshold: float = 0.5) -> np.ndarray:
+    """The product's own F0 estimator restated (NOT pyworld -- see csrc/preprocess_ops.hip: pitch_acf_kernel): normalised
+    autocorrelation over a window of two periods of f0_floor centred on each frame, smallest local maximum within 85 % of the
+    best, parabolic refinement; 0 where max r < threshold.  [S] -> [S // hop + 1] Hz."""
+    x = np.asarray(audio, dtype=np.float32)
+    n = len(x)
+    lag_lo, lag_hi = int(np.floor(np.float32(sr) / np.float32(f0_ceil))), int(np.ceil(np.float32(sr) / np.float32(f0_floor)))
+    win = 2 * lag_hi
+    out = np.zeros(n // hop + 1, dtype=np.float32)
+    for f in range(len(out)):
+        start = f * hop - win // 2
+        idx = np.arange(start, start + win + lag_hi + 1)
+        seg = np.where((idx >= 0) & (idx < n), x[np.clip(idx, 0, n - 1)], 0.0).astype(np.float64)
+        a = seg[:win]
+        e0 = float(a @ a)
+        lags = np.arange(lag_lo - 1, lag_hi + 2)
+        r = np.zeros(len(lags))
+        for li, lag in enumerate(lags):
+            b = seg[lag : lag + win]
+            den = np.sqrt(e0 * float(b @ b))
+            r[li] = float(a @ b) / den if den > 1e-12 else 0.0
+        rmax = r[1:-1].max()
+        if rmax < threshold:
+            continue
+        for li in range(1, len(r) - 1):
+            if r[li] >= 0.85 * rmax and r[li] >= r[li - 1] and r[li] >= r[li + 1]:
+                den = r[li - 1] - 2 * r[li] + r[li + 1]
+                off = 0.5 * (r[li - 1] - r[li + 1]) / den if abs(den) > 1e-12 else 0.0
+                out[f] = sr / (lags[li] + min(max(off, -0.5), 0.5))
+                break
+    return out

@@ -580,6 +580,40 @@ def test_bucketed_allreduce_path_on_rccl_world_of_one(cuda_device):
             assert torch.equal(v, dp.last_grads[side][k]), (side, k)
 
 
+def test_graph_mode_under_data_parallelism_on_rccl_world_of_one(cuda_device):
+    """use_graph=True with a process group: the step is three graphs (up to the discriminators' gradients | their update + the
+    generator's backward | the generator's update) with the two flat-buffer all-reduces issued eagerly between them -- on a
+    one-rank "nccl" group five steps must end exactly where five plain single-GPU steps do."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(8)
+    B, S = 2, 2048
+    y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device)
+    mel = torch.randn(B, 80, S // 256, generator=g).to(cuda_device)
+    plain = HiFiGANTrainer(device=cuda_device, seed=5)
+    out_plain = [plain.training_step(mel, y) for _ in range(5)]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_device)
+    try:
+        dp = HiFiGANTrainer(device=cuda_device, seed=5, process_group=True, use_graph=True)
+        out_dp = [dp.training_step(mel, y) for _ in range(5)]
+        assert dp._graph_failed is None, dp._graph_failed
+        assert [len(e["graphs"]) for e in dp._graphs.values()] == [3]
+    finally:
+        dist.destroy_process_group()
+    assert out_plain == out_dp
+    for k, v in plain.state_dict().items():
+        assert torch.equal(v, dp.state_dict()[k]), k
+
+
 def test_multi_resolution_stft_loss_value_and_gradient(cuda_device):
     """The selectable multi-resolution STFT loss (BASELINE config 4) vs torch.stft + autograd on the CPU."""
     from everyvoice_amd.train.hifigan import MultiResolutionSTFTLoss

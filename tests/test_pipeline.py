@@ -173,7 +173,7 @@ def test_batched_preprocessing_equals_one_by_one_and_dataset_statistics(tmp_path
     assert [k["basename"] for k in kept] and sorted(k["basename"] for k in kept) == sorted(k["basename"] for k in kept1) == [f"u{i}" for i in range(5)]
     assert batched.counters == single.counters and batched.counters["audio_empty"] == 1 and batched.counters["processed_files"] == 5
     for k in kept:
-        for kind, fn in (("spec", "spec-22050-mel-librosa.pt"), ("energy", "energy.pt")):
+        for kind, fn in (("spec", "spec-22050-mel-librosa.pt"), ("energy", "energy.pt"), ("pitch", "pitch.pt")):
             a = torch.load(tmp_path / "b" / kind / f"{k['basename']}--default--default--{fn}")
             b = torch.load(tmp_path / "s" / kind / f"{k['basename']}--default--default--{fn}")
             assert torch.equal(a, b), (k["basename"], kind)
@@ -185,11 +185,46 @@ def test_batched_preprocessing_equals_one_by_one_and_dataset_statistics(tmp_path
     assert (tmp_path / "b" / ".config-lock").exists()
     # dataset statistics of the energy files, then their standardisation in place
     es, ps = batched.compute_stats(tmp_path / "b", pitch=True)
-    assert len(es) == 5 and len(ps) == 0
+    assert len(es) == 5 and len(ps) == 5  # pitch/<...>--pitch.pt is written next to energy (one value per frame)
+    assert torch.load(tmp_path / "b" / "pitch" / "u0--default--default--pitch.pt").shape == torch.load(tmp_path / "b" / "energy" / "u0--default--default--energy.pt").shape
     allv = torch.cat([torch.load(p) for p in sorted((tmp_path / "b" / "energy").iterdir())])
     stats = batched.normalize_stats(tmp_path / "b", es, ps)
-    assert set(stats) == {"energy"} and stats["energy"]["sample_size"] == 5
+    assert set(stats) == {"energy", "pitch"} and stats["energy"]["sample_size"] == 5
     assert stats["energy"]["mean"] == pytest.approx(float(allv.mean()), rel=1e-5) and stats["energy"]["std"] == pytest.approx(float(allv.std()), rel=1e-5)
     normed = torch.cat([torch.load(p) for p in sorted((tmp_path / "b" / "energy").iterdir())])
     assert abs(float(normed.mean())) < 1e-4 and float(normed.std()) == pytest.approx(1.0, rel=1e-4)
     assert stats["energy"]["norm_min"] == pytest.approx(float(normed.min()), rel=1e-4)
+
+
+@pytest.mark.gpu
+def test_pitch_targets_on_the_device(cuda_device):
+    """extract_pitch (A7): one value per hop, known F0 of harmonic test tones within 1 %, unvoiced stretches interpolated across,
+    an utterance without voicing -> zeros (preprocessor.py:277-283), and frame by frame the same estimator as its numpy
+    restatement.  (The reference's pyworld estimator is not reproduced: values are this estimator's.)"""
+    from oracle.preprocess_ref import pitch_acf_ref
+
+    sr, hop = 22050, 256
+    t = torch.arange(sr, dtype=torch.float32) / sr
+    tone = lambda f: sum(torch.sin(2 * np.pi * f * k * t) / k for k in (1, 2, 3, 4)) * 0.2  # noqa: E731
+    gen = torch.Generator().manual_seed(0)
+    glide = 0.2 * torch.sin(2 * np.pi * torch.cumsum(120.0 + 80.0 * t, 0) / sr)
+    noise = 0.05 * torch.randn(sr, generator=gen)
+    mixed = torch.cat([tone(220.0)[: sr // 3], torch.zeros(sr // 3), tone(330.0)[: sr - 2 * (sr // 3)]])
+    batch = torch.stack([tone(110.0), tone(440.0), glide, noise, mixed])
+    lens = torch.tensor([sr, sr, sr, sr, sr])
+    raw = pipeline.extract_pitch(batch.to(cuda_device), lens, hop, sr, interpolate=False).cpu()
+    assert raw.shape == (5, sr // hop + 1)
+    mid = slice(6, raw.shape[1] - 6)
+    assert float((raw[0, mid] - 110.0).abs().max()) < 1.1 and float((raw[1, mid] - 440.0).abs().max()) < 4.4
+    want_glide = (120.0 + 80.0 * torch.arange(raw.shape[1]) * hop / sr)
+    assert float(((raw[2, mid] - want_glide[mid]).abs() / want_glide[mid]).max()) < 0.02
+    assert float((raw[3] > 0).float().mean()) < 0.1  # white noise: (almost) no frame is voiced
+    for i in (0, 2, 4):
+        ref = pitch_acf_ref(batch[i].numpy(), hop, sr)
+        voiced = (ref > 0) & (raw[i].numpy() > 0)
+        assert (ref > 0).sum() == (raw[i].numpy() > 0).sum() and np.abs(ref[voiced] - raw[i].numpy()[voiced]).max() < 0.05
+    out = pipeline.extract_pitch(batch.to(cuda_device), lens, hop, sr).cpu()
+    assert float(out[4].min()) > 200.0  # the silent third is bridged between 220 and 330 Hz, as the reference's _interpolate does
+    gap = out[4, 30:57]
+    assert bool(((gap[1:] - gap[:-1]) >= -1e-3).all()) and 220.0 <= float(gap.min()) and float(gap.max()) <= 331.0
+    assert float(pipeline.extract_pitch(torch.zeros(1, sr, device=cuda_device), None, hop, sr).abs().max()) == 0.0
