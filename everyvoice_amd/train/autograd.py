@@ -53,6 +53,7 @@ class Tape:
     def backward(self) -> None:
         for fn in reversed(self._ops):
             fn()
+        ops.wgrad_join()  # weight-gradient kernels queued beside this chain (ops.side_wgrad) are part of this backward
         self._ops.clear()
 
 
@@ -118,7 +119,8 @@ def resblock_pair(tape: Tape, x: Var, c1, c2, slope: float, training: bool = Tru
             return
         C2, N2 = dy.shape[0], dy.shape[1] * dy.shape[2]
         if not c2.frozen:
-            ops.row_reduce(0, dy, None, db2, C2, N2, accumulate=True)
+            with ops.side_wgrad(dy, db2):
+                ops.row_reduce(0, dy, None, db2, C2, N2, accumulate=True)
             ops.conv1d_fused_wgrad(t, w2.shape, dy, dw2, c2.stride, c2.pad, c2.dil, c2.groups)
         dt = ops.conv1d_fused_dgrad(dy, w2, t.shape[2], c2.stride, c2.pad, c2.dil, c2.groups, x_for_fallback=t)
         if c1.frozen:

@@ -396,7 +396,7 @@ class HiFiGANTrainer:
     def __init__(self, config: HiFiGANConfig | None = None, device="cuda:0", lr=2e-4, betas=(0.8, 0.99), eps=1e-8,
                  weight_decay=0.01, seed=1234, process_group=None, reconstruction_loss="mel", stft_loss_weight=45.0,
                  precision="f32", optimizer="adamw", alpha=0.99, gan_type="original", wgan_clip_value=0.01,
-                 generator_warmup_steps=0, use_graph=False, parallel_streams=True):
+                 generator_warmup_steps=0, use_graph=False, parallel_streams=True, side_wgrad=False):
         if precision not in ("f32", "bf16"):
             raise ValueError("precision: 'f32' (exact fp32 arithmetic) or 'bf16' (bf16 convolution operands, fp32 accumulation, "
                              "fp32 master weights and activations: the mixed-precision counterpart of Lightning's bf16-mixed)")
@@ -442,6 +442,10 @@ class HiFiGANTrainer:
         self._loss_buf = torch.zeros(len(self.LOSS_KEYS), device=self.device)      # d, g_adv, g_fm, g_mel, g_stft
         self._slots = torch.zeros(4, n_d, device=self.device)                      # per-discriminator partial d / g_adv / g_fm / d (generated call of the spectral-norm scale)
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        # weight gradients on sibling streams beside the input-gradient chains (ops.side_wgrad).  Off by default: correct in eager
+        # mode (bitwise the same step), but capturing a step that forks a stream from an already forked stream ends in a
+        # segmentation fault inside hipStreamEndCapture on ROCm 7.0, and graph mode is the faster one
+        self.side_wgrad = bool(side_wgrad) and parallel_streams and not self.use_graph
         self._graphs, self._graph_warm = {}, {}
         self._graph_failed = None
         import os
@@ -584,6 +588,7 @@ class HiFiGANTrainer:
         the effective-weight gradients into parameter gradients and hand the now-final slice of the flat gradient buffer to the
         reducer (on whatever stream this bucket's backward ran on)."""
         def done():
+            ops.wgrad_join()  # this bucket's weight-gradient kernels (queued beside the chain) before their results are used
             batches = {}
             for layer in layers:
                 b = getattr(layer, "_batch", None)
@@ -673,8 +678,9 @@ class HiFiGANTrainer:
     def training_step(self, mel_bct: torch.Tensor, audio_bct: torch.Tensor, sync: bool = True):
         """mel [B, n_mels, T/hop], audio [B, 1, T] on the device.  Returns the scalar losses: python floats (ONE device-to-host
         read at the end of the step), or with ``sync=False`` a device tensor in LOSS_KEYS order (no host synchronisation)."""
-        prev = ops.CONV_BACKEND["operands"]
+        prev, prev_side = ops.CONV_BACKEND["operands"], ops.SIDE_WGRAD["on"]
         ops.CONV_BACKEND["operands"] = self.precision
+        ops.SIDE_WGRAD["on"] = self.side_wgrad and self.device.type == "cuda"
         try:
             if self.device.type != "cuda":
                 buf = self._eager_step(mel_bct, audio_bct)
@@ -691,6 +697,7 @@ class HiFiGANTrainer:
                 caller.wait_stream(self._stream)
         finally:
             ops.CONV_BACKEND["operands"] = prev
+            ops.SIDE_WGRAD["on"] = prev_side
         self.global_step += 1
         if not sync:
             return buf
@@ -733,6 +740,7 @@ class HiFiGANTrainer:
         mark("generator step: discriminators + losses + generator backward")
         self._phase_g_update(ctx)
         mark("generator update")
+
         if marks:
             marks[-1][1].synchronize()
             if self.branches.timing:
@@ -763,6 +771,7 @@ class HiFiGANTrainer:
     def _bucket_hook_late(self, tape, group, layers, reducer_box):
         """As `_bucket_hook`, with the reducer looked up when backward runs (the generator's tape is recorded long before it)."""
         def done():
+            ops.wgrad_join()
             batches = {}
             for layer in layers:
                 b = getattr(layer, "_batch", None)

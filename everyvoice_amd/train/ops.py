@@ -123,6 +123,77 @@ def scalar_reduce(mode, a, b, out, scale=1.0, p=0.0, accumulate=False):
     return out
 
 
+# ---- weight gradients beside the input-gradient chain -----------------------------------------------------
+# Backward is a chain layer -> layer through the INPUT gradients; a layer's weight / bias gradient feeds nothing but its
+# parameter-gradient buffer.  With SIDE_WGRAD["on"] (the trainers switch it on around their step) those kernels are queued on a
+# sibling stream of the current one -- forked behind the tensors they read, joined by `wgrad_join` before anything consumes the
+# parameter gradients (every Tape.backward ends with it) -- so the chain does not wait for them.  The tensors a side launch reads
+# stay referenced until the join (see the allocator note in train/layers.py: SNConv.prepare).
+SIDE_WGRAD = {"on": False}
+_SIDE: dict = {}
+_SIDE_STREAMS: set = set()
+
+
+class _SideState:
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device)
+        self.pending = None
+        self.keep = []
+
+
+def _side_state(device):
+    key = _lib.current_stream_ptr(device)
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = _SideState(device)
+        _SIDE_STREAMS.add(st.stream.cuda_stream)
+    return st
+
+
+class side_wgrad:
+    """``with side_wgrad(x, dy): <launch weight-gradient kernels>`` -- on the sibling stream when enabled, in place otherwise."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if t is not None]
+        self.ctx = None
+
+    def __enter__(self):
+        dev = self.tensors[0].device if self.tensors else None
+        if not SIDE_WGRAD["on"] or dev is None or dev.type != "cuda":
+            return self
+        if _lib.current_stream_ptr(dev) in _SIDE_STREAMS:  # already beside a chain: stay here
+            return self
+        self.state = _side_state(dev)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        self.state.stream.wait_event(ready)
+        self.state.keep.extend(self.tensors)
+        self.ctx = torch.cuda.stream(self.state.stream)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            done = torch.cuda.Event()
+            done.record(self.state.stream)
+            self.ctx.__exit__(*exc)
+            self.state.pending = done
+
+        return False
+
+
+def wgrad_join(device=None):
+    """The current stream waits for the weight-gradient kernels its sibling stream still has queued; their inputs may go."""
+    if not _SIDE:
+        return
+    cur = torch.cuda.current_stream(device)
+    st = _SIDE.get(cur.cuda_stream)
+    if st is not None and st.pending is not None:
+        cur.wait_event(st.pending)
+        st.pending = None
+        st.keep.clear()
+
+
 # ---- convolutions ---------------------------------------------------------------------------------------
 ACT_NONE, ACT_LRELU, ACT_SILU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
 
@@ -214,6 +285,7 @@ def conv1d_fused_wgrad(x, w_shape, dy, dw_out, stride=1, pad=0, dil=1, groups=1,
     if _packed() and CONV_BACKEND["wgrad"] != "gemm":
         pk = lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
         if pk > 0:
+          with side_wgrad(x, dy, dw_out):
             ws = WS.get("pkw", pk, x.device)
             _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk_fused(x.data_ptr(), dy.data_ptr(), dw_out.data_ptr(), ws.data_ptr(), pk, B, cin, t_in, cout, t_out, k,
                                                         stride, pad, dil, groups, int(accumulate), float(x_pre_slope), 0, 1.0, _s(x)),
@@ -334,6 +406,37 @@ def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, lrelu_slope=None, a
     return y
 
 
+def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, accumulate):
+    """dw (+)= conv_weight_grad(x, dy) and, when asked, db_out (+)= row sums of dy -- on whichever kernel takes the shape."""
+    cin, B, t_in = x.shape
+    cout, cin_g, k = w_shape
+    t_out = dy.shape[2]
+    N = B * t_out
+    cout_g = cout // groups
+    lib = _lib.load()
+    pk_elems = (lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+                if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"] and CONV_BACKEND["wgrad"] != "gemm" else 0)
+    ws_elems = 0
+    if pk_elems == 0 and (CONV_BACKEND["wgrad"] == "mfma" or (CONV_BACKEND["wgrad"] == "auto" and groups > 1)):
+        ws_elems = lib.evmi_conv1d_wgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+    if pk_elems > 0:  # bf16 operands: packed dy and x, transposing LDS reads (conv_wgrad_bf16_pk.hip)
+        ws = WS.get("pkw", pk_elems, x.device)
+        _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout, t_out,
+                                              k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk")
+    elif ws_elems > 0:  # implicit GEMM on the fp32 matrix cores (conv_wgrad_f32_mfma.hip)
+        ws = WS.get("wgrad", ws_elems, x.device)
+        _chk(lib.evmi_conv1d_wgrad_cbt_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
+                                           k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_f32")
+    else:
+        col = x if (k == 1 and stride == 1 and pad == 0) else unfold(x, k, stride, pad, dil)[0]
+        kg = cin_g * k
+        # dW_g [cout_g, kg] (+)= dY_g [cout_g, N] . col_g^T
+        gemm_groups(dy, col, dw, groups, cout_g, kg, N, N, N, kg, cout_g * N, kg * N, cout_g * kg, tb=True, beta=1.0 if accumulate else 0.0)
+    if db_out is not None:
+        return row_reduce(0, dy, None, db_out, cout, N, accumulate=accumulate)
+    return None
+
+
 def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=None, db_out=None, accumulate=False,
                need_dw=True):
     """Returns (dx, dw, db); dw/db are written (or accumulated) into the given buffers when provided."""
@@ -347,26 +450,8 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
     dw = db = None
     if need_dw:
         dw = dw_out if dw_out is not None else torch.empty_like(w)
-        lib = _lib.load()
-        pk_elems = (lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
-                    if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"] and CONV_BACKEND["wgrad"] != "gemm" else 0)
-        ws_elems = 0 if pk_elems > 0 else lib.evmi_conv1d_wgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) if (CONV_BACKEND["wgrad"] == "mfma" or (CONV_BACKEND["wgrad"] == "auto" and groups > 1)) else 0
-        if pk_elems > 0:  # bf16 operands: packed dy and x, transposing LDS reads (conv_wgrad_bf16_pk.hip)
-            ws = WS.get("pkw", pk_elems, x.device)
-            _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout, t_out,
-                                                  k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk")
-        elif ws_elems > 0:  # implicit GEMM on the fp32 matrix cores (conv_wgrad_f32_mfma.hip)
-            ws = WS.get("wgrad", ws_elems, x.device)
-            _chk(lib.evmi_conv1d_wgrad_cbt_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
-                                               k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_f32")
-        else:
-            col = x if (k == 1 and stride == 1 and pad == 0) else unfold(x, k, stride, pad, dil)[0]
-            beta = 1.0 if accumulate else 0.0
-            kg = cin_g * k
-            # dW_g [cout_g, kg] (+)= dY_g [cout_g, N] . col_g^T
-            gemm_groups(dy, col, dw, groups, cout_g, kg, N, N, N, kg, cout_g * N, kg * N, cout_g * kg, tb=True, beta=beta)
-        if db_out is not None:
-            db = row_reduce(0, dy, None, db_out, cout, N, accumulate=accumulate)
+        with side_wgrad(x, dy, dw, db_out):
+            db = _weight_and_bias_grad(x, w.shape, dy, dw, db_out, stride, pad, dil, groups, accumulate)
     dx = None
     if need_dx and CONV_BACKEND["dgrad"] == "mfma" and dgrad_mfma_supported(B, cin, t_in, cout, t_out, k, stride, dil, groups):
         dx = conv1d_bwd_data_mfma(dy, w, t_in, stride, pad, dil, groups)

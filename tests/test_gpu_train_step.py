@@ -645,3 +645,22 @@ def test_training_step_with_mrstft_option_runs(cuda_device):
     assert out["g_stft"] > 0 and out["g_mel"] > 0 and out["g_total"] == pytest.approx(out["g_adv"] + out["g_fm"] + out["g_mel"] + out["g_stft"])
     with pytest.raises(ValueError):
         HiFiGANTrainer(device=cuda_device, reconstruction_loss="l2")
+
+
+def test_weight_gradients_on_sibling_streams_do_not_change_the_step(cuda_device):
+    """side_wgrad=True (eager mode): weight / bias gradient kernels queued beside the input-gradient chains and joined before
+    anything reads the parameter gradients -- the same arithmetic, so two steps end bitwise where the default schedule does."""
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(8)
+    B, S = 2, 2048
+    y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device)
+    mel = torch.randn(B, 80, S // 256, generator=g).to(cuda_device)
+    outs, sds = [], []
+    for side in (True, False):
+        tr = HiFiGANTrainer(device=cuda_device, seed=5, precision="bf16", side_wgrad=side)
+        outs.append([tr.training_step(mel, y) for _ in range(2)])
+        sds.append(tr.state_dict())
+    assert outs[0] == outs[1]
+    for k in sds[0]:
+        assert torch.equal(sds[0][k], sds[1][k]), k
