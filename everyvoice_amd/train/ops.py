@@ -466,14 +466,23 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
     return dx, dw, db
 
 
+def _convt_via_dgrad():
+    import os
+    if CONV_BACKEND["dgrad"] != "mfma":
+        return False
+    if CONV_BACKEND["operands"] == "bf16":
+        return CONV_BACKEND["packed"]
+    return os.environ.get("EVMI_CONVT_F32_DGRAD", "1") == "1"
+
+
 def conv_transpose1d_fwd(x, w, bias, stride, pad):
     """x [Cin, B, T], w [Cin, Cout, k] -> y [Cout, B, (T-1)*stride - 2*pad + k]  (= dgrad of a strided conv)."""
     cin, B, t_in = x.shape
     _, cout, k = w.shape
     t_out = (t_in - 1) * stride - 2 * pad + k
-    if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"] and dgrad_mfma_supported(B, cout, t_out, cin, t_in, k, stride, 1, 1):
+    if _convt_via_dgrad() and dgrad_mfma_supported(B, cout, t_out, cin, t_in, k, stride, 1, 1):
         # a transposed convolution IS the input gradient of the strided convolution with the same weight tensor
-        # (w [c_in, c_out, k] read as [conv c_out][conv c_in][k]): the polyphase packed kernel, one launch
+        # (w [c_in, c_out, k] read as [conv c_out][conv c_in][k]): the polyphase matrix-core kernels (packed bf16 or fp32), one launch
         y = conv1d_bwd_data_mfma(x, w, t_out, stride, pad, 1, 1)
         if bias is not None:
             _chk(_lib.load().evmi_bias_add_rows_f32(y.data_ptr(), bias.data_ptr(), cout, B * t_out, _s(y)), "evmi_bias_add_rows_f32")
@@ -490,7 +499,7 @@ def conv_transpose1d_bwd(x, w, dy, stride, pad, need_dx=True, dw_out=None, db_ou
     cin, B, t_in = x.shape
     _, cout, k = w.shape
     t_out = dy.shape[2]
-    if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"] and dgrad_mfma_supported(B, cout, t_out, cin, t_in, k, stride, 1, 1):
+    if _convt_via_dgrad() and dgrad_mfma_supported(B, cout, t_out, cin, t_in, k, stride, 1, 1):
         # the adjoint pair of the above: dx = conv1d(dy, w), dw = weight gradient of that convolution with (input, output
         # gradient) = (dy, x) -- both in the transposed convolution's own weight layout [c_in, c_out, k]
         db = row_reduce(0, dy, None, db_out, cout, B * t_out, accumulate=accumulate) if db_out is not None else None

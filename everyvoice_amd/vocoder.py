@@ -24,7 +24,10 @@ from torch import nn
 from . import _lib
 from .config import ACTIVATION_SLOPES, HiFiGANConfig
 
-PRECISIONS = {"bf16": _lib.EVMI_PREC_BF16, "f32": _lib.EVMI_PREC_F32}
+# "bf16": bf16 operands / activations on the bf16 matrix cores (the headline path, native generator object)
+# "f32":  exact fp32 arithmetic on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32 = fmaf chains), channel-major kernels
+# "f32-direct": exact fp32 on the vector ALUs (the native object's direct fmaf kernels; the slowest and simplest path)
+PRECISIONS = {"bf16": _lib.EVMI_PREC_BF16, "f32": _lib.EVMI_PREC_F32, "f32-direct": _lib.EVMI_PREC_F32}
 
 
 class _ConvParams(nn.Module):
@@ -210,8 +213,61 @@ class Generator(nn.Module):
         return mel.to(torch.float32).contiguous()
 
     @torch.no_grad()
+    def _forward_f32_mfma(self, mel: torch.Tensor) -> torch.Tensor:
+        """The exact-fp32 forward on the fp32 matrix cores: the channel-major [C][B][T] convolution kernels of the training path
+        (csrc/conv_cbt_f32_mfma.hip: implicit GEMM, products and sums are exact fp32 fmaf chains) driven layer by layer with the
+        folded weights.  ~15 x the direct vector-ALU kernels' rate at the benchmark shape."""
+        from .train import autograd as ag
+        from .train import ops
+
+        m = self.config.model
+        slope = ACTIVATION_SLOPES[m.activation_function]
+        B, n_mels, T = mel.shape
+        prev = ops.CONV_BACKEND["operands"]
+        ops.CONV_BACKEND["operands"] = "f32"
+        try:
+            x = torch.empty(n_mels, B, T, device=mel.device, dtype=torch.float32)
+            _lib.check(_lib.load().evmi_transpose_bct_cbt_f32(mel.data_ptr(), x.data_ptr(), B, n_mels, T, _lib.current_stream_ptr(mel.device)),
+                       "evmi_transpose_bct_cbt_f32")
+            x = ops.conv1d_fwd(x, self.conv_pre.weight, self.conv_pre.bias, 1, 3, 1, 1)
+            nk = len(m.resblock_kernel_sizes)
+            for i, (u, ku) in enumerate(zip(m.upsample_rates, m.upsample_kernel_sizes)):
+                x = ops.conv_transpose1d_fwd(ops.lrelu(x, slope), self.ups[i].weight, self.ups[i].bias, u, (ku - u) // 2)
+                xs = None
+                for j, (k, dils) in enumerate(zip(m.resblock_kernel_sizes, m.resblock_dilation_sizes)):
+                    rb = self.resblocks[i * nk + j]
+                    y = x
+                    for q, d in enumerate(dils):
+                        if hasattr(rb, "convs1"):
+                            t = ops.conv1d_fwd(ops.lrelu(y, slope), rb.convs1[q].weight, rb.convs1[q].bias, 1, d * (k - 1) // 2, d, 1, lrelu_slope=slope)
+                            t = ops.conv1d_fwd(t, rb.convs2[q].weight, rb.convs2[q].bias, 1, (k - 1) // 2, 1, 1)
+                        else:
+                            t = ops.conv1d_fwd(ops.lrelu(y, slope), rb.convs[q].weight, rb.convs[q].bias, 1, d * (k - 1) // 2, d, 1)
+                        y = ops.axpby(1.0, t, 1.0, y, out=t)
+                    xs = y if xs is None else ops.axpby(1.0, xs, 1.0, y, out=xs)
+                x = ops.elementwise(ops.EW_SCALE, xs, out=xs, p0=1.0 / nk)
+            x = ops.lrelu(x, 0.01)
+            if m.istft_layer:
+                n_fft, hop = self.config.gen_istft_n_fft, self.config.gen_istft_hop_size
+                consts = self.__dict__.get("_istft_consts")
+                if consts is None or consts.device != mel.device:
+                    consts = ag.ISTFTConstants(n_fft, hop, mel.device)
+                    object.__setattr__(self, "_istft_consts", consts)
+                x = ops.conv1d_fwd(ops.reflect_pad_left1(x), self.conv_post.weight, self.conv_post.bias, 1, 3, 1, 1)
+                s = ops.istft_polar(x, n_fft // 2 + 1)
+                raw = ops.conv_transpose1d_fwd(s, consts.weight, None, hop, n_fft // 2)
+                x = ops.elementwise(ops.EW_MUL, raw, consts.inv_envelope(B, x.shape[2]), out=raw)
+            else:
+                x = ops.tanh(ops.conv1d_fwd(x, self.conv_post.weight, self.conv_post.bias, 1, 3, 1, 1))
+        finally:
+            ops.CONV_BACKEND["operands"] = prev
+        return x.view(B, 1, -1)  # [1, B, T'] and [B, 1, T'] are the same bytes
+
+    @torch.no_grad()
     def forward(self, mel: torch.Tensor) -> torch.Tensor:
         mel = self._check_input(mel)
+        if self.precision == "f32":
+            return self._forward_f32_mfma(mel)
         lib = self._ensure_native(mel.device)
         B, _, T = mel.shape
         wav = torch.empty(B, 1, T * self.hop, device=mel.device, dtype=torch.float32)

@@ -87,9 +87,13 @@ def test_conv_transpose1d_f32_vs_torch(cuda_device, u, k):
     torch.testing.assert_close(y.cpu(), want, rtol=1e-5, atol=1e-5)
 
 
+F32_MODES = ["f32", "f32-direct"]  # fp32 matrix-core kernels (channel-major) / direct vector-ALU kernels of the native object
+
+
+@pytest.mark.parametrize("prec", F32_MODES)
 @pytest.mark.parametrize("B,T", [(1, 1), (2, 6), (3, 37), (1, 130)])
-def test_generator_f32_vs_oracle(cuda_device, ref_gen, B, T):
-    model = _product_from_ref(ref_gen, cuda_device, "f32")
+def test_generator_f32_vs_oracle(cuda_device, ref_gen, B, T, prec):
+    model = _product_from_ref(ref_gen, cuda_device, prec)
     mel = synthetic_mel(B, T, seed=100 + T)
     with torch.no_grad():
         want = ref_gen(mel)
@@ -115,8 +119,9 @@ def test_generator_bf16_vs_oracle(cuda_device, ref_gen, B, T):
 def test_generator_vs_committed_fixture(cuda_device, ref_gen, golden_dir):
     g = np.load(golden_dir / "hifigan_v1_small.npz")
     mel, want = torch.from_numpy(g["mel"]), torch.from_numpy(g["wav"])
-    got32 = _product_from_ref(ref_gen, cuda_device, "f32")(mel.to(cuda_device)).cpu()
-    assert float((got32 - want).abs().max()) <= F32_ATOL
+    for prec in F32_MODES:
+        got32 = _product_from_ref(ref_gen, cuda_device, prec)(mel.to(cuda_device)).cpu()
+        assert float((got32 - want).abs().max()) <= F32_ATOL, prec
     got16 = _product_from_ref(ref_gen, cuda_device, "bf16")(mel.to(cuda_device)).cpu()
     assert rel_l2(got16, want) <= BF16_REL_L2
 
@@ -192,10 +197,11 @@ def test_istft_generator_vs_oracle(cuda_device, name, B, T):
     with torch.no_grad():
         want = ref(mel)
     assert want.shape == (B, 1, T * ref.hop)
-    got32 = _product_from_ref(ref, cuda_device, "f32")(mel.to(cuda_device)).cpu()
-    assert got32.shape == want.shape
     scale = float(want.abs().max())
-    assert float((got32 - want).abs().max()) <= 2e-4 * max(1.0, scale)
+    for prec in F32_MODES:
+        got32 = _product_from_ref(ref, cuda_device, prec)(mel.to(cuda_device)).cpu()
+        assert got32.shape == want.shape
+        assert float((got32 - want).abs().max()) <= 2e-4 * max(1.0, scale), prec
     got16 = _product_from_ref(ref, cuda_device, "bf16")(mel.to(cuda_device)).cpu()
     err = rel_l2(got16, want)
     print(f"istft {name} B={B} T={T}: bf16 rel_l2={err:.3e} (|wav| max {scale:.2f})")

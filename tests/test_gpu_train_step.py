@@ -16,14 +16,14 @@ from oracle.hifigan_ref import (GeneratorRef, MultiPeriodDiscriminatorRef, Multi
 pytestmark = pytest.mark.gpu
 
 
-def _params_close(name, got, want, grad, lr=2e-4):
+def _params_close(name, got, want, grad, lr=2e-4, solid_frac=1e-2):
     """Updated parameters after one AdamW step.  The first step moves every element by lr * g / (|g| + eps), i.e.
     by +-lr whatever |g| is, so an element whose gradient sits at rounding-noise level can legitimately move the
     other way: compare where the oracle's gradient is clearly above noise, bound the rest by 2 * lr."""
     diff = (got.reshape(want.shape) - want).abs()
     assert float(diff.max()) <= 2.2 * lr, name
     if grad is not None:
-        solid = grad.abs() > 1e-2 * grad.abs().max()
+        solid = grad.abs() > solid_frac * grad.abs().max()
         if solid.any():
             assert float(diff[solid].max()) <= 5e-6, name
 
@@ -199,8 +199,15 @@ class _bf16_operand_oracle:
         F.conv1d, F.conv2d, F.conv_transpose1d = self.c1, self.c2, self.ct
 
 
+# The fixture's generator gain of 8 per layer drives conv_post to ~1e14: every output sample sits at tanh = +-1, the generator's
+# gradients are exactly zero and y_hat only records signs (one of which flips with the fp32 summation order wherever the
+# pre-activation cancels to 1e-6 of its scale).  The fp32 whole-step tests therefore run the generator at gain 2 (F32_G_GAIN x 8):
+# |conv_post| ~ 0.4 (max 1.8), every generator gradient tensor well above rounding noise.
+F32_G_GAIN = 0.25
+
+
 def test_full_gan_step_matches_oracle(cuda_device, oracle_models):
-    _full_gan_step(cuda_device, oracle_models, "f32")
+    _full_gan_step(cuda_device, oracle_models, "f32", g_gain=F32_G_GAIN)
 
 
 def test_full_gan_step_bf16_operands_match_rounded_oracle(cuda_device, oracle_models):
@@ -225,7 +232,7 @@ def test_full_gan_step_istft_generator_matches_oracle(cuda_device, oracle_models
 def test_full_gan_step_at_bench_size_matches_oracle(cuda_device, oracle_models):
     """BASELINE config 4 at its own size: 16 segments of 8192 samples per GPU -- the shape bench.py times, where the planner
     picks the 128 x 128 split-K tiles and the one-launch polyphase input gradients -- whole step against the CPU oracle in fp32."""
-    _full_gan_step(cuda_device, oracle_models, "f32", B=16, S=8192)
+    _full_gan_step(cuda_device, oracle_models, "f32", g_gain=F32_G_GAIN, B=16, S=8192)
 
 
 def test_full_gan_step_at_bench_size_bf16_operands(cuda_device, oracle_models):
@@ -243,7 +250,7 @@ def test_full_gan_step_config5_vocoder_matches_oracle(cuda_device, oracle_models
 def test_full_gan_step_wgan_rmsprop_clipping_matches_oracle(cuda_device, oracle_models):
     """gan_type "wgan" (everyvoice-spec-to-wav-0.5.json:573-605): critic losses mean D(y_hat) - mean D(y) and -mean D(y_hat),
     RMSprop on both sides, critic weights clipped to +-wgan_clip_value after its step -- against torch autograd + torch.optim.RMSprop."""
-    _full_gan_step(cuda_device, oracle_models, "f32", gan_type="wgan")
+    _full_gan_step(cuda_device, oracle_models, "f32", g_gain=F32_G_GAIN, gan_type="wgan")
 
 
 def test_step_without_side_streams_is_bitwise_the_same(cuda_device):
@@ -410,6 +417,14 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
     mel_kw = C5_MEL if istft == "c5" else {}
     hop = mel_kw.get("hop", 256)
     mel = mel_ref.mel_spectrogram_ref(y.squeeze(1), **mel_kw)[:, :, : S // hop]
+    y32, mel32 = y, mel
+    if precision == "f32":
+        # The fp32 product is compared with the oracle run in FLOAT64 from the same fp32 parameters and inputs.  Two fp32 runs of
+        # this step differ from each other by more than either differs from the exact result: a leaky-ReLU / L1 kink that one of them
+        # takes on the other side moves a gradient tensor by up to 4e-2 of its largest entry at B = 2 (measured: fp32 oracle vs fp64
+        # oracle 4.0e-2 on resblocks.3.convs1.2.weight_v, and the product's deviation from the fp32 oracle was that same 4.0e-2).
+        g_ref, mpd_ref, msd_ref = g_ref.double(), mpd_ref.double(), msd_ref.double()
+        y, mel = y.double(), mel.double()
 
     # ---- oracle step (jik876 training loop order: D step, then G step) ----
     d_params_ref = list(mpd_ref.parameters()) + list(msd_ref.parameters())
@@ -427,8 +442,8 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
     else:
         loss_d = discriminator_loss_ref(r1, g1) + discriminator_loss_ref(r2, g2)
     loss_d.backward()
-    d_grads = {"mpd." + k: v.grad.clone() for k, v in mpd_ref.named_parameters()}
-    d_grads.update({"msd." + k: v.grad.clone() for k, v in msd_ref.named_parameters()})
+    d_grads = {"mpd." + k: v.grad.clone().float() for k, v in mpd_ref.named_parameters()}
+    d_grads.update({"msd." + k: v.grad.clone().float() for k, v in msd_ref.named_parameters()})
     opt_d.step()
     if wgan:
         with torch.no_grad():
@@ -443,13 +458,19 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
     loss_fm = feature_loss_ref(fr1, fg1) + feature_loss_ref(fr2, fg2)
     loss_adv = -sum(gg.mean() for gg in g1 + g2) if wgan else generator_loss_ref(g1) + generator_loss_ref(g2)
     (loss_adv + loss_fm + loss_mel).backward()
-    g_grads = {k: v.grad.clone() for k, v in g_ref.named_parameters()}
+    g_grads = {k: v.grad.clone().float() for k, v in g_ref.named_parameters()}
     opt_g.step()
+    y_hat = y_hat.float()
+    g_ref, mpd_ref, msd_ref = g_ref.float(), mpd_ref.float(), msd_ref.float()  # the updated parameters, for the comparisons below
 
     # ---- the same step on the GPU ----
-    out = tr.training_step(mel.to(cuda_device), y.to(cuda_device))
+    out = tr.training_step(mel32.to(cuda_device), y32.to(cuda_device))
     if precision == "f32":
-        torch.testing.assert_close(tr.last_grads["y_hat"].cpu().view(B, 1, S), y_hat.detach(), rtol=1e-4, atol=1e-5)
+        got_y = tr.last_grads["y_hat"].cpu().view(B, 1, S)
+        bad = ((got_y - y_hat.detach()).abs() > 1e-4).nonzero()
+        if len(bad):
+            print("y_hat mismatches:", [(tuple(i.tolist()), float(got_y[tuple(i)]), float(y_hat.detach()[tuple(i)])) for i in bad[:20]])
+        torch.testing.assert_close(got_y, y_hat.detach(), rtol=1e-4, atol=1e-5)
     else:
         dyh = (tr.last_grads["y_hat"].cpu().view(B, 1, S) - y_hat.detach()).abs()
         assert float(dyh.max()) <= 2e-2 * float(y_hat.detach().abs().max()), float(dyh.max())
@@ -472,10 +493,13 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
                 worst = min(worst, cos)
                 assert cos >= 0.99 and 0.95 <= ratio <= 1.05, f"{key}.{name}: cos {cos:.4f} norm ratio {ratio:.3f}"
         return
+    # fp32 evaluation noise of the generator's gradients against the exact (fp64) step: the fp32 ORACLE itself is 1.15e-2 away from
+    # the fp64 oracle on resblocks.8.convs1.0.weight_v at 2 x 2048 samples (kink flips), 1.3e-3 at 16 x 8192 where they average out
+    g_rel = 1e-2 if B * S >= 65536 else 2e-2
     for name, want in d_grads.items():
         _grad_close(name, tr.last_grads["d"][name].cpu(), want)
     for name, want in g_grads.items():
-        _grad_close(name, tr.last_grads["g"][name].cpu(), want)
+        _grad_close(name, tr.last_grads["g"][name].cpu(), want, rel=g_rel)
     # updated parameters after AdamW on both sides
     if wgan:  # RMSprop's first step is lr * g / (sqrt(0.01 g^2) + eps) = 10 lr sign(g); the clipped critic is compared exactly below
         sd_d = tr.d_params.state_dict()
@@ -486,7 +510,8 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
             assert float(((got - want).abs() > 2.2e-3).float().mean()) < 0.02, k  # entries whose tiny gradient changed sign: +-10 lr
         sd_g = tr.g_params.state_dict()
         for k, v in g_ref.state_dict().items():
-            _params_close(k, sd_g[k].cpu(), v, g_grads.get(k), lr=2e-3)
+            # RMSprop's first step is +-10 lr by the gradient's SIGN: only entries well above the 2e-2 gradient tolerance are pinned
+            _params_close(k, sd_g[k].cpu(), v, g_grads.get(k), lr=2e-3, solid_frac=1e-1)
         return
     sd_g = tr.g_params.state_dict()
     for k, v in g_ref.state_dict().items():

@@ -91,7 +91,17 @@ struct Variant {
   X("c128k11_bn256_md1_occ2", 128, 64, 128, 256, 2, 4, 11, 1, 1, 0, 2)  \
   X("c128k11_bn256_md1_occ3", 128, 64, 128, 256, 2, 4, 11, 1, 1, 0, 3)  \
   X("c128k3_bn256_md1_occ4", 128, 64, 128, 256, 2, 4, 3, 1, 1, 0, 4)    \
-  X("c128k3_bn256_md1_occ2", 128, 64, 128, 256, 2, 4, 3, 1, 1, 0, 2)
+  X("c128k3_bn256_md1_occ2", 128, 64, 128, 256, 2, 4, 3, 1, 1, 0, 2)    \
+  /* round 2: two independent 256-thread blocks per CU (4 waves each, 64 x 128 or 128 x 64 per wave) */ \
+  X("c128k11_w4_mt2nt4_occ2", 128, 64, 128, 256, 2, 2, 11, 1, 5, 0, 2)  \
+  X("c128k11_w4_mt4nt2_occ2", 128, 64, 128, 256, 1, 4, 11, 1, 5, 0, 2)  \
+  X("c128k11_w4_mt2nt4_occ1", 128, 64, 128, 256, 2, 2, 11, 1, 5, 0, 1)  \
+  X("c128k7_w4_mt2nt4_occ2", 128, 64, 128, 256, 2, 2, 7, 1, 5, 0, 2)    \
+  X("c128k3_w4_mt2nt4_occ2", 128, 64, 128, 256, 2, 2, 3, 1, 5, 0, 2)    \
+  X("c256k11_w4_mt2nt4_occ2", 256, 64, 128, 256, 2, 2, 11, 1, 5, 0, 2)  \
+  X("c256k3_w4_mt2nt4_occ2", 256, 64, 128, 256, 2, 2, 3, 1, 5, 0, 2)    \
+  X("c128k11_w4_bn128_occ2", 128, 64, 128, 128, 2, 2, 11, 1, 5, 0, 2)   \
+  X("c128k11_w4_bn128_occ3", 128, 64, 128, 128, 2, 2, 11, 1, 5, 0, 3)
 
 static const std::vector<Variant>& variants() {
   static const std::vector<Variant> v = {
