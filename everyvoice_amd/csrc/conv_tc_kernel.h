@@ -2,6 +2,8 @@
 // instantiates the product table, and by bench_kernels.hip, which instantiates tuning variants).
 #pragma once
 
+#include <type_traits>
+
 #include "conv_tc_mfma.h"
 
 namespace evmi {
@@ -9,14 +11,13 @@ namespace evmi {
 // ABL: ablation bits for the micro-benchmark only (tools/sweep_conv.py); 0 in the product table.
 //   1 = no weight streaming after step 0   2 = activation tile loaded for chunk 0 only
 //   4 = no epilogue                        8 = no MFMA (data movement only)
+//   128 = s_memtime stamps of one wave into args.timeline (start, X tile in LDS, per step: barrier passed / MFMAs issued, ..., stores issued)
 //   64 = activation tile of the NEXT channel chunk prefetched into registers during the current chunk's taps (round 2: measured
 //        0.665 vs 0.600 ms on c128/k11 -- 20 more live VGPRs and the extra address arithmetic cost more than the exposed load)
 template <int CIN_, int KC_, int BM_, int BN_, int WM_, int WN_, int KS_, int TAPS_, int MAXDIL_, int ABL_ = 0, int OCC_ = 0>
 struct ConvTcCfg {
   static constexpr int CIN = CIN_, KC = KC_, BM = BM_, BN = BN_, WM = WM_, WN = WN_, KS = KS_,
                        TAPS = TAPS_, MAXDIL = MAXDIL_, ABL = ABL_;
-  // waves per SIMD the register allocator must leave room for (0: no constraint beyond the block)
-  static constexpr int OCC = OCC_ > 0 ? OCC_ : (WM_ * WN_ + 3) / 4;
   static constexpr int NTHREADS = WM * WN * 64;
   static constexpr int MT = BM / (WM * 32), NT = BN / (WN * 32);
   static constexpr int XS = KC + 8, AS = KC + 8, OS = BM + 8;
@@ -37,6 +38,12 @@ struct ConvTcCfg {
   static constexpr size_t LDS_MAIN = size_t(R_MAX * XS + NABUF * A_TILE) * 2;
   static constexpr size_t LDS_OUT = size_t(BN) * OS * 2;
   static constexpr size_t LDS = LDS_MAIN > LDS_OUT ? LDS_MAIN : LDS_OUT;
+  // waves per SIMD the register allocator must leave room for.  Default: as many workgroups per CU as the LDS admits (up to 8
+  // waves per SIMD) -- two co-resident 8-wave workgroups (<= 128 VGPRs) are what hides one workgroup's tile load / epilogue
+  // behind the other's MFMAs (s_memtime timeline, tools/conv_timeline.py).
+  static constexpr int WG_PER_CU_LDS = int((160 * 1024) / LDS);
+  static constexpr int OCC_AUTO = (WM_ * WN_ + 3) / 4 * (WG_PER_CU_LDS > 2 ? 2 : WG_PER_CU_LDS);
+  static constexpr int OCC = OCC_ > 0 ? OCC_ : (OCC_AUTO > 8 ? 8 : OCC_AUTO);
   static_assert(CIN % KC == 0 && KC % 16 == 0, "channel chunking");
   static_assert(KS % TAPS == 0, "tap groups must be full");
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiling");
@@ -71,6 +78,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   bf16x8 areg[C::A_PER_THREAD];
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if ((C::ABL & 128) && a.timeline && blockIdx.x == 5 && blockIdx.y == 1 && blockIdx.z == 0 && (tid & 63) == 0 && n_stamp < 120)
+      a.timeline[(tid >> 6) * 128 + n_stamp++] = (long long)__builtin_readcyclecounter();
+  };
+  stamp();
 
   auto a_prefetch = [&](int step) {
     const int chunk = step / C::NGROUP, grp = step % C::NGROUP;
@@ -147,32 +160,44 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
     if (C::X_PREFETCH) {
       x_commit();
     } else if (!(C::ABL & 2) || chunk == 0) {
-      const int nvec = rows_needed * (C::KC / 8);
-      for (int v = tid; v < nvec; v += C::NTHREADS) {
-        const int i = v / (C::KC / 8), c8 = v % (C::KC / 8);
-        const int rr = r0 - a.pad + i;
+      // every row segment of the tile is requested before the first one is consumed: ONE memory round trip per chunk
+      // (a loop that loads, activates and stores vector by vector pays one round trip per iteration: measured 9.6k + 6.5k
+      // cycles for the two 39 KB tiles of a c128 block, s_memtime stamps of tools/conv_timeline.py)
+      bf16x8 xv[C::X_PER_THREAD];
+#pragma unroll
+      for (int i = 0; i < C::X_PER_THREAD; ++i) {
+        const int v = tid + i * C::NTHREADS;
+        const int row = v / (C::KC / 8), c8 = v % (C::KC / 8);
+        const int rr = r0 - a.pad + row;
         bf16x8 val;
-        if (rr >= 0 && rr < a.t_in) {
-          val = *reinterpret_cast<const bf16x8*>(xb + (long long)rr * C::CIN + chunk * C::KC + c8 * 8);
-          if (pre != 1.f) {  // slope in [0, 1]: lrelu(x) = max(x, slope * x)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const float f = (float)val[e];
-              val[e] = (bf16_t)fmaxf(f, f * pre);
-            }
+        for (int e = 0; e < 8; ++e) val[e] = (bf16_t)0.f;
+        if (v < x_nvec && rr >= 0 && rr < a.t_in) val = *reinterpret_cast<const bf16x8*>(xb + (long long)rr * C::CIN + chunk * C::KC + c8 * 8);
+        xv[i] = val;
+      }
+#pragma unroll
+      for (int i = 0; i < C::X_PER_THREAD; ++i) {
+        const int v = tid + i * C::NTHREADS;
+        if (v >= x_nvec) continue;
+        const int row = v / (C::KC / 8), c8 = v % (C::KC / 8);
+        bf16x8 val = xv[i];
+        if (pre != 1.f) {  // slope in [0, 1]: lrelu(x) = max(x, slope * x)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)val[e];
+            val[e] = (bf16_t)fmaxf(f, f * pre);
           }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) val[e] = (bf16_t)0.f;
         }
-        *reinterpret_cast<bf16x8*>(Xs + i * C::XS + c8 * 8) = val;
+        *reinterpret_cast<bf16x8*>(Xs + row * C::XS + c8 * 8) = val;
       }
     }
+    stamp();  // X tile written
 #pragma unroll 1
     for (int grp = 0; grp < C::NGROUP; ++grp) {
       const int step = chunk * C::NGROUP + grp;
       if (!(C::ABL & 1) || step == 0) a_commit(step);
       __syncthreads();
+      stamp();  // step barrier passed
       if (step + 1 < C::NSTEP && !(C::ABL & 1)) a_prefetch(step + 1);
       if (C::X_PREFETCH && grp == 0 && chunk + 1 < C::NCHUNK) x_prefetch(chunk + 1);
       const bf16_t* Ab = As + ((C::ABL & 1) ? 0 : (step & (C::NABUF - 1))) * C::A_TILE;
@@ -185,6 +210,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
         else
           acc[0][0][0] += (float)Arow[0] * (float)Brow[0];
       }
+      stamp();  // MFMAs of the step issued
     }
   }
 
@@ -201,6 +227,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
     return;
   }
   __syncthreads();
+  stamp();  // main loop done everywhere
   bf16_t* Os = reinterpret_cast<bf16_t*>(smem);
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt) {
@@ -219,38 +246,75 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
     }
   }
   __syncthreads();
+  stamp();  // staged
   {
     const long long ob = (long long)b * a.out_batch_stride;
     const float scale = a.out_scale, post = a.post_slope;
     constexpr int VPR = C::BM / 8;
-    for (int v = tid; v < C::BN * VPR; v += C::NTHREADS) {
+    constexpr int OPT = (C::BN * VPR + C::NTHREADS - 1) / C::NTHREADS;  // output vectors per thread
+    constexpr int EB = OPT >= 4 ? 4 : OPT;                                // vectors per batch (register budget: 2 x 4 x EB)
+    // residual / running-sum rows are requested for a whole batch of the thread's vectors before the first is consumed:
+    // one memory round trip per batch instead of one per vector (measured 13.5k cycles for 8 dependent trips on a c128 block)
+    auto flat_index = [&](int v) -> long long {
       const int n = v / VPR, c8 = v % VPR;
       const int r = r0 + n;
-      if (r >= a.n_rows) continue;
       const long long flat = (long long)r * a.out_row_stride + m0 + c8 * 8 + a.out_shift;
-      if (flat < 0 || flat >= a.out_limit) continue;
-      const bf16x8 o = *reinterpret_cast<const bf16x8*>(Os + n * C::OS + c8 * 8);
-      float f[8];
+      return (v >= C::BN * VPR || r >= a.n_rows || flat < 0 || flat >= a.out_limit) ? -1 : flat;
+    };
+    // the (residual, running sum) cases are separate straight-line bodies: with the conditions inside, the compiler joins the
+    // paths with s_waitcnt vmcnt(0) after every store
+    auto body = [&](auto has_res, auto has_acc) {
+      constexpr bool RES = decltype(has_res)::value, ACC = decltype(has_acc)::value;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] = (float)o[e];
-      if (a.res) {
-        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.res + ob + flat);
+      for (int i0 = 0; i0 < OPT; i0 += EB) {
+        bf16x8 rv[EB], pv[EB];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += (float)rv[e];
+        for (int i = 0; i < EB; ++i) {
+          // unconditional loads (vectors that are not stored read element 0 of the item): a load under a per-lane condition
+          // makes the compiler branch around it and drain the memory counter at every join
+          const long long flat = flat_index(tid + (i0 + i) * C::NTHREADS);
+          const long long safe = flat < 0 ? 0 : flat;
+          if (RES && i0 + i < OPT) rv[i] = *reinterpret_cast<const bf16x8*>(a.res + ob + safe);
+          if (ACC && i0 + i < OPT) pv[i] = *reinterpret_cast<const bf16x8*>(a.out + ob + safe);
+        }
+#pragma unroll
+        for (int i = 0; i < EB; ++i) {
+          const int v = tid + (i0 + i) * C::NTHREADS;
+          const long long flat = flat_index(v);
+          if (i0 + i >= OPT) continue;
+          const int n = (v / VPR) % C::BN, c8 = v % VPR;
+          const bf16x8 o = *reinterpret_cast<const bf16x8*>(Os + n * C::OS + c8 * 8);
+          float f[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] = (float)o[e];
+          if (RES) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += (float)rv[i][e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= scale;
+          if (ACC) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += (float)pv[i][e];
+          }
+          bf16x8 res;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) res[e] = (bf16_t)(post != 1.f ? lrelu(f[e], post) : f[e]);
+          if (flat >= 0) *reinterpret_cast<bf16x8*>(a.out + ob + flat) = res;
+        }
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) f[e] *= scale;
-      if (a.accumulate) {
-        const bf16x8 pv = *reinterpret_cast<const bf16x8*>(a.out + ob + flat);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] += (float)pv[e];
-      }
-      bf16x8 res;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) res[e] = (bf16_t)(post != 1.f ? lrelu(f[e], post) : f[e]);
-      *reinterpret_cast<bf16x8*>(a.out + ob + flat) = res;
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    if (a.res) {
+      if (a.accumulate) body(T_{}, T_{});
+      else body(T_{}, F_{});
+    } else {
+      if (a.accumulate) body(F_{}, T_{});
+      else body(F_{}, F_{});
     }
   }
+  stamp();  // stores issued
 }
 
 

@@ -37,6 +37,7 @@ struct ConvTcArgs {
   float post_slope;    // leaky-relu slope applied to the final value (1 = identity)
   float out_scale;
   int accumulate;
+  long long* timeline = nullptr;  // debug instantiations only (ABL bit 128): s_memtime stamps of wave 0 of workgroup (5, 1, 0)
 };
 
 // One launch description, so the runtime can size LDS / grid without instantiating templates.
@@ -45,6 +46,9 @@ struct ConvTcLaunch {
   int bm, bn, kc, threads;
   size_t lds_bytes;
   const char* name;
+  // weight layout the kernel reads: 0 = [mtile][chunk][tap][BM][KC]; 1 = the same with the eight 16-byte channel vectors of a
+  // row permuted for the LDS-DMA kernels (slot p of row m holds vector p ^ ((m >> 1) & 7), see conv_tc_dma_kernel.h)
+  int wlayout = 0;
 };
 
 // Returns nullptr if no instantiation covers (c_in, ks, max dilation).

@@ -12,6 +12,9 @@
 //   D: lane l holds output row l&31, channels 8*(reg>>2) + 4*(l>>5) + (reg&3): four consecutive
 //      channels per register quad -> packed to 4 x bf16 and staged through LDS so the global
 //      stores (and the residual / accumulate loads) are full 16-B, row-contiguous accesses.
+#include <cstdlib>
+
+#include "conv_tc_dma_kernel.h"
 #include "conv_tc_kernel.h"
 
 namespace evmi {
@@ -68,7 +71,30 @@ static const ConvTcEntry* conv_tc_table(int* n) {
   return table;
 }
 
+// LDS-DMA kernels for the wide layers (conv_tc_dma_kernel.h); EVMI_CONV_DMA=0 selects the register-staged kernels (A/B)
+#define EVMI_CONV_DMA_TABLE(X) \
+  X(512, 2, 1) X(256, 2, 1) X(128, 2, 1) X(256, 3, 5) X(256, 7, 5) X(256, 11, 5) X(128, 3, 5) X(128, 7, 5) X(128, 11, 5)
+
+static const ConvTcEntry* conv_dma_table(int* n) {
+#define X(cin, ks, md)                                                                          \
+  ConvTcEntry{cin, ks, md, 64, make_conv_dma_launch<ConvDmaCfg<cin, ks, md>>("conv_tc_dma<c" #cin ",k" #ks ",bm128,bn256,kc64>")},
+  static const ConvTcEntry table[] = {EVMI_CONV_DMA_TABLE(X)};
+#undef X
+  *n = (int)(sizeof(table) / sizeof(table[0]));
+  return table;
+}
+
 const ConvTcLaunch* find_conv_tc(int c_in, int c_out, int ks, int dil) {
+  static const bool use_dma = [] {
+    const char* e = getenv("EVMI_CONV_DMA");
+    return !(e && e[0] == '0');
+  }();
+  if (use_dma) {
+    int nd = 0;
+    const ConvTcEntry* d = conv_dma_table(&nd);
+    for (int i = 0; i < nd; ++i)
+      if (d[i].c_in == c_in && d[i].ks == ks && dil <= d[i].max_dil && c_out % d[i].launch.bm == 0) return &d[i].launch;
+  }
   int n = 0;
   const ConvTcEntry* t = conv_tc_table(&n);
   for (int i = 0; i < n; ++i) {

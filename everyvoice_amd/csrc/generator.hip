@@ -174,7 +174,7 @@ static int validate_cfg(const evmi_generator_config& c) {
 }
 
 // ---- bf16 weight preparation -----------------------------------------------------------------------
-// conv weight w[c_out][c_in][ks] (torch) -> kernel layout [mtile][chunk][tap][BM][KC] bf16
+// conv weight w[c_out][c_in][ks] (torch) -> kernel layout [mtile][chunk][tap][BM][KC] bf16 (ConvTcLaunch::wlayout)
 static void relayout_conv(const float* w, int c_out, int c_in, int ks, const ConvTcLaunch* L,
                           std::vector<uint16_t>& arena, size_t off) {
   const int BM = L->bm, KC = L->kc, nch = c_in / KC;
@@ -182,7 +182,8 @@ static void relayout_conv(const float* w, int c_out, int c_in, int ks, const Con
     for (int j = 0; j < ks; ++j)
       for (int c = 0; c < c_in; ++c) {
         const int mt = m / BM, mi = m % BM, chn = c / KC, ci = c % KC;
-        const size_t dst = ((((size_t)mt * nch + chn) * ks + j) * BM + mi) * KC + ci;
+        const int cs = L->wlayout == 1 ? ((((ci >> 3) ^ ((mi >> 1) & 7)) << 3) | (ci & 7)) : ci;  // swizzled 16-byte slot
+        const size_t dst = ((((size_t)mt * nch + chn) * ks + j) * BM + mi) * KC + cs;
         arena[off + dst] = f32_to_bf16_bits(w[((size_t)m * c_in + c) * ks + j]);
       }
 }

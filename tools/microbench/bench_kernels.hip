@@ -3,6 +3,7 @@
 #include <cstring>
 #include <vector>
 
+#include "conv_tc_dma_kernel.h"
 #include "conv_tc_kernel.h"
 #include "resblock_pair_kernel.h"
 
@@ -101,7 +102,9 @@ struct Variant {
   X("c256k11_w4_mt2nt4_occ2", 256, 64, 128, 256, 2, 2, 11, 1, 5, 0, 2)  \
   X("c256k3_w4_mt2nt4_occ2", 256, 64, 128, 256, 2, 2, 3, 1, 5, 0, 2)    \
   X("c128k11_w4_bn128_occ2", 128, 64, 128, 128, 2, 2, 11, 1, 5, 0, 2)   \
-  X("c128k11_w4_bn128_occ3", 128, 64, 128, 128, 2, 2, 11, 1, 5, 0, 3)
+  X("c128k11_w4_bn128_occ3", 128, 64, 128, 128, 2, 2, 11, 1, 5, 0, 3)   \
+  X("c128k11_bn256_tl", 128, 64, 128, 256, 2, 4, 11, 1, 5, 128, 2)      \
+  X("c128k11_w4_mt2nt4_occ2_tl", 128, 64, 128, 256, 2, 2, 11, 1, 5, 128, 2)
 
 static const std::vector<Variant>& variants() {
   static const std::vector<Variant> v = {
@@ -112,6 +115,17 @@ static const std::vector<Variant>& variants() {
 #define X(name, cin, kc, bm, bn, wm, wn, ks, taps, md, abl) \
   Variant{name, cin, ks, md, make_conv_tc_launch<ConvTcCfg<cin, kc, bm, bn, wm, wn, ks, taps, md, abl>>(name)},
       EVMI_VARIANTS(X)
+#undef X
+#define X(name, cin, ks, md, dbg, var) Variant{name, cin, ks, md, make_conv_dma_launch<ConvDmaCfg<cin, ks, md, dbg, var>>(name)},
+      X("c128k11_dma", 128, 11, 5, 0, 0) X("c128k7_dma", 128, 7, 5, 0, 0) X("c128k3_dma", 128, 3, 5, 0, 0)
+      X("c256k11_dma", 256, 11, 5, 0, 0) X("c256k7_dma", 256, 7, 5, 0, 0) X("c256k3_dma", 256, 3, 5, 0, 0)
+      X("c128k11_dma_tl", 128, 11, 5, 1, 0)
+      X("c128k11_dma_v1", 128, 11, 5, 0, 1) X("c128k11_dma_v2", 128, 11, 5, 0, 2) X("c128k11_dma_v3", 128, 11, 5, 0, 3)
+      X("c128k11_dma_v4", 128, 11, 5, 0, 4) X("c128k11_dma_v6", 128, 11, 5, 0, 6) X("c128k11_dma_v7", 128, 11, 5, 0, 7)
+      X("c128k11_dma_a16", 128, 11, 5, 0, 16) X("c128k11_dma_a48", 128, 11, 5, 0, 48)
+      X("c128k11_dma_a64", 128, 11, 5, 0, 64) X("c128k11_dma_a128", 128, 11, 5, 0, 128) X("c128k11_dma_a192", 128, 11, 5, 0, 192)
+      X("c128k11_dma_a208", 128, 11, 5, 0, 208)
+      X("c256k11_dma_v1", 256, 11, 5, 0, 1) X("c256k11_dma_v2", 256, 11, 5, 0, 2) X("c256k11_dma_v3", 256, 11, 5, 0, 3)
 #undef X
   };
   return v;
@@ -125,6 +139,7 @@ __global__ void fill_bf16_kernel(bf16_t* p, long long n, unsigned seed, float sc
   p[i] = (bf16_t)(((int)(h & 0xffff) - 32768) * (scale / 32768.f));
 }
 
+static long long* g_timeline = nullptr;  // device buffer the next evmi_bench_conv_tc call hands to the kernel
 }  // namespace evmi
 
 using namespace evmi;
@@ -165,6 +180,7 @@ int evmi_bench_conv_tc(const char* name, int B, int T, int c_out, int dil, int w
   a.x_batch_stride = (long long)T * cin; a.out_batch_stride = (long long)T * c_out;
   a.out_row_stride = c_out; a.out_shift = 0; a.out_limit = (long long)T * c_out;
   a.pre_slope = pre_slope; a.post_slope = 1.f; a.out_scale = 1.f; a.accumulate = 0;
+  a.timeline = g_timeline;
   hipEvent_t e0, e1;
   EVMI_HIP_CHECK(hipEventCreate(&e0));
   EVMI_HIP_CHECK(hipEventCreate(&e1));
@@ -190,6 +206,24 @@ int evmi_bench_conv_tc(const char* name, int B, int T, int c_out, int dil, int w
 }
 
 }  // extern "C"
+
+// s_memtime stamps (8 waves x 128) of one workgroup of a conv_tc debug variant (ABL bit 128), taken on the last of 3 launches.
+extern "C" int evmi_bench_conv_tc_timeline(const char* name, int B, int T, int dil, int with_residual, float pre_slope,
+                                           long long* stamps_host) {
+  long long* tl = nullptr;
+  EVMI_HIP_CHECK(hipMalloc((void**)&tl, 8 * 128 * 8));
+  EVMI_HIP_CHECK(hipMemset(tl, 0, 8 * 128 * 8));
+  g_timeline = tl;
+  float ms = 0.f;
+  double fl = 0.0;
+  const int rc = evmi_bench_conv_tc(name, B, T, 0, dil, with_residual, pre_slope, 1, &ms, &fl);
+  g_timeline = nullptr;
+  if (rc) return rc;
+  EVMI_HIP_CHECK(hipDeviceSynchronize());
+  EVMI_HIP_CHECK(hipMemcpy(stamps_host, tl, 8 * 128 * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(tl);
+  return EVMI_OK;
+}
 
 // Cycle timeline of workgroup 0 of the fused pair kernel (debug instantiation): returns up to `cap`
 // s_memtime stamps (tile start, x committed, one per step, loops done, stores issued, ... per tile).
