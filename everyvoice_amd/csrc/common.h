@@ -41,6 +41,30 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// Accumulator layout <-> 16 contiguous bytes per lane.  After a 32 x 32 MFMA chain lane (n, h) holds, for every register quad q,
+// channels 8q + 4h .. + 3 of row n.  With d = (two packed-bf16 dwords of quad 2p | two of quad 2p + 1), one v_permlane32_swap per
+// dword pair leaves lane (n, 0) with channels 16p .. 16p + 7 and lane (n, 1) with 16p + 8 .. 16p + 15 of the row.  The exchange is
+// its own inverse (also turns a lane's 16 loaded bytes into the two quads' dwords).
+__device__ __forceinline__ u32x4 swap_quads_bf16(u32x4 d) {
+  const auto r0 = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);  // vdst = dword of quad 2p, src = of quad 2p + 1
+  const auto r1 = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
+  u32x4 o;
+  o[0] = r0[0];
+  o[2] = r0[1];
+  o[1] = r1[0];
+  o[3] = r1[1];
+  return o;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  bf16x2_t pk;
+  pk[0] = (bf16_t)lo;
+  pk[1] = (bf16_t)hi;
+  return __builtin_bit_cast(unsigned, pk);
+}
+__device__ __forceinline__ float bf16_lo(unsigned d) { return __builtin_bit_cast(float, d << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned d) { return __builtin_bit_cast(float, d & 0xffff0000u); }
+
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope release fence,
 // which on gfx950 waits vmcnt(0): in a persistent kernel it would drain every global load that is
 // deliberately kept in flight across the barrier (next tile's activation rows, next tap group's

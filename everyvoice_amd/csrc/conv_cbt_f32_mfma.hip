@@ -140,14 +140,6 @@ __global__ __launch_bounds__(256) void wfrag_dgrad_kernel(const float* __restric
   }
 }
 
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-  bf2 v;
-  v[0] = (__bf16)lo;
-  v[1] = (__bf16)hi;
-  return __builtin_bit_cast(unsigned, v);
-}
-
 // bf16 fragments (v_mfma_f32_32x32x16_bf16 A operand): one 1 KB fragment per (m-block, 16-channel block, tap); lane
 // (mi = lane & 31, kh = lane >> 5) holds the 8 channels cb*16 + kh*8 + 0..7 of row mb*32 + mi as four 32-bit words:
 //   wfb[(((g*MB + mb)*CB + cb)*k + j)*256 + lane*4 + q] = bf16x2(w[.][cb*16 + kh*8 + 2q][j], w[.][.. + 2q + 1][j])

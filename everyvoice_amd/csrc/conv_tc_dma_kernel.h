@@ -106,17 +106,7 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
     const long long f = flat_nt[nt] + co;
     return (row_ok[nt] && f >= 0 && f + 8 <= a.out_limit) ? f : -1;
   };
-  // d = (dwords of quad 2p | dwords of quad 2p + 1)  <->  (this lane's 16 contiguous bytes): the exchange is its own inverse
-  auto swap_quads = [](u32x4 d) -> u32x4 {
-    const auto r0_ = __builtin_amdgcn_permlane32_swap(d[0], d[2], false, false);  // vdst = dword of quad 2p, src = of quad 2p + 1
-    const auto r1_ = __builtin_amdgcn_permlane32_swap(d[1], d[3], false, false);
-    u32x4 o;
-    o[0] = r0_[0];
-    o[2] = r0_[1];
-    o[1] = r1_[0];
-    o[3] = r1_[1];
-    return o;
-  };
+  auto swap_quads = [](u32x4 d) -> u32x4 { return swap_quads_bf16(d); };
 
   // accumulators start at the bias: the direct epilogue only scales, activates and stores
   f32x16 acc[C::MT][C::NT];

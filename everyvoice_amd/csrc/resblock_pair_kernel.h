@@ -72,7 +72,8 @@ struct PairCfg {
   static constexpr size_t OFF_RS = OFF_XA + size_t(RA_MAX) * S;
   static constexpr size_t OFF_T1 = OFF_RS + size_t(BN) * S;
   static constexpr size_t OFF_WS = OFF_T1 + size_t(T1_ROWS) * S;
-  static constexpr size_t LDS = (OFF_WS + NWBUF * size_t(W_TILE)) * 2;
+  static constexpr size_t OFF_BIAS = OFF_WS + NWBUF * size_t(W_TILE);  // 2 x C floats (in bf16 units: 4 C)
+  static constexpr size_t LDS = (OFF_BIAS + 4 * size_t(C)) * 2;
   static_assert(BN % (WAVES * 32) == 0 && C % 32 == 0, "tiling");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -84,7 +85,6 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
   bf16_t* RS = reinterpret_cast<bf16_t*>(smem) + P::OFF_RS;
   bf16_t* T1 = reinterpret_cast<bf16_t*>(smem) + P::OFF_T1;
   bf16_t* WS = reinterpret_cast<bf16_t*>(smem) + P::OFF_WS;
-  bf16_t* OS = XA;  // epilogue staging reuses the (by then dead) conv1 operand tile: BN <= RA_MAX rows
 
   constexpr int C = P::C, S = P::S, KS = P::KS, H2 = (KS - 1) / 2;
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
@@ -173,6 +173,11 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
   };
   int tile = tile_lo + slot;
   if (tile >= tile_hi) return;
+  // both bias vectors sit in LDS for the life of the (persistent) workgroup: accumulators start at the bias, read in the
+  // accumulator layout (channels 8q + 4h .. + 3 per register quad) under the first weight commit of each convolution
+  float* BIAS = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + P::OFF_BIAS);
+  for (int i = tid; i < 2 * C; i += P::NTHREADS) BIAS[i] = i < C ? a.b1[i] : a.b2[i - C];
+  // (made visible by the first step's barrier)
   x_issue(tile);
   w_prefetch(0);
 
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int c = mt * 32 + 8 * q + 4 * (lane >> 5);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b1 + c);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(BIAS + c);
 #pragma unroll
             for (int nt = 0; nt < P::NT; ++nt) {
               const int n = wn * P::NT * 32 + nt * 32 + (lane & 31);
@@ -247,48 +252,57 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
     }
 
     stamp();  // conv loops done (includes the T1 epilogue of conv1)
-    // ---- epilogue: conv2 + b2 -> LDS staging -> + residual (LDS) -> fused coalesced store --------
-    lds_barrier();  // all waves done with XA (conv1) and T1/WS reads of the last step
-#pragma unroll
-    for (int mt = 0; mt < P::MT; ++mt) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int c = mt * 32 + 8 * q + 4 * (lane >> 5);
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b2 + c);
-#pragma unroll
-        for (int nt = 0; nt < P::NT; ++nt) {
-          const int n = wn * P::NT * 32 + nt * 32 + (lane & 31);
-          bf16x4 pk;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) pk[i] = (bf16_t)(acc[mt][nt][4 * q + i] + bv[i]);
-          *reinterpret_cast<bf16x4*>(OS + n * S + c) = pk;
-        }
-      }
-    }
-    lds_barrier();
+    // ---- epilogue: conv2 + b2 + residual (LDS, accumulator layout) -> registers -> 16-byte stores ---------------
+    // No staging pass and no barrier: every wave retires its rows on its own.  Lane (n, h) holds channels 8q + 4h .. + 3 of row
+    // n per register quad q; swap_quads_bf16 turns the packed quads (2p, 2p + 1) into 16 contiguous bytes per lane.
     {
       bf16_t* ob = a.out + (long long)item * a.T * C;
       const float scale = a.out_scale, post = a.post_slope;
-      constexpr int VPR = C / 8;
-      for (int v = tid; v < P::TT * VPR; v += P::NTHREADS) {
-        const int n = v / VPR, c8 = v % VPR;
+      const int hh = lane >> 5;
+#pragma unroll
+      for (int nt = 0; nt < P::NT; ++nt) {
+        const int n = wn * P::NT * 32 + nt * 32 + (lane & 31);
         const int r = r0 + n;
-        if (r >= a.T) continue;
-        const bf16x8 o = *reinterpret_cast<const bf16x8*>(OS + n * S + c8 * 8);
-        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(RS + n * S + c8 * 8);
-        float f[8];
+        const bool ok = n < P::TT && r < a.T;
+        bf16_t* dst = ob + (long long)(ok ? r : 0) * C + 8 * hh;
+        u32x4 pv[P::MT][2];
+        if (a.accumulate) {  // wave-uniform; all of the lane's vectors are requested before the first is consumed
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = ((float)o[e] + (float)rv[e]) * scale;
-        bf16_t* dst = ob + (long long)r * C + c8 * 8;
-        if (a.accumulate) {
-          const bf16x8 pv = *reinterpret_cast<const bf16x8*>(dst);
+          for (int mt = 0; mt < P::MT; ++mt)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] += (float)pv[e];
+            for (int p2 = 0; p2 < 2; ++p2) pv[mt][p2] = *reinterpret_cast<const u32x4*>(dst + mt * 32 + 16 * p2);
         }
-        bf16x8 res;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) res[e] = (bf16_t)(post != 1.f ? fmaxf(f[e], f[e] * post) : f[e]);
-        *reinterpret_cast<bf16x8*>(dst) = res;
+        for (int mt = 0; mt < P::MT; ++mt)
+#pragma unroll
+          for (int p2 = 0; p2 < 2; ++p2) {
+            float f[8];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+              const int c = mt * 32 + 8 * (2 * p2 + qq) + 4 * hh;
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(BIAS + C + c);
+              const bf16x4 rv = *reinterpret_cast<const bf16x4*>(RS + n * S + c);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) f[4 * qq + i] = (acc[mt][nt][4 * (2 * p2 + qq) + i] + bv[i] + (float)rv[i]) * scale;
+            }
+            if (a.accumulate) {
+              const u32x4 d = swap_quads_bf16(pv[mt][p2]);
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                f[2 * w] += bf16_lo(d[w]);
+                f[2 * w + 1] += bf16_hi(d[w]);
+              }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const float lo = post != 1.f ? fmaxf(f[2 * w], f[2 * w] * post) : f[2 * w];
+              const float hi = post != 1.f ? fmaxf(f[2 * w + 1], f[2 * w + 1] * post) : f[2 * w + 1];
+              o[w] = pack_bf16x2(lo, hi);
+            }
+            o = swap_quads_bf16(o);
+            if (ok) *reinterpret_cast<u32x4*>(dst + mt * 32 + 16 * p2) = o;
+          }
       }
     }
     stamp();  // stores issued
