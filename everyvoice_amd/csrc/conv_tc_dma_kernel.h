@@ -37,7 +37,8 @@ __device__ __forceinline__ void lds_dma_b128(const void* g, void* l) {
 //   4 = s_setprio 1 around every MFMA cluster
 //   ablations (results are wrong; timing only): 16 = no step barriers and no weight requests after step 0 (fragment reads +
 //   MFMAs on whatever the LDS holds); 32 = additionally no fragment reads inside the k-loop (MFMAs on the first fragments);
-//   64 = activation tile requested for chunk 0 only; 128 = no epilogue (accumulators kept live)
+//   64 = activation tile requested for chunk 0 only; 128 = no epilogue (accumulators kept live); 256 = no step barriers
+//   (weight requests kept); 512 = no weight requests after step 0 (barriers kept)
 template <int CIN_, int KS_, int MAXDIL_, int DBG_ = 0, int VAR_ = 0>
 struct ConvDmaCfg {
   static constexpr int CIN = CIN_, KS = KS_, MAXDIL = MAXDIL_, DBG = DBG_, VAR = VAR_;
@@ -125,9 +126,22 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
   const float pre = a.pre_slope;
 
   // ---- LDS-DMA requests ------------------------------------------------------------------------------------------
-  auto issue_a = [&](int step) {  // weight image of `step` -> slot step & 1: 16 pieces, two per wave
+  auto issue_a = [&](int step) {  // weight image of `step` -> slot step & 1: 16 pieces
     const bf16_t* src = wb + (long long)step * (C::BM * C::KC) + lane * 8;
     char* dst = As + (step & 1) * C::A_BYTES;
+    if (C::VAR & 1024) {
+      // only the older half of the workgroup requests (four pieces per wave): waves 0-3 win the issue arbitration, finish their
+      // MFMAs 600-900 cycles before waves 4-7 and would wait at the barrier anyway; an LDS-DMA instruction holds its wave
+      // for 100-185 cycles, which the younger waves -- the ones that set the step time -- no longer pay
+      if (wave < C::NWAVES / 2) {
+#pragma unroll
+        for (int i = 0; i < 2 * C::A_PIECES / C::NWAVES; ++i) {
+          const int p = wave + i * (C::NWAVES / 2);
+          lds_dma_b128(src + p * 512, dst + p * 1024);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < C::A_PIECES / C::NWAVES; ++i) {
       const int p = wave + i * C::NWAVES;
@@ -213,9 +227,9 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
 #pragma unroll 1
     for (int tap = 0; tap < C::KS; ++tap) {
       const int step = chunk * C::KS + tap;
-      if (!(C::VAR & 16) || step == 0) __syncthreads();  // weight image of this step (and, at tap 0, the tile) landed and visible; slot (step + 1) & 1 is free
+      if (!(C::VAR & (16 | 256)) || step == 0) __syncthreads();  // weight image of this step (and, at tap 0, the tile) landed and visible; slot (step + 1) & 1 is free
       stamp();
-      if (step + 1 < C::NSTEP && !(C::VAR & 16)) issue_a(step + 1);
+      if (step + 1 < C::NSTEP && !(C::VAR & (16 | 512))) issue_a(step + 1);
       mma_step(As + (step & 1) * C::A_BYTES, tap);
       stamp();
     }

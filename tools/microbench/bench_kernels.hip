@@ -124,7 +124,9 @@ static const std::vector<Variant>& variants() {
       X("c128k11_dma_v4", 128, 11, 5, 0, 4) X("c128k11_dma_v6", 128, 11, 5, 0, 6) X("c128k11_dma_v7", 128, 11, 5, 0, 7)
       X("c128k11_dma_a16", 128, 11, 5, 0, 16) X("c128k11_dma_a48", 128, 11, 5, 0, 48)
       X("c128k11_dma_a64", 128, 11, 5, 0, 64) X("c128k11_dma_a128", 128, 11, 5, 0, 128) X("c128k11_dma_a192", 128, 11, 5, 0, 192)
-      X("c128k11_dma_a208", 128, 11, 5, 0, 208)
+      X("c128k11_dma_v1024", 128, 11, 5, 0, 1024) X("c128k11_dma_v1025", 128, 11, 5, 0, 1025) X("c256k11_dma_v1024", 256, 11, 5, 0, 1024)
+      X("c128k7_dma_v1024", 128, 7, 5, 0, 1024)
+      X("c128k11_dma_a208", 128, 11, 5, 0, 208) X("c128k11_dma_a256", 128, 11, 5, 0, 256) X("c128k11_dma_a512", 128, 11, 5, 0, 512)
       X("c256k11_dma_v1", 256, 11, 5, 0, 1) X("c256k11_dma_v2", 256, 11, 5, 0, 2) X("c256k11_dma_v3", 256, 11, 5, 0, 3)
 #undef X
   };

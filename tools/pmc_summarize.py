@@ -28,6 +28,10 @@ def short(name: str) -> str:
     if m:
         p = [x.strip() for x in m.group(1).split(",")]
         return f"conv_tc_mfma<c{p[0]},k{p[6]},bm{p[2]},bn{p[3]},kc{p[1]},t{p[7]}>"
+    m = re.search(r"ConvDmaCfg<([^>]*)>", name)
+    if m:
+        p = [x.strip() for x in m.group(1).split(",")]
+        return f"conv_tc_dma<c{p[0]},k{p[1]},bm128,bn256,kc64>"
     m = re.search(r"PairCfg<([^>]*)>", name)
     if m:
         p = [x.strip() for x in m.group(1).split(",")]
