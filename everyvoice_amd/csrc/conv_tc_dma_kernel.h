@@ -39,10 +39,11 @@ __device__ __forceinline__ void lds_dma_b128(const void* g, void* l) {
 //   MFMAs on whatever the LDS holds); 32 = additionally no fragment reads inside the k-loop (MFMAs on the first fragments);
 //   64 = activation tile requested for chunk 0 only; 128 = no epilogue (accumulators kept live); 256 = no step barriers
 //   (weight requests kept); 512 = no weight requests after step 0 (barriers kept)
-template <int CIN_, int KS_, int MAXDIL_, int DBG_ = 0, int VAR_ = 0>
+// WN_ = 8: sixteen waves on 512 rows, ONE workgroup per CU (every weight image feeds twice the MFMAs); A/B variant
+template <int CIN_, int KS_, int MAXDIL_, int DBG_ = 0, int VAR_ = 0, int WN_ = 4>
 struct ConvDmaCfg {
   static constexpr int CIN = CIN_, KS = KS_, MAXDIL = MAXDIL_, DBG = DBG_, VAR = VAR_;
-  static constexpr int KC = 64, BM = 128, BN = 256, WM = 2, WN = 4, MT = 2, NT = 2;
+  static constexpr int KC = 64, BM = 128, WM = 2, WN = WN_, MT = 2, NT = 2, BN = WN * NT * 32;
   static constexpr int NTHREADS = WM * WN * 64, NWAVES = WM * WN;
   static constexpr int NCHUNK = CIN / KC, NSTEP = NCHUNK * KS;
   static constexpr int R_MAX = BN + (KS - 1) * MAXDIL;
@@ -56,11 +57,13 @@ struct ConvDmaCfg {
   static constexpr size_t LDS = LDS_MAIN > LDS_OUT ? LDS_MAIN : LDS_OUT;
   static constexpr int X_VEC_PER_THREAD = (X_PIECES * 64 + NTHREADS - 1) / NTHREADS;
   static_assert(CIN % KC == 0, "channel chunking");
-  static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+  static_assert((WN == 4 ? 2 : 1) * LDS <= 160 * 1024, "two workgroups per CU (one for the 16-wave form)");
+  static_assert(A_PIECES % NWAVES == 0 || NWAVES == 16, "weight pieces per wave");
 };
 
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs a) {
+  static_assert(C::NWAVES == 8 || C::NWAVES == 16, "8 or 16 waves");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Xs = smem;
   char* As = smem + C::X_BYTES;
@@ -143,9 +146,9 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
       return;
     }
 #pragma unroll
-    for (int i = 0; i < C::A_PIECES / C::NWAVES; ++i) {
+    for (int i = 0; i < (C::A_PIECES + C::NWAVES - 1) / C::NWAVES; ++i) {
       const int p = wave + i * C::NWAVES;
-      lds_dma_b128(src + p * 512, dst + p * 1024);
+      if (p < C::A_PIECES) lds_dma_b128(src + p * 512, dst + p * 1024);
     }
   };
   auto issue_x = [&](int chunk) {  // activation rows [r0 - pad, + rows_needed) x channels [chunk * 64, + 64), 8-row pieces

@@ -1,21 +1,29 @@
 // Instantiations and launcher of the fused residual-pair kernel (resblock_pair_kernel.h).
+#include <cstdlib>
+
 #include "resblock_pair_chunked_kernel.h"
 
 namespace evmi {
 
-//                  C  KS  BN  TAPS MAXDIL WAVES NWBUF
-// C = 32: all taps of one convolution fit LDS at once (single buffer): 2 weight steps per tile
-#define EVMI_PAIR_TABLE(X)      \
-  X(64, 3, 256, 2, 5, 8, 2)     \
-  X(64, 7, 256, 2, 5, 8, 2)     \
-  X(64, 11, 256, 2, 5, 8, 2)    \
-  X(32, 3, 512, 3, 5, 8, 2)     \
-  X(32, 7, 512, 7, 5, 8, 1)     \
-  X(32, 11, 512, 11, 5, 8, 1)
+//                  C  KS  BN  TAPS MAXDIL WAVES NWBUF OVL
+// C = 32: all taps of one convolution fit LDS at once (single buffer): 2 weight steps per tile.  The first three entries are
+// the two-workgroups-per-CU form (4 waves, 256 rows, T1 over XA), selected by EVMI_PAIR_OVL=1 only: measured 1.22 vs 1.16 ms
+// on c32 / k11 (and 3.1 vs 1.95 ms for a 128-row two-workgroup form at C = 64) -- with half the waves per workgroup the phases
+// of one workgroup are not filled by the other.
+#define EVMI_PAIR_TABLE(X)         \
+  X(32, 3, 256, 3, 5, 4, 2, 1)     \
+  X(32, 7, 256, 7, 5, 4, 1, 1)     \
+  X(32, 11, 256, 11, 5, 4, 1, 1)   \
+  X(64, 3, 256, 2, 5, 8, 2, 0)     \
+  X(64, 7, 256, 2, 5, 8, 2, 0)     \
+  X(64, 11, 256, 2, 5, 8, 2, 0)    \
+  X(32, 3, 512, 3, 5, 8, 2, 0)     \
+  X(32, 7, 512, 7, 5, 8, 1, 0)     \
+  X(32, 11, 512, 11, 5, 8, 1, 0)
 
 static const PairLaunch* pair_table(int* n) {
-#define X(c, ks, bn, taps, md, waves, nwbuf) \
-  make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
+#define X(c, ks, bn, taps, md, waves, nwbuf, ovl) \
+  make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf, ovl>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
   static const PairLaunch table[] = {
       EVMI_PAIR_TABLE(X)
       // C = 128: chunked variant (64-channel operand chunks, 2 x 4 waves of 64 x 64).  Measured on MI355X
@@ -29,10 +37,20 @@ static const PairLaunch* pair_table(int* n) {
 }
 
 const PairLaunch* find_resblock_pair(int c, int ks, int dil) {
+  // A/B switch: EVMI_PAIR_C128=0 routes the 128-channel k = 3 pairs to two LDS-DMA convolution launches instead
+  static const bool c128_pairs = [] {
+    const char* e = getenv("EVMI_PAIR_C128");
+    return !(e && e[0] == '0');
+  }();
+  if (c >= 128 && !c128_pairs) return nullptr;
+  static const int ovl = [] {
+    const char* e = getenv("EVMI_PAIR_OVL");
+    return e ? atoi(e) : 0;
+  }();
   int n = 0;
   const PairLaunch* t = pair_table(&n);
   for (int i = 0; i < n; ++i)
-    if (t[i].c == c && t[i].ks == ks && dil <= t[i].max_dil) return &t[i];
+    if (t[i].c == c && t[i].ks == ks && dil <= t[i].max_dil && (t[i].wg_per_cu == 1 || ovl)) return &t[i];
   return nullptr;
 }
 
@@ -50,7 +68,7 @@ int launch_resblock_pair(const PairLaunch* L, PairArgs a, int B, int n_cu, hipSt
   a.n_tiles = a.tiles_per_item * B;
   // persistent: one workgroup per CU (LDS-bound residency), a multiple of 8 so every XCD gets the
   // same number of workgroups (the kernel's tile walk relies on it)
-  int grid = n_cu > 0 ? n_cu : 256;
+  int grid = (n_cu > 0 ? n_cu : 256) * L->wg_per_cu;
   grid = (grid + 7) / 8 * 8;
   const int needed = (a.n_tiles + 7) / 8 * 8;
   if (grid > needed) grid = needed;

@@ -42,14 +42,18 @@ struct PairArgs {
 struct PairLaunch {
   void (*kernel)(PairArgs);
   int c, ks, bn, tt, threads, max_dil;
+  int wg_per_cu = 1;  // persistent workgroups per CU (LDS-bound residency)
   int kc;  // channel chunk of the weight layout [chunk][tap][C][kc] (== c when the layer is not chunked)
   size_t lds_bytes;
   const char* name;
 };
 
-template <int C_, int KS_, int BN_, int TAPS_, int MAXDIL_, int WAVES_, int DBG_ = 0, int NWBUF_ = 2>
+// OVL_: the intermediate T1 overlays the conv1 operand tile XA (dead once conv1's last MFMA has read it; one more barrier
+// before T1 is written).  With it a 32-channel, 256-row tile needs ~73 KB: TWO 4-wave workgroups share a CU (WG_PER_CU) and one's
+// tile load / epilogue phases run under the other's MFMAs, where a single 8-wave workgroup per CU exposes every phase.
+template <int C_, int KS_, int BN_, int TAPS_, int MAXDIL_, int WAVES_, int DBG_ = 0, int NWBUF_ = 2, int OVL_ = 0>
 struct PairCfg {
-  static constexpr int C = C_, KS = KS_, BN = BN_, TAPS = TAPS_, MAXDIL = MAXDIL_, WAVES = WAVES_, DBG = DBG_;
+  static constexpr int C = C_, KS = KS_, BN = BN_, TAPS = TAPS_, MAXDIL = MAXDIL_, WAVES = WAVES_, DBG = DBG_, OVL = OVL_;
   // weight tap-group buffers in LDS: 2 = commit the next group while the current one is read; 1 = one
   // buffer (lets a whole convolution's taps sit in LDS at once) at the price of a barrier before each commit
   static constexpr int NWBUF = NWBUF_;
@@ -70,11 +74,13 @@ struct PairCfg {
   static constexpr int X_PER_THREAD = (X_VECS_MAX + NTHREADS - 1) / NTHREADS;
   static constexpr size_t OFF_XA = 0;
   static constexpr size_t OFF_RS = OFF_XA + size_t(RA_MAX) * S;
-  static constexpr size_t OFF_T1 = OFF_RS + size_t(BN) * S;
-  static constexpr size_t OFF_WS = OFF_T1 + size_t(T1_ROWS) * S;
+  static constexpr size_t OFF_T1 = OVL ? OFF_XA : OFF_RS + size_t(BN) * S;
+  static constexpr size_t OFF_WS = OVL ? OFF_RS + size_t(BN) * S : OFF_T1 + size_t(T1_ROWS) * S;
   static constexpr size_t OFF_BIAS = OFF_WS + NWBUF * size_t(W_TILE);  // 2 x C floats (in bf16 units: 4 C)
   static constexpr size_t LDS = (OFF_BIAS + 4 * size_t(C)) * 2;
+  static constexpr int WG_PER_CU = (2 * LDS <= 160 * 1024 && WAVES <= 4) ? 2 : 1;
   static_assert(BN % (WAVES * 32) == 0 && C % 32 == 0, "tiling");
+  static_assert(!OVL || T1_ROWS <= RA_MAX, "T1 fits the operand tile it overlays");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -219,6 +225,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
       }
       if (conv == 0) {
         // T1[n] = lrelu(conv1 + b1) for global row r0 - H2 + n, zero outside the sequence
+        if (P::OVL) lds_barrier();  // T1 overlays XA: every wave is done with conv1's last fragment reads
         const float sl = a.slope;
 #pragma unroll
         for (int mt = 0; mt < P::MT; ++mt) {
@@ -323,6 +330,7 @@ static PairLaunch make_pair_launch(const char* name) {
   l.lds_bytes = P::LDS;
   l.name = name;
   l.kc = P::C;
+  l.wg_per_cu = P::WG_PER_CU;
   return l;
 }
 

@@ -117,6 +117,9 @@ static const std::vector<Variant>& variants() {
       EVMI_VARIANTS(X)
 #undef X
 #define X(name, cin, ks, md, dbg, var) Variant{name, cin, ks, md, make_conv_dma_launch<ConvDmaCfg<cin, ks, md, dbg, var>>(name)},
+      Variant{"c128k11_dma_w16", 128, 11, 5, make_conv_dma_launch<ConvDmaCfg<128, 11, 5, 0, 0, 8>>("c128k11_dma_w16")},
+      Variant{"c256k11_dma_w16", 256, 11, 5, make_conv_dma_launch<ConvDmaCfg<256, 11, 5, 0, 0, 8>>("c256k11_dma_w16")},
+      Variant{"c128k3_dma_w16", 128, 3, 5, make_conv_dma_launch<ConvDmaCfg<128, 3, 5, 0, 0, 8>>("c128k3_dma_w16")},
       X("c128k11_dma", 128, 11, 5, 0, 0) X("c128k7_dma", 128, 7, 5, 0, 0) X("c128k3_dma", 128, 3, 5, 0, 0)
       X("c256k11_dma", 256, 11, 5, 0, 0) X("c256k7_dma", 256, 7, 5, 0, 0) X("c256k3_dma", 256, 3, 5, 0, 0)
       X("c128k11_dma_tl", 128, 11, 5, 1, 0)
