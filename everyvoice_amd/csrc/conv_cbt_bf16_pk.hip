@@ -350,68 +350,28 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     }
     return;
   }
-  // The mask / residual / running-sum operands of a (column, m-tile) block are requested for all 16 registers BEFORE the first
-  // is consumed, through unconditional loads (lanes without an output read a clamped, valid address), and the three wave-uniform
-  // cases are separate straight-line bodies.  With the loads under per-element conditions the compiler drained the memory counter
-  // after every one of them: up to 48 dependent round trips per 32 x 32 block (321 s_waitcnt vmcnt(0) in the 32 x 128 kernel).
-  // Element indices are 32-bit (tensors of this model stay far below 2^30 elements): uniform base pointer + one VGPR offset per
-  // load, and the batches are fenced so that the register allocation stays at the main loop's (these kernels live on 6-8 waves
-  // per SIMD: 58-144 VGPRs).
-  const unsigned ch_plane = (unsigned)a.B * (unsigned)a.t_out_total;
-  auto tail = [&](auto act_c, auto mask_c, auto res_c, auto accum_c) {
+  pk_with_act(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
-    constexpr bool MASK = decltype(mask_c)::value, RES = decltype(res_c)::value, ACCUM = decltype(accum_c)::value;
-    constexpr int RB = MT * NT >= 4 ? 4 : 8;  // registers per batch
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const bool col_ok = col_b[nt] >= 0;
-      const unsigned colbase = col_ok ? (unsigned)col_b[nt] * (unsigned)a.t_out_total + (unsigned)col_to[nt] * (unsigned)a.out_stride + (unsigned)out_off : 0u;
+      if (col_b[nt] < 0) continue;
+      float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int rb = 0; rb < 16; rb += RB) {
-          float bv[RB], mk[RB], rs[RB], old[RB];
-          unsigned off[RB];
-#pragma unroll
-          for (int i = 0; i < RB; ++i) {
-            const int r = rb + i;
-            const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int co = co0 + min(m, m_valid - 1);
-            off[i] = colbase + (unsigned)co * ch_plane;
-            bv[i] = a.bias ? a.bias[co] : 0.f;
-            if (MASK) mk[i] = a.out_mask[off[i]];
-            if (RES) rs[i] = a.res[off[i]];
-            if (ACCUM) old[i] = a.y[off[i]];
-          }
-#pragma unroll
-          for (int i = 0; i < RB; ++i) {
-            const int r = rb + i;
-            const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            // separately rounded steps, as the op-by-op sequence this epilogue replaces (no fused multiply-add across them)
-            float v = pk_act<ACT>(__fadd_rn(acc[mt][nt][r], bv[i]), a.act_param);
-            if (MASK) v = __fmul_rn(v, mk[i] > 0.f ? 1.f : a.out_mask_slope);
-            if (RES) v = __fadd_rn(v, rs[i]);
-            if (ACCUM) v = __fadd_rn(old[i], v);
-            if (col_ok && m < m_valid) a.y[off[i]] = v;
-          }
-          __builtin_amdgcn_sched_barrier(0);
+        for (int r = 0; r < 16; ++r) {
+          const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (m >= m_valid) continue;
+          const int co = co0 + m;
+          float v = acc[mt][nt][r];
+          if (a.bias) v += a.bias[co];
+          v = pk_act<ACT>(v, a.act_param);
+          float* dst = ycol + (long long)co * a.B * a.t_out_total;
+          if (a.out_mask) v *= a.out_mask[dst - a.y] > 0.f ? 1.f : a.out_mask_slope;
+          if (a.res) v += a.res[dst - a.y];
+          *dst = a.accumulate ? *dst + v : v;
         }
       }
-    }
-  };
-  using T_ = std::integral_constant<bool, true>;
-  using F_ = std::integral_constant<bool, false>;
-  pk_with_act(a.act, [&](auto act_c) {
-    auto with_acc = [&](auto mask_c, auto res_c) {
-      if (a.accumulate) tail(act_c, mask_c, res_c, T_{});
-      else tail(act_c, mask_c, res_c, F_{});
-    };
-    if (a.out_mask) {
-      if (a.res) with_acc(T_{}, T_{});
-      else with_acc(T_{}, F_{});
-    } else {
-      if (a.res) with_acc(F_{}, T_{});
-      else with_acc(F_{}, F_{});
     }
   });
 }
