@@ -427,7 +427,18 @@ class FastSpeech2Trainer:
         self._prior = None
         self._seed = seed
         self._grad_norm = torch.zeros(1, device=self.device)
+        self._reducer, self._tail_lo = None, None
         self.init_random(seed)
+
+    def _tail_offset(self) -> int:
+        """First element of the flat buffers that belongs to the decoder / mel_linear / postnet (declared last, in this order)."""
+        if self._tail_lo is None:
+            tail = ("decoder.", "mel_linear.", "postnet.")
+            names = self.params.names()
+            lo = min(self.params.offset_of(n) for n in names if n.startswith(tail))
+            assert all(n.startswith(tail) == (self.params.offset_of(n) >= lo) for n in names), "decoder-side parameters are not a suffix of the buffer"
+            self._tail_lo = lo
+        return self._tail_lo
 
     # -- parameters ---------------------------------------------------------------------------------------------------
     def init_random(self, seed: int = 1234):
@@ -597,6 +608,12 @@ class FastSpeech2Trainer:
             x_enc.accumulate(dx)
 
         tape.record(lr_bwd)
+        if self._reducer is not None:
+            # data parallel: the decoder / mel_linear / postnet gradients -- the tail of the flat buffer, ~half of the parameters --
+            # are final once backward leaves the decoder; their all-reduce runs on a side stream under the backward of the
+            # variance adaptor, the aligner and the encoder (recorded BEFORE the decoder's forward = run AFTER its backward)
+            lo_tail, red = self._tail_offset(), self._reducer
+            tape.record(lambda: red.launch(lo_tail, self.params.grad.numel()))
         y = self.decoder.forward(tape, f, mel_lens, seeds)
         mel = masked(tape, dense(tape, y, self.mel_linear), mel_lens)
         n_el = n_frames * c.n_mels
@@ -667,15 +684,21 @@ class FastSpeech2Trainer:
 
     def training_step(self, batch: dict) -> dict:
         """One optimiser step; returns the losses as device scalars (no host synchronisation inside the step)."""
-        from .hifigan import allreduce_mean_
+        from .hifigan import BucketReducer
         prev = ops.CONV_BACKEND["operands"]
         ops.CONV_BACKEND["operands"] = self.precision
         try:
+            # data parallel (SURVEY.md 8e): utterances are sharded across ranks, gradients averaged by a bucketed all-reduce that
+            # overlaps backward (two buckets: see forward_backward)
+            self._reducer = (BucketReducer(self.params.grad, self.pg if self.pg is not True else None,
+                                           lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc)) if self.pg is not None else None)
             losses = self.forward_backward(batch)
         finally:
             ops.CONV_BACKEND["operands"] = prev
-        if self.pg is not None:  # data parallel: utterances are sharded across ranks, gradients averaged (SURVEY.md 8e)
-            allreduce_mean_(self.params.grad, self.pg if self.pg is not True else None, lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
+        if self._reducer is not None:  # the head of the buffer (everything in front of the decoder), then wait + 1/world scaling
+            self._reducer.launch(0, self._tail_offset())
+            self._reducer.finish()
+            self._reducer = None
         g = self.params
         clip = self.training.gradient_clip_val
         if clip is not None:
