@@ -170,7 +170,7 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) off_a[ks] = row_a * 128 + (((2 * ks + h) ^ s_a) << 4);
 
-  auto mma_step = [&](const char* Ab, int tap) {
+  auto mma_step = [&](const char* Ab, int tap, int next_step) {
     const int q = wn * (C::NT * 32) + (lane & 31) + tap * a.dil;  // this lane's activation row (n-tile 0)
     const int s_b = (q >> 1) & 7;
     int off_b[4];
@@ -188,6 +188,7 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
     for (int ks = 0; ks < 4; ++ks) {
       const int cur = (C::VAR & 32) ? 0 : (ks & 1);
       if (ks + 1 < 4 && !(C::VAR & 32)) load(ks + 1, cur ^ 1);
+      if ((C::VAR & 2048) && ks == 0 && next_step >= 0) issue_a(next_step);  // requests among the MFMAs instead of behind the barrier
       if (C::VAR & 2) __builtin_amdgcn_sched_barrier(0);
       if (C::VAR & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -232,8 +233,9 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
       const int step = chunk * C::KS + tap;
       if (!(C::VAR & (16 | 256)) || step == 0) __syncthreads();  // weight image of this step (and, at tap 0, the tile) landed and visible; slot (step + 1) & 1 is free
       stamp();
-      if (step + 1 < C::NSTEP && !(C::VAR & (16 | 512))) issue_a(step + 1);
-      mma_step(As + (step & 1) * C::A_BYTES, tap);
+      const bool more = step + 1 < C::NSTEP && !(C::VAR & (16 | 512));
+      if (more && !(C::VAR & 2048)) issue_a(step + 1);
+      mma_step(As + (step & 1) * C::A_BYTES, tap, (more && (C::VAR & 2048)) ? step + 1 : -1);
       stamp();
     }
   }

@@ -129,6 +129,7 @@ static const std::vector<Variant>& variants() {
       X("c128k11_dma_a64", 128, 11, 5, 0, 64) X("c128k11_dma_a128", 128, 11, 5, 0, 128) X("c128k11_dma_a192", 128, 11, 5, 0, 192)
       X("c128k11_dma_v1024", 128, 11, 5, 0, 1024) X("c128k11_dma_v1025", 128, 11, 5, 0, 1025) X("c256k11_dma_v1024", 256, 11, 5, 0, 1024)
       X("c128k7_dma_v1024", 128, 7, 5, 0, 1024)
+      X("c128k11_dma_v2048", 128, 11, 5, 0, 2048) X("c256k11_dma_v2048", 256, 11, 5, 0, 2048)
       X("c128k11_dma_a208", 128, 11, 5, 0, 208) X("c128k11_dma_a256", 128, 11, 5, 0, 256) X("c128k11_dma_a512", 128, 11, 5, 0, 512)
       X("c256k11_dma_v1", 256, 11, 5, 0, 1) X("c256k11_dma_v2", 256, 11, 5, 0, 2) X("c256k11_dma_v3", 256, 11, 5, 0, 3)
 #undef X
