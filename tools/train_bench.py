@@ -24,7 +24,7 @@ g = torch.Generator().manual_seed(1234)
 y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(dev)
 mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
 tr = HiFiGANTrainer(device=dev, precision=os.environ.get("OPERANDS", "f32"), use_graph=os.environ.get("GRAPH", "0") == "1",
-                    parallel_streams=os.environ.get("STREAMS", "1") == "1")
+                    parallel_streams=os.environ.get("STREAMS", "1") == "1", side_wgrad=os.environ.get("SIDE_WGRAD", "0") == "1")
 for i in range(4):
     out = tr.training_step(mel, y)
 print("graph:", len(tr._graphs), tr._graph_failed)
