@@ -21,6 +21,14 @@
 
 namespace evmi {
 
+// value at p (p must be a valid address for every lane), zero for lanes that are not live.  The load is unconditional and the
+// select follows it: a load under a per-lane condition is compiled as a branch around it with the memory counter drained behind
+// every one (one dependent round trip per element: 128 of them in the prologue of a 128-wide head, 32 per key tile).
+__device__ __forceinline__ float live_load(const float* __restrict__ p, bool live) {
+  const float v = *p;
+  return live ? v : 0.f;
+}
+
 __device__ __forceinline__ float attn_uniform01(unsigned long long seed, unsigned long long i) {
   unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;  // splitmix64, as fs2_train_ops.hip: uniform01
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -37,9 +45,18 @@ __device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r 
 // stage a [DH][32] tile of a channel-major [DH][B][T] slice starting at column t0 (zeros past T)
 template <int DH>
 __device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, long long N, int t0, int T, int tid) {
-  for (int v = tid; v < DH * 32; v += 256) {
-    const int d = v >> 5, tt = v & 31;
-    dst[d * AT_LD + tt] = t0 + tt < T ? src[(long long)d * N + t0 + tt] : 0.f;
+  // all of the thread's elements are requested before the first is stored (unconditional loads from clamped positions)
+  constexpr int NV = DH * 32 / 256;
+  float r[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
+    r[i] = live_load(src + (long long)d * N + min(t0 + tt, T - 1), t0 + tt < T);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
+    dst[d * AT_LD + tt] = r[i];
   }
 }
 
@@ -60,9 +77,10 @@ __global__ __launch_bounds__(256) void attention_train_fwd_kernel(const float* _
   const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
   const int tq = blockIdx.x * 128 + wave * 32 + ln;
   const bool qlive = tq < T;
+  const int tqc = min(tq, T - 1);  // clamped: loads are unconditional, dead lanes are zeroed by a select
   float qreg[DH / 2];
 #pragma unroll
-  for (int s = 0; s < DH / 2; ++s) qreg[s] = qlive ? q[(long long)(2 * s + kh) * N + tq] * scale : 0.f;
+  for (int s = 0; s < DH / 2; ++s) qreg[s] = live_load(q + (long long)(2 * s + kh) * N + tqc, qlive) * scale;
   f32x16 acc[DH / 32];
 #pragma unroll
   for (int i = 0; i < DH / 32; ++i)
@@ -152,14 +170,16 @@ __global__ __launch_bounds__(256) void attention_train_dq_kernel(const float* __
   const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
   const int tq = blockIdx.x * 128 + wave * 32 + ln;
   const bool qlive = tq < T;
+  const int tqc = min(tq, T - 1);  // clamped: loads are unconditional, dead lanes are zeroed by a select
   float qreg[DH / 2], doreg[DH / 2];
 #pragma unroll
   for (int s = 0; s < DH / 2; ++s) {
-    qreg[s] = qlive ? q[(long long)(2 * s + kh) * N + tq] * scale : 0.f;
-    doreg[s] = qlive ? dog[(long long)(2 * s + kh) * N + tq] : 0.f;
+    qreg[s] = live_load(q + (long long)(2 * s + kh) * N + tqc, qlive) * scale;
+    doreg[s] = live_load(dog + (long long)(2 * s + kh) * N + tqc, qlive);
   }
-  const float my_lse = qlive ? lse[((long long)b * H + h) * T + tq] : INFINITY;
-  const float my_d = qlive ? dsum[((long long)b * H + h) * T + tq] : 0.f;
+  const float my_lse_raw = lse[((long long)b * H + h) * T + tqc];
+  const float my_lse = qlive ? my_lse_raw : INFINITY;
+  const float my_d = live_load(dsum + ((long long)b * H + h) * T + tqc, qlive);
   const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
   f32x16 acc[DH / 32];
@@ -221,12 +241,13 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
   const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
   const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
   const int tk = blockIdx.x * 128 + wave * 32 + ln;
-  const bool klive = tk < len;  // padded keys receive no probability mass: zero gradients
+  const bool klive = tk < len;
+  const int tkc = min(tk, T - 1);  // padded keys receive no probability mass: zero gradients
   float kreg[DH / 2], vreg[DH / 2];
 #pragma unroll
   for (int s = 0; s < DH / 2; ++s) {
-    kreg[s] = klive ? kg[(long long)(2 * s + kh) * N + tk] * scale : 0.f;
-    vreg[s] = klive ? vg[(long long)(2 * s + kh) * N + tk] : 0.f;
+    kreg[s] = live_load(kg + (long long)(2 * s + kh) * N + tkc, klive) * scale;
+    vreg[s] = live_load(vg + (long long)(2 * s + kh) * N + tkc, klive);
   }
   const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   f32x16 acck[DH / 32], accv[DH / 32];
@@ -242,8 +263,10 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
     stage_tile<DH>(Os, dog, N, q0, T, tid);
     if (tid < 32) {
       const bool in = q0 + tid < T;
-      lse_s[tid] = in ? lse[((long long)b * H + h) * T + q0 + tid] : INFINITY;
-      d_s[tid] = in ? dsum[((long long)b * H + h) * T + q0 + tid] : 0.f;
+      const long long qi = ((long long)b * H + h) * T + min(q0 + tid, T - 1);
+      const float lv = lse[qi], dv = dsum[qi];
+      lse_s[tid] = in ? lv : INFINITY;
+      d_s[tid] = in ? dv : 0.f;
     }
     __syncthreads();
     f32x16 st, dp;
@@ -300,9 +323,17 @@ template <int DH>
 __device__ __forceinline__ void stage_tile_bf16(bf16_t* __restrict__ x_pc, bf16_t* __restrict__ x_cp, const float* __restrict__ src, long long N,
                                                 int t0, int T, int tid) {
   constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
-  for (int v = tid; v < DH * 32; v += 256) {
-    const int d = v >> 5, tt = v & 31;
-    const bf16_t val = (bf16_t)(t0 + tt < T ? src[(long long)d * N + t0 + tt] : 0.f);
+  constexpr int NV = DH * 32 / 256;
+  float r[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
+    r[i] = live_load(src + (long long)d * N + min(t0 + tt, T - 1), t0 + tt < T);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
+    const bf16_t val = (bf16_t)r[i];
     if (x_pc) x_pc[tt * LP + d] = val;
     if (x_cp) x_cp[d * LC + tt] = val;
   }
@@ -314,7 +345,7 @@ __device__ __forceinline__ void tile_fetch(float (&r)[DH / 8], const float* __re
 #pragma unroll
   for (int i = 0; i < DH / 8; ++i) {
     const int v = tid + i * 256, d = v >> 5, tt = v & 31;
-    r[i] = t0 + tt < T ? src[(long long)d * N + t0 + tt] : 0.f;
+    r[i] = live_load(src + (long long)d * N + min(t0 + tt, T - 1), t0 + tt < T);
   }
 }
 template <int DH>
@@ -352,11 +383,12 @@ __global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const flo
   const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
   const int tq = blockIdx.x * 128 + wave * 32 + ln;
   const bool qlive = tq < T;
+  const int tqc = min(tq, T - 1);  // clamped: loads are unconditional, dead lanes are zeroed by a select
   bf16x8 qreg[DH / 16];
 #pragma unroll
   for (int s = 0; s < DH / 16; ++s)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qreg[s][e] = (bf16_t)(qlive ? q[(long long)(16 * s + 8 * kh + e) * N + tq] * scale : 0.f);
+    for (int e = 0; e < 8; ++e) qreg[s][e] = (bf16_t)(live_load(q + (long long)(16 * s + 8 * kh + e) * N + tqc, qlive) * scale);
   f32x16 acc[DH / 32];
 #pragma unroll
   for (int i = 0; i < DH / 32; ++i)
@@ -445,17 +477,19 @@ __global__ __launch_bounds__(256) void attention_train_dq_bf16_kernel(const floa
   const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
   const int tq = blockIdx.x * 128 + wave * 32 + ln;
   const bool qlive = tq < T;
+  const int tqc = min(tq, T - 1);  // clamped: loads are unconditional, dead lanes are zeroed by a select
   bf16x8 qreg[DH / 16], doreg[DH / 16];
 #pragma unroll
   for (int s = 0; s < DH / 16; ++s)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const long long off = (long long)(16 * s + 8 * kh + e) * N + tq;
-      qreg[s][e] = (bf16_t)(qlive ? q[off] * scale : 0.f);
-      doreg[s][e] = (bf16_t)(qlive ? dog[off] : 0.f);
+      const long long off = (long long)(16 * s + 8 * kh + e) * N + tqc;
+      qreg[s][e] = (bf16_t)(live_load(q + off, qlive) * scale);
+      doreg[s][e] = (bf16_t)live_load(dog + off, qlive);
     }
-  const float my_lse = qlive ? lse[((long long)b * H + h) * T + tq] : INFINITY;
-  const float my_d = qlive ? dsum[((long long)b * H + h) * T + tq] : 0.f;
+  const float my_lse_raw = lse[((long long)b * H + h) * T + tqc];
+  const float my_lse = qlive ? my_lse_raw : INFINITY;
+  const float my_d = live_load(dsum + ((long long)b * H + h) * T + tqc, qlive);
   const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
   f32x16 acc[DH / 32];
@@ -530,14 +564,15 @@ __global__ __launch_bounds__(256) void attention_train_dkv_bf16_kernel(const flo
   const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
   const int tk = blockIdx.x * 128 + wave * 32 + ln;
   const bool klive = tk < len;
+  const int tkc = min(tk, T - 1);
   bf16x8 kreg[DH / 16], vreg[DH / 16];
 #pragma unroll
   for (int s = 0; s < DH / 16; ++s)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const long long off = (long long)(16 * s + 8 * kh + e) * N + tk;
-      kreg[s][e] = (bf16_t)(klive ? kg[off] * scale : 0.f);
-      vreg[s][e] = (bf16_t)(klive ? vg[off] : 0.f);
+      const long long off = (long long)(16 * s + 8 * kh + e) * N + tkc;
+      kreg[s][e] = (bf16_t)(live_load(kg + off, klive) * scale);
+      vreg[s][e] = (bf16_t)live_load(vg + off, klive);
     }
   const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   f32x16 acck[DH / 32], accv[DH / 32];
@@ -558,8 +593,10 @@ __global__ __launch_bounds__(256) void attention_train_dkv_bf16_kernel(const flo
     tile_commit<DH>(of, Os, Ot, tid);
     if (tid < 32) {
       const bool in = q0 + tid < T;
-      lse_s[tid] = in ? lse[((long long)b * H + h) * T + q0 + tid] : INFINITY;
-      d_s[tid] = in ? dsum[((long long)b * H + h) * T + q0 + tid] : 0.f;
+      const long long qi = ((long long)b * H + h) * T + min(q0 + tid, T - 1);
+      const float lv = lse[qi], dv = dsum[qi];
+      lse_s[tid] = in ? lv : INFINITY;
+      d_s[tid] = in ? dv : 0.f;
     }
     __syncthreads();
     if (q0 + 32 < T) {

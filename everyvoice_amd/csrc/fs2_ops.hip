@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void attention_cbt_kernel(const float* __restr
   // Q^T as the B operand of S^T = K.Q^T: lane (query, half) holds Q[query][2s + half], pre-scaled
   float qreg[DH / 2];
 #pragma unroll
-  for (int s = 0; s < DH / 2; ++s) qreg[s] = qlive ? q[(long long)(2 * s + kh) * N + tq] * scale : 0.f;
+  for (int s = 0; s < DH / 2; ++s) {
+    const float qv = q[(long long)(2 * s + kh) * N + min(tq, T - 1)];  // unconditional (clamped) load, then the select
+    qreg[s] = qlive ? qv * scale : 0.f;
+  }
   f32x16 acc[DH / 32];
 #pragma unroll
   for (int i = 0; i < DH / 32; ++i)
@@ -195,11 +198,26 @@ __global__ __launch_bounds__(256) void attention_cbt_kernel(const float* __restr
 
   for (int k0 = 0; k0 < len; k0 += 32) {
     __syncthreads();  // previous tile consumed
-    for (int v = tid; v < DH * 32; v += 256) {
-      const int d = v >> 5, kk = v & 31;
-      const bool in = k0 + kk < T;
-      Ks[d * 32 + kk] = in ? kg[(long long)d * N + k0 + kk] : 0.f;
-      Vs[d * VS + kk] = in ? vg[(long long)d * N + k0 + kk] : 0.f;
+    {
+      // the key / value tile: every element of the thread is requested before the first is stored, through unconditional
+      // loads from clamped positions (a load under a per-lane condition drains the memory counter: 32 dependent round trips
+      // per tile at DH = 128)
+      constexpr int NV = DH * 32 / 256;
+      float kr[NV], vr[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256, d = v >> 5, kk = v & 31;
+        const long long o = (long long)d * N + min(k0 + kk, T - 1);
+        kr[i] = kg[o];
+        vr[i] = vg[o];
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256, d = v >> 5, kk = v & 31;
+        const bool in = k0 + kk < T;
+        Ks[d * 32 + kk] = in ? kr[i] : 0.f;
+        Vs[d * VS + kk] = in ? vr[i] : 0.f;
+      }
     }
     __syncthreads();
     // S^T tile: rows = keys (A operand lane (key, half): K[key][2s + half]), columns = queries
@@ -274,7 +292,10 @@ __global__ __launch_bounds__(256) void attention_cbt_bf16_kernel(const float* __
 #pragma unroll
   for (int s = 0; s < DH / 16; ++s)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qreg[s][e] = (bf16_t)(qlive ? q[(long long)(16 * s + 8 * kh + e) * N + tq] * scale : 0.f);
+    for (int e = 0; e < 8; ++e) {
+      const float qv = q[(long long)(16 * s + 8 * kh + e) * N + min(tq, T - 1)];  // unconditional (clamped) load, then the select
+      qreg[s][e] = (bf16_t)(qlive ? qv * scale : 0.f);
+    }
   f32x16 acc[DH / 32];
 #pragma unroll
   for (int i = 0; i < DH / 32; ++i)
@@ -284,11 +305,23 @@ __global__ __launch_bounds__(256) void attention_cbt_bf16_kernel(const float* __
 
   for (int k0 = 0; k0 < len; k0 += 32) {
     __syncthreads();  // previous tile consumed
-    for (int v = tid; v < DH * 32; v += 256) {
-      const int d = v >> 5, kk = v & 31;
-      const bool in = k0 + kk < T;
-      Ks[kk * KS + d] = (bf16_t)(in ? kg[(long long)d * N + k0 + kk] : 0.f);
-      Vs[d * VSB + kk] = (bf16_t)(in ? vg[(long long)d * N + k0 + kk] : 0.f);
+    {
+      constexpr int NV = DH * 32 / 256;
+      float kr[NV], vr[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256, d = v >> 5, kk = v & 31;
+        const long long o = (long long)d * N + min(k0 + kk, T - 1);
+        kr[i] = kg[o];
+        vr[i] = vg[o];
+      }
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * 256, d = v >> 5, kk = v & 31;
+        const bool in = k0 + kk < T;
+        Ks[kk * KS + d] = (bf16_t)(in ? kr[i] : 0.f);
+        Vs[d * VSB + kk] = (bf16_t)(in ? vr[i] : 0.f);
+      }
     }
     __syncthreads();
     f32x16 st;
