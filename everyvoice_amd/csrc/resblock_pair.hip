@@ -1,6 +1,7 @@
 // Instantiations and launcher of the fused residual-pair kernel (resblock_pair_kernel.h).
 #include <cstdlib>
 
+#include "resblock_pair32_kernel.h"
 #include "resblock_pair_chunked_kernel.h"
 
 namespace evmi {
@@ -25,6 +26,11 @@ static const PairLaunch* pair_table(int* n) {
 #define X(c, ks, bn, taps, md, waves, nwbuf, ovl) \
   make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf, ovl>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
   static const PairLaunch table[] = {
+      // C = 32 as a conv1 / conv2 wave pipeline with the weights in registers (resblock_pair32_kernel.h): EVMI_PAIR32=1 only
+      // (measured equal or slower than the single-team kernels below, see the header)
+      make_pair32_launch<Pair32Cfg<3, 5>>("resblock_pair32<k3>"),
+      make_pair32_launch<Pair32Cfg<7, 5>>("resblock_pair32<k7>"),
+      make_pair32_launch<Pair32Cfg<11, 5>>("resblock_pair32<k11>"),
       EVMI_PAIR_TABLE(X)
       // C = 128: chunked variant (64-channel operand chunks, 2 x 4 waves of 64 x 64).  Measured on MI355X
       // (B=32, T=49152): k3 0.49 ms fused vs 0.56 ms as two conv_tc launches; k7 / k11 are MFMA/LDS-bound
@@ -47,9 +53,13 @@ const PairLaunch* find_resblock_pair(int c, int ks, int dil) {
     const char* e = getenv("EVMI_PAIR_OVL");
     return e ? atoi(e) : 0;
   }();
+  static const bool pair32 = [] {
+    const char* e = getenv("EVMI_PAIR32");
+    return e && e[0] == '1';
+  }();
   int n = 0;
   const PairLaunch* t = pair_table(&n);
-  for (int i = 0; i < n; ++i)
+  for (int i = pair32 ? 0 : 3; i < n; ++i)
     if (t[i].c == c && t[i].ks == ks && dil <= t[i].max_dil && (t[i].wg_per_cu == 1 || ovl)) return &t[i];
   return nullptr;
 }
