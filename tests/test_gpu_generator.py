@@ -206,3 +206,21 @@ def test_istft_generator_vs_oracle(cuda_device, name, B, T):
     err = rel_l2(got16, want)
     print(f"istft {name} B={B} T={T}: bf16 rel_l2={err:.3e} (|wav| max {scale:.2f})")
     assert torch.isfinite(got16).all() and err <= BF16_REL_L2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["EVMI_CONV_DMA=0", "EVMI_PAIR32=1", "EVMI_PAIR_OVL=1", "EVMI_PAIR_C128=0"])
+def test_kernel_variants_behind_switches_match_the_oracle(switch):
+    """The library picks its inference kernels once per process: the variants behind the A/B switches (register-staged convolutions,
+    the conv1 / conv2 wave pipeline and the two-workgroup form of the 32-channel pairs, unfused 128-channel pairs) run the oracle
+    comparisons of this file in a child process each, so a switch that is off by default cannot rot."""
+    import os
+    import subprocess
+    import sys
+
+    key, val = switch.split("=")
+    env = dict(os.environ, **{key: val})
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k",
+                        "bf16_vs_oracle or committed_fixture or full_size_properties or istft_generator"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
