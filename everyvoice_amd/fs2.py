@@ -82,6 +82,9 @@ class FastSpeech2ModelConfig:
     use_postnet: bool = True
     multilingual: bool = False
     multispeaker: bool = False
+    # everyvoice-text-to-spec-0.5.json:265-272 (TargetTrainingTextRepresentationLevel): "characters" / "phones" = symbol ids through
+    # the embedding table; "phonological_features" = 43-dim multi-hot vectors (text/features.py:7) through a bias-free Linear
+    target_text_representation_level: str = "characters"
     # not in the reference's schema (fixed inside the absent module): sizes of the embedding table and the postnet
     n_symbols: int = 80
     n_mels: int = 80
@@ -91,6 +94,8 @@ class FastSpeech2ModelConfig:
     n_speakers: int = 0   # table sizes when multispeaker / multilingual (len(speaker2id) / len(lang2id) in the reference)
     n_languages: int = 0
 
+
+N_PHONOLOGICAL_FEATURES = 43  # everyvoice/text/features.py:7
 
 _LN_EPS = 1e-5
 _BN_EPS = 1e-5
@@ -262,7 +267,9 @@ class FastSpeech2:
     @staticmethod
     def state_dict_shapes(c: FastSpeech2ModelConfig) -> dict:
         """Names and shapes of the state dict (``torchaudio.models.Conformer`` layout for encoder / decoder)."""
-        shapes = {"text_input_layer.weight": (c.n_symbols, c.encoder.input_dim), "position_embedding.inv_freq": (c.encoder.input_dim // 2,)}
+        pfs = c.target_text_representation_level == "phonological_features"
+        shapes = {"text_input_layer.weight": (c.encoder.input_dim, N_PHONOLOGICAL_FEATURES) if pfs else (c.n_symbols, c.encoder.input_dim),
+                  "position_embedding.inv_freq": (c.encoder.input_dim // 2,)}
         for name, cf in (("encoder", c.encoder), ("decoder", c.decoder)):
             d, f, k = cf.input_dim, cf.feedforward_dim, cf.conv_kernel_size
             for i in range(cf.layers):
@@ -372,15 +379,24 @@ class FastSpeech2:
 
     def _forward(self, ids, lens, duration_control, pitch_control, energy_control, durations, speakers, languages):
         lib, dev, c = _lib.load(), self.device, self.config
-        B, L = ids.shape
+        B, L = ids.shape[:2]
         if L > c.max_length:
             raise ValueError(f"text of {L} symbols exceeds max_length {c.max_length}")
         D = c.encoder.input_dim
-        ids32 = ids.to(dev, torch.int32).contiguous()
         lens32 = lens.to(dev, torch.int32).contiguous()
-        x = torch.empty(D, B, L, device=dev, dtype=torch.float32)
-        _chk(lib.evmi_fs2_embed_f32(ids32.data_ptr(), lens32.data_ptr(), self.table.data_ptr(), self.inv_freq.data_ptr(), x.data_ptr(),
-                                    B, L, D, _s(x)), "evmi_fs2_embed_f32")
+        if c.target_text_representation_level == "phonological_features":
+            # ids [B, L, 43] feature vectors: Linear(43 -> D) as a pointwise convolution over [43, B, L], then the positional term
+            # (which also zeroes the padded columns, as the embedding kernel does)
+            if ids.dim() != 3 or ids.shape[2] != N_PHONOLOGICAL_FEATURES:
+                raise ValueError(f"phonological features: expected [B, L, {N_PHONOLOGICAL_FEATURES}], got {tuple(ids.shape)}")
+            feats = ids.to(dev, torch.float32).permute(2, 0, 1).contiguous()
+            x = _conv(feats, self.table.view(D, N_PHONOLOGICAL_FEATURES, 1), None)
+            _chk(lib.evmi_fs2_add_posemb_f32(x.data_ptr(), lens32.data_ptr(), self.inv_freq.data_ptr(), B, L, D, _s(x)), "evmi_fs2_add_posemb_f32")
+        else:
+            ids32 = ids.to(dev, torch.int32).contiguous()
+            x = torch.empty(D, B, L, device=dev, dtype=torch.float32)
+            _chk(lib.evmi_fs2_embed_f32(ids32.data_ptr(), lens32.data_ptr(), self.table.data_ptr(), self.inv_freq.data_ptr(), x.data_ptr(),
+                                        B, L, D, _s(x)), "evmi_fs2_embed_f32")
         x = self.encoder.forward(x, lens32)
         for table, item_ids, what in ((self.speaker_table, speakers, "speakers"), (self.language_table, languages, "languages")):
             if table is not None:

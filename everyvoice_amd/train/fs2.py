@@ -25,7 +25,7 @@ from dataclasses import asdict, dataclass, field
 import torch
 
 from .. import _lib
-from ..fs2 import FastSpeech2ModelConfig, Stats
+from ..fs2 import N_PHONOLOGICAL_FEATURES, FastSpeech2ModelConfig, Stats
 from . import ops
 from .autograd import Tape, Var
 from .layers import ParamGroup, WNConv
@@ -75,16 +75,16 @@ class Dense:
         self.pad = (k - 1) // 2
         self.wshape = (cout, cin, k)
         self.i_w = group.declare(wname, (cout, cin) if linear else (cout, cin, k))
-        self.i_bias = group.declare(bname, (cout,))
+        self.i_bias = group.declare(bname, (cout,)) if bname else None  # bname None: a bias-free layer
 
     def effective(self, training=True):
         return self.group.data(self.i_w).view(self.wshape), self.group.gradient(self.i_w).view(self.wshape)
 
     def bias_data(self):
-        return self.group.data(self.i_bias)
+        return None if self.i_bias is None else self.group.data(self.i_bias)
 
     def db_sink(self):
-        return self.group.gradient(self.i_bias)
+        return None if self.i_bias is None else self.group.gradient(self.i_bias)
 
     def materialize(self):
         pass
@@ -397,7 +397,10 @@ class FastSpeech2Trainer:
         _lib.load()
         g = self.params = ParamGroup(self.device)
         d = c.encoder.input_dim
-        self.text_table = Table(g, "text_input_layer.weight", c.n_symbols, d)
+        self.pfs = c.target_text_representation_level == "phonological_features"
+        # symbol ids -> embedding table, or 43-dim phonological feature vectors -> bias-free Linear (everyvoice/text/features.py:7)
+        self.text_table = None if self.pfs else Table(g, "text_input_layer.weight", c.n_symbols, d)
+        self.text_linear = Dense(g, "text_input_layer.weight", None, N_PHONOLOGICAL_FEATURES, d, linear=True) if self.pfs else None
         self.aligner = _AlignerT(g, d, c.n_mels) if c.learn_alignment else None
         self.encoder = _ConformerT(g, c.encoder, "encoder")
         self.speaker_table = Table(g, "speaker_embedding.weight", max(1, c.n_speakers), d) if c.multispeaker else None
@@ -516,9 +519,14 @@ class FastSpeech2Trainer:
     def forward_backward(self, batch: dict) -> dict:
         """Forward in training mode + every loss + backward; gradients are left in ``self.params.grad``."""
         lib, dev, c, tr = _lib.load(), self.device, self.config, self.training
-        ids = batch["ids"].to(dev, torch.int32).contiguous()
         lens = batch["lens"].to(dev, torch.int32).contiguous()
-        B, L = ids.shape
+        if self.pfs:  # batch["pfs"] [B, L, 43] multi-hot feature vectors (the reference's `pfs` files) -> [43, B, L]
+            feats = batch["pfs"].to(dev, torch.float32).permute(2, 0, 1).contiguous()
+            ids = None
+            B, L = feats.shape[1], feats.shape[2]
+        else:
+            ids = batch["ids"].to(dev, torch.int32).contiguous()
+            B, L = ids.shape
         D = c.encoder.input_dim
         n_tok = float(batch["lens"].sum())
         pad = torch.arange(L, device=dev)[None, :] >= lens[:, None]
@@ -553,6 +561,15 @@ class FastSpeech2Trainer:
             return ((((self._seed * 1000003 + self.global_step) * world + rank) << 16) | (counter[0] - n)) & 0x7FFFFFFFFFFFFFFF
 
         def embed(with_position: bool) -> Var:
+            if self.pfs:  # Linear(43 -> D) over the feature vectors, padded columns zeroed (+ the positional sinusoid)
+                v = dense(tape, Var(feats, needs_grad=False), self.text_linear)
+                if not with_position:
+                    return masked(tape, v, lens)
+                e = v.data.clone()
+                _chk(lib.evmi_fs2_add_posemb_f32(e.data_ptr(), lens.data_ptr(), self.inv_freq.data_ptr(), B, L, D, _s(e)), "evmi_fs2_add_posemb_f32")
+                out = Var(e)
+                tape.record(lambda: out.grad is not None and v.accumulate(ops.mask_cols_(out.grad.clone(), lens)))
+                return out
             e = torch.empty(D, B, L, device=dev, dtype=torch.float32)
             _chk(lib.evmi_fs2_embed_f32(ids.data_ptr(), lens.data_ptr(), self.text_table.data().data_ptr(), self.inv_freq.data_ptr() if with_position else 0,
                                         e.data_ptr(), B, L, D, _s(e)), "evmi_fs2_embed_f32")

@@ -67,6 +67,9 @@ class StatsInfoRef:
     norm_max: float = 3.0
 
 
+N_PHONOLOGICAL_FEATURES = 43  # everyvoice/text/features.py:7
+
+
 @dataclass
 class FastSpeech2ConfigRef:
     encoder: ConformerConfigRef = field(default_factory=ConformerConfigRef)
@@ -75,6 +78,11 @@ class FastSpeech2ConfigRef:
     duration: VariancePredictorConfigRef = field(default_factory=VariancePredictorConfigRef)
     pitch: VariancePredictorConfigRef = field(default_factory=VariancePredictorConfigRef)
     n_symbols: int = 80
+    # "characters" / "phones": symbol ids through an embedding table; "phonological_features": 43-dim multi-hot vectors
+    # (everyvoice/text/features.py:7 N_PHONOLOGICAL_FEATURES) through a bias-free Linear(43 -> input_dim)
+    # (TargetTrainingTextRepresentationLevel, everyvoice/config/type_definitions.py:16-19; the layer itself is in the absent
+    # fs2 submodule: restated, parity unpinned)
+    target_text_representation_level: str = "characters"
     n_mels: int = 80
     n_speakers: int = 0   # > 0: multispeaker (an embedding added to the encoder output, as ming024/FastSpeech2 does)
     n_languages: int = 0  # > 0: multilingual
@@ -209,7 +217,8 @@ class FastSpeech2Ref(nn.Module):
         super().__init__()
         self.cfg = cfg = cfg or FastSpeech2ConfigRef()
         d = cfg.encoder.input_dim
-        self.text_input_layer = nn.Embedding(cfg.n_symbols, d, padding_idx=0)
+        self.pfs = cfg.target_text_representation_level == "phonological_features"
+        self.text_input_layer = nn.Linear(N_PHONOLOGICAL_FEATURES, d, bias=False) if self.pfs else nn.Embedding(cfg.n_symbols, d, padding_idx=0)
         self.position_embedding = PositionalEmbeddingRef(d)
         self.encoder = ConformerRef(cfg.encoder)
         self.speaker_embedding = nn.Embedding(cfg.n_speakers, d) if cfg.n_speakers else None
@@ -228,7 +237,7 @@ class FastSpeech2Ref(nn.Module):
 
     @torch.no_grad()
     def forward(self, ids, lens, duration_control=1.0, pitch_control=1.0, energy_control=1.0, durations=None, speakers=None, languages=None):
-        B, L = ids.shape
+        B, L = ids.shape[:2]  # ids [B, L] symbol ids, or [B, L, 43] phonological feature vectors
         pad = torch.arange(L)[None, :] >= lens[:, None]
         x = self.text_input_layer(ids) + self.position_embedding(L)[None]
         x = x.masked_fill(pad[..., None], 0.0)
@@ -278,8 +287,8 @@ def training_losses_ref(model: FastSpeech2Ref, batch: dict, weights: dict | None
     PARITY UNPINNED like the rest of this file (the training step lives in the absent submodule)."""
     w = {"mel": 1.0, "postnet": 1.0, "pitch": 0.1, "energy": 0.1, "duration": 0.1, "attn_ctc": 0.1, "attn_bin": 0.0}
     w.update(weights or {})
-    ids, lens = batch["ids"], batch["lens"]
-    B, L = ids.shape
+    ids, lens = (batch["pfs"] if getattr(model, "pfs", False) else batch["ids"]), batch["lens"]  # symbol ids, or feature vectors [B, L, 43]
+    B, L = ids.shape[:2]
     pad = torch.arange(L)[None, :] >= lens[:, None]
     losses = {}
     if aligner is not None:

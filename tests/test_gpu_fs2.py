@@ -30,7 +30,8 @@ def _product_config(ref_cfg):
                                   variance_predictors=VariancePredictors(energy=vpc(ref_cfg.energy), duration=vpc(ref_cfg.duration), pitch=vpc(ref_cfg.pitch)),
                                   n_symbols=ref_cfg.n_symbols, n_mels=ref_cfg.n_mels, use_postnet=ref_cfg.use_postnet,
                                   postnet_channels=ref_cfg.postnet_channels, postnet_kernel=ref_cfg.postnet_kernel,
-                                  postnet_layers=ref_cfg.postnet_layers)
+                                  postnet_layers=ref_cfg.postnet_layers,
+                                  target_text_representation_level=ref_cfg.target_text_representation_level)
 
 
 def _models(ref_cfg, cuda_device, seed):
@@ -55,6 +56,27 @@ def _batch(n_symbols, B, L, seed, lens=None):
     ids = torch.randint(1, n_symbols, (B, L), generator=g)
     ids = ids.masked_fill(torch.arange(L)[None] >= lens[:, None], 0)
     return ids, lens, g
+
+
+def test_fs2_phonological_features_input(cuda_device):
+    """target_text_representation_level = "phonological_features" (everyvoice-text-to-spec-0.5.json:265-272): 43-dim multi-hot
+    vectors (text/features.py:7) through a bias-free Linear instead of symbol ids through the embedding table."""
+    ref_cfg = FastSpeech2ConfigRef.small()
+    ref_cfg.target_text_representation_level = "phonological_features"
+    ref, model = _models(ref_cfg, cuda_device, seed=77)
+    assert tuple(ref.state_dict()["text_input_layer.weight"].shape) == (ref_cfg.encoder.input_dim, 43)
+    B, L = 3, 14
+    _, lens, g = _batch(20, B, L, seed=5)
+    feats = (torch.rand(B, L, 43, generator=g) < 0.3).float()
+    durs = torch.randint(0, 6, (B, L), generator=g)
+    durs[:, 0] += 1
+    want = ref(feats, lens, durations=durs)
+    got = model(feats, lens, durations=durs)
+    assert torch.equal(got[2].cpu(), want[2]) and torch.equal(got[5].cpu(), want[5])
+    for i in (0, 1, 3, 4):
+        _close(got[i].cpu(), want[i])
+    with pytest.raises(ValueError, match="phonological features"):
+        model(torch.zeros(B, L, dtype=torch.long), lens, durations=durs)
 
 
 @pytest.mark.parametrize("B,L", [(3, 12), (1, 5), (4, 33)])

@@ -366,6 +366,29 @@ def test_training_step_losses_gradients_and_update(cuda_device, B, L, speakers):
         assert float((diff > 1e-6 + 2e-3 * tr.learning_rate(1)).float().mean()) < 0.01, name
 
 
+def test_training_step_phonological_features_input(cuda_device):
+    """The bias-free Linear(43 -> d) input layer of target_text_representation_level = "phonological_features" in training: losses
+    and every gradient (its own weight included) against torch autograd of the oracle."""
+    ref_cfg = _ref_cfg(0.0)
+    ref_cfg.target_text_representation_level = "phonological_features"
+    tr = _trainer(ref_cfg, cuda_device)
+    batch = _train_batch(ref_cfg, 3, 10, seed=4)
+    g = torch.Generator().manual_seed(21)
+    pad = torch.arange(10)[None] >= batch["lens"][:, None]
+    batch["pfs"] = (torch.rand(3, 10, 43, generator=g) < 0.3).float().masked_fill(pad[..., None], 0.0)
+    ref = _oracle_from(tr, ref_cfg)
+    want = training_losses_ref(ref, batch)
+    want["total"].backward()
+    got = tr.forward_backward(batch)
+    for k, v in want.items():
+        assert float(got[k]) == pytest.approx(float(v), rel=2e-4), k
+    grads = tr.params.gradients()
+    named = dict(ref.named_parameters())
+    assert set(grads) == set(named) and tuple(named["text_input_layer.weight"].shape) == (ref_cfg.encoder.input_dim, 43)
+    for name, p in named.items():
+        _l2close(grads[name], p.grad if p.grad is not None else torch.zeros_like(p), 2e-3, name)
+
+
 def test_training_step_default_model_size_matches_oracle(cuda_device):
     """BASELINE config 3 at its own model size (multi-speaker, as config 5 has it): every loss, every parameter gradient and
     the BatchNorm statistics of one fp32 step against torch-CPU autograd of the oracle.  Gradient tolerance 4e-3 (L2, relative)
