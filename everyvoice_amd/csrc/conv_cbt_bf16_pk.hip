@@ -183,6 +183,12 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
   const uint4* xwin = a.xp + (long long)g * a.octs * plane + (long long)b_first * a.Tp + (long long)to_first * s + shift;
   const int a_units = MBT * kbs * 64;
   const int stage = a_units + a.rows_step * xrow;
+  // Stride-2 / stride-4 layers read units (column * stride + tap): the 16 lanes of a ds_read_b128 group then share 8 / 4 of the
+  // 16 sixteen-byte slots of the bank row (2- / 4-way conflicts: 21-32 % of the LDS cycles of the scale discriminators' layers).
+  // Position p of a staged row holds unit p ^ ((p >> 4) & swz): consecutive 16-unit blocks are rotated against each other, a
+  // group's units land on 16 distinct slots.  Applied on the source side of the LDS-direct loads and again on the reads (rows
+  // are multiples of 64 units, so the row offset of a read does not disturb the block index).
+  const int swz = s == 2 ? 1 : (s == 4 ? 3 : 0);
 
   int colu[NT], col_b[NT], col_to[NT];
 #pragma unroll
@@ -193,11 +199,11 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
       const int bb = (int)(n / n_out);
       col_b[nt] = bb;
       col_to[nt] = (int)(n - (long long)bb * n_out);
-      colu[nt] = a_units + (bb - b_first) * a.Tp + (col_to[nt] - to_first) * s;
+      colu[nt] = (bb - b_first) * a.Tp + (col_to[nt] - to_first) * s;  // window-relative unit of the column (tap 0)
     } else {
       col_b[nt] = -1;
       col_to[nt] = 0;
-      colu[nt] = a_units;  // staged data; the column is never stored
+      colu[nt] = 0;  // staged data; the column is never stored
     }
   }
   int abase[MT];
@@ -243,7 +249,8 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     if (!(a.ablate & 1))
     for (; u < nunits; u += 4) {
       const int r = u / pieces, pi = u - r * pieces;
-      pk_lds_direct(xwin + (long long)(o_lo + r) * plane + pi * 64 + lane, sx + r * xrow + pi * 64);
+      const int pp = pi * 64 + lane;
+      pk_lds_direct(xwin + (long long)(o_lo + r) * plane + (pp ^ ((pp >> 4) & swz)), sx + r * xrow + pi * 64);
       ++issued;
     }
     return issued;
@@ -286,7 +293,10 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) da[mt] = *reinterpret_cast<const bf16x8*>(sm + abase[mt] + qi * 64);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) db[nt] = *reinterpret_cast<const bf16x8*>(sm + colu[nt] + lo);
+      for (int nt = 0; nt < NT; ++nt) {
+        const int p = colu[nt] + lo;
+        db[nt] = *reinterpret_cast<const bf16x8*>(sm + a_units + (p ^ ((p >> 4) & swz)));
+      }
     };
     auto mma = [&](const bf16x8 (&da)[MT], const bf16x8 (&db)[NT]) {
 #pragma unroll
@@ -439,6 +449,17 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
   }
   if (n_max <= 0) return "no outputs";
   if (ext > (1 << 24)) return "row too long";
+  // Items are Tp units apart in the packed rows.  A column tile that spans several (short) items reads, per 16-lane group, units
+  // of more than one item: with Tp = n_out * stride (mod 16) the unit index keeps advancing by `stride` across the item boundary
+  // modulo the 16 slots of a bank row, as inside one long row -- no two lanes of a group on one slot.  Costs at most 15 padding
+  // units per item, so only items of 96 units or more are padded (with every item padded the 128 x 128 kernel's conflicts fell
+  // from 31.8 % to 5.2 % of its LDS cycles, but the GAN step got 0.3 ms slower: the period discriminators' 11-34-unit items grew
+  // by up to half).
+  {
+    static const int align_tp = pk_env_int("EVMI_PK_TP_ALIGN", 1);
+    const long long want_mod = ((long long)n_max * a.stride) & 15;
+    if (align_tp && ext >= pk_env_int("EVMI_PK_TP_ALIGN_MIN", 96)) ext += ((want_mod - (ext & 15)) + 16) & 15;  // (short items: the padding would cost more than the conflicts)
+  }
   a.Tp = (int)ext;
   const long long n_total = (long long)a.B * n_max;
   auto blocks = [&](int i) {
