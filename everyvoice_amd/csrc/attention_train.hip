@@ -318,6 +318,7 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
 // block kb is position 16 kb + 8 (e >> 2) + 4 half + (e & 3) -- so P^T / dS^T feed it straight from registers and the other
 // operand is staged [channel][position] (two 8-byte reads).  Tiles that take part in both kinds of product are staged twice.
 constexpr int ATB_PD = 8;  // bf16 row padding
+__device__ int g_attn_abl = 0;  // TEMP ablation switch
 
 template <int DH>
 __device__ __forceinline__ void stage_tile_bf16(bf16_t* __restrict__ x_pc, bf16_t* __restrict__ x_cp, const float* __restrict__ src, long long N,
@@ -403,18 +404,22 @@ __global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const flo
     tile_fetch<DH>(kf, kg, N, 0, T, tid);
     tile_fetch<DH>(vf, vg, N, 0, T, tid);
   }
+  const int abl = g_attn_abl;
   for (int k0 = 0; k0 < len; k0 += 32) {
     __syncthreads();
+    if (!(abl & 2) || k0 == 0) {
     tile_commit<DH>(kf, Ks, nullptr, tid);
     tile_commit<DH>(vf, nullptr, Vs, tid);
+    }
     __syncthreads();
-    if (k0 + 32 < len) {
+    if (k0 + 32 < len && !(abl & 1)) {
       tile_fetch<DH>(kf, kg, N, k0 + 32, T, tid);
       tile_fetch<DH>(vf, vg, N, k0 + 32, T, tid);
     }
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    if (!(abl & 8))
 #pragma unroll
     for (int s = 0; s < DH / 16; ++s)
       st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Ks[ln * LP + 16 * s + 8 * kh]), qreg[s], st, 0, 0, 0);
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const flo
     bf16x8 pb[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float pr = expf(st[r] - m_new);
+      float pr = (abl & 4) ? st[r] - m_new : expf(st[r] - m_new);
       ps += pr;
       if (p_drop > 0.f) pr = attn_uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? pr * keep : 0.f;
       pb[r >> 3][r & 7] = (bf16_t)pr;
@@ -443,6 +448,7 @@ __global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const flo
     for (int i = 0; i < DH / 32; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] *= corr;
+      if (!(abl & 16))
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_pos_slots(&Vs[(i * 32 + ln) * LC], kb, kh), pb[kb], acc[i], 0, 0, 0);
@@ -647,6 +653,8 @@ __global__ __launch_bounds__(256) void attention_train_dkv_bf16_kernel(const flo
 using namespace evmi;
 
 extern "C" {
+
+int evmi_debug_attn_ablation(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_abl), &v, sizeof(int)); }
 
 int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
                      float p_drop, unsigned long long seed, void* stream) {

@@ -20,6 +20,7 @@ Everything is channel-major fp32 ``x[c][b][t]``; no torch autograd and no torch 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import asdict, dataclass, field
 
 import torch
@@ -337,7 +338,8 @@ class _AlignerT:
                       Dense(g, *name("query", 4), n_mels, self.n_att, 1)]
 
     def forward(self, tape: Tape, text_emb: Var, mel: Var, prior, text_lens32, mel_lens32, n_frames: float, ctc_weight: float, bin_weight: float):
-        """-> (losses dict, hard durations [B, L] int32).  Records the backward of both losses into the projections / embedding."""
+        """-> ``join``; ``join() -> (losses dict, hard durations [B, L] int32, hard alignment)`` once the main stream needs them.
+        Records the backward of both losses into the projections / embedding."""
         from ..heavy import maximum_path
         k = dense(tape, dense(tape, text_emb, self.key[0], ops.ACT_RELU), self.key[1])
         q = dense(tape, dense(tape, dense(tape, mel, self.query[0], ops.ACT_RELU), self.query[1], ops.ACT_RELU), self.query[2])
@@ -354,11 +356,27 @@ class _AlignerT:
         with torch.cuda.stream(self._side):
             ctc, dlogprob = ops.forward_sum_loss_and_grad(logprob, text_lens32, mel_lens32, ctc_weight)
             done.record(self._side)
-        hard, dur = maximum_path(ops.elementwise(16, soft), mel_lens32, text_lens32)  # monotonic search over log(soft): no gradient
-        from ..heavy import binarization_loss
+        # The monotonic search over log(soft) (no gradient; one wave per utterance, ~0.7 ms) gives the durations the length regulator
+        # and the variance targets need -- but the encoder does not: it runs on a second side stream beside the encoder's forward,
+        # and `join()` (called by the trainer in front of the first use of the durations) makes the main stream wait for it.
+        if getattr(self, "_side_mas", None) is None:
+            self._side_mas = torch.cuda.Stream(logprob.device)
+        mas_done = torch.cuda.Event()
+        self._side_mas.wait_event(fork)
+        with torch.cuda.stream(self._side_mas):
+            hard, dur = maximum_path(ops.elementwise(16, soft), mel_lens32, text_lens32)
+            dur = dur.to(torch.int32)
+            mas_done.record(self._side_mas)
+        for t in (hard, dur):  # allocated on the side stream's pool, used (and released) under the main stream
+            t.record_stream(main)
         losses = {"attn_ctc": ctc}
-        if bin_weight > 0.0:
-            losses["attn_bin"] = (binarization_loss(hard, soft) * bin_weight).reshape(1)
+
+        def join():
+            from ..heavy import binarization_loss
+            torch.cuda.current_stream(logprob.device).wait_event(mas_done)
+            if bin_weight > 0.0:
+                losses["attn_bin"] = (binarization_loss(hard, soft) * bin_weight).reshape(1)
+            return losses, dur, hard
 
         def bwd():
             torch.cuda.current_stream(logprob.device).wait_event(done)
@@ -368,7 +386,7 @@ class _AlignerT:
             k.accumulate(dk)
 
         tape.record(bwd)
-        return losses, dur.to(torch.int32), hard
+        return join
 
 
 class FastSpeech2Trainer:
@@ -382,10 +400,13 @@ class FastSpeech2Trainer:
 
     def __init__(self, config: FastSpeech2ModelConfig | None = None, stats: Stats | None = None, training: FastSpeech2TrainingConfig | None = None,
                  device="cuda:0", seed: int = 1234, lang2id: dict | None = None, speaker2id: dict | None = None, process_group=None,
-                 precision: str = "f32"):
+                 precision: str = "f32", side_wgrad: bool | None = None):
         if precision not in ("f32", "bf16"):
             raise ValueError("precision: 'f32' or 'bf16' (bf16 operands of the dense layers, fp32 accumulation / master weights)")
         self.precision = precision
+        # weight / bias gradients on a sibling stream beside the input-gradient chain (ops.side_wgrad): the step is one eager stream
+        # of mostly small launches, so the two fill each other's gaps
+        self.side_wgrad = (os.environ.get("EVMI_FS2_SIDE_WGRAD", "1") == "1") if side_wgrad is None else bool(side_wgrad)
         self.config = c = config or FastSpeech2ModelConfig()
         self.stats = stats or Stats()
         self.training = training or FastSpeech2TrainingConfig()
@@ -584,18 +605,21 @@ class FastSpeech2Trainer:
             bin_w = tr.attn_bin_loss_weight * min(self.current_epoch / epochs, 1.0)
             prior = batch.get("attn_prior")
             prior = None if prior is None else prior.to(dev, torch.float64)[:, :T, :L].contiguous()
-            align_losses, dur, self.last_alignment = self.aligner.forward(tape, embed(False), Var(mel_t, needs_grad=False), prior, lens, mel_lens, n_frames,
-                                                                          tr.attn_ctc_loss_weight, bin_w)
-            losses.update(align_losses)
+            align_join = self.aligner.forward(tape, embed(False), Var(mel_t, needs_grad=False), prior, lens, mel_lens, n_frames,
+                                              tr.attn_ctc_loss_weight, bin_w)
         else:
             dur = batch["durations"].to(dev, torch.int32).clamp_min(0).masked_fill(pad, 0).contiguous()
+
+        x0 = embed(True)
+        x = self.encoder.forward(tape, x0, lens, seeds)
+
+        if learn:  # the alignment search ran beside the encoder
+            align_losses, dur, self.last_alignment = align_join()
+            losses.update(align_losses)
         cum = torch.cumsum(dur, 1, dtype=torch.int32).contiguous()
         log_d_t = torch.log(dur.float() + 1.0).contiguous()
         pitch_t = self._phone_level(batch, "pitch", cum, dur, pad, T)
         energy_t = self._phone_level(batch, "energy", cum, dur, pad, T)
-
-        x0 = embed(True)
-        x = self.encoder.forward(tape, x0, lens, seeds)
 
         for table, key in ((self.speaker_table, "speakers"), (self.language_table, "languages")):
             if table is not None:
@@ -630,7 +654,7 @@ class FastSpeech2Trainer:
             # are final once backward leaves the decoder; their all-reduce runs on a side stream under the backward of the
             # variance adaptor, the aligner and the encoder (recorded BEFORE the decoder's forward = run AFTER its backward)
             lo_tail, red = self._tail_offset(), self._reducer
-            tape.record(lambda: red.launch(lo_tail, self.params.grad.numel()))
+            tape.record(lambda: (ops.wgrad_join(dev), red.launch(lo_tail, self.params.grad.numel())))
         y = self.decoder.forward(tape, f, mel_lens, seeds)
         mel = masked(tape, dense(tape, y, self.mel_linear), mel_lens)
         n_el = n_frames * c.n_mels
@@ -702,8 +726,9 @@ class FastSpeech2Trainer:
     def training_step(self, batch: dict) -> dict:
         """One optimiser step; returns the losses as device scalars (no host synchronisation inside the step)."""
         from .hifigan import BucketReducer
-        prev = ops.CONV_BACKEND["operands"]
+        prev, prev_side = ops.CONV_BACKEND["operands"], ops.SIDE_WGRAD["on"]
         ops.CONV_BACKEND["operands"] = self.precision
+        ops.SIDE_WGRAD["on"] = self.side_wgrad and self.device.type == "cuda"
         try:
             # data parallel (SURVEY.md 8e): utterances are sharded across ranks, gradients averaged by a bucketed all-reduce that
             # overlaps backward (two buckets: see forward_backward)
@@ -712,6 +737,7 @@ class FastSpeech2Trainer:
             losses = self.forward_backward(batch)
         finally:
             ops.CONV_BACKEND["operands"] = prev
+            ops.SIDE_WGRAD["on"] = prev_side
         if self._reducer is not None:  # the head of the buffer (everything in front of the decoder), then wait + 1/world scaling
             self._reducer.launch(0, self._tail_offset())
             self._reducer.finish()

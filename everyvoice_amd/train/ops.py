@@ -704,9 +704,13 @@ def dwconv_bwd(x, w, dy, dw, db, k, need_dx=True):
     dx = torch.empty_like(x) if need_dx else None
     lib = _lib.load()
     n = lib.evmi_dwconv1d_bwd_cbt_f32_ws_elems(C, B, k)
-    ws = WS.get("dw_bwd", n, x.device)
-    _chk(lib.evmi_dwconv1d_bwd_cbt_f32(x.data_ptr(), w.data_ptr(), dy.data_ptr(), _lib.ptr(dx), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, C, B, T, k,
-                                       (k - 1) // 2, _s(x)), "evmi_dwconv1d_bwd_cbt_f32")
+    with side_wgrad(x, dy, dw, db):  # the filter / bias gradient (partial sums per item, then the reduction) beside the chain
+        ws = WS.get("dw_bwd", n, x.device)
+        _chk(lib.evmi_dwconv1d_bwd_cbt_f32(x.data_ptr(), w.data_ptr(), dy.data_ptr(), 0, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, C, B, T, k,
+                                           (k - 1) // 2, _s(x)), "evmi_dwconv1d_bwd_cbt_f32")
+    if need_dx:
+        _chk(lib.evmi_dwconv1d_bwd_cbt_f32(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, 0, 0, 0, C, B, T, k, (k - 1) // 2, _s(x)),
+             "evmi_dwconv1d_bwd_cbt_f32")
     return dx
 
 
