@@ -317,47 +317,44 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
 // (queries) of a tile takes its k slots in the order the half-waves already hold the score tile's registers -- slot (half, e) of
 // block kb is position 16 kb + 8 (e >> 2) + 4 half + (e & 3) -- so P^T / dS^T feed it straight from registers and the other
 // operand is staged [channel][position] (two 8-byte reads).  Tiles that take part in both kinds of product are staged twice.
+//
+// The walked tiles arrive by LDS-direct loads (global_load_lds_dword): the fp32 [DH][32] tile of step i + 1 is requested into a
+// raw staging area right after step i's operands are in place and lands under step i's matrix work without holding a register;
+// at the top of step i + 1 every thread converts the 16 elements IT requested (no cross-thread hazard on the raw area) into the
+// bf16 operand layouts.  (Prefetching through registers made the compiler park the 32 in-flight values in accumulation
+// registers with a full vmcnt(0) wait behind EVERY load: 32 serial round trips per tile in the dK/dV kernel.)
+// The element loops are straight-line: the probability is always computed and masked by a select, the per-query statistics of
+// the dK/dV kernel are read as 16-byte LDS vectors, dropout is a template parameter (its generator costs more than the exp).
 constexpr int ATB_PD = 8;  // bf16 row padding
-__device__ int g_attn_abl = 0;  // TEMP ablation switch
 
+typedef __attribute__((address_space(3))) float at_lds_float_t;
+typedef __attribute__((address_space(1))) const float at_glb_float_t;
+
+// request the [DH][32] fp32 tile of a channel-major slice (columns t0 .. t0 + 31, clamped to T - 1) into raw[DH * 32]: element
+// v = tid + 256 i (channel v >> 5, column v & 31) lands at raw[v]
 template <int DH>
-__device__ __forceinline__ void stage_tile_bf16(bf16_t* __restrict__ x_pc, bf16_t* __restrict__ x_cp, const float* __restrict__ src, long long N,
-                                                int t0, int T, int tid) {
-  constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
-  constexpr int NV = DH * 32 / 256;
-  float r[NV];
+__device__ __forceinline__ void tile_request(float* __restrict__ raw, const float* __restrict__ src, long long N, int t0, int T, int tid) {
+  const float* g = src + (long long)(tid >> 5) * N + min(t0 + (tid & 31), T - 1);
+  float* l = raw + (tid & ~63);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
-    r[i] = live_load(src + (long long)d * N + min(t0 + tt, T - 1), t0 + tt < T);
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
-    const bf16_t val = (bf16_t)r[i];
-    if (x_pc) x_pc[tt * LP + d] = val;
-    if (x_cp) x_cp[d * LC + tt] = val;
-  }
+  for (int i = 0; i < DH / 8; ++i)
+    __builtin_amdgcn_global_load_lds((at_glb_float_t*)(g + (long long)(8 * i) * N), (at_lds_float_t*)(l + 256 * i), 4, 0, 0);
 }
-// the same in two phases: the global loads of the NEXT tile are issued into registers before the current tile's products, the
-// conversion + LDS stores happen at the top of the next iteration (the loads' latency hides behind the matrix work)
-template <int DH>
-__device__ __forceinline__ void tile_fetch(float (&r)[DH / 8], const float* __restrict__ src, long long N, int t0, int T, int tid) {
+// the thread's own 16 elements of a landed tile -> bf16 [position][channel] (PC) and / or [channel][position] (CP), zero past T
+template <int DH, bool PC, bool CP>
+__device__ __forceinline__ void tile_convert(const float* __restrict__ raw, bf16_t* __restrict__ x_pc, bf16_t* __restrict__ x_cp, int t0, int T,
+                                             int tid) {
+  constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
+  const int tt = tid & 31, d0 = tid >> 5;
+  const bool in = t0 + tt < T;
+  float r[DH / 8];
+#pragma unroll
+  for (int i = 0; i < DH / 8; ++i) r[i] = raw[tid + 256 * i];
 #pragma unroll
   for (int i = 0; i < DH / 8; ++i) {
-    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
-    r[i] = live_load(src + (long long)d * N + min(t0 + tt, T - 1), t0 + tt < T);
-  }
-}
-template <int DH>
-__device__ __forceinline__ void tile_commit(const float (&r)[DH / 8], bf16_t* __restrict__ x_pc, bf16_t* __restrict__ x_cp, int tid) {
-  constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
-#pragma unroll
-  for (int i = 0; i < DH / 8; ++i) {
-    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
-    const bf16_t val = (bf16_t)r[i];
-    if (x_pc) x_pc[tt * LP + d] = val;
-    if (x_cp) x_cp[d * LC + tt] = val;
+    const bf16_t val = (bf16_t)(in ? r[i] : 0.f);
+    if (PC) x_pc[tt * LP + d0 + 8 * i] = val;
+    if (CP) x_cp[(d0 + 8 * i) * LC + tt] = val;
   }
 }
 
@@ -368,13 +365,14 @@ __device__ __forceinline__ bf16x8 load_pos_slots(const bf16_t* __restrict__ row,
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int DH>
-__global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256, 2) void attention_train_fwd_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                       float* __restrict__ out, float* __restrict__ lse, int B, int T, int D,
                                                                       float scale, float p_drop, unsigned long long seed) {
   constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * LP];   // [key][channel]
   __shared__ __attribute__((aligned(16))) bf16_t Vs[DH * LC];   // [channel][key]
+  __shared__ __attribute__((aligned(16))) float rawK[DH * 32], rawV[DH * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int len = min(lens[b], T);
@@ -382,6 +380,10 @@ __global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const flo
   const float* q = qkv + ((long long)(h * DH) * B + b) * T;
   const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
   const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
+  if (len > 0) {
+    tile_request<DH>(rawK, kg, N, 0, T, tid);
+    tile_request<DH>(rawV, vg, N, 0, T, tid);
+  }
   const int tq = blockIdx.x * 128 + wave * 32 + ln;
   const bool qlive = tq < T;
   const int tqc = min(tq, T - 1);  // clamped: loads are unconditional, dead lanes are zeroed by a select
@@ -396,49 +398,40 @@ __global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const flo
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const float keep = DROP ? 1.f / (1.f - p_drop) : 1.f;
   const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
 
-  float kf[DH / 8], vf[DH / 8];
-  if (len > 0) {
-    tile_fetch<DH>(kf, kg, N, 0, T, tid);
-    tile_fetch<DH>(vf, vg, N, 0, T, tid);
-  }
-  const int abl = g_attn_abl;
   for (int k0 = 0; k0 < len; k0 += 32) {
+    __syncthreads();  // the requested tile has landed (vmcnt(0) of every wave); the previous step's operand reads are over
+    tile_convert<DH, true, false>(rawK, Ks, nullptr, k0, T, tid);
+    tile_convert<DH, false, true>(rawV, nullptr, Vs, k0, T, tid);
     __syncthreads();
-    if (!(abl & 2) || k0 == 0) {
-    tile_commit<DH>(kf, Ks, nullptr, tid);
-    tile_commit<DH>(vf, nullptr, Vs, tid);
-    }
-    __syncthreads();
-    if (k0 + 32 < len && !(abl & 1)) {
-      tile_fetch<DH>(kf, kg, N, k0 + 32, T, tid);
-      tile_fetch<DH>(vf, vg, N, k0 + 32, T, tid);
+    if (k0 + 32 < len) {
+      tile_request<DH>(rawK, kg, N, k0 + 32, T, tid);
+      tile_request<DH>(rawV, vg, N, k0 + 32, T, tid);
     }
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
-    if (!(abl & 8))
 #pragma unroll
     for (int s = 0; s < DH / 16; ++s)
       st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Ks[ln * LP + 16 * s + 8 * kh]), qreg[s], st, 0, 0, 0);
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      if (k0 + acc_row(r, kh) >= len) st[r] = -INFINITY;
+      st[r] = k0 + acc_row(r, kh) < len ? st[r] : -INFINITY;
       mx = fmaxf(mx, st[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float corr = expf(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx);  // finite: key k0 of the tile is live
+    const float corr = __expf(m_run - m_new);
     float ps = 0.f;
     bf16x8 pb[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float pr = (abl & 4) ? st[r] - m_new : expf(st[r] - m_new);
+      float pr = __expf(st[r] - m_new);
       ps += pr;
-      if (p_drop > 0.f) pr = attn_uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? pr * keep : 0.f;
+      if (DROP) pr = attn_uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? pr * keep : 0.f;
       pb[r >> 3][r & 7] = (bf16_t)pr;
     }
     ps += __shfl_xor(ps, 32, 64);
@@ -448,7 +441,6 @@ __global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const flo
     for (int i = 0; i < DH / 32; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] *= corr;
-      if (!(abl & 16))
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
         acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(load_pos_slots(&Vs[(i * 32 + ln) * LC], kb, kh), pb[kb], acc[i], 0, 0, 0);
@@ -464,8 +456,8 @@ __global__ __launch_bounds__(256) void attention_train_fwd_bf16_kernel(const flo
   if (kh == 0) lse[((long long)b * H + h) * T + tq] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
 }
 
-template <int DH>
-__global__ __launch_bounds__(256) void attention_train_dq_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256, 2) void attention_train_dq_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                      const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                      const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
                                                                      int D, float scale, float p_drop, unsigned long long seed) {
@@ -473,6 +465,7 @@ __global__ __launch_bounds__(256) void attention_train_dq_bf16_kernel(const floa
   __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * LP];   // [key][channel]: S^T = K Q^T
   __shared__ __attribute__((aligned(16))) bf16_t Kt[DH * LC];   // [channel][key]: dQ^T += K^T dS^T
   __shared__ __attribute__((aligned(16))) bf16_t Vs[32 * LP];   // [key][channel]: dPd^T = V dO^T
+  __shared__ __attribute__((aligned(16))) float rawK[DH * 32], rawV[DH * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int len = min(lens[b], T);
@@ -481,6 +474,10 @@ __global__ __launch_bounds__(256) void attention_train_dq_bf16_kernel(const floa
   const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
   const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
   const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
+  if (len > 0) {
+    tile_request<DH>(rawK, kg, N, 0, T, tid);
+    tile_request<DH>(rawV, vg, N, 0, T, tid);
+  }
   const int tq = blockIdx.x * 128 + wave * 32 + ln;
   const bool qlive = tq < T;
   const int tqc = min(tq, T - 1);  // clamped: loads are unconditional, dead lanes are zeroed by a select
@@ -496,7 +493,7 @@ __global__ __launch_bounds__(256) void attention_train_dq_bf16_kernel(const floa
   const float my_lse_raw = lse[((long long)b * H + h) * T + tqc];
   const float my_lse = qlive ? my_lse_raw : INFINITY;
   const float my_d = live_load(dsum + ((long long)b * H + h) * T + tqc, qlive);
-  const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const float keep = DROP ? 1.f / (1.f - p_drop) : 1.f;
   const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
   f32x16 acc[DH / 32];
 #pragma unroll
@@ -504,19 +501,14 @@ __global__ __launch_bounds__(256) void attention_train_dq_bf16_kernel(const floa
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  float kf[DH / 8], vf[DH / 8];
-  if (len > 0) {
-    tile_fetch<DH>(kf, kg, N, 0, T, tid);
-    tile_fetch<DH>(vf, vg, N, 0, T, tid);
-  }
   for (int k0 = 0; k0 < len; k0 += 32) {
     __syncthreads();
-    tile_commit<DH>(kf, Ks, Kt, tid);
-    tile_commit<DH>(vf, Vs, nullptr, tid);
+    tile_convert<DH, true, true>(rawK, Ks, Kt, k0, T, tid);
+    tile_convert<DH, true, false>(rawV, Vs, nullptr, k0, T, tid);
     __syncthreads();
     if (k0 + 32 < len) {
-      tile_fetch<DH>(kf, kg, N, k0 + 32, T, tid);
-      tile_fetch<DH>(vf, vg, N, k0 + 32, T, tid);
+      tile_request<DH>(rawK, kg, N, k0 + 32, T, tid);
+      tile_request<DH>(rawV, vg, N, k0 + 32, T, tid);
     }
     f32x16 st, dp;
 #pragma unroll
@@ -530,9 +522,10 @@ __global__ __launch_bounds__(256) void attention_train_dq_bf16_kernel(const floa
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + acc_row(r, kh);
-      const float pr = key < len ? expf(st[r] - my_lse) : 0.f;
+      float pr = __expf(st[r] - my_lse);
+      pr = key < len ? pr : 0.f;
       float g = dp[r];
-      if (p_drop > 0.f) g = attn_uniform01(seed + h, row_base + (unsigned long long)key) >= p_drop ? g * keep : 0.f;
+      if (DROP) g = attn_uniform01(seed + h, row_base + (unsigned long long)key) >= p_drop ? g * keep : 0.f;
       dsb[r >> 3][r & 7] = (bf16_t)(pr * (g - my_d));
     }
 #pragma unroll
@@ -549,17 +542,26 @@ __global__ __launch_bounds__(256) void attention_train_dq_bf16_kernel(const floa
     for (int r = 0; r < 16; ++r) o[(long long)(i * 32 + acc_row(r, kh)) * N] = acc[i][r] * scale;
 }
 
+// dynamic LDS of the dK/dV kernel: four bf16 operand tiles, two raw fp32 tiles, two generations of the 32 queries' (lse, D)
 template <int DH>
-__global__ __launch_bounds__(256) void attention_train_dkv_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
+constexpr size_t attention_dkv_bf16_lds() {
+  return (size_t)(2 * 32 * (DH + ATB_PD) + 2 * DH * (32 + ATB_PD)) * sizeof(bf16_t) + (size_t)(2 * DH * 32 + 2 * 64) * sizeof(float);
+}
+
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256, 2) void attention_train_dkv_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                       const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                       const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
                                                                       int D, float scale, float p_drop, unsigned long long seed) {
   constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[32 * LP];   // [query][channel]
-  __shared__ __attribute__((aligned(16))) bf16_t Qt[DH * LC];   // [channel][query]
-  __shared__ __attribute__((aligned(16))) bf16_t Os[32 * LP];   // dO [query][channel]
-  __shared__ __attribute__((aligned(16))) bf16_t Ot[DH * LC];   // dO [channel][query]
-  __shared__ float lse_s[32], d_s[32];
+  extern __shared__ __attribute__((aligned(16))) unsigned char at_dyn_lds[];
+  bf16_t* Qs = reinterpret_cast<bf16_t*>(at_dyn_lds);  // [query][channel]
+  bf16_t* Qt = Qs + 32 * LP;                           // [channel][query]
+  bf16_t* Os = Qt + DH * LC;                           // dO [query][channel]
+  bf16_t* Ot = Os + 32 * LP;                           // dO [channel][query]
+  float* rawQ = reinterpret_cast<float*>(Ot + DH * LC);
+  float* rawO = rawQ + DH * 32;
+  float* stat = rawO + DH * 32;                        // [2 generations][lse of the 32 queries | D of the 32 queries]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int len = min(lens[b], T);
@@ -568,6 +570,14 @@ __global__ __launch_bounds__(256) void attention_train_dkv_bf16_kernel(const flo
   const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
   const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
   const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
+  const bool block_live = blockIdx.x * 128 < len;
+  // wave 0 also brings the tile's 32 (lse, D) pairs: lanes 0-31 the lse, lanes 32-63 D, clamped (queries past T are masked below)
+  const float* stat_src = (kh ? dsum : lse) + ((long long)b * H + h) * T;
+  if (block_live) {
+    tile_request<DH>(rawQ, qg, N, 0, T, tid);
+    tile_request<DH>(rawO, dog, N, 0, T, tid);
+    if (wave == 0) __builtin_amdgcn_global_load_lds((at_glb_float_t*)(stat_src + min(ln, T - 1)), (at_lds_float_t*)stat, 4, 0, 0);
+  }
   const int tk = blockIdx.x * 128 + wave * 32 + ln;
   const bool klive = tk < len;
   const int tkc = min(tk, T - 1);
@@ -580,34 +590,24 @@ __global__ __launch_bounds__(256) void attention_train_dkv_bf16_kernel(const flo
       kreg[s][e] = (bf16_t)(live_load(kg + off, klive) * scale);
       vreg[s][e] = (bf16_t)live_load(vg + off, klive);
     }
-  const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  const float keep = DROP ? 1.f / (1.f - p_drop) : 1.f;
+  const unsigned long long col_base = (unsigned long long)b * T * T + (unsigned long long)tkc;
   f32x16 acck[DH / 32], accv[DH / 32];
 #pragma unroll
   for (int i = 0; i < DH / 32; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acck[i][r] = accv[i][r] = 0.f;
-  const bool block_live = blockIdx.x * 128 < len;
 
-  float qf[DH / 8], of[DH / 8];
-  if (block_live) {
-    tile_fetch<DH>(qf, qg, N, 0, T, tid);
-    tile_fetch<DH>(of, dog, N, 0, T, tid);
-  }
-  for (int q0 = 0; q0 < T && block_live; q0 += 32) {
+  for (int q0 = 0, gen = 0; q0 < T && block_live; q0 += 32, gen ^= 1) {
     __syncthreads();
-    tile_commit<DH>(qf, Qs, Qt, tid);
-    tile_commit<DH>(of, Os, Ot, tid);
-    if (tid < 32) {
-      const bool in = q0 + tid < T;
-      const long long qi = ((long long)b * H + h) * T + min(q0 + tid, T - 1);
-      const float lv = lse[qi], dv = dsum[qi];
-      lse_s[tid] = in ? lv : INFINITY;
-      d_s[tid] = in ? dv : 0.f;
-    }
+    tile_convert<DH, true, true>(rawQ, Qs, Qt, q0, T, tid);
+    tile_convert<DH, true, true>(rawO, Os, Ot, q0, T, tid);
     __syncthreads();
     if (q0 + 32 < T) {
-      tile_fetch<DH>(qf, qg, N, q0 + 32, T, tid);
-      tile_fetch<DH>(of, dog, N, q0 + 32, T, tid);
+      tile_request<DH>(rawQ, qg, N, q0 + 32, T, tid);
+      tile_request<DH>(rawO, dog, N, q0 + 32, T, tid);
+      if (wave == 0)
+        __builtin_amdgcn_global_load_lds((at_glb_float_t*)(stat_src + min(q0 + 32 + ln, T - 1)), (at_lds_float_t*)(stat + 64 * (gen ^ 1)), 4, 0, 0);
     }
     f32x16 st, dp;
 #pragma unroll
@@ -617,16 +617,24 @@ __global__ __launch_bounds__(256) void attention_train_dkv_bf16_kernel(const flo
       st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Qs[ln * LP + 16 * s + 8 * kh]), kreg[s], st, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Os[ln * LP + 16 * s + 8 * kh]), vreg[s], dp, 0, 0, 0);
     }
+    // the 16 queries of this half-wave's registers: (r & 3) + 8 (r >> 2) + 4 kh -> four 16-byte vectors of each statistic
     bf16x8 pdb[2], dsb[2];
+    const float* st_l = stat + 64 * gen + 4 * kh;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qi = acc_row(r, kh);
-      const int tq = q0 + qi;
-      const float pr = (klive && tq < T) ? expf(st[r] - lse_s[qi]) : 0.f;
-      float mk = 1.f;
-      if (p_drop > 0.f) mk = attn_uniform01(seed + h, ((unsigned long long)b * T + (unsigned long long)min(tq, T - 1)) * T + (unsigned long long)min(tk, T - 1)) >= p_drop ? keep : 0.f;
-      pdb[r >> 3][r & 7] = (bf16_t)(pr * mk);
-      dsb[r >> 3][r & 7] = (bf16_t)(pr * (dp[r] * mk - d_s[qi]));
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 lse_q = *reinterpret_cast<const f32x4*>(st_l + 8 * g4);
+      const f32x4 d_q = *reinterpret_cast<const f32x4*>(st_l + 32 + 8 * g4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g4 + e;
+        const int tq = q0 + 8 * g4 + 4 * kh + e;
+        float pr = __expf(st[r] - lse_q[e]);
+        pr = (klive && tq < T) ? pr : 0.f;
+        float mk = 1.f;
+        if (DROP) mk = attn_uniform01(seed + h, col_base + (unsigned long long)min(tq, T - 1) * (unsigned long long)T) >= p_drop ? keep : 0.f;
+        pdb[r >> 3][r & 7] = (bf16_t)(pr * mk);
+        dsb[r >> 3][r & 7] = (bf16_t)(pr * (dp[r] * mk - d_q[e]));
+      }
     }
 #pragma unroll
     for (int i = 0; i < DH / 32; ++i)
@@ -653,8 +661,6 @@ __global__ __launch_bounds__(256) void attention_train_dkv_bf16_kernel(const flo
 using namespace evmi;
 
 extern "C" {
-
-int evmi_debug_attn_ablation(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_abl), &v, sizeof(int)); }
 
 int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
                      float p_drop, unsigned long long seed, void* stream) {
@@ -684,10 +690,18 @@ int evmi_mha_fwd_bf16(const float* qkv_dev, const int* lens_dev, float* out_dev,
   const float scale = 1.f / sqrtf((float)dh);
   const dim3 grid((T + 127) / 128, heads, B);
   hipStream_t s = (hipStream_t)stream;
-#define EVMI_MHA_FWD(DH) hipLaunchKernelGGL(attention_train_fwd_bf16_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, scale, p_drop, seed)
-  if (dh == 128) EVMI_MHA_FWD(128);
-  else if (dh == 64) EVMI_MHA_FWD(64);
-  else if (dh == 32) EVMI_MHA_FWD(32);
+#define EVMI_MHA_FWD(DH)                                                                                                          \
+  {                                                                                                                               \
+    if (p_drop > 0.f)                                                                                                             \
+      hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<DH, true>), grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, \
+                         scale, p_drop, seed);                                                                                    \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<DH, false>), grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, \
+                         scale, p_drop, seed);                                                                                    \
+  }
+  if (dh == 128) EVMI_MHA_FWD(128)
+  else if (dh == 64) EVMI_MHA_FWD(64)
+  else if (dh == 32) EVMI_MHA_FWD(32)
   else return fail(EVMI_ERR_UNSUPPORTED, "mha_fwd_bf16: head dimension must be 32, 64 or 128");
 #undef EVMI_MHA_FWD
   EVMI_LAUNCH_CHECK("mha_fwd_bf16");
@@ -706,18 +720,31 @@ int evmi_mha_bwd_bf16(const float* qkv_dev, const int* lens_dev, const float* ou
   const long long n = (long long)B * heads * T;
   hipLaunchKernelGGL(attention_rowdot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out_dev, dout_dev, dsum_dev, B, T, heads, dh);
   const dim3 grid((T + 127) / 128, heads, B);
-#define EVMI_MHA_BWD(DH)                                                                                                          \
+#define EVMI_MHA_BWD_DROP(DH, DROP, SLOT)                                                                                        \
   {                                                                                                                               \
-    hipLaunchKernelGGL(attention_train_dq_bf16_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev, \
-                       dqkv_dev, B, T, D, scale, p_drop, seed);                                                                   \
-    hipLaunchKernelGGL(attention_train_dkv_bf16_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev,\
-                       dqkv_dev, B, T, D, scale, p_drop, seed);                                                                   \
+    constexpr size_t lds = attention_dkv_bf16_lds<DH>();                                                                          \
+    static thread_local bool configured[8] = {};                                                                                  \
+    if (!configured[SLOT]) {                                                                                                      \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)attention_train_dkv_bf16_kernel<DH, DROP>,                                  \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
+      configured[SLOT] = true;                                                                                                    \
+    }                                                                                                                             \
+    hipLaunchKernelGGL((attention_train_dq_bf16_kernel<DH, DROP>), grid, dim3(256), 0, s, qkv_dev, lens_dev, dout_dev, lse_dev,   \
+                       dsum_dev, dqkv_dev, B, T, D, scale, p_drop, seed);                                                         \
+    hipLaunchKernelGGL((attention_train_dkv_bf16_kernel<DH, DROP>), grid, dim3(256), lds, s, qkv_dev, lens_dev, dout_dev, lse_dev,\
+                       dsum_dev, dqkv_dev, B, T, D, scale, p_drop, seed);                                                         \
   }
-  if (dh == 128) EVMI_MHA_BWD(128)
-  else if (dh == 64) EVMI_MHA_BWD(64)
-  else if (dh == 32) EVMI_MHA_BWD(32)
+#define EVMI_MHA_BWD(DH, SLOT)                                                                                                    \
+  {                                                                                                                               \
+    if (p_drop > 0.f) EVMI_MHA_BWD_DROP(DH, true, SLOT)                                                                           \
+    else EVMI_MHA_BWD_DROP(DH, false, SLOT + 1)                                                                                   \
+  }
+  if (dh == 128) EVMI_MHA_BWD(128, 0)
+  else if (dh == 64) EVMI_MHA_BWD(64, 2)
+  else if (dh == 32) EVMI_MHA_BWD(32, 4)
   else return fail(EVMI_ERR_UNSUPPORTED, "mha_bwd_bf16: head dimension must be 32, 64 or 128");
 #undef EVMI_MHA_BWD
+#undef EVMI_MHA_BWD_DROP
   EVMI_LAUNCH_CHECK("mha_bwd_bf16");
   return EVMI_OK;
 }
