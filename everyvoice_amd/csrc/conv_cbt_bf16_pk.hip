@@ -73,6 +73,15 @@ __device__ __forceinline__ float pk_act(float v, float p) {
   if (ACT == 4) return tanhf(v);
   return v;
 }
+// old + ((v * fac) + add) with every operation rounded by itself: hipcc contracts a * b + c into one fma by default, and the
+// un-fused sequence of kernels this tail replaces (scale, then add, then accumulate) rounds three times
+__device__ __forceinline__ float pk_tail(float v, float fac, float add, float old) {
+#pragma clang fp contract(off)
+  const float p = v * fac;
+  const float q = p + add;
+  return old + q;
+}
+
 template <class F>
 __device__ __forceinline__ void pk_with_act(int act, F&& body) {
   switch (act) {
@@ -360,26 +369,61 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     }
     return;
   }
+  // Every global read of the tail (bias, mask, residual, previous value) is requested for a whole 16-register block before the
+  // first is used, from clamped (always valid) addresses: a read under a per-element condition is compiled as a branch with a
+  // full vmcnt(0) wait behind it -- one memory round trip per element, 64-256 in a row per lane.  Absent operands are replaced by
+  // the neutral element (x * 1, x + -0) so the arithmetic is unconditional, and the products / sums are pinned to separate
+  // roundings (no contraction): conv_pk_reduce_kernel computes the same tail for the split-K launches, bit for bit.
   pk_with_act(a.act, [&](auto act_c) {
     constexpr int ACT = decltype(act_c)::value;
+    const long long ch_stride = (long long)a.B * a.t_out_total;
+    const int m_last = m_valid - 1;
+    constexpr int EB = 8;  // registers per batch: 8 loads of each operand in flight, ~40 temporaries
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       if (col_b[nt] < 0) continue;
-      float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
+      const long long col_off = (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (m >= m_valid) continue;
-          const int co = co0 + m;
-          float v = acc[mt][nt][r];
-          if (a.bias) v += a.bias[co];
-          v = pk_act<ACT>(v, a.act_param);
-          float* dst = ycol + (long long)co * a.B * a.t_out_total;
-          if (a.out_mask) v *= a.out_mask[dst - a.y] > 0.f ? 1.f : a.out_mask_slope;
-          if (a.res) v += a.res[dst - a.y];
-          *dst = a.accumulate ? *dst + v : v;
+        for (int r0 = 0; r0 < 16; r0 += EB) {
+          int mrow[EB];
+          long long off[EB];
+          float bv[EB], fac[EB], add[EB], old[EB];
+#pragma unroll
+          for (int e = 0; e < EB; ++e) {
+            const int r = r0 + e;
+            mrow[e] = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            off[e] = col_off + (long long)(co0 + min(mrow[e], m_last)) * ch_stride;
+            bv[e] = 0.f;
+            fac[e] = 1.f;
+            add[e] = -0.f;
+            old[e] = -0.f;
+          }
+          if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) bv[e] = a.bias[co0 + min(mrow[e], m_last)];
+          }
+          if (a.out_mask) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) fac[e] = a.out_mask[off[e]];
+#pragma unroll
+            for (int e = 0; e < EB; ++e) fac[e] = fac[e] > 0.f ? 1.f : a.out_mask_slope;
+          }
+          if (a.res) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) add[e] = a.res[off[e]];
+          }
+          if (a.accumulate) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) old[e] = a.y[off[e]];
+          }
+#pragma unroll
+          for (int e = 0; e < EB; ++e) {
+            float v = pk_act<ACT>(acc[mt][nt][r0 + e] + bv[e], a.act_param);
+            v = pk_tail(v, fac[e], add[e], old[e]);
+            if (mrow[e] < m_valid) a.y[off[e]] = v;
+          }
         }
       }
     }
@@ -400,9 +444,10 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a) {
   const long long bb = n / n_out;
   const int to = (int)(n - bb * n_out);
   float* dst = a.y + ((long long)co * a.B + bb) * a.t_out_total + (long long)to * a.out_stride + a.ph_off[ph];
-  if (a.out_mask) v *= a.out_mask[dst - a.y] > 0.f ? 1.f : a.out_mask_slope;
-  if (a.res) v += a.res[dst - a.y];
-  *dst = a.accumulate ? *dst + v : v;
+  const float fac = a.out_mask ? (a.out_mask[dst - a.y] > 0.f ? 1.f : a.out_mask_slope) : 1.f;
+  const float add = a.res ? a.res[dst - a.y] : -0.f;
+  const float old = a.accumulate ? *dst : -0.f;
+  *dst = pk_tail(v, fac, add, old);
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Static scan of the compiled kernels for serialised global loads: a `s_waitcnt vmcnt(0)` directly behind a SINGLE global load
+(the signature of a load under a per-lane condition, or of a value parked in accumulation registers) costs one memory round trip
+per element.  usage: python tools/isa_scan.py <dir with .s files from hipcc -S --cuda-device-only>"""
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+
+def demangle(n):
+    try:
+        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip() or n
+    except OSError:
+        return n
+
+
+def main():
+    rows = []
+    for f in sorted(Path(sys.argv[1]).glob("*.s")):
+        lines = f.read_text().split("\n")
+        i = 0
+        while i < len(lines):
+            m = re.match(r"^(_Z\w+):", lines[i])
+            if not m:
+                i += 1
+                continue
+            name, j = m.group(1), i + 1
+            seq = []
+            while j < len(lines) and not lines[j].startswith(".Lfunc_end"):
+                s = lines[j].strip()
+                if s.startswith(("global_load_lds", "buffer_load")) and "lds" in s:
+                    seq.append("D")
+                elif s.startswith(("global_load", "buffer_load", "flat_load")):
+                    seq.append("L")
+                elif s.startswith("s_waitcnt") and "vmcnt(0)" in s:
+                    seq.append("W")
+                elif s.startswith(("v_mfma", "s_barrier", "global_store", "ds_", "s_cbranch", "s_branch")):
+                    seq.append(".")
+                j += 1
+            t = "".join(seq)
+            t = re.sub(r"\.+", ".", t)
+            singles = len(re.findall(r"(?<!L)L\.?W", t))  # one load, then a full drain
+            loads = t.count("L")
+            if singles >= 4:
+                rows.append((singles, loads, f.stem, demangle(name)[:110]))
+            i = j
+    for r in sorted(rows, reverse=True):
+        print(f"{r[0]:4d} single-load drains of {r[1]:4d} loads  {r[2]:22s} {r[3]}")
+
+
+if __name__ == "__main__":
+    main()
