@@ -117,6 +117,21 @@ inline uint16_t f32_to_bf16_bits(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// acc + p[0] + p[stride] + ... + p[(n - 1) stride], added in index order (the order is part of the bitwise-reproducibility
+// contract of the split reductions) with eight loads in flight: a plain `for (s) acc += p[s * stride]` is compiled as one
+// load -> vmcnt(0) -> add per trip, i.e. one memory round trip per term.
+__device__ __forceinline__ float ordered_sum_strided(const float* __restrict__ p, long long stride, int n, float acc = 0.f) {
+  for (int s = 0; s < n; s += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long long)min(s + u, n - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = s + u < n ? acc + v[u] : acc;
+  }
+  return acc;
+}
+
+
 // wait until at most n (wave-uniform) vector-memory operations of this wave are outstanding
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
   n = __builtin_amdgcn_readfirstlane(n);

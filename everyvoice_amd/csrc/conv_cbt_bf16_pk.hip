@@ -437,8 +437,7 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a) {
   const int co = blockIdx.y, ph = blockIdx.z;
   const int n_out = a.ph_nout[ph];
   if (n_out <= 0 || n >= (long long)a.B * n_out) return;
-  float v = 0.f;
-  for (int sp = 0; sp < a.ksplit; ++sp) v += a.part[((long long)sp * a.phases + ph) * a.part_stride + (long long)co * a.part_ld + n];
+  float v = ordered_sum_strided(a.part + (long long)ph * a.part_stride + (long long)co * a.part_ld + n, (long long)a.phases * a.part_stride, a.ksplit);
   if (a.bias) v += a.bias[co];
   pk_with_act(a.act, [&](auto act_c) { v = pk_act<decltype(act_c)::value>(v, a.act_param); });
   const long long bb = n / n_out;

@@ -83,8 +83,7 @@ __global__ void conv_smallco_reduce_kernel(ConvDirectArgs a) {
   if (i >= n_total * a.c_out) return;
   const int co = (int)(i / n_total);
   const long long n = i - (long long)co * n_total;
-  float v = a.bias ? a.bias[co] : 0.f;
-  for (int ch = 0; ch < a.nchunks; ++ch) v += a.partial[((long long)ch * a.c_out + co) * n_total + n];
+  float v = ordered_sum_strided(a.partial + (long long)co * n_total + n, (long long)a.c_out * n_total, a.nchunks, a.bias ? a.bias[co] : 0.f);
   v = direct_act(v, a.act, a.act_param);
   const int b = (int)(n / a.n_out);
   const int to = (int)(n - (long long)b * a.n_out);

@@ -174,13 +174,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
 #pragma unroll
   for (int j = 0; j < TGMAX; ++j) {
     if (j >= tgc) break;
+    // the previous values of the 16 rows are requested together, from clamped rows (a read per element under the `accumulate`
+    // condition is one drained round trip each); -0 is the neutral start of a plain store
+    long long off[16];
+    float prev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (m >= a.cout_g) continue;
-      float* dst = a.out + ((long long)(g * a.cout_g + m) * a.cin_g + ci) * k + j_lo + j;
-      *dst = a.accumulate ? *dst + acc[j][r] : acc[j][r];
+      const int m = min(tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, a.cout_g - 1);
+      off[r] = ((long long)(g * a.cout_g + m) * a.cin_g + ci) * k + j_lo + j;
+      prev[r] = -0.f;
     }
+    if (a.accumulate) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[r] = a.out[off[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < a.cout_g) a.out[off[r]] = prev[r] + acc[j][r];
   }
 }
 
@@ -194,9 +204,7 @@ __global__ __launch_bounds__(256) void wgrad_pk_reduce_kernel(const float* __res
   const long long i = base + threadIdx.x;
   if (i < rows_ci)
     for (int j = 0; j < k; ++j) {
-      float acc = 0.f;
-      for (int sidx = 0; sidx < splits; ++sidx) acc += part[sidx * split_stride + j * rows_ci + i];
-      tile[j * 256 + threadIdx.x] = acc;
+      tile[j * 256 + threadIdx.x] = ordered_sum_strided(part + j * rows_ci + i, split_stride, splits);
     }
   __syncthreads();
   const int n_here = (int)min<long long>(256, rows_ci - base);
@@ -214,8 +222,7 @@ __global__ __launch_bounds__(256) void wgrad_pk_reduce_planes_kernel(const float
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;  // co * cin_g + ci
   const int j = blockIdx.y;
   if (i >= rows_ci) return;
-  float acc = 0.f;
-  for (int sidx = 0; sidx < splits; ++sidx) acc += part[sidx * split_stride + j * rows_ci + i];
+  const float acc = ordered_sum_strided(part + j * rows_ci + i, split_stride, splits);
   float* dst = dw + i * k + j;
   *dst = accumulate ? *dst + acc : acc;
 }

@@ -73,9 +73,7 @@ __global__ void pad_dy_kernel(const float* __restrict__ dy, float* __restrict__ 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long long n, int splits, int accumulate) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float v = accumulate ? dw[i] : 0.f;
-  for (int s = 0; s < splits; ++s) v += part[(long long)s * n + i];
-  dw[i] = v;
+  dw[i] = ordered_sum_strided(part + i, n, splits, accumulate ? dw[i] : 0.f);
 }
 
 constexpr int WG_NK = 64;    // contraction indices per step

@@ -25,8 +25,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __re
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)M * N) return;
   const int m = (int)(idx / N), n = (int)(idx % N);
-  float acc = 0.f;
-  for (int sidx = 0; sidx < S; ++sidx) acc += part[(long long)sidx * M * N + idx];
+  const float acc = ordered_sum_strided(part + idx, (long long)M * N, S);
   float* o = out + (long long)m * ldc + n;
   *o = beta == 0.f ? acc : beta * *o + acc;
 }
@@ -255,7 +254,18 @@ __global__ __launch_bounds__(256) void row_reduce_kernel(const float* __restrict
   const float* ar = a + r * N;
   const float* br = b ? b + r * N : nullptr;
   float acc = 0.f;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+  long long i = lo + threadIdx.x;
+  for (; i + 3 * 256 < hi; i += 4 * 256) {  // four independent reads per trip (a one-read loop drains vmcnt behind every element)
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      av[u] = ar[i + u * 256];
+      bv[u] = MODE == 1 ? br[i + u * 256] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc += MODE == 0 ? av[u] : (MODE == 1 ? av[u] * bv[u] : av[u] * av[u]);
+  }
+  for (; i < hi; i += 256) {
     const float av = ar[i];
     acc += MODE == 0 ? av : (MODE == 1 ? av * br[i] : av * av);
   }
@@ -279,7 +289,22 @@ __global__ __launch_bounds__(256) void lrelu_bwd_rowsum_kernel(const float* __re
   const long long r = blockIdx.x;
   const long long lo = (long long)blockIdx.y * seg, hi = min(N, lo + seg);
   float acc = 0.f;
-  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+  long long i = lo + threadIdx.x;
+  for (; i + 3 * 256 < hi; i += 4 * 256) {
+    float dv[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      dv[u] = dy[r * N + i + u * 256];
+      yv[u] = y[r * N + i + u * 256];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float v = dv[u] * (yv[u] > 0.f ? 1.f : slope);
+      dpre[r * N + i + u * 256] = v;
+      acc += v;
+    }
+  }
+  for (; i < hi; i += 256) {
     const float v = dy[r * N + i] * (y[r * N + i] > 0.f ? 1.f : slope);
     dpre[r * N + i] = v;
     acc += v;
@@ -299,8 +324,7 @@ __global__ void row_reduce_final_kernel(const float* __restrict__ part, float* _
                                         float scale, int accumulate) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
-  float t = 0.f;
-  for (int sg = 0; sg < nseg; ++sg) t += part[(long long)r * nseg + sg];
+  const float t = ordered_sum_strided(part + (long long)r * nseg, 1, nseg);
   out[r] = accumulate ? out[r] + t * scale : t * scale;
 }
 
@@ -361,7 +385,20 @@ __global__ __launch_bounds__(256) void scalar_partial_kernel(const float* __rest
                                                              double* __restrict__ part, long long n, float p) {
   __shared__ double sh[4];
   double acc = 0.0;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+  const long long step = (long long)gridDim.x * 256;
+  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * step < n; i += 4 * step) {
+    float av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      av[u] = a[i + u * step];
+      bv[u] = MODE == 0 ? b[i + u * step] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      acc += MODE == 0 ? (double)fabsf(av[u] - bv[u]) : (MODE == 1 ? (double)((av[u] - p) * (av[u] - p)) : (double)av[u]);
+  }
+  for (; i < n; i += step) {
     const float av = a[i];
     acc += MODE == 0 ? (double)fabsf(av - b[i]) : (MODE == 1 ? (double)((av - p) * (av - p)) : (double)av);
   }

@@ -17,6 +17,7 @@ def demangle(n):
 
 def main():
     rows = []
+    loops = []
     for f in sorted(Path(sys.argv[1]).glob("*.s")):
         lines = f.read_text().split("\n")
         i = 0
@@ -38,6 +39,22 @@ def main():
                 elif s.startswith(("v_mfma", "s_barrier", "global_store", "ds_", "s_cbranch", "s_branch")):
                     seq.append(".")
                 j += 1
+            # inner loops that drain behind one or two loads per trip (serial reductions: one memory round trip per element)
+            body = lines[i + 1:j]
+            labels = {mm.group(1): n for n, l in enumerate(body) if (mm := re.match(r"^(\.LBB\d+_\d+):", l))}
+            thin = 0
+            for n, l in enumerate(body):
+                mm = re.search(r"s_cbranch\w+\s+(\.LBB\d+_\d+)", l)
+                if mm and mm.group(1) in labels and labels[mm.group(1)] < n:
+                    seg = [x.strip() for x in body[labels[mm.group(1)]:n]]
+                    if any(re.match(r"^\.LBB", x) for x in seg[1:]):
+                        continue  # not an innermost loop
+                    nl = sum(x.startswith(("global_load", "buffer_load", "flat_load")) and "lds" not in x for x in seg)
+                    nw = sum(x.startswith("s_waitcnt") and "vmcnt(0)" in x for x in seg)
+                    if 1 <= nl <= 2 and nw >= 1:
+                        thin += 1
+            if thin:
+                loops.append((thin, f.stem, demangle(name)[:110]))
             t = "".join(seq)
             t = re.sub(r"\.+", ".", t)
             singles = len(re.findall(r"(?<!L)L\.?W", t))  # one load, then a full drain
@@ -47,6 +64,8 @@ def main():
             i = j
     for r in sorted(rows, reverse=True):
         print(f"{r[0]:4d} single-load drains of {r[1]:4d} loads  {r[2]:22s} {r[3]}")
+    for r in sorted(loops, reverse=True):
+        print(f"{r[0]:4d} thin loop(s): <= 2 loads then vmcnt(0) per trip  {r[1]:22s} {r[2]}")
 
 
 if __name__ == "__main__":
