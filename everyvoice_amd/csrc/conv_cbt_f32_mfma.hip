@@ -529,16 +529,35 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_kernel(ConvF32Args a
       float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        constexpr int EB = 4;  // (8 would push the 128-register kernels of this family over their occupancy step)
+        // bias and previous values in batches of EB from clamped rows: a read under a per-element condition costs a drained
+        // round trip each (64 in a row per lane); 0 / -0 stand in for an absent operand
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (m >= m_valid) continue;
-          const int co = co0 + m;
-          float v = acc[mt][nt][r];
-          if (a.bias) v += a.bias[co];
-          v = conv_act<ACT>(v, a.act_param);
-          float* dst = ycol + (long long)co * a.B * a.t_out_total;
-          *dst = a.accumulate ? *dst + v : v;
+        for (int r0 = 0; r0 < 16; r0 += EB) {
+          int mrow[EB];
+          float* dst[EB];
+          float bv[EB], prev[EB];
+#pragma unroll
+          for (int e = 0; e < EB; ++e) {
+            const int r = r0 + e;
+            mrow[e] = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            dst[e] = ycol + (long long)(co0 + min(mrow[e], m_valid - 1)) * a.B * a.t_out_total;
+            bv[e] = 0.f;
+            prev[e] = -0.f;
+          }
+          if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) bv[e] = a.bias[co0 + min(mrow[e], m_valid - 1)];
+          }
+          if (a.accumulate) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) prev[e] = *dst[e];
+          }
+#pragma unroll
+          for (int e = 0; e < EB; ++e) {
+            const float v = conv_act<ACT>(a.bias ? acc[mt][nt][r0 + e] + bv[e] : acc[mt][nt][r0 + e], a.act_param);
+            if (mrow[e] < m_valid) *dst[e] = prev[e] + v;
+          }
         }
       }
     }
@@ -802,16 +821,35 @@ __global__ __launch_bounds__(256, 2) void conv_cbt_f32_mfma_wp_kernel(ConvF32Arg
       float* ycol = a.y + (long long)col_b[nt] * a.t_out_total + (long long)col_to[nt] * a.out_stride + out_off;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        constexpr int EB = 4;  // (8 would push the 128-register kernels of this family over their occupancy step)
+        // bias and previous values in batches of EB from clamped rows: a read under a per-element condition costs a drained
+        // round trip each (64 in a row per lane); 0 / -0 stand in for an absent operand
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (m >= m_valid) continue;
-          const int co = co0 + m;
-          float v = acc[mt][nt][r];
-          if (a.bias) v += a.bias[co];
-          v = conv_act<ACT>(v, a.act_param);
-          float* dst = ycol + (long long)co * a.B * a.t_out_total;
-          *dst = a.accumulate ? *dst + v : v;
+        for (int r0 = 0; r0 < 16; r0 += EB) {
+          int mrow[EB];
+          float* dst[EB];
+          float bv[EB], prev[EB];
+#pragma unroll
+          for (int e = 0; e < EB; ++e) {
+            const int r = r0 + e;
+            mrow[e] = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            dst[e] = ycol + (long long)(co0 + min(mrow[e], m_valid - 1)) * a.B * a.t_out_total;
+            bv[e] = 0.f;
+            prev[e] = -0.f;
+          }
+          if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) bv[e] = a.bias[co0 + min(mrow[e], m_valid - 1)];
+          }
+          if (a.accumulate) {
+#pragma unroll
+            for (int e = 0; e < EB; ++e) prev[e] = *dst[e];
+          }
+#pragma unroll
+          for (int e = 0; e < EB; ++e) {
+            const float v = conv_act<ACT>(a.bias ? acc[mt][nt][r0 + e] + bv[e] : acc[mt][nt][r0 + e], a.act_param);
+            if (mrow[e] < m_valid) *dst[e] = prev[e] + v;
+          }
         }
       }
     }

@@ -52,19 +52,28 @@ __device__ __forceinline__ void pack_x_block(const PackArgs& p, int bx, int b, i
     const float* src = p.x + ((long long)(g * p.cin_g + o * 8) * p.B + b) * p.t_in + t;
     const long long cs = (long long)p.B * p.t_in;
     const int nch = min(8, p.cin_g - o * 8);
+    // the 8 channel rows (and the 8 mask rows) are requested together from clamped rows and masked by a select: a read under
+    // `i < nch` is compiled as a branch with a vmcnt(0) drain behind it, 8-16 serial round trips per unit
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (i < nch) v[i] = src[i * cs];
+    for (int i = 0; i < 8; ++i) v[i] = src[min(i, nch - 1) * cs];
+    float m[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m[i] = 1.f;
+    if (p.mask) {
+      const float* ms = p.mask + (src - p.x);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m[i] = ms[min(i, nch - 1) * cs];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m[i] = m[i] > 0.f ? 1.f : p.mask_slope;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = i < nch ? v[i] : 0.f;
     if (p.pre_slope != 1.f) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) v[i] = v[i] > 0.f ? v[i] : v[i] * p.pre_slope;
     }
-    if (p.mask) {
-      const float* ms = p.mask + (src - p.x);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (i < nch) v[i] *= ms[i * cs] > 0.f ? 1.f : p.mask_slope;
-    }
+    for (int i = 0; i < 8; ++i) v[i] *= m[i];
   }
   uint4 out;
   out.x = pk_bf16x2(v[0], v[1]);

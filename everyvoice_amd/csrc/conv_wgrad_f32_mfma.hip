@@ -243,13 +243,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_f32_mfma_kernel(WgradArgs a
     if (c >= bc_cur * k) continue;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      // previous values of 8 rows at a time, from clamped rows (a read under a per-element condition drains vmcnt each time)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m >= m_valid) continue;
-        float* dst = outp + (long long)(co0 + m) * kg + (long long)ci0 * k + c;
-        const float v = acc[mt][nt][r];
-        *dst = (a.accumulate && a.splits == 1) ? *dst + v : v;
+      for (int r0 = 0; r0 < 16; r0 += 8) {
+        float* dst[8];
+        float prev[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = r0 + e;
+          const int m = min((wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, m_valid - 1);
+          dst[e] = outp + (long long)(co0 + m) * kg + (long long)ci0 * k + c;
+          prev[e] = -0.f;
+        }
+        if (a.accumulate && a.splits == 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) prev[e] = *dst[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int r = r0 + e;
+          if ((wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < m_valid) *dst[e] = prev[e] + acc[mt][nt][r];
+        }
       }
     }
   }

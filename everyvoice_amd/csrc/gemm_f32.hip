@@ -103,13 +103,22 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmArgs g) {
   // D layout: lane column = n, registers = rows (r & 3) + 8 * (r >> 2) + 4 * kh
   const int n = n0 + wn * 32 + i;
   if (n < g.N) {
+    // the 16 previous values (beta != 0) are requested together from clamped rows, not one drained read per element
+    float* dst[16];
+    float prev[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (m >= g.M) continue;
-      float* dst = C + (long long)m * g.ldc + n;
+      dst[r] = C + (long long)min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, g.M - 1) * g.ldc + n;
+      prev[r] = 0.f;
+    }
+    if (g.beta != 0.f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) prev[r] = *dst[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
       const float v = g.alpha * acc[r];
-      *dst = g.beta == 0.f ? v : g.beta * *dst + v;
+      if (m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < g.M) *dst[r] = g.beta == 0.f ? v : g.beta * prev[r] + v;
     }
   }
 }
