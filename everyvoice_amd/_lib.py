@@ -138,6 +138,7 @@ SYMBOLS = {
     "evmi_softmax_bwd_rows_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_glu_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
     "evmi_dropout_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_float, C.c_ulonglong, C.c_void_p]),
+    "evmi_dropout_fused_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 3 + [C.c_longlong, C.c_float, C.c_ulonglong, C.c_float, C.c_void_p]),
     "evmi_fs2_embed_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "evmi_fs2_bucket_embed_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "evmi_fs2_item_embedding_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),

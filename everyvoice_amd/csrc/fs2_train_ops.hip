@@ -352,6 +352,56 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
   y[i] = uniform01(seed, (unsigned long long)i) >= p ? x[i] / (1.f - p) : 0.f;
 }
 
+// dropout with its neighbour in one pass (the Conformer block's `x + s * dropout(h)` and `dropout(silu(h))`, and their backwards):
+//   MODE 1: y = b + scale * drop(a)      2: y = drop(silu(a))      3: y = drop(a) * silu'(b)      4: y = scale * drop(a)
+// drop(v)[i] = keep(seed, i) ? v[i] / (1 - p) : 0, the same stream as dropout_kernel; four elements per thread.
+template <int MODE>
+__global__ __launch_bounds__(256) void dropout_fused_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
+                                                            long long n, float p, unsigned long long seed, float scale) {
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  float av[4], bv[4];
+  const bool full = i0 + 3 < n;
+  if (full) {
+    const float4 t = *reinterpret_cast<const float4*>(a + i0);
+    av[0] = t.x; av[1] = t.y; av[2] = t.z; av[3] = t.w;
+    if (MODE == 1 || MODE == 3) {
+      const float4 u = *reinterpret_cast<const float4*>(b + i0);
+      bv[0] = u.x; bv[1] = u.y; bv[2] = u.z; bv[3] = u.w;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long long i = min(i0 + e, n - 1);
+      av[e] = a[i];
+      bv[e] = (MODE == 1 || MODE == 3) ? b[i] : 0.f;
+    }
+  }
+  const float inv_keep = 1.f - p;
+  float r[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool keep = uniform01(seed, (unsigned long long)(i0 + e)) >= p;
+    float v = av[e];
+    if (MODE == 2) v = v / (1.f + expf(-v));
+    float d = keep ? v / inv_keep : 0.f;
+    if (MODE == 1) d = bv[e] + scale * d;
+    if (MODE == 3) {
+      const float z = bv[e], sg = 1.f / (1.f + expf(-z));
+      d = d * sg * (1.f + z * (1.f - sg));
+    }
+    if (MODE == 4) d = scale * d;
+    r[e] = d;
+  }
+  if (full) {
+    *reinterpret_cast<float4*>(y + i0) = make_float4(r[0], r[1], r[2], r[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (i0 + e < n) y[i0 + e] = r[e];
+  }
+}
+
 // ---- embeddings, backward ------------------------------------------------------------------------------------------
 // One thread per (table row, channel) walks the tokens in order and adds the ones that map to its row: a fixed order
 // of additions (bitwise reproducible, unlike a scatter with atomics); the row test is wave-uniform (scalar loads).
@@ -528,6 +578,21 @@ int evmi_glu_bwd_f32(const float* p, const float* dy, float* dp, long long n_hal
   if (!p || !dy || !dp || n_half < 1) return fail(EVMI_ERR_INVALID_ARG, "glu_bwd: null pointer or empty input");
   hipLaunchKernelGGL(glu_bwd_kernel, dim3(blocks_for(n_half)), dim3(256), 0, (hipStream_t)stream, p, dy, dp, n_half);
   EVMI_LAUNCH_CHECK("glu_bwd");
+  return EVMI_OK;
+}
+
+int evmi_dropout_fused_f32(int mode, const float* a, const float* b, float* y, long long n, float p, unsigned long long seed, float scale,
+                           void* stream) {
+  if (!a || !y || n < 1 || p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "dropout_fused: null pointer, empty input or p outside [0, 1)");
+  if (mode < 1 || mode > 4 || ((mode == 1 || mode == 3) && !b)) return fail(EVMI_ERR_INVALID_ARG, "dropout_fused: mode 1..4 (1 and 3 take a second operand)");
+  if (((uintptr_t)a | (uintptr_t)y | (uintptr_t)b) & 15) return fail(EVMI_ERR_INVALID_ARG, "dropout_fused: operands must be 16-byte aligned");
+  const dim3 grid(blocks_for((n + 3) / 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 1) hipLaunchKernelGGL(dropout_fused_kernel<1>, grid, dim3(256), 0, s, a, b, y, n, p, seed, scale);
+  else if (mode == 2) hipLaunchKernelGGL(dropout_fused_kernel<2>, grid, dim3(256), 0, s, a, b, y, n, p, seed, scale);
+  else if (mode == 3) hipLaunchKernelGGL(dropout_fused_kernel<3>, grid, dim3(256), 0, s, a, b, y, n, p, seed, scale);
+  else hipLaunchKernelGGL(dropout_fused_kernel<4>, grid, dim3(256), 0, s, a, b, y, n, p, seed, scale);
+  EVMI_LAUNCH_CHECK("dropout_fused");
   return EVMI_OK;
 }
 

@@ -207,6 +207,31 @@ def dropout(tape: Tape, x: Var, p: float, seed: int) -> Var:
     return y
 
 
+def residual_dropout(tape: Tape, a: Var, b: Var, p: float, seed: int, sb: float = 1.0) -> Var:
+    """a + sb * dropout(b, p): one pass forward, one pass for b's gradient (sb * dropout(dy) with the same mask)."""
+    if p <= 0.0:
+        return residual(tape, a, b, sb)
+    y = Var(ops.dropout_fused(1, b.data, a.data, p, seed, sb))
+
+    def bwd():
+        if y.grad is None:
+            return
+        b.accumulate(ops.dropout_fused(4, y.grad, None, p, seed, sb))
+        a.accumulate(y.grad)
+
+    tape.record(bwd)
+    return y
+
+
+def silu_dropout(tape: Tape, x: Var, p: float, seed: int) -> Var:
+    """dropout(silu(x), p) in one pass; backward dropout(dy) * silu'(x) in one pass."""
+    if p <= 0.0:
+        return silu(tape, x)
+    y = Var(ops.dropout_fused(2, x.data, None, p, seed))
+    tape.record(lambda: y.grad is not None and x.accumulate(ops.dropout_fused(3, y.grad, x.data, p, seed)))
+    return y
+
+
 def residual(tape: Tape, a: Var, b: Var, sb: float = 1.0) -> Var:
     """a + sb * b"""
     y = Var(ops.axpby(1.0, a.data, sb, b.data))
@@ -282,21 +307,18 @@ class _ConformerT:
             x = self._ffn_fwd(tape, x, L["ffn1"], p, seeds)
             h = dense(tape, layernorm(tape, x, L["attn_ln"]), L["in_proj"])
             h = attention(tape, h, lens32, self.cfg.heads, p, seeds(self.cfg.heads))
-            h = dropout(tape, dense(tape, h, L["out_proj"]), p, seeds())
-            x = residual(tape, x, h)
+            x = residual_dropout(tape, x, dense(tape, h, L["out_proj"]), p, seeds())
             h = glu(tape, dense(tape, layernorm(tape, x, L["conv_ln"]), L["pw1"]))
             h = batchnorm(tape, dwconv(tape, h, L["dw"]), L["bn"], ops.ACT_SILU)
-            h = dropout(tape, dense(tape, h, L["pw2"]), p, seeds())
-            x = residual(tape, x, h)
+            x = residual_dropout(tape, x, dense(tape, h, L["pw2"]), p, seeds())
             x = self._ffn_fwd(tape, x, L["ffn2"], p, seeds)
             x = layernorm(tape, x, L["final_ln"])
         return x
 
     @staticmethod
     def _ffn_fwd(tape, x, F, p, seeds):
-        h = silu(tape, dense(tape, layernorm(tape, x, F["ln"]), F["l1"]))
-        h = dense(tape, dropout(tape, h, p, seeds()), F["l2"])
-        return residual(tape, x, dropout(tape, h, p, seeds()), 0.5)
+        h = silu_dropout(tape, dense(tape, layernorm(tape, x, F["ln"]), F["l1"]), p, seeds())
+        return residual_dropout(tape, x, dense(tape, h, F["l2"]), p, seeds(), 0.5)
 
 
 class _VariancePredictorT:

@@ -720,6 +720,13 @@ def dropout(x, p, seed):
     return y
 
 
+def dropout_fused(mode, a, b, p, seed, scale=1.0):
+    """evmi_dropout_fused_f32: 1: b + scale * drop(a); 2: drop(silu(a)); 3: drop(a) * silu'(b); 4: scale * drop(a)."""
+    y = torch.empty_like(a)
+    _chk(_lib.load().evmi_dropout_fused_f32(mode, a.data_ptr(), _lib.ptr(b), y.data_ptr(), a.numel(), p, seed, float(scale), _s(a)), "evmi_dropout_fused_f32")
+    return y
+
+
 def glu_bwd(p, dy):
     dp = torch.empty_like(p)
     _chk(_lib.load().evmi_glu_bwd_f32(p.data_ptr(), dy.data_ptr(), dp.data_ptr(), dy.numel(), _s(p)), "evmi_glu_bwd_f32")

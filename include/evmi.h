@@ -553,6 +553,12 @@ int evmi_softmax_bwd_rows_f32(const float* probs_dev, float* dprobs_dev, long lo
 int evmi_glu_bwd_f32(const float* p_dev, const float* dy_dev, float* dp_dev, long long n_half, void* stream);
 /* y[i] = keep(seed, i) ? x[i] / (1 - p) : 0 ; calling it on a gradient with the same seed is the backward. */
 int evmi_dropout_f32(const float* x_dev, float* y_dev, long long n, float p, unsigned long long seed, void* stream);
+/* The same dropout stream fused with its neighbour in the Conformer block (torchaudio's `x + 0.5 * dropout(ffn(x))`,
+ * `dropout(silu(.))` and their backwards): drop(v)[i] = keep(seed, i) ? v[i] / (1 - p) : 0 and
+ *   mode 1: y = b + scale * drop(a)    2: y = drop(silu(a))    3: y = drop(a) * silu'(b)    4: y = scale * drop(a)
+ * (b is read by modes 1 and 3 only; operands 16-byte aligned). */
+int evmi_dropout_fused_f32(int mode, const float* a_dev, const float* b_dev, float* y_dev, long long n, float p,
+                           unsigned long long seed, float scale, void* stream);
 /* Embedding backward: dtable[ids[b][l]][c] += dx[c][b][l] for l < lens[b], ids != skip_id (padding_idx).  One thread per
  * (table row, channel) adds its tokens in order: bitwise reproducible, no atomics.  `rows` = rows of the table. */
 int evmi_fs2_embed_bwd_f32(const float* dx_dev, const int* ids_dev, const int* lens_dev, float* dtable_dev, int rows,

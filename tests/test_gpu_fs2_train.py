@@ -236,6 +236,26 @@ def test_glu_silu_relu_dropout(cuda_device):
     assert torch.equal(y, ops.dropout(x, 0.25, 7)) and not torch.equal(y, ops.dropout(x, 0.25, 8))
 
 
+def test_dropout_fused_with_its_neighbours_equals_the_separate_passes(cuda_device):
+    """evmi_dropout_fused_f32 (x + s * dropout(h), dropout(silu(h)) and both backwards) against the one-operator kernels with
+    the same seed -- same mask, same arithmetic up to the rounding of one fused multiply-add -- at a length that is not a
+    multiple of the four elements a thread takes."""
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(1)
+    dev = cuda_device
+    for n in (4096, 100003):
+        a = torch.randn(n, generator=g).to(dev)
+        b = torch.randn(n, generator=g).to(dev)
+        p, seed = 0.1, 77
+        d = ops.dropout(a, p, seed)
+        _close(ops.dropout_fused(1, a, b, p, seed, 0.5), (b + 0.5 * d).cpu(), 1e-6)
+        _close(ops.dropout_fused(4, a, None, p, seed, 0.5), (0.5 * d).cpu(), 1e-6)
+        _close(ops.dropout_fused(2, a, None, p, seed), ops.dropout(ops.elementwise(ops.EW_SILU, a), p, seed).cpu(), 1e-6)
+        _close(ops.dropout_fused(3, a, b, p, seed), ops.elementwise(ops.EW_SILU_BWD, d, b).cpu(), 1e-6)
+        assert torch.equal(ops.dropout_fused(4, a, None, p, seed, 1.0) == 0, d == 0)  # the same mask
+
+
 # ---- the whole step ------------------------------------------------------------------------------------------------------
 def _ref_cfg(dropout=0.0, speakers=0, default_size=False):
     """``default_size``: the model BASELINE config 3 names and bench.py times (256-dim conformers with 2 x 128 heads and 1024-wide
