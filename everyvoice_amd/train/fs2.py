@@ -429,6 +429,7 @@ class FastSpeech2Trainer:
         # weight / bias gradients on a sibling stream beside the input-gradient chain (ops.side_wgrad): the step is one eager stream
         # of mostly small launches, so the two fill each other's gaps
         self.side_wgrad = (os.environ.get("EVMI_FS2_SIDE_WGRAD", "1") == "1") if side_wgrad is None else bool(side_wgrad)
+        self._stream = None  # set at the end of __init__ (with its sibling streams)
         self.config = c = config or FastSpeech2ModelConfig()
         self.stats = stats or Stats()
         self.training = training or FastSpeech2TrainingConfig()
@@ -475,6 +476,13 @@ class FastSpeech2Trainer:
         self._grad_norm = torch.zeros(1, device=self.device)
         self._reducer, self._tail_lo = None, None
         self.init_random(seed)
+        # the step's stream and its three siblings, taken from the pool back to back (four different hardware queues: training_step)
+        self._stream = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self._stream):
+            ops._side_state(self.device)  # the weight-gradient sibling of self._stream
+        if self.aligner is not None:
+            self.aligner._side = torch.cuda.Stream(self.device)
+            self.aligner._side_mas = torch.cuda.Stream(self.device)
 
     def _tail_offset(self) -> int:
         """First element of the flat buffers that belongs to the decoder / mel_linear / postnet (declared last, in this order)."""
@@ -746,7 +754,24 @@ class FastSpeech2Trainer:
         return y
 
     def training_step(self, batch: dict) -> dict:
-        """One optimiser step; returns the losses as device scalars (no host synchronisation inside the step)."""
+        """One optimiser step; returns the losses as device scalars (no host synchronisation inside the step).
+
+        The step runs on the trainer's own stream (the caller's stream is joined on both sides): that stream and the three
+        sibling streams beside it (weight gradients, CTC loss, alignment search) were taken from the stream pool back to back, so
+        they sit on four different hardware queues whatever the process created before -- on the caller's stream the overlap
+        depended on where the pool's round-robin stood (a GAN trainer earlier in the process cost this step 4.7 ms)."""
+        if self._stream is None:
+            return self._training_step(batch)
+        caller = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(caller)
+        with torch.cuda.stream(self._stream):
+            losses = self._training_step(batch)
+        caller.wait_stream(self._stream)
+        for v in losses.values():
+            v.record_stream(caller)
+        return losses
+
+    def _training_step(self, batch: dict) -> dict:
         from .hifigan import BucketReducer
         prev, prev_side = ops.CONV_BACKEND["operands"], ops.SIDE_WGRAD["on"]
         ops.CONV_BACKEND["operands"] = self.precision
