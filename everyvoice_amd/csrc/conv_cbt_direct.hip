@@ -48,14 +48,26 @@ __global__ __launch_bounds__(256) void conv_smallco_kernel(ConvDirectArgs a) {
   float acc[SMALLCO_MAX] = {0.f, 0.f, 0.f, 0.f};
   const int per_wave = (cc + 3) >> 2;
   const int cb = wave * per_wave, ce = min(cc, cb + per_wave);
-  for (int c = cb; c < ce; ++c) {
-    const float* xr = a.x + ((long long)(c0 + c) * a.B + b) * a.t_in;
+  // four channels per trip, their reads unconditional from clamped positions and issued together (a read under `live && in range`
+  // is a branch + vmcnt(0) drain per (channel, tap): 48 dependent round trips for 16 channels x 3 taps)
+  const long long cs = (long long)a.B * a.t_in;
+  const float* xb = a.x + ((long long)c0 * a.B + b) * a.t_in;
+  for (int c = cb; c < ce; c += 4) {
     for (int j = 0; j < a.k; ++j) {
       const int ti = ti0 + j * a.dil;
-      const float xv = (live && ti >= 0 && ti < a.t_in) ? xr[ti] : 0.f;
+      const bool ok = live && ti >= 0 && ti < a.t_in;
+      const int tic = min(max(ti, 0), a.t_in - 1);
+      float xv[4];
 #pragma unroll
-      for (int co = 0; co < SMALLCO_MAX; ++co)
-        if (co < a.c_out) acc[co] = fmaf(wl[(co * a.cc + c) * a.k + j], xv, acc[co]);
+      for (int u = 0; u < 4; ++u) xv[u] = xb[(long long)min(c + u, ce - 1) * cs + tic];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float x1 = (ok && c + u < ce) ? xv[u] : 0.f;
+        const int cw = min(c + u, ce - 1);
+#pragma unroll
+        for (int co = 0; co < SMALLCO_MAX; ++co)
+          if (co < a.c_out) acc[co] = fmaf(wl[(co * a.cc + cw) * a.k + j], x1, acc[co]);
+      }
     }
   }
 #pragma unroll
@@ -116,19 +128,31 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(ConvDirectArgs a) {
   const int ti0 = to * a.stride - a.pad;
   float xv[CIN1_KMAX];
 #pragma unroll
+  for (int j = 0; j < CIN1_KMAX; ++j) xv[j] = xr[min(max(ti0 + min(j, a.k - 1) * a.dil, 0), a.t_in - 1)];  // all requested, then masked
+#pragma unroll
   for (int j = 0; j < CIN1_KMAX; ++j) {
     const int ti = ti0 + j * a.dil;
-    xv[j] = (j < a.k && ti >= 0 && ti < a.t_in) ? xr[ti] : 0.f;
+    xv[j] = (j < a.k && ti >= 0 && ti < a.t_in) ? xv[j] : 0.f;
   }
   float* dst = a.y + ((long long)co0 * a.B + b) * a.t_out_total + (long long)to * a.out_stride + a.out_offset;
   const long long co_stride = (long long)a.B * a.t_out_total;
-  for (int co = 0; co < nco; ++co) {
-    float v = bl[co];
+  for (int co = 0; co < nco; co += 8) {  // previous values of 8 rows per trip (accumulate), from clamped rows
+    float prev[8];
 #pragma unroll
-    for (int j = 0; j < CIN1_KMAX; ++j) v = fmaf(wl[co * CIN1_KMAX + j], xv[j], v);
-    v = direct_act(v, a.act, a.act_param);
-    *dst = a.accumulate ? *dst + v : v;
-    dst += co_stride;
+    for (int e = 0; e < 8; ++e) prev[e] = -0.f;
+    if (a.accumulate) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) prev[e] = dst[(long long)min(co + e, nco - 1) * co_stride];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (co + e >= nco) break;
+      float v = bl[co + e];
+#pragma unroll
+      for (int j = 0; j < CIN1_KMAX; ++j) v = fmaf(wl[(co + e) * CIN1_KMAX + j], xv[j], v);
+      v = direct_act(v, a.act, a.act_param);
+      dst[(long long)(co + e) * co_stride] = prev[e] + v;
+    }
   }
 }
 
