@@ -7,7 +7,7 @@
 //             dQ = scale * dS K ; dK = scale * dS^T Q ; dV = Pd^T dO                          -> dqkv [3D][B][T]
 //
 // Attention dropout (torch.nn.MultiheadAttention applies it to the normalised probabilities) uses the counter-based generator
-// of fs2_train_ops.hip: element ((b * T + q) * T + k) of the stream seeded with seed + h, so the backward regenerates the mask.
+// of common.h (`uniform01`, the one evmi_dropout_f32 draws from): element ((b * T + q) * T + k) of the stream seeded with seed + h, so the backward regenerates the mask.
 //
 // Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).  Both passes use the transposed-problem trick of
 // the inference kernel (fs2_ops.hip): computing S^T = K Q^T leaves a score tile as lane = query, registers = keys, which is
@@ -27,14 +27,6 @@ namespace evmi {
 __device__ __forceinline__ float live_load(const float* __restrict__ p, bool live) {
   const float v = *p;
   return live ? v : 0.f;
-}
-
-__device__ __forceinline__ float attn_uniform01(unsigned long long seed, unsigned long long i) {
-  unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;  // splitmix64, as fs2_train_ops.hip: uniform01
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
 constexpr int AT_LD = 33;  // staged rows are read both along and across: odd stride
@@ -115,7 +107,7 @@ __global__ __launch_bounds__(256) void attention_train_fwd_kernel(const float* _
       st[r] = expf(st[r] - m_new);
       ps += st[r];  // the normaliser sums the probabilities BEFORE dropout
       if (p_drop > 0.f)
-        st[r] = attn_uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? st[r] * keep : 0.f;
+        st[r] = uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? st[r] * keep : 0.f;
     }
     ps += __shfl_xor(ps, 32, 64);
     l_run = l_run * corr + ps;
@@ -206,7 +198,7 @@ __global__ __launch_bounds__(256) void attention_train_dq_kernel(const float* __
       const int key = k0 + acc_row(r, kh);
       const float pr = key < len ? expf(st[r] - my_lse) : 0.f;
       float g = dp[r];
-      if (p_drop > 0.f) g = attn_uniform01(seed + h, row_base + (unsigned long long)key) >= p_drop ? g * keep : 0.f;
+      if (p_drop > 0.f) g = uniform01(seed + h, row_base + (unsigned long long)key) >= p_drop ? g * keep : 0.f;
       st[r] = pr * (g - my_d);  // dS^T as it lies: lane = query, register = key
     }
 #pragma unroll
@@ -284,7 +276,7 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
       const int tq = q0 + qi;
       const float pr = (klive && tq < T) ? expf(st[r] - lse_s[qi]) : 0.f;
       float mk = 1.f;
-      if (p_drop > 0.f) mk = attn_uniform01(seed + h, ((unsigned long long)b * T + (unsigned long long)min(tq, T - 1)) * T + (unsigned long long)min(tk, T - 1)) >= p_drop ? keep : 0.f;
+      if (p_drop > 0.f) mk = uniform01(seed + h, ((unsigned long long)b * T + (unsigned long long)min(tq, T - 1)) * T + (unsigned long long)min(tk, T - 1)) >= p_drop ? keep : 0.f;
       pd[r] = pr * mk;                        // Pd   : the dropped-out probabilities that multiplied V
       st[r] = pr * (dp[r] * mk - d_s[qi]);    // dS
     }
@@ -431,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_fwd_bf16_kernel(const 
     for (int r = 0; r < 16; ++r) {
       float pr = __expf(st[r] - m_new);
       ps += pr;
-      if (DROP) pr = attn_uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? pr * keep : 0.f;
+      if (DROP) pr = uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? pr * keep : 0.f;
       pb[r >> 3][r & 7] = (bf16_t)pr;
     }
     ps += __shfl_xor(ps, 32, 64);
@@ -525,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_dq_bf16_kernel(const f
       float pr = __expf(st[r] - my_lse);
       pr = key < len ? pr : 0.f;
       float g = dp[r];
-      if (DROP) g = attn_uniform01(seed + h, row_base + (unsigned long long)key) >= p_drop ? g * keep : 0.f;
+      if (DROP) g = uniform01(seed + h, row_base + (unsigned long long)key) >= p_drop ? g * keep : 0.f;
       dsb[r >> 3][r & 7] = (bf16_t)(pr * (g - my_d));
     }
 #pragma unroll
@@ -631,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_dkv_bf16_kernel(const 
         float pr = __expf(st[r] - lse_q[e]);
         pr = (klive && tq < T) ? pr : 0.f;
         float mk = 1.f;
-        if (DROP) mk = attn_uniform01(seed + h, col_base + (unsigned long long)min(tq, T - 1) * (unsigned long long)T) >= p_drop ? keep : 0.f;
+        if (DROP) mk = uniform01(seed + h, col_base + (unsigned long long)min(tq, T - 1) * (unsigned long long)T) >= p_drop ? keep : 0.f;
         pdb[r >> 3][r & 7] = (bf16_t)(pr * mk);
         dsb[r >> 3][r & 7] = (bf16_t)(pr * (dp[r] * mk - d_q[e]));
       }

@@ -132,6 +132,28 @@ __device__ __forceinline__ float ordered_sum_strided(const float* __restrict__ p
 }
 
 
+// Counter-based uniform in [0, 1) for dropout masks: element i of the stream `seed`; the backward (and the attention kernels,
+// tile by tile) regenerate the same mask from the same (seed, i).  A keyed two-round 32-bit mix (the multiply / xor-shift rounds of
+// the `lowbias32` integer hash, the second key injected between the rounds so that streams are not shifted or permuted copies of
+// each other): 3 quarter-rate 32-bit multiplies per draw against the 12 of the splitmix64 it replaces -- at one draw per
+// probability the generator, not the exp, was the larger part of the attention kernels' element loop, and the fused dropout
+// passes sat at the edge of being compute-bound.  The seed-only part is wave-uniform (scalar unit).
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long i) {
+  const unsigned k0 = (unsigned)seed * 0x9E3779B1u + 0x7F4A7C15u;
+  unsigned k1 = (unsigned)(seed >> 32) ^ (k0 >> 15);
+  k1 = k1 * 0x85EBCA6Bu + 0xC2B2AE35u;
+  unsigned h = (unsigned)i ^ k0;
+  h += (unsigned)(i >> 32) * 0x27D4EB2Fu;  // indices past 2^32 (not reached by these models) still get their own draws
+  h ^= h >> 16;
+  h *= 0x7FEB352Du;
+  h ^= k1;
+  h ^= h >> 15;
+  h *= 0x846CA68Bu;
+  h ^= h >> 16;
+  return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+
 // wait until at most n (wave-uniform) vector-memory operations of this wave are outstanding
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
   n = __builtin_amdgcn_readfirstlane(n);

@@ -20,14 +20,7 @@
 
 namespace evmi {
 
-// counter-based uniform in [0, 1): splitmix64 of (seed, element index) -- the backward regenerates the same mask
-__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long i) {
-  unsigned long long z = seed + (i + 1) * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
+// (the dropout generator `uniform01` lives in common.h: the attention kernels draw from the same streams)
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
