@@ -24,6 +24,7 @@ class ParamGroup:
         self._n = 0
         self.flat = self.grad = self.m = self.v = self.step_dev = None
         self._step = 0
+        self._views = {}
 
     def declare(self, name: str, shape, export_shape=None) -> int:
         """``export_shape``: the tensor shape upstream stores under this name when it differs from the one the kernels use
@@ -45,8 +46,14 @@ class ParamGroup:
         self._index = {name: i for i, (name, _, _) in enumerate(self._specs)}
 
     def _view(self, buf, i):
-        _, shape, off = self._specs[i]
-        return buf[off : off + math.prod(shape)].view(shape)
+        # views of the two flat buffers the layers ask for on every call are made once (a slice + view costs ~2 us, ~950 of them
+        # per FastSpeech2 step); the buffers themselves are never re-allocated after finalize()
+        key = (id(buf), i)
+        v = self._views.get(key)
+        if v is None or v[0] is not buf:
+            _, shape, off = self._specs[i]
+            v = self._views[key] = (buf, buf[off : off + math.prod(shape)].view(shape))
+        return v[1]
 
     def data(self, i):
         return self._view(self.flat, i)

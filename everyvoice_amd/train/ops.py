@@ -139,6 +139,10 @@ class _SideState:
         self.stream = torch.cuda.Stream(device)
         self.pending = None
         self.keep = []
+        # one event object per direction, re-recorded on every use (a wait takes the record that precedes it in host order);
+        # creating two events and entering torch.cuda.stream() per weight gradient cost ~33 us of host time each, 3.8 ms per
+        # FastSpeech2 step
+        self.ready, self.done = torch.cuda.Event(), torch.cuda.Event()
 
 
 def _side_state(device):
@@ -163,21 +167,21 @@ class side_wgrad:
             return self
         if _lib.current_stream_ptr(dev) in _SIDE_STREAMS:  # already beside a chain: stay here
             return self
-        self.state = _side_state(dev)
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(dev))
-        self.state.stream.wait_event(ready)
-        self.state.keep.extend(self.tensors)
-        self.ctx = torch.cuda.stream(self.state.stream)
-        self.ctx.__enter__()
+        st = self.state = _side_state(dev)
+        self.prev = torch.cuda.current_stream(dev)
+        st.ready.record(self.prev)
+        st.stream.wait_event(st.ready)
+        st.keep.extend(self.tensors)
+        torch.cuda.set_stream(st.stream)
+        self.ctx = True
         return self
 
     def __exit__(self, *exc):
         if self.ctx is not None:
-            done = torch.cuda.Event()
-            done.record(self.state.stream)
-            self.ctx.__exit__(*exc)
-            self.state.pending = done
+            st = self.state
+            st.done.record(st.stream)
+            torch.cuda.set_stream(self.prev)
+            st.pending = st.done
 
         return False
 
