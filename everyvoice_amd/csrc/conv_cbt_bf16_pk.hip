@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a) {
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct PkTile { int bm, bn; };
-static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {64, 256}, {32, 256}};
+static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {64, 256}, {32, 256}, {128, 256}};
 constexpr int kNumPkTiles = sizeof(kPkTiles) / sizeof(kPkTiles[0]);
 
 static int pk_env_int(const char* name, int dflt) {
@@ -652,6 +652,7 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
     case 2: EVMI_PK_LAUNCH(64, 64, 2, 2, 2) break;
     case 4: EVMI_PK_LAUNCH(64, 256, 1, 4, 4) break;
     case 5: EVMI_PK_LAUNCH(32, 256, 1, 4, 5) break;
+    case 6: EVMI_PK_LAUNCH(128, 256, 2, 2, 6) break;
     default: EVMI_PK_LAUNCH(32, 128, 1, 4, 3) break;
   }
 #undef EVMI_PK_LAUNCH
