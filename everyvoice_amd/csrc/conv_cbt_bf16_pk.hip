@@ -522,13 +522,20 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     a.ksplit = ks;
   }
   // candidate tiles in order of preference; the next one is tried while the staged window does not fit
-  int cand[6], nc = 0;
+  int cand[8], nc = 0;
   // 256-column tiles for narrow layers on many columns (the generator's last stages: 65-131 k columns, 32-64 channels; half the
   // prologues / epilogues per column): measured 26.6 vs 25.3 ms per GAN step (EVMI_PK_WIDE=1 vs 0) -- kept as a switch, off
   static const int wide = pk_env_int("EVMI_PK_WIDE", 0);
   if (a.ksplit > 1) { cand[nc++] = 0; cand[nc++] = 1; cand[nc++] = 2; cand[nc++] = 3; }
   else if (a.cout_g > 64) {
-    if (blocks(0) >= want) cand[nc++] = 0;
+    // Measured at the FastSpeech2 decoder's shapes (32 x 814 columns; tools/debug/pk_tile_bench.py, pack + convolution):
+    //  * 128 x 256 tiles for long contractions on many columns (the postnet's 512 -> 512, k = 5: 150 vs 180 us): the staged window
+    //    and the weight fragments are each read by half as many workgroups;
+    //  * 128 x 128 already from 1.5 workgroups per CU (256-row layers: 1024 -> 256 81 vs 97 us, 256 -> 256 34 vs 38 us on 64 x 128).
+    static const long long want0 = pk_env_int("EVMI_PK_WANT0", 384), want6 = pk_env_int("EVMI_PK_WANT6", 384);
+    static const int kb6 = pk_env_int("EVMI_PK_TILE6_MINKB", 128);
+    if (a.cout_g >= 128 && a.kblocks >= kb6 && blocks(6) >= want6) cand[nc++] = 6;
+    if (blocks(0) >= want0) cand[nc++] = 0;
     if (blocks(1) >= want || nc == 0) cand[nc++] = blocks(1) >= want ? 1 : 2;
     cand[nc++] = 2; cand[nc++] = 3;
   } else if (a.cout_g > 32) {
