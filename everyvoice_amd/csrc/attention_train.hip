@@ -29,28 +29,43 @@ __device__ __forceinline__ float live_load(const float* __restrict__ p, bool liv
   return live ? v : 0.f;
 }
 
-constexpr int AT_LD = 33;  // staged rows are read both along and across: odd stride
 
 // register r of a 32x32 accumulator <-> row index within the tile, for half-wave kh
 __device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
 
-// stage a [DH][32] tile of a channel-major [DH][B][T] slice starting at column t0 (zeros past T)
+// A [DH][32] tile of a channel-major [DH][B][T] slice, columns t0 .. t0 + 31, by LDS-direct loads straight into the operand layout: rows of 32 floats, element (d, t) at d * 32 + (t ^ (d & 31)).
+// The XOR swizzle replaces the odd row stride (a tile is read along its rows and across them: both are conflict-free), and is
+// applied on the SOURCE side -- lane (d, p) of a request fetches column p ^ (d & 31) -- because the hardware writes lane i of a
+// request to base + 4 i.  Columns past T are clamped to T - 1: finite values that only ever meet zero probabilities.  Two
+// generations of every tile: step i + 1 lands while step i computes, one barrier per step.
+typedef __attribute__((address_space(3))) float atf_lds_float_t;
+typedef __attribute__((address_space(1))) const float atf_glb_float_t;
 template <int DH>
-__device__ __forceinline__ void stage_tile(float* __restrict__ dst, const float* __restrict__ src, long long N, int t0, int T, int tid) {
-  // all of the thread's elements are requested before the first is stored (unconditional loads from clamped positions)
-  constexpr int NV = DH * 32 / 256;
-  float r[NV];
+__device__ __forceinline__ void tile_request_swz(float* __restrict__ dst, const float* __restrict__ src, long long N, int t0, int T, int tid) {
+  const int d0 = tid >> 5, p = tid & 31;
+  float* l = dst + (tid & ~63);
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
-    r[i] = live_load(src + (long long)d * N + min(t0 + tt, T - 1), t0 + tt < T);
-  }
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int v = tid + i * 256, d = v >> 5, tt = v & 31;
-    dst[d * AT_LD + tt] = r[i];
+  for (int i = 0; i < DH / 8; ++i) {
+    const int d = d0 + 8 * i;
+    const float* g = src + (long long)d * N + min(t0 + (p ^ (d & 31)), T - 1);
+    __builtin_amdgcn_global_load_lds((atf_glb_float_t*)g, (atf_lds_float_t*)(l + 256 * i), 4, 0, 0);
   }
 }
+// Per-lane offsets of the two kinds of read, computed once (32 registers; the rest of an address is an instruction immediate):
+//   along a row : lane reads column ln of row 2 s + kh             -> (2 s + kh) * 32 + row_off[s & 15]
+//   across rows : lane reads column acc_row(r, kh) of row 32 i + ln -> i * 1024 + col_off[r]
+struct SwzOffsets {
+  int row_off[16], col_off[16];
+  __device__ __forceinline__ SwzOffsets(int ln, int kh) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      row_off[j] = ln ^ ((2 * j + kh) & 31);
+      col_off[j] = ln * 32 + (((j & 3) + 8 * (j >> 2) + 4 * kh) ^ ln);
+    }
+  }
+  __device__ __forceinline__ int along(int s, int kh) const { return (2 * s + kh) * 32 + row_off[s & 15]; }
+  __device__ __forceinline__ int across(int i, int r) const { return i * 1024 + col_off[r]; }
+};
 
 // ---- forward -------------------------------------------------------------------------------------------------------------
 // grid (ceil(T / 128), H, B), 256 threads: every wave owns 32 queries
@@ -58,15 +73,21 @@ template <int DH>
 __global__ __launch_bounds__(256) void attention_train_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                  float* __restrict__ out, float* __restrict__ lse, int B, int T, int D,
                                                                  float scale, float p_drop, unsigned long long seed) {
-  __shared__ float Ks[DH * AT_LD];
-  __shared__ float Vs[DH * AT_LD];
+  extern __shared__ __attribute__((aligned(16))) float atf_lds[];
+  float* Kb = atf_lds;                 // [2 generations][DH][32], swizzled
+  float* Vb = atf_lds + 2 * DH * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const SwzOffsets sw(ln, kh);
   const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int len = min(lens[b], T);
   const long long N = (long long)B * T;
   const float* q = qkv + ((long long)(h * DH) * B + b) * T;
   const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
   const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
+  if (len > 0) {
+    tile_request_swz<DH>(Kb, kg, N, 0, T, tid);
+    tile_request_swz<DH>(Vb, vg, N, 0, T, tid);
+  }
   const int tq = blockIdx.x * 128 + wave * 32 + ln;
   const bool qlive = tq < T;
   const int tqc = min(tq, T - 1);  // clamped: loads are unconditional, dead lanes are zeroed by a select
@@ -82,16 +103,19 @@ __global__ __launch_bounds__(256) void attention_train_fwd_kernel(const float* _
   const float keep = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
 
-  for (int k0 = 0; k0 < len; k0 += 32) {
-    __syncthreads();
-    stage_tile<DH>(Ks, kg, N, k0, T, tid);
-    stage_tile<DH>(Vs, vg, N, k0, T, tid);
-    __syncthreads();
+  for (int k0 = 0, gen = 0; k0 < len; k0 += 32, gen ^= 1) {
+    __syncthreads();  // this step's tiles have landed (vmcnt(0) of every wave); the other generation's readers are done
+    if (k0 + 32 < len) {
+      tile_request_swz<DH>(Kb + (gen ^ 1) * DH * 32, kg, N, k0 + 32, T, tid);
+      tile_request_swz<DH>(Vb + (gen ^ 1) * DH * 32, vg, N, k0 + 32, T, tid);
+    }
+    const float* Ks = Kb + gen * DH * 32;
+    const float* Vs = Vb + gen * DH * 32;
     f32x16 st;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < DH / 2; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * s + kh) * AT_LD + ln], qreg[s], st, 0, 0, 0);
+    for (int s = 0; s < DH / 2; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[sw.along(s, kh)], qreg[s], st, 0, 0, 0);
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -118,7 +142,7 @@ __global__ __launch_bounds__(256) void attention_train_fwd_kernel(const float* _
       for (int r = 0; r < 16; ++r) acc[i][r] *= corr;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(i * 32 + ln) * AT_LD + acc_row(r, kh)], st[r], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[sw.across(i, r)], st[r], acc[i], 0, 0, 0);
     }
   }
   if (!qlive) return;
@@ -150,9 +174,11 @@ __global__ __launch_bounds__(256) void attention_train_dq_kernel(const float* __
                                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                 const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
                                                                 int D, float scale, float p_drop, unsigned long long seed) {
-  __shared__ float Ks[DH * AT_LD];
-  __shared__ float Vs[DH * AT_LD];
+  extern __shared__ __attribute__((aligned(16))) float atf_lds[];
+  float* Kb = atf_lds;                 // [2 generations][DH][32], swizzled
+  float* Vb = atf_lds + 2 * DH * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const SwzOffsets sw(ln, kh);
   const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int len = min(lens[b], T);
   const long long N = (long long)B * T;
@@ -160,6 +186,10 @@ __global__ __launch_bounds__(256) void attention_train_dq_kernel(const float* __
   const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
   const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
   const float* dog = d_o + ((long long)(h * DH) * B + b) * T;
+  if (len > 0) {
+    tile_request_swz<DH>(Kb, kg, N, 0, T, tid);
+    tile_request_swz<DH>(Vb, vg, N, 0, T, tid);
+  }
   const int tq = blockIdx.x * 128 + wave * 32 + ln;
   const bool qlive = tq < T;
   const int tqc = min(tq, T - 1);  // clamped: loads are unconditional, dead lanes are zeroed by a select
@@ -180,18 +210,21 @@ __global__ __launch_bounds__(256) void attention_train_dq_kernel(const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  for (int k0 = 0; k0 < len; k0 += 32) {
+  for (int k0 = 0, gen = 0; k0 < len; k0 += 32, gen ^= 1) {
     __syncthreads();
-    stage_tile<DH>(Ks, kg, N, k0, T, tid);
-    stage_tile<DH>(Vs, vg, N, k0, T, tid);
-    __syncthreads();
+    if (k0 + 32 < len) {
+      tile_request_swz<DH>(Kb + (gen ^ 1) * DH * 32, kg, N, k0 + 32, T, tid);
+      tile_request_swz<DH>(Vb + (gen ^ 1) * DH * 32, vg, N, k0 + 32, T, tid);
+    }
+    const float* Ks = Kb + gen * DH * 32;
+    const float* Vs = Vb + gen * DH * 32;
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < DH / 2; ++s) {
-      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * s + kh) * AT_LD + ln], qreg[s], st, 0, 0, 0);   // S^T  = K Q^T
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(2 * s + kh) * AT_LD + ln], doreg[s], dp, 0, 0, 0);  // dPd^T = V dO^T
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[sw.along(s, kh)], qreg[s], st, 0, 0, 0);   // S^T  = K Q^T
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[sw.along(s, kh)], doreg[s], dp, 0, 0, 0);  // dPd^T = V dO^T
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -205,7 +238,7 @@ __global__ __launch_bounds__(256) void attention_train_dq_kernel(const float* __
     for (int i = 0; i < DH / 32; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r)  // dQ^T [d][query] += K^T [d][key] dS^T [key][query]
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(i * 32 + ln) * AT_LD + acc_row(r, kh)], st[r], acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[sw.across(i, r)], st[r], acc[i], 0, 0, 0);
   }
   if (!qlive) return;
   float* o = dqkv + ((long long)(h * DH) * B + b) * T + tq;
@@ -221,10 +254,12 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
                                                                  const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                  const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
                                                                  int D, float scale, float p_drop, unsigned long long seed) {
-  __shared__ float Qs[DH * AT_LD];
-  __shared__ float Os[DH * AT_LD];
-  __shared__ float lse_s[32], d_s[32];
+  extern __shared__ __attribute__((aligned(16))) float atf_lds[];
+  float* Qb = atf_lds;                 // [2 generations][DH][32], swizzled
+  float* Ob = atf_lds + 2 * DH * 32;
+  float* stat = atf_lds + 4 * DH * 32; // [2 generations][lse of the 32 queries | D of the 32 queries]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
+  const SwzOffsets sw(ln, kh);
   const int h = blockIdx.y, b = blockIdx.z, H = gridDim.y;
   const int len = min(lens[b], T);
   const long long N = (long long)B * T;
@@ -248,33 +283,37 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
 #pragma unroll
     for (int r = 0; r < 16; ++r) acck[i][r] = accv[i][r] = 0.f;
   const bool block_live = blockIdx.x * 128 < len;  // uniform per workgroup
+  // wave 0 also brings the tile's 32 (lse, D) pairs: lanes 0-31 the lse, lanes 32-63 D, clamped (queries past T are masked below)
+  const float* stat_src = (kh ? dsum : lse) + ((long long)b * H + h) * T;
+  auto request = [&](int q0, int gen) {
+    tile_request_swz<DH>(Qb + gen * DH * 32, qg, N, q0, T, tid);
+    tile_request_swz<DH>(Ob + gen * DH * 32, dog, N, q0, T, tid);
+    if (wave == 0) __builtin_amdgcn_global_load_lds((atf_glb_float_t*)(stat_src + min(q0 + ln, T - 1)), (atf_lds_float_t*)(stat + 64 * gen), 4, 0, 0);
+  };
+  if (block_live) request(0, 0);
 
-  for (int q0 = 0; q0 < T && block_live; q0 += 32) {
+  for (int q0 = 0, gen = 0; q0 < T && block_live; q0 += 32, gen ^= 1) {
     __syncthreads();
-    stage_tile<DH>(Qs, qg, N, q0, T, tid);
-    stage_tile<DH>(Os, dog, N, q0, T, tid);
-    if (tid < 32) {
-      const bool in = q0 + tid < T;
-      const long long qi = ((long long)b * H + h) * T + min(q0 + tid, T - 1);
-      const float lv = lse[qi], dv = dsum[qi];
-      lse_s[tid] = in ? lv : INFINITY;
-      d_s[tid] = in ? dv : 0.f;
-    }
-    __syncthreads();
+    if (q0 + 32 < T) request(q0 + 32, gen ^ 1);
+    const float* Qs = Qb + gen * DH * 32;
+    const float* Os = Ob + gen * DH * 32;
+    const float* lse_s = stat + 64 * gen;
+    const float* d_s = lse_s + 32;
     f32x16 st, dp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) st[r] = dp[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < DH / 2; ++s) {
-      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(2 * s + kh) * AT_LD + ln], kreg[s], st, 0, 0, 0);  // S   = Q K^T : lane = key, registers = queries
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[(2 * s + kh) * AT_LD + ln], vreg[s], dp, 0, 0, 0);  // dPd = dO V^T
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[sw.along(s, kh)], kreg[s], st, 0, 0, 0);  // S   = Q K^T : lane = key, registers = queries
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[sw.along(s, kh)], vreg[s], dp, 0, 0, 0);  // dPd = dO V^T
     }
     f32x16 pd;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qi = acc_row(r, kh);
       const int tq = q0 + qi;
-      const float pr = (klive && tq < T) ? expf(st[r] - lse_s[qi]) : 0.f;
+      float pr = expf(st[r] - lse_s[qi]);
+      pr = (klive && tq < T) ? pr : 0.f;
       float mk = 1.f;
       if (p_drop > 0.f) mk = uniform01(seed + h, ((unsigned long long)b * T + (unsigned long long)min(tq, T - 1)) * T + (unsigned long long)min(tk, T - 1)) >= p_drop ? keep : 0.f;
       pd[r] = pr * mk;                        // Pd   : the dropped-out probabilities that multiplied V
@@ -285,8 +324,8 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qi = acc_row(r, kh);
-        accv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[(i * 32 + ln) * AT_LD + qi], pd[r], accv[i], 0, 0, 0);  // dV^T += dO^T Pd
-        acck[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(i * 32 + ln) * AT_LD + qi], st[r], acck[i], 0, 0, 0);  // dK^T += Q^T dS
+        accv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[sw.across(i, r)], pd[r], accv[i], 0, 0, 0);  // dV^T += dO^T Pd
+        acck[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[sw.across(i, r)], st[r], acck[i], 0, 0, 0);  // dK^T += Q^T dS
       }
   }
   if (tk >= T) return;
@@ -663,10 +702,21 @@ int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, 
   const float scale = 1.f / sqrtf((float)dh);
   const dim3 grid((T + 127) / 128, heads, B);
   hipStream_t s = (hipStream_t)stream;
-#define EVMI_MHA_FWD(DH) hipLaunchKernelGGL(attention_train_fwd_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, scale, p_drop, seed)
-  if (dh == 128) EVMI_MHA_FWD(128);
-  else if (dh == 64) EVMI_MHA_FWD(64);
-  else if (dh == 32) EVMI_MHA_FWD(32);
+#define EVMI_MHA_FWD(DH, SLOT)                                                                                                    \
+  {                                                                                                                               \
+    constexpr size_t lds = (size_t)4 * DH * 32 * sizeof(float);                                                                   \
+    static thread_local bool configured[3] = {};                                                                                  \
+    if (!configured[SLOT]) {                                                                                                      \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)attention_train_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds));                                                                              \
+      configured[SLOT] = true;                                                                                                    \
+    }                                                                                                                             \
+    hipLaunchKernelGGL(attention_train_fwd_kernel<DH>, grid, dim3(256), lds, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D,     \
+                       scale, p_drop, seed);                                                                                      \
+  }
+  if (dh == 128) EVMI_MHA_FWD(128, 0)
+  else if (dh == 64) EVMI_MHA_FWD(64, 1)
+  else if (dh == 32) EVMI_MHA_FWD(32, 2)
   else return fail(EVMI_ERR_UNSUPPORTED, "mha_fwd: head dimension must be 32, 64 or 128");
 #undef EVMI_MHA_FWD
   EVMI_LAUNCH_CHECK("mha_fwd");
@@ -753,16 +803,25 @@ int evmi_mha_bwd_f32(const float* qkv_dev, const int* lens_dev, const float* out
   const long long n = (long long)B * heads * T;
   hipLaunchKernelGGL(attention_rowdot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out_dev, dout_dev, dsum_dev, B, T, heads, dh);
   const dim3 grid((T + 127) / 128, heads, B);
-#define EVMI_MHA_BWD(DH)                                                                                                          \
+#define EVMI_MHA_BWD(DH, SLOT)                                                                                                    \
   {                                                                                                                               \
-    hipLaunchKernelGGL(attention_train_dq_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev,      \
+    constexpr size_t lds_q = (size_t)4 * DH * 32 * sizeof(float), lds_kv = lds_q + 128 * sizeof(float);                           \
+    static thread_local bool configured[3] = {};                                                                                  \
+    if (!configured[SLOT]) {                                                                                                      \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)attention_train_dq_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                         (int)lds_q));                                                                            \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)attention_train_dkv_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds_kv));                                                                           \
+      configured[SLOT] = true;                                                                                                    \
+    }                                                                                                                             \
+    hipLaunchKernelGGL(attention_train_dq_kernel<DH>, grid, dim3(256), lds_q, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev,  \
                        dqkv_dev, B, T, D, scale, p_drop, seed);                                                                   \
-    hipLaunchKernelGGL(attention_train_dkv_kernel<DH>, grid, dim3(256), 0, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev,     \
+    hipLaunchKernelGGL(attention_train_dkv_kernel<DH>, grid, dim3(256), lds_kv, s, qkv_dev, lens_dev, dout_dev, lse_dev, dsum_dev,\
                        dqkv_dev, B, T, D, scale, p_drop, seed);                                                                   \
   }
-  if (dh == 128) EVMI_MHA_BWD(128)
-  else if (dh == 64) EVMI_MHA_BWD(64)
-  else if (dh == 32) EVMI_MHA_BWD(32)
+  if (dh == 128) EVMI_MHA_BWD(128, 0)
+  else if (dh == 64) EVMI_MHA_BWD(64, 1)
+  else if (dh == 32) EVMI_MHA_BWD(32, 2)
   else return fail(EVMI_ERR_UNSUPPORTED, "mha_bwd: head dimension must be 32, 64 or 128");
 #undef EVMI_MHA_BWD
   EVMI_LAUNCH_CHECK("mha_bwd");
