@@ -322,8 +322,7 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
 #pragma unroll
     for (int i = 0; i < DH / 32; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qi = acc_row(r, kh);
+      for (int r = 0; r < 16; ++r) {  // (column acc_row(r, kh) of the tile: the query of register r)
         accv[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[sw.across(i, r)], pd[r], accv[i], 0, 0, 0);  // dV^T += dO^T Pd
         acck[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[sw.across(i, r)], st[r], acck[i], 0, 0, 0);  // dK^T += Q^T dS
       }
