@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_fwd_bf16_kernel(const 
   for (int i = 0; i < DH / 32; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[(long long)(i * 32 + acc_row(r, kh)) * N] = acc[i][r] * inv;
-  if (kh == 0) lse[((long long)b * H + h) * T + tq] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
+  if (kh == 0 && lse) lse[((long long)b * H + h) * T + tq] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;  // (inference: no lse)
 }
 
 template <int DH, bool DROP>
@@ -684,6 +684,20 @@ __global__ __launch_bounds__(256, 2) void attention_train_dkv_bf16_kernel(const 
       dk[(long long)(i * 32 + acc_row(r, kh)) * N] = acck[i][r] * scale;
       dv[(long long)(i * 32 + acc_row(r, kh)) * N] = accv[i][r];
     }
+}
+
+// The bf16 forward without dropout; lse may be NULL (the inference forward of fs2_ops.hip: evmi_attention_cbt_bf16 runs on this
+// kernel too -- 149 -> 82 us per decoder layer against the register-staged inference kernel it replaced).
+int launch_mha_fwd_bf16_plain(const float* qkv, const int* lens, float* out, float* lse_or_null, int B, int T, int D, int heads,
+                              hipStream_t s) {
+  const int dh = D / heads;
+  const float scale = 1.f / sqrtf((float)dh);
+  const dim3 grid((T + 127) / 128, heads, B);
+  if (dh == 128) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<128, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, 0ull);
+  else if (dh == 64) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<64, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, 0ull);
+  else if (dh == 32) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<32, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, 0ull);
+  else return 1;
+  return 0;
 }
 
 }  // namespace evmi

@@ -174,4 +174,9 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 }
 
 
+// attention_train.hip: bf16 flash-style forward without dropout (lse_or_null: the training path's saved log-sum-exp, NULL for
+// inference); returns nonzero for an unsupported head dimension (32 / 64 / 128 are built)
+int launch_mha_fwd_bf16_plain(const float* qkv, const int* lens, float* out, float* lse_or_null, int B, int T, int D, int heads,
+                              hipStream_t s);
+
 }  // namespace evmi

@@ -265,117 +265,7 @@ __global__ __launch_bounds__(256) void attention_cbt_kernel(const float* __restr
     for (int r = 0; r < 16; ++r) o[(long long)(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * N] = acc[i][r] * inv;
 }
 
-// bf16-operand version of the fused attention (precision="bf16"): Q, K, V and the probabilities are rounded to bf16 on their
-// way into v_mfma_f32_32x32x16_bf16, scores, softmax statistics and the output accumulate in fp32.  Same structure as above
-// (S^T = K.Q^T leaves the scores as lane = query, registers = keys; P^T feeds O^T = V^T.P^T from the registers it lies in): the
-// k slots of the PV products are assigned to the keys in the order the half-waves already hold them -- slot (half, j) of block
-// kb is key 16 kb + 8 (j >> 2) + 4 half + (j & 3) -- so no cross-lane exchange is needed; V^T is read in that order (two
-// 8-byte reads).  K is staged key-major [key][DH] (bf16, rows padded by 16 bytes), V channel-major [DH][32 keys].
-template <int DH>
-__global__ __launch_bounds__(256) void attention_cbt_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
-                                                                float* __restrict__ out, int B, int T, int D, float scale) {
-  constexpr int KS = DH + 8;   // bf16 elements per staged K row
-  constexpr int VSB = 32 + 8;  // bf16 elements per staged V row
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * KS];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[DH * VSB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, kh = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int len = min(lens[b], T);
-  const long long N = (long long)B * T;
-  const float* q = qkv + ((long long)(h * DH) * B + b) * T;
-  const float* kg = qkv + ((long long)(D + h * DH) * B + b) * T;
-  const float* vg = qkv + ((long long)(2 * D + h * DH) * B + b) * T;
-  const int tq = blockIdx.x * 128 + wave * 32 + ln;
-  const bool qlive = tq < T;
-  // Q^T as the B operand: lane (query, half) holds Q[query][16 s + 8 half + 0..7], pre-scaled
-  bf16x8 qreg[DH / 16];
-#pragma unroll
-  for (int s = 0; s < DH / 16; ++s)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float qv = q[(long long)(16 * s + 8 * kh + e) * N + min(tq, T - 1)];  // unconditional (clamped) load, then the select
-      qreg[s][e] = (bf16_t)(qlive ? qv * scale : 0.f);
-    }
-  f32x16 acc[DH / 32];
-#pragma unroll
-  for (int i = 0; i < DH / 32; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  for (int k0 = 0; k0 < len; k0 += 32) {
-    __syncthreads();  // previous tile consumed
-    {
-      constexpr int NV = DH * 32 / 256;
-      float kr[NV], vr[NV];
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * 256, d = v >> 5, kk = v & 31;
-        const long long o = (long long)d * N + min(k0 + kk, T - 1);
-        kr[i] = kg[o];
-        vr[i] = vg[o];
-      }
-#pragma unroll
-      for (int i = 0; i < NV; ++i) {
-        const int v = tid + i * 256, d = v >> 5, kk = v & 31;
-        const bool in = k0 + kk < T;
-        Ks[kk * KS + d] = (bf16_t)(in ? kr[i] : 0.f);
-        Vs[d * VSB + kk] = (bf16_t)(in ? vr[i] : 0.f);
-      }
-    }
-    __syncthreads();
-    f32x16 st;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) st[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < DH / 16; ++s) {
-      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(&Ks[ln * KS + 16 * s + 8 * kh]);
-      st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qreg[s], st, 0, 0, 0);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (key >= len) st[r] = -INFINITY;
-      mx = fmaxf(mx, st[r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);  // finite: every processed tile has a valid key
-    const float corr = expf(m_run - m_new);
-    float ps = 0.f;
-    bf16x8 pb[2];  // P^T of this lane's query: registers 0..7 -> block 0, 8..15 -> block 1 (keys as they lie)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float pr = expf(st[r] - m_new);
-      ps += pr;
-      pb[r >> 3][r & 7] = (bf16_t)pr;
-    }
-    ps += __shfl_xor(ps, 32, 64);
-    l_run = l_run * corr + ps;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < DH / 32; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] *= corr;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        // V^T rows = channels: lane (channel, half) takes keys 16 kb + 4 half + {0..3} and 16 kb + 8 + 4 half + {0..3}
-        const bf16_t* vr = &Vs[(i * 32 + ln) * VSB + 16 * kb + 4 * kh];
-        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
-        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 8);
-        const bf16x8 va = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[kb], acc[i], 0, 0, 0);
-      }
-    }
-  }
-  if (!qlive) return;
-  const float inv = l_run > 0.f ? 1.f / l_run : 0.f;  // an item of length 0 has no keys: its rows are zeros, not NaN
-  float* o = out + ((long long)(h * DH) * B + b) * T + tq;
-#pragma unroll
-  for (int i = 0; i < DH / 32; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[(long long)(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * N] = acc[i][r] * inv;
-}
+// (the bf16-operand attention of precision="bf16" runs on attention_train.hip's forward kernel: launch_mha_fwd_bf16_plain)
 
 static dim3 grid1d(long long n) { return dim3((unsigned)((n + 255) / 256)); }
 
@@ -468,14 +358,8 @@ int evmi_attention_cbt_bf16(const float* qkv_dev, const int* lens_dev, float* ou
   EVMI_NONNULL(qkv_dev && lens_dev && out_dev, "attention_cbt_bf16");
   if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads) return fail(EVMI_ERR_INVALID_ARG, "attention_cbt_bf16: shape");
   if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "attention_cbt_bf16: grid limits");
-  const int dh = D / heads;
-  const float scale = 1.f / sqrtf((float)dh);
-  const dim3 grid((T + 127) / 128, heads, B);
-  hipStream_t s = (hipStream_t)stream;
-  if (dh == 128) hipLaunchKernelGGL(attention_cbt_bf16_kernel<128>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, B, T, D, scale);
-  else if (dh == 64) hipLaunchKernelGGL(attention_cbt_bf16_kernel<64>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, B, T, D, scale);
-  else if (dh == 32) hipLaunchKernelGGL(attention_cbt_bf16_kernel<32>, grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, B, T, D, scale);
-  else return fail(EVMI_ERR_UNSUPPORTED, "attention_cbt_bf16: head dimension must be 32, 64 or 128");
+  if (launch_mha_fwd_bf16_plain(qkv_dev, lens_dev, out_dev, nullptr, B, T, D, heads, (hipStream_t)stream))
+    return fail(EVMI_ERR_UNSUPPORTED, "attention_cbt_bf16: head dimension must be 32, 64 or 128");
   EVMI_LAUNCH_CHECK("attention_cbt_bf16");
   return EVMI_OK;
 }
