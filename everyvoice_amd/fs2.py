@@ -106,11 +106,17 @@ def _chk(rc, what):
 
 
 def _s(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.current_stream_ptr(t.device)
 
 
 def _conv(x, w, b, k=1, act=ops.ACT_NONE):
     return ops.conv1d_mfma(x, w, b, 1, (k - 1) // 2, 1, 1, act=act)
+
+
+def _conv_add(x, w, b, res, k=1):
+    """res + conv(x): the residual is added in the convolution's epilogue on the packed bf16 kernels (one pass over the output
+    instead of three); elsewhere the convolution and the sum run as before."""
+    return ops.conv1d_fused_fwd(x, w, b, 1, (k - 1) // 2, 1, 1, residual=res)
 
 
 def _layernorm(x, g, b):
@@ -151,7 +157,10 @@ class _Conformer:
             for name in ("ffn1", "ffn2"):
                 L[name] = dict(ln_g=put(sd[p + name + ".sequential.0.weight"]), ln_b=put(sd[p + name + ".sequential.0.bias"]),
                                w1=put(sd[p + name + ".sequential.1.weight"].unsqueeze(-1)), b1=put(sd[p + name + ".sequential.1.bias"]),
-                               w2=put(sd[p + name + ".sequential.4.weight"].unsqueeze(-1)), b2=put(sd[p + name + ".sequential.4.bias"]))
+                               # the block's 0.5 (x + 0.5 * ffn(x)) is folded into the second layer: scaling by a power of two is
+                               # exact, so res + conv(h, w2 / 2, b2 / 2) rounds exactly as x + 0.5 * conv(h, w2, b2) did
+                               w2=put(0.5 * sd[p + name + ".sequential.4.weight"].float().unsqueeze(-1)),
+                               b2=put(0.5 * sd[p + name + ".sequential.4.bias"].float()))
             L["attn"] = dict(ln_g=put(sd[p + "self_attn_layer_norm.weight"]), ln_b=put(sd[p + "self_attn_layer_norm.bias"]),
                              w_in=put(sd[p + "self_attn.in_proj_weight"].unsqueeze(-1)), b_in=put(sd[p + "self_attn.in_proj_bias"]),
                              w_out=put(sd[p + "self_attn.out_proj.weight"].unsqueeze(-1)), b_out=put(sd[p + "self_attn.out_proj.bias"]))
@@ -166,7 +175,7 @@ class _Conformer:
 
     def _ffn(self, x, P):
         h = _conv(_layernorm(x, P["ln_g"], P["ln_b"]), P["w1"], P["b1"], act=ops.ACT_SILU)
-        return ops.axpby(1.0, x, 0.5, _conv(h, P["w2"], P["b2"]))
+        return _conv_add(h, P["w2"], P["b2"], x)
 
     def forward(self, x, lens):
         """x [D, B, T] (padded positions are computed, not masked: the convolution module sees them, as in the reference)."""
@@ -179,12 +188,12 @@ class _Conformer:
             att = torch.empty_like(x)
             attn = lib.evmi_attention_cbt_bf16 if ops.CONV_BACKEND["operands"] == "bf16" else lib.evmi_attention_cbt_f32
             _chk(attn(qkv.data_ptr(), lens.data_ptr(), att.data_ptr(), B, T, D, self.cfg.heads, _s(x)), "evmi_attention_cbt")
-            x = ops.axpby(1.0, x, 1.0, _conv(att, A["w_out"], A["b_out"]))
+            x = _conv_add(att, A["w_out"], A["b_out"], x)
             Cm = L["conv"]
             p = _conv(_layernorm(x, Cm["ln_g"], Cm["ln_b"]), Cm["w_pw1"], Cm["b_pw1"])
             g = ops.elementwise(15, p[:D], p[D:])  # GLU over the channel halves
             h = _dwconv(g, Cm["w_dw"], Cm["b_dw"], self.cfg.conv_kernel_size, 1)  # depthwise + folded BatchNorm + SiLU
-            x = ops.axpby(1.0, x, 1.0, _conv(h, Cm["w_pw2"], Cm["b_pw2"]))
+            x = _conv_add(h, Cm["w_pw2"], Cm["b_pw2"], x)
             x = self._ffn(x, L["ffn2"])
             x = _layernorm(x, L["final"]["g"], L["final"]["b"])
         return x
