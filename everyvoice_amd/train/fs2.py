@@ -59,7 +59,7 @@ class FastSpeech2TrainingConfig:
 
 
 def _s(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _lib.current_stream_ptr(t.device)
 
 
 def _chk(rc, what):
