@@ -140,18 +140,30 @@ def dist_env():
 def timed_region(step_fn, steps: int, warmup: int, sync_fn, barrier_fn, max_reduce_fn) -> float:
     """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + device sync on both
     sides; returns the MAX over ranks of the elapsed seconds."""
+    import gc
+
     for _ in range(warmup):
         step_fn()
     sync_fn()
-    barrier_fn()
-    sync_fn()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step_fn()
-    sync_fn()
-    barrier_fn()
-    sync_fn()
-    elapsed = time.perf_counter() - t0
+    # the cyclic collector stays out of the timed steps (as `timeit` does): late in the process a full collection walks the
+    # previous legs' objects for tens of milliseconds, and whether one fell into a 60 ms region made the FastSpeech2 inference leg
+    # read 5.9 or 8.8 ms per batch from run to run on the same box
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        barrier_fn()
+        sync_fn()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        sync_fn()
+        barrier_fn()
+        sync_fn()
+        elapsed = time.perf_counter() - t0
+    finally:
+        if was_enabled:
+            gc.enable()
     return max_reduce_fn(elapsed)
 
 
@@ -344,6 +356,7 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     from everyvoice_amd.train.hifigan import HiFiGANTrainer
 
     B, S = 16, 8192
+    torch.cuda.empty_cache()
     g = torch.Generator().manual_seed(1234 + rank)
     y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(dev)
     mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
@@ -445,6 +458,9 @@ def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
     from fs2_bench import forward_flops, synthetic_batch
 
     prec = args.train_precision
+    # every leg starts from an empty allocator cache, as the same workload does in a process of its own: served from the blocks the
+    # previous legs left behind, this leg read 5.9 to 8.8 ms per batch from run to run (fresh allocations: 5.9, every time)
+    torch.cuda.empty_cache()
     model = FastSpeech2(device=dev, precision=prec).init_random(1234)
     ids, lens, durs, t_i = synthetic_batch(32, 1234 + rank)
     ids, lens, durs = ids.to(dev), lens.to(dev), durs.to(dev)
@@ -482,6 +498,7 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     from fs2_train_bench import training_batch
 
     prec = args.train_precision
+    torch.cuda.empty_cache()
     tr = FastSpeech2Trainer(device=dev, process_group=True if use_dist else None, precision=prec)  # default config: learn_alignment on
     batch, t_i = training_batch(32, 1234 + rank, device=dev)
     out = {}
