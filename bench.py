@@ -464,7 +464,7 @@ def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
     model = FastSpeech2(device=dev, precision=prec).init_random(1234)
     ids, lens, durs, t_i = synthetic_batch(32, 1234 + rank)
     ids, lens, durs = ids.to(dev), lens.to(dev), durs.to(dev)
-    steps, warmup = 10, 3
+    steps, warmup = 30, 5
     elapsed = timed_region(lambda: model(ids, lens, durations=durs), steps, warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     other = "f32" if prec == "bf16" else "bf16"
     model.precision = other
@@ -506,7 +506,7 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     def step():
         out["losses"] = tr.training_step(batch)
 
-    steps, warmup = 10, 3
+    steps, warmup = 30, 5
     elapsed = timed_region(step, steps, warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     other = "f32" if prec == "bf16" else "bf16"
     tr.precision = other
