@@ -89,6 +89,10 @@ SYMBOLS = {
     "evmi_conv1d_cbt_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
     "evmi_conv1d_cbt_bf16pk": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
     "evmi_conv1d_cbt_bf16pk_ws_elems": (C.c_longlong, [C.c_int] * 10),
+    "evmi_conv1d_cbt_bf16pk_plan": (C.c_int, [C.c_int] * 10),
+    "evmi_conv1d_cbt_bf16_rounds": (C.c_int, [C.c_int] * 10),
+    "evmi_conv1d_dgrad_cbt_bf16pk_plan": (C.c_int, [C.c_int] * 10),
+    "evmi_conv1d_wgrad_cbt_bf16pk_plan": (C.c_int, [C.c_int] * 10),
     "evmi_conv1d_dgrad_cbt_bf16pk": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
     "evmi_conv1d_dgrad_cbt_bf16pk_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv1d_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 6),

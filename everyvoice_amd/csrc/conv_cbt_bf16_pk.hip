@@ -723,6 +723,21 @@ long long evmi_conv1d_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c_out, 
   return (pl.xp_units + pl.wf_units) * 4 + pl.part_elems;
 }
 
+int evmi_conv1d_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil, int groups) {
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (plan_fwd_pk(a, pl, B, c_in, t_in, c_out, n_out, n_out, k, stride, pad, dil, groups, 1, 0)) return -1;
+  return pl.ti + 16 * (a.ksplit > 1 ? a.ksplit : 0);
+}
+
+int evmi_conv1d_dgrad_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil,
+                                      int groups) {
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (plan_dgrad_pk(a, pl, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups)) return -1;
+  return pl.ti + 16 * (a.ksplit > 1 ? a.ksplit : 0);
+}
+
 int evmi_conv1d_cbt_bf16pk(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev,
                            long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out_total, int n_out, int k, int stride,
                            int pad, int dil, int groups, int out_stride, int out_offset, int accumulate, int act, float act_param,

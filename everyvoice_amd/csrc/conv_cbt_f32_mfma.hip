@@ -1269,6 +1269,22 @@ int evmi_conv1d_cbt_f32(const float* x_dev, const float* w_dev, const float* bia
                         stride, pad, dil, groups, out_stride, out_offset, accumulate, act, act_param, stream);
 }
 
+int evmi_conv1d_cbt_bf16_rounds(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil, int groups) {
+  if (groups <= 0 || c_in <= 0 || c_out <= 0 || c_in % groups || c_out % groups) return 0;
+  if (evmi_conv1d_cbt_bf16pk_ws_elems(B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups) > 0) return 1;  // packed kernel
+  {  // GEMV / outer-product shapes stay exact (direct kernels)
+    ConvDirectArgs d = direct_args(B, c_in, t_in, c_out, n_out, n_out, k, stride, pad, dil);
+    int cc, nchunks;
+    if (conv_direct_plan(d, groups, cc, nchunks) > 0) return 0;
+  }
+  ConvF32Args a = {};
+  a.B = B; a.t_in = t_in; a.t_out_total = n_out; a.n_out = n_out;
+  a.cin_g = c_in / groups; a.cout_g = c_out / groups; a.k = k; a.stride = stride; a.dil = dil; a.pad = pad;
+  a.out_stride = 1; a.mtiles_per_group = 1; a.bf = 1;
+  F32Plan pl;
+  return plan_conv_f32(a, groups, pl) == nullptr ? 1 : 0;  // the in-LDS rounding mode of the fp32 kernel takes it
+}
+
 int evmi_conv1d_cbt_bf16(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev,
                          float* wfrag_ws_dev, long long wfrag_ws_elems, int B, int c_in, int t_in, int c_out,
                          int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups, int out_stride,

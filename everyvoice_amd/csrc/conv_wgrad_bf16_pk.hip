@@ -318,6 +318,14 @@ long long evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c
   return (pl.dy_units + pl.x_units) * 4 + pl.part_elems;
 }
 
+int evmi_conv1d_wgrad_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil,
+                                      int groups) {
+  WgradPkArgs a = {};
+  WgradPkPlan pl;
+  if (plan_wgrad_pk(a, pl, B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups)) return -1;
+  return pl.tgmax + 16 * (pl.splits > 1 ? pl.splits : 0);
+}
+
 static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in,
                          int c_out, int n_out, int k, int stride, int pad, int dil, int groups, int accumulate, float x_pre_slope,
                          const float* dy_mask_dev, float dy_mask_slope, void* stream);

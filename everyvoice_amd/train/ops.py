@@ -383,6 +383,15 @@ def wgrad_takes_bf16(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) -> 
             and _lib.load().evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) > 0)
 
 
+def fwd_takes_bf16(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) -> bool:
+    """True where precision="bf16" rounds the operands of this layer's forward convolution (and, with the roles of the channels
+    swapped, of its input gradient) to bf16; GEMV / outer-product shapes and groups narrower than the staging stay exact.
+    The library's own dispatch rule (evmi_conv1d_cbt_bf16_rounds): tests restating the arithmetic ask here."""
+    if not CONV_BACKEND["packed"]:
+        raise RuntimeError("fwd_takes_bf16 states the rule of the default (packed) configuration")
+    return bool(_lib.load().evmi_conv1d_cbt_bf16_rounds(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups))
+
+
 def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bool:
     """False for the degenerate shapes the matrix-core kernel does not stage (rows of a few samples under a long kernel)."""
     return bool(_lib.load().evmi_conv1d_cbt_f32_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups))

@@ -247,6 +247,10 @@ int evmi_conv1d_cbt_bf16(const float* x_dev, const float* w_dev, const float* bi
                          int t_out_total, int n_out, int k, int stride, int pad, int dil, int groups,
                          int out_stride, int out_offset, int accumulate, int act, float act_param,
                          void* stream);
+/* 1 where precision="bf16" rounds this convolution's operands to bf16 (the packed kernel or the in-LDS rounding mode takes the
+ * shape), 0 where the exact fp32 kernels run it (GEMV / outer-product shapes, groups narrower than the staging).  The one
+ * statement of that dispatch rule: parity tests restating the arithmetic for the oracle ask here. */
+int evmi_conv1d_cbt_bf16_rounds(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil, int groups);
 int evmi_conv1d_dgrad_cbt_bf16(const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev,
                                long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k,
                                int stride, int pad, int dil, int groups, void* stream);
@@ -295,6 +299,18 @@ int evmi_conv1d_wgrad_cbt_bf16pk_fused(const float* x_dev, const float* dy_dev, 
                                        int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil,
                                        int groups, int accumulate, float x_pre_slope, const float* dy_mask_dev,
                                        float dy_mask_slope, void* stream);
+/* Which kernel instantiation the planner of the packed bf16 kernels picks for a shape (what tests and profiles name):
+ *   evmi_conv1d_cbt_bf16pk_plan / evmi_conv1d_dgrad_cbt_bf16pk_plan: tile index 0..6 = conv_pk_kernel<128,128> <64,128> <64,64>
+ *   <32,128> <64,256> <32,256> <128,256>, + 16 * the split-K factor when the contraction is split over workgroups (ksplit > 1);
+ *   evmi_conv1d_wgrad_cbt_bf16pk_plan: taps per workgroup of wgrad_pk_kernel<4 | 8>, + 16 * the number of K splits.
+ * -1 = shape not taken by that kernel (the matching *_ws_elems is 0).  Replaces nothing in the reference (it has no kernels:
+ * torch picks its own through F.conv1d, e.g. everyvoice/model/utils.py:10-45); exists so that parity tests can assert that the
+ * instantiation a profile shows is the one a test compared with torch. */
+int evmi_conv1d_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil, int groups);
+int evmi_conv1d_dgrad_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil,
+                                      int groups);
+int evmi_conv1d_wgrad_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil,
+                                      int groups);
 /* Weight gradient of the same convolution as an implicit GEMM on the fp32 matrix cores (no unfold):
  *   dw[co][ci][j] (+)= sum_{b,to} dy[co][b][to] * x[ci][b][to*stride + j*dil - pad]
  * x [c_in][B][t_in], dy [c_out][B][n_out], dw [c_out][c_in/groups][k]; `ws_dev`: 16-byte aligned scratch of

@@ -470,6 +470,93 @@ def test_training_step_default_model_size_bf16_follows_oracle(cuda_device):
     assert cos >= 0.99 and 0.95 <= ratio <= 1.05, (cos, ratio)
 
 
+def _bench_batch(B, take=None):
+    """The synthetic LJSpeech-shaped batch bench.py's FastSpeech2 training leg times (tools/fs2_bench.py: batch 32, <= 187 symbols,
+    <= 947 frames, seed 1234) with given durations; ``take``: its first items only, trimmed to their own longest row."""
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1] / "tools"))
+    from fs2_train_bench import training_batch
+
+    batch, _ = training_batch(B, seed=1234, learn_alignment=False)
+    if take is not None:
+        lens = batch["lens"][:take]
+        L = int(lens.max())
+        T = int(batch["durations"][:take].sum(1).max())
+        batch = dict(ids=batch["ids"][:take, :L], lens=lens, durations=batch["durations"][:take, :L], mel=batch["mel"][:take, :T],
+                     pitch=batch["pitch"][:take, :L], energy=batch["energy"][:take, :L])
+    return batch
+
+
+def _grad_agreement(got_flat, want_flat):
+    g_, w_ = got_flat.double(), want_flat.double()
+    return float(torch.dot(g_, w_) / (g_.norm() * w_.norm())), float(g_.norm() / w_.norm())
+
+
+def test_training_step_at_the_bench_shape_bf16_follows_fp32(cuda_device):
+    """BASELINE config 3 at the batch bench.py times (32 utterances, <= 187 symbols, <= 947 frames): the planner's tile and
+    split-K choices depend on the column count, so the B = 4 tests do not run the timed kernels (conv_pk_kernel<128, 256>,
+    <128, 128> from 1.5 workgroups per CU, the split-K input gradients, wgrad_pk_kernel<4 | 8> over 26 k positions).  Here the
+    timed arithmetic (precision="bf16") runs the whole forward + backward at that size against the exact fp32 step of the same
+    trainer class on the same parameters and batch -- that fp32 path is pinned against the torch-CPU oracle (tests above), and
+    per operator the bench-shape kernels are pinned against torch in test_gpu_train_ops.py.  Every loss within 2e-2, whole
+    gradient cosine >= 0.99 and norm within 5 %, every large tensor's gradient cosine >= 0.97."""
+    from everyvoice_amd.train import ops
+
+    ref_cfg = _ref_cfg(0.0, 0, default_size=True)
+    batch = _bench_batch(32)
+    assert batch["ids"].shape[0] == 32 and int(batch["durations"].sum(1).max()) > 800
+    out = {}
+    for prec in ("f32", "bf16"):
+        tr = _trainer(ref_cfg, cuda_device, precision=prec)
+        ops.CONV_BACKEND["operands"] = prec  # what training_step does around forward_backward
+        try:
+            losses = tr.forward_backward(batch)
+        finally:
+            ops.CONV_BACKEND["operands"] = "f32"
+        out[prec] = ({k: float(v) for k, v in losses.items()}, {k: v.clone() for k, v in tr.params.gradients().items()}, tr.params.grad.clone())
+        del tr
+    for k, v in out["f32"][0].items():
+        assert math.isfinite(out["bf16"][0][k]) and out["bf16"][0][k] == pytest.approx(v, rel=2e-2, abs=1e-4), k
+    cos, ratio = _grad_agreement(out["bf16"][2], out["f32"][2])
+    assert cos >= 0.99 and 0.95 <= ratio <= 1.05, (cos, ratio)
+    for name, g32 in out["f32"][1].items():
+        if g32.numel() >= 4096 and float(g32.norm()) > 1e-6:
+            c, _ = _grad_agreement(out["bf16"][1][name].flatten(), g32.flatten())
+            assert c >= 0.97, f"{name}: cos {c:.4f}"
+    assert float((out["bf16"][2] - out["f32"][2]).abs().max()) > 0.0  # the bf16 kernels did run
+
+
+def test_training_step_bench_slice_bf16_follows_oracle(cuda_device):
+    """The first 8 utterances of the bench batch (full-length rows: up to 187 symbols / 947 frames, 8 x more columns per item
+    than the B = 4 / L = 48 oracle test) in precision="bf16" against torch-CPU autograd of the oracle module: losses within
+    2e-2, whole gradient cosine >= 0.99, norm within 5 %."""
+    from everyvoice_amd.train import ops
+
+    ref_cfg = _ref_cfg(0.0, 0, default_size=True)
+    tr = _trainer(ref_cfg, cuda_device, precision="bf16")
+    batch = _bench_batch(32, take=8)
+    ref = _oracle_from(tr, ref_cfg)
+    want = training_losses_ref(ref, batch)
+    want["total"].backward()
+    ops.CONV_BACKEND["operands"] = "bf16"
+    try:
+        got = tr.forward_backward(batch)
+    finally:
+        ops.CONV_BACKEND["operands"] = "f32"
+    for k, v in want.items():
+        assert float(got[k]) == pytest.approx(float(v), rel=2e-2, abs=1e-4), k
+    grads = tr.params.gradients()
+    flat_g, flat_w = [], []
+    for name, p in ref.named_parameters():
+        if p.grad is not None:
+            flat_g.append(grads[name].cpu().flatten())
+            flat_w.append(p.grad.flatten())
+    cos, ratio = _grad_agreement(torch.cat(flat_g), torch.cat(flat_w))
+    assert cos >= 0.99 and 0.95 <= ratio <= 1.05, (cos, ratio)
+
+
 def test_noam_schedule(cuda_device):
     tr = _trainer(_ref_cfg(), cuda_device)
     o = tr.training.optimizer

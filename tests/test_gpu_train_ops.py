@@ -436,6 +436,96 @@ def test_bf16_packed_kernels_edge_shapes(cuda_device, bf16_operands, case):
                   torch.nn.grad.conv1d_weight(x, w.shape, dy, s, p, d, groups)], 1e-4)
 
 
+# ---- the packed kernels at the shapes bench.py times (every instantiation a profile shows must have met torch) ----
+# (name, B, T, cin, cout, k, stride, pad, dil, groups, forward tile, input-gradient tile, weight-gradient taps): the expected
+# instantiations are what evmi_conv1d_*_bf16pk_plan reports with no EVMI_PK_* switch set (tile index: see include/evmi.h)
+BENCH_SHAPE_CASES = [
+    ("fs2 postnet 512->512 k5 on 32 x 814", 32, 814, 512, 512, 5, 1, 2, 1, 1, 6, 6, 8),        # conv_pk_kernel<128, 256>
+    ("fs2 ffn 256->1024 on 32 x 814", 32, 814, 256, 1024, 1, 1, 0, 1, 1, 0, 0, 4),             # <128, 128> from 1.5 workgroups per CU
+    ("fs2 ffn 1024->256 on 32 x 814", 32, 814, 1024, 256, 1, 1, 0, 1, 1, 0, 0, 4),
+    ("fs2 postnet 80->512 k5 on 32 x 947", 32, 947, 80, 512, 5, 1, 2, 1, 1, 0, 0, 8),          # dgrad: split-K <128, 128>
+    ("fs2 encoder 256->768 on 32 x 187", 32, 187, 256, 768, 1, 1, 0, 1, 1, 1, 2, 4),           # <64, 128> / <64, 64>
+    ("gan generator c32 k11 d5 on 16 x 8192", 16, 8192, 32, 32, 11, 1, 25, 5, 1, 3, 3, 8),     # <32, 128>
+    ("gan generator c64 k7 d3 on 16 x 4096", 16, 4096, 64, 64, 7, 1, 9, 3, 1, 1, 1, 8),        # <64, 128>
+    ("gan generator c128 k3 on 16 x 2048", 16, 2048, 128, 128, 3, 1, 1, 1, 1, 1, 1, 4),
+    ("gan generator c512 k11 d5 on 16 x 32", 16, 32, 512, 512, 11, 1, 25, 5, 1, 0, 0, 8),      # split-K over workgroups
+    ("mpd p2 32->128 s3 on 64 x 4096", 64, 4096, 32, 128, 5, 3, 2, 1, 1, 0, 3, 8),
+    ("mpd p11 1024->1024 on 352 x 28", 352, 28, 1024, 1024, 5, 1, 2, 1, 1, 0, 0, 8),           # short items: <128, 128>
+    ("msd 512->1024 k41 s4 g16 on 32 x 512", 32, 512, 512, 1024, 41, 4, 20, 1, 16, 1, 3, 8),
+    ("msd 128->128 k41 s2 g4 on 32 x 8192", 32, 8192, 128, 128, 41, 2, 20, 1, 4, 3, 3, 8),
+]
+
+
+@pytest.mark.parametrize("case", BENCH_SHAPE_CASES, ids=[c[0] for c in BENCH_SHAPE_CASES])
+def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
+    """Forward, input gradient and weight gradient of the packed bf16 kernels at the layer shapes bench.py's training legs run
+    (batch 32 x <= 947 frames for FastSpeech2, 16 x 8192 samples for the GAN step) against torch on the rounded operands -- the
+    planner's tile and split-K choices depend on the column count, so the small-shape tests above do not reach these
+    instantiations.  The test also asserts WHICH instantiation the planner picks (unless a switch forces one: the child runs of
+    test_packed_conv_every_tile_forced), so that a kernel named in profiles/*_kernel_stats.csv is one a test has compared."""
+    import os
+
+    from everyvoice_amd import _lib
+    from everyvoice_amd.train import ops
+
+    name, B, T, cin, cout, k, s, p, d, groups, tile_f, tile_d, taps_w = case
+    lib = _lib.load()
+    n_out = (T + 2 * p - d * (k - 1) - 1) // s + 1
+    if not any(os.environ.get(v) for v in ("EVMI_PK_TILE", "EVMI_PK_SPLITK", "EVMI_PK_WIDE")):
+        geo = (B, cin, T, cout, n_out, k, s, p, d, groups)
+        assert lib.evmi_conv1d_cbt_bf16pk_plan(*geo) % 16 == tile_f, name
+        assert lib.evmi_conv1d_dgrad_cbt_bf16pk_plan(*geo) % 16 == tile_d, name
+        assert lib.evmi_conv1d_wgrad_cbt_bf16pk_plan(*geo) % 16 == taps_w, name
+    g = torch.Generator().manual_seed(B * 7 + T + k)
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cout, cin // groups, k, generator=g) * (2.0 / (cin // groups * k) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    dy = torch.randn(B, cout, n_out, generator=g)
+    xd, wd, dyd = cbt(x).to(cuda_device), w.to(cuda_device), cbt(dy).to(cuda_device)
+    y = bct(ops.conv1d_fwd(xd, wd, b.to(cuda_device), s, p, d, groups).cpu())
+    dx, dw, _ = ops.conv1d_bwd(xd, wd, dyd, s, p, d, groups)
+    want_y = F.conv1d(_bf(x), _bf(w), b, s, p, d, groups)
+    want_dx = torch.nn.grad.conv1d_input(x.shape, _bf(w), _bf(dy), s, p, d, groups)
+    want_dw = torch.nn.grad.conv1d_weight(_bf(x), w.shape, _bf(dy), s, p, d, groups)
+    for got, want, what in ((y, want_y, "forward"), (bct(dx.cpu()), want_dx, "input gradient"), (dw.cpu(), want_dw, "weight gradient")):
+        err = float((got - want).abs().max() / want.abs().max())
+        assert err <= 1e-4, (name, what, err)  # fp32 accumulation of exact bf16 products: summation order only
+
+
+@pytest.mark.parametrize("tile", range(7))
+def test_packed_conv_every_tile_forced(tile):
+    """conv_pk_kernel<128,128 | 64,128 | 64,64 | 32,128 | 64,256 | 32,256 | 128,256>: the planner picks one per shape; here every one
+    of them is FORCED (EVMI_PK_TILE, read once per process -> a child process each) through the bf16 comparisons with torch of
+    this file -- small shapes, edge shapes and the bench shapes -- so a tile the planner starts choosing tomorrow (as <128, 256>
+    was switched on at the end of round 2) has already met the oracle.  Shapes a forced tile cannot stage fall back to the exact
+    fp32 kernels, which the comparisons accept (closest of the two oracles) or the test's own tolerance covers."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, EVMI_PK_TILE=str(tile))
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k",
+                        "bf16_packed_kernels_at_bench_shapes or bf16_packed_kernels_edge_shapes or conv1d_bf16_operands_dgrad "
+                        "or conv1d_bf16_operands_fwd"],
+                       env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("switch", ["EVMI_PK_SPLITK=0", "EVMI_PK_WIDE=1", "EVMI_WG_SPLITS=1", "EVMI_WG_NST=2"])
+def test_packed_conv_planner_switches(switch):
+    """The planner's other A/B switches (no split-K, 256-column tiles for narrow layers, unsplit / two-slot weight gradients)
+    through the same comparisons in a child process each."""
+    import os
+    import subprocess
+    import sys
+
+    key, val = switch.split("=")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k",
+                        "bf16_packed_kernels_at_bench_shapes or bf16_packed_kernels_edge_shapes or conv1d_wgrad_bf16_packed"],
+                       env=dict(os.environ, **{key: val}), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_conv_kernels_edge_shapes(cuda_device):
     """Single item, single output position, output length 1 per item with many items, channels not a multiple of anything."""
     from everyvoice_amd.train import ops

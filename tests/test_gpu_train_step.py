@@ -157,27 +157,38 @@ _ORIG_CONV1D = F.conv1d
 
 
 class _bf16_operand_oracle:
-    """Context: torch's conv1d / conv2d run with rounded operands wherever the product takes its bf16 kernels (at least 8 input
-    channels per group and more than 4 output channels; GEMV / outer-product shapes and the transposed convolutions are fp32)."""
+    """Context: torch's conv1d / conv2d run with rounded operands wherever the product takes its bf16 kernels -- asked from the
+    product (ops.fwd_takes_bf16 / ops.wgrad_takes_bf16), so a dispatch change cannot silently change what "match" means."""
 
     def __enter__(self):
         self.c1, self.c2 = F.conv1d, F.conv2d
         c1, c2 = self.c1, self.c2
 
-        def takes_bf16(x, w, groups):
-            return w.shape[1] >= 8 and w.shape[0] // groups > 4 and w.shape[0] > 4
+        def takes_bf16(x, w, stride, padding, dilation, groups):
+            """The product's own forward dispatch rule (ops.fwd_takes_bf16 -> evmi_conv1d_cbt_bf16_rounds), not a restatement:
+            Conv2d((k, 1)) on [B, C, H, p] is the Conv1d on B * p items of length H that the product runs."""
+            from everyvoice_amd.train import ops
+
+            one = lambda v: v[0] if isinstance(v, (tuple, list)) else v  # noqa: E731
+            s, p, d = one(stride), one(padding), one(dilation)
+            items = x.shape[0] * (x.shape[3] if x.dim() == 4 else 1)
+            t_in, k = x.shape[2], w.shape[2]
+            t_out = (t_in + 2 * p - d * (k - 1) - 1) // s + 1
+            return ops.fwd_takes_bf16(items, x.shape[1], t_in, w.shape[0], t_out, k, s, p, d, groups)
 
         def conv1d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
-            if torch.is_grad_enabled() and takes_bf16(x, w, groups):
+            rounded = takes_bf16(x, w, stride, padding, dilation, groups)
+            if torch.is_grad_enabled() and rounded:
                 return _RoundedConv.apply(x, w, b, stride, padding, dilation, groups, 1)
-            if takes_bf16(x, w, groups):
+            if rounded:
                 return c1(_bf(x), _bf(w), b, stride, padding, dilation, groups)
             return c1(x, w, b, stride, padding, dilation, groups)
 
         def conv2d(x, w, b=None, stride=1, padding=0, dilation=1, groups=1):
-            if torch.is_grad_enabled() and takes_bf16(x, w, groups):
+            rounded = takes_bf16(x, w, stride, padding, dilation, groups)
+            if torch.is_grad_enabled() and rounded:
                 return _RoundedConv.apply(x, w, b, stride, padding, dilation, groups, 2)
-            if takes_bf16(x, w, groups):
+            if rounded:
                 return c2(_bf(x), _bf(w), b, stride, padding, dilation, groups)
             return c2(x, w, b, stride, padding, dilation, groups)
 
