@@ -718,7 +718,8 @@ int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, 
 #define EVMI_MHA_FWD(DH, SLOT)                                                                                                    \
   {                                                                                                                               \
     constexpr size_t lds = (size_t)4 * DH * 32 * sizeof(float);                                                                   \
-    static thread_local bool configured[3] = {};                                                                                  \
+    static thread_local bool configured_dev[kMaxDevices][3] = {};                                                \
+    bool* configured = configured_dev[device_slot()];          \
     if (!configured[SLOT]) {                                                                                                      \
       EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)attention_train_fwd_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int)lds));                                                                              \
@@ -778,7 +779,8 @@ int evmi_mha_bwd_bf16(const float* qkv_dev, const int* lens_dev, const float* ou
 #define EVMI_MHA_BWD_DROP(DH, DROP, SLOT)                                                                                        \
   {                                                                                                                               \
     constexpr size_t lds = attention_dkv_bf16_lds<DH>();                                                                          \
-    static thread_local bool configured[8] = {};                                                                                  \
+    static thread_local bool configured_dev[kMaxDevices][8] = {};                                                \
+    bool* configured = configured_dev[device_slot()];          \
     if (!configured[SLOT]) {                                                                                                      \
       EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)attention_train_dkv_bf16_kernel<DH, DROP>,                                  \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                  \
@@ -819,7 +821,8 @@ int evmi_mha_bwd_f32(const float* qkv_dev, const int* lens_dev, const float* out
 #define EVMI_MHA_BWD(DH, SLOT)                                                                                                    \
   {                                                                                                                               \
     constexpr size_t lds_q = (size_t)4 * DH * 32 * sizeof(float), lds_kv = lds_q + 128 * sizeof(float);                           \
-    static thread_local bool configured[3] = {};                                                                                  \
+    static thread_local bool configured_dev[kMaxDevices][3] = {};                                                \
+    bool* configured = configured_dev[device_slot()];          \
     if (!configured[SLOT]) {                                                                                                      \
       EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)attention_train_dq_kernel<DH>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                          (int)lds_q));                                                                            \

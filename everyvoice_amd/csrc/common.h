@@ -11,6 +11,17 @@
 
 namespace evmi {
 
+// Launch-attribute caches and library-owned scratch are kept PER DEVICE (and per host thread): a process that drives several GPUs
+// -- a module moved with .to(), tests over several devices -- must set hipFuncAttributeMaxDynamicSharedMemorySize on each of them
+// and must not hand one device's scratch to another.
+constexpr int kMaxDevices = 16;
+inline int device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return 0;
+  return d;
+}
+
+
 // ---- error plumbing -----------------------------------------------------------------------
 void set_error(const std::string& msg);
 int fail(int code, const std::string& msg);

@@ -643,7 +643,8 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   a.xcd_remap = xcd_remap;
   a.ablate = pk_env_int("EVMI_PK_ABLATE", 0);
   const size_t lds = pl.lds;
-  static thread_local size_t configured[kNumPkTiles] = {0};
+  static thread_local size_t configured_dev[kMaxDevices][kNumPkTiles] = {};
+  size_t* configured = configured_dev[device_slot()];
 #define EVMI_PK_LAUNCH(BM, BN, WM, WN, IDX)                                                                              \
   {                                                                                                                      \
     if (lds > configured[IDX]) {                                                                                         \

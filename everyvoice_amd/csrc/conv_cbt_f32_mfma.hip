@@ -1024,7 +1024,8 @@ static int dispatch_conv_f32(ConvF32Args a, const F32Plan& pl, hipStream_t strea
     EVMI_HIP_CHECK(hipMemsetAsync(a.tl, 0, 24 * 4 * 4 * sizeof(long long), stream));
   }
 
-  static thread_local size_t configured[4 * kNumTiles] = {0};
+  static thread_local size_t configured_dev[kMaxDevices][4 * kNumTiles] = {};
+  size_t* configured = configured_dev[device_slot()];
 #define EVMI_F32_LAUNCH1(BM, BN, WM, WN, KS, BFM, IDX)                                                             \
   {                                                                                                                \
     if (lds > configured[IDX]) {                                                                                   \

@@ -105,8 +105,11 @@ const ConvTcLaunch* find_conv_tc(int c_in, int c_out, int ks, int dil) {
 }
 
 int launch_conv_tc(const ConvTcLaunch* L, const ConvTcArgs& a, int B, hipStream_t stream) {
-  static thread_local const void* configured[64];
-  static thread_local int n_configured = 0;
+  static thread_local const void* configured_dev[kMaxDevices][64];
+  static thread_local int n_configured_dev[kMaxDevices] = {};
+  const int dev_slot = device_slot();
+  const void** configured = configured_dev[dev_slot];
+  int& n_configured = n_configured_dev[dev_slot];
   bool seen = false;
   for (int i = 0; i < n_configured; ++i) seen |= (configured[i] == (const void*)L->kernel);
   if (!seen) {

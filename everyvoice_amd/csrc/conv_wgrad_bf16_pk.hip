@@ -379,7 +379,8 @@ static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev,
   a.accumulate = pl.splits > 1 ? 0 : accumulate;
   a.partial = pl.splits > 1;
   a.c_out = c_out;
-  static thread_local size_t configured[2] = {0, 0};
+  static thread_local size_t configured_dev[kMaxDevices][2] = {};
+  size_t* configured = configured_dev[device_slot()];
   const size_t lds = pl.lds;
   if (pl.tgmax == 4) {
     if (lds > configured[0]) {

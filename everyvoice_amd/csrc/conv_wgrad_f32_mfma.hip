@@ -358,7 +358,8 @@ int evmi_conv1d_wgrad_cbt_f32(const float* x_dev, const float* dy_dev, float* dw
   a.out = p.splits > 1 ? part : dw_dev;
   a.out_split_stride = p.splits > 1 ? w_elems : 0;
   const dim3 grid(p.ctiles, groups * p.mtiles, p.splits);
-  static thread_local size_t configured[6] = {0, 0, 0, 0, 0, 0};
+  static thread_local size_t configured_dev[kMaxDevices][6] = {};
+  size_t* configured = configured_dev[device_slot()];
 #define EVMI_WG_LAUNCH(BM, WM, WN, NST, IDX)                                                                        \
   {                                                                                                                 \
     if (p.lds > configured[IDX]) {                                                                                  \

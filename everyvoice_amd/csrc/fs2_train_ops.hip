@@ -165,6 +165,14 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_cbt_kernel(const float* __r
   __shared__ double sh[4];
   const int c = blockIdx.x;
   const float* xr = x + (long long)c * N;
+  if (momentum < 0.f) {  // evaluation mode: the running statistics normalise, nothing is updated
+    const float mean = running_mean[c], rstd = 1.f / sqrtf(running_var[c] + eps);
+    if (threadIdx.x == 0) { mean_out[c] = mean; rstd_out[c] = rstd; }
+    const float ga = gamma[c] * rstd, be = beta[c];
+    float* yr = y + (long long)c * N;
+    for (long long i = threadIdx.x; i < N; i += 256) yr[i] = bn_act((xr[i] - mean) * ga + be, act);
+    return;
+  }
   double s = 0.0;
   for (long long i = threadIdx.x; i < N; i += 256) s += (double)xr[i];
   const float mean = (float)(block_sum(s, sh) / (double)N);
@@ -508,6 +516,7 @@ int evmi_batchnorm_fwd_cbt_f32(const float* x, const float* gamma, const float* 
   if ((running_mean == nullptr) != (running_var == nullptr)) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: running_mean and running_var go together");
   if (C < 1 || n_cols < 1) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: empty input");
   if (act != 0 && act != 2 && act != 4) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: act must be 0 (none), 2 (SiLU) or 4 (tanh)");
+  if (momentum < 0.f && (!running_mean || !running_var)) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: evaluation mode (momentum < 0) needs the running statistics");
   hipLaunchKernelGGL(batchnorm_fwd_cbt_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean_out, rstd_out,
                      running_mean, running_var, n_cols, eps, momentum, act);
   EVMI_LAUNCH_CHECK("batchnorm_fwd_cbt");

@@ -192,7 +192,8 @@ int launch_istft_head(const bf16_t* x, const bf16_t* w, const float* bias, float
   const int n_out = IS_HOP * L;
   dim3 grid((n_out + IS_SAMPLES - 1) / IS_SAMPLES, B);
   auto lds_of = [](int c) { return (size_t)((IS_FRAMES + IS_KS - 1) * (c + 8) + IS_KS * 32 * (c + 8)) * 2; };
-  static thread_local bool configured[3] = {false, false, false};
+  static thread_local bool configured_dev[kMaxDevices][3] = {};
+  bool* configured = configured_dev[device_slot()];
 #define EVMI_ISTFT_CASE(CC, IDX)                                                                                  \
   if (c_in == CC) {                                                                                               \
     const size_t lds = lds_of(CC) > (size_t)IS_FRAMES * 40 * 4 ? lds_of(CC) : (size_t)IS_FRAMES * 40 * 4;        \

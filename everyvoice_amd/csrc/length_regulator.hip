@@ -117,7 +117,8 @@ static int ensure_cum(LrWorkspace& ws, size_t n) {
   return EVMI_OK;
 }
 
-static thread_local LrWorkspace g_lr_ws;
+static thread_local LrWorkspace g_lr_ws_dev[kMaxDevices];  // (scratch belongs to the device it was allocated on)
+#define g_lr_ws g_lr_ws_dev[device_slot()]
 
 int length_regulate(const void* values, const int64_t* dur, void* out, int64_t* out_lens,
                     int32_t* index, int B, int L, int D, int t_max, int elem_bytes, hipStream_t s) {

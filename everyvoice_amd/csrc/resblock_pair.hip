@@ -65,8 +65,11 @@ const PairLaunch* find_resblock_pair(int c, int ks, int dil) {
 }
 
 int launch_resblock_pair(const PairLaunch* L, PairArgs a, int B, int n_cu, hipStream_t stream) {
-  static thread_local const void* configured[32];
-  static thread_local int n_configured = 0;
+  static thread_local const void* configured_dev[kMaxDevices][32];
+  static thread_local int n_configured_dev[kMaxDevices] = {};
+  const int dev_slot = device_slot();
+  const void** configured = configured_dev[dev_slot];
+  int& n_configured = n_configured_dev[dev_slot];
   bool seen = false;
   for (int i = 0; i < n_configured; ++i) seen |= (configured[i] == (const void*)L->kernel);
   if (!seen) {

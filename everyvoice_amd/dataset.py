@@ -61,6 +61,10 @@ def resolve_filelist_loader(name_or_callable):
 class SpecDataset(Dataset):
     """(spec, audio, basename, spec_from_audio) per utterance for vocoder training."""
 
+    def get_labels(self):
+        """What ``use_weighted_sampler`` balances over (dataloader/imbalanced_sampler.py:51-58): the speaker of every item."""
+        return [item.get("speaker", "default") for item in self.audio_files]
+
     def __init__(self, audio_files: list[dict], config: HiFiGANConfig, use_segments: bool = False, finetune: bool | None = None):
         self.config = config
         self.audio_files = audio_files
@@ -138,6 +142,53 @@ class ShardedSampler(Sampler):
         return iter(idx[self.rank : self.total : self.world])
 
 
+class ImbalancedDatasetSampler(Sampler):
+    """everyvoice/dataloader/imbalanced_sampler.py:14-68 (ufoym's imbalanced-dataset-sampler as the reference adapts it): draws
+    ``num_samples`` indices with replacement, item i with probability proportional to 1 / (number of items carrying i's label),
+    so every label is drawn equally often.  Labels: ``labels``, else ``callback_get_label(dataset)``, else a TensorDataset's
+    second tensor, else ``dataset.get_labels()``.  ``seed`` / ``set_epoch`` / ``rank``: a reproducible stream per epoch and per
+    data-parallel rank (the reference draws from torch's global generator)."""
+
+    def __init__(self, dataset, labels=None, indices=None, num_samples=None, callback_get_label=None, seed: int | None = None, rank: int = 0):
+        from collections import Counter
+
+        self.indices = list(range(len(dataset))) if indices is None else list(indices)
+        self.callback_get_label = callback_get_label
+        self.num_samples = len(self.indices) if num_samples is None else num_samples
+        labels = self._get_labels(dataset) if labels is None else labels
+        labels = [x.item() if torch.is_tensor(x) else x for x in labels]
+        if len(labels) != len(self.indices):
+            raise ValueError(f"{len(labels)} labels for {len(self.indices)} indices")
+        # the reference sorts its (index, label) frame by index before taking the weights but draws through the UNSORTED index
+        # list (imbalanced_sampler.py:43-49, 61-64): reproduced as is, so that an explicit unsorted `indices` behaves the same
+        order = sorted(range(len(self.indices)), key=lambda j: self.indices[j])
+        labels = [labels[j] for j in order]
+        count = Counter(labels)
+        self.weights = torch.tensor([1.0 / count[x] for x in labels], dtype=torch.float64)
+        self.seed, self.rank, self.epoch = seed, rank, 0
+
+    def _get_labels(self, dataset):
+        if self.callback_get_label:
+            return self.callback_get_label(dataset)
+        if isinstance(dataset, torch.utils.data.TensorDataset):
+            return dataset.tensors[1]
+        if isinstance(dataset, Dataset):
+            return dataset.get_labels()
+        raise NotImplementedError
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def __iter__(self):
+        g = None
+        if self.seed is not None:
+            g = torch.Generator().manual_seed((self.seed * 1000003 + self.epoch) * 4099 + self.rank)
+        return (self.indices[i] for i in torch.multinomial(self.weights, self.num_samples, replacement=True, generator=g).tolist())
+
+    def __len__(self):
+        return self.num_samples
+
+
 def vocoder_collate(batch):
     """list of (spec [M, F], audio [S], basename, spec_from_audio [M, F]) -> (spec [B, M, F], audio [B, S], basenames, spec [B, M, F])."""
     spec, audio, names, spec_out = zip(*batch)
@@ -172,8 +223,13 @@ class BaseDataModule:
 
     def train_dataloader(self):
         # sampler=None in the reference; under DDP every rank must see its own shard, which Lightning arranges by injecting a
-        # DistributedSampler: the same thing is done here explicitly
-        self.train_sampler = ShardedSampler(len(self.train_dataset), self.rank, self.world, shuffle=True, seed=self.seed) if self.world > 1 else None
+        # DistributedSampler: the same thing is done here explicitly.  use_weighted_sampler: label-balanced draws
+        # (dataloader/__init__.py:54-58), each rank its own len / world of them
+        if self.use_weighted_sampler:
+            n = len(self.train_dataset)
+            self.train_sampler = ImbalancedDatasetSampler(self.train_dataset, num_samples=(n + self.world - 1) // self.world, seed=self.seed, rank=self.rank)
+        else:
+            self.train_sampler = ShardedSampler(len(self.train_dataset), self.rank, self.world, shuffle=True, seed=self.seed) if self.world > 1 else None
         return DataLoader(self.train_dataset, batch_size=self.batch_size, num_workers=self.config.training.train_data_workers,
                           pin_memory=False, drop_last=True, collate_fn=self.collate_fn, sampler=self.train_sampler,
                           shuffle=False if self.train_sampler is not None else None)
@@ -183,7 +239,8 @@ class BaseDataModule:
                           pin_memory=False, drop_last=False, collate_fn=self.collate_fn)
 
     def val_dataloader(self):
-        return DataLoader(self.val_dataset, batch_size=1, num_workers=0, pin_memory=False, drop_last=True, collate_fn=self.collate_fn)
+        sampler = ImbalancedDatasetSampler(self.val_dataset, seed=self.seed) if self.use_weighted_sampler else None  # dataloader/__init__.py:80-84
+        return DataLoader(self.val_dataset, batch_size=1, num_workers=0, pin_memory=False, drop_last=True, collate_fn=self.collate_fn, sampler=sampler)
 
     def prepare_data(self):
         raise NotImplementedError("This method should be implemented by the child class")

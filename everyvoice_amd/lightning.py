@@ -135,6 +135,16 @@ class HiFiGAN(_Module):
             tr.optimizer, tr.gan_type = o.name, t.gan_type
             tr.wgan_clip_value, tr.generator_warmup_steps = t.wgan_clip_value, t.generator_warmup_steps
 
+    def restart_optimizers(self):
+        """Moments, step counters and the global step back to zero (the driver's "optimizer hyperparameters changed" branch,
+        helpers.py:341-356, when the trainer already exists)."""
+        tr = self.trainer_
+        for grp in (tr.g_params, tr.d_params):
+            grp.m.zero_()
+            grp.v.zero_()
+            grp.set_step(0)
+        tr.global_step = 0
+
     def configure_optimizers(self):
         """Two optimisers (generator, discriminators) of the configured kind; they live as flat buffers inside the trainer
         (one fused kernel each), described here the way Lightning would list them."""
@@ -210,21 +220,78 @@ class HiFiGAN(_Module):
 # =====================================================================================================================
 @dataclass
 class FastSpeech2Config:
-    """The feature-prediction config as the path needs it: ``model`` (FastSpeech2ModelConfig) + ``training``."""
+    """The feature-prediction config as the path needs it (``FeaturePredictionConfig``, everyvoice/model/feature_prediction/config.py):
+    ``model`` (FastSpeech2ModelConfig) + ``training`` (loss weights over the driver-side BaseTrainingConfig fields) +
+    ``preprocessing`` (save_dir, audio) and the symbol inventory the data side encodes token strings with (``symbols``: what the
+    reference derives from ``text.symbols`` in its text front-end, out of scope here)."""
 
     model: object = None
     training: object = None
+    preprocessing: object = None
+    symbols: list | None = None
     VERSION: str = "1.0"
 
     def __post_init__(self):
+        from .config import PreprocessingConfig
         from .fs2 import FastSpeech2ModelConfig
         from .train.fs2 import FastSpeech2TrainingConfig
 
+        if isinstance(self.model, dict):
+            self.model = _dataclass_from_dict(FastSpeech2ModelConfig, self.model)
+        if isinstance(self.training, dict):
+            self.training = FastSpeech2TrainingConfig(**self.training)
+        if self.preprocessing is None or isinstance(self.preprocessing, dict):
+            self.preprocessing = PreprocessingConfig(**(self.preprocessing or {}))
         self.model = self.model or FastSpeech2ModelConfig()
         self.training = self.training or FastSpeech2TrainingConfig()
 
+    # -- the two class-level entry points the driver uses (base_cli/helpers.py:85, 111; shared_types.py:90-94) ------------------
+    @classmethod
+    def load_config_from_path(cls, path) -> "FastSpeech2Config":
+        """A YAML or JSON config file -> config; relative paths are resolved against the file's directory."""
+        path = Path(path)
+        text = path.read_text(encoding="utf8")
+        if path.suffix.lower() == ".json":
+            data = json.loads(text)
+        else:
+            import yaml
+
+            data = yaml.safe_load(text) or {}
+        try:
+            cfg = cls(**data)
+        except TypeError as e:
+            raise TypeError("Unable to load config.  Possible causes: is it really a FeaturePredictionConfig? or the correct version?") from e
+        base = path.resolve().parent
+        t = cfg.training
+        for name in ("training_filelist", "validation_filelist", "finetune_checkpoint"):
+            v = getattr(t, name)
+            if v is not None and not Path(v).is_absolute():
+                setattr(t, name, (base / v).resolve())
+        if not cfg.preprocessing.save_dir.is_absolute():
+            cfg.preprocessing.save_dir = (base / cfg.preprocessing.save_dir).resolve()
+        if not t.logger.save_dir.is_absolute():
+            t.logger.save_dir = (base / t.logger.save_dir).resolve()
+        return cfg
+
+    def model_dump(self, mode: str = "json") -> dict:
+        return {"VERSION": self.VERSION, "model": asdict(self.model), "training": self.training.json_dict(paths=True),
+                "preprocessing": self.preprocessing.model_dump(mode="json"), "symbols": list(self.symbols) if self.symbols is not None else None}
+
+    def update_config(self, new_config: dict) -> "FastSpeech2Config":
+        """Nested update from ``-c key.sub=value`` overrides (shared_types.py:90-121): merged into the dumped config, rebuilt."""
+        def merge(a, b):
+            out = dict(a)
+            for k, v in b.items():
+                out[k] = merge(out[k], v) if isinstance(v, dict) and isinstance(out.get(k), dict) else v
+            return out
+
+        self.__init__(**merge(self.model_dump(), new_config))
+        return self
+
     def model_checkpoint_dump(self) -> dict:
-        return json.loads(json.dumps({"VERSION": self.VERSION, "model": asdict(self.model), "training": asdict(self.training)}, default=str))
+        """JSON-only and path-free (tests/test_model.py:85-151)."""
+        return json.loads(json.dumps({"VERSION": self.VERSION, "model": asdict(self.model), "training": self.training.json_dict(),
+                                      "symbols": list(self.symbols) if self.symbols is not None else None}, default=str))
 
 
 class FastSpeech2(_Module):
@@ -265,6 +332,13 @@ class FastSpeech2(_Module):
         if self.trainer_ is not None:
             self.trainer_.training = self.config.training
 
+    def restart_optimizers(self):
+        tr = self.trainer_
+        tr.params.m.zero_()
+        tr.params.v.zero_()
+        tr.params.step = 0
+        tr.global_step = 0
+
     def configure_optimizers(self):
         o = self.config.training.optimizer
         return [{"name": "adamw", "schedule": "noam", **asdict(o)}]
@@ -278,16 +352,9 @@ class FastSpeech2(_Module):
         return out
 
     def validation_step(self, batch: dict, batch_idx: int = 0):
-        """The training losses on a validation batch without an update (``validation/mel_loss`` is the monitored one)."""
-        tr = self.trainer_
-        from .train import ops
-
-        prev = ops.CONV_BACKEND["operands"]
-        ops.CONV_BACKEND["operands"] = tr.precision
-        try:
-            losses = {k: float(v) for k, v in tr.forward_backward(batch).items()}
-        finally:
-            ops.CONV_BACKEND["operands"] = prev
+        """The losses of a validation batch in evaluation mode, as the reference's loop runs them under ``model.eval()``: dropout
+        off, BatchNorm on its running statistics (not updated), no backward (``validation/mel_loss`` is the monitored one)."""
+        losses = {k: float(v) for k, v in self.trainer_.evaluate(batch).items()}
         self.log_dict({f"validation/{k}_loss": v for k, v in losses.items()})
         return losses.get("mel", losses.get("total"))
 
@@ -319,12 +386,7 @@ class FastSpeech2(_Module):
             hp = ckpt["hyper_parameters"]
             c = hp["config"]
             model_cfg = FastSpeech2ModelConfig.from_dict(c["model"]) if hasattr(FastSpeech2ModelConfig, "from_dict") else _dataclass_from_dict(FastSpeech2ModelConfig, c["model"])
-            tr_d = dict(c.get("training", {}))
-            if "optimizer" in tr_d:
-                od = dict(tr_d["optimizer"])
-                od["betas"] = tuple(od.get("betas", (0.9, 0.999)))
-                tr_d["optimizer"] = NoamOptimizerConfig(**od)
-            config = FastSpeech2Config(model=model_cfg, training=FastSpeech2TrainingConfig(**tr_d))
+            config = FastSpeech2Config(model=model_cfg, training=FastSpeech2TrainingConfig(**dict(c.get("training", {}))), symbols=c.get("symbols"))
             st = hp.get("stats")
             stats = Stats(pitch=StatsInfo(**st["pitch"]), energy=StatsInfo(**st["energy"])) if st else None
         except (KeyError, TypeError, ValueError) as e:
@@ -382,14 +444,20 @@ def load_config_base_command(model_config, config_args: list[str], config_file: 
 
 
 def save_configuration_to_log_dir(config) -> Path:
-    """<save_dir>/<name>/<version>/<sub_dir>/hparams.yaml with the JSON form of the config (helpers.py:150-170)."""
+    """<save_dir>/<name>/<version>/<sub_dir>/hparams.yaml with the JSON form of the config (helpers.py:150-170).  Under
+    ``--devices N`` every rank must agree on <sub_dir> (a timestamp): the parent takes it once and hands it to its children
+    (EVMI_LOG_SUB_DIR); only rank 0 writes the file."""
     lg = config.training.logger
+    sub = os.environ.get("EVMI_LOG_SUB_DIR")
+    if sub:
+        object.__setattr__(lg, "_sub_dir", sub)
     log_dir = Path(lg.save_dir) / lg.name / lg.version / lg.sub_dir
     log_dir.mkdir(parents=True, exist_ok=True)
-    import yaml
+    if int(os.environ.get("RANK", "0")) == 0:
+        import yaml
 
-    with (log_dir / "hparams.yaml").open("w", encoding="UTF-8") as f:
-        yaml.dump(json.loads(json.dumps(config.model_dump(mode="json") if hasattr(config, "model_dump") else config.model_checkpoint_dump())), stream=f)
+        with (log_dir / "hparams.yaml").open("w", encoding="UTF-8") as f:
+            yaml.dump(json.loads(json.dumps(config.model_dump(mode="json") if hasattr(config, "model_dump") else config.model_checkpoint_dump())), stream=f)
     return log_dir
 
 
@@ -457,10 +525,22 @@ def fit(model_obj, data, config, monitor: str, log_dir: Path, gradient_clip_val=
     vci = t.val_check_interval
     val_every_steps = vci if isinstance(vci, int) and not isinstance(vci, bool) else (max(1, int(steps_per_epoch * vci)) if vci else None)
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
     def validate():
-        vals = [model_obj.validation_step(b, i) for i, b in enumerate(val_loader)]
+        # every rank takes the validation batches i = rank (mod world); the monitored value is the mean over all of them
+        # (Lightning: a DistributedSampler on the validation loader + sync_dist logging), so every rank ranks checkpoints alike
+        vals = [model_obj.validation_step(b, i) for i, b in enumerate(val_loader) if i % world == rank]
         vals = [v for v in vals if v is not None]
-        value = sum(vals) / len(vals) if vals else float("nan")
+        tot, cnt = float(sum(vals)), float(len(vals))
+        if world > 1:
+            import torch.distributed as dist
+
+            dev = getattr(model_obj, "device", torch.device("cpu"))
+            acc = torch.tensor([tot, cnt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(acc)
+            tot, cnt = float(acc[0]), float(acc[1])
+        value = tot / cnt if cnt else float("nan")
         model_obj.log(monitor, value)
         note("validate", model_obj.global_step, value)
         if rank == 0:
@@ -489,6 +569,8 @@ def fit(model_obj, data, config, monitor: str, log_dir: Path, gradient_clip_val=
             if t.max_steps and t.max_steps > 0 and step >= t.max_steps:
                 done = True
                 break
+        if not done:
+            model_obj.current_epoch = epoch + 1  # the epoch is complete: a checkpoint written now resumes with the next one
         if t.check_val_every_n_epoch and (epoch + 1) % t.check_val_every_n_epoch == 0:
             validate()
         if t.ckpt_epochs and (epoch + 1) % t.ckpt_epochs == 0:
@@ -508,7 +590,7 @@ def train_base_command(model_config, data_module, model, monitor: str, config_ar
     model_kwargs = dict(model_kwargs or {})
     n_dev = _resolve_devices(devices)
     if n_dev > 1 and "WORLD_SIZE" not in os.environ:
-        return _launch_ranks(n_dev, model_config, data_module, model, monitor, config_args, config_file, gradient_clip_val)
+        return _launch_ranks(n_dev, model_config, data_module, model, monitor, config_args, config_file, gradient_clip_val, accelerator, model_kwargs)
     config = load_config_base_command(model_config, config_args, Path(config_file))
     log_dir = save_configuration_to_log_dir(config)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -518,8 +600,12 @@ def train_base_command(model_config, data_module, model, monitor: str, config_ar
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if not dist.is_initialized():
-            torch.cuda.set_device(device)
-            dist.init_process_group("nccl", device_id=device)
+            if device.type == "cuda":
+                torch.cuda.set_device(device)
+            if device.type == "cuda":
+                dist.init_process_group("nccl", device_id=device)
+            else:
+                dist.init_process_group("gloo")
         model_kwargs.setdefault("process_group", True)
     try:
         data = data_module(config, rank=rank, world=world)
@@ -549,6 +635,8 @@ def train_base_command(model_config, data_module, model, monitor: str, config_ar
             model_obj._restore_optimizers = False
             if model_obj._pending_ckpt is not None:
                 model_obj._pending_ckpt = {**model_obj._pending_ckpt, "global_step": 0, "epoch": 0, "optimizer_states": []}
+            if getattr(model_obj, "trainer_", None) is not None and hasattr(model_obj, "restart_optimizers"):
+                model_obj.restart_optimizers()  # load_from_checkpoint(device=...) already built the trainer and restored its moments
             model_obj.current_epoch = 0
         else:
             resume = {"epoch": model_obj.current_epoch}
@@ -575,36 +663,52 @@ def _resolve_devices(devices) -> int:
     return int(devices)
 
 
-def _launch_ranks(n, model_config, data_module, model, monitor, config_args, config_file, gradient_clip_val) -> int:
+def _launch_ranks(n, model_config, data_module, model, monitor, config_args, config_file, gradient_clip_val, accelerator="auto", model_kwargs=None) -> int:
     """``--devices N --strategy ddp``: one process per GPU over RCCL, each running this same command (never exec: the parent
-    has not touched the GPU and stays alive to return the children's exit code)."""
+    has not touched the GPU and stays alive to return the children's exit code).  What the children need travels as one JSON
+    document: the three classes by qualified name, the config arguments, the accelerator and the model keyword arguments
+    (JSON values only: a process group or a device cannot cross a process boundary and is refused)."""
     import socket
     import subprocess
+    import time
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("EVMI_LOG_SUB_DIR", time.strftime("%Y-%m-%d-%H-%M-%S"))  # one log directory for all ranks
+    kwargs = dict(model_kwargs or {})
+    try:
+        json.dumps(kwargs)
+    except TypeError as e:
+        raise TypeError(f"model_kwargs must be JSON values to reach the ranks started by --devices {n}: {e}") from e
     spec = {"model_config": f"{model_config.__module__}:{model_config.__qualname__}", "data_module": f"{data_module.__module__}:{data_module.__qualname__}",
             "model": f"{model.__module__}:{model.__qualname__}", "monitor": monitor, "config_args": list(config_args or []), "config_file": str(config_file),
-            "gradient_clip_val": gradient_clip_val}
+            "gradient_clip_val": gradient_clip_val, "accelerator": accelerator, "model_kwargs": kwargs}
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            "-m", "everyvoice_amd.lightning", json.dumps(spec)]
     return subprocess.run(cmd, env=env).returncode
 
 
-def _main(argv):
+def _resolve_class(spec: str):
+    """"module:Outer.Inner" -> the class (qualified names of nested classes are walked attribute by attribute)."""
     import importlib
 
+    mod, _, qual = spec.partition(":")
+    obj = importlib.import_module(mod)
+    for part in qual.split("."):
+        if part == "<locals>":
+            raise ValueError(f"{spec}: a class defined inside a function cannot be found by the ranks of --devices N; define it at module level")
+        obj = getattr(obj, part)
+    return obj
+
+
+def _main(argv):
     spec = json.loads(argv[0])
-
-    def resolve(s):
-        mod, _, name = s.partition(":")
-        return getattr(importlib.import_module(mod), name)
-
-    train_base_command(resolve(spec["model_config"]), resolve(spec["data_module"]), resolve(spec["model"]), spec["monitor"], spec["config_args"],
-                       Path(spec["config_file"]), devices="auto", gradient_clip_val=spec["gradient_clip_val"])
+    train_base_command(_resolve_class(spec["model_config"]), _resolve_class(spec["data_module"]), _resolve_class(spec["model"]), spec["monitor"],
+                       spec["config_args"], Path(spec["config_file"]), accelerator=spec.get("accelerator", "auto"), devices="auto",
+                       gradient_clip_val=spec["gradient_clip_val"], model_kwargs=spec.get("model_kwargs") or {})
     return 0
 
 

@@ -272,6 +272,7 @@ class GpuPreprocessor:
         self.transform = MelSpectrogram(self.cfg.n_fft, self.cfg.fft_window_size, self.cfg.fft_hop_size,
                                         self.cfg.input_sampling_rate, self.cfg.n_mels, self.cfg.f_min, self.cfg.f_max)
         self.counters: dict[str, int] = {}
+        self._interp = None
 
     def features(self, audio: torch.Tensor):
         """audio [S] (host or device) -> (log-mel [n_mels, S // hop], energy [S // hop]) on the device."""
@@ -343,6 +344,7 @@ class GpuPreprocessor:
                 save_wav(x_host[j, :n], feature_path(save_dir, "audio", *ids, f"audio-{sr_tag}.wav"), sr_tag, self.cfg.target_bit_depth)
                 save_tensor(mel_host[j, :, :frames].clone(), feature_path(save_dir, "spec", *ids, spec_fn))
                 save_tensor(energy_host[j, :frames].clone(), feature_path(save_dir, "energy", *ids, "energy.pt"))
+                self.process_attn_prior(it, frames, save_dir, overwrite)  # (the reference's stage order: ... spec, attn, energy, pitch)
                 if pitch_host is not None:
                     save_tensor(pitch_host[j, :frames].clone(), feature_path(save_dir, "pitch", *ids, "pitch.pt"))
                 self.counters["processed_files"] = self.counters.get("processed_files", 0) + 1
@@ -360,6 +362,48 @@ class GpuPreprocessor:
             flush(sr)
         self.save_config_lock(save_dir, in_progress=False)
         return kept
+
+    def process_attn_prior(self, item: dict, frames: int, save_dir, overwrite: bool = False) -> list[Path]:
+        """The ``attn`` stage (preprocessor.py:672-740): one beta-binomial prior [frames, tokens] (float64, computed on the device
+        by evmi_attention_prior_f64) per text representation the item carries -- ``attn/<...>--characters-attn-prior.pt`` for
+        ``character_tokens``, ``...--phones-attn-prior.pt`` for ``phone_tokens`` ("/"-joined token strings, as the reference's text
+        stage writes them into the filelist; a list of tokens is accepted too).  Existing files are kept unless ``overwrite``."""
+        from .heavy import BetaBinomialInterpolator
+
+        written = []
+        ids = (item["basename"], item.get("speaker", "default"), item.get("language", "default"))
+        for key, name in (("character_tokens", "characters"), ("phone_tokens", "phones")):
+            toks = item.get(key)
+            if not toks:  # None in datasets of the other representation, "" in multi-source datasets
+                continue
+            n_tok = len(toks.split("/")) if isinstance(toks, str) else len(toks)
+            path = feature_path(save_dir, "attn", *ids, f"{name}-attn-prior.pt")
+            if path.exists() and not overwrite:
+                continue
+            if self._interp is None:
+                self._interp = BetaBinomialInterpolator(device=self.device)
+            prior = self._interp(frames, n_tok)
+            assert tuple(prior.shape) == (frames, n_tok)
+            save_tensor(prior, path)
+            written.append(path)
+            if len(self._interp._cache) > 256:
+                self._interp._cache.clear()
+        return written
+
+    @staticmethod
+    def write_filelist(items: list[dict], path, fields=("basename", "speaker", "language", "characters", "character_tokens", "phone_tokens")) -> Path:
+        """The processed filelist (``<save_dir>/<name>.psv``, preprocessor.py:1113-1180: text lives in the filelist, not on disk):
+        pipe-separated with a header line, the columns the items actually carry."""
+        path = Path(path)
+        path.parent.mkdir(parents=True, exist_ok=True)
+        cols = [f for f in fields if any(it.get(f) not in (None, "") for it in items)] or ["basename"]
+        with open(path, "w", encoding="utf8", newline="") as f:
+            f.write("|".join(cols) + "\n")
+            for it in items:
+                vals = [it.get(c, "") for c in cols]
+                vals = ["/".join(v) if isinstance(v, (list, tuple)) else ("" if v is None else str(v)) for v in vals]
+                f.write("|".join(v.replace("\\", "\\\\").replace("|", "\\|") for v in vals) + "\n")
+        return path
 
     # -- dataset statistics (preprocessor.py:378-490) -------------------------------------------------------------------
     def compute_stats(self, save_dir, energy: bool = True, pitch: bool = True):

@@ -45,6 +45,8 @@ class NoamOptimizerConfig:
 
 @dataclass
 class FastSpeech2TrainingConfig:
+    """``FastSpeech2TrainingConfig`` (everyvoice/.schema/everyvoice-text-to-spec-0.5.json:499-551) over the driver-side fields of
+    ``BaseTrainingConfig`` (everyvoice/config/shared_types.py:180-258: what ``train_base_command`` reads, helpers.py:234-259)."""
     batch_size: int = 16
     optimizer: NoamOptimizerConfig = field(default_factory=NoamOptimizerConfig)
     mel_loss_weight: float = 1.0
@@ -56,6 +58,59 @@ class FastSpeech2TrainingConfig:
     attn_bin_loss_weight: float = 0.1
     attn_bin_loss_warmup_epochs: int = 100
     gradient_clip_val: float | None = 1.0
+    # -- BaseTrainingConfig --
+    save_top_k_ckpts: int = 5
+    ckpt_steps: int | None = None
+    ckpt_epochs: int | None = 1
+    val_check_interval: int | float | None = 500
+    check_val_every_n_epoch: int | None = None
+    max_epochs: int = 1000
+    max_steps: int = 100000
+    finetune_checkpoint: object = None   # Path | None
+    training_filelist: object = "path/to/your/preprocessed/training_filelist.psv"
+    validation_filelist: object = "path/to/your/preprocessed/validation_filelist.psv"
+    filelist_loader: str = "everyvoice.utils.generic_psv_filelist_reader"
+    logger: object = None                # config.LoggerConfig
+    val_data_workers: int = 0
+    train_data_workers: int = 4
+    use_weighted_sampler: bool = False
+
+    def __post_init__(self):
+        from pathlib import Path
+
+        from ..config import LoggerConfig
+
+        if isinstance(self.optimizer, dict):
+            od = dict(self.optimizer)
+            od["betas"] = tuple(od.get("betas", (0.9, 0.999)))
+            self.optimizer = NoamOptimizerConfig(**od)
+        if self.logger is None or isinstance(self.logger, dict):
+            self.logger = LoggerConfig(**(self.logger or {}))
+        if self.ckpt_epochs is not None and self.ckpt_steps is not None:
+            raise ValueError("ckpt_epochs and ckpt_steps have to be mutually exclusive")
+        for name in ("finetune_checkpoint", "training_filelist", "validation_filelist"):
+            v = getattr(self, name)
+            if v is not None and not isinstance(v, Path):
+                setattr(self, name, Path(v))
+
+    def json_dict(self, paths: bool = False) -> dict:
+        """JSON-only form; ``paths=False`` drops every path-valued field and the logger (checkpoints travel between machines:
+        shared_types.py:56-88, tests/test_model.py:85-151)."""
+        from pathlib import Path
+
+        out = {}
+        for k, v in self.__dict__.items():
+            if k == "logger":
+                if paths:
+                    out[k] = v.model_dump(mode="json")
+            elif isinstance(v, Path):
+                if paths:
+                    out[k] = str(v)
+            elif k == "optimizer":
+                out[k] = {**asdict(v), "betas": list(v.betas)}
+            else:
+                out[k] = v
+        return out
 
 
 def _s(t):
@@ -133,6 +188,9 @@ class Table:
 
 
 # ---- tape operators ---------------------------------------------------------------------------------------------------
+_EVAL = [False]  # FastSpeech2Trainer.evaluate: dropout off, BatchNorm on its running statistics (and not updating them)
+
+
 def dense(tape: Tape, x: Var, layer, act=ops.ACT_NONE) -> Var:
     """conv1d / Linear (+ ReLU or tanh in the epilogue: their backward only needs the output)."""
     assert act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_TANH)
@@ -175,6 +233,8 @@ def layernorm(tape: Tape, x: Var, ln: Affine) -> Var:
 
 
 def batchnorm(tape: Tape, x: Var, bn: Affine, act=ops.ACT_NONE) -> Var:
+    if _EVAL[0]:
+        return Var(ops.batchnorm_fwd(x.data, bn.gamma(), bn.beta(), bn.running_mean, bn.running_var, act, momentum=-1.0)[0])
     out, mean, rstd = ops.batchnorm_fwd(x.data, bn.gamma(), bn.beta(), bn.running_mean, bn.running_var, act)
     bn.batches += 1
     y = Var(out)
@@ -302,7 +362,7 @@ class _ConformerT:
         return [L["bn"] for L in self.layers]
 
     def forward(self, tape: Tape, x: Var, lens32, seeds) -> Var:
-        p = self.cfg.dropout
+        p = 0.0 if _EVAL[0] else self.cfg.dropout
         for L in self.layers:
             x = self._ffn_fwd(tape, x, L["ffn1"], p, seeds)
             h = dense(tape, layernorm(tape, x, L["attn_ln"]), L["in_proj"])
@@ -342,7 +402,7 @@ class _VariancePredictorT:
         """x [D, B, L] -> [1, B, L], zero at the padded positions."""
         for conv, ln in self.layers:
             h = dense(tape, dwconv(tape, x, conv[0]), conv[1], ops.ACT_RELU) if self.cfg.depthwise else dense(tape, x, conv[0], ops.ACT_RELU)
-            x = dropout(tape, layernorm(tape, h, ln), self.cfg.dropout, seeds())
+            x = dropout(tape, layernorm(tape, h, ln), 0.0 if _EVAL[0] else self.cfg.dropout, seeds())
         return masked(tape, dense(tape, x, self.linear), lens32)
 
 
@@ -541,7 +601,7 @@ class FastSpeech2Trainer:
         return {"state_dict": {k: v.cpu() for k, v in self.state_dict().items()},
                 "optimizer_states": [{"m": g.m.cpu(), "v": g.v.cpu(), "step": g.step}],
                 "global_step": self.global_step,
-                "hyper_parameters": {"config": asdict(self.config), "stats": asdict(self.stats), "training": asdict(self.training),
+                "hyper_parameters": {"config": asdict(self.config), "stats": asdict(self.stats), "training": self.training.json_dict(),
                                      "lang2id": dict(self.lang2id), "speaker2id": dict(self.speaker2id)},
                 "model_info": {"name": "FastSpeech2", "version": self._VERSION}}
 
@@ -591,7 +651,8 @@ class FastSpeech2Trainer:
         n_frames = float(mel_lens_host.sum())
         mel_t = batch["mel"].to(dev, torch.float32)[:, :T].permute(2, 0, 1).contiguous()  # [n_mels, B, T]
 
-        self.params.zero_grad()
+        if not _EVAL[0]:
+            self.params.zero_grad()
         for cv in self._wn:
             cv.materialize()
         tape = Tape()
@@ -695,14 +756,30 @@ class FastSpeech2Trainer:
                 h = batchnorm(tape, dense(tape, h, conv), bn, ops.ACT_TANH if i < len(self.postnet) - 1 else ops.ACT_NONE)
             post = masked(tape, residual(tape, mel, h), mel_lens)
             losses["postnet"] = mse_loss(tape, post, mel_t, n_el, tr.postnet_loss_weight)
-        tape.backward()
-        for cv in self._wn:
-            cv.finish_grads()
+        if _EVAL[0]:
+            ops.wgrad_join(dev)
+        else:
+            tape.backward()
+            for cv in self._wn:
+                cv.finish_grads()
         total = torch.zeros(1, device=dev)
         for v in losses.values():
             ops.axpby(1.0, total, 1.0, v, out=total)
         losses["total"] = total
         return losses
+
+    def evaluate(self, batch: dict) -> dict:
+        """The losses of a batch in evaluation mode (the reference validates under ``model.eval()``): dropout off, BatchNorm
+        normalising with its running statistics and leaving them (and ``num_batches_tracked``) untouched, no backward, no
+        gradients written, no optimiser state touched."""
+        prev = ops.CONV_BACKEND["operands"]
+        ops.CONV_BACKEND["operands"] = self.precision
+        _EVAL[0] = True
+        try:
+            return self.forward_backward(batch)
+        finally:
+            _EVAL[0] = False
+            ops.CONV_BACKEND["operands"] = prev
 
     def _phone_level(self, batch, key, cum, dur, pad, T):
         """Phone-level variance targets [B, L]: given as such (``pitch``), or frame-level (``pitch_frames`` [B, T]) averaged over

@@ -705,6 +705,7 @@ def batchnorm_fwd(x, gamma, beta, running_mean, running_var, act=ACT_NONE, eps=1
     y = torch.empty_like(x)
     mean = torch.empty(C, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
+    # momentum < 0: evaluation mode (running statistics normalise and stay as they are)
     _chk(_lib.load().evmi_batchnorm_fwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                 _lib.ptr(running_mean), _lib.ptr(running_var), C, N, eps, momentum, act, _s(x)), "evmi_batchnorm_fwd_cbt_f32")
     return y, mean, rstd

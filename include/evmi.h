@@ -525,7 +525,9 @@ int evmi_layernorm_bwd_cbt_f32(const float* x_dev, const float* gamma_dev, const
                                float* dgamma_dev, float* dbeta_dev, float* ws_dev, long long ws_elems, int C,
                                long long n_cols, float eps, int accumulate_dx, void* stream);
 /* BatchNorm1d in training mode over every column of a channel row, followed by act (0 none, 2 SiLU, 4 tanh):
- * writes the batch mean / 1/sqrt(var + eps) [C] and, when given, updates the running statistics (unbiased variance). */
+ * writes the batch mean / 1/sqrt(var + eps) [C] and, when given, updates the running statistics (unbiased variance).
+ * momentum < 0: evaluation mode (model.eval() in the reference's validation loop) -- the running statistics normalise and are
+ * not updated. */
 int evmi_batchnorm_fwd_cbt_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev,
                                float* mean_dev, float* rstd_dev, float* running_mean_dev, float* running_var_dev,
                                int C, long long n_cols, float eps, float momentum, int act, void* stream);
