@@ -134,22 +134,22 @@ SYMBOLS = {
     "evmi_batchnorm_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
     "evmi_dwconv1d_bwd_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 3),
     "evmi_dwconv1d_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_longlong] + [C.c_int] * 5 + [C.c_void_p]),
-    "evmi_mha_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
-    "evmi_mha_fwd_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
-    "evmi_mha_bwd_bf16": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
-    "evmi_mha_bwd_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p]),
+    "evmi_mha_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
+    "evmi_mha_fwd_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
+    "evmi_mha_bwd_bf16": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
+    "evmi_mha_bwd_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
     "evmi_softmax_rows_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_softmax_bwd_rows_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_ulonglong, C.c_void_p]),
     "evmi_glu_bwd_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p]),
-    "evmi_dropout_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_float, C.c_ulonglong, C.c_void_p]),
-    "evmi_dropout_fused_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 3 + [C.c_longlong, C.c_float, C.c_ulonglong, C.c_float, C.c_void_p]),
+    "evmi_dropout_f32": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
+    "evmi_dropout_fused_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 3 + [C.c_longlong, C.c_float, C.c_ulonglong, C.c_void_p, C.c_float, C.c_void_p]),
     "evmi_fs2_embed_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]),
     "evmi_fs2_bucket_embed_bwd_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
     "evmi_fs2_item_embedding_bwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_length_regulate_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_forward_sum_grad_f32_ws_elems": (C.c_longlong, [C.c_int] * 3),
     "evmi_forward_sum_grad_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_longlong] + [C.c_int] * 3 + [C.c_float, C.c_float, C.c_void_p]),
-    "evmi_align_attention_bwd_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_float, C.c_void_p]),
+    "evmi_align_attention_bwd_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_float, C.c_void_p, C.c_void_p]),
     "evmi_align_qk_grad_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
     "evmi_dgrad_weights_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
     "evmi_gemm_batched_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
@@ -166,6 +166,9 @@ SYMBOLS = {
     "evmi_weight_norm_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
     "evmi_weight_norm_bwd_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "evmi_normalize_vec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "evmi_optimizer_step_lrdev_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_longlong, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_float, C.c_void_p]),
+    "evmi_store_f32": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
+    "evmi_store_u64": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_void_p]),
     "evmi_optimizer_step_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_longlong] + [C.c_float] * 5 + [C.c_int, C.c_void_p, C.c_float, C.c_void_p]),
     "evmi_comm_unique_id": (C.c_int, [C.c_void_p]),
     "evmi_comm_init_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int]),
@@ -220,8 +223,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.evmi_abi_version() != 1:
-        raise ImportError(f"{path}: ABI version {lib.evmi_abi_version()} != 1")
+    if lib.evmi_abi_version() != 2:
+        raise ImportError(f"{path}: ABI version {lib.evmi_abi_version()} != 2")
     _lib = lib
     return lib
 

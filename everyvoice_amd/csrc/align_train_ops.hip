@@ -159,8 +159,9 @@ __global__ __launch_bounds__(256) void align_attention_bwd_kernel(const float* _
                                                                  const double* __restrict__ prior, const int* __restrict__ hard,
                                                                  const float* __restrict__ dlogprob, const int* __restrict__ text_lens,
                                                                  float* __restrict__ da, float* __restrict__ rowsum, int T, int L,
-                                                                 float bin_scale) {
+                                                                 float bin_scale, const float* __restrict__ bin_count) {
   __shared__ float red[4];
+  if (bin_count) bin_scale /= *bin_count;  // weight / (number of hard cells), the count left on the device
   const int b = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
   const long long row = ((long long)b * T + t) * L;
   const int len = min(text_lens[b], L);
@@ -256,12 +257,12 @@ int evmi_forward_sum_grad_f32(const float* logprob, const int* text_lens, const 
 
 int evmi_align_attention_bwd_f32(const float* soft, const float* logprob, const double* prior, const int* hard, const float* dlogprob,
                                  const int* text_lens, float* da, float* rowsum, float* colsum, int B, int T, int L, float bin_scale,
-                                 void* stream) {
+                                 const float* bin_count_dev, void* stream) {
   if (!soft || !logprob || !text_lens || !da || !rowsum || !colsum) return fail(EVMI_ERR_INVALID_ARG, "align_attention_bwd: null pointer");
   if (B <= 0 || T <= 0 || L <= 0 || B > 65535) return fail(EVMI_ERR_INVALID_ARG, "align_attention_bwd: shape");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(align_attention_bwd_kernel, dim3(T, B), dim3(256), 0, s, soft, logprob, prior, hard, dlogprob, text_lens, da, rowsum, T, L,
-                     bin_scale);
+                     bin_scale, bin_count_dev);
   EVMI_LAUNCH_CHECK("align_attention_bwd");
   hipLaunchKernelGGL(align_colsum_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, da, colsum, B, T, L);
   EVMI_LAUNCH_CHECK("align_colsum");

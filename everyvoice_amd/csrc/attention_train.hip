@@ -72,7 +72,8 @@ struct SwzOffsets {
 template <int DH>
 __global__ __launch_bounds__(256) void attention_train_fwd_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                  float* __restrict__ out, float* __restrict__ lse, int B, int T, int D,
-                                                                 float scale, float p_drop, unsigned long long seed) {
+                                                                 float scale, float p_drop, SeedArg seed_arg) {
+  const unsigned long long seed = seed_arg.get();
   extern __shared__ __attribute__((aligned(16))) float atf_lds[];
   float* Kb = atf_lds;                 // [2 generations][DH][32], swizzled
   float* Vb = atf_lds + 2 * DH * 32;
@@ -173,7 +174,8 @@ template <int DH>
 __global__ __launch_bounds__(256) void attention_train_dq_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                 const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                 const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
-                                                                int D, float scale, float p_drop, unsigned long long seed) {
+                                                                int D, float scale, float p_drop, SeedArg seed_arg) {
+  const unsigned long long seed = seed_arg.get();
   extern __shared__ __attribute__((aligned(16))) float atf_lds[];
   float* Kb = atf_lds;                 // [2 generations][DH][32], swizzled
   float* Vb = atf_lds + 2 * DH * 32;
@@ -253,7 +255,8 @@ template <int DH>
 __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                  const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                  const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
-                                                                 int D, float scale, float p_drop, unsigned long long seed) {
+                                                                 int D, float scale, float p_drop, SeedArg seed_arg) {
+  const unsigned long long seed = seed_arg.get();
   extern __shared__ __attribute__((aligned(16))) float atf_lds[];
   float* Qb = atf_lds;                 // [2 generations][DH][32], swizzled
   float* Ob = atf_lds + 2 * DH * 32;
@@ -398,7 +401,8 @@ __device__ __forceinline__ bf16x8 load_pos_slots(const bf16_t* __restrict__ row,
 template <int DH, bool DROP>
 __global__ __launch_bounds__(256, 2) void attention_train_fwd_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                       float* __restrict__ out, float* __restrict__ lse, int B, int T, int D,
-                                                                      float scale, float p_drop, unsigned long long seed) {
+                                                                      float scale, float p_drop, SeedArg seed_arg) {
+  const unsigned long long seed = seed_arg.get();
   constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * LP];   // [key][channel]
   __shared__ __attribute__((aligned(16))) bf16_t Vs[DH * LC];   // [channel][key]
@@ -490,7 +494,8 @@ template <int DH, bool DROP>
 __global__ __launch_bounds__(256, 2) void attention_train_dq_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                      const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                      const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
-                                                                     int D, float scale, float p_drop, unsigned long long seed) {
+                                                                     int D, float scale, float p_drop, SeedArg seed_arg) {
+  const unsigned long long seed = seed_arg.get();
   constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * LP];   // [key][channel]: S^T = K Q^T
   __shared__ __attribute__((aligned(16))) bf16_t Kt[DH * LC];   // [channel][key]: dQ^T += K^T dS^T
@@ -582,7 +587,8 @@ template <int DH, bool DROP>
 __global__ __launch_bounds__(256, 2) void attention_train_dkv_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                       const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                       const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
-                                                                      int D, float scale, float p_drop, unsigned long long seed) {
+                                                                      int D, float scale, float p_drop, SeedArg seed_arg) {
+  const unsigned long long seed = seed_arg.get();
   constexpr int LP = DH + ATB_PD, LC = 32 + ATB_PD;
   extern __shared__ __attribute__((aligned(16))) unsigned char at_dyn_lds[];
   bf16_t* Qs = reinterpret_cast<bf16_t*>(at_dyn_lds);  // [query][channel]
@@ -693,9 +699,9 @@ int launch_mha_fwd_bf16_plain(const float* qkv, const int* lens, float* out, flo
   const int dh = D / heads;
   const float scale = 1.f / sqrtf((float)dh);
   const dim3 grid((T + 127) / 128, heads, B);
-  if (dh == 128) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<128, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, 0ull);
-  else if (dh == 64) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<64, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, 0ull);
-  else if (dh == 32) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<32, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, 0ull);
+  if (dh == 128) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<128, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, SeedArg{0ull, nullptr});
+  else if (dh == 64) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<64, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, SeedArg{0ull, nullptr});
+  else if (dh == 32) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<32, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, SeedArg{0ull, nullptr});
   else return 1;
   return 0;
 }
@@ -707,7 +713,8 @@ using namespace evmi;
 extern "C" {
 
 int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
-                     float p_drop, unsigned long long seed, void* stream) {
+                     float p_drop, unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream) {
+  const SeedArg seed{seed_value, seed_base_dev};
   if (!qkv_dev || !lens_dev || !out_dev || !lse_dev) return fail(EVMI_ERR_INVALID_ARG, "mha_fwd: null pointer");
   if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads || p_drop < 0.f || p_drop >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "mha_fwd: shape / dropout");
   if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "mha_fwd: grid limits");
@@ -738,7 +745,8 @@ int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, 
 }
 
 int evmi_mha_fwd_bf16(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
-                      float p_drop, unsigned long long seed, void* stream) {
+                      float p_drop, unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream) {
+  const SeedArg seed{seed_value, seed_base_dev};
   if (!qkv_dev || !lens_dev || !out_dev || !lse_dev) return fail(EVMI_ERR_INVALID_ARG, "mha_fwd_bf16: null pointer");
   if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads || p_drop < 0.f || p_drop >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "mha_fwd_bf16: shape / dropout");
   if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "mha_fwd_bf16: grid limits");
@@ -765,8 +773,9 @@ int evmi_mha_fwd_bf16(const float* qkv_dev, const int* lens_dev, float* out_dev,
 }
 
 int evmi_mha_bwd_bf16(const float* qkv_dev, const int* lens_dev, const float* out_dev, const float* dout_dev, const float* lse_dev,
-                      float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop, unsigned long long seed,
+                      float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop, unsigned long long seed_value, const unsigned long long* seed_base_dev,
                       void* stream) {
+  const SeedArg seed{seed_value, seed_base_dev};
   if (!qkv_dev || !lens_dev || !out_dev || !dout_dev || !lse_dev || !dsum_dev || !dqkv_dev) return fail(EVMI_ERR_INVALID_ARG, "mha_bwd_bf16: null pointer");
   if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads || p_drop < 0.f || p_drop >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "mha_bwd_bf16: shape / dropout");
   if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "mha_bwd_bf16: grid limits");
@@ -807,8 +816,9 @@ int evmi_mha_bwd_bf16(const float* qkv_dev, const int* lens_dev, const float* ou
 }
 
 int evmi_mha_bwd_f32(const float* qkv_dev, const int* lens_dev, const float* out_dev, const float* dout_dev, const float* lse_dev,
-                     float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop, unsigned long long seed,
+                     float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop, unsigned long long seed_value, const unsigned long long* seed_base_dev,
                      void* stream) {
+  const SeedArg seed{seed_value, seed_base_dev};
   if (!qkv_dev || !lens_dev || !out_dev || !dout_dev || !lse_dev || !dsum_dev || !dqkv_dev) return fail(EVMI_ERR_INVALID_ARG, "mha_bwd: null pointer");
   if (B <= 0 || T <= 0 || D <= 0 || heads <= 0 || D % heads || p_drop < 0.f || p_drop >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "mha_bwd: shape / dropout");
   if (B > 65535 || heads > 65535) return fail(EVMI_ERR_UNSUPPORTED, "mha_bwd: grid limits");

@@ -143,6 +143,16 @@ __device__ __forceinline__ float ordered_sum_strided(const float* __restrict__ p
 }
 
 
+// A dropout seed as the kernels receive it: `value` by value plus an optional device-resident base.  With a base the effective
+// seed is (value + *base) & (2^63 - 1): a step captured into a HIP graph keeps `value` (the draw's index inside the step) and gets
+// a new mask every replay because the host rewrites *base (seed, step, rank) before it -- and an eager step that stores the same
+// base draws bit for bit the same masks.  base == NULL: the seed is `value`, as before.
+struct SeedArg {
+  unsigned long long value;
+  const unsigned long long* base;
+  __device__ __forceinline__ unsigned long long get() const { return base ? ((value + *base) & 0x7FFFFFFFFFFFFFFFull) : value; }
+};
+
 // Counter-based uniform in [0, 1) for dropout masks: element i of the stream `seed`; the backward (and the attention kernels,
 // tile by tile) regenerate the same mask from the same (seed, i).  A keyed two-round 32-bit mix (the multiply / xor-shift rounds of
 // the `lowbias32` integer hash, the second key injected between the rounds so that streams are not shifted or permuted copies of

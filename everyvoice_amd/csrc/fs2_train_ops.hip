@@ -347,7 +347,8 @@ __global__ void glu_bwd_kernel(const float* __restrict__ p, const float* __restr
   dp[n + i] = d * a * s * (1.f - s);
 }
 
-__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float p, unsigned long long seed) {
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float p, SeedArg seed_arg) {
+  const unsigned long long seed = seed_arg.get();
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   y[i] = uniform01(seed, (unsigned long long)i) >= p ? x[i] / (1.f - p) : 0.f;
@@ -358,7 +359,8 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 // drop(v)[i] = keep(seed, i) ? v[i] / (1 - p) : 0, the same stream as dropout_kernel; four elements per thread.
 template <int MODE>
 __global__ __launch_bounds__(256) void dropout_fused_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
-                                                            long long n, float p, unsigned long long seed, float scale) {
+                                                            long long n, float p, SeedArg seed_arg, float scale) {
+  const unsigned long long seed = seed_arg.get();
   const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i0 >= n) return;
   float av[4], bv[4];
@@ -583,8 +585,9 @@ int evmi_glu_bwd_f32(const float* p, const float* dy, float* dp, long long n_hal
   return EVMI_OK;
 }
 
-int evmi_dropout_fused_f32(int mode, const float* a, const float* b, float* y, long long n, float p, unsigned long long seed, float scale,
-                           void* stream) {
+int evmi_dropout_fused_f32(int mode, const float* a, const float* b, float* y, long long n, float p, unsigned long long seed_value,
+                           const unsigned long long* seed_base_dev, float scale, void* stream) {
+  const SeedArg seed{seed_value, seed_base_dev};
   if (!a || !y || n < 1 || p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "dropout_fused: null pointer, empty input or p outside [0, 1)");
   if (mode < 1 || mode > 4 || ((mode == 1 || mode == 3) && !b)) return fail(EVMI_ERR_INVALID_ARG, "dropout_fused: mode 1..4 (1 and 3 take a second operand)");
   if (((uintptr_t)a | (uintptr_t)y | (uintptr_t)b) & 15) return fail(EVMI_ERR_INVALID_ARG, "dropout_fused: operands must be 16-byte aligned");
@@ -598,7 +601,9 @@ int evmi_dropout_fused_f32(int mode, const float* a, const float* b, float* y, l
   return EVMI_OK;
 }
 
-int evmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned long long seed, void* stream) {
+int evmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned long long seed_value, const unsigned long long* seed_base_dev,
+                     void* stream) {
+  const SeedArg seed{seed_value, seed_base_dev};
   if (!x || !y || n < 1 || p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "dropout: null pointer, empty input or p outside [0, 1)");
   hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n, p, seed);
   EVMI_LAUNCH_CHECK("dropout");

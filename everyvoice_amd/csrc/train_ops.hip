@@ -339,6 +339,7 @@ __global__ void row_reduce_final_kernel(const float* __restrict__ part, float* _
 //   20: y = a * min(1, p0 / (sqrt(c[0]) + 1e-6))   (gradient-norm clipping, c[0] = sum of squares on the device)
 //   18: y = a * silu'(b)                    19: y = b > 0 ? a : 0  (ReLU backward from the output)
 //   23: y = p0 (fill)
+//   24: y = p0 * a / c[0]  (device scalar: a count that changes from batch to batch without changing a captured graph)
 //   21: y = a / c[0]  (device scalar)        22: op 17 with p0 / (sqrt(c[0]) sqrt(c[1])) as the first coefficient (device scalars)
 //   16: y = log(a)                          17: y = p0 * (a - b) + p1 * sign(a - b) / a   (d/da of the two STFT-loss terms, a = |Y^|, b = |Y|)
 template <int OP>
@@ -369,6 +370,7 @@ __global__ void ew_kernel(const float* __restrict__ a, const float* __restrict__
   else if (OP == 20) r = a[i] * fminf(1.f, p0 / (sqrtf(c[0]) + 1e-6f));
   else if (OP == 21) r = a[i] / c[0];
   else if (OP == 23) r = p0;
+  else if (OP == 24) r = p0 * a[i] / c[0];
   else if (OP == 22) {  // op 17 with its first coefficient p0 / (||a - b|| ||b||) formed from the squared norms c[0], c[1] on the device
     const float nd = sqrtf(c[0]), ny = sqrtf(c[1]);
     const float k0 = nd > 0.f ? p0 / (nd * ny) : 0.f;
@@ -718,9 +720,10 @@ __device__ __forceinline__ float optimizer_update(int kind, float pv, float gv, 
 // four parameters per thread (16-byte accesses: the update is pure HBM traffic, 7 streams); n4 = n / 4, tail elements scalar
 __global__ void optimizer_step_kernel(int kind, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                       float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps, float wd,
-                                      int step, const int* __restrict__ step_dev, float clip) {
+                                      int step, const int* __restrict__ step_dev, float clip, const float* __restrict__ lr_dev) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n4 = n >> 2;
+  if (lr_dev) lr = *lr_dev;  // a scheduled learning rate the host stored on the device (a captured step replays with the new value)
   const float st = (float)(step_dev ? *step_dev : step);
   const float bc1 = kind == 2 ? 1.f : 1.f - powf(beta1, st), rsq_bc2 = kind == 2 ? 1.f : 1.f / sqrtf(1.f - powf(beta2, st));
   if (i < n4) {
@@ -892,7 +895,7 @@ int evmi_elementwise_f32(int op, const float* a_dev, const float* b_dev, const f
   hipStream_t s = (hipStream_t)stream;
 #define EW(OPN) case OPN: hipLaunchKernelGGL(ew_kernel<OPN>, grid1d(n), dim3(256), 0, s, a_dev, b_dev, c_dev, y_dev, n, p0, p1); break;
   switch (op) {
-    EW(0) EW(1) EW(2) EW(3) EW(4) EW(5) EW(6) EW(7) EW(8) EW(9) EW(10) EW(11) EW(12) EW(13) EW(14) EW(15) EW(16) EW(17) EW(18) EW(19) EW(20) EW(21) EW(22) EW(23)
+    EW(0) EW(1) EW(2) EW(3) EW(4) EW(5) EW(6) EW(7) EW(8) EW(9) EW(10) EW(11) EW(12) EW(13) EW(14) EW(15) EW(16) EW(17) EW(18) EW(19) EW(20) EW(21) EW(22) EW(23) EW(24)
     default: return fail(EVMI_ERR_INVALID_ARG, "elementwise: unknown op");
   }
 #undef EW
@@ -1027,14 +1030,53 @@ int evmi_normalize_vec_f32(const float* x_dev, float* y_dev, int n, float eps, v
   return EVMI_OK;
 }
 
+static int optimizer_step_impl(int kind, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, const int* step_dev, float clip, const float* lr_dev,
+                               void* stream);
+
 int evmi_optimizer_step_f32(int kind, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr, float beta1,
                             float beta2, float eps, float weight_decay, int step, const int* step_dev, float clip, void* stream) {
+  return optimizer_step_impl(kind, p_dev, g_dev, m_dev, v_dev, n, lr, beta1, beta2, eps, weight_decay, step, step_dev, clip, nullptr, stream);
+}
+
+int evmi_optimizer_step_lrdev_f32(int kind, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, const float* lr_dev,
+                                  float beta1, float beta2, float eps, float weight_decay, const int* step_dev, float clip, void* stream) {
+  EVMI_NONNULL(lr_dev && step_dev, "optimizer_step_lrdev");
+  return optimizer_step_impl(kind, p_dev, g_dev, m_dev, v_dev, n, 0.f, beta1, beta2, eps, weight_decay, 0, step_dev, clip, lr_dev, stream);
+}
+
+__global__ void store_f32_kernel(float* dst, int n, float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+  const float v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+  for (int i = 0; i < n; ++i) dst[i] = v[i];
+}
+__global__ void store_u64_kernel(unsigned long long* dst, unsigned long long v) { *dst = v; }
+
+int evmi_store_f32(float* dst_dev, int n, const float* values_host, void* stream) {
+  EVMI_NONNULL(dst_dev && values_host, "store_f32");
+  if (n < 1 || n > 8) return fail(EVMI_ERR_INVALID_ARG, "store_f32: 1..8 values");
+  float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < n; ++i) v[i] = values_host[i];  // copied NOW: they travel in the kernel's argument block, not through host memory later
+  hipLaunchKernelGGL(store_f32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst_dev, n, v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
+  EVMI_LAUNCH_CHECK("store_f32");
+  return EVMI_OK;
+}
+
+int evmi_store_u64(unsigned long long* dst_dev, unsigned long long value, void* stream) {
+  EVMI_NONNULL(dst_dev, "store_u64");
+  hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, dst_dev, value);
+  EVMI_LAUNCH_CHECK("store_u64");
+  return EVMI_OK;
+}
+
+static int optimizer_step_impl(int kind, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, const int* step_dev, float clip, const float* lr_dev,
+                               void* stream) {
   EVMI_NONNULL(p_dev && g_dev && v_dev && (kind == 2 || m_dev), "optimizer_step");
   if (kind < 0 || kind > 2) return fail(EVMI_ERR_INVALID_ARG, "optimizer_step: kind (0 AdamW, 1 Adam, 2 RMSprop)");
   if ((reinterpret_cast<uintptr_t>(p_dev) | reinterpret_cast<uintptr_t>(g_dev) | reinterpret_cast<uintptr_t>(m_dev) | reinterpret_cast<uintptr_t>(v_dev)) & 15)
     return fail(EVMI_ERR_INVALID_ARG, "optimizer_step: buffers must be 16-byte aligned");
   hipLaunchKernelGGL(optimizer_step_kernel, grid1d((n >> 2) + 3), dim3(256), 0, (hipStream_t)stream, kind, p_dev, g_dev, m_dev, v_dev, n, lr, beta1,
-                     beta2, eps, weight_decay, step, step_dev, clip);
+                     beta2, eps, weight_decay, step, step_dev, clip, lr_dev);
   EVMI_LAUNCH_CHECK("optimizer_step");
   return EVMI_OK;
 }

@@ -678,6 +678,10 @@ def _launch_ranks(n, model_config, data_module, model, monitor, config_args, con
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("EVMI_LOG_SUB_DIR", time.strftime("%Y-%m-%d-%H-%M-%S"))  # one log directory for all ranks
+    for cls in (model_config, data_module, model):
+        if "<locals>" in cls.__qualname__:
+            raise ValueError(f"{cls.__module__}:{cls.__qualname__}: a class defined inside a function cannot be found by the ranks of --devices {n}; "
+                             "define it at module level")
     kwargs = dict(model_kwargs or {})
     try:
         json.dumps(kwargs)
@@ -696,10 +700,10 @@ def _resolve_class(spec: str):
     import importlib
 
     mod, _, qual = spec.partition(":")
+    if "<locals>" in qual.split("."):
+        raise ValueError(f"{spec}: a class defined inside a function cannot be found by the ranks of --devices N; define it at module level")
     obj = importlib.import_module(mod)
     for part in qual.split("."):
-        if part == "<locals>":
-            raise ValueError(f"{spec}: a class defined inside a function cannot be found by the ranks of --devices N; define it at module level")
         obj = getattr(obj, part)
     return obj
 

@@ -43,6 +43,13 @@ class Var:
             ops.axpby(1.0, self.grad, 1.0, g, out=self.grad)
 
 
+class _Cut:
+    """A point of the tape where backward may be interrupted (``Tape.backward_segments``); ``join`` runs before the interruption."""
+
+    def __init__(self, join=None):
+        self.join = join
+
+
 class Tape:
     def __init__(self):
         self._ops = []
@@ -50,10 +57,30 @@ class Tape:
     def record(self, fn) -> None:
         self._ops.append(fn)
 
+    def cut(self, join=None) -> None:
+        """Mark this point: ``backward_segments`` stops here (after everything recorded LATER has run its backward).  Used where a
+        gradient bucket becomes final and its all-reduce -- which is not part of a captured HIP graph -- has to be issued."""
+        self._ops.append(_Cut(join))
+
     def backward(self) -> None:
         for fn in reversed(self._ops):
-            fn()
+            if not isinstance(fn, _Cut):
+                fn()
         ops.wgrad_join()  # weight-gradient kernels queued beside this chain (ops.side_wgrad) are part of this backward
+        self._ops.clear()
+
+    def backward_segments(self):
+        """Generator form: every ``next()`` runs the backward up to the next cut (weight-gradient kernels queued beside the chain
+        are joined first, then the cut's own ``join``); the last one runs to the start of the tape."""
+        for fn in reversed(self._ops):
+            if isinstance(fn, _Cut):
+                ops.wgrad_join()
+                if fn.join is not None:
+                    fn.join()
+                yield
+            else:
+                fn()
+        ops.wgrad_join()
         self._ops.clear()
 
 

@@ -320,12 +320,14 @@ def masked(tape: Tape, x: Var, lens32) -> Var:
     return y
 
 
-def mse_loss(tape: Tape, pred: Var, target: torch.Tensor, count: float, weight: float) -> torch.Tensor:
-    """weight * sum((pred - target)^2) / count -> device scalar; both operands are zero outside the valid region."""
+def mse_loss(tape: Tape, pred: Var, target: torch.Tensor, count_dev: torch.Tensor, weight: float) -> torch.Tensor:
+    """weight * sum((pred - target)^2) / count -> device scalar; both operands are zero outside the valid region.  ``count_dev``:
+    the number of valid elements as a DEVICE scalar (it changes from batch to batch; a captured step must not bake it in)."""
     diff = ops.axpby(1.0, pred.data, -1.0, target)
     out = torch.empty(1, device=diff.device, dtype=torch.float32)
-    ops.scalar_reduce(1, diff, None, out, scale=weight / count, p=0.0)
-    tape.record(lambda: pred.accumulate(ops.elementwise(ops.EW_SCALE, diff, p0=2.0 * weight / count)))
+    ops.scalar_reduce(1, diff, None, out, scale=weight, p=0.0)
+    ops.elementwise(ops.EW_SCALE_DIV_SCALAR, out, c=count_dev, out=out, p0=1.0)
+    tape.record(lambda: pred.accumulate(ops.elementwise(ops.EW_SCALE_DIV_SCALAR, diff, c=count_dev, p0=2.0 * weight)))
     return out
 
 
@@ -419,7 +421,13 @@ class _AlignerT:
         self.query = [Dense(g, *name("query", 0), n_mels, 2 * n_mels, 3), Dense(g, *name("query", 2), 2 * n_mels, n_mels, 1),
                       Dense(g, *name("query", 4), n_mels, self.n_att, 1)]
 
-    def forward(self, tape: Tape, text_emb: Var, mel: Var, prior, text_lens32, mel_lens32, n_frames: float, ctc_weight: float, bin_weight: float):
+    def join_side(self):
+        """The main stream waits for the CTC side stream (what the aligner's backward does anyway; a captured stretch that ends
+        before that backward must not leave the forked stream unjoined)."""
+        if getattr(self, "_pending_done", None) is not None:
+            torch.cuda.current_stream(self._pending_done_device).wait_event(self._pending_done)
+
+    def forward(self, tape: Tape, text_emb: Var, mel: Var, prior, text_lens32, mel_lens32, n_frames_dev, ctc_weight: float, bin_weight: float):
         """-> ``join``; ``join() -> (losses dict, hard durations [B, L] int32, hard alignment)`` once the main stream needs them.
         Records the backward of both losses into the projections / embedding."""
         from ..heavy import maximum_path
@@ -449,9 +457,11 @@ class _AlignerT:
             hard, dur = maximum_path(ops.elementwise(16, soft), mel_lens32, text_lens32)
             dur = dur.to(torch.int32)
             mas_done.record(self._side_mas)
-        for t in (hard, dur):  # allocated on the side stream's pool, used (and released) under the main stream
-            t.record_stream(main)
+        if not torch.cuda.is_current_stream_capturing():
+            for t in (hard, dur):  # allocated on the side stream's pool, used (and released) under the main stream
+                t.record_stream(main)
         losses = {"attn_ctc": ctc}
+        self._pending_done, self._pending_done_device = done, logprob.device
 
         def join():
             from ..heavy import binarization_loss
@@ -463,7 +473,7 @@ class _AlignerT:
         def bwd():
             torch.cuda.current_stream(logprob.device).wait_event(done)
             dq, dk = ops.align_attention_bwd(q.data, k.data, soft, logprob, prior, hard if bin_weight > 0.0 else None, dlogprob, text_lens32,
-                                             self.temperature, bin_weight / n_frames)
+                                             self.temperature, bin_weight, bin_count=n_frames_dev)
             q.accumulate(dq)
             k.accumulate(dk)
 
@@ -482,7 +492,7 @@ class FastSpeech2Trainer:
 
     def __init__(self, config: FastSpeech2ModelConfig | None = None, stats: Stats | None = None, training: FastSpeech2TrainingConfig | None = None,
                  device="cuda:0", seed: int = 1234, lang2id: dict | None = None, speaker2id: dict | None = None, process_group=None,
-                 precision: str = "f32", side_wgrad: bool | None = None):
+                 precision: str = "f32", side_wgrad: bool | None = None, use_graph: bool = False, graph_buckets: tuple | None = None):
         if precision not in ("f32", "bf16"):
             raise ValueError("precision: 'f32' or 'bf16' (bf16 operands of the dense layers, fp32 accumulation / master weights)")
         self.precision = precision
@@ -490,6 +500,9 @@ class FastSpeech2Trainer:
         # of mostly small launches, so the two fill each other's gaps
         self.side_wgrad = (os.environ.get("EVMI_FS2_SIDE_WGRAD", "1") == "1") if side_wgrad is None else bool(side_wgrad)
         self._stream = None  # set at the end of __init__ (with its sibling streams)
+        self.use_graph = bool(use_graph)
+        self.graph_buckets = tuple(int(v) for v in graph_buckets) if graph_buckets else None  # (symbols, frames) multiples to pad to
+        self._graphs, self._graph_warm, self._graph_failed, self.last_step_was_graph = {}, {}, None, False
         self.config = c = config or FastSpeech2ModelConfig()
         self.stats = stats or Stats()
         self.training = training or FastSpeech2TrainingConfig()
@@ -534,6 +547,8 @@ class FastSpeech2Trainer:
         self._prior = None
         self._seed = seed
         self._grad_norm = torch.zeros(1, device=self.device)
+        self._seed_base = torch.zeros(1, device=self.device, dtype=torch.int64)  # (seed, step, rank) << 16: see _store_step_scalars
+        self._scal = torch.zeros(8, device=self.device, dtype=torch.float32)     # [learning rate, tokens, frames, mel elements]
         self._reducer, self._tail_lo = None, None
         self.init_random(seed)
         # the step's stream and its three siblings, taken from the pool back to back (four different hardware queues: training_step)
@@ -627,29 +642,102 @@ class FastSpeech2Trainer:
         return o.learning_rate * w ** 0.5 * min(step ** -0.5, step * w ** -1.5)
 
     # -- the step -------------------------------------------------------------------------------------------------------
-    def forward_backward(self, batch: dict) -> dict:
-        """Forward in training mode + every loss + backward; gradients are left in ``self.params.grad``."""
-        lib, dev, c, tr = _lib.load(), self.device, self.config, self.training
-        lens = batch["lens"].to(dev, torch.int32).contiguous()
-        if self.pfs:  # batch["pfs"] [B, L, 43] multi-hot feature vectors (the reference's `pfs` files) -> [43, B, L]
-            feats = batch["pfs"].to(dev, torch.float32).permute(2, 0, 1).contiguous()
-            ids = None
-            B, L = feats.shape[1], feats.shape[2]
-        else:
-            ids = batch["ids"].to(dev, torch.int32).contiguous()
-            B, L = ids.shape
-        D = c.encoder.input_dim
-        n_tok = float(batch["lens"].sum())
-        pad = torch.arange(L, device=dev)[None, :] >= lens[:, None]
+    def _world_rank(self):
+        if self.pg is None:
+            return 1, 0
+        import torch.distributed as dist
+
+        grp = self.pg if self.pg is not True else None
+        return dist.get_world_size(grp), dist.get_rank(grp)
+
+    def _prepare(self, batch: dict):
+        """Host batch -> (device batch in the step's dtypes / layouts, host-side facts about it).  Everything that needs the host
+        (lengths, counts, the padded shape) is decided HERE, before the step: the step itself then is a fixed launch sequence for a
+        given padded shape, which is what lets it be captured into a HIP graph and replayed on other batches of that shape."""
+        dev = self.device
+        lens_host = batch["lens"].to("cpu", torch.int64)
         learn = self.aligner is not None
-        if learn:  # durations come out of the aligner below; the frame counts are the data's
+        L = int(batch["pfs"].shape[1] if self.pfs else batch["ids"].shape[1])
+        B = int(lens_host.shape[0])
+        if learn:  # durations come out of the aligner; the frame counts are the data's
             mel_lens_host = batch["mel_lens"].to("cpu", torch.int64)
         else:
-            mel_lens_host = batch["durations"].to("cpu").clamp_min(0).masked_fill(torch.arange(L)[None, :] >= batch["lens"].to("cpu")[:, None], 0).sum(1)
-        mel_lens = mel_lens_host.to(dev, torch.int32).contiguous()
+            pad_host = torch.arange(L)[None, :] >= lens_host[:, None]
+            dur_host = batch["durations"].to("cpu").clamp_min(0).masked_fill(pad_host, 0)
+            mel_lens_host = dur_host.sum(1)
         T = int(mel_lens_host.max())
+        Lp, Tp = L, T
+        if self.graph_buckets is not None:  # padded shapes from a small set: captured steps get reused (see training_step)
+            Lp = -(-L // self.graph_buckets[0]) * self.graph_buckets[0]
+            Tp = -(-T // self.graph_buckets[1]) * self.graph_buckets[1]
+
+        def fit(t: torch.Tensor, sizes: dict) -> torch.Tensor:
+            """Slice / zero-pad the given axes of a batch tensor to the step's padded shape."""
+            for axis, size in sizes.items():
+                if t.shape[axis] > size:
+                    t = t.narrow(axis, 0, size)
+                elif t.shape[axis] < size:
+                    padding = [0, 0] * t.dim()
+                    padding[2 * (t.dim() - 1 - axis) + 1] = size - t.shape[axis]
+                    t = torch.nn.functional.pad(t, padding)
+            return t
+
+        d = {"lens": batch["lens"].to(dev, torch.int32).contiguous(), "mel_lens": mel_lens_host.to(dev, torch.int32).contiguous()}
+        if self.pfs:  # batch["pfs"] [B, L, 43] multi-hot feature vectors (the reference's `pfs` files) -> [43, B, L]
+            d["pfs"] = fit(batch["pfs"].to(dev, torch.float32), {1: Lp}).permute(2, 0, 1).contiguous()
+        else:
+            d["ids"] = fit(batch["ids"].to(dev, torch.int32), {1: Lp}).contiguous()
+        if not learn:
+            d["durations"] = fit(dur_host.to(dev, torch.int32), {1: Lp}).contiguous()
+        d["mel_t"] = fit(batch["mel"].to(dev, torch.float32), {1: Tp}).permute(2, 0, 1).contiguous()  # [n_mels, B, T]
+        if learn and batch.get("attn_prior") is not None:
+            d["attn_prior"] = fit(batch["attn_prior"].to(dev, torch.float64), {1: Tp, 2: Lp}).contiguous()
+        for key in ("pitch", "energy"):
+            if key in batch:
+                d[key] = fit(batch[key].to(dev, torch.float32), {1: Lp}).contiguous()
+            else:
+                d[key + "_frames"] = fit(batch[key + "_frames"].to(dev, torch.float32), {1: Tp}).contiguous()
+        for table, key in ((self.speaker_table, "speakers"), (self.language_table, "languages")):
+            if table is not None:
+                if batch.get(key) is None:
+                    raise ValueError(f"this model needs `{key}` ids [B]")
+                d[key] = batch[key].to(dev, torch.int32).contiguous()
         n_frames = float(mel_lens_host.sum())
-        mel_t = batch["mel"].to(dev, torch.float32)[:, :T].permute(2, 0, 1).contiguous()  # [n_mels, B, T]
+        meta = dict(B=B, L=Lp, T=Tp, n_tok=float(lens_host.sum()), n_frames=n_frames, n_el=n_frames * self.config.n_mels)
+        return d, meta
+
+    def _store_step_scalars(self, meta: dict) -> None:
+        """What changes from step to step without changing the launch sequence lives on the device: the dropout seed base
+        (seed, step, rank) and [learning rate of this step, token count, frame count, mel element count]."""
+        world, rank = self._world_rank()
+        base = ((((self._seed * 1000003 + self.global_step) * world + rank) << 16)) & 0x7FFFFFFFFFFFFFFF
+        ops.store_u64(self._seed_base, base)
+        ops.store_f32(self._scal, [self.learning_rate(self.global_step + 1), meta["n_tok"], meta["n_frames"], meta["n_el"]])
+
+    def forward_backward(self, batch: dict) -> dict:
+        """Forward in training mode + every loss + backward; gradients are left in ``self.params.grad``."""
+        d, meta = self._prepare(batch)
+        self._store_step_scalars(meta)
+        prev = ops.SEED_BASE[0]
+        ops.SEED_BASE[0] = self._seed_base
+        try:
+            return self._forward_backward(d, meta)
+        finally:
+            ops.SEED_BASE[0] = prev
+
+    def _forward_backward(self, batch: dict, meta: dict, segmented: bool = False):
+        """The launch sequence of one step on a prepared (device) batch: no host read, no host-dependent argument.
+        ``segmented``: -> (backward generator, losses) instead of running the backward: every ``next()`` runs it up to the next
+        gradient-bucket boundary (data-parallel graph capture: the all-reduces sit between the captured stretches), and
+        ``_finish_backward(losses)`` completes the step's gradient side."""
+        lib, dev, c, tr = _lib.load(), self.device, self.config, self.training
+        lens, mel_lens, mel_t = batch["lens"], batch["mel_lens"], batch["mel_t"]
+        feats, ids = batch.get("pfs"), batch.get("ids")
+        B, L, T = meta["B"], meta["L"], meta["T"]
+        D = c.encoder.input_dim
+        n_tok, n_frames, n_el = self._scal[1:2], self._scal[2:3], self._scal[3:4]  # device scalars (see _store_step_scalars)
+        pad = torch.arange(L, device=dev)[None, :] >= lens[:, None]
+        learn = self.aligner is not None
 
         if not _EVAL[0]:
             self.params.zero_grad()
@@ -658,19 +746,13 @@ class FastSpeech2Trainer:
         tape = Tape()
         counter = [0]
 
-        world, rank = 1, 0
-        if self.pg is not None:
-            import torch.distributed as dist
-
-            grp = self.pg if self.pg is not True else None
-            world, rank = dist.get_world_size(grp), dist.get_rank(grp)
-
         def seeds(n=1):
-            """Counter-based dropout seeds: distinct per (seed, step, rank, draw) -- every data-parallel rank masks its shard
+            """Counter-based dropout seeds: the draw's index inside the step; the kernels add the device-resident base
+            (seed, step, rank) << 16 -- distinct per (seed, step, rank, draw): every data-parallel rank masks its shard
             independently, as per-process RNG streams do under DDP."""
             counter[0] += n
             assert counter[0] < 65536, "more dropout draws in one step than the seed layout reserves"
-            return ((((self._seed * 1000003 + self.global_step) * world + rank) << 16) | (counter[0] - n)) & 0x7FFFFFFFFFFFFFFF
+            return counter[0] - n
 
         def embed(with_position: bool) -> Var:
             if self.pfs:  # Linear(43 -> D) over the feature vectors, padded columns zeroed (+ the positional sinusoid)
@@ -694,12 +776,10 @@ class FastSpeech2Trainer:
         if learn:
             epochs = max(1, tr.attn_bin_loss_warmup_epochs)
             bin_w = tr.attn_bin_loss_weight * min(self.current_epoch / epochs, 1.0)
-            prior = batch.get("attn_prior")
-            prior = None if prior is None else prior.to(dev, torch.float64)[:, :T, :L].contiguous()
-            align_join = self.aligner.forward(tape, embed(False), Var(mel_t, needs_grad=False), prior, lens, mel_lens, n_frames,
+            align_join = self.aligner.forward(tape, embed(False), Var(mel_t, needs_grad=False), batch.get("attn_prior"), lens, mel_lens, n_frames,
                                               tr.attn_ctc_loss_weight, bin_w)
         else:
-            dur = batch["durations"].to(dev, torch.int32).clamp_min(0).masked_fill(pad, 0).contiguous()
+            dur = batch["durations"]
 
         x0 = embed(True)
         x = self.encoder.forward(tape, x0, lens, seeds)
@@ -714,9 +794,7 @@ class FastSpeech2Trainer:
 
         for table, key in ((self.speaker_table, "speakers"), (self.language_table, "languages")):
             if table is not None:
-                if batch.get(key) is None:
-                    raise ValueError(f"this model needs `{key}` ids [B]")
-                x = self._add_item_embedding(tape, x, table, batch[key].to(dev, torch.int32).contiguous(), lens)
+                x = self._add_item_embedding(tape, x, table, batch[key], lens)
 
         w = tr.duration_loss_weight
         losses["duration"] = mse_loss(tape, self.duration_predictor.forward(tape, x, lens, seeds), log_d_t.view(1, B, L), n_tok, w)
@@ -740,7 +818,10 @@ class FastSpeech2Trainer:
             x_enc.accumulate(dx)
 
         tape.record(lr_bwd)
-        if self._reducer is not None:
+        if segmented:
+            # (captured data-parallel step: the stretch ends here; every stream forked so far must be back on the main one)
+            tape.cut(self.aligner.join_side if learn else None)
+        elif self._reducer is not None:
             # data parallel: the decoder / mel_linear / postnet gradients -- the tail of the flat buffer, ~half of the parameters --
             # are final once backward leaves the decoder; their all-reduce runs on a side stream under the backward of the
             # variance adaptor, the aligner and the encoder (recorded BEFORE the decoder's forward = run AFTER its backward)
@@ -748,7 +829,6 @@ class FastSpeech2Trainer:
             tape.record(lambda: (ops.wgrad_join(dev), red.launch(lo_tail, self.params.grad.numel())))
         y = self.decoder.forward(tape, f, mel_lens, seeds)
         mel = masked(tape, dense(tape, y, self.mel_linear), mel_lens)
-        n_el = n_frames * c.n_mels
         losses["mel"] = mse_loss(tape, mel, mel_t, n_el, tr.mel_loss_weight)
         if self.postnet:
             h = mel
@@ -758,11 +838,17 @@ class FastSpeech2Trainer:
             losses["postnet"] = mse_loss(tape, post, mel_t, n_el, tr.postnet_loss_weight)
         if _EVAL[0]:
             ops.wgrad_join(dev)
-        else:
-            tape.backward()
+            return self._finish_backward(losses, grads=False)
+        if segmented:
+            return tape.backward_segments(), losses
+        tape.backward()
+        return self._finish_backward(losses)
+
+    def _finish_backward(self, losses: dict, grads: bool = True) -> dict:
+        if grads:
             for cv in self._wn:
                 cv.finish_grads()
-        total = torch.zeros(1, device=dev)
+        total = torch.zeros(1, device=self.device)
         for v in losses.values():
             ops.axpby(1.0, total, 1.0, v, out=total)
         losses["total"] = total
@@ -786,8 +872,8 @@ class FastSpeech2Trainer:
         each symbol's frames -- ``average_data_by_durations``, everyvoice/preprocessor/preprocessor.py:287-300 (1e-7 for zero frames)."""
         dev = self.device
         if key in batch:
-            return batch[key].to(dev, torch.float32).masked_fill(pad, 0.0).contiguous()
-        fr = batch[key + "_frames"].to(dev, torch.float32)[:, :T].contiguous()
+            return batch[key].masked_fill(pad, 0.0).contiguous()
+        fr = batch[key + "_frames"]
         B, L = dur.shape
         sums = torch.empty(B, L, device=dev, dtype=torch.float32)
         _chk(_lib.load().evmi_length_regulate_bwd_cbt_f32(fr.data_ptr(), cum.data_ptr(), sums.data_ptr(), 1, B, L, T, _s(fr)), "evmi_length_regulate_bwd_cbt_f32")
@@ -836,7 +922,16 @@ class FastSpeech2Trainer:
         The step runs on the trainer's own stream (the caller's stream is joined on both sides): that stream and the three
         sibling streams beside it (weight gradients, CTC loss, alignment search) were taken from the stream pool back to back, so
         they sit on four different hardware queues whatever the process created before -- on the caller's stream the overlap
-        depended on where the pool's round-robin stood (a GAN trainer earlier in the process cost this step 4.7 ms)."""
+        depended on where the pool's round-robin stood (a GAN trainer earlier in the process cost this step 4.7 ms).
+
+        ``use_graph``: the step is ~1,650 launches whose host cost (Python + ctypes, ~10 us each) is twice its device time.  For a
+        padded batch shape (B, L, T) that has been seen GRAPH_WARMUP_STEPS times the launch sequence is captured into a HIP graph
+        (``torch.cuda.CUDAGraph`` on the step's stream, the sibling streams forked from it) and every later batch of that shape is
+        one replay: inputs are copied into the graph's static buffers, and what changes from step to step without changing the
+        sequence -- dropout seed base, learning rate, token / frame counts -- is stored on the device first
+        (``_store_step_scalars``).  Shapes seen once or twice run eagerly; ``graph_buckets=(l, t)`` pads L and T up to multiples,
+        so a real data stream lands on a small set of shapes (the extra padded columns enter the Conformer's BatchNorm statistics,
+        as the reference's own padding does).  Eager and replayed steps are bit for bit the same arithmetic."""
         if self._stream is None:
             return self._training_step(batch)
         caller = torch.cuda.current_stream(self.device)
@@ -844,37 +939,156 @@ class FastSpeech2Trainer:
         with torch.cuda.stream(self._stream):
             losses = self._training_step(batch)
         caller.wait_stream(self._stream)
-        for v in losses.values():
-            v.record_stream(caller)
+        if not self.last_step_was_graph:
+            for v in losses.values():
+                v.record_stream(caller)
         return losses
 
+    GRAPH_WARMUP_STEPS = 2
+    GRAPH_CACHE = 24  # captured shapes kept (least recently used out first)
+
     def _training_step(self, batch: dict) -> dict:
-        from .hifigan import BucketReducer
-        prev, prev_side = ops.CONV_BACKEND["operands"], ops.SIDE_WGRAD["on"]
+        prev, prev_side, prev_base = ops.CONV_BACKEND["operands"], ops.SIDE_WGRAD["on"], ops.SEED_BASE[0]
         ops.CONV_BACKEND["operands"] = self.precision
         ops.SIDE_WGRAD["on"] = self.side_wgrad and self.device.type == "cuda"
+        ops.SEED_BASE[0] = self._seed_base
         try:
-            # data parallel: utterances are sharded across ranks, gradients averaged by a bucketed all-reduce that
-            # overlaps backward (two buckets: see forward_backward)
-            self._reducer = (BucketReducer(self.params.grad, self.pg if self.pg is not True else None,
-                                           lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc)) if self.pg is not None else None)
-            losses = self.forward_backward(batch)
+            d, meta = self._prepare(batch)
+            self._store_step_scalars(meta)
+            self.last_step_was_graph = False
+            entry = None
+            if self.use_graph and self._graph_failed is None:
+                entry = self._graph_entry(d, meta)
+            if entry is None:
+                losses = self._step_body(d, meta)
+            else:
+                for k, v in d.items():  # into the captured step's static inputs (same shapes by construction of the key)
+                    entry["inputs"][k].copy_(v)
+                self._replay(entry)
+                losses = entry["losses"]
+                self.last_step_was_graph = True
         finally:
             ops.CONV_BACKEND["operands"] = prev
             ops.SIDE_WGRAD["on"] = prev_side
+            ops.SEED_BASE[0] = prev_base
+        self.global_step += 1
+        return losses
+
+    def _step_body(self, d: dict, meta: dict) -> dict:
+        """Forward + backward + gradient exchange + clipping + optimiser on a prepared batch (eager; also what gets captured)."""
+        from .hifigan import BucketReducer
+
+        # data parallel (SURVEY.md 8e): utterances are sharded across ranks, gradients averaged by a bucketed all-reduce that
+        # overlaps backward (two buckets: see _forward_backward)
+        self._reducer = (BucketReducer(self.params.grad, self.pg if self.pg is not True else None,
+                                       lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc)) if self.pg is not None else None)
+        losses = self._forward_backward(d, meta)
         if self._reducer is not None:  # the head of the buffer (everything in front of the decoder), then wait + 1/world scaling
             self._reducer.launch(0, self._tail_offset())
             self._reducer.finish()
             self._reducer = None
+        self._clip_and_update()
+        return losses
+
+    def _clip_and_update(self):
         g = self.params
         clip = self.training.gradient_clip_val
         if clip is not None:
             # g *= min(1, clip / (||g|| + 1e-6)), the norm staying on the device (torch.nn.utils.clip_grad_norm_)
             ops.scalar_reduce(1, g.grad, None, self._grad_norm, p=0.0)
             ops.elementwise(ops.EW_CLIP_SCALE, g.grad, None, self._grad_norm, out=g.grad, p0=float(clip))
-        self.global_step += 1
         o = self.training.optimizer
-        g.adamw(self.learning_rate(self.global_step), tuple(o.betas), o.eps, o.weight_decay)
+        g.adamw(0.0, tuple(o.betas), o.eps, o.weight_decay, lr_dev=self._scal[0:1])  # the rate of this step: _store_step_scalars
         for cv in self._wn:
             cv._w = None
-        return losses
+
+    # -- HIP-graph execution -----------------------------------------------------------------------------------------------------
+    def _graph_key(self, d: dict, meta: dict):
+        tr = self.training
+        bin_w = tr.attn_bin_loss_weight * min(self.current_epoch / max(1, tr.attn_bin_loss_warmup_epochs), 1.0) if self.aligner is not None else 0.0
+        return (meta["B"], meta["L"], meta["T"], tuple(sorted(d)), self.precision, bin_w, tr.gradient_clip_val, self.pg is not None)
+
+    def _graph_entry(self, d: dict, meta: dict):
+        """The captured step for this batch's padded shape, or None (not seen often enough yet, or capturing failed: eager)."""
+        key = self._graph_key(d, meta)
+        entry = self._graphs.get(key)
+        if entry is not None:
+            self._graphs[key] = self._graphs.pop(key)  # most recently used last
+            return entry
+        n = self._graph_warm.get(key, 0)
+        if n < self.GRAPH_WARMUP_STEPS:  # eager steps grow the per-stream workspaces and set the kernels' launch attributes
+            self._graph_warm[key] = n + 1
+            if len(self._graph_warm) > 4096:
+                self._graph_warm.clear()
+            return None
+        try:
+            entry = self._capture(d, meta)
+        except Exception as e:  # noqa: BLE001 -- whatever the runtime objected to: the eager path is always available
+            self._graph_failed = f"{type(e).__name__}: {e}"
+            torch.cuda.synchronize(self.device)
+            return None
+        self._graphs[key] = entry
+        while len(self._graphs) > self.GRAPH_CACHE:
+            self._graphs.pop(next(iter(self._graphs)))
+        return entry
+
+    def _capture(self, d: dict, meta: dict) -> dict:
+        """Record the step on static copies of the inputs.  Capturing executes nothing: host-side counters the step's code bumps
+        (optimiser step, BatchNorm batch counts) are put back -- `_replay` advances them."""
+        inputs = {k: v.clone() for k, v in d.items()}
+        step0, batches0 = self.params._step, [bn.batches for bn in self._bn]
+        torch.cuda.synchronize(self.device)
+        graphs, holder = [], {}
+        pool = torch.cuda.graph_pool_handle()
+
+        def cap(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=self._stream, capture_error_mode="thread_local"):
+                fn()
+            graphs.append(g)
+
+        try:
+            if self.pg is None:
+                cap(lambda: holder.__setitem__("losses", self._step_body(inputs, meta)))
+            else:
+                self._capture_data_parallel(cap, inputs, meta, holder)
+        finally:
+            self.params._step = step0
+            for bn, b in zip(self._bn, batches0):
+                bn.batches = b
+            self._reducer = None
+        return dict(graphs=graphs, inputs=inputs, losses=holder["losses"], cuts=holder.get("cuts", []))
+
+    def _replay(self, entry: dict) -> None:
+        graphs, cuts = entry["graphs"], entry["cuts"]
+        for i, g in enumerate(graphs):
+            g.replay()
+            if i < len(cuts):
+                cuts[i]()  # the gradient exchange that sits between two captured stretches (RCCL calls are not captured)
+        self.params._step += 1
+        for bn in self._bn:
+            bn.batches += 1
+
+    def _capture_data_parallel(self, cap, inputs, meta, holder):
+        """Under data parallelism the step is three captured stretches with the two bucket all-reduces issued between them, the
+        first one on a side stream so that it runs UNDER the second stretch (the backward of the variance adaptor, the aligner
+        and the encoder): forward + backward down to the decoder | rest of the backward | clipping + optimiser."""
+        from .hifigan import BucketReducer
+
+        red = BucketReducer(self.params.grad, self.pg if self.pg is not True else None, lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
+        lo_tail, n_all = self._tail_offset(), self.params.grad.numel()
+        state = {}
+
+        def part_a():
+            state["segments"], holder["losses"] = self._forward_backward(inputs, meta, segmented=True)  # cut where the tail bucket is final
+            next(state["segments"])
+
+        def part_b():
+            for _ in state["segments"]:
+                pass
+            self._finish_backward(holder["losses"])
+
+        cap(part_a)
+        cap(part_b)
+        cap(self._clip_and_update)
+        holder["cuts"] = [lambda: red.launch(lo_tail, n_all), lambda: (red.launch(0, lo_tail), red.finish())]

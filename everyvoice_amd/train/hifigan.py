@@ -916,11 +916,20 @@ class HiFiGANTrainer:
             if n < self.GRAPH_WARMUP_STEPS or self.keep_grads:
                 self._graph_warm[key] = n + 1
                 return self._eager_step(mel_bct, audio_bct)
+            steps = (self.g_params.step, self.d_params.step)
             try:
                 entry = self._capture(key, mel_bct, audio_bct, warm)
             except Exception as e:  # noqa: BLE001 -- whatever the runtime objected to: the eager path is always available
                 self._graph_failed = f"{type(e).__name__}: {e}"
                 torch.cuda.synchronize(self.device)
+                # nothing of the aborted capture has run, but its host-side bookkeeping has: the spectral-norm layers hold
+                # prepared (weight, sigma, u, v) tuples that live in the dead graph's pool and were never computed, and the
+                # optimisers' host counters were bumped.  Put both back before the eager step.
+                for layer in self._sn_layers():
+                    layer._ready.clear()
+                    layer._held.clear()
+                    layer._calls.clear()
+                self.g_params._step, self.d_params._step = steps
                 return self._eager_step(mel_bct, audio_bct)
             self._graphs[key] = entry
         ops.copy(mel_bct.to(torch.float32).contiguous(), out=entry["mel"])

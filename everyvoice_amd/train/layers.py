@@ -101,7 +101,7 @@ class ParamGroup:
 
     OPTIMIZERS = {"adamw": 0, "adam": 1, "rms": 2}
 
-    def optimizer_step(self, name="adamw", lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, alpha=0.99, clip=0.0):
+    def optimizer_step(self, name="adamw", lr=1e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01, alpha=0.99, clip=0.0, lr_dev=None):
         """One step of the configured optimiser (the reference's union: AdamOptimizer / AdamWOptimizer / RMSOptimizer,
         everyvoice/.schema/everyvoice-spec-to-wav-0.5.json:434-622) over the flat buffer; ``clip`` > 0 clamps the updated
         parameters (WGAN).  The step number lives on the device, so a captured HIP graph of the step replays correctly."""
@@ -113,12 +113,17 @@ class ParamGroup:
         st = _lib.current_stream_ptr(self.flat.device)
         _lib.check(lib.evmi_counter_add_i32(self.step_dev.data_ptr(), 1, st), "evmi_counter_add_i32")
         b1, b2 = (alpha, 0.0) if kind == 2 else betas
+        if lr_dev is not None:  # a scheduled rate the caller stored on the device (graph replays pick up the new value)
+            _lib.check(lib.evmi_optimizer_step_lrdev_f32(kind, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                                         self.flat.numel(), lr_dev.data_ptr(), b1, b2, eps, weight_decay, self.step_dev.data_ptr(),
+                                                         float(clip), st), "evmi_optimizer_step_lrdev_f32")
+            return
         _lib.check(lib.evmi_optimizer_step_f32(kind, self.flat.data_ptr(), self.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                                self.flat.numel(), lr, b1, b2, eps, weight_decay, self._step, self.step_dev.data_ptr(),
                                                float(clip), st), "evmi_optimizer_step_f32")
 
-    def adamw(self, lr, betas, eps, weight_decay):
-        self.optimizer_step("adamw", lr, betas, eps, weight_decay)
+    def adamw(self, lr, betas, eps, weight_decay, lr_dev=None):
+        self.optimizer_step("adamw", lr, betas, eps, weight_decay, lr_dev=lr_dev)
 
 
 class _ConvBase:

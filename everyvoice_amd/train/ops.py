@@ -96,7 +96,7 @@ def elementwise(op, a, b=None, c=None, out=None, p0=0.0, p1=0.0):
     return out
 
 
-EW_DIV_SCALAR, EW_STFT_GRAD_DEV, EW_FILL = 21, 22, 23
+EW_DIV_SCALAR, EW_STFT_GRAD_DEV, EW_FILL, EW_SCALE_DIV_SCALAR = 21, 22, 23, 24
 
 
 def fill_(x, value=0.0):
@@ -742,16 +742,36 @@ def dwconv_bwd(x, w, dy, dw, db, k, need_dx=True):
     return dx
 
 
+# A device-resident base added to every dropout seed ([1] int64 tensor, or None): the FastSpeech2 trainer stores
+# (seed, step, rank) << 16 there before each step and passes the draw's index as `seed`, so a step captured into a HIP graph
+# draws fresh masks on every replay (include/evmi.h: evmi_dropout_f32).
+SEED_BASE = [None]
+
+
+def store_f32(dst: torch.Tensor, values) -> None:
+    """dst[: len(values)] = values (<= 8 floats), carried in a kernel's argument block (no host buffer to keep alive)."""
+    import ctypes as C
+
+    vals = [float(v) for v in values]
+    arr = (C.c_float * len(vals))(*vals)
+    _chk(_lib.load().evmi_store_f32(dst.data_ptr(), len(vals), arr, _s(dst)), "evmi_store_f32")
+
+
+def store_u64(dst: torch.Tensor, value: int) -> None:
+    _chk(_lib.load().evmi_store_u64(dst.data_ptr(), int(value) & 0xFFFFFFFFFFFFFFFF, _s(dst)), "evmi_store_u64")
+
+
 def dropout(x, p, seed):
     y = torch.empty_like(x)
-    _chk(_lib.load().evmi_dropout_f32(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _s(x)), "evmi_dropout_f32")
+    _chk(_lib.load().evmi_dropout_f32(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _lib.ptr(SEED_BASE[0]), _s(x)), "evmi_dropout_f32")
     return y
 
 
 def dropout_fused(mode, a, b, p, seed, scale=1.0):
     """evmi_dropout_fused_f32: 1: b + scale * drop(a); 2: drop(silu(a)); 3: drop(a) * silu'(b); 4: scale * drop(a)."""
     y = torch.empty_like(a)
-    _chk(_lib.load().evmi_dropout_fused_f32(mode, a.data_ptr(), _lib.ptr(b), y.data_ptr(), a.numel(), p, seed, float(scale), _s(a)), "evmi_dropout_fused_f32")
+    _chk(_lib.load().evmi_dropout_fused_f32(mode, a.data_ptr(), _lib.ptr(b), y.data_ptr(), a.numel(), p, seed, _lib.ptr(SEED_BASE[0]), float(scale), _s(a)),
+         "evmi_dropout_fused_f32")
     return y
 
 
@@ -777,7 +797,7 @@ def attention_train_fwd(qkv, lens32, heads, p=0.0, seed=0):
     lse = torch.empty(B, heads, T, device=qkv.device, dtype=torch.float32)
     lib = _lib.load()
     fn = lib.evmi_mha_fwd_bf16 if CONV_BACKEND["operands"] == "bf16" else lib.evmi_mha_fwd_f32
-    _chk(fn(qkv.data_ptr(), lens32.data_ptr(), out.data_ptr(), lse.data_ptr(), B, T, D, heads, float(p), int(seed), _s(qkv)), "evmi_mha_fwd")
+    _chk(fn(qkv.data_ptr(), lens32.data_ptr(), out.data_ptr(), lse.data_ptr(), B, T, D, heads, float(p), int(seed), _lib.ptr(SEED_BASE[0]), _s(qkv)), "evmi_mha_fwd")
     return out, (out, lse, lens32)
 
 
@@ -789,7 +809,7 @@ def attention_train_bwd(qkv, saved, dout, heads, p=0.0, seed=0):
     lib = _lib.load()
     fn = lib.evmi_mha_bwd_bf16 if CONV_BACKEND["operands"] == "bf16" else lib.evmi_mha_bwd_f32
     _chk(fn(qkv.data_ptr(), lens32.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dsum.data_ptr(), dqkv.data_ptr(), B, T, D3 // 3, heads,
-            float(p), int(seed), _s(qkv)), "evmi_mha_bwd")
+            float(p), int(seed), _lib.ptr(SEED_BASE[0]), _s(qkv)), "evmi_mha_bwd")
     return dqkv
 
 
@@ -820,8 +840,8 @@ def align_attention_fwd(q, k, prior, text_lens32, temperature):
     return soft, logprob
 
 
-def align_attention_bwd(q, k, soft, logprob, prior, hard, dlogprob, text_lens32, temperature, bin_scale):
-    """-> (dq [A, B, T], dk [A, B, L])"""
+def align_attention_bwd(q, k, soft, logprob, prior, hard, dlogprob, text_lens32, temperature, bin_scale, bin_count=None):
+    """-> (dq [A, B, T], dk [A, B, L]); ``bin_count``: device scalar the binarisation weight is divided by (the frame count)."""
     lib = _lib.load()
     A, B, T = q.shape
     L = k.shape[2]
@@ -830,7 +850,7 @@ def align_attention_bwd(q, k, soft, logprob, prior, hard, dlogprob, text_lens32,
     rs = torch.empty(B, T, device=dev, dtype=torch.float32)
     cs = torch.empty(B, L, device=dev, dtype=torch.float32)
     _chk(lib.evmi_align_attention_bwd_f32(soft.data_ptr(), logprob.data_ptr(), _lib.ptr(prior), _lib.ptr(hard), _lib.ptr(dlogprob), text_lens32.data_ptr(),
-                                          da.data_ptr(), rs.data_ptr(), cs.data_ptr(), B, T, L, bin_scale, _s(q)), "evmi_align_attention_bwd_f32")
+                                          da.data_ptr(), rs.data_ptr(), cs.data_ptr(), B, T, L, bin_scale, _lib.ptr(bin_count), _s(q)), "evmi_align_attention_bwd_f32")
     dq = torch.empty_like(q)
     dk = torch.empty_like(k)
     gemm_groups(k, da, dq, B, A, T, L, B * L, L, B * T, L, T * L, T, tb=True)  # K_b . da_b^T

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define EVMI_ABI_VERSION 1
+#define EVMI_ABI_VERSION 2
 
 enum {
   EVMI_OK = 0,
@@ -394,6 +394,17 @@ int evmi_normalize_vec_f32(const float* x_dev, float* y_dev, int n, float eps, v
 int evmi_optimizer_step_f32(int kind, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n, float lr,
                             float beta1, float beta2, float eps, float weight_decay, int step, const int* step_dev,
                             float clip, void* stream);
+/* The same step with the learning rate read from lr_dev[0] and the step number from step_dev[0]: a scheduled rate (Noam,
+ * everyvoice/config/shared_types.py:311-320) that the host stores on the device before each step, so that a captured HIP graph of
+ * the step replays with the current value. */
+int evmi_optimizer_step_lrdev_f32(int kind, float* p_dev, const float* g_dev, float* m_dev, float* v_dev, long long n,
+                                  const float* lr_dev, float beta1, float beta2, float eps, float weight_decay, const int* step_dev,
+                                  float clip, void* stream);
+/* dst_dev[0..n) = values_host[0..n) (n <= 8) / dst_dev[0] = value, the values travelling in the kernel's argument block (read when
+ * the call is made, ordered on the stream like any launch): per-step scalars of a captured training step (learning rate, counts,
+ * the dropout seed base) without a host buffer that would have to outlive the copy. */
+int evmi_store_f32(float* dst_dev, int n, const float* values_host, void* stream);
+int evmi_store_u64(unsigned long long* dst_dev, unsigned long long value, void* stream);
 /* out[c][b][t] = in[b][c][t]: a torch [B, C, T] batch into the channel-major layout of the training kernels. */
 int evmi_transpose_bct_cbt_f32(const float* in_dev, float* out_dev, int B, int C, int T, void* stream);
 /* counter[0] += delta (the device-side step counters of the optimisers). */
@@ -549,17 +560,17 @@ int evmi_dwconv1d_bwd_cbt_f32(const float* x_dev, const float* w_dev, const floa
  * evmi_dropout_f32 uses).  Backward: dqkv [3D][B][T] from d out; dsum [B][heads][T] is scratch.  fp32 matrix cores, one
  * writer per output element, fixed summation order (bitwise reproducible). */
 int evmi_mha_fwd_f32(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
-                     float p_drop, unsigned long long seed, void* stream);
+                     float p_drop, unsigned long long seed, const unsigned long long* seed_base_dev, void* stream);
 int evmi_mha_bwd_f32(const float* qkv_dev, const int* lens_dev, const float* out_dev, const float* dout_dev,
                      const float* lse_dev, float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop,
-                     unsigned long long seed, void* stream);
+                     unsigned long long seed, const unsigned long long* seed_base_dev, void* stream);
 /* The same two passes with bf16 operands (precision "bf16", BASELINE config 3): Q / K / V / dO, the probabilities and the score
  * gradients are rounded to bf16 into v_mfma_f32_32x32x16_bf16; scores, softmax statistics and accumulators are fp32. */
 int evmi_mha_fwd_bf16(const float* qkv_dev, const int* lens_dev, float* out_dev, float* lse_dev, int B, int T, int D, int heads,
-                      float p_drop, unsigned long long seed, void* stream);
+                      float p_drop, unsigned long long seed, const unsigned long long* seed_base_dev, void* stream);
 int evmi_mha_bwd_bf16(const float* qkv_dev, const int* lens_dev, const float* out_dev, const float* dout_dev,
                       const float* lse_dev, float* dsum_dev, float* dqkv_dev, int B, int T, int D, int heads, float p_drop,
-                      unsigned long long seed, void* stream);
+                      unsigned long long seed, const unsigned long long* seed_base_dev, void* stream);
 /* scores [B][Tq][Tk] -> softmax over the keys tk < lens[b] in place (0 beyond); with p > 0 also
  * dropped = dropout(probabilities, p) from the counter-based generator keyed by `seed`. */
 int evmi_softmax_rows_f32(float* scores_dev, float* dropped_dev, const int* lens_dev, int B, int Tq, int Tk, float p,
@@ -569,14 +580,19 @@ int evmi_softmax_bwd_rows_f32(const float* probs_dev, float* dprobs_dev, long lo
                               unsigned long long seed, void* stream);
 /* GLU over two halves p = [a; b] of n_half elements each: dp = [dy * sigmoid(b); dy * a * sigmoid'(b)]. */
 int evmi_glu_bwd_f32(const float* p_dev, const float* dy_dev, float* dp_dev, long long n_half, void* stream);
-/* y[i] = keep(seed, i) ? x[i] / (1 - p) : 0 ; calling it on a gradient with the same seed is the backward. */
-int evmi_dropout_f32(const float* x_dev, float* y_dev, long long n, float p, unsigned long long seed, void* stream);
+/* y[i] = keep(seed, i) ? x[i] / (1 - p) : 0 ; calling it on a gradient with the same seed is the backward.
+ * `seed_base_dev` (may be NULL) here and in evmi_dropout_fused_f32 / evmi_mha_*: a device-resident 64-bit base; the effective
+ * seed is then (seed + *seed_base_dev) & (2^63 - 1).  A training step captured into a HIP graph passes the draw's index as `seed`
+ * and rewrites the base (seed, step, rank) before every replay: new masks per step, none baked into the graph (the reference's
+ * torch.nn.Dropout draws from the process's generator state, which advances on its own). */
+int evmi_dropout_f32(const float* x_dev, float* y_dev, long long n, float p, unsigned long long seed,
+                     const unsigned long long* seed_base_dev, void* stream);
 /* The same dropout stream fused with its neighbour in the Conformer block (torchaudio's `x + 0.5 * dropout(ffn(x))`,
  * `dropout(silu(.))` and their backwards): drop(v)[i] = keep(seed, i) ? v[i] / (1 - p) : 0 and
  *   mode 1: y = b + scale * drop(a)    2: y = drop(silu(a))    3: y = drop(a) * silu'(b)    4: y = scale * drop(a)
  * (b is read by modes 1 and 3 only; operands 16-byte aligned). */
 int evmi_dropout_fused_f32(int mode, const float* a_dev, const float* b_dev, float* y_dev, long long n, float p,
-                           unsigned long long seed, float scale, void* stream);
+                           unsigned long long seed, const unsigned long long* seed_base_dev, float scale, void* stream);
 /* Embedding backward: dtable[ids[b][l]][c] += dx[c][b][l] for l < lens[b], ids != skip_id (padding_idx).  One thread per
  * (table row, channel) adds its tokens in order: bitwise reproducible, no atomics.  `rows` = rows of the table. */
 int evmi_fs2_embed_bwd_f32(const float* dx_dev, const int* ids_dev, const int* lens_dev, float* dtable_dev, int rows,
@@ -600,11 +616,13 @@ int evmi_forward_sum_grad_f32(const float* logprob_dev, const int* text_lens_dev
                               float* loss_per_item_dev, float* grad_dev, float* ws_dev, long long ws_elems, int B, int T,
                               int L, float blank_logprob, float weight, void* stream);
 /* Backward of evmi_align_attention_f32 down to the distance scores: da [B][T][L] from the CTC gradient dlogprob (or NULL) and
- * the binarisation loss on `hard` (or NULL; bin_scale = weight / number of hard cells); also rowsum [B][T] = sum_l da and
+ * the binarisation loss on `hard` (or NULL; bin_scale = weight / number of hard cells -- or the weight alone with the count in
+ * bin_count_dev[0], so that a captured step serves batches with different frame counts); also rowsum [B][T] = sum_l da and
  * colsum [B][L] = sum_t da.  prior as given to the forward (or NULL). */
 int evmi_align_attention_bwd_f32(const float* soft_dev, const float* logprob_dev, const double* prior_dev, const int* hard_dev,
                                  const float* dlogprob_dev, const int* text_lens_dev, float* da_dev, float* rowsum_dev,
-                                 float* colsum_dev, int B, int T, int L, float bin_scale, void* stream);
+                                 float* colsum_dev, int B, int T, int L, float bin_scale, const float* bin_count_dev,
+                                 void* stream);
 /* In place m[c][n] = coef * (x[c][n] * sums[n] - m[c][n]) over A rows of BN columns: finishes dq (m = K . da^T, coef = -2 temp)
  * and dk (m = Q . da, coef = -2 temp with the sign folded: dk = 2 temp (m - k * colsum)). */
 int evmi_align_qk_grad_f32(const float* x_dev, const float* sums_dev, float* m_dev, int A, long long BN, float coef,

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/evmi.h but not exported"
     assert set(names) == set(_lib.SYMBOLS), "ctypes table and header disagree"
-    assert lib.evmi_abi_version() == 1
+    assert lib.evmi_abi_version() == 2
 
 
 def test_generator_object_without_gpu():

@@ -11,6 +11,7 @@ from pathlib import Path
 
 import torch
 import torch.distributed as dist
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -141,3 +142,48 @@ def test_rank_count_mismatch_is_a_hard_error(monkeypatch, capfd):
     monkeypatch.setenv("LOCAL_RANK", "0")
     assert bench.main(["--gpus", "8", "--selftest-cpu"]) == 2
     assert "WORLD_SIZE=4" in capfd.readouterr().err
+
+
+def test_train_base_command_devices_2_over_gloo(tmp_path, monkeypatch):
+    """``train_base_command(..., devices=2)`` outside a launcher starts one rank per device running the same command
+    (base_cli/interfaces.py:84-97 -> Lightning's DDP launcher).  With CPU stand-ins for the three classes (tests/ddp_stub.py) over
+    gloo this checks the driver's own part: the classes travel by qualified name (nested ones too), ``model_kwargs`` and the
+    accelerator reach the ranks, every rank writes into ONE log directory, rank shards are disjoint and cover the data,
+    validation is sharded and its mean agreed between ranks, and only rank 0 writes checkpoints."""
+    import json
+    import os
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parents[1]
+    monkeypatch.chdir(root)
+    monkeypatch.setenv("PYTHONPATH", str(root) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "EVMI_LOG_SUB_DIR"):
+        monkeypatch.delenv(k, raising=False)
+    sys.path.insert(0, str(root))
+    from everyvoice_amd.lightning import train_base_command
+    from tests.ddp_stub import Outer, StubData, StubModel
+
+    cfg = Outer.StubConfig(training=dict(batch_size=2, max_epochs=1, max_steps=100, val_check_interval=None, check_val_every_n_epoch=1, save_top_k_ckpts=1,
+                                         logger=dict(save_dir=tmp_path / "logs", name="ddp")))
+    (tmp_path / "cfg.json").write_text(json.dumps(cfg.model_dump(mode="json")))
+    rc = train_base_command(Outer.StubConfig, StubData, StubModel, "validation/stub", [], tmp_path / "cfg.json", accelerator="cpu", devices=2,
+                            model_kwargs={"scale": 3.0, "tag": "from-the-parent"})
+    assert rc == 0
+    runs = list((tmp_path / "logs" / "ddp" / "base").iterdir())
+    assert len(runs) == 1 and (runs[0] / "hparams.yaml").exists()  # one <sub_dir> for both ranks
+    rec = json.loads((tmp_path / "logs" / "rank0.json").read_text())
+    assert not (tmp_path / "logs" / "rank1.json").exists()  # rank 0 alone saves checkpoints
+    assert rec["world"] == 2 and rec["scale"] == 3.0 and rec["tag"] == "from-the-parent" and rec["process_group"] and rec["sub_dir"] == runs[0].name
+    assert rec["seen"] == [0, 2, 4, 6] and rec["val_seen"] == [0, 2, 4]  # rank 0's shard of the data / of the validation batches
+    assert rec["monitor"]["validation/stub"] == pytest.approx(3.0 * (0 + 1 + 2 + 3 + 4) / 5)  # mean over BOTH ranks' batches
+    assert (runs[0] / "checkpoints" / "last.ckpt").exists() and (tmp_path / "logs" / "prepared.txt").read_text() == "rank 0\n"
+    # a class defined inside a function cannot be found by the children: refused with a message, not a crash in N processes
+    from everyvoice_amd.lightning import _resolve_class
+
+    assert _resolve_class("tests.ddp_stub:Outer.StubConfig") is Outer.StubConfig
+    with pytest.raises(ValueError, match="module level"):
+        _resolve_class("tests.ddp_stub:f.<locals>.C")
+    with pytest.raises(TypeError, match="JSON"):
+        train_base_command(Outer.StubConfig, StubData, StubModel, "validation/stub", [], tmp_path / "cfg.json", accelerator="cpu", devices=2,
+                           model_kwargs={"process_group": object()})

@@ -144,3 +144,100 @@ def test_fastspeech2_module_contract_and_vocoder_matching_loop(dataset, cuda_dev
         assert torch.load(p["spec"]).shape == (80, p["frames"])
     with pytest.raises(NotImplementedError, match="textgrid"):
         pipeline.synthesize_helper(infer, [[1, 2]], None, None, 1.0, 0, ["textgrid"], vocoder_model=voc)
+
+
+def _small_fs2_model_dict(n_symbols=8, learn_alignment=True):
+    conf = dict(layers=2, heads=2, input_dim=64, feedforward_dim=128, conv_kernel_size=5, dropout=0.1)
+    vp = dict(n_layers=2, kernel_size=3, input_dim=64, n_bins=16, dropout=0.1)
+    return dict(encoder=conf, decoder=dict(conf), variance_predictors=dict(energy=vp, duration=dict(vp), pitch=dict(vp)), n_symbols=n_symbols, n_mels=80,
+                postnet_channels=32, learn_alignment=learn_alignment)
+
+
+def test_train_base_command_fastspeech2_over_a_preprocessed_directory(dataset, cuda_device):
+    """The FastSpeech2 side of the driver contract end to end (base_cli/helpers.py:173-195 with FastSpeech2Config /
+    FastSpeech2DataModule / FastSpeech2): the GPU preprocessor writes spec / energy / pitch AND the attention priors
+    (preprocessor.py:672-740) for token strings in the filelist, dataset statistics become the model's Stats, the data module
+    collates utterances (utils/heavy.py:24-36) into the step's batch, the loop validates in evaluation mode, checkpoints, and a
+    second call resumes weights + optimiser + counters."""
+    from everyvoice_amd import pipeline
+    from everyvoice_amd.fs2 import Stats, StatsInfo
+    from everyvoice_amd.fs2_dataset import FastSpeech2DataModule
+    from everyvoice_amd.lightning import FastSpeech2, FastSpeech2Config, train_base_command
+
+    root, _, kept = dataset
+    pre = pipeline.GpuPreprocessor(device=cuda_device)
+    g = torch.Generator().manual_seed(1)
+    items = []
+    for k in kept:
+        n_tok = 6 + int(torch.randint(0, 6, (1,), generator=g))
+        items.append(dict(basename=k["basename"], speaker="default", language="default", wav=k["wav"],
+                          character_tokens="/".join("abcd"[int(j)] for j in torch.randint(0, 4, (n_tok,), generator=g))))
+    kept2 = pre.process(items, root / "pre", overwrite=True)
+    for k in kept2:  # [frames, tokens] float64, the reference's file name
+        prior = torch.load(root / "pre" / "attn" / f"{k['basename']}--default--default--characters-attn-prior.pt", weights_only=True)
+        assert prior.dtype == torch.float64 and tuple(prior.shape) == (k["frames"], len(k["character_tokens"].split("/")))
+        assert torch.allclose(prior.sum(1), torch.ones(k["frames"], dtype=torch.float64), atol=1e-6)  # a distribution over tokens per frame
+    stats = pre.normalize_stats(root / "pre", *pre.compute_stats(root / "pre"))
+    st = Stats(pitch=StatsInfo(**{f: stats["pitch"][f] for f in ("min", "max", "std", "mean", "norm_min", "norm_max")}),
+               energy=StatsInfo(**{f: stats["energy"][f] for f in ("min", "max", "std", "mean", "norm_min", "norm_max")}))
+    pre.write_filelist(kept2, root / "fs2_train.psv")
+    pre.write_filelist(kept2[:3], root / "fs2_val.psv")
+    cfg = dict(model=_small_fs2_model_dict(), symbols=list("abcd"), preprocessing=dict(save_dir=str(root / "pre")),
+               training=dict(batch_size=2, train_data_workers=0, max_steps=4, val_check_interval=2, save_top_k_ckpts=1, training_filelist=str(root / "fs2_train.psv"),
+                             validation_filelist=str(root / "fs2_val.psv"), logger=dict(save_dir=str(root / "logs"), name="fs2")))
+    (root / "fs2.json").write_text(json.dumps(cfg))
+    calls = []
+    m = train_base_command(FastSpeech2Config, FastSpeech2DataModule, FastSpeech2, "validation/mel_loss", [], root / "fs2.json", accelerator="gpu", devices="1",
+                           model_kwargs=dict(stats=st, precision="f32"), calls=calls)
+    assert m.global_step == 4 and [c[1] for c in calls if c[0] == "validate"] == [2, 4]
+    assert m.logged["training/total_loss"] > 0 and m.logged["validation/mel_loss"] > 0 and "training/attn_ctc_loss" in m.logged
+    run = next((root / "logs" / "fs2" / "base").iterdir())
+    ck = torch.load(run / "checkpoints" / "last.ckpt", weights_only=True)
+    json.dumps(ck["hyper_parameters"])
+    steps_per_epoch = len(kept2) // 2
+    # "epoch" = complete epochs behind the checkpoint: step 4 falls inside epoch (4 - 1) // steps_per_epoch, which resume restarts
+    assert ck["model_info"] == {"name": "FastSpeech2", "version": "1.0"} and ck["global_step"] == 4 and ck["epoch"] == 3 // steps_per_epoch
+    assert "training_filelist" not in ck["hyper_parameters"]["config"]["training"] and ck["hyper_parameters"]["config"]["symbols"] == list("abcd")
+    m2 = train_base_command(FastSpeech2Config, FastSpeech2DataModule, FastSpeech2, "validation/mel_loss",
+                            [f"training.finetune_checkpoint={json.dumps(str(run / 'checkpoints' / 'last.ckpt'))}", "training.max_steps=6"], root / "fs2.json",
+                            accelerator="gpu", devices="1", model_kwargs=dict(precision="f32"))
+    assert m2.global_step == 6 and m2.trainer_.params.step == 6 and m2.stats.pitch.mean == pytest.approx(st.pitch.mean)
+    # a changed optimiser block restarts the optimiser -- also when load_from_checkpoint already built the trainer on a device
+    m3 = train_base_command(FastSpeech2Config, FastSpeech2DataModule, FastSpeech2, "validation/mel_loss",
+                            [f"training.finetune_checkpoint={json.dumps(str(run / 'checkpoints' / 'last.ckpt'))}", "training.max_steps=1",
+                             "training.optimizer.warmup_steps=7"], root / "fs2.json", accelerator="gpu", devices="1",
+                            model_kwargs=dict(precision="f32", device=str(cuda_device)))
+    assert m3.global_step == 1 and m3.trainer_.params.step == 1
+
+
+def test_fastspeech2_validation_runs_in_evaluation_mode(cuda_device):
+    """validation_step: dropout off (two calls agree bit for bit), BatchNorm on its running statistics and leaving them, the step
+    counters and the gradients' owner state alone (the reference validates under model.eval()); a training step in between still
+    moves the statistics."""
+    from everyvoice_amd.fs2 import FastSpeech2ModelConfig
+    from everyvoice_amd.lightning import FastSpeech2, FastSpeech2Config, _dataclass_from_dict
+
+    mc = _dataclass_from_dict(FastSpeech2ModelConfig, _small_fs2_model_dict(n_symbols=20, learn_alignment=False))
+    model = FastSpeech2(FastSpeech2Config(model=mc), device=cuda_device, precision="f32")
+    g = torch.Generator().manual_seed(3)
+    L = 12
+    durs = torch.randint(1, 4, (2, L), generator=g)
+    T = int(durs.sum(1).max())
+    batch = dict(ids=torch.randint(1, 20, (2, L), generator=g), lens=torch.tensor([L, L]), durations=durs, mel=torch.randn(2, T, 80, generator=g),
+                 pitch=torch.randn(2, L, generator=g), energy=torch.randn(2, L, generator=g))
+    model.training_step(batch, 0)
+    tr = model.trainer_
+    before = {k: v.clone() for k, v in tr.state_dict().items()}
+    m_before, batches = tr.params.m.clone(), [bn.batches for bn in tr._bn]
+    a = model.validation_step(batch, 0)
+    b = model.validation_step(batch, 1)
+    assert a == b and a > 0 and model.global_step == 1
+    after = tr.state_dict()
+    assert all(torch.equal(v, after[k]) for k, v in before.items()), "validation changed parameters or BatchNorm statistics"
+    assert torch.equal(m_before, tr.params.m) and batches == [bn.batches for bn in tr._bn]
+    # evaluation mode is not training mode with the same inputs: batch statistics vs running statistics
+    train_mel = float(tr.forward_backward(batch)["mel"])
+    assert abs(train_mel - a) > 1e-6
+    model.training_step(batch, 1)
+    assert not torch.equal(before["encoder.conformer_layers.0.conv_module.sequential.3.running_mean"],
+                           tr.state_dict()["encoder.conformer_layers.0.conv_module.sequential.3.running_mean"])

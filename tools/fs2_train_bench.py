@@ -38,12 +38,14 @@ def main():
     B = int(os.environ.get("EVMI_FS2_B", "32"))
     from everyvoice_amd.fs2 import FastSpeech2ModelConfig
     learn = os.environ.get("EVMI_FS2_LEARN_ALIGNMENT", "1") == "1"
-    tr = FastSpeech2Trainer(FastSpeech2ModelConfig(learn_alignment=learn), device=dev, precision=os.environ.get("OPERANDS", "f32"))
+    tr = FastSpeech2Trainer(FastSpeech2ModelConfig(learn_alignment=learn), device=dev, precision=os.environ.get("OPERANDS", "f32"),
+                            use_graph=os.environ.get("EVMI_FS2_GRAPH", "1") == "1")
     batch, T_i = training_batch(B, learn_alignment=learn, device=dev)
     print(f"parameters {tr.params.numel():,}")
-    for _ in range(2):
+    for _ in range(4):  # two eager steps, the capture, one replay
         losses = tr.training_step(batch)
     torch.cuda.synchronize()
+    print(f"graph: {tr.last_step_was_graph}" + (f" (capture failed: {tr._graph_failed})" if tr._graph_failed else ""))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
     t0 = time.perf_counter()
     for _ in range(n):
