@@ -46,8 +46,8 @@ class Var:
 class _Cut:
     """A point of the tape where backward may be interrupted (``Tape.backward_segments``); ``join`` runs before the interruption."""
 
-    def __init__(self, join=None):
-        self.join = join
+    def __init__(self, join=None, tag=None):
+        self.join, self.tag = join, tag
 
 
 class Tape:
@@ -57,10 +57,11 @@ class Tape:
     def record(self, fn) -> None:
         self._ops.append(fn)
 
-    def cut(self, join=None) -> None:
+    def cut(self, join=None, tag=None) -> None:
         """Mark this point: ``backward_segments`` stops here (after everything recorded LATER has run its backward).  Used where a
-        gradient bucket becomes final and its all-reduce -- which is not part of a captured HIP graph -- has to be issued."""
-        self._ops.append(_Cut(join))
+        gradient bucket becomes final and its all-reduce -- which is not part of a captured HIP graph -- has to be issued.
+        ``tag`` is handed to the consumer (``backward_segments`` yields it), e.g. the bucket's range in the flat buffer."""
+        self._ops.append(_Cut(join, tag))
 
     def backward(self) -> None:
         for fn in reversed(self._ops):
@@ -69,15 +70,18 @@ class Tape:
         ops.wgrad_join()  # weight-gradient kernels queued beside this chain (ops.side_wgrad) are part of this backward
         self._ops.clear()
 
-    def backward_segments(self):
+    def backward_segments(self, stop=None):
         """Generator form: every ``next()`` runs the backward up to the next cut (weight-gradient kernels queued beside the chain
-        are joined first, then the cut's own ``join``); the last one runs to the start of the tape."""
+        are joined first, then the cut's own ``join``) and yields the cut's tag; the last one runs to the start of the tape and
+        ends the generator.  ``stop(tag) -> bool`` chooses the cuts to honour (default: all)."""
         for fn in reversed(self._ops):
             if isinstance(fn, _Cut):
+                if stop is not None and not stop(fn.tag):
+                    continue
                 ops.wgrad_join()
                 if fn.join is not None:
                     fn.join()
-                yield
+                yield fn.tag
             else:
                 fn()
         ops.wgrad_join()

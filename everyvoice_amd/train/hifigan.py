@@ -783,10 +783,22 @@ class HiFiGANTrainer:
                 b.finish(ls)
             if reducer_box[0] is not None:
                 reducer_box[0].launch(*self._bucket_range(group, layers))
+        tape.cut(tag=self._bucket_range(group, layers))  # (backward reaches `done` first, then this point)
         tape.record(done)
 
     def _phase_d_backward(self, ctx, reducer):
         """Discriminator step up to its gradients: the discriminators side by side, the spectral-norm scale's two calls too."""
+        self._phase_d_prelude(ctx)
+        self._phase_d_group(ctx, range(len(self.discriminators())), reducer)
+        self._phase_d_epilogue(ctx)
+
+    def d_bucket_groups(self):
+        """The discriminators as gradient-bucket groups for a captured data-parallel step: [period discriminators] (164 MB of
+        gradients: reduced UNDER the second group's forward + backward), [scale discriminators] (118 MB)."""
+        n_p = len(self.mpd)
+        return [list(range(n_p)), list(range(n_p, n_p + len(self.msd)))]
+
+    def _phase_d_prelude(self, ctx):
         y, y_hat, B = ctx["y"], ctx["y_hat"], ctx["B"]
         self.d_params.zero_grad()
         for layer in ctx["d_layers"]:
@@ -796,15 +808,22 @@ class HiFiGANTrainer:
         pair_t = torch.empty(1, 2 * B, T, device=self.device, dtype=torch.float32)
         ops.copy(y, out=pair_t[:, :B])
         ops.copy(y_hat.data, out=pair_t[:, B:])  # y_hat.detach()
-        d_tape = ag.Tape()
         pair = ag.Var(pair_t, needs_grad=False)
         pairs = [pair]
+        pool_tape = ag.Tape()  # (the pyramid of a gradient-free input: nothing to run backward)
         for _ in self.msd[1:]:
-            pairs.append(ag.avgpool4s2(d_tape, pairs[-1]))
+            pairs.append(ag.avgpool4s2(pool_tape, pairs[-1]))
+        ctx["d_ins"] = [pair] * len(self.mpd) + pairs
+
+    def _phase_d_group(self, ctx, idxs, reducer):
+        """Forward + backward of the discriminators `idxs`, side by side; every one's gradient bucket is finished (and, eagerly,
+        its all-reduce launched) as its stream leaves it."""
+        y, y_hat, ins = ctx["y"], ctx["y_hat"], ctx["d_ins"]
+        d_tape = ag.Tape()
         ds = self.discriminators()
-        ins = [pair] * len(self.mpd) + pairs
         fns = []
-        for i, d in enumerate(ds):
+        for i in idxs:
+            d = ds[i]
             if any(isinstance(layer, SNConv) for layer in d.layers()):
                 # its bucket closes on the main stream once both chains' backward has been joined
                 self._bucket_hook(d_tape, self.d_params, d.layers(), reducer)
@@ -813,11 +832,14 @@ class HiFiGANTrainer:
             else:
                 fns.append(lambda sub, i=i, d=d: self._d_branch(sub, i, d, ins[i], reducer))
         parallel_section(d_tape, self.branches, fns)
-        d_tape.backward()  # every discriminator's bucket is finished (and its all-reduce launched) as its stream leaves it
+        d_tape.backward()
+
+    def _phase_d_epilogue(self, ctx):
         for layer in self._sn_layers():
             layer.release()  # every stream has been joined: the prepared spectral-norm tensors may go
         ops.scalar_reduce(2, self._slots[0], None, self._loss_buf[0:1])
         ops.scalar_reduce(2, self._slots[3], None, self._loss_buf[0:1], accumulate=True)
+        ctx.pop("d_ins", None)
         if self.keep_grads:
             self.last_grads["d"] = {k: v.clone() for k, v in self.d_params.gradients().items()}
 
@@ -883,6 +905,9 @@ class HiFiGANTrainer:
         if y_hat_in.grad is not None:
             total = ops.axpby(1.0, total, 1.0, y_hat_in.grad, out=total)
         y_hat.grad = total
+        if ctx.get("g_segmented"):  # captured data-parallel step: the generator's backward is run bucket by bucket by the caller
+            ctx["g_segments"] = ctx["g_tape"].backward_segments(ctx.get("g_stop"))
+            return
         ctx["g_tape"].backward()  # buckets: conv_post, the upsampling stages, conv_pre
         if self.keep_grads:
             self.last_grads["g"] = {k: v.clone() for k, v in self.g_params.gradients().items()}
@@ -934,13 +959,10 @@ class HiFiGANTrainer:
             self._graphs[key] = entry
         ops.copy(mel_bct.to(torch.float32).contiguous(), out=entry["mel"])
         ops.copy(audio_bct.to(torch.float32).contiguous(), out=entry["audio"])
-        graphs = entry["graphs"]
-        graphs[0].replay()
-        if len(graphs) > 1:
-            self._allreduce_whole(self.d_params)
-            graphs[1].replay()
-            self._allreduce_whole(self.g_params)
-            graphs[2].replay()
+        for g, after in zip(entry["graphs"], entry["after"]):
+            g.replay()
+            if after is not None:
+                after()  # the gradient exchange at this bucket boundary: RCCL calls sit between the captured stretches
         # the host-side step counters follow the device-side ones the graph increments
         if not warm:
             self.d_params._step += 1
@@ -951,45 +973,125 @@ class HiFiGANTrainer:
         if self.pg is not None:
             allreduce_mean_(group.grad, self.pg if self.pg is not True else None, lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc))
 
+    # smallest generator-side bucket (floats) worth a stretch boundary of its own: smaller ones ride with the next
+    MIN_G_BUCKET = 1 << 20
+
     def _capture(self, key, mel_bct, audio_bct, warm):
+        """One GPU: the whole step is ONE graph.  Data parallel: the step is captured in stretches that end where a gradient
+        bucket becomes final -- [generator forward + period discriminators] [scale discriminators] [discriminator update +
+        generator-step discriminator pass + generator backward down to the first large bucket] ... [generator update] -- and
+        between two stretches that bucket's all-reduce is launched on a side stream (RCCL calls are not captured), so it runs
+        UNDER the next stretch; only an optimiser waits for its buckets (the reference: DDP buckets firing inside
+        backward, base_cli/helpers.py:252-270)."""
         mel_s = mel_bct.to(torch.float32).contiguous().clone()
         audio_s = audio_bct.to(torch.float32).contiguous().clone()
         steps = (self.g_params.step, self.d_params.step)
         torch.cuda.synchronize(self.device)
         pool = torch.cuda.graph_pool_handle()
-        graphs = []
+        graphs, after = [], []
         ctx = {}
 
-        def cap(fn):
+        def cap(fn, then=None):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=pool, stream=self._stream, capture_error_mode="thread_local"):
                 fn()
             graphs.append(g)
+            after.append(then)
 
-        def part_a():
+        def whole():
             ctx.update(self._phase_generator_forward(mel_s, audio_s))
             if not warm:
                 self._phase_d_backward(ctx, None)
+                self._phase_d_update(ctx)
+            self._phase_g_backward(ctx, adversarial=not warm)
+            self._phase_g_update(ctx)
 
-        def part_b():
+        try:
+            if self.pg is None:
+                cap(whole)
+            else:
+                self._capture_data_parallel(cap, ctx, mel_s, audio_s, warm)
+        finally:
+            ctx.clear()
+            # capturing does not execute: the host-side counters the phases bumped are put back (replay bumps them again)
+            self.g_params._step, self.d_params._step = steps
+        return dict(graphs=graphs, after=after, mel=mel_s, audio=audio_s)
+
+    def _capture_data_parallel(self, cap_raw, ctx, mel_s, audio_s, warm):
+        scale = lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc)  # noqa: E731
+        pg = self.pg if self.pg is not True else None
+        d_red, g_red = BucketReducer(self.d_params.grad, pg, scale), BucketReducer(self.g_params.grad, pg, scale)
+        self._dp_reducers = (d_red, g_red)  # (kept: their side streams live across replays)
+        thens = []
+
+        def cap(fn):
+            cap_raw(fn, lambda i=len(thens): thens[i] and thens[i]())
+            thens.append(None)
+
+        def first():
+            ctx.update(self._phase_generator_forward(mel_s, audio_s))
+            if not warm:
+                self._phase_d_prelude(ctx)
+
+        if warm:
+            cap(first)
+        else:
+            groups = self.d_bucket_groups()
+            ds = self.discriminators()
+            d_front = min(self.d_params.offset_of(n) for n in self.d_params.names())  # alignment padding in front, if any
+            for gi, idxs in enumerate(groups):
+                lo, hi = self._bucket_range(self.d_params, [layer for i in idxs for layer in ds[i].layers()])
+                last = gi == len(groups) - 1
+
+                def stretch(gi=gi, idxs=idxs, last=last):
+                    if gi == 0:
+                        first()
+                    self._phase_d_group(ctx, idxs, None)
+                    if last:
+                        self._phase_d_epilogue(ctx)
+
+                cap(stretch)
+                if last:  # the discriminators' optimiser comes next: wait for every bucket, scale by 1 / world
+                    thens[-1] = lambda lo=lo, hi=hi: (d_red.launch(lo, hi), d_red.launch(0, d_front), d_red.finish())
+                else:  # runs on the side stream UNDER the next group's forward + backward
+                    thens[-1] = lambda lo=lo, hi=hi: d_red.launch(lo, hi)
+        # generator step: the first stretch runs the discriminators' update, the generator-step discriminator pass, the losses
+        # and the generator's backward down to the first bucket boundary worth a cut; then one stretch per further bucket
+        ctx["g_segmented"] = True
+        pending = [0]
+
+        def stop(tag):  # small buckets (conv_post, the narrow late stages) ride with the next one
+            pending[0] += tag[1] - tag[0]
+            if pending[0] >= self.MIN_G_BUCKET:
+                pending[0] = 0
+                return True
+            return False
+
+        ctx["g_stop"] = stop
+        state = {"cut": None, "done": False}
+
+        def advance():
+            try:
+                state["cut"] = next(ctx["g_segments"])[0]  # gradients from here to the previous cut are final
+            except StopIteration:
+                state["cut"], state["done"] = 0, True
+
+        def g_first():
             if not warm:
                 self._phase_d_update(ctx)
             self._phase_g_backward(ctx, adversarial=not warm)
+            advance()
 
-        def part_c():
-            self._phase_g_update(ctx)
-
-        if self.pg is None:
-            cap(lambda: (part_a(), part_b(), part_c()))
-        else:
-            cap(part_a)
-            cap(part_b)
-            cap(part_c)
-        ctx.clear()
-        # capturing does not execute: the host-side counters the phases bumped are put back (replay bumps them again)
-        self.g_params._step, self.d_params._step = steps
-        return dict(graphs=graphs, mel=mel_s, audio=audio_s)
-
+        hi = self.g_params.grad.numel()
+        cap(g_first)
+        while True:
+            lo, done = state["cut"], state["done"]
+            thens[-1] = (lambda lo=lo, hi=hi: (g_red.launch(lo, hi), g_red.finish())) if done else (lambda lo=lo, hi=hi: g_red.launch(lo, hi))
+            hi = lo
+            if done:
+                break
+            cap(advance)
+        cap(lambda: self._phase_g_update(ctx))
 
 def _to_cbt_kernel(x_bct: torch.Tensor) -> torch.Tensor:
     """[B, C, T] -> [C, B, T] with library copy kernels (one strided row-block copy per item: layout change only)."""

@@ -617,9 +617,10 @@ def test_bucketed_allreduce_path_on_rccl_world_of_one(cuda_device):
 
 
 def test_graph_mode_under_data_parallelism_on_rccl_world_of_one(cuda_device):
-    """use_graph=True with a process group: the step is three graphs (up to the discriminators' gradients | their update + the
-    generator's backward | the generator's update) with the two flat-buffer all-reduces issued eagerly between them -- on a
-    one-rank "nccl" group five steps must end exactly where five plain single-GPU steps do."""
+    """use_graph=True with a process group: the step is captured in stretches that end at gradient-bucket boundaries (period
+    discriminators | scale discriminators | discriminator update + generator backward down to its first large bucket | ... |
+    generator update), each bucket's RCCL all-reduce launched on a side stream between two replays so that it runs under the next
+    stretch -- on a one-rank "nccl" group five steps must end exactly where five plain single-GPU steps do."""
     import os
     import socket
 
@@ -642,7 +643,8 @@ def test_graph_mode_under_data_parallelism_on_rccl_world_of_one(cuda_device):
         dp = HiFiGANTrainer(device=cuda_device, seed=5, process_group=True, use_graph=True)
         out_dp = [dp.training_step(mel, y) for _ in range(5)]
         assert dp._graph_failed is None, dp._graph_failed
-        assert [len(e["graphs"]) for e in dp._graphs.values()] == [3]
+        (entry,) = dp._graphs.values()
+        assert len(entry["graphs"]) >= 5 and sum(a is not None for a in entry["after"]) == len(entry["graphs"])  # cut at bucket boundaries
     finally:
         dist.destroy_process_group()
     assert out_plain == out_dp
