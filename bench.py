@@ -251,11 +251,12 @@ def cpu_baseline(frames: int, batch: int) -> dict:
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     best = None
     with torch.no_grad():
-        for n in sorted({min(avail, c) for c in (8, 16, 32, 64, avail)}):
+        probe = mel[:1, :, : min(256, mel.shape[2])]  # long enough that the thread count matters as it does on the sample itself
+        for n in sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)}):
             torch.set_num_threads(n)
-            ref(mel[:1, :, :8])
+            ref(probe)
             t0 = time.perf_counter()
-            ref(mel[:1, :, :8])
+            ref(probe)
             dt = time.perf_counter() - t0
             if best is None or dt < best[0]:
                 best = (dt, n)
@@ -273,6 +274,17 @@ def cpu_baseline(frames: int, batch: int) -> dict:
         "sample": f"oracle/hifigan_ref.py GeneratorRef fp32, torch {torch.__version__} CPU, {cores} threads, "
                   f"mel [{batch},80,{frames}] slice of the bench input ({wav.numel()} samples in {dt:.2f} s)",
     }
+
+
+def _median_time(fn, warmup: int, repeats: int) -> float:
+    for _ in range(warmup):
+        fn()
+    ts = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
 
 
 def cpu_baseline_train(cores: int, batch: int = 16) -> dict:
@@ -308,13 +320,10 @@ def cpu_baseline_train(cores: int, batch: int = 16) -> dict:
         (generator_loss_ref(g1) + generator_loss_ref(g2) + feature_loss_ref(fr1, fg1) + feature_loss_ref(fr2, fg2) + loss_mel).backward()
         opt_g.step()
 
-    step()
-    t0 = time.perf_counter()
-    step()
-    dt = time.perf_counter() - t0
+    dt = _median_time(step, warmup=1, repeats=3)
     return {"value": round(batch / 16.0 / dt, 4), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/hifigan_ref.py full GAN step (torch autograd + AdamW) on {batch} segments of 8192 samples, {cores} threads: "
-                      f"{dt:.2f} s; scaled to 16 segments per step"}
+                      f"{dt:.2f} s (median of 3 after 1 warm-up); scaled to 16 segments per step"}
 
 
 def cpu_baseline_fs2(cores: int, batch: int = 32, repeats: int = 10) -> dict:
@@ -338,6 +347,15 @@ def cpu_baseline_fs2(cores: int, batch: int = 32, repeats: int = 10) -> dict:
     frames = int(t_i[:batch].sum())
     return {"value": round(frames / dt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"oracle/fs2_ref.py FastSpeech2Ref fp32, first {batch} utterances of the bench batch ({frames} frames in {dt:.2f} s, mean of {repeats} passes), {cores} threads"}
+
+
+def _graph_info(trainer) -> dict:
+    """Whether the timed steps were HIP-graph replays (and of how many captured stretches), or why not."""
+    failed = getattr(trainer, "_graph_failed", None)
+    entries = list(getattr(trainer, "_graphs", {}).values())
+    used = bool(entries) and failed is None
+    return {"used": used, "reason": failed if failed else (None if used else "no shape was captured (use_graph off or too few steps)"),
+            "stretches": [len(e["graphs"]) for e in entries]}
 
 
 def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
@@ -368,11 +386,27 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
         losses.update(trainer.training_step(mel, y))
 
     from everyvoice_amd.train import autograd as ag
+    from everyvoice_amd.train import ops as train_ops
 
     ag.activation_elements(reset=True)
-    step()  # (eager: the graph is captured on a later warm-up step) -- counts the activations one step creates
+    train_ops.flop_counter(reset=True)
+    step()  # (eager: the graph is captured on a later warm-up step) -- counts the activations and the contractions one step issues
     act_elems = ag.activation_elements(reset=True)
+    counted_flops = train_ops.flop_counter(reset=True)
     elapsed = timed_region(step, args.train_steps, args.train_warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    graph_info = _graph_info(trainer)
+    comm_ms = None
+    if use_dist:  # the same steps again with events around every bucket's all-reduce (on its side stream): exchange ms per step
+        reds = getattr(trainer, "_dp_reducers", ())
+        for r in reds:
+            r.timing = []
+        n_comm = max(3, args.train_steps // 5)
+        for _ in range(n_comm):
+            step()
+        torch.cuda.synchronize(dev)
+        comm_ms = round(sum(r.comm_ms() for r in reds) / n_comm, 3) if reds else None
+        for r in reds:
+            r.timing = None
     # the other precision beside it (same trainer object, fewer steps)
     other = "f32" if prec == "bf16" else "bf16"
     trainer.precision = other
@@ -383,11 +417,15 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     del trainer
     trainer_mr = HiFiGANTrainer(device=dev, process_group=True if use_dist else None, precision=prec, reconstruction_loss="mel+mrstft", use_graph=True)
     losses_mr = {}
-    n_mr = max(3, args.train_steps // 5)
-    elapsed_mr = timed_region(lambda: losses_mr.update(trainer_mr.training_step(mel, y)), n_mr, 4, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    n_mr = args.train_steps
+    elapsed_mr = timed_region(lambda: losses_mr.update(trainer_mr.training_step(mel, y)), n_mr, args.train_warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    graph_info_mr = _graph_info(trainer_mr)
     params = {"generator": trainer_mr.g_params.numel(), "discriminators": trainer_mr.d_params.numel()}
     del trainer_mr
-    flop_per_step = 25.8e6 * B * S  # per GPU
+    # algorithmic FLOPs of one step per GPU: the contractions the tape issued in one eager step, 2 per multiply-add, convolutions at
+    # their dense B * T_out * C_out * (C_in / groups) * k products (ops.flop_counter) -- SURVEY.md 8(d)'s estimate was 25.8 MFLOP per
+    # segment sample (3.38 TFLOP per step)
+    flop_per_step = counted_flops
     tflops = flop_per_step * args.train_steps / elapsed / 1e12
     # bf16 mode: forward and input-gradient convolutions on the bf16 matrix cores (2.5 PFLOP/s dense), weight gradients still on
     # the fp32 ones (157 TFLOP/s): priced against the bf16 peak, the stricter denominator
@@ -398,7 +436,8 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     # three forward reads, weight-gradient write, weight-norm backward (5), optimiser (7 streams) -- 19 passes
     algorithmic_bytes = 4 * (5 * act_elems + 19 * n_params)
     roof = {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
-            "traffic": None, "flop_per_step_per_gpu": flop_per_step, "scope": "whole training step",
+            "traffic": None, "flop_per_step_per_gpu": flop_per_step, "flop_count": "exact: counted from the step's own launches (ops.flop_counter)",
+            "survey_estimate_flop_per_step": 25.8e6 * B * S, "scope": "whole training step",
             "algorithmic_bytes_per_step": algorithmic_bytes, "activation_elements_per_step": act_elems,
             "algorithmic_hbm_gbs": round(algorithmic_bytes * args.train_steps / elapsed / 1e9, 1)}
     pmc_files = sorted((ROOT / "profiles").glob("*train_pmc_summary.json"))
@@ -439,7 +478,10 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
         "dtype": prec,
         "other_precision": {"dtype": other, "value": round(n_other / elapsed_other, 3), "unit": "steps/s", "ms_per_step": round(elapsed_other / n_other * 1e3, 2), "steps": n_other},
         "with_mrstft_loss": {"reconstruction_loss": "mel+mrstft", "value": round(n_mr / elapsed_mr, 3), "unit": "steps/s",
-                             "ms_per_step": round(elapsed_mr / n_mr * 1e3, 2), "steps": n_mr, "g_stft": round(losses_mr.get("g_stft", 0.0), 4)},
+                             "ms_per_step": round(elapsed_mr / n_mr * 1e3, 2), "steps": n_mr, "warmup": args.train_warmup,
+                             "g_stft": round(losses_mr.get("g_stft", 0.0), 4), "graph": graph_info_mr},
+        "graph": graph_info,
+        "allreduce_ms_per_step": comm_ms,
         "parallelism": f"dp{world}" + (" (RCCL all-reduce of 2 flat gradient buffers per step, bucketed, overlapped with backward)" if world > 1 else ""),
         "params": params,
         "last_losses": {k: round(v, 4) for k, v in losses.items()},
@@ -499,7 +541,7 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
 
     prec = args.train_precision
     torch.cuda.empty_cache()
-    tr = FastSpeech2Trainer(device=dev, process_group=True if use_dist else None, precision=prec)  # default config: learn_alignment on
+    tr = FastSpeech2Trainer(device=dev, process_group=True if use_dist else None, precision=prec, use_graph=True)  # default config: learn_alignment on
     batch, t_i = training_batch(32, 1234 + rank, device=dev)
     out = {}
 
@@ -510,7 +552,9 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     elapsed = timed_region(step, steps, warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     other = "f32" if prec == "bf16" else "bf16"
     tr.precision = other
-    elapsed_other = timed_region(step, 3, 1, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    graph_info = _graph_info(tr)
+    n_other = 10
+    elapsed_other = timed_region(step, n_other, 4, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
     tr.precision = prec
     flops = 3.0 * forward_flops(batch["lens"], t_i, int(batch["ids"].shape[1]), int(t_i.max()), 32)
     tflops = flops * steps / elapsed / 1e12
@@ -518,8 +562,9 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     return {"metric": "fastspeech2_train_steps_per_sec_bs32", "value": round(steps / elapsed, 3), "unit": "steps/s",
             "ms_per_step": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": warmup, "batch_per_gpu": 32, "global_batch": 32 * world,
             "frames_per_sec": round(world * int(t_i.sum()) * steps / elapsed, 1), "scaling": "weak", "dtype": prec,
-            "other_precision": {"dtype": other, "value": round(3 / elapsed_other, 3), "unit": "steps/s", "ms_per_step": round(elapsed_other / 3 * 1e3, 2), "steps": 3},
-            "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient buffer)" if world > 1 else ""),
+            "other_precision": {"dtype": other, "value": round(n_other / elapsed_other, 3), "unit": "steps/s", "ms_per_step": round(elapsed_other / n_other * 1e3, 2), "steps": n_other},
+            "graph": graph_info,
+            "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient buffer in two buckets, the first under the rest of backward)" if world > 1 else ""),
             "params": tr.params.numel(), "last_losses": {k: round(float(v), 4) for k, v in out["losses"].items()},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
                          "traffic": None, "flop_per_step": flops, "scope": "whole step (forward + backward + optimiser)"}}
@@ -546,13 +591,10 @@ def cpu_baseline_fs2_train(cores: int, batch: int = 8) -> dict:
         torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
         opt.step()
 
-    step()
-    t0 = time.perf_counter()
-    step()
-    dt = time.perf_counter() - t0
+    dt = _median_time(step, warmup=1, repeats=3)
     return {"value": round(batch / 32.0 / dt, 4), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/fs2_ref.py training step (torch autograd + clipping + AdamW) on the first {batch} utterances of the bench batch, "
-                      f"{cores} threads: {dt:.2f} s; scaled to 32 utterances per step"}
+                      f"{cores} threads: {dt:.2f} s (median of 3 after 1 warm-up); scaled to 32 utterances per step"}
 
 
 def main(argv=None) -> int:
@@ -611,11 +653,24 @@ def main(argv=None) -> int:
     # the other arithmetic beside it (the reference computes in fp32; bf16 operands with fp32 accumulation are SURVEY 8(d) C2's contract)
     other = "f32" if args.precision == "bf16" else "bf16"
     model_o = upstream_init_generator(other).to(dev).eval()
-    n_other = 2
-    elapsed_o = timed_region(lambda: model_o.generator(mel), n_other, 1, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    n_other, w_other = 20, 5
+    elapsed_o = timed_region(lambda: model_o.generator(mel), n_other, w_other, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    flops_step = 2.0 * gen.macs_per_sample() * samples_per_step
+    peak_o = 157.0 if other == "f32" else MFMA_PEAK_TFLOPS_BF16
+    tf_o = flops_step * n_other / elapsed_o / 1e12
     other_precision = {"dtype": other, "value": round(world * samples_per_step * n_other / elapsed_o, 1), "unit": "samples/s",
-                       "ms_per_step": round(elapsed_o / n_other * 1e3, 3), "steps": n_other}
+                       "ms_per_step": round(elapsed_o / n_other * 1e3, 3), "steps": n_other, "warmup": w_other,
+                       "roofline": {"bound": "mfma", "achieved": round(tf_o, 2), "peak": peak_o, "unit": "TFLOP/s", "frac": round(tf_o / peak_o, 4),
+                                    "scope": "whole forward" + (" on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: 157 TFLOP/s nominal)" if other == "f32" else "")}}
     del model_o
+    # length sensitivity: the same batch of 32 at 128 and 566 frames, in the headline precision
+    lengths = {}
+    for frames_l in (128, 566):
+        mel_l = synthetic_mel(args.batch, frames_l, 1234 + rank).to(dev)
+        el = timed_region(lambda: gen(mel_l), 20, 5, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+        lengths[str(frames_l)] = {"value": round(world * args.batch * frames_l * gen.hop * 20 / el, 1), "unit": "samples/s", "ms_per_step": round(el / 20 * 1e3, 3),
+                                  "steps": 20, "warmup": 5}
+        del mel_l
 
     train = None
     if not args.no_train:
@@ -661,6 +716,7 @@ def main(argv=None) -> int:
             "whole_job_tflops": round(value * flops_per_sample / 1e12, 2),
             "realtime_factor": round(value / 22050.0, 1),
             "other_precision": other_precision,
+            "length_sensitivity": lengths,
             "roofline": roof,
         }
         if use_dist:

@@ -361,6 +361,7 @@ class BucketReducer:
         self.flat, self.pg, self.scale_fn = flat_grad, process_group, scale_fn
         self.works = []
         self.stream = torch.cuda.Stream(flat_grad.device) if flat_grad.is_cuda else None
+        self.timing = None  # a list: every launch appends (start, end) events on the side stream (bench.py: all-reduce ms per step)
 
     def launch(self, lo: int, hi: int) -> None:
         import torch.distributed as dist
@@ -373,7 +374,16 @@ class BucketReducer:
             ready.record(torch.cuda.current_stream(self.flat.device))  # gradients of this bucket are final from here on
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ready)
-                self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.timing is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
+                # RCCL: enqueued behind `ready` on the side stream, runs while the launching stream goes on with backward;
+                # wait() orders the side stream behind the collective (it does not block the host under "nccl")
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True).wait()
+                if self.timing is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self.stream)
+                    self.timing.append((e0, e1))
         else:
             self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -386,6 +396,16 @@ class BucketReducer:
         if self.stream is not None:
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
         self.scale_fn(self.flat, 1.0 / dist.get_world_size(self.pg))
+
+    def comm_ms(self, reset: bool = True) -> float:
+        """Summed device time of the recorded all-reduces (synchronises)."""
+        if not self.timing:
+            return 0.0
+        self.timing[-1][1].synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.timing)
+        if reset:
+            self.timing.clear()
+        return ms
 
 
 class HiFiGANTrainer:

@@ -24,6 +24,23 @@ def _chk(rc: int, what: str) -> None:
     _lib.check(rc, what)
 
 
+# Algorithmic FLOPs of the contractions issued since the last reset (2 per multiply-add; convolutions count their dense
+# B * T_out * C_out * (C_in / groups) * k products whichever kernel serves them): bench.py prices a training step with the count
+# of one eager step instead of an estimate.
+_FLOPS = [0.0]
+
+
+def flop_counter(reset: bool = False) -> float:
+    n = _FLOPS[0]
+    if reset:
+        _FLOPS[0] = 0.0
+    return n
+
+
+def _count_conv(B, t_out, cout, cin_g, k):
+    _FLOPS[0] += 2.0 * B * t_out * cout * cin_g * k
+
+
 class Workspace:
     """Grow-only scratch buffers keyed by (role, stream): launches on different HIP streams may overlap on the device, so every
     stream has its own (unfold matrices, packed operands and weight fragments are large and short-lived).  They are grown
@@ -53,12 +70,14 @@ def gemm(a, b, out, ta=False, tb=False, alpha=1.0, beta=0.0, M=None, N=None, K=N
         M, K = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
         N = b.shape[0] if tb else b.shape[1]
         lda, ldb, ldc = a.stride(0), b.stride(0), out.stride(0)
+    _FLOPS[0] += 2.0 * M * N * K
     _chk(lib.evmi_gemm_f32(int(ta), int(tb), M, N, K, alpha, a.data_ptr(), lda, b.data_ptr(), ldb, beta, out.data_ptr(), ldc, _s(out)), "evmi_gemm_f32")
     return out
 
 
 def gemm_groups(a, b, out, groups, M, N, K, lda, ldb, ldc, sa, sb, sc, ta=False, tb=False, alpha=1.0, beta=0.0):
     """``groups`` independent GEMMs at fixed element strides (one per convolution group)."""
+    _FLOPS[0] += 2.0 * groups * M * N * K
     _chk(_lib.load().evmi_gemm_batched_f32(int(ta), int(tb), M, N, K, alpha, a.data_ptr(), lda, sa, b.data_ptr(), ldb, sb, beta,
                                            out.data_ptr(), ldc, sc, groups, _s(out)), "evmi_gemm_batched_f32")
     return out
@@ -221,6 +240,7 @@ def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=No
     if out is None:
         out = torch.empty(cout, B, t_conv, device=x.device, dtype=torch.float32)
     lib = _lib.load()
+    _count_conv(B, t_conv if n_out is None else n_out, cout, cin_g, k)
     if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"]:
         n_eff = t_conv if n_out is None else n_out
         pk_elems = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t_in, cout, n_eff, k, stride, pad, dil, groups)
@@ -255,6 +275,7 @@ def conv1d_fused_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, act=ACT_NONE,
     if _packed() and CONV_BACKEND["fwd"] == "mfma":
         pk = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
         if pk > 0:
+            _count_conv(B, t_out, cout, cin // groups, k)
             y = torch.empty(cout, B, t_out, device=x.device, dtype=torch.float32)
             ws = WS.get("pk", pk, x.device)
             _chk(lib.evmi_conv1d_cbt_bf16pk_fused(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), y.data_ptr(), ws.data_ptr(), pk, B, cin, t_in, cout, t_out,
@@ -276,6 +297,7 @@ def conv1d_fused_dgrad(dy, w, t_in, stride=1, pad=0, dil=1, groups=1, dy_mask=No
     if _packed() and CONV_BACKEND["dgrad"] == "mfma" and not ((dx_mask is not None or residual is not None) and k < stride):
         pk = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
         if pk > 0:
+            _count_conv(B, t_out, cout, cin_g, k)
             dx = zeros(cin, B, t_in, device=dy.device) if k < stride else torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
             ws = WS.get("pk", pk, dy.device)
             _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_fused(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk, B, cin, t_in, cout, t_out, k, stride,
@@ -299,6 +321,7 @@ def conv1d_fused_wgrad(x, w_shape, dy, dw_out, stride=1, pad=0, dil=1, groups=1,
     if _packed() and CONV_BACKEND["wgrad"] != "gemm":
         pk = lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
         if pk > 0:
+          _count_conv(B, t_out, cout, cin // groups, k)
           with side_wgrad(x, dy, dw_out):
             ws = WS.get("pkw", pk, x.device)
             _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk_fused(x.data_ptr(), dy.data_ptr(), dw_out.data_ptr(), ws.data_ptr(), pk, B, cin, t_in, cout, t_out, k,
@@ -330,6 +353,7 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
     if CONV_BACKEND["operands"] == "bf16" and CONV_BACKEND["packed"]:
         pk_elems = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
         if pk_elems > 0:
+            _count_conv(B, t_out, cout, cin_g, k)
             ws = WS.get("pk", pk_elems, dy.device)
             dx = zeros(cin, B, t_in, device=dy.device) if k < stride else torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
             _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout,
@@ -337,6 +361,7 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
             return dx
     ws_elems = lib.evmi_conv1d_dgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
     if ws_elems > 0:  # every phase in one launch, weight fragments straight from w
+        _count_conv(B, t_out, cout, cin_g, k)
         ws = WS.get("wfrag", ws_elems, dy.device)
         dx = zeros(cin, B, t_in, device=dy.device) if k < stride else torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
         fn = lib.evmi_conv1d_dgrad_cbt_bf16 if CONV_BACKEND["operands"] == "bf16" else lib.evmi_conv1d_dgrad_cbt_f32
@@ -442,6 +467,8 @@ def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, 
     ws_elems = 0
     if pk_elems == 0 and (CONV_BACKEND["wgrad"] == "mfma" or (CONV_BACKEND["wgrad"] == "auto" and groups > 1)):
         ws_elems = lib.evmi_conv1d_wgrad_cbt_f32_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+    if pk_elems > 0 or ws_elems > 0:
+        _count_conv(B, t_out, cout, cin_g, k)
     if pk_elems > 0:  # bf16 operands: packed dy and x, transposing LDS reads (conv_wgrad_bf16_pk.hip)
         ws = WS.get("pkw", pk_elems, x.device)
         _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout, t_out,
