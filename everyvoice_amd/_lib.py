@@ -166,6 +166,16 @@ SYMBOLS = {
     "evmi_weight_norm_fwd_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
     "evmi_weight_norm_bwd_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]),
     "evmi_normalize_vec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "evmi_conv_tc_supported": (C.c_int, [C.c_int] * 4),
+    "evmi_conv_tc_relayout_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "evmi_conv_tc_tm_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_float] * 4 + [C.c_void_p]),
+    "evmi_conv1d_wgrad_tm_bf16_ws_elems": (C.c_longlong, [C.c_longlong] + [C.c_int] * 4),
+    "evmi_conv1d_wgrad_tm_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong, C.c_longlong] + [C.c_int] * 6 + [C.c_void_p]),
+    "evmi_tm_colsum_bf16_ws_elems": (C.c_longlong, [C.c_longlong, C.c_int]),
+    "evmi_tm_colsum_bf16": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
+    "evmi_cbt_f32_to_tm_bf16": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_float, C.c_float, C.c_void_p]),
+    "evmi_tm_bf16_to_cbt_f32": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "evmi_tm_lrelu_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p]),
     "evmi_optimizer_step_lrdev_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_longlong, C.c_void_p] + [C.c_float] * 4 + [C.c_void_p, C.c_float, C.c_void_p]),
     "evmi_store_f32": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "evmi_store_u64": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_void_p]),

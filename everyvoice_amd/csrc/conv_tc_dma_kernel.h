@@ -252,8 +252,8 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
     return;
   }
   stamp();
-  if (a.res) {
-    // ---- residual layers: acc -> bf16 -> LDS [BN][BM+8] -> full-row fused stores ------------------------------------------
+  if (a.res || a.mask) {
+    // ---- residual (and training-mask) layers: acc -> bf16 -> LDS [BN][BM+8] -> full-row fused stores ----------------------
     // The residual rows have to be read in full 128-byte lines: fetched in the accumulator layout (32 rows x 32 B per
     // instruction) they cost 17-21k cycles per tile (measured), against 3-5k for the staged pass.
     __syncthreads();
@@ -286,17 +286,19 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
     };
     // residual / running-sum rows of a batch are requested before the first is consumed; unconditional loads and separate
     // straight-line bodies per case (conditions around the loads make the compiler drain the memory counter at every join)
-    auto body = [&](auto has_acc) {
-      constexpr bool ACC = decltype(has_acc)::value;
+    const float mslope = a.mask_slope;
+    auto body = [&](auto has_acc, auto has_res, auto has_mask) {
+      constexpr bool ACC = decltype(has_acc)::value, RES = decltype(has_res)::value, MSK = decltype(has_mask)::value;
 #pragma unroll
       for (int i0 = 0; i0 < OPT; i0 += EB) {
-        bf16x8 rv[EB], pv[EB];
+        bf16x8 rv[EB], pv[EB], mv[EB];
 #pragma unroll
         for (int i = 0; i < EB; ++i) {
           const long long flat = flat_index(tid + (i0 + i) * C::NTHREADS);
           const long long safe = flat < 0 ? 0 : flat;
-          rv[i] = *reinterpret_cast<const bf16x8*>(a.res + ob + safe);
+          if (RES) rv[i] = *reinterpret_cast<const bf16x8*>(a.res + ob + safe);
           if (ACC) pv[i] = *reinterpret_cast<const bf16x8*>(a.out + ob + safe);
+          if (MSK) mv[i] = *reinterpret_cast<const bf16x8*>(a.mask + ob + safe);
         }
 #pragma unroll
         for (int i = 0; i < EB; ++i) {
@@ -306,7 +308,17 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
           const bf16x8 o = *reinterpret_cast<const bf16x8*>(Os + n * C::OS + c8 * 8);
           float f[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) f[e] = ((float)o[e] + (float)rv[i][e]) * scale;
+          for (int e = 0; e < 8; ++e) f[e] = (float)o[e];
+          if (MSK) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)mv[i][e] > 0.f ? f[e] : f[e] * mslope;
+          }
+          if (RES) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += (float)rv[i][e];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[e] *= scale;
           if (ACC) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += (float)pv[i][e];
@@ -318,8 +330,13 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
         }
       }
     };
-    if (a.accumulate) body(std::integral_constant<bool, true>{});
-    else body(std::integral_constant<bool, false>{});
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    if (a.mask) {  // (training launches: never with a running sum)
+      if (a.res) body(F_{}, T_{}, T_{});
+      else body(F_{}, F_{}, T_{});
+    } else if (a.accumulate) body(T_{}, T_{}, F_{});
+    else body(F_{}, T_{}, F_{});
   } else {
     // ---- epilogue: registers -> (x scale, + running sum, leaky-ReLU) -> bf16 -> 16-byte stores -------------------------
     const float scale = a.out_scale, post = a.post_slope;

@@ -263,11 +263,12 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
     };
     // the (residual, running sum) cases are separate straight-line bodies: with the conditions inside, the compiler joins the
     // paths with s_waitcnt vmcnt(0) after every store
-    auto body = [&](auto has_res, auto has_acc) {
-      constexpr bool RES = decltype(has_res)::value, ACC = decltype(has_acc)::value;
+    const float mslope = a.mask_slope;
+    auto body = [&](auto has_res, auto has_acc, auto has_mask) {
+      constexpr bool RES = decltype(has_res)::value, ACC = decltype(has_acc)::value, MSK = decltype(has_mask)::value;
 #pragma unroll
       for (int i0 = 0; i0 < OPT; i0 += EB) {
-        bf16x8 rv[EB], pv[EB];
+        bf16x8 rv[EB], pv[EB], mv[EB];
 #pragma unroll
         for (int i = 0; i < EB; ++i) {
           // unconditional loads (vectors that are not stored read element 0 of the item): a load under a per-lane condition
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
           const long long safe = flat < 0 ? 0 : flat;
           if (RES && i0 + i < OPT) rv[i] = *reinterpret_cast<const bf16x8*>(a.res + ob + safe);
           if (ACC && i0 + i < OPT) pv[i] = *reinterpret_cast<const bf16x8*>(a.out + ob + safe);
+          if (MSK && i0 + i < OPT) mv[i] = *reinterpret_cast<const bf16x8*>(a.mask + ob + safe);
         }
 #pragma unroll
         for (int i = 0; i < EB; ++i) {
@@ -287,6 +289,10 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
           float f[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) f[e] = (float)o[e];
+          if (MSK) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (float)mv[i][e] > 0.f ? f[e] : f[e] * mslope;
+          }
           if (RES) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] += (float)rv[i][e];
@@ -306,12 +312,15 @@ __global__ __launch_bounds__(C::NTHREADS, C::OCC) void conv_tc_kernel(ConvTcArgs
     };
     using T_ = std::integral_constant<bool, true>;
     using F_ = std::integral_constant<bool, false>;
-    if (a.res) {
-      if (a.accumulate) body(T_{}, T_{});
-      else body(T_{}, F_{});
+    if (a.mask) {  // (training launches: never with a running sum)
+      if (a.res) body(T_{}, F_{}, T_{});
+      else body(F_{}, F_{}, T_{});
+    } else if (a.res) {
+      if (a.accumulate) body(T_{}, T_{}, F_{});
+      else body(T_{}, F_{}, F_{});
     } else {
-      if (a.accumulate) body(F_{}, T_{});
-      else body(F_{}, F_{});
+      if (a.accumulate) body(F_{}, T_{}, F_{});
+      else body(F_{}, F_{}, F_{});
     }
   }
   stamp();  // stores issued

@@ -1,7 +1,8 @@
 // Implicit-GEMM 1-D convolution on MFMA for time-major / channel-last bf16 activations.
 //
-//   out[r, m] = post( [accumulate ? out : 0] + out_scale * ( bias[m] + residual[r, m]
-//                      + sum_{j < KS} sum_{c < CIN} W[m][j][c] * pre(x[r + j*dil - pad, c]) ) )
+//   out[r, m] = post( [accumulate ? out : 0] + out_scale * ( residual[r, m] + maskfac[r, m] * ( bias[m]
+//                      + sum_{j < KS} sum_{c < CIN} W[m][j][c] * pre(x[r + j*dil - pad, c]) ) ) )
+//   (maskfac = 1 without a mask tensor, else mask[r, m] > 0 ? 1 : mask_slope: the activation backward of a training launch)
 //
 // GEMM view per block: D[BM channels x BN rows] = A[BM x (KS*CIN)] * B[(KS*CIN) x BN], where
 // B is never materialised: the activation tile (BN + (KS-1)*dil rows x KC channels) sits in LDS
@@ -37,6 +38,11 @@ struct ConvTcArgs {
   float post_slope;    // leaky-relu slope applied to the final value (1 = identity)
   float out_scale;
   int accumulate;
+  // training (input-gradient launches): the convolution's own value is multiplied by (mask > 0 ? 1 : mask_slope) BEFORE the
+  // residual is added -- mask: a tensor indexed like out, the INPUT of the leaky ReLU in front of the convolution whose input
+  // gradient this launch computes (or the output of that activation: same sign).  nullptr: no mask.
+  const bf16_t* mask = nullptr;
+  float mask_slope = 1.f;
   long long* timeline = nullptr;  // debug instantiations only (ABL bit 128): s_memtime stamps of wave 0 of workgroup (5, 1, 0)
 };
 

@@ -41,6 +41,14 @@ struct WgradPkArgs {
   int accumulate;      // splits == 1 only: dw += instead of =
   int partial, c_out;  // 1: out is the partial-tile buffer [split][tap][c_out][cin_g]
   long long split_stride;  // floats between partial copies
+  // TM instantiation (time-major bf16 tensors [row][C], rows = the flat (item, padded position) index, zero rows around every
+  // item): the 16-byte unit (octet o, row f) is gathered from row f of the tensor by the LDS-direct load (one global address
+  // per lane) -- no packed copy.  x rows are shifted by x_row_off = -pad (+ tap offsets); both tensors are readable (finite)
+  // for a guard of rows in front of row 0 and behind the last row.
+  const __bf16* dy_tm;
+  const __bf16* x_tm;
+  int cy_row, cx_row;      // elements per row (total channels) of dy / x
+  long long x_row_off;
 };
 
 constexpr int WG_KS = 64;  // positions per K step (4 MFMA K blocks)
@@ -59,7 +67,7 @@ __device__ __forceinline__ bf16x8 join_tr(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TGMAX>
+template <int TGMAX, bool TM = false>
 __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -106,7 +114,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
     int u = wave;
     for (; u < 8; u += 4) {  // dy: 8 octet rows x 64 units = one 1 KB piece each
       const int o = min(oy0 + u, a.octs_y - 1);
-      pk_lds_direct(dy_g + (long long)o * a.plane_y + f0 + lane, sy + u * WG_YROW);
+      if (TM) pk_lds_direct(reinterpret_cast<const uint4*>(a.dy_tm + (f0 + lane) * a.cy_row + (g * a.cout_g + o * 8)), sy + u * WG_YROW);
+      else pk_lds_direct(dy_g + (long long)o * a.plane_y + f0 + lane, sy + u * WG_YROW);
       ++issued;
     }
     u -= 8;
@@ -114,7 +123,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
     for (; u < 8 * xpieces; u += 4) {
       const int r = u / xpieces, pi = u - r * xpieces;
       const int o = min(ox0 + r, a.octs_x - 1);
-      pk_lds_direct(x_g + (long long)o * a.plane_x + x0 + pi * 64 + lane, sx + r * xrow + pi * 64);
+      if (TM) pk_lds_direct(reinterpret_cast<const uint4*>(a.x_tm + (x0 + a.x_row_off + pi * 64 + lane) * a.cx_row + (g * a.cin_g + o * 8)),
+                            sx + r * xrow + pi * 64);
+      else pk_lds_direct(x_g + (long long)o * a.plane_x + x0 + pi * 64 + lane, sx + r * xrow + pi * 64);
       ++issued;
     }
     return issued;
@@ -344,6 +355,93 @@ int evmi_conv1d_wgrad_cbt_bf16pk_fused(const float* x_dev, const float* dy_dev, 
                                        int accumulate, float x_pre_slope, const float* dy_mask_dev, float dy_mask_slope, void* stream) {
   return wgrad_pk_impl(x_dev, dy_dev, dw_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups, accumulate,
                        x_pre_slope, dy_mask_dev, dy_mask_slope, stream);
+}
+
+// ---- time-major operands (train_tm.hip's residual stacks): no pack, the kernel gathers its units from [row][C] tensors ----------
+static const char* plan_wgrad_tm(WgradPkArgs& a, WgradPkPlan& pl, long long rows, int c_in, int c_out, int k, int dil) {
+  if (c_in < 32 || c_out < 32 || (c_in % 8) || (c_out % 8) || k <= 0 || dil <= 0 || rows <= 0) return "bad shape (channels: multiples of 8, at least 32)";
+  a.cout_g = c_out; a.cin_g = c_in; a.k = k; a.stride = 1; a.dil = dil;
+  pl.octs_y = a.octs_y = c_out / 8;
+  pl.octs_x = a.octs_x = c_in / 8;
+  a.ksteps = (int)((rows + WG_KS - 1) / WG_KS);
+  const int tgcap = 8;
+  a.ntg = (k + tgcap - 1) / tgcap;
+  a.tg = (k + a.ntg - 1) / a.ntg;
+  pl.tgmax = a.tg <= 4 ? 4 : 8;
+  a.tiles_ci = (c_in + 63) / 64;
+  a.tiles_co = (c_out + 63) / 64;
+  const long long xwin = (long long)(WG_KS - 1) + (long long)(a.tg - 1) * dil + 1;
+  if (xwin > 64 * 12) return "input window too long";
+  a.xpieces = (int)((xwin + 63) / 64);
+  a.xrow = a.xpieces * 64 + 4;
+  const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
+  a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
+  pl.lds = a.nst * stage_bytes;
+  if (pl.lds > 160 * 1024) return "LDS budget";
+  const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co;
+  const long long want = 512;
+  int splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / 8));
+  a.steps_per_split = (a.ksteps + splits - 1) / splits;
+  splits = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;
+  pl.splits = splits;
+  if (splits > 65535) return "grid limits";
+  pl.grid = dim3(a.tiles_ci * a.ntg, a.tiles_co, splits);
+  a.split_stride = (long long)c_out * c_in * k;
+  pl.part_elems = splits > 1 ? a.split_stride * splits : 0;
+  return nullptr;
+}
+
+long long evmi_conv1d_wgrad_tm_bf16_ws_elems(long long rows, int c_in, int c_out, int k, int dil) {
+  WgradPkArgs a = {};
+  WgradPkPlan pl;
+  if (plan_wgrad_tm(a, pl, rows, c_in, c_out, k, dil)) return -1;
+  return std::max<long long>(pl.part_elems, 4);
+}
+
+int evmi_conv1d_wgrad_tm_bf16(const void* x_tm, const void* dy_tm, float* dw_dev, float* ws_dev, long long ws_elems, long long rows, int c_in,
+                              int c_out, int k, int pad, int dil, int accumulate, void* stream) {
+  if (!x_tm || !dy_tm || !dw_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_tm_bf16: null pointer");
+  if ((reinterpret_cast<uintptr_t>(x_tm) | reinterpret_cast<uintptr_t>(dy_tm)) & 15) return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_tm_bf16: operands must be 16-byte aligned");
+  WgradPkArgs a = {};
+  WgradPkPlan pl;
+  if (const char* why = plan_wgrad_tm(a, pl, rows, c_in, c_out, k, dil)) return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_wgrad_tm_bf16: ") + why);
+  if (pl.part_elems > 0 && (!ws_dev || ws_elems < pl.part_elems)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_tm_bf16: workspace missing or too small");
+  hipStream_t s = (hipStream_t)stream;
+  a.dy_tm = reinterpret_cast<const __bf16*>(dy_tm);
+  a.x_tm = reinterpret_cast<const __bf16*>(x_tm);
+  a.cy_row = c_out; a.cx_row = c_in; a.x_row_off = -(long long)pad;
+  a.out = pl.splits > 1 ? ws_dev : dw_dev;
+  a.accumulate = pl.splits > 1 ? 0 : accumulate;
+  a.partial = pl.splits > 1;
+  a.c_out = c_out;
+  static thread_local size_t configured_dev[kMaxDevices][2] = {};
+  size_t* configured = configured_dev[device_slot()];
+  const size_t lds = pl.lds;
+  if (pl.tgmax == 4) {
+    if (lds > configured[0]) {
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured[0] = lds;
+    }
+    hipLaunchKernelGGL((wgrad_pk_kernel<4, true>), pl.grid, dim3(256), lds, s, a);
+  } else {
+    if (lds > configured[1]) {
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured[1] = lds;
+    }
+    hipLaunchKernelGGL((wgrad_pk_kernel<8, true>), pl.grid, dim3(256), lds, s, a);
+  }
+  EVMI_LAUNCH_CHECK("wgrad_tm_kernel");
+  if (pl.splits > 1) {
+    const long long rows_ci = (long long)c_out * c_in;
+    if (rows_ci >= 131072)
+      hipLaunchKernelGGL(wgrad_pk_reduce_kernel, dim3((unsigned)((rows_ci + 255) / 256)), dim3(256), (size_t)k * 256 * sizeof(float), s, ws_dev,
+                         dw_dev, rows_ci, k, pl.splits, a.split_stride, accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_pk_reduce_planes_kernel, dim3((unsigned)((rows_ci + 255) / 256), k), dim3(256), 0, s, ws_dev, dw_dev, rows_ci, k,
+                         pl.splits, a.split_stride, accumulate);
+    EVMI_LAUNCH_CHECK("wgrad_tm_reduce");
+  }
+  return EVMI_OK;
 }
 
 static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in,

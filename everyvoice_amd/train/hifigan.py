@@ -117,6 +117,12 @@ class GeneratorT:
         m = cfg.model
         self.resblock2 = str(getattr(m.resblock, "value", m.resblock)) == "2"
         self.fused_pairs = True  # residual pairs as ag.resblock_pair (False: the unfused op sequence, for A/B tests)
+        # precision="bf16": the residual stacks in time-major bf16 on the inference convolution kernels (train/mrf_tm.py) where
+        # those kernels take the stage's shapes; False: the channel-major packed path everywhere (A/B switch, other configurations)
+        import os
+
+        self.time_major = os.environ.get("EVMI_TRAIN_TM", "1") == "1"
+        self._tm_stages: dict = {}
         self.istft = bool(m.istft_layer)
         self._istft_consts = None
         self._istft_cfg = (cfg.gen_istft_n_fft, cfg.gen_istft_hop_size)
@@ -170,6 +176,20 @@ class GeneratorT:
             y = ag.add(tape, t, y)
         return y
 
+    def _tm_stage(self, i: int, x: torch.Tensor):
+        """The time-major MRF of stage i when it applies: bf16 operands, ResBlock1 pairs, shapes the inference kernels take."""
+        if not (self.time_major and self.fused_pairs and not self.resblock2 and x.is_cuda and ops.CONV_BACKEND["operands"] == "bf16"
+                and ops.CONV_BACKEND["packed"] and 1 < self.num_kernels <= 3):
+            return None
+        st = self._tm_stages.get(i)
+        if st is None:
+            from .mrf_tm import MRFStageTM, stage_supported
+
+            pairs = [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)]
+            ok = stage_supported(x.shape[0], [p[0][0].k for p in pairs], [[c1.dil for c1, _ in p] for p in pairs]) and x.shape[2] % 16 == 0
+            st = self._tm_stages[i] = MRFStageTM(x.shape[0], pairs, self.slope, x.device) if ok else False
+        return st or None
+
     def forward(self, tape: ag.Tape, mel: ag.Var, bucket_hook=None, branches: Branches | None = None) -> ag.Var:
         """`bucket_hook(layers)` is called before the forward of each group of layers whose parameters form one gradient bucket.
         ``branches``: the MRF branches of a stage (kernel sizes 3 / 7 / 11: independent residual chains) run side by side."""
@@ -180,6 +200,10 @@ class GeneratorT:
             hook(self.stage_layers(i))
             x = ag.lrelu(tape, x, self.slope)
             x = ag.conv_transpose1d(tape, x, up)
+            tm = self._tm_stage(i, x.data)
+            if tm is not None:  # the whole MRF of this stage in the inference layout: one op, its own backward
+                x = tm.apply(tape, x, branches)
+                continue
             if branches is not None and self.num_kernels > 1:  # (also without side streams: same summation order either way)
                 leaves = fan_out(tape, x, self.num_kernels)
                 ys = parallel_section(tape, branches, [(lambda sub, j=j: self._mrf_branch(sub, leaves[j], i, j)) for j in range(self.num_kernels)])

@@ -311,6 +311,37 @@ int evmi_conv1d_dgrad_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int 
                                       int groups);
 int evmi_conv1d_wgrad_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil,
                                       int groups);
+/* ---- Training on TIME-MAJOR bf16 activations (csrc/train_tm.hip): the generator's residual stacks (upstream ResBlock1 / MRF,
+ * jik876 hifi-gan models.py; the reference reaches them through hfgl.model.HiFiGAN.training_step) run their
+ * training forward and input gradients on the inference convolution kernels, with no layout pass between two convolutions.
+ * A TM tensor: bf16 [B][Tp][C], the T valid rows of an item at rows [PL, PL + T), zero rows around them; pointers address row 0 of
+ * item 0; the allocation keeps >= 64 zero rows in front and >= 256 behind (the weight gradient walks the flat row index).
+ *   evmi_conv_tc_supported      1 when a time-major kernel takes (c_in, c_out, ks, dil)
+ *   evmi_conv_tc_relayout_f32   w fp32 [c_out][c_in][ks] -> the bf16 tile layout the kernel streams; transpose = 1: the weights of
+ *                               the INPUT GRADIENT of the convolution with w [c_in][c_out][ks] (channels swapped, taps reversed)
+ *   evmi_conv_tc_tm_bf16        out = post( out_scale * ( residual + maskfac * ( bias + conv(pre(x)) ) ) ), "same" padding,
+ *                               pre / post = leaky ReLU with the given slopes (1 = none), maskfac = mask > 0 ? 1 : mask_slope
+ *                               (mask NULL: 1) -- the activation backward of an input-gradient launch
+ *   evmi_conv1d_wgrad_tm_bf16   dw[co][ci][j] (+)= sum_rows dy[row][co] * x[row + j*dil - pad][ci] over all `rows` = B * Tp flat rows
+ *                               (split-K, fixed summation order); ws: evmi_conv1d_wgrad_tm_bf16_ws_elems floats (-1: shape not taken)
+ *   evmi_tm_colsum_bf16         db[c] (+)= sum_rows dy[row][c] (bias gradient); ws: evmi_tm_colsum_bf16_ws_elems floats
+ *   evmi_cbt_f32_to_tm_bf16     fp32 [C][B][T] -> TM, v = leaky_relu(x, slope) * scale;  evmi_tm_bf16_to_cbt_f32: scale * (a + b + c) -> fp32
+ *   evmi_tm_lrelu_bf16          elementwise over a whole TM buffer (zero rows stay zero) */
+int evmi_conv_tc_supported(int c_in, int c_out, int ks, int dil);
+int evmi_conv_tc_relayout_f32(const float* w_dev, void* dst_bf16_dev, int c_in, int c_out, int ks, int dil, int transpose, void* stream);
+int evmi_conv_tc_tm_bf16(const void* x_tm, const void* w_laid, const float* bias_dev, const void* res_tm, const void* mask_tm, void* out_tm,
+                         int B, int T, int Tp, int PL, int c_in, int c_out, int ks, int dil, float pre_slope, float post_slope,
+                         float mask_slope, float out_scale, void* stream);
+long long evmi_conv1d_wgrad_tm_bf16_ws_elems(long long rows, int c_in, int c_out, int k, int dil);
+int evmi_conv1d_wgrad_tm_bf16(const void* x_tm, const void* dy_tm, float* dw_dev, float* ws_dev, long long ws_elems, long long rows,
+                              int c_in, int c_out, int k, int pad, int dil, int accumulate, void* stream);
+long long evmi_tm_colsum_bf16_ws_elems(long long rows, int C);
+int evmi_tm_colsum_bf16(const void* dy_tm, float* db_dev, float* ws_dev, long long ws_elems, long long rows, int C, int accumulate,
+                        void* stream);
+int evmi_cbt_f32_to_tm_bf16(const float* x_dev, void* tm_dev, int C, int B, int T, int Tp, int PL, float slope, float scale, void* stream);
+int evmi_tm_bf16_to_cbt_f32(const void* a_tm, const void* b_tm, const void* c_tm, float* out_dev, int C, int B, int T, int Tp, int PL,
+                            float scale, void* stream);
+int evmi_tm_lrelu_bf16(const void* x_tm, void* y_tm, long long n_elems, float slope, void* stream);
 /* Weight gradient of the same convolution as an implicit GEMM on the fp32 matrix cores (no unfold):
  *   dw[co][ci][j] (+)= sum_{b,to} dy[co][b][to] * x[ci][b][to*stride + j*dil - pad]
  * x [c_in][B][t_in], dy [c_out][B][n_out], dw [c_out][c_in/groups][k]; `ws_dev`: 16-byte aligned scratch of

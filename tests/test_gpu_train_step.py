@@ -702,3 +702,16 @@ def test_weight_gradients_on_sibling_streams_do_not_change_the_step(cuda_device)
     assert outs[0] == outs[1]
     for k in sds[0]:
         assert torch.equal(sds[0][k], sds[1][k]), k
+
+
+def test_channel_major_generator_path_behind_its_switch():
+    """precision="bf16" trains the generator's residual stacks in time-major bf16 on the inference kernels by default
+    (train/mrf_tm.py); EVMI_TRAIN_TM=0 keeps every layer on the channel-major packed kernels.  The switch is read when a trainer is
+    built: the bf16 whole-step comparisons of this file run once more in a child process with it off, so that path cannot rot."""
+    import os
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "bf16 and not behind_its_switch"],
+                       env=dict(os.environ, EVMI_TRAIN_TM="0"), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
