@@ -168,6 +168,8 @@ SYMBOLS = {
     "evmi_normalize_vec_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "evmi_conv_tc_supported": (C.c_int, [C.c_int] * 4),
     "evmi_conv_tc_relayout_f32": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "evmi_conv_tc_tile_layout": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_int)] * 3),
+    "evmi_conv_tc_relayout_batched_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "evmi_conv_tc_tm_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 8 + [C.c_float] * 4 + [C.c_void_p]),
     "evmi_conv1d_wgrad_tm_bf16_ws_elems": (C.c_longlong, [C.c_longlong] + [C.c_int] * 4),
     "evmi_conv1d_wgrad_tm_bf16": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong, C.c_longlong] + [C.c_int] * 6 + [C.c_void_p]),

@@ -70,7 +70,7 @@ class MRFStageTM:
     def __init__(self, C: int, branch_pairs, slope: float, device):
         self.C, self.pairs, self.slope, self.device = C, branch_pairs, slope, torch.device(device)
         self._bufs: dict = {}
-        self._w: dict = {}
+        self._table = self._table_base = self._arena = None
         self.zero_bias = torch.zeros(max(C, 8), device=self.device, dtype=torch.float32)
 
     # ---- storage ---------------------------------------------------------------------------------------------------
@@ -83,21 +83,42 @@ class MRFStageTM:
             b = self._bufs[k] = TMBuf(self.C, B, T, self.device)
         return b
 
-    def _laid(self, layer, transpose: bool) -> torch.Tensor:
-        """The layer's effective weight in the convolution kernel's tile layout (bf16), re-laid on the device (weights change every step)."""
-        key = (id(layer), transpose)
-        dst = self._w.get(key)
-        if dst is None:
-            dst = self._w[key] = torch.empty(self.C * self.C * layer.k // 2, device=self.device, dtype=torch.float32)
-        w, _ = layer.effective(True)
-        _lib.check(_lib.load().evmi_conv_tc_relayout_f32(w.data_ptr(), dst.data_ptr(), self.C, self.C, layer.k, layer.dil if not transpose else layer.dil,
-                                                         int(transpose), _s(self.device)), "evmi_conv_tc_relayout_f32")
-        return dst
+    def _relayout_all(self):
+        """Every convolution's effective weight into its kernel's tile layout (bf16), forward form and input-gradient form
+        (channels swapped, taps reversed), in ONE launch: weights change every step, the table that drives the kernel does not.
+        The effective weights of an optimiser's weight-normed layers live in one flat buffer (layers.WNBatch): offsets from
+        its lowest address."""
+        import ctypes as C
+
+        lib = _lib.load()
+        layers = [c for br in self.pairs for pr in br for c in pr]
+        ws = [c.effective(True)[0] for c in layers]
+        base = min(w.data_ptr() for w in ws)
+        if self._table is None or self._table_base != base:
+            rows, off = [], 0
+            self._w_off = {}
+            for c, w in zip(layers, ws):
+                bm, kc, wl = C.c_int(), C.c_int(), C.c_int()
+                _lib.check(lib.evmi_conv_tc_tile_layout(self.C, self.C, c.k, c.dil, C.byref(bm), C.byref(kc), C.byref(wl)), "evmi_conv_tc_tile_layout")
+                for mode in (0, 1):
+                    assert (w.data_ptr() - base) % 4 == 0
+                    rows.append([(w.data_ptr() - base) // 4, off, c.k, bm.value, kc.value, wl.value, mode, 0])
+                    self._w_off[(id(c), bool(mode))] = off
+                    off += self.C * self.C * c.k
+            self._arena = torch.empty((off + 1) // 2, device=self.device, dtype=torch.float32)
+            self._table = torch.tensor(rows, dtype=torch.int64).to(self.device)
+            self._table_base, self._base_w = base, min(ws, key=lambda w: w.data_ptr())
+            self._ks_max = max(c.k for c in layers)
+        _lib.check(lib.evmi_conv_tc_relayout_batched_f32(base, self._arena.data_ptr(), self._table.data_ptr(), self._table.shape[0], self.C, self._ks_max,
+                                                         _s(self.device)), "evmi_conv_tc_relayout_batched_f32")
+
+    def _laid_ptr(self, layer, transpose: bool) -> int:
+        return self._arena.data_ptr() + 2 * self._w_off[(id(layer), transpose)]
 
     # ---- kernels ---------------------------------------------------------------------------------------------------
     def _conv(self, x: TMBuf, w_laid, bias, out: TMBuf, k, dil, pre=1.0, post=1.0, res: TMBuf | None = None, mask: TMBuf | None = None, mask_slope=1.0):
         ops._count_conv(x.B, x.T, self.C, self.C, k)
-        _lib.check(_lib.load().evmi_conv_tc_tm_bf16(x.ptr, w_laid.data_ptr(), bias.data_ptr(), res.ptr if res is not None else 0,
+        _lib.check(_lib.load().evmi_conv_tc_tm_bf16(x.ptr, w_laid, bias.data_ptr(), res.ptr if res is not None else 0,
                                                     mask.ptr if mask is not None else 0, out.ptr, x.B, x.T, x.Tp, x.PL, self.C, self.C, k, dil,
                                                     float(pre), float(post), float(mask_slope), 1.0, _s(self.device)), "evmi_conv_tc_tm_bf16")
 
@@ -139,21 +160,17 @@ class MRFStageTM:
         slope = self.slope
         u = self.buf("u", B, T)
         self._to_tm(x.data, u)
-        laid = {}
+        self._relayout_all()
         outs = [None] * nb
 
         def fwd_branch(j):
             def go():
                 cur = u
                 for m, (c1, c2) in enumerate(self.pairs[j]):
-                    laid[(j, m, 1, False)] = self._laid(c1, False)
-                    laid[(j, m, 2, False)] = self._laid(c2, False)
-                    laid[(j, m, 1, True)] = self._laid(c1, True)
-                    laid[(j, m, 2, True)] = self._laid(c2, True)
                     t = self.buf(("t", j, m), B, T)
                     y = self.buf(("y", j, m), B, T)
-                    self._conv(cur, laid[(j, m, 1, False)], c1.bias_data(), t, c1.k, c1.dil, pre=slope, post=slope)
-                    self._conv(t, laid[(j, m, 2, False)], c2.bias_data(), y, c2.k, 1, res=cur)
+                    self._conv(cur, self._laid_ptr(c1, False), c1.bias_data(), t, c1.k, c1.dil, pre=slope, post=slope)
+                    self._conv(t, self._laid_ptr(c2, False), c2.bias_data(), y, c2.k, 1, res=cur)
                     ag._ACTIVATION_ELEMS[0] += t.numel_body  # (two bf16 tensors = one fp32 tensor's bytes in the bench's pricing)
                     cur = y
                 outs[j] = cur
@@ -183,12 +200,12 @@ class MRFStageTM:
                         self._colsum(dcur, c2.call_db_sink())
                         self._wgrad(t, dcur, dw2, c2.k, 1)
                         dc1 = self.buf(("dc1", j), B, T)
-                        self._conv(dcur, laid[(j, m, 2, True)], self.zero_bias, dc1, c2.k, 1, mask=t, mask_slope=slope)
+                        self._conv(dcur, self._laid_ptr(c2, True), self.zero_bias, dc1, c2.k, 1, mask=t, mask_slope=slope)
                         self._colsum(dc1, c1.call_db_sink())
                         self._lrelu(cur, act)
                         self._wgrad(act, dc1, dw1, c1.k, c1.dil)
                         dx = self.buf(("dx", j, m % 2), B, T)
-                        self._conv(dc1, laid[(j, m, 1, True)], self.zero_bias, dx, c1.k, c1.dil, mask=cur, mask_slope=slope, res=dcur)
+                        self._conv(dc1, self._laid_ptr(c1, True), self.zero_bias, dx, c1.k, c1.dil, mask=cur, mask_slope=slope, res=dcur)
                         dcur = dx
                     dxs[j] = dcur
                 return go

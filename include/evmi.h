@@ -329,6 +329,11 @@ int evmi_conv1d_wgrad_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int 
  *   evmi_tm_lrelu_bf16          elementwise over a whole TM buffer (zero rows stay zero) */
 int evmi_conv_tc_supported(int c_in, int c_out, int ks, int dil);
 int evmi_conv_tc_relayout_f32(const float* w_dev, void* dst_bf16_dev, int c_in, int c_out, int ks, int dil, int transpose, void* stream);
+/* ... all C x C layers of a residual stack in one launch: table_dev[l] = {source offset (floats from w_base_dev), destination offset
+ * (bf16 elements from dst_base), ks, BM, KC, wlayout (evmi_conv_tc_tile_layout), transpose, 0} as 8 int64 each. */
+int evmi_conv_tc_tile_layout(int c_in, int c_out, int ks, int dil, int* bm, int* kc, int* wlayout);
+int evmi_conv_tc_relayout_batched_f32(const float* w_base_dev, void* dst_base_bf16_dev, const long long* table_dev, int n_layers, int C,
+                                      int ks_max, void* stream);
 int evmi_conv_tc_tm_bf16(const void* x_tm, const void* w_laid, const float* bias_dev, const void* res_tm, const void* mask_tm, void* out_tm,
                          int B, int T, int Tp, int PL, int c_in, int c_out, int ks, int dil, float pre_slope, float post_slope,
                          float mask_slope, float out_scale, void* stream);

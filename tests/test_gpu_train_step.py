@@ -502,7 +502,11 @@ def _full_gan_step(cuda_device, oracle_models, precision, g_gain=1.0, istft=Fals
                 if os.environ.get("EVMI_TEST_REPORT"):
                     print(f"COS {cos:.4f} ratio {ratio:.3f} {key}.{name}")
                 worst = min(worst, cos)
-                assert cos >= 0.99 and 0.95 <= ratio <= 1.05, f"{key}.{name}: cos {cos:.4f} norm ratio {ratio:.3f}"
+                # norm: within 5 % on the channel-major path (fp32 storage); the generator's residual stacks in time-major bf16
+                # (the default, train/mrf_tm.py) store activations AND gradients in bf16: within 8 % (measured 5.2 % on the worst
+                # tensor, a weight_g gradient -- one scalar per channel, a sum of near-cancelling terms)
+                tol = 0.05 if (os.environ.get("EVMI_TRAIN_TM", "1") == "0" or key == "d") else 0.08
+                assert cos >= 0.99 and 1.0 - tol <= ratio <= 1.0 + tol, f"{key}.{name}: cos {cos:.4f} norm ratio {ratio:.3f}"
         return
     # fp32 evaluation noise of the generator's gradients against the exact (fp64) step: the fp32 ORACLE itself is 1.15e-2 away from
     # the fp64 oracle on resblocks.8.convs1.0.weight_v at 2 x 2048 samples (kink flips), 1.3e-3 at 16 x 8192 where they average out
