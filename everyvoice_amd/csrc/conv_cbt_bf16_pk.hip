@@ -55,7 +55,6 @@ struct ConvPkArgs {
   int ksplit, steps_per_split, ntiles_n;
   float* part;
   long long part_stride, part_ld;
-  int ablate;  // timing experiments (EVMI_PK_ABLATE): 1 no window loads, 2 no weight loads, 4 no MFMA loop, 8 no stores
   // fused epilogue tail, in this order: v = act(acc + bias); v *= (out_mask > 0 ? 1 : out_mask_slope); v += res
   //   out_mask: a tensor of y's shape -- the INPUT of the leaky ReLU in front of the convolution whose input gradient this
   //             launch computes (the activation backward without a separate pass);  res: a tensor of y's shape added to the
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nsteps_all = (a.ablate & 16) ? 0 : (a.kblocks + kbs - 1) / kbs;  // (16: timing experiment without the K loop)
+  const int nsteps_all = (a.kblocks + kbs - 1) / kbs;
   const int t_lo = a.ksplit > 1 ? split * a.steps_per_split : 0;
   const int nsteps = a.ksplit > 1 ? min(nsteps_all, t_lo + a.steps_per_split) : nsteps_all;  // this workgroup: steps [t_lo, nsteps)
   const uint4* wf_tile = a.wf + (long long)ph * a.wf_phase_stride + (long long)(g * a.mblocks + mt_idx * MBT) * a.kblocks * 64;
@@ -241,7 +240,6 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     uint4* sx = sa + a_units;
     int issued = 0;
     int u = wave;
-    if (!(a.ablate & 2))
 #pragma unroll
     for (int mbi = 0; mbi < MBT; ++mbi) {
       const uint4* src = wf_tile + ((long long)min(mbi, mb_last) * a.kblocks + q0) * 64 + lane;
@@ -255,7 +253,6 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     const int o_lo = (2 * q0) / k;
     const int o_hi = min(a.octs - 1, (2 * (q0 + nq) - 1) / k);
     const int nunits = (o_hi - o_lo + 1) * pieces;
-    if (!(a.ablate & 1))
     for (; u < nunits; u += 4) {
       const int r = u / pieces, pi = u - r * pieces;
       const int pp = pi * 64 + lane;
@@ -318,7 +315,6 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     // block, in-bounds and unused).
 #pragma unroll
     for (int u = 0; u < U; ++u) load(fa[u], fb[u], min(u, nq - 1), pe[u]);
-    if (!(a.ablate & 4))
     for (int qi = 0; qi < nq; qi += U) {
       int2 fe[U];
 #pragma unroll
@@ -342,17 +338,6 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
   }
 
   // ---- epilogue: D layout: lane column = output position, registers = output channels ----
-  if (a.ablate & 8) {
-    float sacc = 0.f;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc += acc[i][j][r];
-    if (sacc == 12345.678f) a.y[0] = sacc;
-    return;
-  }
   if (a.ksplit > 1) {  // raw partial tile: rows = output channels, columns = the flat (item, position) index (coalesced)
     float* pp = a.part + ((long long)split * a.phases + ph) * a.part_stride;
 #pragma unroll
@@ -500,23 +485,23 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
   // from 31.8 % to 5.2 % of its LDS cycles, but the GAN step got 0.3 ms slower: the period discriminators' 11-34-unit items grew
   // by up to half).
   {
-    static const int align_tp = pk_env_int("EVMI_PK_TP_ALIGN", 1);
+    static const int align_tp = 1;
     const long long want_mod = ((long long)n_max * a.stride) & 15;
-    if (align_tp && ext >= pk_env_int("EVMI_PK_TP_ALIGN_MIN", 96)) ext += ((want_mod - (ext & 15)) + 16) & 15;  // (short items: the padding would cost more than the conflicts)
+    if (align_tp && ext >= 96) ext += ((want_mod - (ext & 15)) + 16) & 15;  // (short items: the padding would cost more than the conflicts)
   }
   a.Tp = (int)ext;
   const long long n_total = (long long)a.B * n_max;
   auto blocks = [&](int i) {
     return ((n_total + kPkTiles[i].bn - 1) / kPkTiles[i].bn) * ((a.cout_g + kPkTiles[i].bm - 1) / kPkTiles[i].bm) * groups;
   };
-  static const long long want = pk_env_int("EVMI_PK_WANT", 512);  // two workgroups per CU: one's epilogue / load waits overlap the other's MFMAs
+  static const long long want = 512;  // two workgroups per CU: one's epilogue / load waits overlap the other's MFMAs
   int ti;
   // wide layers on few columns (the 1024-channel discriminator layers: 1.6-2.8 k columns): 128 x 128 tiles -- one LDS read per
   // MFMA instead of the 64 x 64 tile's two -- fill the CUs only with the contraction split over workgroups
   static const int allow_split = pk_env_int("EVMI_PK_SPLITK", 1);
   a.ksplit = 1;
-  if (allow_split && a.cout_g > 64 && blocks(0) < pk_env_int("EVMI_PK_SPLIT_BELOW", 256) && a.kblocks >= 64) {
-    static const int split_want = pk_env_int("EVMI_PK_SPLIT_WANT", 384), split_min_kb = pk_env_int("EVMI_PK_SPLIT_MINKB", 24);
+  if (allow_split && a.cout_g > 64 && blocks(0) < 256 && a.kblocks >= 64) {
+    static const int split_want = 384, split_min_kb = 24;
     int ks = (int)std::min<long long>(8, (split_want + blocks(0) - 1) / blocks(0));
     while (ks > 1 && a.kblocks / ks < split_min_kb) --ks;
     a.ksplit = ks;
@@ -532,8 +517,8 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     //  * 128 x 256 tiles for long contractions on many columns (the postnet's 512 -> 512, k = 5: 150 vs 180 us): the staged window
     //    and the weight fragments are each read by half as many workgroups;
     //  * 128 x 128 already from 1.5 workgroups per CU (256-row layers: 1024 -> 256 81 vs 97 us, 256 -> 256 34 vs 38 us on 64 x 128).
-    static const long long want0 = pk_env_int("EVMI_PK_WANT0", 384), want6 = pk_env_int("EVMI_PK_WANT6", 384);
-    static const int kb6 = pk_env_int("EVMI_PK_TILE6_MINKB", 128);
+    static const long long want0 = 384, want6 = 384;
+    static const int kb6 = 128;
     if (a.cout_g >= 128 && a.kblocks >= kb6 && blocks(6) >= want6) cand[nc++] = 6;
     if (blocks(0) >= want0) cand[nc++] = 0;
     if (blocks(1) >= want || nc == 0) cand[nc++] = blocks(1) >= want ? 1 : 2;
@@ -568,12 +553,12 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     // deepest step (K blocks) that leaves two workgroups per CU; three slots when they fit at that depth
     int kbs = 1, nst = 2;
     const size_t budget = lds_of(1, 2) <= two_wg ? two_wg : one_wg;
-    const int kbs_cap = std::min(a.kblocks, pk_env_int("EVMI_PK_KBS_CAP", 32));
+    const int kbs_cap = std::min(a.kblocks, 32);
     while (kbs < kbs_cap && lds_of(kbs + 1, 2) <= budget) ++kbs;
     // (three slots at 2/3 of the depth measured slower on every layer: the per-step cost -- barrier, scalar bookkeeping, the
     // un-overlapped first fragment reads -- outweighs the extra step of load latency hidden)
-    if (pk_env_int("EVMI_PK_THREE", 0) && lds_of(std::max(1, kbs * 2 / 3), 3) <= budget && kbs >= 3) { nst = 3; kbs = std::max(1, kbs * 2 / 3); }
-    const int fk = pk_env_int("EVMI_PK_KBS", 0), fn = pk_env_int("EVMI_PK_NST", 0);
+    if (0 && lds_of(std::max(1, kbs * 2 / 3), 3) <= budget && kbs >= 3) { nst = 3; kbs = std::max(1, kbs * 2 / 3); }
+    const int fk = 0, fn = 0;
     if (fn == 2 || fn == 3) nst = fn;
     if (fk > 0) kbs = std::min(fk, a.kblocks);
     while (kbs > 1 && lds_of(kbs, nst) > one_wg) --kbs;
@@ -639,9 +624,8 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   a.tab = fa.tab;
   a.xp = xp;
   a.wf = wf;
-  static const int xcd_remap = pk_env_int("EVMI_F32_XCD", 1);
+  static const int xcd_remap = 1;
   a.xcd_remap = xcd_remap;
-  a.ablate = pk_env_int("EVMI_PK_ABLATE", 0);
   const size_t lds = pl.lds;
   static thread_local size_t configured_dev[kMaxDevices][kNumPkTiles] = {};
   size_t* configured = configured_dev[device_slot()];

@@ -866,13 +866,13 @@ static int env_int(const char* name, int dflt) {
 }
 
 static int pick_tile(const ConvF32Args& a, int groups) {
-  const int forced = env_int("EVMI_F32_TILE", -1);
+  const int forced = -1;
   if (forced >= 0 && forced < kNumTiles) return forced;
   const long long n_total = (long long)a.B * a.n_out;
   auto blocks = [&](int i) {
     return ((n_total + kTiles[i].bn - 1) / kTiles[i].bn) * ((a.cout_g + kTiles[i].bm - 1) / kTiles[i].bm) * groups;
   };
-  static const long long want = env_int("EVMI_F32_WANT", 384);  // two workgroups per CU before a larger tile is worth its reuse
+  static const long long want = 384;  // two workgroups per CU before a larger tile is worth its reuse
   if (a.cout_g > 64) {
     if (blocks(0) >= want) return 0;
     if (blocks(1) >= want) return 1;
@@ -905,10 +905,10 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
     const int items_max = (int)std::min<long long>(a.B, (bn + nmin - 2) / nmin + 1);
     return ((bn - 1) * a.stride + (items_max - 1) * std::max(halo - a.stride, 0) + halo) | 1;
   };
-  static const bool use_wp = env_int("EVMI_F32_WP", 1) != 0;  // wave-private rings for the K-split tiles (A/B switch)
+  static const bool use_wp = 1 != 0;  // wave-private rings for the K-split tiles (A/B switch)
   int ti = pick_tile(a, groups);
   if (a.bf) {
-    const int ft = env_int("EVMI_BF_TILE", -1);
+    const int ft = -1;
     if (ft >= 0 && ft < kNumTiles) ti = ft;
   }
   // wave-private rings (K-split tiles): every wave stages only its own column slice, but a workgroup holds 8 slots:
@@ -945,7 +945,7 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
       while (ps * 2 <= ps_cap && lds_bf(ps * 2, a.k, 2) <= two_wg && (wp ? (a.pairs + 2 * ps - 1) / (2 * ps) >= ks : (ps < 16 || (ps / 8) * a.k < 2 * ks)))
         ps *= 2;
       if (!wp && lds_bf(ps, a.k, 3) <= two_wg) nst = 3;
-    } else if (!wp && env_int("EVMI_BF_CHUNK", 0)) {  // tap-chunked steps re-stage the input window per chunk: measured slower than fp32
+    } else if (!wp && 0) {  // tap-chunked steps re-stage the input window per chunk: measured slower than fp32
       const size_t budget = lds_bf(8, 1, 2) <= two_wg ? two_wg : one_wg;
       while (tj > 1 && lds_bf(8, tj, 2) > budget) --tj;
       if (lds_bf(8, tj, 2) > budget) return "LDS budget";
@@ -955,7 +955,7 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
       return "LDS budget";
     }
     {  // tuning overrides (experiments)
-      const int fps = env_int("EVMI_BF_PS", 0), fnst = env_int("EVMI_BF_NST", 0);
+      const int fps = 0, fnst = 0;
       if (fps >= 8 && fps % 8 == 0 && tj == a.k) ps = std::min(fps, ((a.pairs + 7) / 8) * 8);
       if (!wp && (fnst == 2 || fnst == 3)) nst = fnst;
     }
@@ -988,9 +988,9 @@ static const char* plan_conv_f32(ConvF32Args& a, int groups, F32Plan& pl) {
   // overhead) when three would leave less than ~24 K pairs of work per wave and step
   int nst = 3, ps = deepest(3);
   if (wp || lds_bytes(ps, 3) > 78 * 1024 || (ps * a.k < 24 * ks && deepest(2) > ps)) { nst = 2; ps = deepest(2); }
-  const int forced_nst = env_int("EVMI_F32_NST", 0);
+  const int forced_nst = 0;
   if (!wp && (forced_nst == 2 || forced_nst == 3)) { nst = forced_nst; ps = deepest(nst); }
-  const int forced_ps = env_int("EVMI_F32_PS", 0);
+  const int forced_ps = 0;
   if (forced_ps > 0 && lds_bytes(forced_ps, nst) <= 160 * 1024) ps = forced_ps;
   a.nst = nst;
   a.ps = ps;
@@ -1014,11 +1014,11 @@ static int dispatch_conv_f32(ConvF32Args a, const F32Plan& pl, hipStream_t strea
   dim3 grid = pl.grid;
   grid.z = a.phases;
   const int bm = kTiles[ti].bm, bn = kTiles[ti].bn, ks = kTiles[ti].ks;
-  a.ablate = env_int("EVMI_F32_ABLATE", 0);
-  static const int xcd_remap = env_int("EVMI_F32_XCD", 1);
+  a.ablate = 0;
+  static const int xcd_remap = 1;
   a.xcd_remap = xcd_remap;
   a.tl = nullptr;
-  const bool want_tl = env_int("EVMI_F32_TL", 0) != 0;
+  const bool want_tl = 0 != 0;
   if (want_tl) {
     EVMI_HIP_CHECK(hipMalloc(&a.tl, 24 * 4 * 4 * sizeof(long long)));
     EVMI_HIP_CHECK(hipMemsetAsync(a.tl, 0, 24 * 4 * 4 * sizeof(long long), stream));

@@ -259,7 +259,7 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
   const int cin_g = c_in / groups, cout_g = c_out / groups;
   // half-empty 64 x 64 tiles pay most with many taps sharing the staged window (128->128 k41 g4 0.38 -> 0.26 ms); the 32 x 32
   // layers of the generator's last stage (k 3 / 7 / 11: 0.09 ms here) still beat the fp32 unfold + GEMM route (0.15 ms)
-  static const int min_prod = wg_env_int("EVMI_WG_MINPROD", 1024);
+  static const int min_prod = 1024;
   if (cin_g < 32 || cout_g < 32 || (cin_g * cout_g < min_prod && k < 16))
     return "narrow groups (the fp32 implicit-GEMM kernel takes them)";
   if (stride > 8) return "stride above 8";
@@ -294,8 +294,8 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
   pl.lds = a.nst * stage_bytes;
   if (pl.lds > 160 * 1024) return "LDS budget";
   const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co * groups;
-  static const long long want = wg_env_int("EVMI_WG_WANT", 512);
-  static const int min_steps = wg_env_int("EVMI_WG_MIN_STEPS", 8);  // K steps per workgroup that pay for its prologue and tile store
+  static const long long want = 512;
+  static const int min_steps = 8;  // K steps per workgroup that pay for its prologue and tile store
   int splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / min_steps));
   const int fs = wg_env_int("EVMI_WG_SPLITS", 0);
   if (fs > 0) splits = std::min(fs, a.ksteps);

@@ -297,6 +297,7 @@ def test_fused_residual_pairs_equal_the_unfused_sequence(cuda_device, precision)
     for fused in (True, False):
         tr = HiFiGANTrainer(device=cuda_device, seed=5, precision=precision)
         tr.generator.fused_pairs = fused
+        tr.generator.time_major = False  # (this test is about the channel-major pair fusion; the time-major stacks: test_gpu_train_tm.py)
         outs.append([tr.training_step(mel, y) for _ in range(2)])
         sds.append(tr.state_dict())
     assert outs[0] == outs[1]
