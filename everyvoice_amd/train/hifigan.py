@@ -66,18 +66,20 @@ class Branches:
         for st in used:
             st.wait_event(fork)
         evs = []
-        for i, fn in items:
-            with torch.cuda.stream(used[i % len(used)]):
-                if self.timing is not None:
-                    e0 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                fn()
-                if self.timing is not None:
-                    e1 = torch.cuda.Event(enable_timing=True)
-                    e1.record()
-                    evs.append((e0, e1))
-        for st in used:
-            main.wait_stream(st)
+        try:
+            for i, fn in items:
+                with torch.cuda.stream(used[i % len(used)]):
+                    if self.timing is not None:
+                        e0 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    fn()
+                    if self.timing is not None:
+                        e1 = torch.cuda.Event(enable_timing=True)
+                        e1.record()
+                        evs.append((e0, e1))
+        finally:  # (also when a branch raised: a stream capture must not be left with forked streams unjoined)
+            for st in used:
+                main.wait_stream(st)
         if self.timing is not None:
             self.timing.append(evs)
 
@@ -401,13 +403,15 @@ class BucketReducer:
                 if self.timing is not None:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record(self.stream)
-                # RCCL: enqueued behind `ready` on the side stream, runs while the launching stream goes on with backward;
-                # wait() orders the side stream behind the collective (it does not block the host under "nccl")
-                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True).wait()
-                if self.timing is not None:
+                # RCCL: enqueued behind `ready` on the side stream, runs while the launching stream goes on with backward
+                work = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                if self.timing is not None:  # (measurement runs only: order the side stream behind the collective, then stamp)
+                    work.wait()
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record(self.stream)
                     self.timing.append((e0, e1))
+                else:
+                    self.works.append(work)
         else:
             self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
@@ -865,17 +869,23 @@ class HiFiGANTrainer:
         y, y_hat, ins = ctx["y"], ctx["y_hat"], ctx["d_ins"]
         d_tape = ag.Tape()
         ds = self.discriminators()
-        fns = []
-        for i in idxs:
-            d = ds[i]
-            if any(isinstance(layer, SNConv) for layer in d.layers()):
-                # its bucket closes on the main stream once both chains' backward has been joined
-                self._bucket_hook(d_tape, self.d_params, d.layers(), reducer)
-                fns.append(lambda sub, i=i, d=d: self._d_branch_sn(sub, i, d, y, "real"))
-                fns.append(lambda sub, i=i, d=d: self._d_branch_sn(sub, i, d, y_hat.data, "fake"))
-            else:
-                fns.append(lambda sub, i=i, d=d: self._d_branch(sub, i, d, ins[i], reducer))
-        parallel_section(d_tape, self.branches, fns)
+        idxs = set(idxs)
+        items = []  # (stream index, fn): every chain keeps the stream it has when all discriminators run together -- the
+        slot = 0    # per-stream workspaces the eager warm-up steps grew are the ones a captured stretch of a subset finds
+        for i, d in enumerate(ds):
+            sn = any(isinstance(layer, SNConv) for layer in d.layers())
+            if i in idxs:
+                if sn:
+                    # its bucket closes on the main stream once both chains' backward has been joined
+                    self._bucket_hook(d_tape, self.d_params, d.layers(), reducer)
+                    items.append((slot, lambda sub, i=i, d=d: self._d_branch_sn(sub, i, d, y, "real")))
+                    items.append((slot + 1, lambda sub, i=i, d=d: self._d_branch_sn(sub, i, d, y_hat.data, "fake")))
+                else:
+                    items.append((slot, lambda sub, i=i, d=d: self._d_branch(sub, i, d, ins[i], reducer)))
+            slot += 2 if sn else 1
+        subs = [ag.Tape() for _ in items]
+        self.branches.run_indexed([(j, (lambda k=k, fn=fn: fn(subs[k]))) for k, (j, fn) in enumerate(items)])
+        d_tape.record(lambda: self.branches.run_indexed([(j, subs[k].backward) for k, (j, _) in enumerate(items)]))
         d_tape.backward()
 
     def _phase_d_epilogue(self, ctx):
