@@ -558,12 +558,6 @@ class FastSpeech2Trainer:
         if self.aligner is not None:
             self.aligner._side = torch.cuda.Stream(self.device)
             self.aligner._side_mas = torch.cuda.Stream(self.device)
-        # the variance predictors' streams (graph mode: _forward_backward); weight gradients stay in place on them (a sibling
-        # stream forked from an already forked stream breaks graph capture: DESIGN 9.10)
-        self._predictor_streams = [torch.cuda.Stream(self.device) for _ in range(3)]
-        for st in self._predictor_streams:
-            ops._SIDE_STREAMS.add(st.cuda_stream)
-        self._join_predictors = self._start_predictor_backward = None
 
     def _tail_offset(self) -> int:
         """First element of the flat buffers that belongs to the decoder / mel_linear / postnet (declared last, in this order)."""
@@ -803,73 +797,15 @@ class FastSpeech2Trainer:
                 x = self._add_item_embedding(tape, x, table, batch[key], lens)
 
         w = tr.duration_loss_weight
-        side = self._predictor_streams if (self.use_graph and not _EVAL[0]) else None
-        if side is None:
-            losses["duration"] = mse_loss(tape, self.duration_predictor.forward(tape, x, lens, seeds), log_d_t.view(1, B, L), n_tok, w)
-            losses["pitch"] = mse_loss(tape, self.pitch_predictor.forward(tape, x, lens, seeds), pitch_t.view(1, B, L), n_tok, tr.pitch_loss_weight)
-            x = self._add_bucket_embedding(tape, x, pitch_t, self.pitch_bins, self.pitch_table)
-            losses["energy"] = mse_loss(tape, self.energy_predictor.forward(tape, x, lens, seeds), energy_t.view(1, B, L), n_tok, tr.energy_loss_weight)
-            x = self._add_bucket_embedding(tape, x, energy_t, self.energy_bins, self.energy_table)
-        else:
-            # Under teacher forcing the three variance predictors are side branches: they read the encoder output (the energy
-            # predictor: + the pitch embedding), feed only their own losses, and hand a gradient back.  ~200 small launches that sat
-            # in the main chain; with the step replayed as a HIP graph they cost nothing to issue, so they run on three streams of
-            # their own beside the length regulator and the decoder -- forward and backward (sub-tapes; the backward is started when
-            # the main backward starts, its gradients are added where the predictors stood, in the same order: same bits).
-            # (In eager mode the host issues launches in program order at ~10 us each: the same arrangement measured slower there.)
-            main = torch.cuda.current_stream(dev)
-            x_in = x
-            x1 = self._add_bucket_embedding(Tape(), x, pitch_t, self.pitch_bins, self.pitch_table)  # (its backward is recorded below, in order)
-            specs = [("duration", self.duration_predictor, x_in, log_d_t, w), ("pitch", self.pitch_predictor, x_in, pitch_t, tr.pitch_loss_weight),
-                     ("energy", self.energy_predictor, x1, energy_t, tr.energy_loss_weight)]
-            fork = torch.cuda.Event()
-            fork.record(main)
-            subs, leaves, fdone, bdone = [], [], [], [torch.cuda.Event() for _ in specs]
-            for (name, pred, src, target, weight), st in zip(specs, side):
-                leaf = Var(src.data)
-                sub = Tape()
-                st.wait_event(fork)
-                with torch.cuda.stream(st):
-                    losses[name] = mse_loss(sub, pred.forward(sub, leaf, lens, seeds), target.view(1, B, L), n_tok, weight)
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                subs.append(sub)
-                leaves.append(leaf)
-                fdone.append(ev)
-            self._side_forward_done = fdone
-
-            def join_predictors():  # (also what a stretch boundary of a captured data-parallel step runs: no forked stream left open)
-                for ev in bdone:
-                    torch.cuda.current_stream(dev).wait_event(ev)
-
-            started = [False]
-
-            def start_backward():  # recorded LAST (below): the first thing backward does
-                m = torch.cuda.current_stream(dev)
-                go = torch.cuda.Event()
-                go.record(m)
-                for sub, st, ev in zip(subs, side, bdone):
-                    st.wait_event(go)
-                    with torch.cuda.stream(st):
-                        sub.backward()
-                        ev.record(st)
-                started[0] = True
-
-            self._start_predictor_backward, self._join_predictors = start_backward, (lambda: started[0] and join_predictors())
-            # the tape, in forward order: [duration, pitch] -> pitch embedding -> [energy] -> energy embedding
-            def handed_over(i):
-                """A predictor's input gradient: made on its stream, consumed on this one (rule: a tensor may cross streams only
-                if the allocator knows -- outside a captured graph, whose pool is static)."""
-                g_ = leaves[i].grad
-                if not torch.cuda.is_current_stream_capturing():
-                    g_.record_stream(torch.cuda.current_stream(dev))
-                return g_
-
-            tape.record(lambda: (join_predictors(), x_in.accumulate(handed_over(1)), x_in.accumulate(handed_over(0))))
-            y1 = x1
-            tape.record(lambda: y1.grad is not None and self._bucket_embedding_backward(y1, x_in, pitch_t, self.pitch_bins, self.pitch_table))
-            tape.record(lambda: (join_predictors(), x1.accumulate(handed_over(2))))
-            x = self._add_bucket_embedding(tape, x1, energy_t, self.energy_bins, self.energy_table)
+        # (Measured and not kept: the three variance predictors -- side branches under teacher forcing, ~200 small launches -- on
+        # streams of their own beside the length regulator and the decoder, forward and backward.  In graph mode, where issuing them
+        # costs nothing: 26.7 vs 24.1 ms per step, same box, twice.  The replayed graph already keeps the device busy; three more
+        # concurrent chains of small kernels take slots from the decoder's large ones.)
+        losses["duration"] = mse_loss(tape, self.duration_predictor.forward(tape, x, lens, seeds), log_d_t.view(1, B, L), n_tok, w)
+        losses["pitch"] = mse_loss(tape, self.pitch_predictor.forward(tape, x, lens, seeds), pitch_t.view(1, B, L), n_tok, tr.pitch_loss_weight)
+        x = self._add_bucket_embedding(tape, x, pitch_t, self.pitch_bins, self.pitch_table)
+        losses["energy"] = mse_loss(tape, self.energy_predictor.forward(tape, x, lens, seeds), energy_t.view(1, B, L), n_tok, tr.energy_loss_weight)
+        x = self._add_bucket_embedding(tape, x, energy_t, self.energy_bins, self.energy_table)
 
         frames = torch.empty(D, B, T, device=dev, dtype=torch.float32)
         _chk(lib.evmi_length_regulate_cbt_f32(x.data.data_ptr(), cum.data_ptr(), frames.data_ptr(), D, B, L, T, _s(frames)), "evmi_length_regulate_cbt_f32")
@@ -888,7 +824,7 @@ class FastSpeech2Trainer:
         tape.record(lr_bwd)
         if segmented:
             # (captured data-parallel step: the stretch ends here; every stream forked so far must be back on the main one)
-            tape.cut(lambda: ((self.aligner.join_side() if learn else None), (self._join_predictors() if self._join_predictors else None)))
+            tape.cut(self.aligner.join_side if learn else None)
         elif self._reducer is not None:
             # data parallel: the decoder / mel_linear / postnet gradients -- the tail of the flat buffer, ~half of the parameters --
             # are final once backward leaves the decoder; their all-reduce runs on a side stream under the backward of the
@@ -904,13 +840,6 @@ class FastSpeech2Trainer:
                 h = batchnorm(tape, dense(tape, h, conv), bn, ops.ACT_TANH if i < len(self.postnet) - 1 else ops.ACT_NONE)
             post = masked(tape, residual(tape, mel, h), mel_lens)
             losses["postnet"] = mse_loss(tape, post, mel_t, n_el, tr.postnet_loss_weight)
-        if side is not None:
-            for ev in self._side_forward_done:  # the predictors' losses are read (summed) on the main stream
-                torch.cuda.current_stream(dev).wait_event(ev)
-            if not torch.cuda.is_current_stream_capturing():
-                for name in ("duration", "pitch", "energy"):
-                    losses[name].record_stream(torch.cuda.current_stream(dev))
-            tape.record(self._start_predictor_backward)
         if _EVAL[0]:
             ops.wgrad_join(dev)
             return self._finish_backward(losses, grads=False)

@@ -23,11 +23,20 @@ B, S = int(os.environ.get("EVMI_TRAIN_B", "16")), 8192
 g = torch.Generator().manual_seed(1234)
 y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(dev)
 mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
-tr = HiFiGANTrainer(device=dev, precision=os.environ.get("OPERANDS", "f32"), use_graph=os.environ.get("GRAPH", "0") == "1",
+pg = None
+if os.environ.get("DP1") == "1":  # the data-parallel code path on a one-rank RCCL group: what its captured stretches cost on one GPU
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    pg = True
+tr = HiFiGANTrainer(device=dev, precision=os.environ.get("OPERANDS", "f32"), use_graph=os.environ.get("GRAPH", "0") == "1", process_group=pg,
                     parallel_streams=os.environ.get("STREAMS", "1") == "1", side_wgrad=os.environ.get("SIDE_WGRAD", "0") == "1")
 for i in range(4):
     out = tr.training_step(mel, y)
-print("graph:", len(tr._graphs), tr._graph_failed)
+print("graph:", [len(e["graphs"]) for e in tr._graphs.values()], tr._graph_failed)
 torch.cuda.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 t0 = time.perf_counter()
@@ -42,3 +51,6 @@ if tr.phase_times:
         if len(sec) > 3:
             print("  branches (ms):", sec)
 print(f"G params {tr.g_params.numel():,}  D params {tr.d_params.numel():,}")
+if pg:
+    import torch.distributed as dist
+    dist.destroy_process_group()
