@@ -106,7 +106,8 @@ __global__ void peak_normalize_kernel(const float* __restrict__ src, float* __re
 // normalised-autocorrelation tracker with the same interface -- one value per hop at t = f * hop, 0 for unvoiced frames, search
 // range [f0_floor, f0_ceil] = WORLD's defaults [71, 800] Hz -- so that FastSpeech2's pitch targets can be made on the device:
 //   r(lag) = sum_n x[n] x[n + lag] / sqrt(sum_n x[n]^2 * sum_n x[n + lag]^2)      n over a window of `win` samples centred on the frame
-//   best   = the SMALLEST lag whose r is a local maximum >= 0.85 * max_lag r (guards against picking a multiple of the period)
+//   best   = the SMALLEST lag whose r is a local maximum >= 0.95 * max_lag r (guards against picking a multiple of the period;
+//            at 0.85 formant structure put a half-period peak in reach on real speech: octave-up runs on LJ010-0008)
 //   voiced = r(best) >= threshold;  f0 = sr / (best + parabolic offset)
 // One workgroup per (frame, item); lags are spread over the threads, the window is staged once in LDS.
 __global__ __launch_bounds__(256) void pitch_acf_kernel(const float* __restrict__ audio, const int* __restrict__ lens, float* __restrict__ f0,
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void pitch_acf_kernel(const float* __restrict_
   float out = 0.f;
   if (f * hop < n + hop && rmax >= threshold) {
     for (int li = 1; li < nl - 1; ++li) {
-      if (r[li] >= 0.85f * rmax && r[li] >= r[li - 1] && r[li] >= r[li + 1]) {
+      if (r[li] >= 0.95f * rmax && r[li] >= r[li - 1] && r[li] >= r[li + 1]) {
         const float a = r[li - 1], c0 = r[li], d = r[li + 1];
         const float den = a - 2.f * c0 + d;
         const float off = fabsf(den) > 1e-12f ? 0.5f * (a - d) / den : 0.f;

@@ -144,11 +144,14 @@ def loudness(audio: torch.Tensor, lens: torch.Tensor, sample_rate: int) -> torch
 
 
 def extract_pitch(audio: torch.Tensor, lens: torch.Tensor | None, hop: int, sample_rate: int, f0_floor: float = 71.0, f0_ceil: float = 800.0,
-                  voicing_threshold: float = 0.5, interpolate: bool = True) -> torch.Tensor:
+                  voicing_threshold: float = 0.8, interpolate: bool = True) -> torch.Tensor:
     """Frame-level pitch [items, S // hop + 1] (Hz) of a zero-padded batch [items, t_max] on the device -- the interface and the
     post-processing of ``Preprocessor.extract_pitch`` (preprocessor.py:244-285: unvoiced frames -> NaN -> linear interpolation
     across them, an utterance without any voiced frame -> zeros), with a normalised-autocorrelation estimator in place of
-    pyworld's dio + stonemask (third-party CPU DSP, not reproduced: the VALUES differ from the reference's, the format does not)."""
+    pyworld's dio + stonemask (third-party CPU DSP, not reproduced: the VALUES differ from the reference's, the format does not).
+    A frame is voiced when its best normalised autocorrelation reaches ``voicing_threshold``; 0.8 (and the 95 % rule for the
+    shortest acceptable lag) are what the speech anchor of tests/test_pipeline.py settled: at 0.5 / 85 % weakly periodic frames
+    produced octave-up runs on the reference's LJ010-0008 (phone-level correlation with its ming024 pitch fixture 0.40; now 0.96)."""
     from . import _lib
 
     if not audio.is_cuda:

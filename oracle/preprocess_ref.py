@@ -85,9 +85,9 @@ def loudness_ref(waveform: torch.Tensor, sample_rate: int) -> float:
         return float(bias + 10 * np.log10((g[:, 0] * ef).sum()))
 
 
-def pitch_acf_ref(audio: np.ndarray, hop: int, sr: int, f0_floor: float = 71.0, f0_ceil: float = 800.0, threshold: float = 0.5) -> np.ndarray:
+def pitch_acf_ref(audio: np.ndarray, hop: int, sr: int, f0_floor: float = 71.0, f0_ceil: float = 800.0, threshold: float = 0.8) -> np.ndarray:
     """The product's own F0 estimator restated (NOT pyworld -- see csrc/preprocess_ops.hip: pitch_acf_kernel): normalised
-    autocorrelation over a window of two periods of f0_floor centred on each frame, smallest local maximum within 85 % of the
+    autocorrelation over a window of two periods of f0_floor centred on each frame, smallest local maximum within 95 % of the
     best, parabolic refinement; 0 where max r < threshold.  [S] -> [S // hop + 1] Hz."""
     x = np.asarray(audio, dtype=np.float32)
     n = len(x)
@@ -110,7 +110,7 @@ def pitch_acf_ref(audio: np.ndarray, hop: int, sr: int, f0_floor: float = 71.0, 
         if rmax < threshold:
             continue
         for li in range(1, len(r) - 1):
-            if r[li] >= 0.85 * rmax and r[li] >= r[li - 1] and r[li] >= r[li + 1]:
+            if r[li] >= 0.95 * rmax and r[li] >= r[li - 1] and r[li] >= r[li + 1]:
                 den = r[li - 1] - 2 * r[li] + r[li + 1]
                 off = 0.5 * (r[li - 1] - r[li + 1]) / den if abs(den) > 1e-12 else 0.0
                 out[f] = sr / (lags[li] + min(max(off, -0.5), 0.5))

@@ -164,26 +164,35 @@ def test_train_base_command_fastspeech2_over_a_preprocessed_directory(dataset, c
     from everyvoice_amd.fs2_dataset import FastSpeech2DataModule
     from everyvoice_amd.lightning import FastSpeech2, FastSpeech2Config, train_base_command
 
-    root, _, kept = dataset
+    root, _, _ = dataset
     pre = pipeline.GpuPreprocessor(device=cuda_device)
     g = torch.Generator().manual_seed(1)
     items = []
-    for k in kept:
+    for i, n in enumerate([40000, 30000, 52000, 25000, 36000, 45000]):
+        # voiced material (harmonics on a gliding fundamental + a little noise): the fixture's white noise has no pitch, and an
+        # all-unvoiced data set has zero pitch variance -- its standardised targets are 0 / 0, in the reference as here
+        t = torch.arange(n, dtype=torch.float32) / 22050.0
+        f0 = 110.0 + 15.0 * i + 60.0 * t / t[-1]
+        phase = 2 * np.pi * torch.cumsum(f0, 0) / 22050.0
+        x = sum(torch.sin(k * phase) / k for k in (1, 2, 3, 4)) * 0.15 + 0.01 * torch.randn(n, generator=g)
+        _write_wav(root / f"v{i}.wav", x.numpy())
         n_tok = 6 + int(torch.randint(0, 6, (1,), generator=g))
-        items.append(dict(basename=k["basename"], speaker="default", language="default", wav=k["wav"],
+        items.append(dict(basename=f"v{i}", speaker="default", language="default", wav=root / f"v{i}.wav",
                           character_tokens="/".join("abcd"[int(j)] for j in torch.randint(0, 4, (n_tok,), generator=g))))
-    kept2 = pre.process(items, root / "pre", overwrite=True)
+    kept2 = pre.process(items, root / "pre_fs2")
+    assert len(kept2) == 6
     for k in kept2:  # [frames, tokens] float64, the reference's file name
-        prior = torch.load(root / "pre" / "attn" / f"{k['basename']}--default--default--characters-attn-prior.pt", weights_only=True)
+        prior = torch.load(root / "pre_fs2" / "attn" / f"{k['basename']}--default--default--characters-attn-prior.pt", weights_only=True)
         assert prior.dtype == torch.float64 and tuple(prior.shape) == (k["frames"], len(k["character_tokens"].split("/")))
         # (probabilities of the zoomed beta-binomial table; the values are pinned against the reference in test_gpu_length_regulator.py)
         assert torch.isfinite(prior).all() and float(prior.min()) >= 0.0 and float(prior.max()) <= 1.0 and float(prior.sum()) > 0.0
-    stats = pre.normalize_stats(root / "pre", *pre.compute_stats(root / "pre"))
+    stats = pre.normalize_stats(root / "pre_fs2", *pre.compute_stats(root / "pre_fs2"))
+    assert stats["pitch"]["std"] > 1.0 and 100.0 < stats["pitch"]["mean"] < 300.0  # Hz before standardisation: the glides above
     st = Stats(pitch=StatsInfo(**{f: stats["pitch"][f] for f in ("min", "max", "std", "mean", "norm_min", "norm_max")}),
                energy=StatsInfo(**{f: stats["energy"][f] for f in ("min", "max", "std", "mean", "norm_min", "norm_max")}))
     pre.write_filelist(kept2, root / "fs2_train.psv")
     pre.write_filelist(kept2[:3], root / "fs2_val.psv")
-    cfg = dict(model=_small_fs2_model_dict(), symbols=list("abcd"), preprocessing=dict(save_dir=str(root / "pre")),
+    cfg = dict(model=_small_fs2_model_dict(), symbols=list("abcd"), preprocessing=dict(save_dir=str(root / "pre_fs2")),
                training=dict(batch_size=2, train_data_workers=0, max_steps=4, val_check_interval=2, save_top_k_ckpts=1, training_filelist=str(root / "fs2_train.psv"),
                              validation_filelist=str(root / "fs2_val.psv"), logger=dict(save_dir=str(root / "logs"), name="fs2")))
     (root / "fs2.json").write_text(json.dumps(cfg))
