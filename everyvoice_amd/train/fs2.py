@@ -426,6 +426,8 @@ class _AlignerT:
         before that backward must not leave the forked stream unjoined)."""
         if getattr(self, "_pending_done", None) is not None:
             torch.cuda.current_stream(self._pending_done_device).wait_event(self._pending_done)
+            self._pending_done = None  # joined: the aligner's backward (possibly in the NEXT captured stretch) must not wait on an
+                                       # event that belongs to this one
 
     def forward(self, tape: Tape, text_emb: Var, mel: Var, prior, text_lens32, mel_lens32, n_frames_dev, ctc_weight: float, bin_weight: float):
         """-> ``join``; ``join() -> (losses dict, hard durations [B, L] int32, hard alignment)`` once the main stream needs them.
@@ -471,7 +473,7 @@ class _AlignerT:
             return losses, dur, hard
 
         def bwd():
-            torch.cuda.current_stream(logprob.device).wait_event(done)
+            self.join_side()  # (the CTC side stream: its gradient is needed now)
             dq, dk = ops.align_attention_bwd(q.data, k.data, soft, logprob, prior, hard if bin_weight > 0.0 else None, dlogprob, text_lens32,
                                              self.temperature, bin_weight, bin_count=n_frames_dev)
             q.accumulate(dq)

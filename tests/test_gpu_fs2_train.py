@@ -828,3 +828,41 @@ def test_graph_buckets_pad_to_a_small_set_of_shapes(cuda_device):
             assert torch.equal(le[k], lg[k]), (i, k)
     assert len(tr._graphs) <= len(shapes) <= 2 and tr._graph_failed is None and tr.last_step_was_graph
     assert torch.equal(tr.params.flat, plain.params.flat)
+
+
+@pytest.mark.parametrize("learn_alignment", [False, True])
+def test_graph_mode_under_data_parallelism_on_rccl_world_of_one(cuda_device, learn_alignment):
+    """use_graph=True with a process group (what bench.py runs on N > 1 GPUs): the step is captured in three stretches -- forward +
+    backward down to the decoder | the rest of the backward | clipping + optimiser -- with the two bucket all-reduces launched
+    between the replays (the first one on a side stream, under the second stretch).  On a one-rank "nccl" group five steps must
+    end exactly where five single-GPU steps end (dropout on: the seed base carries the rank and the world size)."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+
+    ref_cfg = _ref_cfg(0.1)
+    batches = [_shaped_batch(ref_cfg, seed, learn_alignment, cuda_device) for seed in (5, 6)]
+    plain = _trainer(ref_cfg, cuda_device, learn_alignment=learn_alignment)
+    for i in range(5):
+        plain.training_step(batches[i % 2])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_device)
+    try:
+        dp = _trainer(ref_cfg, cuda_device, learn_alignment=learn_alignment, process_group=True, use_graph=True)
+        used = []
+        for i in range(5):
+            dp.training_step(batches[i % 2])
+            used.append(dp.last_step_was_graph)
+        torch.cuda.synchronize()
+        assert dp._graph_failed is None, dp._graph_failed
+        assert used == [False, False, True, True, True] and [len(e["graphs"]) for e in dp._graphs.values()] == [3]
+    finally:
+        dist.destroy_process_group()
+    sa, sb = plain.state_dict(), dp.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(plain.params.m, dp.params.m)
