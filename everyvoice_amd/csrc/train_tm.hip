@@ -107,9 +107,9 @@ __global__ void tm_lrelu_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict
 }
 
 // column sums of dy [rows][C] in two fixed-order passes: part[blk][C] over COLSUM_ROWS rows each, then db[c] (+)= sum_blk.
-// 256 rows per workgroup: ~530 workgroups at 16 x 8192 rows (the first version gave every workgroup 2048 rows -- 66 workgroups on
-// 256 CUs, 38 us per launch, 2.7 ms per GAN step).
-constexpr int COLSUM_ROWS = 256;
+// 512 rows per workgroup: ~265 workgroups at 16 x 8192 rows (the first version gave every workgroup 2048 rows -- 66 workgroups on
+// 256 CUs, 38 us per launch, 2.7 ms per GAN step; 256 rows made the second pass walk 66 partial rows per thread: 11 us).
+constexpr int COLSUM_ROWS = 512;
 __global__ __launch_bounds__(256) void tm_colsum_partial_kernel(const bf16_t* __restrict__ dy, float* __restrict__ part, long long rows, int C) {
   // thread = (row lane rl, octet o): 256 threads cover 256 / octs rows per pass
   const int octs = C >> 3;
