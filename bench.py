@@ -61,6 +61,9 @@ def parse_args(argv=None):
     p.add_argument("--profile-passes", type=int, default=3)
     p.add_argument("--no-train", action="store_true", help="skip the GAN-training leg (second half of the metric)")
     p.add_argument("--no-fs2", action="store_true", help="skip the FastSpeech2 feature-prediction inference leg")
+    p.add_argument("--no-side-legs", action="store_true",
+                   help="skip the other-precision and length-sensitivity inference legs (profiling runs: per-kernel counters then average over "
+                        "launches of ONE shape)")
     p.add_argument("--train-precision", default="bf16", choices=["bf16", "f32"],
                    help="training legs: bf16 convolution operands with fp32 accumulation / master weights (BASELINE config 3 names bf16), "
                         "or the exact fp32 path; the other one is timed beside it with fewer steps")
@@ -559,6 +562,11 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     flops = 3.0 * forward_flops(batch["lens"], t_i, int(batch["ids"].shape[1]), int(t_i.max()), 32)
     tflops = flops * steps / elapsed / 1e12
     peak = MFMA_PEAK_TFLOPS_BF16 if prec == "bf16" else 157.0
+    traffic, traffic_src = None, None
+    metas = sorted((ROOT / "profiles").glob("*fs2_pmc_summary.meta.json"))
+    if metas:  # recorded rocprofv3 --pmc passes over this step (tools/gpu_profile_fs2_train.sh): HBM bytes per step, all kernels
+        traffic = round(json.loads(metas[-1].read_text())["hbm_bytes_per_step"])
+        traffic_src = f"profiles/{metas[-1].name.replace('.meta', '')}: FETCH_SIZE + WRITE_SIZE of every kernel of the step (raw KiB counters, separate --pmc passes)"
     return {"metric": "fastspeech2_train_steps_per_sec_bs32", "value": round(steps / elapsed, 3), "unit": "steps/s",
             "ms_per_step": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": warmup, "batch_per_gpu": 32, "global_batch": 32 * world,
             "frames_per_sec": round(world * int(t_i.sum()) * steps / elapsed, 1), "scaling": "weak", "dtype": prec,
@@ -567,7 +575,7 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
             "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient buffer in two buckets, the first under the rest of backward)" if world > 1 else ""),
             "params": tr.params.numel(), "last_losses": {k: round(float(v), 4) for k, v in out["losses"].items()},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
-                         "traffic": None, "flop_per_step": flops, "scope": "whole step (forward + backward + optimiser)"}}
+                         "traffic": traffic, "traffic_source": traffic_src, "flop_per_step": flops, "scope": "whole step (forward + backward + optimiser)"}}
 
 
 def cpu_baseline_fs2_train(cores: int, batch: int = 8) -> dict:
@@ -595,6 +603,35 @@ def cpu_baseline_fs2_train(cores: int, batch: int = 8) -> dict:
     return {"value": round(batch / 32.0 / dt, 4), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/fs2_ref.py training step (torch autograd + clipping + AdamW) on the first {batch} utterances of the bench batch, "
                       f"{cores} threads: {dt:.2f} s (median of 3 after 1 warm-up); scaled to 32 utterances per step"}
+
+
+def _side_legs(args, other, gen, mel, samples_per_step, dev, rank, world, barrier, max_reduce):
+    """The other arithmetic beside the headline (the reference computes in fp32; bf16 operands with fp32 accumulation are SURVEY 8(d)
+    C2's contract) and the length sensitivity SURVEY.md 8(d) C2 asks for."""
+    import torch
+
+    model_o = upstream_init_generator(other).to(dev).eval()
+    n_other, w_other = 20, 5
+
+    elapsed_o = timed_region(lambda: model_o.generator(mel), n_other, w_other, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    flops_step = 2.0 * gen.macs_per_sample() * samples_per_step
+    peak_o = 157.0 if other == "f32" else MFMA_PEAK_TFLOPS_BF16
+    tf_o = flops_step * n_other / elapsed_o / 1e12
+    other_precision = {"dtype": other, "value": round(world * samples_per_step * n_other / elapsed_o, 1), "unit": "samples/s",
+                       "ms_per_step": round(elapsed_o / n_other * 1e3, 3), "steps": n_other, "warmup": w_other,
+                       "roofline": {"bound": "mfma", "achieved": round(tf_o, 2), "peak": peak_o, "unit": "TFLOP/s", "frac": round(tf_o / peak_o, 4),
+                                    "scope": "whole forward" + (" on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: 157 TFLOP/s nominal)" if other == "f32" else "")}}
+    del model_o
+    # length sensitivity (SURVEY.md 8(d) C2): the same batch of 32 at 128 and 566 frames, in the headline precision
+    lengths = {}
+    for frames_l in (128, 566):
+        mel_l = synthetic_mel(args.batch, frames_l, 1234 + rank).to(dev)
+        el = timed_region(lambda: gen(mel_l), 20, 5, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+        lengths[str(frames_l)] = {"value": round(world * args.batch * frames_l * gen.hop * 20 / el, 1), "unit": "samples/s", "ms_per_step": round(el / 20 * 1e3, 3),
+                                  "steps": 20, "warmup": 5}
+        del mel_l
+
+    return other_precision, lengths
 
 
 def main(argv=None) -> int:
@@ -652,25 +689,9 @@ def main(argv=None) -> int:
     value = world * samples_per_step * args.steps / elapsed
     # the other arithmetic beside it (the reference computes in fp32; bf16 operands with fp32 accumulation are SURVEY 8(d) C2's contract)
     other = "f32" if args.precision == "bf16" else "bf16"
-    model_o = upstream_init_generator(other).to(dev).eval()
-    n_other, w_other = 20, 5
-    elapsed_o = timed_region(lambda: model_o.generator(mel), n_other, w_other, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
-    flops_step = 2.0 * gen.macs_per_sample() * samples_per_step
-    peak_o = 157.0 if other == "f32" else MFMA_PEAK_TFLOPS_BF16
-    tf_o = flops_step * n_other / elapsed_o / 1e12
-    other_precision = {"dtype": other, "value": round(world * samples_per_step * n_other / elapsed_o, 1), "unit": "samples/s",
-                       "ms_per_step": round(elapsed_o / n_other * 1e3, 3), "steps": n_other, "warmup": w_other,
-                       "roofline": {"bound": "mfma", "achieved": round(tf_o, 2), "peak": peak_o, "unit": "TFLOP/s", "frac": round(tf_o / peak_o, 4),
-                                    "scope": "whole forward" + (" on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: 157 TFLOP/s nominal)" if other == "f32" else "")}}
-    del model_o
-    # length sensitivity: the same batch of 32 at 128 and 566 frames, in the headline precision
-    lengths = {}
-    for frames_l in (128, 566):
-        mel_l = synthetic_mel(args.batch, frames_l, 1234 + rank).to(dev)
-        el = timed_region(lambda: gen(mel_l), 20, 5, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
-        lengths[str(frames_l)] = {"value": round(world * args.batch * frames_l * gen.hop * 20 / el, 1), "unit": "samples/s", "ms_per_step": round(el / 20 * 1e3, 3),
-                                  "steps": 20, "warmup": 5}
-        del mel_l
+    other_precision, lengths = None, {}
+    if not args.no_side_legs:
+        other_precision, lengths = _side_legs(args, other, gen, mel, samples_per_step, dev, rank, world, barrier, max_reduce)
 
     train = None
     if not args.no_train:

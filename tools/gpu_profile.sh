@@ -5,7 +5,7 @@ TAG=${1:-r01}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-FLAGS=${BENCH_FLAGS:---no-train --no-fs2}
+FLAGS="${BENCH_FLAGS:---no-train --no-fs2} --no-side-legs"
 BENCH="python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --profile-passes 1 $FLAGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- $BENCH > $OUT/${TAG}_trace.log 2>&1
 # PMC passes: counters only (no other trace domains), one TCC-heavy counter per pass
