@@ -153,8 +153,10 @@ __global__ __launch_bounds__(256) void prep_pk_kernel(PackArgs p, WfragArgs f) {
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
-  static_assert(WM * WN == 4, "four waves");
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) {
+  static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves");
+  constexpr int NW = WM * WN;  // eight-wave tiles: the loads of a ring step are issued by twice the waves (an LDS-direct load costs its
+                               // wave ~100 cycles of issue while the LDS feeds MFMAs), and a CU holds 16 waves instead of 8
   constexpr int MT = BM / (WM * 32), NT = BN / (WN * 32), MBT = BM / 32;
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
 
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     for (int mbi = 0; mbi < MBT; ++mbi) {
       const uint4* src = wf_tile + ((long long)min(mbi, mb_last) * a.kblocks + q0) * 64 + lane;
       uint4* dst = sa + mbi * kbs * 64;
-      for (; u < nq; u += 4) {
+      for (; u < nq; u += NW) {
         pk_lds_direct(src + u * 64, dst + u * 64);
         ++issued;
       }
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_pk_kernel(ConvPkArgs a) {
     const int o_lo = (2 * q0) / k;
     const int o_hi = min(a.octs - 1, (2 * (q0 + nq) - 1) / k);
     const int nunits = (o_hi - o_lo + 1) * pieces;
-    for (; u < nunits; u += 4) {
+    for (; u < nunits; u += NW) {
       const int r = u / pieces, pi = u - r * pieces;
       const int pp = pi * 64 + lane;
       pk_lds_direct(xwin + (long long)(o_lo + r) * plane + (pp ^ ((pp >> 4) & swz)), sx + r * xrow + pi * 64);
@@ -436,7 +438,8 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a) {
 
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct PkTile { int bm, bn; };
-static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {64, 256}, {32, 256}, {128, 256}};
+// (index 7, 8: eight-wave forms of 128 x 256 and 128 x 128 -- 64 x 64 / 64 x 32 per wave)
+static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {64, 256}, {32, 256}, {128, 256}, {128, 256}, {128, 128}};
 constexpr int kNumPkTiles = sizeof(kPkTiles) / sizeof(kPkTiles[0]);
 
 static int pk_env_int(const char* name, int dflt) {
@@ -520,6 +523,10 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     static const long long want0 = 384, want6 = 384;
     static const int kb6 = 128;
     if (a.cout_g >= 128 && a.kblocks >= kb6 && blocks(6) >= want6) cand[nc++] = 6;
+    //  * short contractions on many columns (the FastSpeech2 decoder's 256-channel dense layers: 16 K blocks, 26 k columns): the
+    //    eight-wave 128 x 128 tile -- 71 vs 82 us (256 -> 1024), 56 vs 62 us (256 -> 768), pack included (tools/pk_tile_sweep.py);
+    //    slower everywhere else (longer contractions, short items, grouped layers), as is the eight-wave 128 x 256 tile
+    if (a.kblocks <= 16 && a.k == 1 && blocks(8) >= 2 * want0) cand[nc++] = 8;
     if (blocks(0) >= want0) cand[nc++] = 0;
     if (blocks(1) >= want || nc == 0) cand[nc++] = blocks(1) >= want ? 1 : 2;
     cand[nc++] = 2; cand[nc++] = 3;
@@ -636,7 +643,7 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
       configured[IDX] = lds;                                                                                             \
     }                                                                                                                    \
-    hipLaunchKernelGGL((conv_pk_kernel<BM, BN, WM, WN>), pl.grid, dim3(256), lds, stream, a);                            \
+    hipLaunchKernelGGL((conv_pk_kernel<BM, BN, WM, WN>), pl.grid, dim3(WM * WN * 64), lds, stream, a);                   \
   }
   switch (pl.ti) {
     case 0: EVMI_PK_LAUNCH(128, 128, 2, 2, 0) break;
@@ -645,6 +652,8 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
     case 4: EVMI_PK_LAUNCH(64, 256, 1, 4, 4) break;
     case 5: EVMI_PK_LAUNCH(32, 256, 1, 4, 5) break;
     case 6: EVMI_PK_LAUNCH(128, 256, 2, 2, 6) break;
+    case 7: EVMI_PK_LAUNCH(128, 256, 2, 4, 7) break;
+    case 8: EVMI_PK_LAUNCH(128, 128, 2, 4, 8) break;
     default: EVMI_PK_LAUNCH(32, 128, 1, 4, 3) break;
   }
 #undef EVMI_PK_LAUNCH

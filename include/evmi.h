@@ -300,8 +300,8 @@ int evmi_conv1d_wgrad_cbt_bf16pk_fused(const float* x_dev, const float* dy_dev, 
                                        int groups, int accumulate, float x_pre_slope, const float* dy_mask_dev,
                                        float dy_mask_slope, void* stream);
 /* Which kernel instantiation the planner of the packed bf16 kernels picks for a shape (what tests and profiles name):
- *   evmi_conv1d_cbt_bf16pk_plan / evmi_conv1d_dgrad_cbt_bf16pk_plan: tile index 0..6 = conv_pk_kernel<128,128> <64,128> <64,64>
- *   <32,128> <64,256> <32,256> <128,256>, + 16 * the split-K factor when the contraction is split over workgroups (ksplit > 1);
+ *   evmi_conv1d_cbt_bf16pk_plan / evmi_conv1d_dgrad_cbt_bf16pk_plan: tile index 0..8 = conv_pk_kernel<128,128> <64,128> <64,64>
+ *   <32,128> <64,256> <32,256> <128,256>, 7 / 8 = the eight-wave <128,256> / <128,128>, + 16 * the split-K factor when the contraction is split over workgroups (ksplit > 1);
  *   evmi_conv1d_wgrad_cbt_bf16pk_plan: taps per workgroup of wgrad_pk_kernel<4 | 8>, + 16 * the number of K splits.
  * -1 = shape not taken by that kernel (the matching *_ws_elems is 0).  Replaces nothing in the reference (it has no kernels:
  * torch picks its own through F.conv1d, e.g. everyvoice/model/utils.py:10-45); exists so that parity tests can assert that the

@@ -441,8 +441,8 @@ def test_bf16_packed_kernels_edge_shapes(cuda_device, bf16_operands, case):
 # instantiations are what evmi_conv1d_*_bf16pk_plan reports with no EVMI_PK_* switch set (tile index: see include/evmi.h)
 BENCH_SHAPE_CASES = [
     ("fs2 postnet 512->512 k5 on 32 x 814", 32, 814, 512, 512, 5, 1, 2, 1, 1, 6, 6, 8),        # conv_pk_kernel<128, 256>
-    ("fs2 ffn 256->1024 on 32 x 814", 32, 814, 256, 1024, 1, 1, 0, 1, 1, 0, 0, 4),             # <128, 128> from 1.5 workgroups per CU
-    ("fs2 ffn 1024->256 on 32 x 814", 32, 814, 1024, 256, 1, 1, 0, 1, 1, 0, 0, 4),
+    ("fs2 ffn 256->1024 on 32 x 814", 32, 814, 256, 1024, 1, 1, 0, 1, 1, 8, 0, 4),             # the eight-wave <128, 128> for short contractions
+    ("fs2 ffn 1024->256 on 32 x 814", 32, 814, 1024, 256, 1, 1, 0, 1, 1, 0, 8, 4),
     ("fs2 postnet 80->512 k5 on 32 x 947", 32, 947, 80, 512, 5, 1, 2, 1, 1, 0, 0, 8),          # dgrad: split-K <128, 128>
     ("fs2 encoder 256->768 on 32 x 187", 32, 187, 256, 768, 1, 1, 0, 1, 1, 1, 2, 4),           # <64, 128> / <64, 64>
     ("gan generator c32 k11 d5 on 16 x 8192", 16, 8192, 32, 32, 11, 1, 25, 5, 1, 3, 3, 8),     # <32, 128>
@@ -492,9 +492,10 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
         assert err <= 1e-4, (name, what, err)  # fp32 accumulation of exact bf16 products: summation order only
 
 
-@pytest.mark.parametrize("tile", range(7))
+@pytest.mark.parametrize("tile", range(9))
 def test_packed_conv_every_tile_forced(tile):
-    """conv_pk_kernel<128,128 | 64,128 | 64,64 | 32,128 | 64,256 | 32,256 | 128,256>: the planner picks one per shape; here every one
+    """conv_pk_kernel<128,128 | 64,128 | 64,64 | 32,128 | 64,256 | 32,256 | 128,256> and the eight-wave <128,256> / <128,128> (indices 7, 8):
+    the planner picks one per shape; here every one
     of them is FORCED (EVMI_PK_TILE, read once per process -> a child process each) through the bf16 comparisons with torch of
     this file -- the bench shapes, the edge shapes and the strided / grouped input-gradient shapes -- so a tile the planner starts choosing tomorrow (as <128, 256>
     was switched on at the end of round 2) has already met the oracle.  Shapes a forced tile cannot stage fall back to the exact
