@@ -84,6 +84,7 @@ SYMBOLS = {
         C.c_int,
         [C.c_void_p] * 7 + [C.c_int] * 7 + [C.c_void_p],
     ),
+    "evmi_spectrogram_layout_f32": (C.c_int, [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p]),
     "evmi_gemm_f32": (C.c_int, [C.c_int] * 5 + [C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p]),
     "evmi_conv1d_cbt_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),
     "evmi_conv1d_cbt_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 15 + [C.c_float, C.c_void_p]),

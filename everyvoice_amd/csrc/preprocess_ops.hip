@@ -164,6 +164,29 @@ __global__ __launch_bounds__(256) void pitch_acf_kernel(const float* __restrict_
   f0[(long long)b * n_frames + f] = out;
 }
 
+
+// Finishing pass of the generic spectrogram transforms (spec types "linear" / "raw" / "mel" / "istft" of
+// everyvoice/utils/heavy.py:47-119): the DFT is evmi_stft_frames_f32 + evmi_gemm_f32 and leaves real / imaginary planes [C][B*F];
+// torchaudio's tensors are batch-major.  One thread per output element, consecutive threads along F (both sides coalesced).
+__global__ void spectrogram_layout_kernel(int mode, const float* __restrict__ re, const float* __restrict__ im, float* __restrict__ out,
+                                          int B, int C, int F) {
+  const long long n = (long long)B * C * F;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int f = (int)(i % F);
+  const int c = (int)((i / F) % C);
+  const int b = (int)(i / ((long long)F * C));
+  const long long plane = (long long)c * B * F + (long long)b * F + f;  // [C][B*F]
+  if (mode == 0) out[i] = re[plane] * re[plane] + im[plane] * im[plane];
+  else if (mode == 1) { out[2 * i] = re[plane]; out[2 * i + 1] = im[plane]; }
+  else if (mode == 2) out[i] = re[plane];
+  else if (mode == 4) out[i] = sqrtf(re[plane] * re[plane] + im[plane] * im[plane]);
+  else {  // 3: complex [B][C][F][2] (re) -> real rows then imaginary rows [2C][B*F] (out)
+    out[plane] = re[2 * i];
+    out[(long long)C * B * F + plane] = re[2 * i + 1];
+  }
+}
+
 }  // namespace evmi
 
 using namespace evmi;
@@ -224,6 +247,15 @@ int evmi_peak_normalize_f32(const float* src_dev, float* dst_dev, const int* len
   if (!src_dev || !dst_dev || !lens_dev || items <= 0 || t_max <= 0) return fail(EVMI_ERR_INVALID_ARG, "peak_normalize: arguments");
   hipLaunchKernelGGL(peak_normalize_kernel, dim3(items), dim3(256), 0, (hipStream_t)stream, src_dev, dst_dev, lens_dev, t_max, target);
   EVMI_LAUNCH_CHECK("peak_normalize");
+  return EVMI_OK;
+}
+
+int evmi_spectrogram_layout_f32(int mode, const float* re_dev, const float* im_dev, float* out_dev, int B, int C, int F, void* stream) {
+  if (mode < 0 || mode > 4 || !re_dev || !out_dev || ((mode == 0 || mode == 1 || mode == 4) && !im_dev) || B <= 0 || C <= 0 || F <= 0)
+    return fail(EVMI_ERR_INVALID_ARG, "spectrogram_layout: arguments");
+  const long long n = (long long)B * C * F;
+  hipLaunchKernelGGL(spectrogram_layout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mode, re_dev, im_dev, out_dev, B, C, F);
+  EVMI_LAUNCH_CHECK("spectrogram_layout");
   return EVMI_OK;
 }
 

@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from .config import AudioConfig
-from .spectral import MelSpectrogram
+from .spectral import MelSpectrogram, get_spectral_transform
 
 SEP = "--"
 
@@ -274,14 +274,25 @@ class GpuPreprocessor:
         self.pitch = pitch  # also write pitch/<...>--pitch.pt (FastSpeech2's pitch targets; this library's own estimator, see extract_pitch)
         self.transform = MelSpectrogram(self.cfg.n_fft, self.cfg.fft_window_size, self.cfg.fft_hop_size,
                                         self.cfg.input_sampling_rate, self.cfg.n_mels, self.cfg.f_min, self.cfg.f_max)
+        # spec_type "mel" / "linear" (heavy.py:59-68, 101-107): the generic transforms, one utterance at a time (the ragged one-launch
+        # front end above is the default type's); "raw" is complex and has no log / energy -- the reference's process_spec fails on it too
+        self.generic = None
+        if self.cfg.spec_type != "mel-librosa":
+            if self.cfg.spec_type not in ("mel", "linear"):
+                raise ValueError(f"preprocessing.audio.spec_type {self.cfg.spec_type!r}: a real-valued spectrogram type is needed")
+            self.generic = get_spectral_transform(self.cfg.spec_type, self.cfg.n_fft, self.cfg.fft_window_size, self.cfg.fft_hop_size,
+                                                  self.cfg.input_sampling_rate, self.cfg.n_mels, self.cfg.f_min, self.cfg.f_max)
         self.counters: dict[str, int] = {}
         self._interp = None
 
     def features(self, audio: torch.Tensor):
         """audio [S] (host or device) -> (log-mel [n_mels, S // hop], energy [S // hop]) on the device."""
         x = audio.to(self.device)
-        mel, energy = self.transform(x, log=True, return_energy=True)
         n = x.shape[-1] // self.cfg.fft_hop_size
+        if self.generic is not None:  # extract_spectral_features + extract_energy (preprocessor.py:220-233, 302-309) on any real spec
+            spec = torch.log(torch.clamp(self.generic(x), min=1e-5))[..., :n].contiguous()
+            return spec, torch.linalg.norm(spec, dim=-2)
+        mel, energy = self.transform(x, log=True, return_energy=True)
         return mel[..., :n].contiguous(), energy[..., :n].contiguous()
 
     # -- .config-lock (preprocessor.py:974-1082) ----------------------------------------------------------------------
@@ -337,7 +348,12 @@ class GpuPreprocessor:
                 return
             t_max = max(lens)
             x = x[:, :t_max].contiguous()
-            mel, energy = self.transform(x, log=True, return_energy=True, lens=torch.tensor(lens, dtype=torch.int32))
+            if self.generic is None:
+                mel, energy = self.transform(x, log=True, return_energy=True, lens=torch.tensor(lens, dtype=torch.int32))
+            else:
+                per_item = [self.features(x[j, : lens[j]]) for j in range(len(lens))]
+                mel = torch.nn.utils.rnn.pad_sequence([m.t() for m, _ in per_item], batch_first=True).transpose(1, 2)
+                energy = torch.nn.utils.rnn.pad_sequence([e for _, e in per_item], batch_first=True)
             pitch_host = extract_pitch(x, torch.tensor(lens), hop, sr_tag).cpu() if self.pitch else None
             x_host, mel_host, energy_host = x.cpu(), mel.cpu(), energy.cpu()
             for j, i in enumerate(kept_idx):

@@ -120,6 +120,16 @@ int evmi_mel_spectrogram_ragged_f32(const float* audio_dev, const int* lens_dev,
                                     int n_samples_max, int n_fft, int hop, int n_bins_padded, int n_mels, int apply_log,
                                     void* stream);
 
+/* The other spec types of get_spectral_transform (everyvoice/utils/heavy.py:59-68 "mel" = torchaudio MelSpectrogram(norm="slaney"),
+ * :101-114 "linear" / "raw" = torchaudio Spectrogram(power = 2 / None), :115-118 "istft" = InverseSpectrogram): the DFT itself is
+ * evmi_stft_frames_f32 + evmi_gemm_f32 with the windowed basis, which leaves real / imaginary planes [C][B*F]; this is the finishing
+ * pass into torchaudio's batch-major tensors.
+ *   mode 0: out [B][C][F] = re^2 + im^2      mode 4: sqrt(re^2 + im^2)      mode 1: out [B][C][F][2] = (re, im)  (complex64)
+ *   mode 2: out [B][C][F] = re               (a mel projection [n_mels][B*F] back to batch-major; im_dev unused)
+ *   mode 3: re_dev = complex [B][C][F][2] -> out [2C][B*F]: real rows, then imaginary rows (the inverse transform's operand) */
+int evmi_spectrogram_layout_f32(int mode, const float* re_dev, const float* im_dev, float* out_dev, int B, int C, int F,
+                                void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * HiFiGAN / iSTFTNet generator — replaces the forward of `hfgl.utils.HiFiGANGenerator` /
  * the generator inside `hfgl.model.HiFiGAN` (absent submodule; call sites

@@ -86,3 +86,52 @@ def mel_spectrogram_ref(audio, sr=22050, n_fft=1024, win=1024, hop=256, n_mels=8
     if truncate:
         mel = mel[..., : audio.shape[-1] // hop]
     return mel
+
+
+# ---- the other branches of get_spectral_transform (everyvoice/utils/heavy.py:59-68, 101-118) -------------------------------------------
+# torchaudio is not installed here; its transforms are thin wrappers whose arithmetic is torch.stft / torch.istft (both present) and
+# torchaudio.functional.melscale_fbanks (restated below from its published algorithm: parity of the filterbank is unpinned).
+
+
+def spectrogram_ref(audio: torch.Tensor, n_fft: int, win: int, hop: int, power=2.0) -> torch.Tensor:
+    """torchaudio.transforms.Spectrogram(n_fft, win_length, hop_length, power): torch.stft(hann, centred, reflect, one-sided), then
+    |.|^power (power None: the complex tensor)."""
+    audio = torch.as_tensor(audio, dtype=torch.float32)
+    lead = audio.shape[:-1]  # (torchaudio packs the leading dimensions into one batch axis and unpacks them afterwards)
+    spec = torch.stft(audio.reshape(-1, audio.shape[-1]), n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=True,
+                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+    spec = spec.reshape(lead + spec.shape[-2:])
+    if power is None:
+        return spec
+    return spec.abs() if power == 1 else spec.abs().pow(power)
+
+
+def htk_slaney_fbanks(sr: int, n_freqs: int, n_mels: int, fmin: float, fmax: float) -> np.ndarray:
+    """torchaudio.functional.melscale_fbanks(n_freqs, fmin, fmax, n_mels, sr, norm="slaney", mel_scale="htk") -> [n_freqs, n_mels]."""
+    all_freqs = np.linspace(0, sr // 2, n_freqs)
+    m_min = 2595.0 * np.log10(1.0 + fmin / 700.0)
+    m_max = 2595.0 * np.log10(1.0 + fmax / 700.0)
+    m_pts = np.linspace(m_min, m_max, n_mels + 2)
+    f_pts = 700.0 * (10.0 ** (m_pts / 2595.0) - 1.0)
+    fb = np.zeros((n_freqs, n_mels))
+    for m in range(n_mels):
+        lo, mid, hi = f_pts[m], f_pts[m + 1], f_pts[m + 2]
+        for i, f in enumerate(all_freqs):
+            down = (f - lo) / (mid - lo)
+            up = (hi - f) / (hi - mid)
+            fb[i, m] = max(0.0, min(down, up)) * 2.0 / (hi - lo)
+    return fb.astype(np.float32)
+
+
+def torchaudio_mel_ref(audio, sr, n_fft, win, hop, n_mels, fmin=0.0, fmax=None) -> torch.Tensor:
+    """torchaudio.transforms.MelSpectrogram(..., norm="slaney", center=True): fb^T @ |STFT|^2."""
+    fmax = float(sr // 2) if fmax is None else fmax
+    fb = torch.from_numpy(htk_slaney_fbanks(sr, n_fft // 2 + 1, n_mels, fmin, fmax))
+    spec = spectrogram_ref(audio, n_fft, win, hop, 2.0)
+    return torch.matmul(spec.transpose(-1, -2), fb).transpose(-1, -2)
+
+
+def inverse_spectrogram_ref(spec: torch.Tensor, n_fft: int, win: int, hop: int) -> torch.Tensor:
+    """torchaudio.transforms.InverseSpectrogram(n_fft, win_length, hop_length): torch.istft(hann, centred, one-sided)."""
+    return torch.istft(spec, n_fft, hop_length=hop, win_length=win, window=torch.hann_window(win), center=True, normalized=False,
+                       onesided=True)

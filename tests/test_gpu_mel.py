@@ -91,3 +91,60 @@ def test_silence_and_edges(cuda_device):
         tr(torch.zeros(1, 300, device=cuda_device))
     with pytest.raises(RuntimeError, match="GPU only"):
         tr(torch.zeros(1, 4096))
+
+
+# ---- the other branches of get_spectral_transform (everyvoice/utils/heavy.py:59-68, 101-118) ----------------------------------------
+# Tolerance: the DFT is a fp32 GEMM with a 1024-term (or shorter) dot product per bin where torch runs an FFT: relative to the largest
+# value of the tensor 2e-5; power spectra square that.
+SPEC_CASES = [(1024, 1024, 256, (2, 8192)), (512, 400, 100, (3, 5000)), (400, 400, 200, (1, 2, 4000)), (2048, 1200, 240, (2, 9600))]
+
+
+@pytest.mark.parametrize("n_fft,win,hop,shape", SPEC_CASES)
+def test_linear_and_raw_spectrograms_match_torch_stft(cuda_device, n_fft, win, hop, shape):
+    from everyvoice_amd.spectral import get_spectral_transform
+
+    audio = torch.randn(*shape, generator=torch.Generator().manual_seed(n_fft + hop)) * 0.3
+    lin = get_spectral_transform("linear", n_fft, win, hop)(audio.to(cuda_device)).cpu()
+    want = mel_ref.spectrogram_ref(audio, n_fft, win, hop, 2.0)
+    assert lin.shape == want.shape == shape[:-1] + (n_fft // 2 + 1, 1 + shape[-1] // hop)
+    assert float((lin - want).abs().max()) <= 1e-4 * float(want.max())
+    raw = get_spectral_transform("raw", n_fft, win, hop)(audio.to(cuda_device)).cpu()
+    want_c = mel_ref.spectrogram_ref(audio, n_fft, win, hop, None)
+    assert raw.dtype == torch.complex64 and raw.shape == want_c.shape
+    assert float((raw - want_c).abs().max()) <= 2e-5 * float(want_c.abs().max())
+
+
+def test_torchaudio_mel_branch(cuda_device):
+    from everyvoice_amd.spectral import get_spectral_transform
+
+    audio = torch.randn(2, 12000, generator=torch.Generator().manual_seed(3)) * 0.2
+    tr = get_spectral_transform("mel", 1024, 1024, 256, sample_rate=22050, n_mels=80, f_min=0, f_max=8000)
+    got = tr(audio.to(cuda_device)).cpu()
+    want = mel_ref.torchaudio_mel_ref(audio, 22050, 1024, 1024, 256, 80, 0.0, 8000.0)
+    assert got.shape == want.shape == (2, 80, 1 + 12000 // 256)
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.max())
+
+
+@pytest.mark.parametrize("n_fft,win,hop,shape", SPEC_CASES)
+def test_inverse_spectrogram_matches_torch_istft_and_round_trips(cuda_device, n_fft, win, hop, shape):
+    from everyvoice_amd.spectral import get_spectral_transform
+
+    frames = 1 + shape[-1] // hop
+    g = torch.Generator().manual_seed(hop)
+    spec = torch.complex(torch.randn(*shape[:-1], n_fft // 2 + 1, frames, generator=g), torch.randn(*shape[:-1], n_fft // 2 + 1, frames, generator=g))
+    inv = get_spectral_transform("istft", n_fft, win, hop)
+    got = inv(spec.to(cuda_device)).cpu()
+    want = mel_ref.inverse_spectrogram_ref(spec.reshape(-1, n_fft // 2 + 1, frames), n_fft, win, hop).reshape(shape[:-1] + (-1,))
+    assert got.shape == want.shape == shape[:-1] + (hop * (frames - 1),)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    # analysis -> synthesis returns the signal (the property that holds at any size)
+    audio = torch.randn(*shape, generator=g) * 0.3
+    S = shape[-1] // hop * hop
+    back = inv(get_spectral_transform("raw", n_fft, win, hop)(audio[..., :S].to(cuda_device))).cpu()
+    assert back.shape[-1] == S and float((back - audio[..., :S]).abs().max()) <= 2e-5
+
+
+def test_unknown_spec_type_returns_none_like_the_reference():
+    from everyvoice_amd.spectral import get_spectral_transform
+
+    assert get_spectral_transform("no-such-type", 1024, 1024, 256) is None

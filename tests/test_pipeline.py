@@ -197,6 +197,41 @@ def test_batched_preprocessing_equals_one_by_one_and_dataset_statistics(tmp_path
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("spec_type", ["linear", "mel"])
+def test_preprocessing_with_the_other_spec_types(tmp_path, cuda_device, spec_type):
+    """preprocessing.audio.spec_type "linear" / "mel" (everyvoice/utils/heavy.py:59-68, 101-107): the files carry the type in their
+    name, hold log(clamp(transform(audio), 1e-5)) truncated to samples // hop frames, and energy is its norm over the bins."""
+    from oracle import mel_ref
+
+    gen = torch.Generator().manual_seed(4)
+    items = []
+    for i, n in enumerate([20000, 9000]):
+        _write_wav(tmp_path / f"v{i}.wav", 0.3 * torch.tanh(torch.randn(n, generator=gen)).numpy())
+        items.append(dict(basename=f"v{i}", speaker="default", language="default", wav=tmp_path / f"v{i}.wav"))
+    pre = pipeline.GpuPreprocessor(AudioConfig(spec_type=spec_type), device=cuda_device, batch_items=4, pitch=False)
+    kept = pre.process(items, tmp_path / "o")
+    assert len(kept) == 2
+    for k in kept:
+        wa, _, _ = pipeline.load_wav(tmp_path / "o" / "audio" / f"{k['basename']}--default--default--audio-22050.wav")
+        spec = torch.load(tmp_path / "o" / "spec" / f"{k['basename']}--default--default--spec-22050-{spec_type}.pt")
+        if spec_type == "linear":
+            want = mel_ref.spectrogram_ref(wa[0], 1024, 1024, 256, 2.0)
+        else:
+            want = mel_ref.torchaudio_mel_ref(wa[0], 22050, 1024, 1024, 256, 80, 0.0, 8000.0)
+        want = torch.log(torch.clamp(want, min=1e-5))[:, : k["frames"]]
+        assert spec.shape == want.shape == ((513 if spec_type == "linear" else 80), k["frames"])
+        # compared before the logarithm, relative to the largest bin (the fp32 DFT's error is absolute: the log of a bin 60 dB below
+        # the peak moves by 1e-2), and in the log domain on the bins within 30 dB of it
+        assert float((spec.exp() - want.exp()).abs().max()) <= 1e-4 * float(want.exp().max())
+        loud = want > want.max() - 7.0
+        assert float((spec - want)[loud].abs().max()) <= 2e-3
+        energy = torch.load(tmp_path / "o" / "energy" / f"{k['basename']}--default--default--energy.pt")
+        torch.testing.assert_close(energy, torch.linalg.norm(spec, dim=0), rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        pipeline.GpuPreprocessor(AudioConfig(spec_type="raw"), device=cuda_device)
+
+
+@pytest.mark.gpu
 def test_autocorrelation_pitch_tracker_on_known_tones_and_against_its_own_restatement(cuda_device):
     """extract_pitch (A7) is NOT the reference's estimator (pyworld dio + stonemask, preprocessor.py:244-285): it is this library's
     own normalised-autocorrelation tracker behind the reference's interface.  What this test establishes is therefore limited to:
