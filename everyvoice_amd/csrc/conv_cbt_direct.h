@@ -22,4 +22,10 @@ struct ConvDirectArgs {
 long long conv_direct_plan(const ConvDirectArgs& in, int groups, int& cc, int& nchunks);
 int launch_conv_direct(ConvDirectArgs a, int groups, float* ws, long long ws_elems, hipStream_t stream);
 
+// Weight gradient of a one-input-channel convolution (x [B][t_in], dy [c_out][B][n_out] -> dw [c_out][k]).  Plan: 0 = not such a
+// shape, otherwise the floats of scratch (one partial per workgroup, added in index order by a second launch).
+long long wgrad_cin1_plan(int B, int c_in, int n_out, int c_out, int k, int groups);
+int launch_wgrad_cin1(const float* x, const float* dy, float* dw, float* ws, long long ws_elems, int B, int t_in, int n_out, int c_out, int k,
+                      int stride, int pad, int dil, int accumulate, hipStream_t stream);
+
 }  // namespace evmi

@@ -156,6 +156,109 @@ __global__ __launch_bounds__(256) void conv_cin1_kernel(ConvDirectArgs a) {
   }
 }
 
+// ---- weight gradient of the one-input-channel layers (1 -> 32 k5 s3 of every period discriminator, 1 -> 128 k15 of every scale
+// discriminator):  dw[co][j] = sum_n dy[co][n] * x[b(n)][to(n) * stride + j * dil - pad].  As a GEMM this is 128 x 15 outputs over a
+// 131 k-long contraction: one tile, so the matrix-core kernel splits it 64 ways at most, copies dy into its padded layout first and
+// takes 150-340 us for 67 MB of dy.  Here: thread = column (coalesced rows of dy), 8 output channels x k taps of accumulators per
+// thread, the k inputs of a column loaded once for the 8 channels; the workgroup's accumulators meet in the LDS
+// ([value][thread], one padded row per value) and leave as one partial per workgroup; a second pass adds the partials in index order.
+constexpr int WCIN1_CO = 8;        // output channels per workgroup
+constexpr int WCIN1_COLS = 16;     // columns per thread
+
+struct WgradCin1Args {
+  const float* x;    // [B][t_in]
+  const float* dy;   // [c_out][B][n_out]
+  float* partial;    // [nblk][c_out][k]
+  int B, t_in, n_out, c_out, k, stride, dil, pad;
+};
+
+__global__ __launch_bounds__(256) void wgrad_cin1_kernel(WgradCin1Args a) {
+  extern __shared__ float red[];  // [WCIN1_CO * CIN1_KMAX][257]
+  const int tid = threadIdx.x;
+  const int co0 = blockIdx.y * WCIN1_CO;
+  const long long n_total = (long long)a.B * a.n_out;
+  const long long n0 = (long long)blockIdx.x * (256 * WCIN1_COLS);
+  float acc[WCIN1_CO][CIN1_KMAX];
+#pragma unroll
+  for (int e = 0; e < WCIN1_CO; ++e)
+#pragma unroll
+    for (int j = 0; j < CIN1_KMAX; ++j) acc[e][j] = 0.f;
+  const long long row = n_total;  // elements between channels of dy
+  for (int i = 0; i < WCIN1_COLS; ++i) {
+    const long long n = n0 + (long long)i * 256 + tid;
+    const bool live = n < n_total;
+    const long long nc = live ? n : n_total - 1;
+    const int b = (int)(nc / a.n_out);
+    const int to = (int)(nc - (long long)b * a.n_out);
+    const float* xr = a.x + (long long)b * a.t_in;
+    const int ti0 = to * a.stride - a.pad;
+    float xv[CIN1_KMAX], dv[WCIN1_CO];
+#pragma unroll
+    for (int j = 0; j < CIN1_KMAX; ++j) xv[j] = xr[min(max(ti0 + min(j, a.k - 1) * a.dil, 0), a.t_in - 1)];  // requested together, masked below
+#pragma unroll
+    for (int e = 0; e < WCIN1_CO; ++e) dv[e] = a.dy[(long long)min(co0 + e, a.c_out - 1) * row + nc];
+#pragma unroll
+    for (int j = 0; j < CIN1_KMAX; ++j) {
+      const int ti = ti0 + j * a.dil;
+      xv[j] = (live && j < a.k && ti >= 0 && ti < a.t_in) ? xv[j] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < WCIN1_CO; ++e)
+#pragma unroll
+      for (int j = 0; j < CIN1_KMAX; ++j) acc[e][j] = fmaf(dv[e], xv[j], acc[e][j]);
+  }
+#pragma unroll
+  for (int e = 0; e < WCIN1_CO; ++e)
+#pragma unroll
+    for (int j = 0; j < CIN1_KMAX; ++j) red[(e * CIN1_KMAX + j) * 257 + tid] = acc[e][j];
+  __syncthreads();
+  if (tid < WCIN1_CO * CIN1_KMAX) {
+    const int e = tid / CIN1_KMAX, j = tid - e * CIN1_KMAX;
+    if (co0 + e < a.c_out && j < a.k) {
+      const float* r = red + tid * 257;
+      float v = 0.f;
+      for (int t = 0; t < 256; ++t) v += r[t];  // fixed order
+      a.partial[((long long)blockIdx.x * a.c_out + co0 + e) * a.k + j] = v;
+    }
+  }
+}
+
+__global__ void wgrad_cin1_final_kernel(const float* __restrict__ partial, float* __restrict__ dw, int n, int nblk, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  dw[i] = ordered_sum_strided(partial + i, n, nblk, accumulate ? dw[i] : 0.f);
+}
+
+long long wgrad_cin1_plan(int B, int c_in, int n_out, int c_out, int k, int groups) {
+  static const bool disabled = getenv("EVMI_NO_DIRECT_CONV") != nullptr;
+  if (disabled || c_in != 1 || groups != 1 || k > CIN1_KMAX || c_out > 4096) return 0;
+  const long long n_total = (long long)B * n_out;
+  const long long nblk = (n_total + 256 * WCIN1_COLS - 1) / (256 * WCIN1_COLS);
+  return nblk * c_out * k;
+}
+
+int launch_wgrad_cin1(const float* x, const float* dy, float* dw, float* ws, long long ws_elems, int B, int t_in, int n_out, int c_out, int k,
+                      int stride, int pad, int dil, int accumulate, hipStream_t stream) {
+  const long long need = wgrad_cin1_plan(B, 1, n_out, c_out, k, 1);
+  if (need == 0) return fail(EVMI_ERR_UNSUPPORTED, "wgrad_cin1: not a one-input-channel shape");
+  if (!ws || ws_elems < need) return fail(EVMI_ERR_INVALID_ARG, "wgrad_cin1: workspace missing or too small");
+  const long long n_total = (long long)B * n_out;
+  const int nblk = (int)((n_total + 256 * WCIN1_COLS - 1) / (256 * WCIN1_COLS));
+  WgradCin1Args a{x, dy, ws, B, t_in, n_out, c_out, k, stride, dil, pad};
+  const size_t lds = (size_t)WCIN1_CO * CIN1_KMAX * 257 * sizeof(float);
+  static thread_local bool configured[kMaxDevices] = {};
+  if (!configured[device_slot()]) {
+    EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_cin1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured[device_slot()] = true;
+  }
+  hipLaunchKernelGGL(wgrad_cin1_kernel, dim3(nblk, (c_out + WCIN1_CO - 1) / WCIN1_CO), dim3(256), lds, stream, a);
+  EVMI_LAUNCH_CHECK("wgrad_cin1");
+  const int n = c_out * k;
+  hipLaunchKernelGGL(wgrad_cin1_final_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ws, dw, n, nblk, accumulate);
+  EVMI_LAUNCH_CHECK("wgrad_cin1_final");
+  return EVMI_OK;
+}
+
 long long conv_direct_plan(const ConvDirectArgs& in, int groups, int& cc, int& nchunks) {
   cc = nchunks = 0;
   static const bool disabled = getenv("EVMI_NO_DIRECT_CONV") != nullptr;  // A/B against the matrix-core kernel

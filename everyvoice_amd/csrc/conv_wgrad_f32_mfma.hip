@@ -23,6 +23,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "conv_cbt_direct.h"
 
 namespace evmi {
 
@@ -326,6 +327,7 @@ extern "C" {
 /* Floats of workspace evmi_conv1d_wgrad_cbt_f32 needs for this shape; 0 when the shape is not supported. */
 long long evmi_conv1d_wgrad_cbt_f32_ws_elems(int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil,
                                              int groups) {
+  if (const long long direct = wgrad_cin1_plan(B, c_in, n_out, c_out, k, groups)) return direct + 64;  // (conv_cbt_direct.hip)
   WgradPlan p;
   return plan_wgrad(B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups, p) ? 0 : p.ws_elems;
 }
@@ -334,6 +336,8 @@ int evmi_conv1d_wgrad_cbt_f32(const float* x_dev, const float* dy_dev, float* dw
                               int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil, int groups,
                               int accumulate, void* stream) {
   if (!x_dev || !dy_dev || !dw_dev || !ws_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_cbt_f32: null pointer");
+  if (wgrad_cin1_plan(B, c_in, n_out, c_out, k, groups))  // one input channel: an outer product per column, not a GEMM
+    return launch_wgrad_cin1(x_dev, dy_dev, dw_dev, ws_dev, ws_elems, B, t_in, n_out, c_out, k, stride, pad, dil, accumulate, (hipStream_t)stream);
   WgradPlan p;
   if (const char* why = plan_wgrad(B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups, p))
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_wgrad_cbt_f32: ") + why);

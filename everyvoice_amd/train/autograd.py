@@ -215,16 +215,16 @@ def scale(tape: Tape, x: Var, s: float) -> Var:
 
 
 def avgpool4s2(tape: Tape, x: Var) -> Var:
-    y = Var(ops.avgpool4s2(x.data))
-    t_in = x.data.shape[2]
-    tape.record(lambda: y.grad is not None and x.accumulate(ops.avgpool4s2_bwd(y.grad, t_in)))
+    y = Var(ops.avgpool4s2(x.data), needs_grad=x.needs_grad)  # (a view of a gradient-free input needs none: the first convolution
+    t_in = x.data.shape[2]                                      #  behind it skips its input gradient)
+    tape.record(lambda: y.grad is not None and x.needs_grad and x.accumulate(ops.avgpool4s2_bwd(y.grad, t_in)))
     return y
 
 
 def period_view(tape: Tape, x: Var, period: int) -> Var:
     _, B, T = x.data.shape
-    y = Var(ops.period_view(x.data, period))
-    tape.record(lambda: y.grad is not None and x.accumulate(ops.period_view_bwd(y.grad, B, T, period)))
+    y = Var(ops.period_view(x.data, period), needs_grad=x.needs_grad)
+    tape.record(lambda: y.grad is not None and x.needs_grad and x.accumulate(ops.period_view_bwd(y.grad, B, T, period)))
     return y
 
 

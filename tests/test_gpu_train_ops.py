@@ -222,7 +222,10 @@ WGRAD_CASES = [
     (22, 28, 64, 96, 5, 3, 2, 1, 1),          # strided (k,1) convolution on short rows
     (4, 513, 64, 128, 41, 4, 20, 1, 16),      # scale discriminator: grouped, stride 4, odd length
     (3, 65, 40, 1, 3, 1, 1, 1, 1),            # logit convolution (one output channel)
-    (5, 333, 1, 32, 15, 1, 7, 1, 1),          # first layer (one input channel)
+    (5, 333, 1, 32, 15, 1, 7, 1, 1),          # first layer (one input channel): the direct kernel of conv_cbt_direct.hip
+    (64, 1366, 1, 32, 5, 3, 2, 1, 1),         # ... period discriminator's, strided: several column blocks, partials added in order
+    (3, 9000, 1, 128, 15, 1, 7, 1, 1),        # ... scale discriminator's
+    (2, 100, 1, 20, 16, 2, 3, 2, 1),          # ... the longest kernel it takes, dilated, channels not a multiple of its block of 8
     (2, 1000, 32, 32, 3, 1, 1, 1, 1),         # 42 channels per column tile would exceed cin: clipped tile
 ]
 
