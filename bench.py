@@ -693,11 +693,21 @@ def main(argv=None) -> int:
     if not args.no_side_legs:
         other_precision, lengths = _side_legs(args, other, gen, mel, samples_per_step, dev, rank, world, barrier, max_reduce)
 
+    def guarded(name, fn, *a):
+        """The secondary legs never take the headline line down with them: a failure is reported in the leg's object (and on stderr)."""
+        try:
+            return fn(*a)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+
+            traceback.print_exc(file=sys.stderr)
+            return {"error": f"{name}: {type(e).__name__}: {e}"}
+
     train = None
     if not args.no_train:
-        train = train_leg(args, dev, rank, world, use_dist, barrier, max_reduce)
-    fs2 = None if args.no_fs2 else fs2_leg(args, dev, rank, world, barrier, max_reduce)
-    fs2_train = None if args.no_fs2 else fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce)
+        train = guarded("train_leg", train_leg, args, dev, rank, world, use_dist, barrier, max_reduce)
+    fs2 = None if args.no_fs2 else guarded("fs2_leg", fs2_leg, args, dev, rank, world, barrier, max_reduce)
+    fs2_train = None if args.no_fs2 else guarded("fs2_train_leg", fs2_train_leg, args, dev, rank, world, use_dist, barrier, max_reduce)
 
     result = None
     if rank == 0:
@@ -751,11 +761,12 @@ def main(argv=None) -> int:
             result["cpu_baseline"] = cpu_baseline(args.cpu_frames, args.cpu_batch)
             result["gpu_over_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
             cores = result["cpu_baseline"]["cores"]
-            if train is not None:
-                train["cpu_baseline"] = cpu_baseline_train(cores)
-            if fs2 is not None:
-                fs2["cpu_baseline"] = cpu_baseline_fs2(cores)
-                fs2_train["cpu_baseline"] = cpu_baseline_fs2_train(cores)
+            if train is not None and "error" not in train:
+                train["cpu_baseline"] = guarded("cpu_baseline_train", cpu_baseline_train, cores)
+            if fs2 is not None and "error" not in fs2:
+                fs2["cpu_baseline"] = guarded("cpu_baseline_fs2", cpu_baseline_fs2, cores)
+            if fs2_train is not None and "error" not in fs2_train:
+                fs2_train["cpu_baseline"] = guarded("cpu_baseline_fs2_train", cpu_baseline_fs2_train, cores)
     if use_dist:
         import torch.distributed as dist
 

@@ -376,6 +376,15 @@ def allreduce_mean_(flat_grad: torch.Tensor, process_group, scale_fn) -> torch.T
     return flat_grad
 
 
+def capture_agreed(ok: bool, pg, device) -> bool:
+    """True when every rank of the group reports ``ok`` (one MIN all-reduce of a flag, issued by every rank whatever its own outcome)."""
+    import torch.distributed as dist
+
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(None if pg is True else pg) == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=None if pg is True else pg)
+    return bool(int(flag.item()))
+
+
 class BucketReducer:
     """Data-parallel gradient exchange overlapped with backward: the flat gradient buffer of one optimiser is
     reduced in contiguous buckets, each launched -- asynchronously, on a side stream when the buffer lives on a GPU -- the
@@ -996,10 +1005,17 @@ class HiFiGANTrainer:
                 self._graph_warm[key] = n + 1
                 return self._eager_step(mel_bct, audio_bct)
             steps = (self.g_params.step, self.d_params.step)
+            failure = None
             try:
                 entry = self._capture(key, mel_bct, audio_bct, warm)
             except Exception as e:  # noqa: BLE001 -- whatever the runtime objected to: the eager path is always available
-                self._graph_failed = f"{type(e).__name__}: {e}"
+                failure = f"{type(e).__name__}: {e}"
+            # data parallel: the captured schedule and the eager one cut the gradients into different buckets, i.e. issue different
+            # sequences of collectives -- every rank takes the eager path unless the capture succeeded on all of them
+            if self.pg is not None and not capture_agreed(failure is None, self.pg, self.device) and failure is None:
+                failure, entry = "graph capture failed on another rank", None
+            if failure is not None:
+                self._graph_failed = failure
                 torch.cuda.synchronize(self.device)
                 # nothing of the aborted capture has run, but its host-side bookkeeping has: the spectral-norm layers hold
                 # prepared (weight, sigma, u, v) tuples that live in the dead graph's pool and were never computed, and the
