@@ -104,6 +104,28 @@ def test_bucketed_overlapped_allreduce_is_a_mean_over_ranks(tmp_path):
     assert torch.equal(b0, b1) and torch.allclose(b0, torch.arange(23, dtype=torch.float32) * 1.5)
 
 
+def _agree_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from everyvoice_amd.train.hifigan import capture_agreed
+
+    got = [capture_agreed(True, True, "cpu"),            # every rank captured its graphs
+           capture_agreed(rank != 1, True, "cpu"),       # rank 1 failed: nobody may replay
+           capture_agreed(False, True, "cpu")]
+    Path(out_dir, f"a{rank}.json").write_text(json.dumps(got))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_ranks_agree_on_the_capture_outcome(tmp_path):
+    """The captured data-parallel step cuts the gradients into other buckets than the eager one (train/hifigan.py: d_bucket_groups):
+    a rank whose capture failed would issue another sequence of collectives than its peers.  Every rank reports its outcome in one
+    MIN all-reduce and all take the eager path unless all succeeded."""
+    world = 2
+    mp.spawn(_agree_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert json.loads(Path(tmp_path, f"a{r}.json").read_text()) == [True, False, False]
+
+
 def test_dist_env_and_roofline_aggregation(monkeypatch):
     monkeypatch.setenv("RANK", "3")
     monkeypatch.setenv("LOCAL_RANK", "1")
