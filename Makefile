@@ -11,6 +11,12 @@ LIB        := everyvoice_amd/libevmi_hip.so
 
 all: $(LIB)
 
+# The inference convolution kernels' epilogues are VALU-bound at 32 / 64 channels, and fmaxf(f, f * slope) costs THREE vector ops when
+# NaNs are honoured (the compiler canonicalises f with a self-max first).  These two files hold no NaN test; fmaxf already returns the
+# other operand for a quiet NaN, so results do not change.
+NONAN      := resblock_pair conv_tc_mfma
+$(foreach f,$(NONAN),$(eval $(BUILD)/$(f).o: HIPFLAGS += -fno-honor-nans))
+
 $(BUILD)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/evmi.h
 	@mkdir -p $(BUILD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "conv_tc_mfma.h"
+#include "resblock_branch_kernel.h"
 #include "resblock_pair_kernel.h"
 
 namespace evmi {
@@ -460,6 +461,40 @@ static int forward_tc(evmi_generator* g, const float* mel, float* wav, int B, in
       const std::vector<TcConv>& convs = g->tc_rb[i * c.num_kernels + j];
       const int nd = c.num_dilations[j];
       const bf16_t* cur = U;
+      // the whole branch in one launch where its pairs are bound by the residual stream's round trips (resblock_branch_kernel.h)
+      if (c.resblock_type == 1 && nd >= 1 && nd <= 3) {
+        int dils[3] = {1, 1, 1};
+        bool pairs_ok = true;
+        for (int m = 0; m < nd; ++m) {
+          dils[m] = convs[2 * m].dil;
+          pairs_ok = pairs_ok && g->tc_pair[i * c.num_kernels + j][m] != nullptr && convs[2 * m + 1].dil == 1;
+        }
+        const BranchLaunch* bl = pairs_ok ? find_resblock_branch(cout, convs[0].ks, nd, dils) : nullptr;
+        if (bl) {
+          BranchArgs ba;
+          ba.x = U;
+          ba.out = ACC;
+          for (int m = 0; m < 3; ++m) {
+            const int mm = m < nd ? m : nd - 1;
+            ba.w[2 * m] = warena + g->tc_pair_w[i * c.num_kernels + j][mm];
+            ba.w[2 * m + 1] = ba.w[2 * m] + (size_t)cout * cout * convs[2 * mm].ks;
+            ba.b[2 * m] = barena + convs[2 * mm].bias_off;
+            ba.b[2 * m + 1] = barena + convs[2 * mm + 1].bias_off;
+            ba.dil[m] = dils[mm];
+          }
+          ba.T = len_out;
+          ba.np = nd;
+          ba.slope = c.lrelu_slope;
+          ba.post_slope = (j == c.num_kernels - 1) ? (last_stage ? c.post_lrelu_slope : c.lrelu_slope) : 1.f;
+          ba.out_scale = 1.f / c.num_kernels;
+          ba.accumulate = j > 0;
+          EVMI_TRY(rec.begin());
+          EVMI_TRY(launch_resblock_branch(bl, ba, B, g->n_cu, s));
+          EVMI_TRY(rec.end(bl->name, convs[0].layer + "+" + std::to_string(2 * nd), 4.0 * nd * B * (double)len_out * cout * cout * convs[0].ks,
+                           2.0 * B * (double)lim * (2 + ba.accumulate) + 4.0 * nd * cout * cout * convs[0].ks));
+          continue;
+        }
+      }
       for (int m = 0; m < nd; ++m) {
         const bool last = m == nd - 1;
         bf16_t* nxt = last ? ACC : P[m & 1];

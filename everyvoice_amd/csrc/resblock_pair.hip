@@ -1,6 +1,7 @@
 // Instantiations and launcher of the fused residual-pair kernel (resblock_pair_kernel.h).
 #include <cstdlib>
 
+#include "resblock_branch_kernel.h"
 #include "resblock_pair32_kernel.h"
 #include "resblock_pair_chunked_kernel.h"
 
@@ -11,20 +12,21 @@ namespace evmi {
 // the two-workgroups-per-CU form (4 waves, 256 rows, T1 over XA), selected by EVMI_PAIR_OVL=1 only: measured 1.22 vs 1.16 ms
 // on c32 / k11 (and 3.1 vs 1.95 ms for a 128-row two-workgroup form at C = 64) -- with half the waves per workgroup the phases
 // of one workgroup are not filled by the other.
-#define EVMI_PAIR_TABLE(X)         \
-  X(32, 3, 256, 3, 5, 4, 2, 1)     \
-  X(32, 7, 256, 7, 5, 4, 1, 1)     \
-  X(32, 11, 256, 11, 5, 4, 1, 1)   \
-  X(64, 3, 256, 2, 5, 8, 2, 0)     \
-  X(64, 7, 256, 2, 5, 8, 2, 0)     \
-  X(64, 11, 256, 2, 5, 8, 2, 0)    \
-  X(32, 3, 512, 3, 5, 8, 2, 0)     \
-  X(32, 7, 512, 7, 5, 8, 1, 0)     \
-  X(32, 11, 512, 11, 5, 8, 1, 0)
+#define EVMI_PAIR_TABLE(X)            \
+  X(32, 3, 256, 3, 5, 4, 2, 1, 0)     \
+  X(32, 7, 256, 7, 5, 4, 1, 1, 0)     \
+  X(32, 11, 256, 11, 5, 4, 1, 1, 0)   \
+  X(64, 3, 256, 2, 5, 8, 2, 0, WR)    \
+  X(64, 7, 256, 2, 5, 8, 2, 0, WR)    \
+  X(64, 11, 256, 2, 5, 8, 2, 0, WR)   \
+  X(32, 3, 512, 3, 5, 8, 2, 0, 0)     \
+  X(32, 7, 512, 7, 5, 8, 1, 0, 0)     \
+  X(32, 11, 512, 11, 5, 8, 1, 0, WR)
 
 static const PairLaunch* pair_table(int* n) {
-#define X(c, ks, bn, taps, md, waves, nwbuf, ovl) \
-  make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf, ovl>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
+#define WR 1  // weights resident in registers (PairCfg::WRES)
+#define X(c, ks, bn, taps, md, waves, nwbuf, ovl, wres) \
+  make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf, ovl, wres>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
   static const PairLaunch table[] = {
       // C = 32 as a conv1 / conv2 wave pipeline with the weights in registers (resblock_pair32_kernel.h): EVMI_PAIR32=1 only
       // (measured equal or slower than the single-team kernels below, see the header)
@@ -38,6 +40,7 @@ static const PairLaunch* pair_table(int* n) {
       make_pair_chunked_launch<PairChunkedCfg<128, 64, 3, 256, 5, 2, 4>>("resblock_pair_mfma<c128,k3,bn256,kc64>"),
   };
 #undef X
+#undef WR
   *n = (int)(sizeof(table) / sizeof(table[0]));
   return table;
 }
@@ -82,6 +85,73 @@ int launch_resblock_pair(const PairLaunch* L, PairArgs a, int B, int n_cu, hipSt
   // persistent: one workgroup per CU (LDS-bound residency), a multiple of 8 so every XCD gets the
   // same number of workgroups (the kernel's tile walk relies on it)
   int grid = (n_cu > 0 ? n_cu : 256) * L->wg_per_cu;
+  grid = (grid + 7) / 8 * 8;
+  const int needed = (a.n_tiles + 7) / 8 * 8;
+  if (grid > needed) grid = needed;
+  hipLaunchKernelGGL(L->kernel, dim3(grid), dim3(L->threads), L->lds_bytes, stream, a);
+  EVMI_LAUNCH_CHECK(L->name);
+  return EVMI_OK;
+}
+
+// ---- whole branches (resblock_branch_kernel.h) ------------------------------------------------------------------------------------------
+//                    C  KS  BN  TAPS WAVES NWBUF
+// Only where the pair kernels are bound by the residual stream's round trips and the branch's halo stays small: k = 3 and k = 7 at 32
+// channels, k = 3 at 64 (k = 11 recomputes 23 % of every tile and is MFMA-bound as pairs already; 64 channels x k = 7 does not fit).
+static const BranchLaunch* branch_table(int* n) {
+  static const BranchLaunch table[] = {
+      make_branch_launch<BranchCfg<32, 3, 512, 3, 8, 2>>("resblock_branch_mfma<c32,k3,bn512>"),
+      make_branch_launch<BranchCfg<32, 7, 512, 7, 8, 1>>("resblock_branch_mfma<c32,k7,bn512>"),
+      make_branch_launch<BranchCfg<64, 3, 256, 2, 8, 2>>("resblock_branch_mfma<c64,k3,bn256>"),
+  };
+  *n = (int)(sizeof(table) / sizeof(table[0]));
+  return table;
+}
+
+// valid rows per tile of a branch with these dilations, or 0 when a convolution would read past the LDS tiles
+static int branch_valid_rows(const BranchLaunch& L, int np, const int* dil) {
+  const int H = (L.ks - 1) / 2;
+  if (np != 3 || dil[0] < 1 || L.bn + 2 * dil[0] * H > L.rb) return 0;
+  int m = 0;
+  for (int p = 0; p < np; ++p) {
+    const int h1 = dil[p] * H;
+    if (dil[p] < 1 || m + 2 * h1 + L.bn > L.rb || m + h1 + L.bn + 2 * H > L.rb) return 0;
+    m += h1 + H;
+  }
+  const int tt = L.bn + 2 * dil[0] * H - 2 * m;
+  return tt > 0 ? tt : 0;
+}
+
+const BranchLaunch* find_resblock_branch(int c, int ks, int np, const int* dil) {
+  // A/B switch: EVMI_BRANCH=0 keeps the pair kernels (same bits: tests/test_gpu_generator.py compares the two)
+  static const bool enabled = [] {
+    const char* e = getenv("EVMI_BRANCH");
+    return !(e && e[0] == '0');
+  }();
+  if (!enabled) return nullptr;
+  int n = 0;
+  const BranchLaunch* t = branch_table(&n);
+  for (int i = 0; i < n; ++i)
+    if (t[i].c == c && t[i].ks == ks && 4 * branch_valid_rows(t[i], np, dil) >= 3 * t[i].bn) return &t[i];  // (a halo above 25 % does not pay)
+  return nullptr;
+}
+
+int launch_resblock_branch(const BranchLaunch* L, BranchArgs a, int B, int n_cu, hipStream_t stream) {
+  static thread_local const void* configured_dev[kMaxDevices][8];
+  static thread_local int n_configured_dev[kMaxDevices] = {};
+  const int dev_slot = device_slot();
+  const void** configured = configured_dev[dev_slot];
+  int& n_configured = n_configured_dev[dev_slot];
+  bool seen = false;
+  for (int i = 0; i < n_configured; ++i) seen |= (configured[i] == (const void*)L->kernel);
+  if (!seen) {
+    EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)L->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L->lds_bytes));
+    if (n_configured < 8) configured[n_configured++] = (const void*)L->kernel;
+  }
+  a.tt = branch_valid_rows(*L, a.np, a.dil);
+  if (a.tt <= 0) return fail(EVMI_ERR_UNSUPPORTED, "resblock_branch: dilations beyond the LDS tiles");
+  a.tiles_per_item = (a.T + a.tt - 1) / a.tt;
+  a.n_tiles = a.tiles_per_item * B;
+  int grid = (n_cu > 0 ? n_cu : 256);  // persistent: one workgroup per CU, a multiple of 8 (the kernel's tile walk relies on it)
   grid = (grid + 7) / 8 * 8;
   const int needed = (a.n_tiles + 7) / 8 * 8;
   if (grid > needed) grid = needed;

@@ -36,7 +36,8 @@ struct PairChunkedCfg {
 };
 
 template <class P>
-__global__ __launch_bounds__(P::NTHREADS, 2) void resblock_pair_chunked_kernel(PairArgs a) {
+// (one workgroup per CU by its LDS: the register budget is the full 256 per wave at two waves per SIMD)
+__global__ __launch_bounds__(P::NTHREADS) void resblock_pair_chunked_kernel(PairArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* XA = reinterpret_cast<bf16_t*>(smem) + P::OFF_XA;
   bf16_t* T1 = reinterpret_cast<bf16_t*>(smem) + P::OFF_T1;
@@ -58,7 +59,10 @@ __global__ __launch_bounds__(P::NTHREADS, 2) void resblock_pair_chunked_kernel(P
   if (tile >= tile_hi) return;
 
   bf16x8 xreg[P::XV];
-  bf16x8 wreg[P::W_PER_THREAD];
+  // weight images are requested TWO steps ahead (a ring of three register sets): a step is 16 MFMAs per wave, far shorter than the
+  // L2 round trip that a one-step-ahead prefetch had to cover
+  constexpr int WRING = 3;
+  bf16x8 wreg[WRING][P::W_PER_THREAD];
   bf16x8 rreg[P::RV];
 
   auto x_issue = [&](int t, int chunk) {
@@ -95,19 +99,19 @@ __global__ __launch_bounds__(P::NTHREADS, 2) void resblock_pair_chunked_kernel(P
   };
   // step s: conv = s / STEPS_PER_CONV; within a conv: chunk-major, tap-minor.  Global layout per conv:
   // [chunk][tap][C][KC] (the conv_tc layout with BM = C)
-  auto w_prefetch = [&](int s) {
+  auto w_prefetch = [&](int s, int slot) {
     const int conv = s / P::STEPS_PER_CONV, rem = s % P::STEPS_PER_CONV;
     const bf16_t* src = (conv ? a.w2 : a.w1) + (long long)rem * C * KC;
 #pragma unroll
     for (int i = 0; i < P::W_PER_THREAD; ++i)
-      wreg[i] = *reinterpret_cast<const bf16x8*>(src + (long long)(tid + i * P::NTHREADS) * 8);
+      wreg[slot][i] = *reinterpret_cast<const bf16x8*>(src + (long long)(tid + i * P::NTHREADS) * 8);
   };
-  auto w_commit = [&](int s) {
+  auto w_commit = [&](int s, int slot) {
     bf16_t* dst = WS + (s & 1) * P::W_TILE;
 #pragma unroll
     for (int i = 0; i < P::W_PER_THREAD; ++i) {
       const int v = tid + i * P::NTHREADS;
-      *reinterpret_cast<bf16x8*>(dst + (v / (KC / 8)) * P::SW + (v % (KC / 8)) * 8) = wreg[i];
+      *reinterpret_cast<bf16x8*>(dst + (v / (KC / 8)) * P::SW + (v % (KC / 8)) * 8) = wreg[slot][i];
     }
   };
   auto out_offset = [&](int r0, int i) -> unsigned {
@@ -118,7 +122,9 @@ __global__ __launch_bounds__(P::NTHREADS, 2) void resblock_pair_chunked_kernel(P
   };
 
   x_issue(tile, 0);
-  w_prefetch(0);
+#pragma unroll
+  for (int s = 0; s < WRING - 1; ++s) w_prefetch(s, s);
+  static_assert(P::NSTEP % WRING == 0, "the ring position of a step is the same in every tile");
 
   for (; tile < tile_hi; tile += per_xcd_wg) {
     const int item = tile / a.tiles_per_item, rt = tile % a.tiles_per_item;
@@ -137,16 +143,17 @@ __global__ __launch_bounds__(P::NTHREADS, 2) void resblock_pair_chunked_kernel(P
 
     // ---------------- conv1 (dilated) over the activated residual stream ----------------
     zero_acc();
+    static_assert(KS % WRING == 0, "the ring slot of a step is its tap: static under the unrolled tap loop");
 #pragma unroll 1
     for (int chunk = 0; chunk < P::NCH; ++chunk) {
       if (chunk > 0) lds_barrier();  // done reading the previous chunk's rows (chunk 0: barrier at the loop end)
       x_commit();
-#pragma unroll 1
+#pragma unroll
       for (int tap = 0; tap < KS; ++tap) {
         const int s = chunk * KS + tap;
-        w_commit(s);
+        w_commit(s, tap % WRING);
         lds_barrier();
-        w_prefetch(s + 1);
+        w_prefetch((s + WRING - 1) % P::NSTEP, (tap + WRING - 1) % WRING);
         if (tap == 0) {
           if (chunk + 1 < P::NCH) x_issue(tile, chunk + 1);
           else x_issue(next, 0);
@@ -189,12 +196,12 @@ __global__ __launch_bounds__(P::NTHREADS, 2) void resblock_pair_chunked_kernel(P
     zero_acc();
 #pragma unroll 1
     for (int chunk = 0; chunk < P::NCH; ++chunk) {
-#pragma unroll 1
+#pragma unroll
       for (int tap = 0; tap < KS; ++tap) {
         const int s = P::STEPS_PER_CONV + chunk * KS + tap;
-        w_commit(s);
+        w_commit(s, tap % WRING);
         lds_barrier();
-        w_prefetch(s + 1 == P::NSTEP ? 0 : s + 1);
+        w_prefetch((s + WRING - 1) % P::NSTEP, (tap + WRING - 1) % WRING);  // (wraps to the next tile's first images)
         const bf16_t* Arow = WS + (s & 1) * P::W_TILE + (wm * P::MT * 32 + (lane & 31)) * P::SW + (lane >> 5) * 8;
         const bf16_t* Brow = T1 + (wn * P::NT * 32 + (lane & 31) + tap) * P::ST + chunk * KC + (lane >> 5) * 8;
         mma_tap_group<P::MT, P::NT, KC / 16, 1, 0, 32 * P::SW, 32 * P::ST>(Arow, Brow, 0, acc);

@@ -51,9 +51,12 @@ struct PairLaunch {
 // OVL_: the intermediate T1 overlays the conv1 operand tile XA (dead once conv1's last MFMA has read it; one more barrier
 // before T1 is written).  With it a 32-channel, 256-row tile needs ~73 KB: TWO 4-wave workgroups share a CU (WG_PER_CU) and one's
 // tile load / epilogue phases run under the other's MFMAs, where a single 8-wave workgroup per CU exposes every phase.
-template <int C_, int KS_, int BN_, int TAPS_, int MAXDIL_, int WAVES_, int DBG_ = 0, int NWBUF_ = 2, int OVL_ = 0>
+// WRES_: the weights of both convolutions stay in registers for the life of the persistent workgroup (NSTEP x W_PER_THREAD vectors,
+// loaded once) and are committed to the LDS from there: a two-tap step at 64 channels is 16 MFMAs per wave, shorter than the L2 round
+// trip of the next step's weights that the one-step-ahead prefetch has to cover.
+template <int C_, int KS_, int BN_, int TAPS_, int MAXDIL_, int WAVES_, int DBG_ = 0, int NWBUF_ = 2, int OVL_ = 0, int WRES_ = 0>
 struct PairCfg {
-  static constexpr int C = C_, KS = KS_, BN = BN_, TAPS = TAPS_, MAXDIL = MAXDIL_, WAVES = WAVES_, DBG = DBG_, OVL = OVL_;
+  static constexpr int C = C_, KS = KS_, BN = BN_, TAPS = TAPS_, MAXDIL = MAXDIL_, WAVES = WAVES_, DBG = DBG_, OVL = OVL_, WRES = WRES_;
   // weight tap-group buffers in LDS: 2 = commit the next group while the current one is read; 1 = one
   // buffer (lets a whole convolution's taps sit in LDS at once) at the price of a barrier before each commit
   static constexpr int NWBUF = NWBUF_;
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
   const int tile_hi = min(a.n_tiles, tile_lo + tiles_per_xcd);
 
   bf16x8 xreg[P::X_PER_THREAD];
-  bf16x8 wreg[P::W_PER_THREAD];
+  bf16x8 wreg[P::WRES ? P::NSTEP : 1][P::W_PER_THREAD];
 
   auto x_issue = [&](int tile) {
     const int item = tile / a.tiles_per_item, rt = tile % a.tiles_per_item;
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
 #pragma unroll
     for (int i = 0; i < P::W_PER_THREAD; ++i) {
       const int v = tid + i * P::NTHREADS;
-      if (P::W_EXACT || v < nvec) wreg[i] = *reinterpret_cast<const bf16x8*>(src + (long long)v * 8);
+      if (P::W_EXACT || v < nvec) wreg[P::WRES ? s : 0][i] = *reinterpret_cast<const bf16x8*>(src + (long long)v * 8);
     }
   };
   auto w_commit = [&](int s) {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
       const int v = tid + i * P::NTHREADS;
       if (P::W_EXACT || v < nvec) {
         const int row = v / (C / 8), c8 = v % (C / 8);
-        *reinterpret_cast<bf16x8*>(dst + row * S + c8 * 8) = wreg[i];
+        *reinterpret_cast<bf16x8*>(dst + row * S + c8 * 8) = wreg[P::WRES ? s : 0][i];
       }
     }
   };
@@ -183,9 +186,14 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
   // accumulator layout (channels 8q + 4h .. + 3 per register quad) under the first weight commit of each convolution
   float* BIAS = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + P::OFF_BIAS);
   for (int i = tid; i < 2 * C; i += P::NTHREADS) BIAS[i] = i < C ? a.b1[i] : a.b2[i - C];
-  // (made visible by the first step's barrier)
+  lds_barrier();  // (the first tile's accumulators are initialised from it before the first step's barrier)
   x_issue(tile);
-  w_prefetch(0);
+  if (P::WRES) {
+#pragma unroll
+    for (int s = 0; s < P::NSTEP; ++s) w_prefetch(s);
+  } else {
+    w_prefetch(0);
+  }
 
   for (; tile < tile_hi; tile += per_xcd_wg) {
     const int item = tile / a.tiles_per_item, rt = tile % a.tiles_per_item;
@@ -198,12 +206,20 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
     f32x16 acc[P::MT][P::NT];
 #pragma unroll
     for (int conv = 0; conv < 2; ++conv) {
+      {  // accumulators start at the bias (accumulator layout: channels 8q + 4h .. + 3 per register quad): the epilogues, which are
+         // VALU-bound at these channel counts, only activate / add the residual
+        const float* bias = BIAS + conv * C;
 #pragma unroll
-      for (int i = 0; i < P::MT; ++i)
+        for (int i = 0; i < P::MT; ++i)
 #pragma unroll
-        for (int j = 0; j < P::NT; ++j)
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + i * 32 + 8 * q + 4 * (lane >> 5));
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < P::NT; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] = bv[r];
+          }
+      }
       const bf16_t* Bsrc = conv ? T1 : XA;
       const int b_tap_stride = (conv ? 1 : a.dil1) * S;
       // tap groups are fully unrolled so that the (possibly shorter) last group is static too
@@ -213,7 +229,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
         if (P::NWBUF == 1 && s > 0) lds_barrier();  // everyone is done reading the single weight buffer
         w_commit(s);
         lds_barrier();
-        w_prefetch(s + 1 == P::NSTEP ? 0 : s + 1);  // wraps to the next tile's first group
+        if (!P::WRES) w_prefetch(s + 1 == P::NSTEP ? 0 : s + 1);  // wraps to the next tile's first group
         if (s == 0 && next < tile_hi) x_issue(next);  // after the weight loads: they stay in flight
         const bf16_t* Arow = WS + (s & (P::NWBUF - 1)) * P::W_TILE + (lane & 31) * S + (lane >> 5) * 8;
         const bf16_t* Brow = Bsrc + (wn * P::NT * 32 + (lane & 31)) * S + grp * P::TAPS * b_tap_stride + (lane >> 5) * 8;
@@ -227,22 +243,27 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
         // T1[n] = lrelu(conv1 + b1) for global row r0 - H2 + n, zero outside the sequence
         if (P::OVL) lds_barrier();  // T1 overlays XA: every wave is done with conv1's last fragment reads
         const float sl = a.slope;
+        const bool edge = r0 - H2 < 0 || r0 - H2 + P::BN > a.T;  // (wave-uniform) rows outside the sequence in this tile
 #pragma unroll
         for (int mt = 0; mt < P::MT; ++mt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int c = mt * 32 + 8 * q + 4 * (lane >> 5);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(BIAS + c);
 #pragma unroll
             for (int nt = 0; nt < P::NT; ++nt) {
               const int n = wn * P::NT * 32 + nt * 32 + (lane & 31);
-              const int g = r0 - H2 + n;
-              const float mask = (g >= 0 && g < a.T) ? 1.f : 0.f;
               bf16x4 pk;
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                const float f = acc[mt][nt][4 * q + i] + bv[i];
-                pk[i] = (bf16_t)(fmaxf(f, f * sl) * mask);
+                const float f = acc[mt][nt][4 * q + i];
+                pk[i] = (bf16_t)fmaxf(f, f * sl);
+              }
+              if (edge) {
+                const int g = r0 - H2 + n;
+                if (g < 0 || g >= a.T) {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) pk[i] = (bf16_t)0.f;
+                }
               }
               *reinterpret_cast<bf16x4*>(T1 + n * S + c) = pk;
             }
@@ -287,10 +308,9 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
               const int c = mt * 32 + 8 * (2 * p2 + qq) + 4 * hh;
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(BIAS + C + c);
               const bf16x4 rv = *reinterpret_cast<const bf16x4*>(RS + n * S + c);
 #pragma unroll
-              for (int i = 0; i < 4; ++i) f[4 * qq + i] = (acc[mt][nt][4 * (2 * p2 + qq) + i] + bv[i] + (float)rv[i]) * scale;
+              for (int i = 0; i < 4; ++i) f[4 * qq + i] = (acc[mt][nt][4 * (2 * p2 + qq) + i] + (float)rv[i]) * scale;
             }
             if (a.accumulate) {
               const u32x4 d = swap_quads_bf16(pv[mt][p2]);

@@ -209,7 +209,7 @@ def test_istft_generator_vs_oracle(cuda_device, name, B, T):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["EVMI_CONV_DMA=0", "EVMI_PAIR32=1", "EVMI_PAIR_OVL=1", "EVMI_PAIR_C128=0"])
+@pytest.mark.parametrize("switch", ["EVMI_CONV_DMA=0", "EVMI_PAIR32=1", "EVMI_PAIR_OVL=1", "EVMI_PAIR_C128=0", "EVMI_BRANCH=0"])
 def test_kernel_variants_behind_switches_match_the_oracle(switch):
     """The library picks its inference kernels once per process: the variants behind the A/B switches (register-staged convolutions,
     the conv1 / conv2 wave pipeline and the two-workgroup form of the 32-channel pairs, unfused 128-channel pairs) run the oracle
@@ -224,3 +224,41 @@ def test_kernel_variants_behind_switches_match_the_oracle(switch):
                         "bf16_vs_oracle or committed_fixture or full_size_properties or istft_generator"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+_BRANCH_CHILD = """
+import sys, torch
+sys.path.insert(0, {root!r})
+import bench
+torch.manual_seed(0)
+model = bench.upstream_init_generator("bf16").to("cuda:0").eval()
+for B, T in ((3, 40), (2, 301), (8, 768)):
+    wav = model.generator(bench.synthetic_mel(B, T, 99 + T).to("cuda:0"))
+    torch.save(wav.cpu(), {out!r} + f"/wav_{{B}}_{{T}}.pt")
+"""
+
+
+@pytest.mark.gpu
+def test_whole_branch_kernel_gives_the_bits_of_the_pair_kernels(tmp_path, cuda_device):
+    """resblock_branch_kernel.h keeps a branch's running value in LDS over its three pairs; its rounding points are the pair kernel's
+    (bf16 where that one stores), so the waveform must be IDENTICAL to the one of a process with EVMI_BRANCH=0 -- at a tile-ragged
+    length, at a length shorter than one tile's halo, and at the bench's 768 frames (every tile position of the persistent walk)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = str(Path(__file__).resolve().parents[1])
+    outs = {}
+    for flag in ("1", "0"):
+        d = tmp_path / f"branch{flag}"
+        d.mkdir()
+        r = subprocess.run([sys.executable, "-c", _BRANCH_CHILD.format(root=root, out=str(d))], env=dict(os.environ, EVMI_BRANCH=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[flag] = {p.name: torch.load(p) for p in sorted(d.iterdir())}
+    assert sorted(outs["1"]) == sorted(outs["0"]) and len(outs["1"]) == 3
+    for name, a in outs["1"].items():
+        b = outs["0"][name]
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
