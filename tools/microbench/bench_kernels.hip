@@ -236,7 +236,7 @@ extern "C" int evmi_bench_conv_tc_timeline(const char* name, int B, int T, int d
 extern "C" int evmi_debug_pair_timeline(int c, int ks, int dil, int B, int T, long long* stamps_host, int cap) {
   using namespace evmi;
   PairLaunch L;
-  if (c == 64 && ks == 11) L = make_pair_launch<PairCfg<64, 11, 256, 2, 5, 8, 1>>("dbg_pair_c64k11");
+  if (c == 64 && ks == 11) L = make_pair_launch<PairCfg<64, 11, 256, 2, 5, 8, 1, 2, 0, 1>>("dbg_pair_c64k11");
   else if (c == 64 && ks == 3) L = make_pair_launch<PairCfg<64, 3, 256, 2, 5, 8, 1>>("dbg_pair_c64k3");
   else if (c == 32 && ks == 11) L = make_pair_launch<PairCfg<32, 11, 512, 11, 5, 8, 1, 1>>("dbg_pair_c32k11");
   else if (c == 32 && ks == 3) L = make_pair_launch<PairCfg<32, 3, 512, 3, 5, 8, 1, 2>>("dbg_pair_c32k3");
