@@ -119,6 +119,26 @@ __device__ __forceinline__ void mma_tap_group(const bf16_t* __restrict__ Arow, c
   }
 }
 
+// leaky ReLU with packed fp32 multiplies (v_pk_mul_f32: two values per op) -- the activation passes of the 32 / 64-channel inference
+// kernels are VALU-bound.  Same arithmetic as fmaxf(f, f * slope) per element.
+__device__ __forceinline__ bf16x4 lrelu4_bf16(f32x4 f, float slope) {
+  const f32x4 m = f * slope;
+  bf16x4 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r[e] = (bf16_t)fmaxf(f[e], m[e]);
+  return r;
+}
+__device__ __forceinline__ bf16x8 lrelu8_bf16(bf16x8 x, float slope) {
+  f32x4 lo, hi;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { lo[e] = (float)x[e]; hi[e] = (float)x[4 + e]; }
+  const f32x4 ml = lo * slope, mh = hi * slope;
+  bf16x8 r;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { r[e] = (bf16_t)fmaxf(lo[e], ml[e]); r[4 + e] = (bf16_t)fmaxf(hi[e], mh[e]); }
+  return r;
+}
+
 // host-side round-to-nearest-even fp32 -> bf16 bits (NaN kept quiet)
 inline uint16_t f32_to_bf16_bits(float f) {
   uint32_t u;

@@ -67,8 +67,8 @@ struct BranchCfg {
   static constexpr size_t OFF_RS = OFF_XA + size_t(RB) * S;
   static constexpr size_t OFF_T1 = OFF_RS + size_t(RB) * S;
   static constexpr size_t OFF_WS = OFF_T1 + size_t(RB) * S;
-  static constexpr size_t OFF_BIAS = OFF_WS + NWBUF * size_t(W_TILE);  // 6 x C floats (in bf16 units: 12 C)
-  static constexpr size_t LDS = (OFF_BIAS + 12 * size_t(C)) * 2;
+  static constexpr size_t OFF_BIAS = OFF_WS + NWBUF * size_t(W_TILE);  // 2 copies x 6 x C floats (in bf16 units: 24 C)
+  static constexpr size_t LDS = (OFF_BIAS + 24 * size_t(C)) * 2;
   static_assert(BN % (WAVES * 32) == 0 && C % 32 == 0, "tiling");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -125,13 +125,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
       if (v < x_nvec) {
         const int row = v / (C / 8), c8 = v % (C / 8);
         const bf16x8 raw = xreg[i];
-        bf16x8 act;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float f = (float)raw[e];
-          act[e] = (bf16_t)fmaxf(f, f * sl);
-        }
-        *reinterpret_cast<bf16x8*>(XA + row * S + c8 * 8) = act;
+        *reinterpret_cast<bf16x8*>(XA + row * S + c8 * 8) = lrelu8_bf16(raw, sl);
         *reinterpret_cast<bf16x8*>(RS + row * S + c8 * 8) = raw;
       }
     }
@@ -173,7 +167,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
     for (int e = 0; e < 8; ++e) z[e] = (bf16_t)0.f;
     for (int v = tid; v < 3 * P::RB * S / 8; v += P::NTHREADS) *reinterpret_cast<bf16x8*>(XA + v * 8) = z;
   }
-  for (int i = tid; i < 2 * np * C; i += P::NTHREADS) BIAS[i] = a.b[i / C][i % C];
+  for (int i = tid; i < 4 * np * C; i += P::NTHREADS) BIAS[i] = a.b[(i % (2 * np * C)) / C][i % C];  // (two copies: see the pair kernel)
   lds_barrier();
   x_issue(tile);
   if (P::WRES) {
@@ -205,13 +199,13 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
 #pragma unroll
           for (int i = 0; i < P::MT; ++i)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + i * 32 + 8 * q + 4 * (lane >> 5));
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-              for (int j = 0; j < P::NT; ++j)
+              for (int j = 0; j < P::NT; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (j & 1) * 2 * np * C + i * 32 + 8 * q + 4 * (lane >> 5));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] = bv[r];
-            }
+              }
         }
         // conv1: XA rows Mp + n + j d;  conv2: T1 rows Mp + h1 + n + j
         const bf16_t* Bsrc = conv ? T1 + (mp + h1) * S : XA + mp * S;
@@ -243,12 +237,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
               for (int nt = 0; nt < P::NT; ++nt) {
                 const int n = wn * P::NT * 32 + nt * 32 + (lane & 31);
                 const int row = mp + h1 + n;
-                bf16x4 pk;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                  const float f = acc[mt][nt][4 * q + i];
-                  pk[i] = (bf16_t)fmaxf(f, f * sl);
-                }
+                bf16x4 pk = lrelu4_bf16(f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]}, sl);
                 if (edge) {
                   const int g = g0 + row;
                   if (g < 0 || g >= a.T) {
@@ -287,11 +276,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
                   for (int i = 0; i < 4; ++i) raw[i] = (bf16_t)0.f;
                 }
               }
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const float y = (float)raw[i];
-                act[i] = (bf16_t)fmaxf(y, y * sl);
-              }
+              act = lrelu4_bf16(f32x4{(float)raw[0], (float)raw[1], (float)raw[2], (float)raw[3]}, sl);
               *reinterpret_cast<bf16x4*>(RS + row * S + c) = raw;
               *reinterpret_cast<bf16x4*>(XA + row * S + c) = act;
             }

@@ -79,8 +79,8 @@ struct PairCfg {
   static constexpr size_t OFF_RS = OFF_XA + size_t(RA_MAX) * S;
   static constexpr size_t OFF_T1 = OVL ? OFF_XA : OFF_RS + size_t(BN) * S;
   static constexpr size_t OFF_WS = OVL ? OFF_RS + size_t(BN) * S : OFF_T1 + size_t(T1_ROWS) * S;
-  static constexpr size_t OFF_BIAS = OFF_WS + NWBUF * size_t(W_TILE);  // 2 x C floats (in bf16 units: 4 C)
-  static constexpr size_t LDS = (OFF_BIAS + 4 * size_t(C)) * 2;
+  static constexpr size_t OFF_BIAS = OFF_WS + NWBUF * size_t(W_TILE);  // 2 copies x 2 x C floats (in bf16 units: 8 C)
+  static constexpr size_t LDS = (OFF_BIAS + 8 * size_t(C)) * 2;
   static constexpr int WG_PER_CU = (2 * LDS <= 160 * 1024 && WAVES <= 4) ? 2 : 1;
   static_assert(BN % (WAVES * 32) == 0 && C % 32 == 0, "tiling");
   static_assert(!OVL || T1_ROWS <= RA_MAX, "T1 fits the operand tile it overlays");
@@ -136,12 +136,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
       if (v < x_nvec) {
         const int row = v / (C / 8), c8 = v % (C / 8);
         const bf16x8 raw = xreg[i];
-        bf16x8 act;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float f = (float)raw[e];
-          act[e] = (bf16_t)fmaxf(f, f * sl);
-        }
+        const bf16x8 act = lrelu8_bf16(raw, sl);
         *reinterpret_cast<bf16x8*>(XA + row * S + c8 * 8) = act;
         const int n = row - H2 - h1;
         if (n >= 0 && n < P::BN) *reinterpret_cast<bf16x8*>(RS + n * S + c8 * 8) = raw;
@@ -185,7 +180,9 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
   // both bias vectors sit in LDS for the life of the (persistent) workgroup: accumulators start at the bias, read in the
   // accumulator layout (channels 8q + 4h .. + 3 per register quad) under the first weight commit of each convolution
   float* BIAS = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + P::OFF_BIAS);
-  for (int i = tid; i < 2 * C; i += P::NTHREADS) BIAS[i] = i < C ? a.b1[i] : a.b2[i - C];
+  // (two copies: the accumulators of the second row tile are initialised by loads of their own -- from one copy the compiler shares the
+  //  loads and pays a v_mov per accumulator register, on the VALU these kernels are bound by)
+  for (int i = tid; i < 4 * C; i += P::NTHREADS) BIAS[i] = (i % (2 * C)) < C ? a.b1[i % (2 * C)] : a.b2[i % (2 * C) - C];
   lds_barrier();  // (the first tile's accumulators are initialised from it before the first step's barrier)
   x_issue(tile);
   if (P::WRES) {
@@ -212,13 +209,13 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
 #pragma unroll
         for (int i = 0; i < P::MT; ++i)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + i * 32 + 8 * q + 4 * (lane >> 5));
+          for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int j = 0; j < P::NT; ++j)
+            for (int j = 0; j < P::NT; ++j) {
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (j & 1) * 2 * C + i * 32 + 8 * q + 4 * (lane >> 5));
 #pragma unroll
               for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] = bv[r];
-          }
+            }
       }
       const bf16_t* Bsrc = conv ? T1 : XA;
       const int b_tap_stride = (conv ? 1 : a.dil1) * S;
@@ -252,12 +249,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
 #pragma unroll
             for (int nt = 0; nt < P::NT; ++nt) {
               const int n = wn * P::NT * 32 + nt * 32 + (lane & 31);
-              bf16x4 pk;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const float f = acc[mt][nt][4 * q + i];
-                pk[i] = (bf16_t)fmaxf(f, f * sl);
-              }
+              bf16x4 pk = lrelu4_bf16(f32x4{acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]}, sl);
               if (edge) {
                 const int g = r0 - H2 + n;
                 if (g < 0 || g >= a.T) {
