@@ -48,11 +48,13 @@ struct BranchLaunch {
 // WRES_: the weights of all 2 NP convolutions stay in registers for the life of the persistent workgroup (loaded once) and are committed to
 // the LDS from there every step -- a k = 3 step is 12 MFMAs per wave, far shorter than the L2 round trip of the next step's weights that
 // the pair kernel's one-step-ahead prefetch has to cover
-template <int C_, int KS_, int BN_, int TAPS_, int WAVES_, int NWBUF_, int NP_ = 3, int WRES_ = 1>
+// WM_: waves along the output channels (the others along the rows)
+template <int C_, int KS_, int BN_, int TAPS_, int WAVES_, int NWBUF_, int NP_ = 3, int WRES_ = 1, int WM_ = 1>
 struct BranchCfg {
   static constexpr int C = C_, KS = KS_, BN = BN_, TAPS = TAPS_, WAVES = WAVES_, NWBUF = NWBUF_, NP = NP_, WRES = WRES_;
+  static constexpr int WM = WM_, WN = WAVES / WM;
   static constexpr int NTHREADS = WAVES * 64;
-  static constexpr int MT = C / 32, NT = BN / (WAVES * 32);
+  static constexpr int MT = C / (WM * 32), NT = BN / (WN * 32);
   static constexpr int S = C + 8;
   static constexpr int H = (KS - 1) / 2;
   static constexpr int RB = BN + 16 * H;
@@ -69,7 +71,7 @@ struct BranchCfg {
   static constexpr size_t OFF_WS = OFF_T1 + size_t(RB) * S;
   static constexpr size_t OFF_BIAS = OFF_WS + NWBUF * size_t(W_TILE);  // 2 copies x 6 x C floats (in bf16 units: 24 C)
   static constexpr size_t LDS = (OFF_BIAS + 24 * size_t(C)) * 2;
-  static_assert(BN % (WAVES * 32) == 0 && C % 32 == 0, "tiling");
+  static_assert(BN % (WN * 32) == 0 && C % (WM * 32) == 0 && WAVES % WM == 0, "tiling");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
   float* BIAS = reinterpret_cast<float*>(reinterpret_cast<bf16_t*>(smem) + P::OFF_BIAS);
 
   constexpr int C = P::C, S = P::S, KS = P::KS, H = P::H;
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / P::WN, wn = wave % P::WN;
+  const int cb = wm * P::MT * 32;  // first output channel of this wave
   constexpr int np = P::NP;
   int mtot = 0;
 #pragma unroll
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
             for (int q = 0; q < 4; ++q)
 #pragma unroll
               for (int j = 0; j < P::NT; ++j) {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (j & 1) * 2 * np * C + i * 32 + 8 * q + 4 * (lane >> 5));
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (j & 1) * 2 * np * C + cb + i * 32 + 8 * q + 4 * (lane >> 5));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] = bv[r];
               }
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
           lds_barrier();
           if (!P::WRES) w_prefetch(s + 1 == nstep ? 0 : s + 1);  // wraps to the next tile's first group
           if (s == 0 && next < tile_hi) x_issue(next);
-          const bf16_t* Arow = WS + (s & (P::NWBUF - 1)) * P::W_TILE + (lane & 31) * S + (lane >> 5) * 8;
+          const bf16_t* Arow = WS + (s & (P::NWBUF - 1)) * P::W_TILE + (cb + (lane & 31)) * S + (lane >> 5) * 8;
           const bf16_t* Brow = Bsrc + (wn * P::NT * 32 + (lane & 31)) * S + grp * P::TAPS * b_tap_stride + (lane >> 5) * 8;
           if (grp + 1 < P::NG || P::LAST_TAPS == P::TAPS)
             mma_tap_group<P::MT, P::NT, C / 16, P::TAPS, C * S, 32 * S, 32 * S>(Arow, Brow, b_tap_stride, acc);
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
           for (int mt = 0; mt < P::MT; ++mt) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const int c = mt * 32 + 8 * q + 4 * (lane >> 5);
+              const int c = cb + mt * 32 + 8 * q + 4 * (lane >> 5);
 #pragma unroll
               for (int nt = 0; nt < P::NT; ++nt) {
                 const int n = wn * P::NT * 32 + nt * 32 + (lane & 31);
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
         for (int mt = 0; mt < P::MT; ++mt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int c = mt * 32 + 8 * q + 4 * (lane >> 5);
+            const int c = cb + mt * 32 + 8 * q + 4 * (lane >> 5);
 #pragma unroll
             for (int nt = 0; nt < P::NT; ++nt) {
               const int n = wn * P::NT * 32 + nt * 32 + (lane & 31);
@@ -298,7 +301,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
 #pragma unroll
             for (int mt = 0; mt < P::MT; ++mt)
 #pragma unroll
-              for (int p2 = 0; p2 < 2; ++p2) pv[mt][p2] = *reinterpret_cast<const u32x4*>(dst + mt * 32 + 16 * p2);
+              for (int p2 = 0; p2 < 2; ++p2) pv[mt][p2] = *reinterpret_cast<const u32x4*>(dst + cb + mt * 32 + 16 * p2);
           }
 #pragma unroll
           for (int mt = 0; mt < P::MT; ++mt)
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
               float f[8];
 #pragma unroll
               for (int qq = 0; qq < 2; ++qq) {
-                const int c = mt * 32 + 8 * (2 * p2 + qq) + 4 * hh;
+                const int c = cb + mt * 32 + 8 * (2 * p2 + qq) + 4 * hh;
                 const bf16x4 rv = *reinterpret_cast<const bf16x4*>(RS + (mnext + n) * S + c);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) f[4 * qq + i] = (acc[mt][nt][4 * (2 * p2 + qq) + i] + (float)rv[i]) * scale;
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_branch_kernel(BranchArgs
                 o[w] = pack_bf16x2(lo, hi);
               }
               o = swap_quads_bf16(o);
-              if (ok) *reinterpret_cast<u32x4*>(dst + mt * 32 + 16 * p2) = o;
+              if (ok) *reinterpret_cast<u32x4*>(dst + cb + mt * 32 + 16 * p2) = o;
             }
         }
       }

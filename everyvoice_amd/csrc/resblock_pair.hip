@@ -7,26 +7,28 @@
 
 namespace evmi {
 
-//                  C  KS  BN  TAPS MAXDIL WAVES NWBUF OVL
+//                  C  KS  BN  TAPS MAXDIL WAVES NWBUF OVL WRES WM   (sixteen waves at 32 channels: four per SIMD keep the VALU-bound activation
+//                  passes and the LDS latency of the short MFMA steps covered, -7 ... -9 %; at 64 channels the 2 (channels) x 8 (rows) split
+//                  costs a fragment read per MFMA instead of 0.75 and measured equal or slower: eight waves there)
 // C = 32: all taps of one convolution fit LDS at once (single buffer): 2 weight steps per tile.  The first three entries are
 // the two-workgroups-per-CU form (4 waves, 256 rows, T1 over XA), selected by EVMI_PAIR_OVL=1 only: measured 1.22 vs 1.16 ms
 // on c32 / k11 (and 3.1 vs 1.95 ms for a 128-row two-workgroup form at C = 64) -- with half the waves per workgroup the phases
 // of one workgroup are not filled by the other.
-#define EVMI_PAIR_TABLE(X)            \
-  X(32, 3, 256, 3, 5, 4, 2, 1, 0)     \
-  X(32, 7, 256, 7, 5, 4, 1, 1, 0)     \
-  X(32, 11, 256, 11, 5, 4, 1, 1, 0)   \
-  X(64, 3, 256, 2, 5, 8, 2, 0, WR)    \
-  X(64, 7, 256, 2, 5, 8, 2, 0, WR)    \
-  X(64, 11, 256, 2, 5, 8, 2, 0, WR)   \
-  X(32, 3, 512, 3, 5, 8, 2, 0, 0)     \
-  X(32, 7, 512, 7, 5, 8, 1, 0, 0)     \
-  X(32, 11, 512, 11, 5, 8, 1, 0, WR)
+#define EVMI_PAIR_TABLE(X)               \
+  X(32, 3, 256, 3, 5, 4, 2, 1, 0, 1)     \
+  X(32, 7, 256, 7, 5, 4, 1, 1, 0, 1)     \
+  X(32, 11, 256, 11, 5, 4, 1, 1, 0, 1)   \
+  X(64, 3, 256, 2, 5, 8, 2, 0, WR, 1)    \
+  X(64, 7, 256, 2, 5, 8, 2, 0, WR, 1)    \
+  X(64, 11, 256, 2, 5, 8, 2, 0, WR, 1)   \
+  X(32, 3, 512, 3, 5, 8, 2, 0, 0, 1)     \
+  X(32, 7, 512, 7, 5, 8, 1, 0, 0, 1)     \
+  X(32, 11, 512, 11, 5, 16, 1, 0, WR, 1)
 
 static const PairLaunch* pair_table(int* n) {
 #define WR 1  // weights resident in registers (PairCfg::WRES)
-#define X(c, ks, bn, taps, md, waves, nwbuf, ovl, wres) \
-  make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf, ovl, wres>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
+#define X(c, ks, bn, taps, md, waves, nwbuf, ovl, wres, wm) \
+  make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf, ovl, wres, wm>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
   static const PairLaunch table[] = {
       // C = 32 as a conv1 / conv2 wave pipeline with the weights in registers (resblock_pair32_kernel.h): EVMI_PAIR32=1 only
       // (measured equal or slower than the single-team kernels below, see the header)
@@ -99,8 +101,8 @@ int launch_resblock_pair(const PairLaunch* L, PairArgs a, int B, int n_cu, hipSt
 // channels, k = 3 at 64 (k = 11 recomputes 23 % of every tile and is MFMA-bound as pairs already; 64 channels x k = 7 does not fit).
 static const BranchLaunch* branch_table(int* n) {
   static const BranchLaunch table[] = {
-      make_branch_launch<BranchCfg<32, 3, 512, 3, 8, 2>>("resblock_branch_mfma<c32,k3,bn512>"),
-      make_branch_launch<BranchCfg<32, 7, 512, 7, 8, 1>>("resblock_branch_mfma<c32,k7,bn512>"),
+      make_branch_launch<BranchCfg<32, 3, 512, 3, 16, 2>>("resblock_branch_mfma<c32,k3,bn512>"),
+      make_branch_launch<BranchCfg<32, 7, 512, 7, 16, 1>>("resblock_branch_mfma<c32,k7,bn512>"),
       make_branch_launch<BranchCfg<64, 3, 256, 2, 8, 2>>("resblock_branch_mfma<c64,k3,bn256>"),
   };
   *n = (int)(sizeof(table) / sizeof(table[0]));

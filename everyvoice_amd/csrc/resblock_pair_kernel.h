@@ -54,14 +54,16 @@ struct PairLaunch {
 // WRES_: the weights of both convolutions stay in registers for the life of the persistent workgroup (NSTEP x W_PER_THREAD vectors,
 // loaded once) and are committed to the LDS from there: a two-tap step at 64 channels is 16 MFMAs per wave, shorter than the L2 round
 // trip of the next step's weights that the one-step-ahead prefetch has to cover.
-template <int C_, int KS_, int BN_, int TAPS_, int MAXDIL_, int WAVES_, int DBG_ = 0, int NWBUF_ = 2, int OVL_ = 0, int WRES_ = 0>
+// WM_: waves along the output channels (the others along the rows): 64 channels on sixteen waves = 2 x 8 of 32 x 32 tiles
+template <int C_, int KS_, int BN_, int TAPS_, int MAXDIL_, int WAVES_, int DBG_ = 0, int NWBUF_ = 2, int OVL_ = 0, int WRES_ = 0, int WM_ = 1>
 struct PairCfg {
   static constexpr int C = C_, KS = KS_, BN = BN_, TAPS = TAPS_, MAXDIL = MAXDIL_, WAVES = WAVES_, DBG = DBG_, OVL = OVL_, WRES = WRES_;
+  static constexpr int WM = WM_, WN = WAVES / WM;
   // weight tap-group buffers in LDS: 2 = commit the next group while the current one is read; 1 = one
   // buffer (lets a whole convolution's taps sit in LDS at once) at the price of a barrier before each commit
   static constexpr int NWBUF = NWBUF_;
   static constexpr int NTHREADS = WAVES * 64;
-  static constexpr int MT = C / 32, NT = BN / (WAVES * 32);
+  static constexpr int MT = C / (WM * 32), NT = BN / (WN * 32);
   static constexpr int S = C + 8;  // LDS row stride (elements): odd multiple of 16 B -> conflict-free b128 reads
   static constexpr int TT = BN - (KS - 1);
   static constexpr int RA_MAX = BN + (KS - 1) * MAXDIL;
@@ -82,7 +84,7 @@ struct PairCfg {
   static constexpr size_t OFF_BIAS = OFF_WS + NWBUF * size_t(W_TILE);  // 2 copies x 2 x C floats (in bf16 units: 8 C)
   static constexpr size_t LDS = (OFF_BIAS + 8 * size_t(C)) * 2;
   static constexpr int WG_PER_CU = (2 * LDS <= 160 * 1024 && WAVES <= 4) ? 2 : 1;
-  static_assert(BN % (WAVES * 32) == 0 && C % 32 == 0, "tiling");
+  static_assert(BN % (WN * 32) == 0 && C % (WM * 32) == 0 && WAVES % WM == 0, "tiling");
   static_assert(!OVL || T1_ROWS <= RA_MAX, "T1 fits the operand tile it overlays");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
   bf16_t* WS = reinterpret_cast<bf16_t*>(smem) + P::OFF_WS;
 
   constexpr int C = P::C, S = P::S, KS = P::KS, H2 = (KS - 1) / 2;
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / P::WN, wn = wave % P::WN;
+  const int cb = wm * P::MT * 32;  // first output channel of this wave
   const int h1 = a.dil1 * (KS - 1) / 2;
   const int ra = P::BN + (KS - 1) * a.dil1;  // rows of XA actually needed
   const int x_nvec = ra * (C / 8);
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
           for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int j = 0; j < P::NT; ++j) {
-              const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (j & 1) * 2 * C + i * 32 + 8 * q + 4 * (lane >> 5));
+              const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + (j & 1) * 2 * C + cb + i * 32 + 8 * q + 4 * (lane >> 5));
 #pragma unroll
               for (int r = 0; r < 4; ++r) acc[i][j][4 * q + r] = bv[r];
             }
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
         lds_barrier();
         if (!P::WRES) w_prefetch(s + 1 == P::NSTEP ? 0 : s + 1);  // wraps to the next tile's first group
         if (s == 0 && next < tile_hi) x_issue(next);  // after the weight loads: they stay in flight
-        const bf16_t* Arow = WS + (s & (P::NWBUF - 1)) * P::W_TILE + (lane & 31) * S + (lane >> 5) * 8;
+        const bf16_t* Arow = WS + (s & (P::NWBUF - 1)) * P::W_TILE + (cb + (lane & 31)) * S + (lane >> 5) * 8;
         const bf16_t* Brow = Bsrc + (wn * P::NT * 32 + (lane & 31)) * S + grp * P::TAPS * b_tap_stride + (lane >> 5) * 8;
         if (grp + 1 < P::NG || P::LAST_TAPS == P::TAPS)
           mma_tap_group<P::MT, P::NT, C / 16, P::TAPS, C * S, 32 * S, 32 * S>(Arow, Brow, b_tap_stride, acc);
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
         for (int mt = 0; mt < P::MT; ++mt) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int c = mt * 32 + 8 * q + 4 * (lane >> 5);
+            const int c = cb + mt * 32 + 8 * q + 4 * (lane >> 5);
 #pragma unroll
             for (int nt = 0; nt < P::NT; ++nt) {
               const int n = wn * P::NT * 32 + nt * 32 + (lane & 31);
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
 #pragma unroll
           for (int mt = 0; mt < P::MT; ++mt)
 #pragma unroll
-            for (int p2 = 0; p2 < 2; ++p2) pv[mt][p2] = *reinterpret_cast<const u32x4*>(dst + mt * 32 + 16 * p2);
+            for (int p2 = 0; p2 < 2; ++p2) pv[mt][p2] = *reinterpret_cast<const u32x4*>(dst + cb + mt * 32 + 16 * p2);
         }
 #pragma unroll
         for (int mt = 0; mt < P::MT; ++mt)
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
             float f[8];
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
-              const int c = mt * 32 + 8 * (2 * p2 + qq) + 4 * hh;
+              const int c = cb + mt * 32 + 8 * (2 * p2 + qq) + 4 * hh;
               const bf16x4 rv = *reinterpret_cast<const bf16x4*>(RS + n * S + c);
 #pragma unroll
               for (int i = 0; i < 4; ++i) f[4 * qq + i] = (acc[mt][nt][4 * (2 * p2 + qq) + i] + (float)rv[i]) * scale;
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
               o[w] = pack_bf16x2(lo, hi);
             }
             o = swap_quads_bf16(o);
-            if (ok) *reinterpret_cast<u32x4*>(dst + mt * 32 + 16 * p2) = o;
+            if (ok) *reinterpret_cast<u32x4*>(dst + cb + mt * 32 + 16 * p2) = o;
           }
       }
     }
