@@ -152,7 +152,15 @@ inline uint16_t f32_to_bf16_bits(float f) {
 // contract of the split reductions) with eight loads in flight: a plain `for (s) acc += p[s * stride]` is compiled as one
 // load -> vmcnt(0) -> add per trip, i.e. one memory round trip per term.
 __device__ __forceinline__ float ordered_sum_strided(const float* __restrict__ p, long long stride, int n, float acc = 0.f) {
-  for (int s = 0; s < n; s += 8) {
+  int s = 0;
+  for (; s + 16 <= n; s += 16) {  // (sixteen in flight while there are that many: a 64-way split is four round trips, not eight)
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = p[(long long)(s + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  for (; s < n; s += 8) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = p[(long long)min(s + u, n - 1) * stride];
