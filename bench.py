@@ -369,8 +369,9 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
     front-end.  --train-precision bf16 (default): bf16 operands, fp32 accumulation / master weights / activations -- forward,
     input gradient and weight gradient of every convolution on the packed-input kernels (conv_cbt_bf16_pk.hip,
     conv_wgrad_bf16_pk.hip); f32: the exact path on the fp32 matrix cores (conv_cbt_f32_mfma.hip, conv_wgrad_f32_mfma.hip);
-    the other one is timed beside it.  The roofline object prices the step at SURVEY.md 8(d)'s 25.8 MFLOP per segment sample
-    (12.9 M MAC: D step 6.21 M + G step 6.70 M) against the dense bf16 MFMA peak (bf16) or the 157 TFLOP/s fp32 matrix peak."""
+    the other one is timed beside it.  The roofline object prices the step with the FLOPs its own launches issue (counted by
+    train/ops.py: every convolution / GEMM call of one eager step, 3.44 TFLOP at this shape; SURVEY.md 8(d)'s estimate was 25.8 MFLOP
+    per segment sample) against the dense bf16 MFMA peak (bf16) or the 157 TFLOP/s fp32 matrix peak."""
     import torch
 
     from everyvoice_amd.spectral import MelSpectrogram
