@@ -245,9 +245,12 @@ __global__ void dwconv_bwd_dx_kernel(const float* __restrict__ dy, const float* 
 
 constexpr int DW_KMAX = 32;
 // part[c][b][j] = sum_t x[c][b][t + j - pad] * dy[c][b][t] (j < k), part[c][b][k] = sum_t dy : one workgroup per (c, b) row
+// STAGED: the row of x sits in LDS, zero padded by the kernel's reach (each thread otherwise issues k conditional global loads per
+// position: the anti-pattern of DESIGN.md 9.12; rows longer than the LDS take the direct form)
+template <bool STAGED>
 __global__ __launch_bounds__(256) void dwconv_bwd_dw_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                    float* __restrict__ part, int B, int T, int k, int pad) {
-  __shared__ double sh[4];
+  extern __shared__ float xs[];  // STAGED: [T + k - 1], xs[i] = x[i - pad]
   const int b = blockIdx.x, c = blockIdx.y;
   const float* xr = x + ((long long)c * B + b) * T;
   const float* dr = dy + ((long long)c * B + b) * T;
@@ -255,25 +258,48 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dw_partial_kernel(const float*
 #pragma unroll
   for (int j = 0; j < DW_KMAX; ++j) acc[j] = 0.f;
   float sb = 0.f;
-  for (int t = threadIdx.x; t < T; t += 256) {
-    const float d = dr[t];
-    sb += d;
+  if (STAGED) {
+    for (int i = threadIdx.x; i < T + k - 1; i += 256) {
+      const int ti = i - pad;
+      const float v = xr[min(max(ti, 0), T - 1)];  // (requested unconditionally, selected afterwards)
+      xs[i] = (ti >= 0 && ti < T) ? v : 0.f;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float d = dr[t];
+      sb += d;
 #pragma unroll
-    for (int j = 0; j < DW_KMAX; ++j) {
-      const int ti = t + j - pad;
-      if (j < k && ti >= 0 && ti < T) acc[j] = fmaf(xr[ti], d, acc[j]);
+      for (int j = 0; j < DW_KMAX; ++j)
+        if (j < k) acc[j] = fmaf(xs[t + j], d, acc[j]);  // (a padded position adds 0 * d: the sum's bits do not change)
+    }
+  } else {
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float d = dr[t];
+      sb += d;
+#pragma unroll
+      for (int j = 0; j < DW_KMAX; ++j) {
+        const int ti = t + j - pad;
+        if (j < k && ti >= 0 && ti < T) acc[j] = fmaf(xr[ti], d, acc[j]);
+      }
     }
   }
+  // k + 1 workgroup sums: the wave-level halves of all of them first, ONE barrier, then the four wave sums of value j added by thread
+  // j in the order block_sum adds them (same bits as k + 1 calls of block_sum, without their 2 (k + 1) barriers: 46.7 -> ? us per launch)
+  __shared__ double shw[4][DW_KMAX + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j <= DW_KMAX; ++j) {
+    if (j < k || j == DW_KMAX) {
+      double v = j == DW_KMAX ? (double)sb : (double)acc[j < DW_KMAX ? j : 0];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) shw[wave][j] = v;
+    }
+  }
+  __syncthreads();
   float* pr = part + ((long long)c * B + b) * (k + 1);
-#pragma unroll
-  for (int j = 0; j < DW_KMAX; ++j) {
-    if (j < k) {
-      const double tot = block_sum((double)acc[j], sh);
-      if (threadIdx.x == 0) pr[j] = (float)tot;
-    }
-  }
-  const double tb = block_sum((double)sb, sh);
-  if (threadIdx.x == 0) pr[k] = (float)tb;
+  if (threadIdx.x < k) pr[threadIdx.x] = (float)(shw[0][threadIdx.x] + shw[1][threadIdx.x] + shw[2][threadIdx.x] + shw[3][threadIdx.x]);
+  if (threadIdx.x == 0) pr[k] = (float)(shw[0][DW_KMAX] + shw[1][DW_KMAX] + shw[2][DW_KMAX] + shw[3][DW_KMAX]);
 }
 
 // dw[c][j] += sum_b part[c][b][j] ; db[c] += sum_b part[c][b][k]   (fixed order)
@@ -549,7 +575,9 @@ int evmi_dwconv1d_bwd_cbt_f32(const float* x, const float* w, const float* dy, f
   }
   if (dw) {
     if (!ws || ws_elems < evmi_dwconv1d_bwd_cbt_f32_ws_elems(C, B, k)) return fail(EVMI_ERR_INVALID_ARG, "dwconv_bwd: workspace missing or too small");
-    hipLaunchKernelGGL(dwconv_bwd_dw_partial_kernel, dim3(B, C), dim3(256), 0, s, x, dy, ws, B, T, k, pad);
+    const size_t lds = (size_t)(T + k - 1) * sizeof(float);
+    if (lds <= 40 * 1024) hipLaunchKernelGGL(dwconv_bwd_dw_partial_kernel<true>, dim3(B, C), dim3(256), lds, s, x, dy, ws, B, T, k, pad);
+    else hipLaunchKernelGGL(dwconv_bwd_dw_partial_kernel<false>, dim3(B, C), dim3(256), 0, s, x, dy, ws, B, T, k, pad);
     EVMI_LAUNCH_CHECK("dwconv_bwd_dw_partial");
     hipLaunchKernelGGL(dwconv_bwd_dw_final_kernel, dim3(blocks_for((long long)C * (k + 1))), dim3(256), 0, s, ws, dw, db, C, B, k);
     EVMI_LAUNCH_CHECK("dwconv_bwd_dw_final");
