@@ -157,6 +157,22 @@ __device__ __forceinline__ float bn_act_grad(float z, int act) {
   return 1.f;
 }
 
+// A 256-thread workgroup walking ONE row of N values (thread t takes t, t + 256, ...): `body(i, u)`-style loops compile to one load ->
+// wait -> use per trip (a memory round trip per 256 values: 68 us for a 26 k-value BatchNorm row).  row_walk issues the loads of eight
+// trips before the first use; the order in which a thread meets its values -- and with it every sum's bits -- is unchanged.
+template <class Load, class Use>
+__device__ __forceinline__ void row_walk(long long N, Load load, Use use) {
+  long long i = threadIdx.x;
+  for (; i + 7 * 256 < N; i += 8 * 256) {
+    decltype(load(i)) v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = load(i + u * 256);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) use(i + u * 256, v[u]);
+  }
+  for (; i < N; i += 256) use(i, load(i));
+}
+
 __global__ __launch_bounds__(256) void batchnorm_fwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ y,
                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
@@ -170,14 +186,14 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_cbt_kernel(const float* __r
     if (threadIdx.x == 0) { mean_out[c] = mean; rstd_out[c] = rstd; }
     const float ga = gamma[c] * rstd, be = beta[c];
     float* yr = y + (long long)c * N;
-    for (long long i = threadIdx.x; i < N; i += 256) yr[i] = bn_act((xr[i] - mean) * ga + be, act);
+    row_walk(N, [&](long long i) { return xr[i]; }, [&](long long i, float v) { yr[i] = bn_act((v - mean) * ga + be, act); });
     return;
   }
   double s = 0.0;
-  for (long long i = threadIdx.x; i < N; i += 256) s += (double)xr[i];
+  row_walk(N, [&](long long i) { return xr[i]; }, [&](long long, float v) { s += (double)v; });
   const float mean = (float)(block_sum(s, sh) / (double)N);
   double q = 0.0;
-  for (long long i = threadIdx.x; i < N; i += 256) { const float d = xr[i] - mean; q += (double)(d * d); }
+  row_walk(N, [&](long long i) { return xr[i]; }, [&](long long, float v) { const float d = v - mean; q += (double)(d * d); });
   const double ss = block_sum(q, sh);
   const float var = (float)(ss / (double)N);
   const float rstd = 1.f / sqrtf(var + eps);
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_cbt_kernel(const float* __r
   }
   const float ga = gamma[c] * rstd, be = beta[c];
   float* yr = y + (long long)c * N;
-  for (long long i = threadIdx.x; i < N; i += 256) yr[i] = bn_act((xr[i] - mean) * ga + be, act);
+  row_walk(N, [&](long long i) { return xr[i]; }, [&](long long i, float v) { yr[i] = bn_act((v - mean) * ga + be, act); });
 }
 
 __global__ __launch_bounds__(256) void batchnorm_bwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -205,12 +221,13 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_cbt_kernel(const float* __r
   const float* dr = dy + (long long)c * N;
   const float mean = mean_in[c], rstd = rstd_in[c], ga = gamma[c], be = beta[c];
   double s1 = 0.0, s2 = 0.0;
-  for (long long i = threadIdx.x; i < N; i += 256) {
-    const float xh = (xr[i] - mean) * rstd;
-    const float dz = dr[i] * bn_act_grad(xh * ga + be, act);
+  struct XD { float x, d; };
+  row_walk(N, [&](long long i) { return XD{xr[i], dr[i]}; }, [&](long long, XD v) {
+    const float xh = (v.x - mean) * rstd;
+    const float dz = v.d * bn_act_grad(xh * ga + be, act);
     s1 += (double)dz;
     s2 += (double)(dz * xh);
-  }
+  });
   const double t1 = block_sum(s1, sh);
   const double t2 = block_sum(s2, sh);
   if (threadIdx.x == 0) {
@@ -219,11 +236,11 @@ __global__ __launch_bounds__(256) void batchnorm_bwd_cbt_kernel(const float* __r
   }
   const float m1 = (float)(t1 / (double)N), m2 = (float)(t2 / (double)N);
   float* dxr = dx + (long long)c * N;
-  for (long long i = threadIdx.x; i < N; i += 256) {
-    const float xh = (xr[i] - mean) * rstd;
-    const float dz = dr[i] * bn_act_grad(xh * ga + be, act);
+  row_walk(N, [&](long long i) { return XD{xr[i], dr[i]}; }, [&](long long i, XD v) {
+    const float xh = (v.x - mean) * rstd;
+    const float dz = v.d * bn_act_grad(xh * ga + be, act);
     dxr[i] = ga * rstd * (dz - m1 - xh * m2);
-  }
+  });
 }
 
 // ---- depthwise convolution backward ----------------------------------------------------------------------------------
