@@ -210,9 +210,7 @@ __global__ void align_colsum_kernel(const float* __restrict__ da, float* __restr
   if (i >= B * L) return;
   const int b = i / L, l = i - b * L;
   const float* p = da + (long long)b * T * L + l;
-  float s = 0.f;
-  for (int t = 0; t < T; ++t) s += p[(long long)t * L];
-  colsum[i] = s;
+  colsum[i] = ordered_sum_strided(p, L, T);  // (same order of additions, sixteen loads in flight: 238 -> ~30 us at 947 frames)
 }
 
 // in place: m[c][b][n] = coef * (x[c][b][n] * sums[b][n] - m[c][b][n])
