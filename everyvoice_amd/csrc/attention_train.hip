@@ -165,7 +165,15 @@ __global__ void attention_rowdot_kernel(const float* __restrict__ o, const float
   const long long N = (long long)B * T;
   const long long base = ((long long)(h * DH) * B + b) * T + t;
   float acc = 0.f;
-  for (int d = 0; d < DH; ++d) acc = fmaf(o[base + d * N], d_o[base + d * N], acc);
+  int d = 0;
+  for (; d + 8 <= DH; d += 8) {  // sixteen loads in flight (a plain loop is one memory round trip per d: 53 us at DH = 128); same fmaf order
+    float ov[8], dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { ov[u] = o[base + (d + u) * N]; dv[u] = d_o[base + (d + u) * N]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fmaf(ov[u], dv[u], acc);
+  }
+  for (; d < DH; ++d) acc = fmaf(o[base + d * N], d_o[base + d * N], acc);
   dsum[i] = acc;
 }
 
