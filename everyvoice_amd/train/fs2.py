@@ -721,14 +721,15 @@ class FastSpeech2Trainer:
         next batch (0.7 ms of a 24 ms step in the trace: `tools/trace_gaps.py`).  Now the host never waits, and a host batch (a data
         loader's) is uploaded and laid out UNDER step n while the step's stream only waits for the upload stream's event.  A batch
         that already holds device tensors may have been produced by work still queued on the caller's stream: the upload stream
-        then queues behind it (a device-side dependency; the host still runs ahead)."""
+        then queues behind it (a device-side dependency; the host still runs ahead) -- unless the caller sets `batch_ready = True`
+        (a prefetcher that synchronised its own copies, or a batch resident on the device from the start, as in bench.py)."""
         if self.device.type != "cuda":
             return self._prepare(batch)
         if getattr(self, "_upload", None) is None:
             self._upload = torch.cuda.Stream(self.device)
         step = torch.cuda.current_stream(self.device)
-        if any(torch.is_tensor(v) and v.is_cuda for v in batch.values()):
-            self._upload.wait_stream(step)
+        if any(torch.is_tensor(v) and v.is_cuda for v in batch.values()) and not getattr(self, "batch_ready", False):
+            self._upload.wait_stream(step)  # (`batch_ready = True`: the caller vouches that the batch's device tensors are complete)
         with torch.cuda.stream(self._upload):
             d, meta = self._prepare(batch)
         step.wait_stream(self._upload)
