@@ -492,6 +492,8 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     const long long want_mod = ((long long)n_max * a.stride) & 15;
     if (align_tp && ext >= 96) ext += ((want_mod - (ext & 15)) + 16) & 15;  // (short items: the padding would cost more than the conflicts)
   }
+  // pointwise stride-1 layers are packed tight (ext == t_in here): the layout the weight gradient reads too (conv_pk_common.h)
+  const bool shared = a.phases == 1 && PL == 0 && pk_shared_shape(a.k, a.stride, 0, a.dil, groups) && ext == t_in && pk_shared_items(a.B, t_in);
   a.Tp = (int)ext;
   const long long n_total = (long long)a.B * n_max;
   auto blocks = [&](int i) {
@@ -595,7 +597,7 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
   pl.PL = PL;
   pl.cin_g = cin_g; pl.t_in = t_in; pl.groups = groups;
   // slack: the last window piece of the last tile reads up to 63 units past its window, rows of the last octet included
-  pl.xp_units = (long long)groups * a.octs * a.B * a.Tp + (long long)a.xrow + 64;
+  pl.xp_units = (long long)groups * a.octs * a.B * a.Tp + std::max<long long>((long long)a.xrow + 64, shared ? PK_SHARED_SLACK : 0);
   a.wf_phase_stride = (long long)groups * a.mblocks * a.kblocks * 64;
   pl.wf_units = a.wf_phase_stride * a.phases + ((long long)a.kblocks * 8 + 15) / 16;  // + the K-block offset table (int2 each)
   if (pl.xp_units >= (1LL << 31)) return "packed input too large";
@@ -609,8 +611,11 @@ struct PkInputFusion {  // what the pack applies to the input on its way in (see
   float mask_slope = 1.f;
 };
 
+// stage 0: pack + weight fragments + convolution; 1: the pack alone (the packed input is left at the head of ws); 2: the rest, on the
+// input stage 1 packed into the same ws (same shape, hence the same plan)
 static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float* w, float* ws, long long ws_elems, int wmode,
-                     int rows_g, int kch_g, int k_full, int stride_full, hipStream_t stream, PkInputFusion in = PkInputFusion()) {
+                     int rows_g, int kch_g, int k_full, int stride_full, hipStream_t stream, PkInputFusion in = PkInputFusion(),
+                     int stage = 0) {
   const long long need = (pl.xp_units + pl.wf_units) * 4 + pl.part_elems;
   if (!ws || ws_elems < need || (reinterpret_cast<uintptr_t>(ws) & 15))
     return fail(EVMI_ERR_INVALID_ARG, "conv_cbt_bf16_pk: workspace missing, too small or unaligned");
@@ -625,9 +630,15 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   fa.kblocks = a.kblocks; fa.mode = wmode; fa.k_full = k_full; fa.stride = stride_full; fa.phase_stride_words = a.wf_phase_stride * 4;
   fa.tab = reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases); fa.kb_step = a.kb_step; fa.xrow = a.xrow; fa.dil = a.dil;
   fa.gx = a.kblocks; fa.gy = pl.groups * a.mblocks; fa.gz = a.phases;
+  if (stage == 1) fa.gx = fa.gy = fa.gz = 0;
+  if (stage == 2) pa.gx = pa.gy = pa.gz = 0;
   const long long n_prep = (long long)pa.gx * pa.gy * pa.gz + (long long)fa.gx * fa.gy * fa.gz;
   if (n_prep > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_bf16_pk: grid limits (preparation pass)");
-  hipLaunchKernelGGL(prep_pk_kernel, dim3((unsigned)n_prep), dim3(256), 0, stream, pa, fa);
+  if (n_prep > 0) hipLaunchKernelGGL(prep_pk_kernel, dim3((unsigned)n_prep), dim3(256), 0, stream, pa, fa);
+  if (stage == 1) {
+    EVMI_LAUNCH_CHECK("conv_cbt_bf16_pk (pack)");
+    return EVMI_OK;
+  }
   a.tab = fa.tab;
   a.xp = xp;
   a.wf = wf;
@@ -782,6 +793,23 @@ int evmi_conv1d_dgrad_cbt_bf16pk(const float* dy_dev, const float* w_dev, float*
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk: ") + why);
   a.y = dx_dev;
   return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream);
+}
+
+/* The same call in two steps, so that a caller can put something between them: stage 1 packs dy into the head of ws and returns;
+ * stage 2 (same arguments, same ws, untouched in between) prepares the weight fragments and runs the convolution on it.  What goes
+ * between them in training: the fork of the weight-gradient stream -- the weight gradient of a pointwise layer reads that packed dy
+ * (evmi_conv1d_wgrad_cbt_bf16pk_prepacked) and can then run BESIDE the input gradient instead of behind it. */
+int evmi_conv1d_dgrad_cbt_bf16pk_staged(int stage, const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems,
+                                        int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
+                                        void* stream) {
+  if (stage != 1 && stage != 2) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged: stage 1 or 2");
+  if (!dy_dev || !w_dev || !dx_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged: null pointer");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_dgrad_pk(a, pl, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk_staged: ") + why);
+  a.y = dx_dev;
+  return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream, PkInputFusion(), stage);
 }
 
 /* Input gradient with the fusions of a backward pass: dy is multiplied by (dy_mask > 0 ? 1 : dy_mask_slope) while it is packed

@@ -82,6 +82,18 @@ __device__ __forceinline__ void pack_x_block(const PackArgs& p, int bx, int b, i
   out.w = pk_bf16x2(v[6], v[7]);
   p.xp[((long long)go * p.B + b) * p.Tp + u] = out;
 }
+// A packed tensor that BOTH the convolution kernels and the weight-gradient kernel read.  For pointwise stride-1 layers (k = 1, no
+// padding, one group) nothing reads across an item boundary, so the weight gradient needs no padding between the items -- only rows
+// (B * Tp units per channel octet) that end on one of its K steps (64 positions), or its last step would run into the next octet's
+// row.  The convolution kernels pack such a layer TIGHT (Tp = t_in: a padded item would cost their column tiles a third window piece:
+// measured 76 -> 90 us on the FastSpeech2 feed-forward layers).  So when B * t_in is a multiple of 64 the forward convolution's packed
+// input and the input-gradient convolution's packed dy ARE the weight gradient's operands (Tq = t_in): no second pack (`pack2_kernel`:
+// 90 launches, 1.6 ms of a FastSpeech2 step).  PK_SHARED_SLACK: units behind the tensor that are kept zero (the weight gradient's
+// staging reads a window past the end).
+static inline bool pk_shared_shape(int k, int stride, int pad, int dil, int groups) { return k == 1 && stride == 1 && pad == 0 && dil == 1 && groups == 1; }
+static inline bool pk_shared_items(int B, int n) { return ((long long)B * n) % 64 == 0; }
+constexpr int PK_SHARED_SLACK = 384;
+
 static inline PackArgs make_pack_args(const float* x, uint4* xp, int cin_g, int octs, int B, int t_in, int Tp, int PL, int slack_units,
                                       int groups) {
   PackArgs p;

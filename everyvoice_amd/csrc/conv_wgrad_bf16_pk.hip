@@ -271,6 +271,9 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
   long long Tq = ((long long)n_out + 15) / 16 * 16;
   // ... and the rows of the packed dy must end on a K-step boundary (the step past the end would read the next row)
   while (Tq * stride < need || ((long long)B * Tq) % WG_KS) Tq += 16;
+  // pointwise stride-1 layers whose rows end on a K step anyway: tight items, the layout the convolution kernels pack (conv_pk_common.h)
+  static_assert(WG_KS == 64, "pk_shared_items states the K step");
+  if (pk_shared_shape(k, stride, pad, dil, groups) && pk_shared_items(B, n_out) && t_in == n_out) Tq = n_out;
   if (Tq > (1 << 22)) return "row too long";
   pl.Tq = (int)Tq;
   a.plane_y = (long long)B * Tq;
@@ -339,13 +342,31 @@ int evmi_conv1d_wgrad_cbt_bf16pk_plan(int B, int c_in, int t_in, int c_out, int 
 
 static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in,
                          int c_out, int n_out, int k, int stride, int pad, int dil, int groups, int accumulate, float x_pre_slope,
-                         const float* dy_mask_dev, float dy_mask_slope, void* stream);
+                         const float* dy_mask_dev, float dy_mask_slope, void* stream, const void* x_packed_dev = nullptr,
+                         const void* dy_packed_dev = nullptr);
 
 int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in,
                                  int t_in, int c_out, int n_out, int k, int stride, int pad, int dil, int groups, int accumulate,
                                  void* stream) {
   return wgrad_pk_impl(x_dev, dy_dev, dw_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups, accumulate, 1.f,
                        nullptr, 1.f, stream);
+}
+
+/* Pointwise stride-1 layers (k = 1, no padding, one group): operands that are ALREADY packed -- x_packed_dev: the head of the workspace
+ * the forward evmi_conv1d_cbt_bf16pk* call of this layer was given (its packed input), dy_packed_dev: the head of the workspace of the
+ * layer's input-gradient call (its packed dy); either may be NULL (then the fp32 tensor is packed here as usual); B * t must be a
+ * multiple of 64 (evmi_conv1d_bf16pk_shares_packed).  The caller keeps
+ * those workspaces untouched until this call has run. */
+int evmi_conv1d_wgrad_cbt_bf16pk_prepacked(const float* x_dev, const void* x_packed_dev, const float* dy_dev, const void* dy_packed_dev,
+                                           float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in, int c_out, int n_out,
+                                           int k, int stride, int pad, int dil, int groups, int accumulate, void* stream) {
+  return wgrad_pk_impl(x_dev, dy_dev, dw_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups, accumulate, 1.f,
+                       nullptr, 1.f, stream, x_packed_dev, dy_packed_dev);
+}
+/* 1 when a layer of this shape packs its operands in the format the call above reads (evmi_conv1d_cbt_bf16pk / _dgrad_ and the weight
+ * gradient agree on it), else 0. */
+int evmi_conv1d_bf16pk_shares_packed(int B, int t, int k, int stride, int pad, int dil, int groups) {
+  return pk_shared_shape(k, stride, pad, dil, groups) && pk_shared_items(B, t) ? 1 : 0;
 }
 
 /* The same with the operands transformed while they are packed: x -> leaky_relu(x, x_pre_slope) (the activation in front of the
@@ -446,8 +467,12 @@ int evmi_conv1d_wgrad_tm_bf16(const void* x_tm, const void* dy_tm, float* dw_dev
 
 static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in,
                          int c_out, int n_out, int k, int stride, int pad, int dil, int groups, int accumulate, float x_pre_slope,
-                         const float* dy_mask_dev, float dy_mask_slope, void* stream) {
-  if (!x_dev || !dy_dev || !dw_dev || !ws_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_cbt_bf16pk: null pointer");
+                         const float* dy_mask_dev, float dy_mask_slope, void* stream, const void* x_packed_dev,
+                         const void* dy_packed_dev) {
+  if ((!x_dev && !x_packed_dev) || (!dy_dev && !dy_packed_dev) || !dw_dev || !ws_dev)
+    return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_cbt_bf16pk: null pointer");
+  if ((x_packed_dev || dy_packed_dev) && !pk_shared_shape(k, stride, pad, dil, groups))
+    return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_cbt_bf16pk: pre-packed operands exist for pointwise stride-1 layers only");
   WgradPkArgs a = {};
   WgradPkPlan pl;
   if (const char* why = plan_wgrad_pk(a, pl, B, c_in, t_in, c_out, n_out, k, stride, pad, dil, groups))
@@ -468,11 +493,17 @@ static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev,
                                groups);
   px.pre_slope = x_pre_slope;
   py.mask = dy_mask_dev; py.mask_slope = dy_mask_slope;
+  // an operand that arrives packed (the forward convolution's input / the input-gradient convolution's dy, in the shared item
+  // layout: plan_wgrad_pk's Tq is the tight t_in for these shapes) is read where it lies; its pack is an empty grid
+  if ((x_packed_dev || dy_packed_dev) && !(pk_shared_items(B, n_out) && pl.Tq == n_out && t_in == n_out))
+    return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_cbt_bf16pk: packed operands need rows that end on a K step (B * t a multiple of 64)");
+  if (dy_packed_dev) py.gx = py.gy = py.gz = 0;
+  if (x_packed_dev) px.gx = px.gy = px.gz = 0;
   const long long n_pack = (long long)py.gx * py.gy * py.gz + (long long)px.gx * px.gy * px.gz;
   if (n_pack > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv1d_wgrad_cbt_bf16pk: grid limits (pack)");
-  hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)n_pack), dim3(256), 0, s, py, px);
-  a.dyp = dyp;
-  a.xp = xp;
+  if (n_pack > 0) hipLaunchKernelGGL(pack2_kernel, dim3((unsigned)n_pack), dim3(256), 0, s, py, px);
+  a.dyp = dy_packed_dev ? reinterpret_cast<const uint4*>(dy_packed_dev) : dyp;
+  a.xp = x_packed_dev ? reinterpret_cast<const uint4*>(x_packed_dev) : xp;
   a.out = pl.splits > 1 ? part : dw_dev;
   a.accumulate = pl.splits > 1 ? 0 : accumulate;
   a.partial = pl.splits > 1;

@@ -195,7 +195,8 @@ def dense(tape: Tape, x: Var, layer, act=ops.ACT_NONE) -> Var:
     """conv1d / Linear (+ ReLU or tanh in the epilogue: their backward only needs the output)."""
     assert act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_TANH)
     w, dw_sink = layer.effective(True)
-    y = Var(ops.conv1d_fwd(x.data, w, layer.bias_data(), 1, layer.pad, 1, 1, act=act))
+    packed = {}  # pointwise layers on the packed bf16 kernels: x is packed once (here), dy once (input gradient), for all three products
+    y = Var(ops.conv1d_fwd(x.data, w, layer.bias_data(), 1, layer.pad, 1, 1, act=act, keep=packed))
 
     def bwd():
         if y.grad is None:
@@ -205,7 +206,9 @@ def dense(tape: Tape, x: Var, layer, act=ops.ACT_NONE) -> Var:
             dy = ops.elementwise(ops.EW_RELU_BWD, dy, y.data)
         elif act == ops.ACT_TANH:
             dy = ops.tanh_bwd(dy, y.data)
-        dx, _, _ = ops.conv1d_bwd(x.data, w, dy, 1, layer.pad, 1, 1, need_dx=x.needs_grad, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True)
+        dx, _, _ = ops.conv1d_bwd(x.data, w, dy, 1, layer.pad, 1, 1, need_dx=x.needs_grad, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True,
+                                  packed=packed)
+        packed.clear()
         if dx is not None:
             x.accumulate(dx)
 

@@ -231,9 +231,17 @@ def wgrad_join(device=None):
 ACT_NONE, ACT_LRELU, ACT_SILU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
 
 
+def shares_packed(B, t, k, stride, pad, dil, groups) -> bool:
+    """True for the layers whose packed bf16 operands serve forward, input gradient AND weight gradient (pointwise, stride 1, B * t a
+    multiple of the weight gradient's K step)."""
+    return bool(_packed() and _lib.load().evmi_conv1d_bf16pk_shares_packed(B, t, k, stride, pad, dil, groups))
+
+
 def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=None, out_stride=1, out_offset=0,
-                accumulate=False, act=ACT_NONE, act_param=0.0):
-    """fp32 matrix-core implicit GEMM (evmi_conv1d_cbt_f32): x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out]."""
+                accumulate=False, act=ACT_NONE, act_param=0.0, keep=None):
+    """fp32 matrix-core implicit GEMM (evmi_conv1d_cbt_f32): x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out].
+    ``keep`` (a dict): on the packed bf16 path of a pointwise stride-1 layer the call gets a workspace of its own, left in
+    ``keep["x_packed"]`` -- its head is the packed input, which the layer's weight gradient reads again (no second pack)."""
     cin, B, t_in = x.shape
     cout, cin_g, k = w.shape
     t_conv = conv_out_len(t_in, k, stride, pad, dil)
@@ -245,7 +253,10 @@ def conv1d_mfma(x, w, bias, stride=1, pad=0, dil=1, groups=1, out=None, n_out=No
         n_eff = t_conv if n_out is None else n_out
         pk_elems = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t_in, cout, n_eff, k, stride, pad, dil, groups)
         if pk_elems > 0:  # packed bf16 copy of x + A fragments (conv_cbt_bf16_pk.hip)
-            ws = WS.get("pk", pk_elems, x.device)
+            if keep is not None and n_out is None and shares_packed(B, t_in, k, stride, pad, dil, groups):
+                ws = keep["x_packed"] = torch.empty(pk_elems, device=x.device, dtype=torch.float32)
+            else:
+                ws = WS.get("pk", pk_elems, x.device)
             _chk(lib.evmi_conv1d_cbt_bf16pk(x.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in,
                                             cout, out.shape[2], n_eff, k, stride, pad, dil, groups, out_stride, out_offset,
                                             int(accumulate), act, float(act_param), _s(x)), "evmi_conv1d_cbt_bf16pk")
@@ -343,7 +354,7 @@ def dgrad_mfma_supported(B, cin, t_in, cout, t_out, k, stride, dil, groups) -> b
     return mfma_conv_supported(B, cout, t_out, cin, n_out, M, 1, dil if stride == 1 else 1, groups)
 
 
-def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
+def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1, keep=None):
     """Input gradient of conv1d on the fp32 matrix cores: `stride` polyphase stride-1 convolutions of dy with
     re-indexed weights, each writing its own residue class of dx (strided layers all have dilation 1)."""
     cout, B, t_out = dy.shape
@@ -354,7 +365,10 @@ def conv1d_bwd_data_mfma(dy, w, t_in, stride=1, pad=0, dil=1, groups=1):
         pk_elems = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
         if pk_elems > 0:
             _count_conv(B, t_out, cout, cin_g, k)
-            ws = WS.get("pk", pk_elems, dy.device)
+            if keep is not None and shares_packed(B, t_out, k, stride, pad, dil, groups):  # (``keep["dy_packed"]``: see conv1d_mfma)
+                ws = keep["dy_packed"] = torch.empty(pk_elems, device=dy.device, dtype=torch.float32)
+            else:
+                ws = WS.get("pk", pk_elems, dy.device)
             dx = zeros(cin, B, t_in, device=dy.device) if k < stride else torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
             _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout,
                                                   t_out, k, stride, pad, dil, groups, _s(dy)), "evmi_conv1d_dgrad_cbt_bf16pk")
@@ -425,20 +439,20 @@ def mfma_conv_supported(B, cin, t_in, cout, n_out, k, stride, dil, groups) -> bo
 _ACT_EW = {ACT_SILU: 13, ACT_RELU: 14, ACT_TANH: EW_TANH}
 
 
-def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, lrelu_slope=None, act=ACT_NONE):
+def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, lrelu_slope=None, act=ACT_NONE, keep=None):
     """x [Cin, B, T], w [Cout, Cin/groups, k] -> y [Cout, B, T_out] (leaky-relu applied in the epilogue when a slope is given;
     ``act``: one of the other epilogue activations)."""
     cin, B, t_in = x.shape
     cout, cin_g, k = w.shape
     if act != ACT_NONE:
         if CONV_BACKEND["fwd"] == "mfma" and mfma_conv_supported(B, cin, t_in, cout, conv_out_len(t_in, k, stride, pad, dil), k, stride, dil, groups):
-            return conv1d_mfma(x, w, bias, stride, pad, dil, groups, act=act)
+            return conv1d_mfma(x, w, bias, stride, pad, dil, groups, act=act, keep=keep)
         y = conv1d_fwd(x, w, bias, stride, pad, dil, groups)
         return elementwise(_ACT_EW[act], y, out=y)
     if CONV_BACKEND["fwd"] == "mfma" and mfma_conv_supported(B, cin, t_in, cout, conv_out_len(t_in, k, stride, pad, dil), k, stride, dil, groups):
         if lrelu_slope is None:
-            return conv1d_mfma(x, w, bias, stride, pad, dil, groups)
-        return conv1d_mfma(x, w, bias, stride, pad, dil, groups, act=ACT_LRELU, act_param=lrelu_slope)
+            return conv1d_mfma(x, w, bias, stride, pad, dil, groups, keep=keep)
+        return conv1d_mfma(x, w, bias, stride, pad, dil, groups, act=ACT_LRELU, act_param=lrelu_slope, keep=keep)
     if lrelu_slope is not None:
         y = conv1d_fwd(x, w, bias, stride, pad, dil, groups)
         return elementwise(EW_LRELU, y, out=y, p0=lrelu_slope)
@@ -454,7 +468,7 @@ def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, lrelu_slope=None, a
     return y
 
 
-def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, accumulate):
+def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, accumulate, packed=None):
     """dw (+)= conv_weight_grad(x, dy) and, when asked, db_out (+)= row sums of dy -- on whichever kernel takes the shape."""
     cin, B, t_in = x.shape
     cout, cin_g, k = w_shape
@@ -471,8 +485,16 @@ def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, 
         _count_conv(B, t_out, cout, cin_g, k)
     if pk_elems > 0:  # bf16 operands: packed dy and x, transposing LDS reads (conv_wgrad_bf16_pk.hip)
         ws = WS.get("pkw", pk_elems, x.device)
-        _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout, t_out,
-                                              k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk")
+        xp = packed.get("x_packed") if packed else None
+        dyp = packed.get("dy_packed") if packed else None
+        if (xp is not None or dyp is not None) and shares_packed(B, t_in, k, stride, pad, dil, groups):
+            # the forward's packed input / the input gradient's packed dy, read where they lie (no second pack)
+            _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk_prepacked(x.data_ptr(), _lib.ptr(xp), dy.data_ptr(), _lib.ptr(dyp), dw.data_ptr(), ws.data_ptr(),
+                                                            pk_elems, B, cin, t_in, cout, t_out, k, stride, pad, dil, groups, int(accumulate),
+                                                            _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk_prepacked")
+        else:
+            _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout, t_out,
+                                                  k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk")
     elif ws_elems > 0:  # implicit GEMM on the fp32 matrix cores (conv_wgrad_f32_mfma.hip)
         ws = WS.get("wgrad", ws_elems, x.device)
         _chk(lib.evmi_conv1d_wgrad_cbt_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
@@ -488,8 +510,10 @@ def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, 
 
 
 def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=None, db_out=None, accumulate=False,
-               need_dw=True):
-    """Returns (dx, dw, db); dw/db are written (or accumulated) into the given buffers when provided."""
+               need_dw=True, packed=None):
+    """Returns (dx, dw, db); dw/db are written (or accumulated) into the given buffers when provided.
+    ``packed``: the dict the layer's forward call filled (``conv1d_fwd(..., keep=packed)``): a pointwise stride-1 layer on the packed
+    bf16 kernels then packs x once (forward) and dy once (input gradient) for all three of its products."""
     cin, B, t_in = x.shape
     cout, cin_g, k = w.shape
     t_out = dy.shape[2]
@@ -499,11 +523,31 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
     wm = w.reshape(cout, cin_g * k)
     dw = db = None
     side = None
+    share = packed is not None and need_dw and shares_packed(B, t_in, k, stride, pad, dil, groups)
+    share_dy = (share and need_dx and CONV_BACKEND["dgrad"] == "mfma" and dgrad_mfma_supported(B, cin, t_in, cout, t_out, k, stride, dil, groups)
+                and _lib.load().evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups) > 0)
+    staged = None
+    if share_dy:
+        # dy is packed FIRST, as a launch of its own, so that the weight gradient's stream can fork behind the pack and in front of
+        # the input gradient: both read the one packed dy side by side.  (Forking behind the whole input gradient instead -- one more
+        # cross-stream edge per layer on the chain's critical path -- cost a captured FastSpeech2 step 4 ms: 21.9 -> 25.8 ms.)
+        lib = _lib.load()
+        pk_elems = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
+        ws = packed["dy_packed"] = torch.empty(pk_elems, device=dy.device, dtype=torch.float32)
+        dx = torch.empty(cin, B, t_in, device=dy.device, dtype=torch.float32)
+        staged = (lib, ws, pk_elems, dx)
+        _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged(1, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout, t_out,
+                                                     k, stride, pad, dil, groups, _s(dy)), "evmi_conv1d_dgrad_cbt_bf16pk_staged")
     if need_dw:
         dw = dw_out if dw_out is not None else torch.empty_like(w)
-        side = side_wgrad(x, dy, dw, db_out).mark()  # fork here; the launches are issued behind the input gradient's (below)
+        side = side_wgrad(x, dy, dw, db_out, *(packed.values() if share else ())).mark()  # fork here; the launches are issued behind the input gradient's (below)
     dx = None
-    if need_dx and CONV_BACKEND["dgrad"] == "mfma" and dgrad_mfma_supported(B, cin, t_in, cout, t_out, k, stride, dil, groups):
+    if staged is not None:
+        lib, ws, pk_elems, dx = staged
+        _count_conv(B, t_out, cout, cin_g, k)
+        _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged(2, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout, t_out,
+                                                     k, stride, pad, dil, groups, _s(dy)), "evmi_conv1d_dgrad_cbt_bf16pk_staged")
+    elif need_dx and CONV_BACKEND["dgrad"] == "mfma" and dgrad_mfma_supported(B, cin, t_in, cout, t_out, k, stride, dil, groups):
         dx = conv1d_bwd_data_mfma(dy, w, t_in, stride, pad, dil, groups)
     elif need_dx:
         pointwise = k == 1 and stride == 1 and pad == 0
@@ -515,7 +559,7 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
         dx = dcol.view(cin, B, t_in) if pointwise else fold(dcol, cin, B, t_in, t_out, k, stride, pad, dil)
     if side is not None:
         with side:
-            db = _weight_and_bias_grad(x, w.shape, dy, dw, db_out, stride, pad, dil, groups, accumulate)
+            db = _weight_and_bias_grad(x, w.shape, dy, dw, db_out, stride, pad, dil, groups, accumulate, packed=packed if share else None)
     return dx, dw, db
 
 

@@ -290,6 +290,12 @@ long long evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c
 int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev,
                                  long long ws_elems, int B, int c_in, int t_in, int c_out, int n_out, int k, int stride,
                                  int pad, int dil, int groups, int accumulate, void* stream);
+/* evmi_conv1d_dgrad_cbt_bf16pk in two steps (same arguments and workspace for both): stage 1 packs dy into the head of ws_dev, stage 2
+ * runs the rest on it.  Between them a training step forks its weight-gradient stream: a pointwise layer's weight gradient reads the
+ * packed dy (evmi_conv1d_wgrad_cbt_bf16pk_prepacked) beside the input gradient. */
+int evmi_conv1d_dgrad_cbt_bf16pk_staged(int stage, const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems,
+                                        int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
+                                        void* stream);
 /* The packed bf16 convolution kernels with a residual block's neighbours fused in (no separate activation / add passes, no
  * activated copies in HBM) -- the training-side counterpart of SURVEY.md 8b's evmi_resblock1_fused_{fwd,bwd}:
  *   forward   y = act(conv(leaky_relu(x, pre_slope)) + bias) + residual
@@ -305,6 +311,17 @@ int evmi_conv1d_dgrad_cbt_bf16pk_fused(const float* dy_dev, const float* w_dev, 
                                        int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil,
                                        int groups, float pre_slope, const float* dy_mask_dev, float dy_mask_slope,
                                        const float* dx_mask_dev, float dx_mask_slope, const float* residual_dev, void* stream);
+/* Pointwise stride-1 layers (k = 1, no padding, one group) whose B * t is a multiple of 64 (evmi_conv1d_bf16pk_shares_packed(...) == 1:
+ * the rows of the tight packing end on a K step of the weight gradient) pack their operands ONCE: the
+ * forward call's packed input (the head of the workspace it was given) and the input-gradient call's packed dy (the head of ITS
+ * workspace) are in the layout the weight gradient reads (conv_pk_common.h), so a caller that keeps those two
+ * workspaces alive hands them over here and no operand is packed a second time (replaces the x / dy re-layout that
+ * torch.nn.functional.conv1d's weight gradient would do internally; reference call sites as evmi_conv1d_wgrad_cbt_bf16pk).
+ * Either packed pointer may be NULL: that operand is then packed from its fp32 tensor as usual. */
+int evmi_conv1d_wgrad_cbt_bf16pk_prepacked(const float* x_dev, const void* x_packed_dev, const float* dy_dev, const void* dy_packed_dev,
+                                           float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in, int c_out, int n_out,
+                                           int k, int stride, int pad, int dil, int groups, int accumulate, void* stream);
+int evmi_conv1d_bf16pk_shares_packed(int B, int t, int k, int stride, int pad, int dil, int groups);
 int evmi_conv1d_wgrad_cbt_bf16pk_fused(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems,
                                        int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad, int dil,
                                        int groups, int accumulate, float x_pre_slope, const float* dy_mask_dev,

@@ -573,3 +573,43 @@ def test_allreduce_bucket_c_abi_on_a_world_of_one(cuda_device):
         assert torch.equal(g.cpu(), want)
     finally:
         _lib.check(lib.evmi_comm_destroy(comm), "evmi_comm_destroy")
+
+
+@pytest.mark.parametrize("B,T,cin,cout", [(4, 336, 96, 160), (32, 814, 256, 1024), (3, 64, 1024, 256), (2, 32, 40, 48)])
+def test_pointwise_layers_pack_their_operands_once(cuda_device, bf16_operands, B, T, cin, cout):
+    """k = 1 / stride 1 layers on the packed bf16 kernels: the forward's packed input and the input gradient's packed dy are in the
+    layout the weight gradient reads (conv_pk_common.h: tight items, rows that end on one of its K steps), so `conv1d_fwd(..., keep=d)` + `conv1d_bwd(..., packed=d)`
+    pack every operand once.  Same kernels on the same packed bits: the results must be IDENTICAL to the path that packs again, and
+    match torch on the rounded operands."""
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(B * 131 + T)
+    x = torch.randn(B, cin, T, generator=g)
+    w = torch.randn(cout, cin, 1, generator=g) * 0.1
+    bias = torch.randn(cout, generator=g)
+    dy = torch.randn(B, cout, T, generator=g)
+    xd, wd, bd, dyd = cbt(x).to(cuda_device), w.to(cuda_device), bias.to(cuda_device), cbt(dy).to(cuda_device)
+    assert ops.shares_packed(B, T, 1, 1, 0, 1, 1) and not ops.shares_packed(B, T, 3, 1, 1, 1, 1) and not ops.shares_packed(B, T, 1, 2, 0, 1, 1)
+    assert not ops.shares_packed(5, 333, 1, 1, 0, 1, 1)  # rows that do not end on a K step of the weight gradient: packed twice, as before
+    keep = {}
+    y_keep = ops.conv1d_fwd(xd, wd, bd, 1, 0, 1, 1, keep=keep)
+    y_plain = ops.conv1d_fwd(xd, wd, bd, 1, 0, 1, 1)
+    assert "x_packed" in keep and torch.equal(y_keep, y_plain)
+    dw_a, dw_b = torch.zeros_like(wd), torch.zeros_like(wd)
+    db_a, db_b = torch.zeros_like(bd), torch.zeros_like(bd)
+    dx_a, _, _ = ops.conv1d_bwd(xd, wd, dyd, 1, 0, 1, 1, need_dx=True, dw_out=dw_a, db_out=db_a, accumulate=True, packed=keep)
+    assert "dy_packed" in keep
+    dx_b, _, _ = ops.conv1d_bwd(xd, wd, dyd, 1, 0, 1, 1, need_dx=True, dw_out=dw_b, db_out=db_b, accumulate=True)
+    ops.wgrad_join(cuda_device)
+    torch.cuda.synchronize()
+    assert torch.equal(dx_a, dx_b) and torch.equal(dw_a, dw_b) and torch.equal(db_a, db_b)
+    # without an input gradient only x arrives packed
+    dw_c = torch.zeros_like(wd)
+    ops.conv1d_bwd(xd, wd, dyd, 1, 0, 1, 1, need_dx=False, dw_out=dw_c, accumulate=True, packed={"x_packed": keep["x_packed"]})
+    torch.cuda.synchronize()
+    assert torch.equal(dw_c, dw_a)
+    # and against torch on the bf16-rounded operands
+    xr, wr, dyr = x.bfloat16().float(), w.bfloat16().float().requires_grad_(), dy.bfloat16().float()
+    F.conv1d(xr, wr, None).backward(dyr)
+    scale = float(wr.grad.abs().max())
+    assert float((dw_a.cpu() - wr.grad).abs().max()) <= 1e-4 * scale + 1e-5
