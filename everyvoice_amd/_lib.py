@@ -55,8 +55,51 @@ class LaunchRecord(C.Structure):
     ]
 
 
+class PkFlatJob(C.Structure):  # evmi_pkflat_job
+    _fields_ = [("mode", C.c_int), ("n_items", C.c_int), ("T", C.c_int), ("c_in", C.c_int), ("c_out", C.c_int), ("k", C.c_int),
+                ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int), ("groups", C.c_int), ("w", C.c_void_p), ("ws", C.c_void_p),
+                ("ws_elems", C.c_longlong)]
+
+
+class PkFlatPair(C.Structure):  # evmi_pkflat_pair
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("units", C.c_longlong), ("scale", C.c_float)]
+
+
+class PkFlatRows(C.Structure):  # evmi_pkflat_rows
+    _fields_ = [("dy", C.c_void_p), ("plane", C.c_longlong), ("units", C.c_longlong), ("C", C.c_int), ("db", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/evmi.h declares
 SYMBOLS = {
+    "evmi_conv_pkflat_ws_elems": (C.c_longlong, [C.c_int] * 10),
+    "evmi_conv_pkflat_plan": (C.c_int, [C.c_int] * 10),
+    "evmi_conv_pkflat_prepare": (C.c_int, [C.c_int, C.POINTER(PkFlatJob), C.c_void_p]),
+    "evmi_conv_pkflat_fwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
+                             + [C.c_int] * 13 + [C.c_float, C.c_void_p]),
+    "evmi_conv_pkflat_dgrad": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 12
+                               + [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "evmi_conv_pkflat_wgrad_ws_elems": (C.c_longlong, [C.c_int] * 8),
+    "evmi_conv_pkflat_wgrad": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 10
+                               + [C.c_void_p]),
+    "evmi_pkflat_zero": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
+    "evmi_disc_first_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 6
+                            + [C.c_float, C.c_void_p]),
+    "evmi_disc_first_wgrad_ws_elems": (C.c_longlong, [C.c_int] * 4),
+    "evmi_disc_first_wgrad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_longlong] + [C.c_int] * 5 + [C.c_void_p]),
+    "evmi_disc_first_dgrad": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]),
+    "evmi_disc_post_fwd_ws_elems": (C.c_longlong, [C.c_int] * 3),
+    "evmi_disc_post_fwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                     C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "evmi_disc_post_dgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 6
+                             + [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "evmi_disc_post_wgrad_ws_elems": (C.c_longlong, [C.c_int] * 4),
+    "evmi_disc_post_wgrad": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+                             + [C.c_int] * 4 + [C.c_void_p]),
+    "evmi_pkflat_absdiff_ws_elems": (C.c_longlong, [C.c_int]),
+    "evmi_pkflat_absdiff": (C.c_int, [C.c_int, C.POINTER(PkFlatPair), C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "evmi_pkflat_rowsum_ws_elems": (C.c_longlong, [C.c_int, C.POINTER(PkFlatRows)]),
+    "evmi_pkflat_rowsum": (C.c_int, [C.c_int, C.POINTER(PkFlatRows), C.c_void_p, C.c_longlong, C.c_void_p]),
     "evmi_abi_version": (C.c_int, []),
     "evmi_last_error": (C.c_char_p, []),
     "evmi_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),

@@ -62,6 +62,23 @@ struct ConvPkArgs {
   const float* out_mask;
   float out_mask_slope;
   const float* res;
+  // Flat packed output (the discriminator chains, csrc/disc_chain.hip): po.y != nullptr -- the tile is written as 16-byte units of
+  // 8 bf16 channels into a packed tensor [channel octet][unit] (rows `plane` units apart), the layout the next layer's loads read.
+  // Column n of phase ph is unit w = n * out_stride + ph_off[ph] of the COMPUTE geometry: items Tc units apart, of which the first
+  // `valid` are outputs; unit (b, u) = (w / Tc, w % Tc) is stored at b * Ts + u (another item pitch: the consumer's), the other
+  // columns are dropped (the gaps of a packed tensor stay zero: buffers are zeroed once, kernels write valid units only).
+  //   value = act(acc + bias);  (+ fm_scale * sign(xf - xr): the feature-matching gradient, xf = mask, xr = fm);  * lrelu'(mask)
+  // mask / fm: packed tensors of the output's shape (item pitch Tm, rows mplane apart).
+  struct FlatOut {
+    uint4* y;
+    long long plane;
+    int Tc, valid, Ts;
+    const uint4* mask;
+    const uint4* fm;
+    long long mplane;
+    int Tm;
+    float mask_slope, fm_scale;
+  } po;
 };
 
 template <int ACT>
@@ -356,6 +373,67 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
     }
     return;
   }
+  if (a.po.y) {  // ---- flat packed output: bf16 units [octet][unit], straight from the accumulators ----
+    pk_with_act(a.act, [&](auto act_c) {
+      constexpr int ACT = decltype(act_c)::value;
+      const int m_last = m_valid - 1;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = (int)n0 + (wn * NT + nt) * 32 + ln;
+        const int w = n * a.out_stride + out_off;  // (flat tensors stay far below 2^31 units)
+        const int bb = w / a.po.Tc;
+        const int u = w - bb * a.po.Tc;
+        const bool ok = col_b[nt] >= 0 && w >= 0 && u < a.po.valid;
+        const long long dst_u = ok ? (long long)bb * a.po.Ts + u : 0;
+        const long long msk_u = ok ? (long long)bb * a.po.Tm + u : 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int mb = (wm * MT + mt) * 32;
+          float v[16];
+          {
+            float bv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bv[r] = 0.f;
+            if (a.bias) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) bv[r] = a.bias[co0 + min(mb + (r & 3) + 8 * (r >> 2) + 4 * kh, m_last)];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = pk_act<ACT>(acc[mt][nt][r] + bv[r], a.act_param);
+          }
+          if (a.po.mask) {  // lane (n, kh) holds channels 8 i + 4 kh .. + 3 of octet i: the kh-th 8 bytes of that octet's unit
+            uint2 mk[4], fr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const long long row = (co0 + min(mb + 8 * i, m_last & ~7)) >> 3;
+              const uint2* src = reinterpret_cast<const uint2*>(a.po.mask + row * a.po.mplane + msk_u) + kh;
+              mk[i] = *src;
+              fr[i] = mk[i];
+              if (a.po.fm) fr[i] = *(reinterpret_cast<const uint2*>(a.po.fm + row * a.po.mplane + msk_u) + kh);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pk_flat_tail4(v + 4 * i, mk[i], fr[i], a.po.fm_scale, a.po.mask_slope);
+          }
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            u32x4 d;
+            d[0] = pack_bf16x2(v[8 * p + 0], v[8 * p + 1]);
+            d[1] = pack_bf16x2(v[8 * p + 2], v[8 * p + 3]);
+            d[2] = pack_bf16x2(v[8 * p + 4], v[8 * p + 5]);
+            d[3] = pack_bf16x2(v[8 * p + 6], v[8 * p + 7]);
+            const u32x4 o = swap_quads_bf16(d);  // lane (n, kh): the 8 channels of octet 2 p + kh
+            const int m_oct = mb + 8 * (2 * p + kh);
+            if (ok && m_oct < m_valid) {
+              uint4 st;
+              st.x = o[0]; st.y = o[1]; st.z = o[2]; st.w = o[3];
+              a.po.y[(long long)((co0 + m_oct) >> 3) * a.po.plane + dst_u] = st;
+            }
+          }
+        }
+      }
+    });
+    return;
+  }
   // Every global read of the tail (bias, mask, residual, previous value) is requested for a whole 16-register block before the
   // first is used, from clamped (always valid) addresses: a read under a per-element condition is compiled as a branch with a
   // full vmcnt(0) wait behind it -- one memory round trip per element, 64-256 in a row per lane.  Absent operands are replaced by
@@ -434,6 +512,39 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a) {
   const float add = a.res ? a.res[dst - a.y] : -0.f;
   const float old = a.accumulate ? *dst : -0.f;
   *dst = pk_tail(v, fac, add, old);
+}
+
+// The same for a flat packed output: one thread per (channel octet, column n); grid (ceil(n / 256), c_out / 8, phases)
+__global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int oc = blockIdx.y, ph = blockIdx.z;
+  const int n_out = a.ph_nout[ph];
+  if (n_out <= 0 || n >= n_out) return;  // (flat: B == 1)
+  const int w = n * a.out_stride + a.ph_off[ph];
+  const int bb = w / a.po.Tc, u = w - bb * a.po.Tc;
+  if (w < 0 || u >= a.po.valid) return;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    v[e] = ordered_sum_strided(a.part + (long long)ph * a.part_stride + (long long)(oc * 8 + e) * a.part_ld + n, (long long)a.phases * a.part_stride, a.ksplit);
+  if (a.bias) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += a.bias[oc * 8 + e];
+  }
+  pk_with_act(a.act, [&](auto act_c) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = pk_act<decltype(act_c)::value>(v[e], a.act_param);
+  });
+  if (a.po.mask) {
+    const long long mu = (long long)oc * a.po.mplane + (long long)bb * a.po.Tm + u;
+    const uint4 mk = a.po.mask[mu];
+    const uint4 fr = a.po.fm ? a.po.fm[mu] : mk;
+    pk_flat_tail4(v, make_uint2(mk.x, mk.y), make_uint2(fr.x, fr.y), a.po.fm_scale, a.po.mask_slope);
+    pk_flat_tail4(v + 4, make_uint2(mk.z, mk.w), make_uint2(fr.z, fr.w), a.po.fm_scale, a.po.mask_slope);
+  }
+  uint4 st;
+  st.x = pack_bf16x2(v[0], v[1]); st.y = pack_bf16x2(v[2], v[3]); st.z = pack_bf16x2(v[4], v[5]); st.w = pack_bf16x2(v[6], v[7]);
+  a.po.y[(long long)oc * a.po.plane + (long long)bb * a.po.Ts + u] = st;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -611,6 +722,37 @@ struct PkInputFusion {  // what the pack applies to the input on its way in (see
   float mask_slope = 1.f;
 };
 
+static int launch_pk_tile(ConvPkArgs& a, const PkPlan& pl, hipStream_t stream) {
+  static const int xcd_remap = 1;
+  a.xcd_remap = xcd_remap;
+  const size_t lds = pl.lds;
+  static thread_local size_t configured_dev[kMaxDevices][kNumPkTiles] = {};
+  size_t* configured = configured_dev[device_slot()];
+#define EVMI_PK_LAUNCH(BM, BN, WM, WN, IDX)                                                                              \
+  {                                                                                                                      \
+    if (lds > configured[IDX]) {                                                                                         \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pk_kernel<BM, BN, WM, WN>,                                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
+      configured[IDX] = lds;                                                                                             \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((conv_pk_kernel<BM, BN, WM, WN>), pl.grid, dim3(WM * WN * 64), lds, stream, a);                   \
+  }
+  switch (pl.ti) {
+    case 0: EVMI_PK_LAUNCH(128, 128, 2, 2, 0) break;
+    case 1: EVMI_PK_LAUNCH(64, 128, 1, 4, 1) break;
+    case 2: EVMI_PK_LAUNCH(64, 64, 2, 2, 2) break;
+    case 4: EVMI_PK_LAUNCH(64, 256, 1, 4, 4) break;
+    case 5: EVMI_PK_LAUNCH(32, 256, 1, 4, 5) break;
+    case 6: EVMI_PK_LAUNCH(128, 256, 2, 2, 6) break;
+    case 7: EVMI_PK_LAUNCH(128, 256, 2, 4, 7) break;
+    case 8: EVMI_PK_LAUNCH(128, 128, 2, 4, 8) break;
+    default: EVMI_PK_LAUNCH(32, 128, 1, 4, 3) break;
+  }
+#undef EVMI_PK_LAUNCH
+  EVMI_LAUNCH_CHECK("conv_cbt_bf16_pk");
+  return EVMI_OK;
+}
+
 // stage 0: pack + weight fragments + convolution; 1: the pack alone (the packed input is left at the head of ws); 2: the rest, on the
 // input stage 1 packed into the same ws (same shape, hence the same plan)
 static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float* w, float* ws, long long ws_elems, int wmode,
@@ -642,33 +784,7 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   a.tab = fa.tab;
   a.xp = xp;
   a.wf = wf;
-  static const int xcd_remap = 1;
-  a.xcd_remap = xcd_remap;
-  const size_t lds = pl.lds;
-  static thread_local size_t configured_dev[kMaxDevices][kNumPkTiles] = {};
-  size_t* configured = configured_dev[device_slot()];
-#define EVMI_PK_LAUNCH(BM, BN, WM, WN, IDX)                                                                              \
-  {                                                                                                                      \
-    if (lds > configured[IDX]) {                                                                                         \
-      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pk_kernel<BM, BN, WM, WN>,                                    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
-      configured[IDX] = lds;                                                                                             \
-    }                                                                                                                    \
-    hipLaunchKernelGGL((conv_pk_kernel<BM, BN, WM, WN>), pl.grid, dim3(WM * WN * 64), lds, stream, a);                   \
-  }
-  switch (pl.ti) {
-    case 0: EVMI_PK_LAUNCH(128, 128, 2, 2, 0) break;
-    case 1: EVMI_PK_LAUNCH(64, 128, 1, 4, 1) break;
-    case 2: EVMI_PK_LAUNCH(64, 64, 2, 2, 2) break;
-    case 4: EVMI_PK_LAUNCH(64, 256, 1, 4, 4) break;
-    case 5: EVMI_PK_LAUNCH(32, 256, 1, 4, 5) break;
-    case 6: EVMI_PK_LAUNCH(128, 256, 2, 2, 6) break;
-    case 7: EVMI_PK_LAUNCH(128, 256, 2, 4, 7) break;
-    case 8: EVMI_PK_LAUNCH(128, 128, 2, 4, 8) break;
-    default: EVMI_PK_LAUNCH(32, 128, 1, 4, 3) break;
-  }
-#undef EVMI_PK_LAUNCH
-  EVMI_LAUNCH_CHECK("conv_cbt_bf16_pk");
+  if (int rc = launch_pk_tile(a, pl, stream)) return rc;
   if (a.ksplit > 1) {
     hipLaunchKernelGGL(conv_pk_reduce_kernel, dim3((unsigned)((a.part_ld + 255) / 256), pl.c_out, a.phases), dim3(256), 0, stream, a);
     EVMI_LAUNCH_CHECK("conv_pk_reduce");
@@ -711,6 +827,87 @@ static const char* plan_dgrad_pk(ConvPkArgs& a, PkPlan& pl, int B, int c_in, int
     if (ph_pad[phi] < 0) return "negative phase padding";
   }
   return plan_pk(a, c_out / groups, t_out, groups, ph_pad, pl);
+}
+
+
+// ---- flat packed tensors in, flat packed tensors out (the discriminator chains) ---------------------------------------------------
+// The input is ONE long row: n_items items T units apart laid end to end, every item's gap zero; the kernel runs as a one-item
+// convolution over it (B = 1: no item arithmetic in its window loads, the unit index advances by `stride` per column everywhere).
+struct PkFlatShape {
+  int mode;  // 0: forward; 1: input gradient (polyphase)
+  int n_items, T, c_in, c_out, k, stride, pad, dil, groups;
+};
+constexpr int PKFLAT_MAX_JOBS = 16;
+struct WfragBatch {
+  WfragArgs job[PKFLAT_MAX_JOBS];
+  int start[PKFLAT_MAX_JOBS + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void wfrag_pk_batch_kernel(WfragBatch b) {
+  int j = 0;
+  while (j + 1 < b.n && (int)blockIdx.x >= b.start[j + 1]) ++j;
+  const WfragArgs& f = b.job[j];
+  const unsigned bid = blockIdx.x - b.start[j];
+  const unsigned q = bid % f.gx, r = bid / f.gx;
+  wfrag_pk_block(f, (int)q, (int)(r % f.gy), (int)(r / f.gy));
+}
+
+static const char* plan_flat(const PkFlatShape& sh, ConvPkArgs& a, PkPlan& pl) {
+  if (sh.n_items <= 0 || sh.T <= 0) return "bad flat shape";
+  if ((sh.c_in / std::max(1, sh.groups)) % 8 || (sh.c_out / std::max(1, sh.groups)) % 8) return "channels per group must be multiples of 8";
+  const long long len = (long long)sh.n_items * sh.T;
+  if (len * std::max(1, sh.stride) >= (1LL << 30)) return "flat row too long";
+  if (sh.mode == 0) {
+    if (sh.T % sh.stride) return "item pitch must be a multiple of the stride";
+    const int n_cols = (int)(len / sh.stride);
+    return plan_fwd_pk(a, pl, 1, sh.c_in, (int)len, sh.c_out, n_cols, n_cols, sh.k, sh.stride, sh.pad, sh.dil, sh.groups, 1, 0);
+  }
+  return plan_dgrad_pk(a, pl, 1, sh.c_in, (int)(len * sh.stride), sh.c_out, (int)len, sh.k, sh.stride, sh.pad, sh.dil, sh.groups);
+}
+
+static WfragArgs flat_wfrag_args(const PkFlatShape& sh, const ConvPkArgs& a, const PkPlan& pl, const float* w, float* ws) {
+  uint4* wf = reinterpret_cast<uint4*>(ws);
+  WfragArgs fa;
+  const int cg_in = sh.c_in / sh.groups, cg_out = sh.c_out / sh.groups;
+  fa.w = w; fa.wf = reinterpret_cast<unsigned*>(wf);
+  fa.rows_g = sh.mode == 0 ? cg_out : cg_in; fa.kch_g = sh.mode == 0 ? cg_in : cg_out;
+  fa.kt = a.k; fa.MB = a.mblocks; fa.octs = a.octs; fa.kblocks = a.kblocks; fa.mode = sh.mode; fa.k_full = sh.k; fa.stride = sh.stride;
+  fa.phase_stride_words = a.wf_phase_stride * 4;
+  fa.tab = reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases); fa.kb_step = a.kb_step; fa.xrow = a.xrow; fa.dil = a.dil;
+  fa.gx = a.kblocks; fa.gy = pl.groups * a.mblocks; fa.gz = a.phases;
+  return fa;
+}
+
+static int launch_flat(const PkFlatShape& sh, const void* in_dev, long long in_plane, const float* w, const float* bias, float* ws,
+                       long long ws_elems, int prepared, ConvPkArgs::FlatOut po, int act, float act_param, hipStream_t stream) {
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_flat(sh, a, pl)) return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_pkflat: ") + why);
+  const long long need = pl.wf_units * 4 + pl.part_elems;
+  if (!ws || ws_elems < need || (reinterpret_cast<uintptr_t>(ws) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat: workspace missing, too small or unaligned");
+  if (!in_dev || !w || !po.y) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat: null pointer");
+  WfragArgs fa = flat_wfrag_args(sh, a, pl, w, ws);
+  if (!prepared) {
+    PackArgs pa = {};
+    const long long n_prep = (long long)fa.gx * fa.gy * fa.gz;
+    hipLaunchKernelGGL(prep_pk_kernel, dim3((unsigned)n_prep), dim3(256), 0, stream, pa, fa);
+    EVMI_LAUNCH_CHECK("conv_pkflat (fragments)");
+  }
+  a.tab = fa.tab;
+  a.wf = reinterpret_cast<const uint4*>(ws);
+  a.part = reinterpret_cast<float*>(reinterpret_cast<uint4*>(ws) + pl.wf_units);
+  a.Tp = (int)in_plane;                                            // B == 1: the octet rows are `Tp` units apart
+  a.xp = reinterpret_cast<const uint4*>(in_dev) - pl.PL;           // the front guard of the tensor is the left padding
+  a.bias = bias; a.act = act; a.act_param = act_param; a.accumulate = 0;
+  a.po = po;
+  if (int rc = launch_pk_tile(a, pl, stream)) return rc;
+  if (a.ksplit > 1) {
+    int n_max = 0;
+    for (int p = 0; p < a.phases; ++p) n_max = std::max(n_max, a.ph_nout[p]);
+    hipLaunchKernelGGL(conv_pk_reduce_flat_kernel, dim3((unsigned)((n_max + 255) / 256), pl.c_out / 8, a.phases), dim3(256), 0, stream, a);
+    EVMI_LAUNCH_CHECK("conv_pk_reduce_flat");
+  }
+  return EVMI_OK;
 }
 
 }  // namespace evmi
@@ -832,6 +1029,81 @@ int evmi_conv1d_dgrad_cbt_bf16pk_fused(const float* dy_dev, const float* w_dev, 
   PkInputFusion in;
   in.pre_slope = pre_slope; in.mask = dy_mask_dev; in.mask_slope = dy_mask_slope;
   return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream, in);
+}
+
+
+/* ---- flat packed convolutions (include/evmi.h: "discriminator chains") ---- */
+static PkFlatShape flat_shape(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups) {
+  PkFlatShape sh;
+  sh.mode = mode; sh.n_items = n_items; sh.T = T; sh.c_in = c_in; sh.c_out = c_out; sh.k = k; sh.stride = stride; sh.pad = pad; sh.dil = dil;
+  sh.groups = groups;
+  return sh;
+}
+
+long long evmi_conv_pkflat_ws_elems(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups) {
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (groups <= 0 || stride <= 0 || plan_flat(flat_shape(mode, n_items, T, c_in, c_out, k, stride, pad, dil, groups), a, pl)) return 0;
+  return pl.wf_units * 4 + pl.part_elems;
+}
+
+int evmi_conv_pkflat_plan(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups) {
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (groups <= 0 || stride <= 0 || plan_flat(flat_shape(mode, n_items, T, c_in, c_out, k, stride, pad, dil, groups), a, pl)) return -1;
+  return pl.ti + 16 * (a.ksplit > 1 ? a.ksplit : 0);
+}
+
+int evmi_conv_pkflat_prepare(int n_jobs, const evmi_pkflat_job* jobs, void* stream) {
+  if (n_jobs < 0 || (n_jobs && !jobs)) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_prepare: bad job list");
+  for (int j0 = 0; j0 < n_jobs; j0 += PKFLAT_MAX_JOBS) {
+    WfragBatch b;
+    b.n = std::min(PKFLAT_MAX_JOBS, n_jobs - j0);
+    b.start[0] = 0;
+    for (int j = 0; j < b.n; ++j) {
+      const evmi_pkflat_job& jb = jobs[j0 + j];
+      const PkFlatShape sh = flat_shape(jb.mode, jb.n_items, jb.T, jb.c_in, jb.c_out, jb.k, jb.stride, jb.pad, jb.dil, jb.groups);
+      ConvPkArgs a = {};
+      PkPlan pl;
+      if (jb.groups <= 0 || jb.stride <= 0) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_prepare: bad shape");
+      if (const char* why = plan_flat(sh, a, pl)) return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_pkflat_prepare: ") + why);
+      if (!jb.w || !jb.ws || jb.ws_elems < pl.wf_units * 4 + pl.part_elems || (reinterpret_cast<uintptr_t>(jb.ws) & 15))
+        return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_prepare: weights / workspace missing, too small or unaligned");
+      b.job[j] = flat_wfrag_args(sh, a, pl, jb.w, jb.ws);
+      const long long nb = (long long)b.job[j].gx * b.job[j].gy * b.job[j].gz;
+      if (b.start[j] + nb > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv_pkflat_prepare: grid limits");
+      b.start[j + 1] = b.start[j] + (int)nb;
+    }
+    if (b.start[b.n] > 0) hipLaunchKernelGGL(wfrag_pk_batch_kernel, dim3((unsigned)b.start[b.n]), dim3(256), 0, (hipStream_t)stream, b);
+    EVMI_LAUNCH_CHECK("conv_pkflat_prepare");
+  }
+  return EVMI_OK;
+}
+
+int evmi_conv_pkflat_fwd(const void* x_pk, long long x_plane, const float* w_dev, const float* bias_dev, void* y_pk, long long y_plane,
+                         float* ws_dev, long long ws_elems, int prepared, int n_items, int T_x, int c_in, int c_out, int k, int stride, int pad,
+                         int dil, int groups, int valid, int T_store, int act, float act_param, void* stream) {
+  if (act < 0 || act > 4) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_fwd: activation");
+  if (groups <= 0 || stride <= 0 || T_x % stride) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_fwd: the item pitch must be a multiple of the stride");
+  ConvPkArgs::FlatOut po = {};
+  po.y = reinterpret_cast<uint4*>(y_pk); po.plane = y_plane; po.Tc = T_x / stride; po.valid = valid; po.Ts = T_store;
+  return launch_flat(flat_shape(0, n_items, T_x, c_in, c_out, k, stride, pad, dil, groups), x_pk, x_plane, w_dev, bias_dev, ws_dev, ws_elems,
+                     prepared, po, act, act_param, (hipStream_t)stream);
+}
+
+int evmi_conv_pkflat_dgrad(const void* dy_pk, long long dy_plane, const float* w_dev, void* dx_pk, long long dx_plane, float* ws_dev,
+                           long long ws_elems, int prepared, int n_items, int T_dy, int c_in, int c_out, int k, int stride, int pad, int dil,
+                           int groups, int valid, int T_store, const void* mask_pk, const void* fm_pk, long long mask_plane, int T_mask,
+                           float mask_slope, float fm_scale, void* stream) {
+  if (groups <= 0 || stride <= 0) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_dgrad: bad shape");
+  if (fm_pk && !mask_pk) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_dgrad: the feature-matching reference needs the mask tensor (the generated side's activation)");
+  if (k < stride) return fail(EVMI_ERR_UNSUPPORTED, "conv_pkflat_dgrad: kernel shorter than the stride");
+  ConvPkArgs::FlatOut po = {};
+  po.y = reinterpret_cast<uint4*>(dx_pk); po.plane = dx_plane; po.Tc = T_dy * stride; po.valid = valid; po.Ts = T_store;
+  po.mask = reinterpret_cast<const uint4*>(mask_pk); po.fm = reinterpret_cast<const uint4*>(fm_pk); po.mplane = mask_plane; po.Tm = T_mask;
+  po.mask_slope = mask_slope; po.fm_scale = fm_scale;
+  return launch_flat(flat_shape(1, n_items, T_dy, c_in, c_out, k, stride, pad, dil, groups), dy_pk, dy_plane, w_dev, nullptr, ws_dev, ws_elems,
+                     prepared, po, 0, 0.f, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -20,6 +20,21 @@ __device__ __forceinline__ unsigned pk_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, v);
 }
 
+// Tail of a flat packed output for four channels of one unit: v = (v + fm_scale * sign(xf - xr)) * lrelu'(xf), xf / xr the four
+// bf16 values of the mask tensor (the layer's own activated output) and of the feature-matching reference (xr = xf: no term).
+__device__ __forceinline__ void pk_flat_tail4(float* v, uint2 mk, uint2 fr, float fm_scale, float mask_slope) {
+#pragma clang fp contract(off)
+  const float xf[4] = {bf16_lo(mk.x), bf16_hi(mk.x), bf16_lo(mk.y), bf16_hi(mk.y)};
+  const float xr[4] = {bf16_lo(fr.x), bf16_hi(fr.x), bf16_lo(fr.y), bf16_hi(fr.y)};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float dlt = xf[e] - xr[e];
+    const float sg = dlt > 0.f ? fm_scale : (dlt < 0.f ? -fm_scale : 0.f);
+    const float t = v[e] + sg;
+    v[e] = t * (xf[e] > 0.f ? 1.f : mask_slope);
+  }
+}
+
 // x [groups*cin_g][B][t_in] fp32 -> xp [groups][octs][B][Tp] units; unit (g, o, b, u) = channels g*cin_g + 8o..8o+7 at t = u - PL.
 // Logical grid (ceil(Tp / 256), B, groups*octs): one thread per unit, consecutive threads consecutive u (coalesced reads of 8
 // channel rows, 16-byte writes).  The workgroups of the last row also zero `slack_units` units behind the tensor (read by the

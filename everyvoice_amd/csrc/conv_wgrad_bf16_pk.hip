@@ -49,6 +49,11 @@ struct WgradPkArgs {
   const __bf16* x_tm;
   int cy_row, cx_row;      // elements per row (total channels) of dy / x
   long long x_row_off;
+  // flat packed operands (the discriminator chains): the x unit of (position f, tap j) is f * s + j * d + x_unit_off
+  long long x_unit_off;
+  // block-diagonal mode for narrow groups: the workgroup's "group" is a super-group of several convolution groups (cout_g / cin_g
+  // above are the super-group's widths); only the blocks (co / bd_cout == ci / bd_cin) are stored, as dw[co][ci % bd_cin][j]
+  int bd_cout, bd_cin;
 };
 
 constexpr int WG_KS = 64;  // positions per K step (4 MFMA K blocks)
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
       ++issued;
     }
     u -= 8;
-    const long long x0 = f0 * s + (long long)j_lo * d;
+    const long long x0 = f0 * s + (long long)j_lo * d + (TM ? 0 : a.x_unit_off);
     for (; u < 8 * xpieces; u += 4) {
       const int r = u / xpieces, pi = u - r * xpieces;
       const int o = min(ox0 + r, a.octs_x - 1);
@@ -165,19 +170,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   }
 
   // ---- store: lane column = input channel, registers = output channels ----
-  const int ci = tile_ci * 64 + wn * 32 + (lane & 31);
-  if (ci >= a.cin_g) return;
+  const int ci_sg = tile_ci * 64 + wn * 32 + (lane & 31);
+  if (ci_sg >= a.cin_g) return;
+  const int cig = a.bd_cin ? ci_sg / a.bd_cin : 0;           // convolution group inside the super-group (block-diagonal mode)
+  const int ci = a.bd_cin ? ci_sg - cig * a.bd_cin : ci_sg;  // input channel inside its convolution group
+  const int cin_st = a.bd_cin ? a.bd_cin : a.cin_g;
   if (a.partial) {  // partial tiles [split][tap][c_out][cin_g]: consecutive lanes consecutive addresses
     float* outp = a.out + (long long)split * a.split_stride;
-    const long long tap_stride = (long long)a.c_out * a.cin_g;
+    const long long tap_stride = (long long)a.c_out * cin_st;
 #pragma unroll
     for (int j = 0; j < TGMAX; ++j) {
       if (j >= tgc) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m >= a.cout_g) continue;
-        outp[(j_lo + j) * tap_stride + (long long)(g * a.cout_g + m) * a.cin_g + ci] = acc[j][r];
+        if (m >= a.cout_g || (a.bd_cout && m / a.bd_cout != cig)) continue;
+        outp[(j_lo + j) * tap_stride + (long long)(g * a.cout_g + m) * cin_st + ci] = acc[j][r];
       }
     }
     return;
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = min(tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, a.cout_g - 1);
-      off[r] = ((long long)(g * a.cout_g + m) * a.cin_g + ci) * k + j_lo + j;
+      off[r] = ((long long)(g * a.cout_g + m) * cin_st + ci) * k + j_lo + j;
       prev[r] = -0.f;
     }
     if (a.accumulate) {
@@ -200,8 +208,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
       for (int r = 0; r < 16; ++r) prev[r] = a.out[off[r]];
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < a.cout_g) a.out[off[r]] = prev[r] + acc[j][r];
+    for (int r = 0; r < 16; ++r) {
+      const int m = tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      if (m < a.cout_g && !(a.bd_cout && m / a.bd_cout != cig)) a.out[off[r]] = prev[r] + acc[j][r];
+    }
   }
 }
 
@@ -315,6 +325,28 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
 
   if (pl.dy_units >= (1LL << 31) || pl.x_units >= (1LL << 31)) return "packed operands too large";
   return nullptr;
+}
+
+// the packed-operand instantiations (one attribute cache for every caller: the attribute belongs to the kernel, not to the call site)
+static int launch_wgrad_packed(const WgradPkArgs& a, const WgradPkPlan& pl, hipStream_t s) {
+  static thread_local size_t configured_dev[kMaxDevices][2] = {};
+  size_t* configured = configured_dev[device_slot()];
+  const size_t lds = pl.lds;
+  if (pl.tgmax == 4) {
+    if (lds > configured[0]) {
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured[0] = lds;
+    }
+    hipLaunchKernelGGL((wgrad_pk_kernel<4>), pl.grid, dim3(256), lds, s, a);
+  } else {
+    if (lds > configured[1]) {
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      configured[1] = lds;
+    }
+    hipLaunchKernelGGL((wgrad_pk_kernel<8>), pl.grid, dim3(256), lds, s, a);
+  }
+  EVMI_LAUNCH_CHECK("wgrad_pk_kernel");
+  return EVMI_OK;
 }
 
 }  // namespace evmi
@@ -465,6 +497,97 @@ int evmi_conv1d_wgrad_tm_bf16(const void* x_tm, const void* dy_tm, float* dw_dev
   return EVMI_OK;
 }
 
+// ---- flat packed operands (the discriminator chains): dy one long row of n_items * T_dy units per channel octet, x one of
+// n_items * T_dy * stride units; unit f of dy pairs with unit f * stride + j * dil - pad of x.  No pack, no per-item padding rule:
+// the zero gaps of dy cancel whatever x holds beside them.  Groups narrower than 32 channels run block-diagonally. ------------
+static const char* plan_wgrad_flat(WgradPkArgs& a, WgradPkPlan& pl, int& sgroups, long long n_pos, int c_in, int c_out, int k, int stride, int dil,
+                                   int groups) {
+  if (groups <= 0 || c_in <= 0 || c_out <= 0 || c_in % groups || c_out % groups || k <= 0 || stride <= 0 || dil <= 0 || n_pos <= 0) return "bad shape";
+  int cin_g = c_in / groups, cout_g = c_out / groups;
+  if (cin_g % 8 || cout_g % 8) return "channels per group must be multiples of 8";
+  if (stride > 8) return "stride above 8";
+  a.bd_cout = a.bd_cin = 0;
+  sgroups = groups;
+  if (groups > 1 && (cin_g < 32 || cout_g < 32)) {  // super-groups of m convolution groups: 64 output channels where the group count allows
+    int m = std::max(1, 64 / cout_g);
+    while (m > 1 && groups % m) m >>= 1;
+    if (m > 1) {
+      a.bd_cout = cout_g; a.bd_cin = cin_g;
+      cin_g *= m; cout_g *= m; sgroups = groups / m;
+    }
+  }
+  a.cout_g = cout_g; a.cin_g = cin_g; a.k = k; a.stride = stride; a.dil = dil;
+  pl.octs_y = a.octs_y = cout_g / 8;
+  pl.octs_x = a.octs_x = cin_g / 8;
+  a.ksteps = (int)((n_pos + WG_KS - 1) / WG_KS);
+  const int tgcap = 8;
+  a.ntg = (k + tgcap - 1) / tgcap;
+  a.tg = (k + a.ntg - 1) / a.ntg;
+  pl.tgmax = a.tg <= 4 ? 4 : 8;
+  a.tiles_ci = (cin_g + 63) / 64;
+  a.tiles_co = (cout_g + 63) / 64;
+  const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;
+  if (xwin > 64 * 12) return "input window too long";
+  a.xpieces = (int)((xwin + 63) / 64);
+  a.xrow = a.xpieces * 64 + 4;
+  const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
+  a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
+  pl.lds = a.nst * stage_bytes;
+  if (pl.lds > 160 * 1024) return "LDS budget";
+  const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co * sgroups;
+  const long long want = 512;
+  int splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / 8));
+  a.steps_per_split = (a.ksteps + splits - 1) / splits;
+  splits = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;
+  pl.splits = splits;
+  if ((long long)a.tiles_ci * a.ntg > 0x7fffffffLL || (long long)sgroups * a.tiles_co > 65535 || splits > 65535) return "grid limits";
+  pl.grid = dim3(a.tiles_ci * a.ntg, sgroups * a.tiles_co, splits);
+  a.split_stride = (long long)c_out * (c_in / groups) * k;
+  pl.part_elems = splits > 1 ? a.split_stride * splits : 0;
+  return nullptr;
+}
+
+long long evmi_conv_pkflat_wgrad_ws_elems(int n_items, int T_dy, int c_in, int c_out, int k, int stride, int dil, int groups) {
+  WgradPkArgs a = {};
+  WgradPkPlan pl;
+  int sg;
+  if (plan_wgrad_flat(a, pl, sg, (long long)n_items * T_dy, c_in, c_out, k, stride, dil, groups)) return -1;
+  return std::max<long long>(pl.part_elems, 4);
+}
+
+int evmi_conv_pkflat_wgrad(const void* x_pk, long long x_plane, const void* dy_pk, long long dy_plane, float* dw_dev, float* ws_dev,
+                           long long ws_elems, int n_items, int T_dy, int c_in, int c_out, int k, int stride, int pad, int dil, int groups,
+                           int accumulate, void* stream) {
+  if (!x_pk || !dy_pk || !dw_dev) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_wgrad: null pointer");
+  WgradPkArgs a = {};
+  WgradPkPlan pl;
+  int sgroups;
+  if (const char* why = plan_wgrad_flat(a, pl, sgroups, (long long)n_items * T_dy, c_in, c_out, k, stride, dil, groups))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_pkflat_wgrad: ") + why);
+  if (pl.part_elems > 0 && (!ws_dev || ws_elems < pl.part_elems)) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_wgrad: workspace missing or too small");
+  hipStream_t s = (hipStream_t)stream;
+  a.dyp = reinterpret_cast<const uint4*>(dy_pk);
+  a.xp = reinterpret_cast<const uint4*>(x_pk);
+  a.plane_y = dy_plane; a.plane_x = x_plane;
+  a.x_unit_off = -(long long)pad;
+  a.out = pl.splits > 1 ? ws_dev : dw_dev;
+  a.accumulate = pl.splits > 1 ? 0 : accumulate;
+  a.partial = pl.splits > 1;
+  a.c_out = c_out;
+  if (int rc = launch_wgrad_packed(a, pl, s)) return rc;
+  if (pl.splits > 1) {
+    const long long rows_ci = (long long)c_out * (c_in / groups);
+    if (rows_ci >= 131072)
+      hipLaunchKernelGGL(wgrad_pk_reduce_kernel, dim3((unsigned)((rows_ci + 255) / 256)), dim3(256), (size_t)k * 256 * sizeof(float), s, ws_dev,
+                         dw_dev, rows_ci, k, pl.splits, a.split_stride, accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_pk_reduce_planes_kernel, dim3((unsigned)((rows_ci + 255) / 256), k), dim3(256), 0, s, ws_dev, dw_dev, rows_ci, k,
+                         pl.splits, a.split_stride, accumulate);
+    EVMI_LAUNCH_CHECK("wgrad_pk_reduce (flat)");
+  }
+  return EVMI_OK;
+}
+
 static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in,
                          int c_out, int n_out, int k, int stride, int pad, int dil, int groups, int accumulate, float x_pre_slope,
                          const float* dy_mask_dev, float dy_mask_slope, void* stream, const void* x_packed_dev,
@@ -508,23 +631,7 @@ static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev,
   a.accumulate = pl.splits > 1 ? 0 : accumulate;
   a.partial = pl.splits > 1;
   a.c_out = c_out;
-  static thread_local size_t configured_dev[kMaxDevices][2] = {};
-  size_t* configured = configured_dev[device_slot()];
-  const size_t lds = pl.lds;
-  if (pl.tgmax == 4) {
-    if (lds > configured[0]) {
-      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured[0] = lds;
-    }
-    hipLaunchKernelGGL((wgrad_pk_kernel<4>), pl.grid, dim3(256), lds, s, a);
-  } else {
-    if (lds > configured[1]) {
-      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      configured[1] = lds;
-    }
-    hipLaunchKernelGGL((wgrad_pk_kernel<8>), pl.grid, dim3(256), lds, s, a);
-  }
-  EVMI_LAUNCH_CHECK("wgrad_pk_kernel");
+  if (int rc = launch_wgrad_packed(a, pl, s)) return rc;
   if (pl.splits > 1) {
     const long long rows_ci = (long long)c_out * cin_g;
     if (rows_ci >= 131072)  // enough (co, ci) pairs to fill the chip with one workgroup per 256 of them: coalesced both ways

@@ -1,0 +1,281 @@
+"""One discriminator of the GAN step as a chain on flat packed bf16 tensors (precision="bf16").
+
+Upstream's DiscriminatorP / DiscriminatorS (jik876 hifi-gan models.py; the reference reaches them through
+``hfgl.model.HiFiGAN.training_step``) are ``conv -> leaky_relu`` chains whose every activation is read three
+times (next convolution, feature matching, its own backward).  Op by op on the channel-major fp32 path each of those reads went
+through a re-layout pass (``prep_pk`` / ``pack2`` / ``pad_x`` / ``pad_dy``: a third of the step's HBM bytes and ~500 launches per
+step).  Here an activation exists ONCE, as the flat packed bf16 tensor (include/evmi.h, "Discriminator chains") the
+matrix-core kernels load directly:
+
+    A_1 = first(audio)                          evmi_disc_first_fwd      (one input channel: direct kernel, reads the waveform itself)
+    A_{i+1} = lrelu(conv_i(A_i))  i = 1..L-1    evmi_conv_pkflat_fwd     (epilogue writes the consumer's packed layout)
+    logits = post(A_L)                          evmi_disc_post_fwd
+    G_L = (post^T dlogits [+ fm]) * lrelu'(A_L) evmi_disc_post_dgrad
+    G_i = (conv_i^T G_{i+1} [+ fm]) * lrelu'(A_i)   evmi_conv_pkflat_dgrad   (mask = A_i itself; fm = the real waveform's A_i)
+    dw_i += wgrad(A_i, G_{i+1})                 evmi_conv_pkflat_wgrad   (reads the same two tensors)
+    db_i += rowsum(G_{i+1})                     evmi_pkflat_rowsum       (all layers of the chain in one launch pair)
+
+Geometry: the items of a tensor lie end to end with a zero gap behind each -- the next convolution's padding -- so every kernel
+runs over ONE long row.  A convolution with stride s computes output items ``Tc`` units apart from input items ``s * Tc`` apart and
+stores them at the pitch its consumer wants; the gradient tensors take the transposed pitches.  ``_geometry`` derives all of it.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from .. import _lib
+from . import autograd as ag
+from . import ops
+
+FRONT, TAIL = 64, 2048  # zero guard units in front of / behind every row
+
+
+class PF:
+    """A flat packed tensor: C channels, n_items items T units apart, `valid` data units per item (zeroed once; kernels write data only)."""
+
+    __slots__ = ("C", "n_items", "T", "valid", "plane", "buf", "ptr")
+
+    def __init__(self, C_, n_items, T, valid, device):
+        self.C, self.n_items, self.T, self.valid = C_, n_items, T, valid
+        self.plane = (FRONT + n_items * T + TAIL + 63) // 64 * 64
+        self.buf = torch.zeros((C_ // 8) * self.plane * 4, device=device, dtype=torch.float32)  # 16-byte units as 4 floats
+        self.ptr = self.buf.data_ptr() + FRONT * 16
+
+    @property
+    def units(self) -> int:
+        return (self.C // 8) * self.plane
+
+
+def _conv_len(t, k, s, p, d=1):
+    return (t + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+class _Cfg:
+    """Everything static about one (chain, item count, length, role): tensor geometry, buffers, per-call workspaces."""
+
+    def __init__(self, chain, n_audio, t_audio, with_grad, device):
+        lib = _lib.load()
+        self.n_audio, self.t_audio = n_audio, t_audio
+        p = chain.period
+        self.n_items = n_audio * p
+        self.H = (t_audio + p - 1) // p
+        convs = chain.convs
+        L = len(convs)
+        self.lens = [self.H]
+        for c in convs:
+            self.lens.append(_conv_len(self.lens[-1], c.k, c.stride, c.pad, c.dil))
+        # compute pitch of layer i (1..L-1): items of its output Tc apart, of its input s * Tc apart
+        self.Tc = [0] * L
+        for i in range(1, L):
+            c = convs[i]
+            right = (self.lens[i + 1] - 1) * c.stride + (c.k - 1) * c.dil - c.pad - (self.lens[i] - 1)
+            need_gap = max(c.pad, right, 0)
+            gdy = -(-max(0, (c.k - 1) * c.dil - c.pad) // c.stride)
+            self.Tc[i] = max(self.lens[i + 1] + gdy, -(-(self.lens[i] + need_gap) // c.stride))
+        post = chain.conv_post
+        # activation A_i (i = 1..L): pitch dictated by its consumer
+        T_A = [0] * (L + 1)
+        for i in range(1, L):
+            T_A[i] = convs[i].stride * self.Tc[i]
+        T_A[L] = max(self.Tc[L - 1] if L > 1 else 0, self.lens[L] + max(post.pad, post.k - 1 - post.pad))
+        self.A = [None] + [PF(convs[i - 1].cout, self.n_items, T_A[i], self.lens[i], device) for i in range(1, L + 1)]
+        # gradient G_i (shape of A_i): pitch = compute pitch of the layer that produced A_i (its dgrad / wgrad read it flat)
+        self.G = [None] * (L + 1)
+        if with_grad:
+            for i in range(1, L + 1):
+                T_G = self.Tc[i - 1] if i >= 2 else T_A[1]
+                self.G[i] = PF(convs[i - 1].cout, self.n_items, T_G, self.lens[i], device)
+        # per-call workspaces (weight fragments + split partials): own buffers, so that fragments prepared at the start of a phase
+        # survive until their call
+        self.ws_f, self.ws_d = [None] * L, [None] * L
+        for i in range(1, L):
+            c = convs[i]
+            n = lib.evmi_conv_pkflat_ws_elems(0, self.n_items, T_A[i], c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups)
+            if n <= 0:
+                raise RuntimeError(f"disc chain: forward layer {c.name} not taken by the flat packed kernel")
+            self.ws_f[i] = torch.empty(n, device=device, dtype=torch.float32)
+            if with_grad:
+                n = lib.evmi_conv_pkflat_ws_elems(1, self.n_items, self.Tc[i], c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups)
+                if n <= 0:
+                    raise RuntimeError(f"disc chain: input gradient of layer {c.name} not taken by the flat packed kernel")
+                self.ws_d[i] = torch.empty(n, device=device, dtype=torch.float32)
+        self.logits_n = _conv_len(self.lens[L], post.k, post.stride, post.pad, post.dil)
+        assert post.stride == 1 and self.logits_n == self.lens[L], "the logit layer is a 'same' convolution"
+        # feature-matching scales: 2 / numel of every feature map (upstream feature_loss: mean |.| per map, times 2)
+        self.fm_scale = [0.0] + [2.0 / (convs[i - 1].cout * self.n_items * self.lens[i]) for i in range(1, L + 1)]
+
+
+class DiscChain:
+    """Host side of one discriminator's chain.  ``supported(d)``: all shapes are taken by the flat packed kernels."""
+
+    def __init__(self, disc, period: int, device):
+        self.disc, self.period, self.device = disc, period, torch.device(device)
+        self.convs, self.conv_post = disc.convs, disc.conv_post
+        self._cfgs: dict = {}
+        c0 = self.convs[0]
+        ok = (c0.cin == 1 and c0.groups == 1 and c0.k <= 16 and c0.cout % 8 == 0 and c0.dil == 1 and self.conv_post.cout == 1
+              and self.conv_post.k <= 8 and self.conv_post.groups == 1 and self.conv_post.stride == 1 and self.conv_post.dil == 1)
+        for c in self.convs[1:]:
+            ok = ok and (c.cin // c.groups) % 8 == 0 and (c.cout // c.groups) % 8 == 0 and c.k >= c.stride and not c.transposed
+        self.ok = bool(ok)
+
+    def cfg(self, n_audio, t_audio, role, with_grad) -> _Cfg:
+        key = (n_audio, t_audio, role, with_grad)
+        c = self._cfgs.get(key)
+        if c is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("disc chain: buffers would have to be created during graph capture: warm the step up eagerly first")
+            c = self._cfgs[key] = _Cfg(self, n_audio, t_audio, with_grad, self.device)
+        return c
+
+    # ---- forward ------------------------------------------------------------------------------------------------------------------
+    def forward(self, tape: ag.Tape, audio: ag.Var, training=True, role="pair"):
+        """audio.data [1, n_audio, t_audio] fp32 -> (logits Var [1, n_items, n], ChainFmaps)."""
+        lib = _lib.load()
+        x = audio.data
+        _, n_audio, t_audio = x.shape
+        frozen = all(layer.frozen for layer in self.convs)
+        with_grad = audio.needs_grad or not frozen
+        cfg = self.cfg(n_audio, t_audio, role, with_grad)
+        convs, post, L = self.convs, self.conv_post, len(self.convs)
+        st = ops._s(x)
+        eff = [c.effective(training) + (c.call_db_sink(),) for c in convs]  # (w, dw sink, db sink) per call, in layer order
+        w_post, dw_post = post.effective(training)
+        db_post = post.call_db_sink()
+        # weight fragments of every matrix-core call of this pass (and of its backward) in one launch
+        jobs = (_lib.PkFlatJob * (2 * (L - 1)))()
+        nj = 0
+        for i in range(1, L):
+            c = convs[i]
+            for mode, T, ws in ((0, cfg.A[i].T, cfg.ws_f[i]), (1, cfg.Tc[i], cfg.ws_d[i])):
+                if mode == 1 and not with_grad:
+                    continue
+                j = jobs[nj]
+                j.mode, j.n_items, j.T, j.c_in, j.c_out, j.k, j.stride, j.pad, j.dil, j.groups = mode, cfg.n_items, T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups
+                j.w, j.ws, j.ws_elems = eff[i][0].data_ptr(), ws.data_ptr(), ws.numel()
+                nj += 1
+        _lib.check(lib.evmi_conv_pkflat_prepare(nj, jobs, st), "evmi_conv_pkflat_prepare")
+        c0 = convs[0]
+        A = cfg.A
+        _lib.check(lib.evmi_disc_first_fwd(x.data_ptr(), n_audio, t_audio, self.period, eff[0][0].data_ptr(), c0.bias_data().data_ptr(), A[1].ptr, A[1].plane,
+                                           A[1].T, cfg.lens[1], c0.cout, c0.k, c0.stride, c0.pad, 0.1, st), "evmi_disc_first_fwd")
+        ops._count_conv(cfg.n_items, cfg.lens[1], c0.cout, 1, c0.k)
+        for i in range(1, L):
+            c = convs[i]
+            _lib.check(lib.evmi_conv_pkflat_fwd(A[i].ptr, A[i].plane, eff[i][0].data_ptr(), c.bias_data().data_ptr(), A[i + 1].ptr, A[i + 1].plane,
+                                                cfg.ws_f[i].data_ptr(), cfg.ws_f[i].numel(), 1, cfg.n_items, A[i].T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil,
+                                                c.groups, cfg.lens[i + 1], A[i + 1].T, ops.ACT_LRELU, 0.1, st), "evmi_conv_pkflat_fwd")
+            ops._count_conv(cfg.n_items, cfg.lens[i + 1], c.cout, c.cin // c.groups, c.k)
+        n = cfg.logits_n
+        logits = torch.empty(1, cfg.n_items, n, device=x.device, dtype=torch.float32)
+        ws = ops.WS.get("dc_post", lib.evmi_disc_post_fwd_ws_elems(cfg.n_items, n, post.cin), x.device)
+        _lib.check(lib.evmi_disc_post_fwd(A[L].ptr, A[L].plane, A[L].T, cfg.n_items, n, w_post.data_ptr(), post.bias_data().data_ptr(), logits.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), post.cin, post.k, post.pad, st), "evmi_disc_post_fwd")
+        ops._count_conv(cfg.n_items, n, 1, post.cin, post.k)
+        ag._ACTIVATION_ELEMS[0] += sum(a.C * cfg.n_items * a.valid for a in A[1:]) // 2  # (bf16: half an fp32 element each)
+        out = ag.Var(logits)
+        fm = ChainFmaps(self, cfg, out)
+
+        def bwd():
+            if out.grad is None:
+                return
+            self._backward(cfg, fm, audio, out.grad, eff, (w_post, dw_post, db_post), frozen)
+
+        tape.record(bwd)
+        return out, fm
+
+    # ---- backward -----------------------------------------------------------------------------------------------------------------
+    def _backward(self, cfg: _Cfg, fm: "ChainFmaps", audio: ag.Var, dlogits, eff, post_eff, frozen):
+        lib = _lib.load()
+        convs, post, L = self.convs, self.conv_post, len(self.convs)
+        A, G = cfg.A, cfg.G
+        dev = dlogits.device
+        st = ops._s(dlogits)
+        ref = fm.ref  # the real waveform's activations (generator step): feature-matching gradients ride in the epilogues
+        w_post, dw_post, db_post = post_eff
+        n = cfg.logits_n
+
+        def fm_args(i):
+            return (A[i].ptr, ref.A[i].ptr if ref is not None else 0, A[i].plane, A[i].T, 0.1, cfg.fm_scale[i] if ref is not None else 0.0)
+
+        if ref is not None:
+            assert all(ref.A[i].T == A[i].T and ref.A[i].plane == A[i].plane for i in range(1, L + 1)), "feature-matching pair: different geometry"
+        _lib.check(lib.evmi_disc_post_dgrad(dlogits.data_ptr(), w_post.data_ptr(), G[L].ptr, G[L].plane, G[L].T, cfg.n_items, n, post.cin, post.k, post.pad,
+                                            *fm_args(L), st), "evmi_disc_post_dgrad")
+        ops._count_conv(cfg.n_items, n, 1, post.cin, post.k)
+        if not frozen:
+            ws = ops.WS.get("dc_postw", lib.evmi_disc_post_wgrad_ws_elems(cfg.n_items, n, post.cin, post.k), dev)
+            _lib.check(lib.evmi_disc_post_wgrad(A[L].ptr, A[L].plane, A[L].T, cfg.n_items, n, dlogits.data_ptr(), dw_post.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                post.cin, post.k, post.pad, 1, st), "evmi_disc_post_wgrad")
+            ops.scalar_reduce(2, dlogits, None, db_post, accumulate=True)
+            ops._count_conv(cfg.n_items, n, 1, post.cin, post.k)
+        for i in range(L - 1, 0, -1):
+            c = convs[i]
+            need_dx = i > 1 or audio.needs_grad or not frozen  # G_1 feeds the first layer's weight gradient / the waveform's gradient
+            if need_dx:
+                _lib.check(lib.evmi_conv_pkflat_dgrad(G[i + 1].ptr, G[i + 1].plane, eff[i][0].data_ptr(), G[i].ptr, G[i].plane, cfg.ws_d[i].data_ptr(),
+                                                      cfg.ws_d[i].numel(), 1, cfg.n_items, G[i + 1].T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups,
+                                                      cfg.lens[i], G[i].T, *fm_args(i), st), "evmi_conv_pkflat_dgrad")
+                ops._count_conv(cfg.n_items, cfg.lens[i + 1], c.cout, c.cin // c.groups, c.k)
+            if not frozen:
+                nws = lib.evmi_conv_pkflat_wgrad_ws_elems(cfg.n_items, G[i + 1].T, c.cin, c.cout, c.k, c.stride, c.dil, c.groups)
+                if nws < 0:
+                    raise RuntimeError(f"disc chain: weight gradient of {c.name} not taken by the flat packed kernel")
+                ws = ops.WS.get("dc_wg", nws, dev)
+                _lib.check(lib.evmi_conv_pkflat_wgrad(A[i].ptr, A[i].plane, G[i + 1].ptr, G[i + 1].plane, eff[i][1].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                      cfg.n_items, G[i + 1].T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups, 1, st), "evmi_conv_pkflat_wgrad")
+                ops._count_conv(cfg.n_items, cfg.lens[i + 1], c.cout, c.cin // c.groups, c.k)
+        c0 = convs[0]
+        x = audio.data
+        if not frozen:
+            nws = lib.evmi_disc_first_wgrad_ws_elems(cfg.n_items, cfg.lens[1], c0.cout, c0.k)
+            ws = ops.WS.get("dc_w0", nws, dev)
+            _lib.check(lib.evmi_disc_first_wgrad(x.data_ptr(), cfg.n_audio, cfg.t_audio, self.period, G[1].ptr, G[1].plane, G[1].T, cfg.lens[1],
+                                                 eff[0][1].data_ptr(), eff[0][2].data_ptr(), ws.data_ptr(), ws.numel(), c0.cout, c0.k, c0.stride, c0.pad, 1, st),
+                       "evmi_disc_first_wgrad")
+            ops._count_conv(cfg.n_items, cfg.lens[1], c0.cout, 1, c0.k)
+            # bias gradients of the matrix-core layers: row sums of G_2 .. G_L, one launch pair
+            rows = (_lib.PkFlatRows * (L - 1))()
+            for i in range(1, L):
+                r = rows[i - 1]
+                r.dy, r.plane, r.units, r.C, r.db = G[i + 1].ptr, G[i + 1].plane, cfg.n_items * G[i + 1].T, convs[i].cout, eff[i][2].data_ptr()
+            ws = ops.WS.get("dc_rows", lib.evmi_pkflat_rowsum_ws_elems(L - 1, rows), dev)
+            _lib.check(lib.evmi_pkflat_rowsum(L - 1, rows, ws.data_ptr(), ws.numel(), st), "evmi_pkflat_rowsum")
+        if audio.needs_grad:
+            dxv = torch.empty(1, cfg.n_items, cfg.H, device=dev, dtype=torch.float32)
+            _lib.check(lib.evmi_disc_first_dgrad(G[1].ptr, G[1].plane, G[1].T, cfg.lens[1], eff[0][0].data_ptr(), dxv.data_ptr(), cfg.n_items, cfg.H, c0.cout,
+                                                 c0.k, c0.stride, c0.pad, st), "evmi_disc_first_dgrad")
+            ops._count_conv(cfg.n_items, cfg.lens[1], c0.cout, 1, c0.k)
+            audio.accumulate(dxv if self.period == 1 else ops.period_view_bwd(dxv, cfg.n_audio, cfg.t_audio, self.period))
+
+
+class ChainFmaps:
+    """The feature maps of one chain call: the packed activations A_1 .. A_L (owned by the chain's buffers) and the logits Var."""
+
+    def __init__(self, chain: DiscChain, cfg: _Cfg, logits: ag.Var):
+        self.chain, self.cfg, self.logits = chain, cfg, logits
+        self.A = cfg.A
+        self.ref = None  # set by feature_matching(): the real-waveform call whose activations the backward compares with
+
+    def feature_matching(self, real: "ChainFmaps", slot: torch.Tensor) -> None:
+        """slot[0] += 2 * sum over the feature maps of mean |fake - real| (upstream feature_loss); the gradients are produced by
+        this call's backward (packed maps: in the input-gradient epilogues; logits: here, as on the op-by-op path)."""
+        lib = _lib.load()
+        cfg = self.cfg
+        L = len(self.chain.convs)
+        pairs = (_lib.PkFlatPair * L)()
+        for i in range(1, L + 1):
+            p = pairs[i - 1]
+            p.a, p.b, p.units, p.scale = self.A[i].buf.data_ptr(), real.A[i].buf.data_ptr(), self.A[i].units, cfg.fm_scale[i]
+        dev = slot.device
+        ws = ops.WS.get("dc_fm", lib.evmi_pkflat_absdiff_ws_elems(L), dev)
+        _lib.check(lib.evmi_pkflat_absdiff(L, pairs, slot.data_ptr(), ws.data_ptr(), ws.numel(), ops._s(slot)), "evmi_pkflat_absdiff")
+        fg, fr = self.logits, real.logits
+        n = fg.data.numel()
+        ops.scalar_reduce(0, fg.data, fr.data, slot, scale=2.0 / n, accumulate=True)
+        fg.accumulate(ops.elementwise(ops.EW_SIGN_DIFF, fg.data, fr.data, p0=2.0 / n))
+        self.ref = real

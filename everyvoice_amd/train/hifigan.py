@@ -227,6 +227,24 @@ class GeneratorT:
         return ag.tanh(tape, x)
 
 
+def _chain_for(disc, period: int, x: torch.Tensor):
+    """The flat packed bf16 chain of a discriminator (train/disc_chain.py) when it applies: precision "bf16" on the packed kernels,
+    on a GPU; ``EVMI_DISC_CHAIN=0`` keeps the op-by-op channel-major path (A/B switch; the tests run both)."""
+    if not (x.is_cuda and ops._packed() and _DISC_CHAIN):
+        return None
+    ch = getattr(disc, "_chain", None)
+    if ch is None:
+        from .disc_chain import DiscChain
+
+        ch = disc._chain = DiscChain(disc, period, x.device)
+    return ch if ch.ok else None
+
+
+import os as _os
+
+_DISC_CHAIN = _os.environ.get("EVMI_DISC_CHAIN", "1") == "1"
+
+
 class DiscriminatorPT:
     def __init__(self, group: ParamGroup, prefix: str, period: int):
         self.period = period
@@ -238,7 +256,10 @@ class DiscriminatorPT:
     def layers(self):
         return [*self.convs, self.conv_post]
 
-    def forward(self, tape, audio: ag.Var, training=True):
+    def forward(self, tape, audio: ag.Var, training=True, role="pair"):
+        chain = _chain_for(self, self.period, audio.data)
+        if chain is not None:
+            return chain.forward(tape, audio, training, role)
         x = ag.period_view(tape, audio, self.period)  # [1, B*p, H]: Conv2d((k,1)) == Conv1d over H per column
         fmap = []
         for conv in self.convs:
@@ -262,7 +283,10 @@ class DiscriminatorST:
     def layers(self):
         return [*self.convs, self.conv_post]
 
-    def forward(self, tape, x: ag.Var, training=True):
+    def forward(self, tape, x: ag.Var, training=True, role="pair"):
+        chain = _chain_for(self, 1, x.data)
+        if chain is not None:
+            return chain.forward(tape, x, training, role)
         fmap = []
         for conv in self.convs:
             x = ag.conv1d_lrelu(tape, x, conv, 0.1, training)
@@ -714,10 +738,10 @@ class HiFiGANTrainer:
 
     def _d_branch_sn(self, tape, i: int, d, audio: torch.Tensor, kind: str):
         """One of the two forward calls of the spectral-norm scale (each sees its own power iteration): a chain of its own."""
-        self._d_losses(d.forward(tape, ag.Var(audio, needs_grad=False))[0], kind, self._slots[3 if kind == "fake" else 0, i : i + 1])
+        self._d_losses(d.forward(tape, ag.Var(audio, needs_grad=False), role=kind)[0], kind, self._slots[3 if kind == "fake" else 0, i : i + 1])
 
-    def _g_forward(self, tape, d, x: ag.Var):
-        return d.forward(tape, x)
+    def _g_forward(self, tape, d, x: ag.Var, role: str):
+        return d.forward(tape, x, role=role)
 
     def _g_losses(self, i: int, real, fake):
         """Adversarial and feature-matching terms of one discriminator (into slots i) with their gradients."""
@@ -726,6 +750,9 @@ class HiFiGANTrainer:
         dg.grad = torch.empty_like(dg.data)
         # original: mean((1 - D(y_hat))^2); wgan: -mean(D(y_hat))  (= the "real" form of the critic term)
         self._logit_loss(dg.data, dg.grad, True, n, self._slots[1, i : i + 1])
+        if not isinstance(fg_list, list):  # a packed chain (train/disc_chain.py): one launch pair; gradients ride in its backward
+            fg_list.feature_matching(fr_list, self._slots[2, i : i + 1])
+            return
         for fr, fg in zip(fr_list, fg_list):
             n = fg.data.numel()
             ops.scalar_reduce(0, fg.data, fr.data, self._slots[2, i : i + 1], scale=2.0 / n, accumulate=True)
@@ -944,10 +971,10 @@ class HiFiGANTrainer:
             res_r, res_f = [None] * nd, [None] * nd
 
             def fwd_real(i):
-                return lambda sub: res_r.__setitem__(i, self._g_forward(sub, ds[i], ins_r[i]))
+                return lambda sub: res_r.__setitem__(i, self._g_forward(sub, ds[i], ins_r[i], "g_real"))
 
             def fwd_fake(i):
-                return lambda sub: res_f.__setitem__(i, self._g_forward(sub, ds[i], ins_f[i]))
+                return lambda sub: res_f.__setitem__(i, self._g_forward(sub, ds[i], ins_f[i], "g_fake"))
 
             sn_first = [i for i, d in enumerate(ds) if any(isinstance(l, SNConv) for l in d.layers())]
             order_fake = [fwd_fake(i) for i in range(nd)]

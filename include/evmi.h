@@ -374,6 +374,89 @@ int evmi_cbt_f32_to_tm_bf16(const float* x_dev, void* tm_dev, int C, int B, int 
 int evmi_tm_bf16_to_cbt_f32(const void* a_tm, const void* b_tm, const void* c_tm, float* out_dev, int C, int B, int T, int Tp, int PL,
                             float scale, void* stream);
 int evmi_tm_lrelu_bf16(const void* x_tm, void* y_tm, long long n_elems, float slope, void* stream);
+/* ---- Discriminator chains on FLAT PACKED bf16 tensors (csrc/conv_cbt_bf16_pk.hip, conv_wgrad_bf16_pk.hip, disc_chain.hip; host side
+ * train/disc_chain.py).  MPD / MSD (jik876 hifi-gan models.py DiscriminatorP / DiscriminatorS -- the reference reaches them through
+ * hfgl.model.HiFiGAN.training_step) are chains of strided / grouped convolutions with a leaky ReLU behind each; with
+ * precision "bf16" every activation between two of their layers is kept ONCE, in the layout the matrix-core kernels load:
+ *   flat packed tensor = bf16 [C / 8 octet rows][units], a unit = the 8 channels of one position (16 bytes); rows `plane` units apart;
+ *   n_items items laid end to end, T units apart, the first `valid` units of an item are data; the gap behind every item, >= 64 units
+ *   in front of unit 0 and >= 2048 behind the last item are ZERO and stay zero (the buffer is zeroed once, kernels write valid units
+ *   only).  The gap is the next convolution's zero padding (right side of this item = left side of the next one), so a convolution
+ *   runs over the whole row as over ONE item: T_in = stride * T_out, T_in - valid_in >= max(pad, taps read past the item's end).
+ *   Pointers address unit 0 of row 0.
+ *   evmi_conv_pkflat_fwd      y = act(bias + conv(x)); column v of the flat output (item v / Tc, position v % Tc, Tc = T_x / stride) is
+ *                             stored at item * T_store + position when position < valid, dropped otherwise
+ *   evmi_conv_pkflat_dgrad    dx = conv_input_grad(dy) [+ fm_scale * sign(mask - fm)] * (mask > 0 ? 1 : mask_slope): the polyphase input
+ *                             gradient over the flat dy (items T_dy apart; dx items stride * T_dy apart in the compute geometry, stored
+ *                             T_store apart); mask = the layer's own activated input of the forward pass (a flat packed tensor of dx's
+ *                             shape, items T_mask apart): leaky-ReLU backward; fm = the same activation of the real waveform: the
+ *                             feature-matching gradient (NULL: none)
+ *   evmi_conv_pkflat_wgrad    dw[co][ci][j] (+)= sum_f dy[co][f] * x[ci][f * stride + j * dil - pad] over the flat index f of dy (groups
+ *                             narrower than 32 channels run block-diagonally on the same kernel); ws: _wgrad_ws_elems floats
+ *   evmi_conv_pkflat_prepare  the weight fragments of up to 16 calls in one launch (a job: the call's shape, its weights, its workspace);
+ *                             the calls then pass prepared = 1.  ws of a call: evmi_conv_pkflat_ws_elems floats (0: shape not taken)
+ *   evmi_disc_first_*         the one-input-channel first layer on the waveform itself: item (b, c) of the period view is
+ *                             x[h] = audio[b][h * period + c], reflected past the end (period 1: the waveform); forward -> flat packed,
+ *                             weight / bias gradient from a flat packed dy, input gradient -> fp32 [n_items][H]
+ *   evmi_disc_post_*          the one-output-channel logit layer: flat packed x -> fp32 logits [n_items][n]; dlogits -> flat packed dx
+ *                             (with the mask / feature-matching tail); weight gradient
+ *   evmi_pkflat_absdiff       out[0] += sum_l scale_l * sum |a_l - b_l| over pairs of whole buffers (gaps are zero in both)
+ *   evmi_pkflat_rowsum        db_l[c] += sum of row c of dy_l (bias gradients of a whole chain in one launch pair) */
+typedef struct {
+  int mode; /* 0: forward, 1: input gradient */
+  int n_items, T, c_in, c_out, k, stride, pad, dil, groups; /* T: item pitch of the call's flat INPUT (x / dy) */
+  const float* w;
+  float* ws;
+  long long ws_elems;
+} evmi_pkflat_job;
+typedef struct {
+  const void* a;
+  const void* b;
+  long long units; /* 16-byte units of each buffer */
+  float scale;
+} evmi_pkflat_pair;
+typedef struct {
+  const void* dy;
+  long long plane, units; /* units per row that are summed (n_items * T) */
+  int C;
+  float* db;
+} evmi_pkflat_rows;
+long long evmi_conv_pkflat_ws_elems(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups);
+int evmi_conv_pkflat_plan(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups);
+int evmi_conv_pkflat_prepare(int n_jobs, const evmi_pkflat_job* jobs, void* stream);
+int evmi_conv_pkflat_fwd(const void* x_pk, long long x_plane, const float* w_dev, const float* bias_dev, void* y_pk, long long y_plane,
+                         float* ws_dev, long long ws_elems, int prepared, int n_items, int T_x, int c_in, int c_out, int k, int stride, int pad,
+                         int dil, int groups, int valid, int T_store, int act, float act_param, void* stream);
+int evmi_conv_pkflat_dgrad(const void* dy_pk, long long dy_plane, const float* w_dev, void* dx_pk, long long dx_plane, float* ws_dev,
+                           long long ws_elems, int prepared, int n_items, int T_dy, int c_in, int c_out, int k, int stride, int pad, int dil,
+                           int groups, int valid, int T_store, const void* mask_pk, const void* fm_pk, long long mask_plane, int T_mask,
+                           float mask_slope, float fm_scale, void* stream);
+long long evmi_conv_pkflat_wgrad_ws_elems(int n_items, int T_dy, int c_in, int c_out, int k, int stride, int dil, int groups);
+int evmi_conv_pkflat_wgrad(const void* x_pk, long long x_plane, const void* dy_pk, long long dy_plane, float* dw_dev, float* ws_dev,
+                           long long ws_elems, int n_items, int T_dy, int c_in, int c_out, int k, int stride, int pad, int dil, int groups,
+                           int accumulate, void* stream);
+int evmi_pkflat_zero(void* buf, long long n_units, void* stream);
+int evmi_disc_first_fwd(const float* audio_dev, int n_audio, int t_audio, int period, const float* w_dev, const float* bias_dev, void* y_pk,
+                        long long y_plane, int T_store, int n_out, int c_out, int k, int stride, int pad, float slope, void* stream);
+long long evmi_disc_first_wgrad_ws_elems(int n_items, int n_out, int c_out, int k);
+int evmi_disc_first_wgrad(const float* audio_dev, int n_audio, int t_audio, int period, const void* dy_pk, long long dy_plane, int T_dy, int n_out,
+                          float* dw_dev, float* db_dev, float* ws_dev, long long ws_elems, int c_out, int k, int stride, int pad, int accumulate,
+                          void* stream);
+int evmi_disc_first_dgrad(const void* dy_pk, long long dy_plane, int T_dy, int n_out, const float* w_dev, float* dx_dev, int n_items, int H, int c_out,
+                          int k, int stride, int pad, void* stream);
+long long evmi_disc_post_fwd_ws_elems(int n_items, int n, int C);
+int evmi_disc_post_fwd(const void* x_pk, long long x_plane, int T_x, int n_items, int n, const float* w_dev, const float* bias_dev, float* logits_dev,
+                       float* ws_dev, long long ws_elems, int C, int k, int pad, void* stream);
+int evmi_disc_post_dgrad(const float* dlogits_dev, const float* w_dev, void* dx_pk, long long dx_plane, int T_store, int n_items, int n, int C, int k,
+                         int pad, const void* mask_pk, const void* fm_pk, long long mask_plane, int T_mask, float mask_slope, float fm_scale,
+                         void* stream);
+long long evmi_disc_post_wgrad_ws_elems(int n_items, int n, int C, int k);
+int evmi_disc_post_wgrad(const void* x_pk, long long x_plane, int T_x, int n_items, int n, const float* dlogits_dev, float* dw_dev, float* ws_dev,
+                         long long ws_elems, int C, int k, int pad, int accumulate, void* stream);
+long long evmi_pkflat_absdiff_ws_elems(int n_pairs);
+int evmi_pkflat_absdiff(int n_pairs, const evmi_pkflat_pair* pairs, float* out_dev, float* ws_dev, long long ws_elems, void* stream);
+long long evmi_pkflat_rowsum_ws_elems(int n_jobs, const evmi_pkflat_rows* jobs);
+int evmi_pkflat_rowsum(int n_jobs, const evmi_pkflat_rows* jobs, float* ws_dev, long long ws_elems, void* stream);
 /* Weight gradient of the same convolution as an implicit GEMM on the fp32 matrix cores (no unfold):
  *   dw[co][ci][j] (+)= sum_{b,to} dy[co][b][to] * x[ci][b][to*stride + j*dil - pad]
  * x [c_in][B][t_in], dy [c_out][B][n_out], dw [c_out][c_in/groups][k]; `ws_dev`: 16-byte aligned scratch of
