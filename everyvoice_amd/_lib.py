@@ -56,9 +56,8 @@ class LaunchRecord(C.Structure):
 
 
 class PkFlatJob(C.Structure):  # evmi_pkflat_job
-    _fields_ = [("mode", C.c_int), ("n_items", C.c_int), ("T", C.c_int), ("c_in", C.c_int), ("c_out", C.c_int), ("k", C.c_int),
-                ("stride", C.c_int), ("pad", C.c_int), ("dil", C.c_int), ("groups", C.c_int), ("w", C.c_void_p), ("ws", C.c_void_p),
-                ("ws_elems", C.c_longlong)]
+    _fields_ = [("mode", C.c_int), ("c_in", C.c_int), ("c_out", C.c_int), ("k", C.c_int), ("stride", C.c_int), ("groups", C.c_int),
+                ("w", C.c_void_p), ("wf", C.c_void_p), ("wf_elems", C.c_longlong)]
 
 
 class PkFlatPair(C.Structure):  # evmi_pkflat_pair
@@ -73,10 +72,12 @@ class PkFlatRows(C.Structure):  # evmi_pkflat_rows
 SYMBOLS = {
     "evmi_conv_pkflat_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv_pkflat_plan": (C.c_int, [C.c_int] * 10),
-    "evmi_conv_pkflat_prepare": (C.c_int, [C.c_int, C.POINTER(PkFlatJob), C.c_void_p]),
+    "evmi_conv_pkflat_tab": (C.c_int, [C.c_int] * 10 + [C.c_void_p, C.c_longlong, C.c_void_p]),
+    "evmi_conv_pkflat_frag_elems": (C.c_longlong, [C.c_int] * 6),
+    "evmi_conv_pkflat_fragments": (C.c_int, [C.c_int, C.POINTER(PkFlatJob), C.c_void_p]),
     "evmi_conv_pkflat_fwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong]
-                             + [C.c_int] * 13 + [C.c_float, C.c_void_p]),
-    "evmi_conv_pkflat_dgrad": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 12
+                             + [C.c_int] * 12 + [C.c_float, C.c_void_p]),
+    "evmi_conv_pkflat_dgrad": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong] + [C.c_int] * 11
                                + [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "evmi_conv_pkflat_wgrad_ws_elems": (C.c_longlong, [C.c_int] * 8),
     "evmi_conv_pkflat_wgrad": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 10

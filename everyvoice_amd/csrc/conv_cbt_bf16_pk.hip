@@ -55,6 +55,10 @@ struct ConvPkArgs {
   int ksplit, steps_per_split, ntiles_n;
   float* part;
   long long part_stride, part_ld;
+  // (Folding the reduce into the last-arriving workgroup of a tile -- partial store, __threadfence, atomic counter -- was built and
+  // measured: 91 -> 160 us on the 1024 -> 1024 k = 5 layer, 83 -> 338 us with four splits.  A device-scope release on this
+  // multi-XCD part writes the XCD's L2 back and invalidates it in EVERY workgroup; the kernel boundary in front of a reduce launch
+  // does that once.  The separate reduce pass stays.)
   // fused epilogue tail, in this order: v = act(acc + bias); v *= (out_mask > 0 ? 1 : out_mask_slope); v += res
   //   out_mask: a tensor of y's shape -- the INPUT of the leaky ReLU in front of the convolution whose input gradient this
   //             launch computes (the activation backward without a separate pass);  res: a tensor of y's shape added to the
@@ -616,10 +620,27 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
   // MFMA instead of the 64 x 64 tile's two -- fill the CUs only with the contraction split over workgroups
   static const int allow_split = pk_env_int("EVMI_PK_SPLITK", 1);
   a.ksplit = 1;
-  if (allow_split && a.cout_g > 64 && blocks(0) < 256 && a.kblocks >= 64) {
-    static const int split_want = 384, split_min_kb = 24;
-    int ks = (int)std::min<long long>(8, (split_want + blocks(0) - 1) / blocks(0));
-    while (ks > 1 && a.kblocks / ks < split_min_kb) --ks;
+  // (flat one-item calls -- B == 1 with thousands of columns -- also split between 256 and 384 tiles: 4.2-4.7 k columns of a
+  // 1024-channel layer otherwise fall to 64 x 128 tiles, 136 vs 92 us, tools/pkflat_bench.py)
+  if (allow_split && a.cout_g > 64 && blocks(0) < (a.B == 1 ? 384 : 256) && a.kblocks >= 64) {
+    static const int split_min_kb = 24;
+    int ks;
+    if (a.B == 1) {
+      // flat calls: the split that needs the fewest rounds of the chip's 512 workgroup slots per unit of contraction, a reduce pass
+      // priced at ~4 % of a round per split (4.2 k columns x 1024 channels: 264 tiles -- two splits are 528 workgroups, one past a
+      // round, three are 792: two rounds of a third of the contraction each)
+      double best = 1e30;
+      ks = 1;
+      for (int c = 2; c <= 8; ++c) {
+        if (a.kblocks / c < split_min_kb) break;
+        const double cost = (double)((blocks(0) * c + 511) / 512) / c + 0.04 * c;
+        if (cost < best) { best = cost; ks = c; }
+      }
+    } else {
+      static const int split_want = 384;
+      ks = (int)std::min<long long>(8, (split_want + blocks(0) - 1) / blocks(0));
+      while (ks > 1 && a.kblocks / ks < split_min_kb) --ks;
+    }
     a.ksplit = ks;
   }
   // candidate tiles in order of preference; the next one is tried while the staged window does not fit
@@ -837,19 +858,78 @@ struct PkFlatShape {
   int mode;  // 0: forward; 1: input gradient (polyphase)
   int n_items, T, c_in, c_out, k, stride, pad, dil, groups;
 };
-constexpr int PKFLAT_MAX_JOBS = 16;
-struct WfragBatch {
-  WfragArgs job[PKFLAT_MAX_JOBS];
+// Weight fragments of a flat call depend on the layer alone (shape, direction, weights) -- not on the item count or the tile the
+// planner picks: one fragment buffer serves every call of a layer in a phase of the step (discriminator step pair, generator step
+// real / generated).  The K-block offset table and the split counters are per call and static: written once (evmi_conv_pkflat_tab).
+struct FragGeom {
+  int rows_g, kch_g, kt, MB, octs, kblocks, phases, groups;
+  long long phase_stride_units;
+};
+static FragGeom frag_geom(int mode, int c_in, int c_out, int k, int stride, int groups) {
+  FragGeom f;
+  const int cin_g = c_in / groups, cout_g = c_out / groups;
+  f.groups = groups;
+  f.rows_g = mode == 0 ? cout_g : cin_g;
+  f.kch_g = mode == 0 ? cin_g : cout_g;
+  f.kt = mode == 0 ? k : (stride == 1 ? k : (k + stride - 1) / stride);
+  f.phases = mode == 0 ? 1 : std::min(stride, k);
+  f.MB = (f.rows_g + 31) / 32;
+  f.octs = (f.kch_g + 7) / 8;
+  f.kblocks = (f.octs * f.kt + 1) / 2;
+  f.phase_stride_units = (long long)groups * f.MB * f.kblocks * 64;
+  return f;
+}
+struct FragJob {
+  const float* w;
+  unsigned* wf;
+  int mode, rows_g, kch_g, kt, MB, octs, kblocks, k_full, stride, phases;
+  long long phase_stride_words;
+};
+constexpr int PKFLAT_MAX_JOBS = 32;
+struct FragBatch {
+  FragJob job[PKFLAT_MAX_JOBS];
   int start[PKFLAT_MAX_JOBS + 1];
   int n;
 };
-__global__ __launch_bounds__(256) void wfrag_pk_batch_kernel(WfragBatch b) {
-  int j = 0;
-  while (j + 1 < b.n && (int)blockIdx.x >= b.start[j + 1]) ++j;
-  const WfragArgs& f = b.job[j];
-  const unsigned bid = blockIdx.x - b.start[j];
-  const unsigned q = bid % f.gx, r = bid / f.gx;
-  wfrag_pk_block(f, (int)q, (int)(r % f.gy), (int)(r / f.gy));
+// One workgroup per (group, 32-row block, channel octet): reads the block's weights once, coalesced (forward: 8 x kt contiguous
+// floats per row; input gradient: 32 rows x k contiguous floats per channel), and writes the half-fragments of every (phase, tap).
+__global__ __launch_bounds__(256) void wfrag_flat_kernel(FragBatch b) {
+  int jn = 0;
+  while (jn + 1 < b.n && (int)blockIdx.x >= b.start[jn + 1]) ++jn;
+  const FragJob& f = b.job[jn];
+  const int bid = blockIdx.x - b.start[jn];
+  const int gmb = bid / f.octs, o = bid - gmb * f.octs;
+  const int g = gmb / f.MB, mb = gmb - g * f.MB;
+  const int t = threadIdx.x;
+  const int r = f.mode == 0 ? t >> 3 : t & 31, c = f.mode == 0 ? t & 7 : t >> 5;
+  const int row = mb * 32 + r, kc = o * 8 + c;
+  const bool valid = row < f.rows_g && kc < f.kch_g;
+  const int kt = f.kt;
+  const float* src = f.mode == 0 ? f.w + ((long long)(g * f.rows_g + row) * f.kch_g + kc) * kt
+                                 : f.w + ((long long)(g * f.kch_g + kc) * f.rows_g + row) * f.k_full;
+  for (int phi = 0; phi < f.phases; ++phi) {
+    const int m_phi = f.mode == 0 ? kt : (f.k_full - phi + f.stride - 1) / f.stride, lead = kt - m_phi;
+    unsigned* dst = f.wf + phi * f.phase_stride_words + (long long)gmb * f.kblocks * 256;
+    for (int j = 0; j < kt; ++j) {
+      float v = 0.f;
+      if (valid && j >= lead) v = f.mode == 0 ? src[j] : src[phi + f.stride * (m_phi - 1 - (j - lead))];
+      const float other = __shfl_xor(v, f.mode == 0 ? 1 : 32, 64);
+      if ((c & 1) == 0) {
+        const int h = o * kt + j;
+        dst[((h >> 1) * 64 + (h & 1) * 32 + r) * 4 + (c >> 1)] = pk_bf16x2(v, other);
+      }
+    }
+    if (o == f.octs - 1 && ((f.octs * kt) & 1) && (c & 1) == 0)  // odd tail: the upper half of the last K block is zero weights
+      dst[((f.kblocks - 1) * 64 + 32 + r) * 4 + (c >> 1)] = 0u;
+  }
+}
+// per K block: window offsets (units) of its two halves (as wfrag_pk_block writes them)
+__global__ void flat_tab_kernel(int2* tab, int kblocks, int kb_step, int kt, int octs, int xrow, int dil) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= kblocks) return;
+  const int o_lo = (2 * (q / kb_step) * kb_step) / kt;
+  const int h0 = 2 * q, h1 = h0 + 1 < octs * kt ? h0 + 1 : h0;
+  tab[q] = make_int2((h0 / kt - o_lo) * xrow + (h0 % kt) * dil, (h1 / kt - o_lo) * xrow + (h1 % kt) * dil);
 }
 
 static const char* plan_flat(const PkFlatShape& sh, ConvPkArgs& a, PkPlan& pl) {
@@ -857,45 +937,42 @@ static const char* plan_flat(const PkFlatShape& sh, ConvPkArgs& a, PkPlan& pl) {
   if ((sh.c_in / std::max(1, sh.groups)) % 8 || (sh.c_out / std::max(1, sh.groups)) % 8) return "channels per group must be multiples of 8";
   const long long len = (long long)sh.n_items * sh.T;
   if (len * std::max(1, sh.stride) >= (1LL << 30)) return "flat row too long";
+  const char* why;
   if (sh.mode == 0) {
     if (sh.T % sh.stride) return "item pitch must be a multiple of the stride";
     const int n_cols = (int)(len / sh.stride);
-    return plan_fwd_pk(a, pl, 1, sh.c_in, (int)len, sh.c_out, n_cols, n_cols, sh.k, sh.stride, sh.pad, sh.dil, sh.groups, 1, 0);
+    why = plan_fwd_pk(a, pl, 1, sh.c_in, (int)len, sh.c_out, n_cols, n_cols, sh.k, sh.stride, sh.pad, sh.dil, sh.groups, 1, 0);
+  } else {
+    why = plan_dgrad_pk(a, pl, 1, sh.c_in, (int)(len * sh.stride), sh.c_out, (int)len, sh.k, sh.stride, sh.pad, sh.dil, sh.groups);
   }
-  return plan_dgrad_pk(a, pl, 1, sh.c_in, (int)(len * sh.stride), sh.c_out, (int)len, sh.k, sh.stride, sh.pad, sh.dil, sh.groups);
+  if (why) return why;
+  const FragGeom f = frag_geom(sh.mode, sh.c_in, sh.c_out, sh.k, sh.stride, sh.groups);
+  if (f.kt != a.k || f.MB != a.mblocks || f.octs != a.octs || f.kblocks != a.kblocks || f.phases != a.phases || f.phase_stride_units != a.wf_phase_stride)
+    return "fragment geometry (internal)";
+  return nullptr;
+}
+// workspace of a call: [offset table][split partial tiles]
+struct FlatWs {
+  long long tab_units, total_floats;
+};
+static FlatWs flat_ws(const ConvPkArgs& a, const PkPlan& pl) {
+  FlatWs w;
+  w.tab_units = ((long long)a.kblocks * 8 + 15) / 16;
+  w.total_floats = w.tab_units * 4 + pl.part_elems;
+  return w;
 }
 
-static WfragArgs flat_wfrag_args(const PkFlatShape& sh, const ConvPkArgs& a, const PkPlan& pl, const float* w, float* ws) {
-  uint4* wf = reinterpret_cast<uint4*>(ws);
-  WfragArgs fa;
-  const int cg_in = sh.c_in / sh.groups, cg_out = sh.c_out / sh.groups;
-  fa.w = w; fa.wf = reinterpret_cast<unsigned*>(wf);
-  fa.rows_g = sh.mode == 0 ? cg_out : cg_in; fa.kch_g = sh.mode == 0 ? cg_in : cg_out;
-  fa.kt = a.k; fa.MB = a.mblocks; fa.octs = a.octs; fa.kblocks = a.kblocks; fa.mode = sh.mode; fa.k_full = sh.k; fa.stride = sh.stride;
-  fa.phase_stride_words = a.wf_phase_stride * 4;
-  fa.tab = reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases); fa.kb_step = a.kb_step; fa.xrow = a.xrow; fa.dil = a.dil;
-  fa.gx = a.kblocks; fa.gy = pl.groups * a.mblocks; fa.gz = a.phases;
-  return fa;
-}
-
-static int launch_flat(const PkFlatShape& sh, const void* in_dev, long long in_plane, const float* w, const float* bias, float* ws,
-                       long long ws_elems, int prepared, ConvPkArgs::FlatOut po, int act, float act_param, hipStream_t stream) {
+static int launch_flat(const PkFlatShape& sh, const void* in_dev, long long in_plane, const void* wf_dev, const float* bias, float* ws,
+                       long long ws_elems, ConvPkArgs::FlatOut po, int act, float act_param, hipStream_t stream) {
   ConvPkArgs a = {};
   PkPlan pl;
   if (const char* why = plan_flat(sh, a, pl)) return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_pkflat: ") + why);
-  const long long need = pl.wf_units * 4 + pl.part_elems;
-  if (!ws || ws_elems < need || (reinterpret_cast<uintptr_t>(ws) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat: workspace missing, too small or unaligned");
-  if (!in_dev || !w || !po.y) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat: null pointer");
-  WfragArgs fa = flat_wfrag_args(sh, a, pl, w, ws);
-  if (!prepared) {
-    PackArgs pa = {};
-    const long long n_prep = (long long)fa.gx * fa.gy * fa.gz;
-    hipLaunchKernelGGL(prep_pk_kernel, dim3((unsigned)n_prep), dim3(256), 0, stream, pa, fa);
-    EVMI_LAUNCH_CHECK("conv_pkflat (fragments)");
-  }
-  a.tab = fa.tab;
-  a.wf = reinterpret_cast<const uint4*>(ws);
-  a.part = reinterpret_cast<float*>(reinterpret_cast<uint4*>(ws) + pl.wf_units);
+  const FlatWs fw = flat_ws(a, pl);
+  if (!ws || ws_elems < fw.total_floats || (reinterpret_cast<uintptr_t>(ws) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat: workspace missing, too small or unaligned");
+  if (!in_dev || !wf_dev || !po.y || (reinterpret_cast<uintptr_t>(wf_dev) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat: null / unaligned pointer");
+  a.tab = reinterpret_cast<const int2*>(ws);
+  a.wf = reinterpret_cast<const uint4*>(wf_dev);
+  a.part = ws + fw.tab_units * 4;
   a.Tp = (int)in_plane;                                            // B == 1: the octet rows are `Tp` units apart
   a.xp = reinterpret_cast<const uint4*>(in_dev) - pl.PL;           // the front guard of the tensor is the left padding
   a.bias = bias; a.act = act; a.act_param = act_param; a.accumulate = 0;
@@ -1044,7 +1121,7 @@ long long evmi_conv_pkflat_ws_elems(int mode, int n_items, int T, int c_in, int 
   ConvPkArgs a = {};
   PkPlan pl;
   if (groups <= 0 || stride <= 0 || plan_flat(flat_shape(mode, n_items, T, c_in, c_out, k, stride, pad, dil, groups), a, pl)) return 0;
-  return pl.wf_units * 4 + pl.part_elems;
+  return flat_ws(a, pl).total_floats;
 }
 
 int evmi_conv_pkflat_plan(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups) {
@@ -1054,45 +1131,66 @@ int evmi_conv_pkflat_plan(int mode, int n_items, int T, int c_in, int c_out, int
   return pl.ti + 16 * (a.ksplit > 1 ? a.ksplit : 0);
 }
 
-int evmi_conv_pkflat_prepare(int n_jobs, const evmi_pkflat_job* jobs, void* stream) {
-  if (n_jobs < 0 || (n_jobs && !jobs)) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_prepare: bad job list");
+int evmi_conv_pkflat_tab(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups, float* ws_dev,
+                         long long ws_elems, void* stream) {
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (groups <= 0 || stride <= 0) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_tab: bad shape");
+  if (const char* why = plan_flat(flat_shape(mode, n_items, T, c_in, c_out, k, stride, pad, dil, groups), a, pl))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_pkflat_tab: ") + why);
+  const FlatWs fw = flat_ws(a, pl);
+  if (!ws_dev || ws_elems < fw.total_floats || (reinterpret_cast<uintptr_t>(ws_dev) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_tab: workspace missing, too small or unaligned");
+  hipLaunchKernelGGL(flat_tab_kernel, dim3((a.kblocks + 255) / 256), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<int2*>(ws_dev), a.kblocks, a.kb_step, a.k,
+                     a.octs, a.xrow, a.dil);
+  EVMI_LAUNCH_CHECK("conv_pkflat_tab");
+  return EVMI_OK;
+}
+
+long long evmi_conv_pkflat_frag_elems(int mode, int c_in, int c_out, int k, int stride, int groups) {
+  if (groups <= 0 || stride <= 0 || c_in <= 0 || c_out <= 0 || c_in % groups || c_out % groups || k <= 0) return 0;
+  const FragGeom f = frag_geom(mode, c_in, c_out, k, stride, groups);
+  return f.phase_stride_units * f.phases * 4;
+}
+
+int evmi_conv_pkflat_fragments(int n_jobs, const evmi_pkflat_job* jobs, void* stream) {
+  if (n_jobs < 0 || (n_jobs && !jobs)) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_fragments: bad job list");
   for (int j0 = 0; j0 < n_jobs; j0 += PKFLAT_MAX_JOBS) {
-    WfragBatch b;
+    FragBatch b;
     b.n = std::min(PKFLAT_MAX_JOBS, n_jobs - j0);
     b.start[0] = 0;
     for (int j = 0; j < b.n; ++j) {
       const evmi_pkflat_job& jb = jobs[j0 + j];
-      const PkFlatShape sh = flat_shape(jb.mode, jb.n_items, jb.T, jb.c_in, jb.c_out, jb.k, jb.stride, jb.pad, jb.dil, jb.groups);
-      ConvPkArgs a = {};
-      PkPlan pl;
-      if (jb.groups <= 0 || jb.stride <= 0) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_prepare: bad shape");
-      if (const char* why = plan_flat(sh, a, pl)) return fail(EVMI_ERR_UNSUPPORTED, std::string("conv_pkflat_prepare: ") + why);
-      if (!jb.w || !jb.ws || jb.ws_elems < pl.wf_units * 4 + pl.part_elems || (reinterpret_cast<uintptr_t>(jb.ws) & 15))
-        return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_prepare: weights / workspace missing, too small or unaligned");
-      b.job[j] = flat_wfrag_args(sh, a, pl, jb.w, jb.ws);
-      const long long nb = (long long)b.job[j].gx * b.job[j].gy * b.job[j].gz;
-      if (b.start[j] + nb > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv_pkflat_prepare: grid limits");
+      if (jb.groups <= 0 || jb.stride <= 0 || jb.c_in <= 0 || jb.c_out <= 0 || jb.c_in % jb.groups || jb.c_out % jb.groups || jb.k <= 0 || jb.mode < 0 || jb.mode > 1)
+        return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_fragments: bad shape");
+      const FragGeom f = frag_geom(jb.mode, jb.c_in, jb.c_out, jb.k, jb.stride, jb.groups);
+      if (!jb.w || !jb.wf || jb.wf_elems < f.phase_stride_units * f.phases * 4 || (reinterpret_cast<uintptr_t>(jb.wf) & 15))
+        return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_fragments: weights / fragment buffer missing, too small or unaligned");
+      FragJob& q = b.job[j];
+      q.w = jb.w; q.wf = reinterpret_cast<unsigned*>(jb.wf); q.mode = jb.mode; q.rows_g = f.rows_g; q.kch_g = f.kch_g; q.kt = f.kt; q.MB = f.MB;
+      q.octs = f.octs; q.kblocks = f.kblocks; q.k_full = jb.k; q.stride = jb.stride; q.phases = f.phases; q.phase_stride_words = f.phase_stride_units * 4;
+      const long long nb = (long long)f.groups * f.MB * f.octs;
+      if (b.start[j] + nb > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv_pkflat_fragments: grid limits");
       b.start[j + 1] = b.start[j] + (int)nb;
     }
-    if (b.start[b.n] > 0) hipLaunchKernelGGL(wfrag_pk_batch_kernel, dim3((unsigned)b.start[b.n]), dim3(256), 0, (hipStream_t)stream, b);
-    EVMI_LAUNCH_CHECK("conv_pkflat_prepare");
+    if (b.start[b.n] > 0) hipLaunchKernelGGL(wfrag_flat_kernel, dim3((unsigned)b.start[b.n]), dim3(256), 0, (hipStream_t)stream, b);
+    EVMI_LAUNCH_CHECK("conv_pkflat_fragments");
   }
   return EVMI_OK;
 }
 
-int evmi_conv_pkflat_fwd(const void* x_pk, long long x_plane, const float* w_dev, const float* bias_dev, void* y_pk, long long y_plane,
-                         float* ws_dev, long long ws_elems, int prepared, int n_items, int T_x, int c_in, int c_out, int k, int stride, int pad,
+int evmi_conv_pkflat_fwd(const void* x_pk, long long x_plane, const void* wf_dev, const float* bias_dev, void* y_pk, long long y_plane,
+                         float* ws_dev, long long ws_elems, int n_items, int T_x, int c_in, int c_out, int k, int stride, int pad,
                          int dil, int groups, int valid, int T_store, int act, float act_param, void* stream) {
   if (act < 0 || act > 4) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_fwd: activation");
   if (groups <= 0 || stride <= 0 || T_x % stride) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_fwd: the item pitch must be a multiple of the stride");
   ConvPkArgs::FlatOut po = {};
   po.y = reinterpret_cast<uint4*>(y_pk); po.plane = y_plane; po.Tc = T_x / stride; po.valid = valid; po.Ts = T_store;
-  return launch_flat(flat_shape(0, n_items, T_x, c_in, c_out, k, stride, pad, dil, groups), x_pk, x_plane, w_dev, bias_dev, ws_dev, ws_elems,
-                     prepared, po, act, act_param, (hipStream_t)stream);
+  return launch_flat(flat_shape(0, n_items, T_x, c_in, c_out, k, stride, pad, dil, groups), x_pk, x_plane, wf_dev, bias_dev, ws_dev, ws_elems,
+                     po, act, act_param, (hipStream_t)stream);
 }
 
-int evmi_conv_pkflat_dgrad(const void* dy_pk, long long dy_plane, const float* w_dev, void* dx_pk, long long dx_plane, float* ws_dev,
-                           long long ws_elems, int prepared, int n_items, int T_dy, int c_in, int c_out, int k, int stride, int pad, int dil,
+int evmi_conv_pkflat_dgrad(const void* dy_pk, long long dy_plane, const void* wf_dev, void* dx_pk, long long dx_plane, float* ws_dev,
+                           long long ws_elems, int n_items, int T_dy, int c_in, int c_out, int k, int stride, int pad, int dil,
                            int groups, int valid, int T_store, const void* mask_pk, const void* fm_pk, long long mask_plane, int T_mask,
                            float mask_slope, float fm_scale, void* stream) {
   if (groups <= 0 || stride <= 0) return fail(EVMI_ERR_INVALID_ARG, "conv_pkflat_dgrad: bad shape");
@@ -1102,8 +1200,8 @@ int evmi_conv_pkflat_dgrad(const void* dy_pk, long long dy_plane, const float* w
   po.y = reinterpret_cast<uint4*>(dx_pk); po.plane = dx_plane; po.Tc = T_dy * stride; po.valid = valid; po.Ts = T_store;
   po.mask = reinterpret_cast<const uint4*>(mask_pk); po.fm = reinterpret_cast<const uint4*>(fm_pk); po.mplane = mask_plane; po.Tm = T_mask;
   po.mask_slope = mask_slope; po.fm_scale = fm_scale;
-  return launch_flat(flat_shape(1, n_items, T_dy, c_in, c_out, k, stride, pad, dil, groups), dy_pk, dy_plane, w_dev, nullptr, ws_dev, ws_elems,
-                     prepared, po, 0, 0.f, (hipStream_t)stream);
+  return launch_flat(flat_shape(1, n_items, T_dy, c_in, c_out, k, stride, pad, dil, groups), dy_pk, dy_plane, wf_dev, nullptr, ws_dev, ws_elems,
+                     po, 0, 0.f, (hipStream_t)stream);
 }
 
 }  // extern "C"

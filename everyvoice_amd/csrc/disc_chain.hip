@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void disc_first_fwd_kernel(FirstFwdArgs a) {
 }
 
 // ---- first layer, weight + bias gradient: partial[blk][co][k + 1] (last column: sum of dy) -----------------------------------------
-constexpr int DC_WCOLS = 8;  // columns per thread
+constexpr int DC_WCOLS = 4;  // columns per thread
 struct FirstWgradArgs {
   AudioView xv;
   const uint4* dy;
@@ -93,46 +93,53 @@ struct FirstWgradArgs {
   int T, n_out, n_items, c_out, k, stride, pad;
   float* partial;
 };
+template <int KT>  // taps held in registers (8: the period discriminators' k = 5; 16: the scale discriminators' k = 15)
 __global__ __launch_bounds__(256) void disc_first_wgrad_kernel(FirstWgradArgs a) {
-  extern __shared__ float red[];  // [8 * (DC_KMAX + 1)][257]
+  extern __shared__ float red[];  // [8 * (KT + 1)][257]
   const int tid = threadIdx.x, o = blockIdx.y;
   const int n_total = a.n_items * a.n_out;
   const int n0 = blockIdx.x * (256 * DC_WCOLS);
-  float acc[8][DC_KMAX + 1];
+  float acc[8][KT + 1];
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int j = 0; j <= DC_KMAX; ++j) acc[e][j] = 0.f;
+    for (int j = 0; j <= KT; ++j) acc[e][j] = 0.f;
   for (int i = 0; i < DC_WCOLS; ++i) {
     const int n = n0 + i * 256 + tid;
     const bool live = n < n_total;
     const int nc = live ? n : n_total - 1;
     const int item = nc / a.n_out, to = nc - item * a.n_out;
     const uint4 du = a.dy[(long long)o * a.plane + (long long)item * a.T + to];
-    float x[DC_KMAX], dv[8];
+    float x[KT], dv[8];
 #pragma unroll
-    for (int j = 0; j < DC_KMAX; ++j) x[j] = (live && j < a.k) ? a.xv.at(item, to * a.stride + j - a.pad) : 0.f;
+    for (int j = 0; j < KT; ++j) x[j] = (live && j < a.k) ? a.xv.at(item, to * a.stride + j - a.pad) : 0.f;
     unpack8(du, dv);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float d = live ? dv[e] : 0.f;
 #pragma unroll
-      for (int j = 0; j < DC_KMAX; ++j) acc[e][j] = fmaf(d, x[j], acc[e][j]);
-      acc[e][DC_KMAX] += d;
+      for (int j = 0; j < KT; ++j) acc[e][j] = fmaf(d, x[j], acc[e][j]);
+      acc[e][KT] += d;
     }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int j = 0; j <= DC_KMAX; ++j) red[(e * (DC_KMAX + 1) + j) * 257 + tid] = acc[e][j];
+    for (int j = 0; j <= KT; ++j) red[(e * (KT + 1) + j) * 257 + tid] = acc[e][j];
   __syncthreads();
-  if (tid < 8 * (DC_KMAX + 1)) {
-    const int e = tid / (DC_KMAX + 1), j = tid - e * (DC_KMAX + 1);
-    if (j < a.k || j == DC_KMAX) {
+  if (tid < 8 * (KT + 1)) {
+    const int e = tid / (KT + 1), j = tid - e * (KT + 1);
+    if (j < a.k || j == KT) {
       const float* r = red + tid * 257;
       float v = 0.f;
-      for (int t = 0; t < 256; ++t) v += r[t];  // fixed order
-      a.partial[((long long)blockIdx.x * a.c_out + o * 8 + e) * (a.k + 1) + (j == DC_KMAX ? a.k : j)] = v;
+      for (int t = 0; t < 256; t += 8) {  // fixed order, eight LDS reads in flight
+        float q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = r[t + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += q[u];
+      }
+      a.partial[((long long)blockIdx.x * a.c_out + o * 8 + e) * (a.k + 1) + (j == KT ? a.k : j)] = v;
     }
   }
 }
@@ -526,13 +533,16 @@ int evmi_disc_first_wgrad(const float* audio_dev, int n_audio, int t_audio, int 
   a.stride = stride; a.pad = pad; a.partial = ws_dev;
   const long long n = (long long)n_items * n_out;
   const int nblk = (int)((n + 256 * DC_WCOLS - 1) / (256 * DC_WCOLS));
-  const size_t lds = (size_t)8 * (DC_KMAX + 1) * 257 * sizeof(float);
-  static thread_local bool configured[kMaxDevices] = {};
-  if (!configured[device_slot()]) {
-    EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)disc_first_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured[device_slot()] = true;
+  const bool k8 = k <= 8;
+  const size_t lds = (size_t)8 * ((k8 ? 8 : DC_KMAX) + 1) * 257 * sizeof(float);
+  static thread_local bool configured[kMaxDevices][2] = {};
+  if (!configured[device_slot()][k8]) {
+    if (k8) EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)disc_first_wgrad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)disc_first_wgrad_kernel<DC_KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured[device_slot()][k8] = true;
   }
-  hipLaunchKernelGGL(disc_first_wgrad_kernel, dim3(nblk, c_out / 8), dim3(256), lds, (hipStream_t)stream, a);
+  if (k8) hipLaunchKernelGGL(disc_first_wgrad_kernel<8>, dim3(nblk, c_out / 8), dim3(256), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(disc_first_wgrad_kernel<DC_KMAX>, dim3(nblk, c_out / 8), dim3(256), lds, (hipStream_t)stream, a);
   EVMI_LAUNCH_CHECK("disc_first_wgrad");
   const int nf = c_out * (k + 1);
   hipLaunchKernelGGL(disc_first_wgrad_final_kernel, dim3((nf + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws_dev, dw_dev, db_dev, c_out, k, nblk, accumulate);

@@ -89,20 +89,20 @@ class _Cfg:
             for i in range(1, L + 1):
                 T_G = self.Tc[i - 1] if i >= 2 else T_A[1]
                 self.G[i] = PF(convs[i - 1].cout, self.n_items, T_G, self.lens[i], device)
-        # per-call workspaces (weight fragments + split partials): own buffers, so that fragments prepared at the start of a phase
-        # survive until their call
+        # per-call workspaces: the call's static K-block offset table and split counters (written once, here) + its split partial tiles
         self.ws_f, self.ws_d = [None] * L, [None] * L
+        st = _lib.current_stream_ptr(device)
         for i in range(1, L):
             c = convs[i]
-            n = lib.evmi_conv_pkflat_ws_elems(0, self.n_items, T_A[i], c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups)
-            if n <= 0:
-                raise RuntimeError(f"disc chain: forward layer {c.name} not taken by the flat packed kernel")
-            self.ws_f[i] = torch.empty(n, device=device, dtype=torch.float32)
-            if with_grad:
-                n = lib.evmi_conv_pkflat_ws_elems(1, self.n_items, self.Tc[i], c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups)
+            for mode, T, dst in ((0, T_A[i], self.ws_f), (1, self.Tc[i], self.ws_d)):
+                if mode == 1 and not with_grad:
+                    continue
+                shape = (mode, self.n_items, T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups)
+                n = lib.evmi_conv_pkflat_ws_elems(*shape)
                 if n <= 0:
-                    raise RuntimeError(f"disc chain: input gradient of layer {c.name} not taken by the flat packed kernel")
-                self.ws_d[i] = torch.empty(n, device=device, dtype=torch.float32)
+                    raise RuntimeError(f"disc chain: layer {c.name} (direction {mode}) not taken by the flat packed kernel")
+                dst[i] = torch.empty(n, device=device, dtype=torch.float32)
+                _lib.check(lib.evmi_conv_pkflat_tab(*shape, dst[i].data_ptr(), n, st), "evmi_conv_pkflat_tab")
         self.logits_n = _conv_len(self.lens[L], post.k, post.stride, post.pad, post.dil)
         assert post.stride == 1 and self.logits_n == self.lens[L], "the logit layer is a 'same' convolution"
         # feature-matching scales: 2 / numel of every feature map (upstream feature_loss: mean |.| per map, times 2)
@@ -122,6 +122,55 @@ class DiscChain:
         for c in self.convs[1:]:
             ok = ok and (c.cin // c.groups) % 8 == 0 and (c.cout // c.groups) % 8 == 0 and c.k >= c.stride and not c.transposed
         self.ok = bool(ok)
+        self._frag_bufs: dict = {}   # (layer, direction, slot) -> fragment buffer
+        self._frag_map: dict = {}    # (layer, direction, weight pointer) -> (epoch, fragment buffer)
+
+    # ---- weight fragments: per (layer, direction, weights), shared by every call of the layer while the weights stand ----------
+    EPOCH = [0]  # bumped whenever discriminator weights change (HiFiGANTrainer._materialize): older fragments are stale
+
+    def _frag_buf(self, i, mode, slot):
+        key = (i, mode, slot)
+        buf = self._frag_bufs.get(key)
+        if buf is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("disc chain: fragment buffers would have to be created during graph capture: warm the step up eagerly first")
+            c = self.convs[i]
+            n = _lib.load().evmi_conv_pkflat_frag_elems(mode, c.cin, c.cout, c.k, c.stride, c.groups)
+            buf = self._frag_bufs[key] = torch.empty(n, device=self.device, dtype=torch.float32)
+        return buf
+
+    def _call_weights(self, i):
+        """The effective weights of the coming forward calls of layer i, in call order."""
+        c = self.convs[i]
+        if hasattr(c, "_ready"):  # spectral norm: one weight tensor per prepared call
+            return [r[0] for r in c._ready]
+        if c._w is None:
+            c.materialize()
+        return [c._w]
+
+    def frag_jobs(self, dgrad_slots=(True,)):
+        """(direction, layer, weights, buffer) of every fragment set the coming phase needs; ``dgrad_slots[s]``: call s of a layer
+        also runs its input gradient (the last entry stands for further calls)."""
+        jobs = []
+        for i in range(1, len(self.convs)):
+            for s, w in enumerate(self._call_weights(i)):
+                for mode in (0, 1):
+                    if mode == 1 and not dgrad_slots[min(s, len(dgrad_slots) - 1)]:
+                        continue
+                    wf = self._frag_buf(i, mode, s)
+                    self._frag_map[(i, mode, w.data_ptr())] = (self.EPOCH[0], wf)
+                    jobs.append((mode, self.convs[i], w, wf))
+        return jobs
+
+    def _frag(self, i, mode, w, role):
+        """The fragments of `w` for layer i: prepared by the trainer at the start of the phase, or made here (direct calls)."""
+        e = self._frag_map.get((i, mode, w.data_ptr()))
+        if e is not None and e[0] == self.EPOCH[0]:
+            return e[1]
+        wf = self._frag_buf(i, mode, ("local", role))
+        launch_fragments([(mode, self.convs[i], w, wf)], self.device)
+        self._frag_map[(i, mode, w.data_ptr())] = (self.EPOCH[0], wf)
+        return wf
 
     def cfg(self, n_audio, t_audio, role, with_grad) -> _Cfg:
         key = (n_audio, t_audio, role, with_grad)
@@ -146,19 +195,8 @@ class DiscChain:
         eff = [c.effective(training) + (c.call_db_sink(),) for c in convs]  # (w, dw sink, db sink) per call, in layer order
         w_post, dw_post = post.effective(training)
         db_post = post.call_db_sink()
-        # weight fragments of every matrix-core call of this pass (and of its backward) in one launch
-        jobs = (_lib.PkFlatJob * (2 * (L - 1)))()
-        nj = 0
-        for i in range(1, L):
-            c = convs[i]
-            for mode, T, ws in ((0, cfg.A[i].T, cfg.ws_f[i]), (1, cfg.Tc[i], cfg.ws_d[i])):
-                if mode == 1 and not with_grad:
-                    continue
-                j = jobs[nj]
-                j.mode, j.n_items, j.T, j.c_in, j.c_out, j.k, j.stride, j.pad, j.dil, j.groups = mode, cfg.n_items, T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups
-                j.w, j.ws, j.ws_elems = eff[i][0].data_ptr(), ws.data_ptr(), ws.numel()
-                nj += 1
-        _lib.check(lib.evmi_conv_pkflat_prepare(nj, jobs, st), "evmi_conv_pkflat_prepare")
+        wf_f = [None] + [self._frag(i, 0, eff[i][0], role) for i in range(1, L)]
+        wf_d = [None] + [self._frag(i, 1, eff[i][0], role) if with_grad else None for i in range(1, L)]
         c0 = convs[0]
         A = cfg.A
         _lib.check(lib.evmi_disc_first_fwd(x.data_ptr(), n_audio, t_audio, self.period, eff[0][0].data_ptr(), c0.bias_data().data_ptr(), A[1].ptr, A[1].plane,
@@ -166,8 +204,8 @@ class DiscChain:
         ops._count_conv(cfg.n_items, cfg.lens[1], c0.cout, 1, c0.k)
         for i in range(1, L):
             c = convs[i]
-            _lib.check(lib.evmi_conv_pkflat_fwd(A[i].ptr, A[i].plane, eff[i][0].data_ptr(), c.bias_data().data_ptr(), A[i + 1].ptr, A[i + 1].plane,
-                                                cfg.ws_f[i].data_ptr(), cfg.ws_f[i].numel(), 1, cfg.n_items, A[i].T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil,
+            _lib.check(lib.evmi_conv_pkflat_fwd(A[i].ptr, A[i].plane, wf_f[i].data_ptr(), c.bias_data().data_ptr(), A[i + 1].ptr, A[i + 1].plane,
+                                                cfg.ws_f[i].data_ptr(), cfg.ws_f[i].numel(), cfg.n_items, A[i].T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil,
                                                 c.groups, cfg.lens[i + 1], A[i + 1].T, ops.ACT_LRELU, 0.1, st), "evmi_conv_pkflat_fwd")
             ops._count_conv(cfg.n_items, cfg.lens[i + 1], c.cout, c.cin // c.groups, c.k)
         n = cfg.logits_n
@@ -183,13 +221,13 @@ class DiscChain:
         def bwd():
             if out.grad is None:
                 return
-            self._backward(cfg, fm, audio, out.grad, eff, (w_post, dw_post, db_post), frozen)
+            self._backward(cfg, fm, audio, out.grad, eff, (w_post, dw_post, db_post), frozen, wf_d)
 
         tape.record(bwd)
         return out, fm
 
     # ---- backward -----------------------------------------------------------------------------------------------------------------
-    def _backward(self, cfg: _Cfg, fm: "ChainFmaps", audio: ag.Var, dlogits, eff, post_eff, frozen):
+    def _backward(self, cfg: _Cfg, fm: "ChainFmaps", audio: ag.Var, dlogits, eff, post_eff, frozen, wf_d):
         lib = _lib.load()
         convs, post, L = self.convs, self.conv_post, len(self.convs)
         A, G = cfg.A, cfg.G
@@ -217,8 +255,8 @@ class DiscChain:
             c = convs[i]
             need_dx = i > 1 or audio.needs_grad or not frozen  # G_1 feeds the first layer's weight gradient / the waveform's gradient
             if need_dx:
-                _lib.check(lib.evmi_conv_pkflat_dgrad(G[i + 1].ptr, G[i + 1].plane, eff[i][0].data_ptr(), G[i].ptr, G[i].plane, cfg.ws_d[i].data_ptr(),
-                                                      cfg.ws_d[i].numel(), 1, cfg.n_items, G[i + 1].T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups,
+                _lib.check(lib.evmi_conv_pkflat_dgrad(G[i + 1].ptr, G[i + 1].plane, wf_d[i].data_ptr(), G[i].ptr, G[i].plane, cfg.ws_d[i].data_ptr(),
+                                                      cfg.ws_d[i].numel(), cfg.n_items, G[i + 1].T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups,
                                                       cfg.lens[i], G[i].T, *fm_args(i), st), "evmi_conv_pkflat_dgrad")
                 ops._count_conv(cfg.n_items, cfg.lens[i + 1], c.cout, c.cin // c.groups, c.k)
             if not frozen:
@@ -251,6 +289,18 @@ class DiscChain:
                                                  c0.k, c0.stride, c0.pad, st), "evmi_disc_first_dgrad")
             ops._count_conv(cfg.n_items, cfg.lens[1], c0.cout, 1, c0.k)
             audio.accumulate(dxv if self.period == 1 else ops.period_view_bwd(dxv, cfg.n_audio, cfg.t_audio, self.period))
+
+
+def launch_fragments(jobs, device) -> None:
+    """jobs: (direction, layer, weights, buffer) as ``DiscChain.frag_jobs`` returns them -- any number of chains' jobs together; the
+    library packs 32 of them into a launch."""
+    if not jobs:
+        return
+    arr = (_lib.PkFlatJob * len(jobs))()
+    for j, (mode, c, w, wf) in zip(arr, jobs):
+        j.mode, j.c_in, j.c_out, j.k, j.stride, j.groups = mode, c.cin, c.cout, c.k, c.stride, c.groups
+        j.w, j.wf, j.wf_elems = w.data_ptr(), wf.data_ptr(), wf.numel()
+    _lib.check(_lib.load().evmi_conv_pkflat_fragments(len(jobs), arr, _lib.current_stream_ptr(device)), "evmi_conv_pkflat_fragments")
 
 
 class ChainFmaps:

@@ -648,6 +648,9 @@ class HiFiGANTrainer:
                 batches.append(b)
         for b in batches:
             b.materialize()
+        from .disc_chain import DiscChain
+
+        DiscChain.EPOCH[0] += 1  # weights may have changed: fragments made from older ones are stale
 
     def _reducer(self, group: ParamGroup):
         """Bucketed all-reduce of one optimiser's flat gradient buffer, overlapped with backward (None on one GPU)."""
@@ -714,6 +717,23 @@ class HiFiGANTrainer:
 
     def _sn_layers(self):
         return [layer for layer in self.d_layers() if isinstance(layer, SNConv)]
+
+    def _prepare_chain_fragments(self, probe: torch.Tensor, generator_step: bool):
+        """Packed discriminator chains (train/disc_chain.py): the bf16 weight fragments of every matrix-core layer of every chain for the
+        coming phase, on the current stream BEFORE the chains fork onto theirs -- a few launches for all eight discriminators, and the
+        generator step's real and generated calls share one set."""
+        jobs = []
+        for d in self.discriminators():
+            chain = _chain_for(d, getattr(d, "period", 1), probe)
+            if chain is None:
+                continue
+            sn = any(isinstance(layer, SNConv) for layer in d.layers())
+            # spectral norm: two calls (real, generated) with their own weights; in the generator step only the generated call runs backward
+            jobs += chain.frag_jobs(((False, True) if generator_step else (True, True)) if sn else (True,))
+        if jobs:
+            from .disc_chain import launch_fragments
+
+            launch_fragments(jobs, self.device)
 
     def _prepare_spectral_norm(self, n_calls: int):
         """Power iterations + effective weights of the spectral-norm scale's next forward calls, every layer on its own stream:
@@ -888,6 +908,7 @@ class HiFiGANTrainer:
         for layer in ctx["d_layers"]:
             layer.frozen = False
         self._prepare_spectral_norm(2)  # real call, then generated call
+        self._prepare_chain_fragments(y, generator_step=False)
         T = y.shape[-1]
         pair_t = torch.empty(1, 2 * B, T, device=self.device, dtype=torch.float32)
         ops.copy(y, out=pair_t[:, :B])
@@ -956,6 +977,7 @@ class HiFiGANTrainer:
         recon = [None]
         if adversarial:
             self._prepare_spectral_norm(2)  # real call, then generated call
+            self._prepare_chain_fragments(y, generator_step=True)
             gd_tape = ag.Tape()
             real = ag.Var(y, needs_grad=False)
             xs_r = self._scale_inputs(gd_tape, real)

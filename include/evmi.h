@@ -393,8 +393,12 @@ int evmi_tm_lrelu_bf16(const void* x_tm, void* y_tm, long long n_elems, float sl
  *                             feature-matching gradient (NULL: none)
  *   evmi_conv_pkflat_wgrad    dw[co][ci][j] (+)= sum_f dy[co][f] * x[ci][f * stride + j * dil - pad] over the flat index f of dy (groups
  *                             narrower than 32 channels run block-diagonally on the same kernel); ws: _wgrad_ws_elems floats
- *   evmi_conv_pkflat_prepare  the weight fragments of up to 16 calls in one launch (a job: the call's shape, its weights, its workspace);
- *                             the calls then pass prepared = 1.  ws of a call: evmi_conv_pkflat_ws_elems floats (0: shape not taken)
+ *   evmi_conv_pkflat_fragments  the bf16 matrix-core fragments of the weights of any number of (layer, direction) pairs, 32 per launch;
+ *                             they depend on the layer alone, so one buffer (evmi_conv_pkflat_frag_elems floats) serves every call of the
+ *                             layer while its weights stand: wf_dev of _fwd / _dgrad
+ *   evmi_conv_pkflat_tab      once per (call shape, workspace): the call's static K-block offset table at the head of its
+ *                             workspace (evmi_conv_pkflat_ws_elems floats, 0: shape not taken; the rest: split-K partial tiles, added in
+ *                             split order by a reduce pass)
  *   evmi_disc_first_*         the one-input-channel first layer on the waveform itself: item (b, c) of the period view is
  *                             x[h] = audio[b][h * period + c], reflected past the end (period 1: the waveform); forward -> flat packed,
  *                             weight / bias gradient from a flat packed dy, input gradient -> fp32 [n_items][H]
@@ -404,10 +408,10 @@ int evmi_tm_lrelu_bf16(const void* x_tm, void* y_tm, long long n_elems, float sl
  *   evmi_pkflat_rowsum        db_l[c] += sum of row c of dy_l (bias gradients of a whole chain in one launch pair) */
 typedef struct {
   int mode; /* 0: forward, 1: input gradient */
-  int n_items, T, c_in, c_out, k, stride, pad, dil, groups; /* T: item pitch of the call's flat INPUT (x / dy) */
-  const float* w;
-  float* ws;
-  long long ws_elems;
+  int c_in, c_out, k, stride, groups;
+  const float* w; /* [c_out][c_in / groups][k] fp32 */
+  void* wf;       /* fragment buffer of evmi_conv_pkflat_frag_elems floats, 16-byte aligned */
+  long long wf_elems;
 } evmi_pkflat_job;
 typedef struct {
   const void* a;
@@ -423,12 +427,15 @@ typedef struct {
 } evmi_pkflat_rows;
 long long evmi_conv_pkflat_ws_elems(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups);
 int evmi_conv_pkflat_plan(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups);
-int evmi_conv_pkflat_prepare(int n_jobs, const evmi_pkflat_job* jobs, void* stream);
-int evmi_conv_pkflat_fwd(const void* x_pk, long long x_plane, const float* w_dev, const float* bias_dev, void* y_pk, long long y_plane,
-                         float* ws_dev, long long ws_elems, int prepared, int n_items, int T_x, int c_in, int c_out, int k, int stride, int pad,
+int evmi_conv_pkflat_tab(int mode, int n_items, int T, int c_in, int c_out, int k, int stride, int pad, int dil, int groups, float* ws_dev,
+                         long long ws_elems, void* stream);
+long long evmi_conv_pkflat_frag_elems(int mode, int c_in, int c_out, int k, int stride, int groups);
+int evmi_conv_pkflat_fragments(int n_jobs, const evmi_pkflat_job* jobs, void* stream);
+int evmi_conv_pkflat_fwd(const void* x_pk, long long x_plane, const void* wf_dev, const float* bias_dev, void* y_pk, long long y_plane,
+                         float* ws_dev, long long ws_elems, int n_items, int T_x, int c_in, int c_out, int k, int stride, int pad,
                          int dil, int groups, int valid, int T_store, int act, float act_param, void* stream);
-int evmi_conv_pkflat_dgrad(const void* dy_pk, long long dy_plane, const float* w_dev, void* dx_pk, long long dx_plane, float* ws_dev,
-                           long long ws_elems, int prepared, int n_items, int T_dy, int c_in, int c_out, int k, int stride, int pad, int dil,
+int evmi_conv_pkflat_dgrad(const void* dy_pk, long long dy_plane, const void* wf_dev, void* dx_pk, long long dx_plane, float* ws_dev,
+                           long long ws_elems, int n_items, int T_dy, int c_in, int c_out, int k, int stride, int pad, int dil,
                            int groups, int valid, int T_store, const void* mask_pk, const void* fm_pk, long long mask_plane, int T_mask,
                            float mask_slope, float fm_scale, void* stream);
 long long evmi_conv_pkflat_wgrad_ws_elems(int n_items, int T_dy, int c_in, int c_out, int k, int stride, int dil, int groups);
