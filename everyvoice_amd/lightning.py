@@ -298,7 +298,10 @@ class FastSpeech2(_Module):
     """``fs2.model.FastSpeech2(config, stats, lang2id, speaker2id)`` (tests/model_stubs.py:44-58)."""
 
     def __init__(self, config: FastSpeech2Config | None = None, stats=None, lang2id: dict | None = None, speaker2id: dict | None = None,
-                 device=None, precision: str = "bf16", process_group=None):
+                 device=None, precision: str = "bf16", process_group=None, use_graph: bool = True, graph_buckets: tuple | None = (16, 64)):
+        """``use_graph`` / ``graph_buckets``: steps replay as HIP graphs per padded batch shape (train/fs2.py); batches are padded up to
+        multiples of (symbols, frames) = ``graph_buckets`` so that the variable-length batches of a real loader fall on a small set of
+        shapes (an LRU of captured shapes; unseen shapes run eagerly twice first).  ``model_kwargs`` of ``train_base_command`` reach here."""
         super().__init__()
         from .fs2 import Stats
 
@@ -307,6 +310,7 @@ class FastSpeech2(_Module):
         self.stats = stats or Stats()
         self.lang2id, self.speaker2id = dict(lang2id or {}), dict(speaker2id or {})
         self.precision, self.process_group = precision, process_group
+        self.use_graph, self.graph_buckets = bool(use_graph), tuple(graph_buckets) if graph_buckets else None
         self.trainer_ = None
         self._pending_ckpt = None
         if device is not None:
@@ -320,7 +324,8 @@ class FastSpeech2(_Module):
             return self
         old = self.trainer_.checkpoint() if self.trainer_ is not None else self._pending_ckpt
         self.trainer_ = FastSpeech2Trainer(self.config.model, self.stats, self.config.training, device=device, lang2id=self.lang2id,
-                                           speaker2id=self.speaker2id, process_group=self.process_group, precision=self.precision)
+                                           speaker2id=self.speaker2id, process_group=self.process_group, precision=self.precision,
+                                           use_graph=self.use_graph and device.type == "cuda", graph_buckets=self.graph_buckets)
         if old is not None:
             self.trainer_.load_checkpoint(old)
         self._pending_ckpt = None

@@ -432,7 +432,8 @@ class _AlignerT:
             self._pending_done = None  # joined: the aligner's backward (possibly in the NEXT captured stretch) must not wait on an
                                        # event that belongs to this one
 
-    def forward(self, tape: Tape, text_emb: Var, mel: Var, prior, text_lens32, mel_lens32, n_frames_dev, ctc_weight: float, bin_weight: float):
+    def forward(self, tape: Tape, text_emb: Var, mel: Var, prior, text_lens32, mel_lens32, n_frames_dev, ctc_weight: float, bin_on: bool,
+                bin_w_dev=None, bin_div_dev=None):
         """-> ``join``; ``join() -> (losses dict, hard durations [B, L] int32, hard alignment)`` once the main stream needs them.
         Records the backward of both losses into the projections / embedding."""
         from ..heavy import maximum_path
@@ -471,14 +472,15 @@ class _AlignerT:
         def join():
             from ..heavy import binarization_loss
             torch.cuda.current_stream(logprob.device).wait_event(mas_done)
-            if bin_weight > 0.0:
-                losses["attn_bin"] = (binarization_loss(hard, soft) * bin_weight).reshape(1)
+            if bin_on:  # the weight ramps with the epoch: it is a device scalar, so the launch sequence (and a captured graph) stays
+                losses["attn_bin"] = ops.elementwise(ops.EW_MUL, binarization_loss(hard, soft).reshape(1), bin_w_dev)
             return losses, dur, hard
 
         def bwd():
             self.join_side()  # (the CTC side stream: its gradient is needed now)
-            dq, dk = ops.align_attention_bwd(q.data, k.data, soft, logprob, prior, hard if bin_weight > 0.0 else None, dlogprob, text_lens32,
-                                             self.temperature, bin_weight, bin_count=n_frames_dev)
+            # (binarisation weight / frame count: one device scalar, frames / weight, divides a unit scale)
+            dq, dk = ops.align_attention_bwd(q.data, k.data, soft, logprob, prior, hard if bin_on else None, dlogprob, text_lens32,
+                                             self.temperature, 1.0 if bin_on else 0.0, bin_count=bin_div_dev if bin_on else n_frames_dev)
             q.accumulate(dq)
             k.accumulate(dk)
 
@@ -747,7 +749,16 @@ class FastSpeech2Trainer:
         world, rank = self._world_rank()
         base = ((((self._seed * 1000003 + self.global_step) * world + rank) << 16)) & 0x7FFFFFFFFFFFFFFF
         ops.store_u64(self._seed_base, base)
-        ops.store_f32(self._scal, [self.learning_rate(self.global_step + 1), meta["n_tok"], meta["n_frames"], meta["n_el"]])
+        bin_w = self._bin_weight()
+        ops.store_f32(self._scal, [self.learning_rate(self.global_step + 1), meta["n_tok"], meta["n_frames"], meta["n_el"], bin_w,
+                                   meta["n_frames"] / bin_w if bin_w > 0.0 else 1.0])
+
+    def _bin_weight(self) -> float:
+        """Weight of the binarisation loss at the current epoch (linear warm-up over ``attn_bin_loss_warmup_epochs``; 0: the term is off)."""
+        if self.aligner is None:
+            return 0.0
+        tr = self.training
+        return tr.attn_bin_loss_weight * min(self.current_epoch / max(1, tr.attn_bin_loss_warmup_epochs), 1.0)
 
     def forward_backward(self, batch: dict) -> dict:
         """Forward in training mode + every loss + backward; gradients are left in ``self.params.grad``."""
@@ -809,10 +820,8 @@ class FastSpeech2Trainer:
 
         losses = {}
         if learn:
-            epochs = max(1, tr.attn_bin_loss_warmup_epochs)
-            bin_w = tr.attn_bin_loss_weight * min(self.current_epoch / epochs, 1.0)
             align_join = self.aligner.forward(tape, embed(False), Var(mel_t, needs_grad=False), batch.get("attn_prior"), lens, mel_lens, n_frames,
-                                              tr.attn_ctc_loss_weight, bin_w)
+                                              tr.attn_ctc_loss_weight, self._bin_weight() > 0.0, self._scal[4:5], self._scal[5:6])
         else:
             dur = batch["durations"]
 
@@ -977,9 +986,8 @@ class FastSpeech2Trainer:
         with torch.cuda.stream(self._stream):
             losses = self._training_step(batch)
         caller.wait_stream(self._stream)
-        if not self.last_step_was_graph:
-            for v in losses.values():
-                v.record_stream(caller)
+        for v in losses.values():
+            v.record_stream(caller)
         return losses
 
     GRAPH_WARMUP_STEPS = 2
@@ -1003,7 +1011,9 @@ class FastSpeech2Trainer:
                 for k, v in d.items():  # into the captured step's static inputs (same shapes by construction of the key)
                     entry["inputs"][k].copy_(v)
                 self._replay(entry)
-                losses = entry["losses"]
+                # copies: the graph's own loss tensors are overwritten by the next replay of this shape, and a caller may keep
+                # losses across steps (running means, deferred logging) -- eager steps hand out fresh tensors too
+                losses = {k: v.clone() for k, v in entry["losses"].items()}
                 self.last_step_was_graph = True
         finally:
             ops.CONV_BACKEND["operands"] = prev
@@ -1043,8 +1053,8 @@ class FastSpeech2Trainer:
     # -- HIP-graph execution -----------------------------------------------------------------------------------------------------
     def _graph_key(self, d: dict, meta: dict):
         tr = self.training
-        bin_w = tr.attn_bin_loss_weight * min(self.current_epoch / max(1, tr.attn_bin_loss_warmup_epochs), 1.0) if self.aligner is not None else 0.0
-        return (meta["B"], meta["L"], meta["T"], tuple(sorted(d)), self.precision, bin_w, tr.gradient_clip_val, self.pg is not None)
+        # (the binarisation weight itself is a device scalar: only whether the term exists shapes the launch sequence)
+        return (meta["B"], meta["L"], meta["T"], tuple(sorted(d)), self.precision, self._bin_weight() > 0.0, tr.gradient_clip_val, self.pg is not None)
 
     def _graph_entry(self, d: dict, meta: dict):
         """The captured step for this batch's padded shape, or None (not seen often enough yet, or capturing failed: eager)."""
