@@ -302,62 +302,61 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
     typedef __attribute__((address_space(4))) const int cint_t;
     cint_t* tbw = (cint_t*)(a.tab + q0);
     auto tb_at = [&](int qi) { return make_int2(tbw[2 * qi], tbw[2 * qi + 1]); };
-    // U K blocks per loop iteration.  (U = 4 for the 32x32 wave tiles measured 5 % slower than 2: those tiles read two 1 KB
-    // fragments per MFMA, i.e. they are bound by LDS read bandwidth -- 30 % of it bank conflicts on the short-row layers --
-    // not by the latency of one round trip.)
-    constexpr int U = 2;
-    int2 pe[2 * U];  // table entries of the step's first 2U blocks, fetched BEFORE the wait for its operands
-#pragma unroll
-    for (int u = 0; u < 2 * U; ++u) pe[u] = tb_at(min(u, nq - 1));
-    wait_vmcnt_le(n_next);  // step t has landed (this wave's part); step t+1 may still be in flight
+    // step t has landed (this wave's part); with three slots step t+1 may still be in flight (two slots -- what the planner picks --
+    // wait for everything: the runtime-count form is a chain of ~8 branches per step)
+    if (nst == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else wait_vmcnt_le(n_next);
     lds_barrier();          // ... everyone's part; the slot about to be refilled was last read in step t-1
     {
       const int issued = t + nst - 1 < nsteps ? issue(t + nst - 1, slot_ahead) : 0;
       n_next = nst == 3 ? issued : 0;
     }
     const uint4* sm = smem + slot * stage;
-    bf16x8 fa[U][MT], fb[U][NT], na[U][MT], nb[U][NT];
-    auto load = [&](bf16x8 (&da)[MT], bf16x8 (&db)[NT], int qi, int2 e) {
-      const int lo = kh ? e.y : e.x;
+    // The K loop, four K blocks per trip on FOUR operand register sets used in rotation: the LDS reads of blocks q + 2, q + 3 are
+    // in flight before the MFMAs of q, q + 1 issue, and no set is ever copied (the two-set form with a "next" pair moved 16 register
+    // pairs per trip: with the address arithmetic, ~45 vector instructions beside 8 MFMAs).  The swizzle of the strided layers'
+    // windows is compiled only into the loop that needs it.  Reads past the step's last block re-read that block (in bounds, unused).
+    auto kloop = [&](auto swz_c) {
+      constexpr bool SWZ = decltype(swz_c)::value;
+      bf16x8 fa[4][MT], fb[4][NT];
+      auto load = [&](int set, int qi) {
+        qi = min(qi, nq - 1);
+        const int2 e = tb_at(qi);
+        const int lo = kh ? e.y : e.x;
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) da[mt] = *reinterpret_cast<const bf16x8*>(sm + abase[mt] + qi * 64);
+        for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *reinterpret_cast<const bf16x8*>(sm + abase[mt] + qi * 64);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int p = colu[nt] + lo;
-        db[nt] = *reinterpret_cast<const bf16x8*>(sm + a_units + (p ^ ((p >> 4) & swz)));
+        for (int nt = 0; nt < NT; ++nt) {
+          const int p = colu[nt] + lo;
+          fb[set][nt] = *reinterpret_cast<const bf16x8*>(sm + a_units + (SWZ ? (p ^ ((p >> 4) & swz)) : p));
+        }
+      };
+      auto mma = [&](int set) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][mt], fb[set][nt], acc[mt][nt], 0, 0, 0);
+      };
+      load(0, 0);
+      load(1, 1);
+      for (int qi = 0; qi < nq; qi += 4) {
+        load(2, qi + 2);
+        load(3, qi + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        if (qi + 1 < nq) mma(1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (qi + 2 >= nq) break;
+        load(0, qi + 4);
+        load(1, qi + 5);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(2);
+        if (qi + 3 < nq) mma(3);
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
-    auto mma = [&](const bf16x8 (&da)[MT], const bf16x8 (&db)[NT]) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[mt], db[nt], acc[mt][nt], 0, 0, 0);
-    };
-    // U K blocks per iteration: the LDS reads of blocks qi+U .. qi+2U-1 are in flight before the MFMAs of qi .. qi+U-1 issue,
-    // and the table entries of the iteration after that are fetched one iteration early (past the end: re-reads of the last
-    // block, in-bounds and unused).
-#pragma unroll
-    for (int u = 0; u < U; ++u) load(fa[u], fb[u], min(u, nq - 1), pe[u]);
-    for (int qi = 0; qi < nq; qi += U) {
-      int2 fe[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) fe[u] = tb_at(min(qi + 2 * U + u, nq - 1));
-#pragma unroll
-      for (int u = 0; u < U; ++u) load(na[u], nb[u], min(qi + U + u, nq - 1), pe[U + u]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (u == 0 || qi + u < nq) mma(fa[u], fb[u]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fa[u][mt] = na[u][mt];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) fb[u][nt] = nb[u][nt];
-        pe[U + u] = fe[u];
-      }
-    }
+    if (swz) kloop(std::true_type{});
+    else kloop(std::false_type{});
   }
 
   // ---- epilogue: D layout: lane column = output position, registers = output channels ----
