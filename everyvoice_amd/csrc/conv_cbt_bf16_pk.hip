@@ -48,7 +48,7 @@ struct ConvPkArgs {
   int phases;
   long long wf_phase_stride;  // units
   int ph_shift[8], ph_nout[8], ph_off[8];
-  int xcd_remap;
+  int xcd_remap, xcd_hb;  // xcd_hb: m-tiles per band of the XCD-ordered tile list (see the kernel)
   // split-K: grid.x = column tiles * ksplit; split sp takes the ring steps [sp * steps_per_split, ...) and stores its raw
   // accumulators to part[sp][phase][c_out][part_ld] (part_ld = B * longest phase); conv_pk_reduce_kernel adds them in split
   // order + epilogue
@@ -173,7 +173,15 @@ __global__ __launch_bounds__(256) void prep_pk_kernel(PackArgs p, WfragArgs f) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+// ADIR: the weight fragments never pass through the LDS.  A fragment is already laid out per lane (wfrag: [K block][lane][8 bf16]),
+// so a wave fetches the fragments of ITS rows for the next ring step straight into registers (two sets of PK_ADIR_KBS x MT
+// fragments, alternating) while the current step computes.  Why: every tile shape and a K loop with a third of the vector
+// instructions ran the 1024-channel layers at the same ~380 TFLOP/s (tools/pkflat_bench.py) -- what did not change between them
+// was the number of 1 KB LDS-direct loads per workgroup and step (weights 2/3 of them), and those are issued at one per ~40-100
+// cycles per CU while the LDS feeds the matrix cores.  With the weights off that path the LDS holds input windows
+// only (a third of the bytes) and serves half the fragment reads.
+constexpr int PK_ADIR_KBS = 5;
+template <int BM, int BN, int WM, int WN, bool ADIR = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) {
   static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves");
   constexpr int NW = WM * WN;  // eight-wave tiles: the loads of a ring step are issued by twice the waves (an LDS-direct load costs its
@@ -187,13 +195,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
   const int kh = lane >> 5, ln = lane & 31;
 
   unsigned bx = blockIdx.x, by = blockIdx.y;
-  if (a.xcd_remap) {  // every XCD (private L2) takes a contiguous range of the m-tile-major tile list
+  if (a.xcd_remap) {
+    // Workgroups go to the eight XCDs (private L2s) round robin; every XCD takes a contiguous run of the tile list.  The list is
+    // ordered in BANDS of xcd_hb m-tiles, column by column inside a band, so a run is a compact block of tiles -- xcd_hb m-tiles
+    // by (columns / runs per band) n-tiles -- whose weight rows and window columns are each fetched into that L2 once and shared.
+    // (xcd_hb = 1 is the plain m-tile-major list: a run is one m-tile across many columns, i.e. every XCD pulls ALL the input
+    // windows through its L2 -- eight copies of the activations over the fabric, the traffic the 1024-channel layers were bound by.)
     const unsigned nwg = gridDim.x * gridDim.y, orig = blockIdx.x + gridDim.x * blockIdx.y;
     if (nwg >= 16) {
       const unsigned q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
       const unsigned L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-      by = L / gridDim.x;
-      bx = L - by * gridDim.x;
+      const unsigned hb = (unsigned)a.xcd_hb, band = L / (hb * gridDim.x), rem = L - band * hb * gridDim.x;
+      const unsigned hcur = min(hb, gridDim.y - band * hb);
+      bx = rem / hcur;
+      by = band * hb + (rem - bx * hcur);
     }
   }
   const int g = by / a.mtiles_per_group, mt_idx = by % a.mtiles_per_group;
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
   const int m_valid = min(BM, a.cout_g - mt_idx * BM);
   const long long plane = (long long)a.B * a.Tp;  // units per octet row
   const uint4* xwin = a.xp + (long long)g * a.octs * plane + (long long)b_first * a.Tp + (long long)to_first * s + shift;
-  const int a_units = MBT * kbs * 64;
+  const int a_units = ADIR ? 0 : MBT * kbs * 64;
   const int stage = a_units + a.rows_step * xrow;
   // Stride-2 / stride-4 layers read units (column * stride + tap): the 16 lanes of a ds_read_b128 group then share 8 / 4 of the
   // 16 sixteen-byte slots of the bank row (2- / 4-way conflicts: 21-32 % of the LDS cycles of the scale discriminators' layers).
@@ -263,15 +278,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
     uint4* sx = sa + a_units;
     int issued = 0;
     int u = wave;
+    if (!ADIR) {
 #pragma unroll
-    for (int mbi = 0; mbi < MBT; ++mbi) {
-      const uint4* src = wf_tile + ((long long)min(mbi, mb_last) * a.kblocks + q0) * 64 + lane;
-      uint4* dst = sa + mbi * kbs * 64;
-      for (; u < nq; u += NW) {
-        pk_lds_direct(src + u * 64, dst + u * 64);
-        ++issued;
+      for (int mbi = 0; mbi < MBT; ++mbi) {
+        const uint4* src = wf_tile + ((long long)min(mbi, mb_last) * a.kblocks + q0) * 64 + lane;
+        uint4* dst = sa + mbi * kbs * 64;
+        for (; u < nq; u += NW) {
+          pk_lds_direct(src + u * 64, dst + u * 64);
+          ++issued;
+        }
+        u -= nq;
       }
-      u -= nq;
     }
     const int o_lo = (2 * q0) / k;
     const int o_hi = min(a.octs - 1, (2 * (q0 + nq) - 1) / k);
@@ -285,6 +302,76 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
     return issued;
   };
 
+  if constexpr (ADIR) {
+    // ---- weights in registers: steps alternate between two fragment sets and two LDS slots (window rows only) ----
+    constexpr int KBS = PK_ADIR_KBS;
+    typedef __attribute__((address_space(4))) const int cint_t;
+    bf16x8 areg[2][KBS][MT];
+    const uint4* arow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) arow[mt] = wf_tile + (long long)min(wm * MT + mt, mb_last) * a.kblocks * 64 + lane;
+    const int q_last = a.kblocks - 1;
+    auto load_a = [&](auto par_c, int t) {  // the fragments of step t into set PAR (K blocks past the end re-read the last one)
+      constexpr int PAR = decltype(par_c)::value;
+      const int q0 = t * KBS;
+#pragma unroll
+      for (int qi = 0; qi < KBS; ++qi) {
+        const int q = min(q0 + qi, q_last);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) areg[PAR][qi][mt] = __builtin_bit_cast(bf16x8, arow[mt][(long long)q * 64]);
+      }
+    };
+    auto step = [&](auto par_c, int t) {
+      constexpr int PAR = decltype(par_c)::value;
+      const int q0 = t * KBS;
+      const int nq = min(KBS, a.kblocks - q0);
+      cint_t* tbw = (cint_t*)(a.tab + q0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // step t has landed: window rows in slot PAR, fragments in set PAR
+      lds_barrier();
+      if (t + 1 < nsteps) {
+        issue(t + 1, PAR ^ 1);
+        if constexpr (PAR == 0) load_a(std::integral_constant<int, 1>{}, t + 1);
+        else load_a(std::integral_constant<int, 0>{}, t + 1);
+      }
+      const uint4* sm = smem + PAR * stage;
+      auto kloop = [&](auto swz_c) {
+        constexpr bool SWZ = decltype(swz_c)::value;
+        bf16x8 fb[3][NT];  // blocks qi, qi + 1, qi + 2 in flight
+        auto load_b = [&](int set, int qi) {
+          qi = min(qi, nq - 1);
+          const int lo = kh ? tbw[2 * qi + 1] : tbw[2 * qi];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const int p = colu[nt] + lo;
+            fb[set][nt] = *reinterpret_cast<const bf16x8*>(sm + (SWZ ? (p ^ ((p >> 4) & swz)) : p));
+          }
+        };
+        load_b(0, 0);
+        load_b(1, 1);
+#pragma unroll
+        for (int qi = 0; qi < KBS; ++qi) {
+          if (qi + 2 < KBS) load_b((qi + 2) % 3, qi + 2);
+          if (qi < nq) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(areg[PAR][qi][mt], fb[qi % 3][nt], acc[mt][nt], 0, 0, 0);
+          }
+        }
+      };
+      if (swz) kloop(std::true_type{});
+      else kloop(std::false_type{});
+    };
+    if (nsteps > t_lo) {
+      issue(t_lo, 0);
+      load_a(std::integral_constant<int, 0>{}, t_lo);
+    }
+    for (int t = t_lo; t < nsteps; t += 2) {
+      step(std::integral_constant<int, 0>{}, t);
+      if (t + 1 < nsteps) step(std::integral_constant<int, 1>{}, t + 1);
+    }
+  } else {
   int n_next = 0;
   const int nst = a.nst;
   if (nsteps > t_lo) issue(t_lo, 0);
@@ -358,6 +445,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
     if (swz) kloop(std::true_type{});
     else kloop(std::false_type{});
   }
+  }  // (!ADIR)
 
   // ---- epilogue: D layout: lane column = output position, registers = output channels ----
   if (a.ksplit > 1) {  // raw partial tile: rows = output channels, columns = the flat (item, position) index (coalesced)
@@ -553,7 +641,8 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct PkTile { int bm, bn; };
 // (index 7, 8: eight-wave forms of 128 x 256 and 128 x 128 -- 64 x 64 / 64 x 32 per wave)
-static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {64, 256}, {32, 256}, {128, 256}, {128, 256}, {128, 128}};
+// (index 9: 128 x 128 with the weight fragments in registers -- conv_pk_kernel<..., ADIR>)
+static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {64, 256}, {32, 256}, {128, 256}, {128, 256}, {128, 128}, {128, 128}};
 constexpr int kNumPkTiles = sizeof(kPkTiles) / sizeof(kPkTiles[0]);
 
 static int pk_env_int(const char* name, int dflt) {
@@ -643,11 +732,13 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     a.ksplit = ks;
   }
   // candidate tiles in order of preference; the next one is tried while the staged window does not fit
-  int cand[8], nc = 0;
+  int cand[12], nc = 0;
   // 256-column tiles for narrow layers on many columns (the generator's last stages: 65-131 k columns, 32-64 channels; half the
   // prologues / epilogues per column): measured 26.6 vs 25.3 ms per GAN step (EVMI_PK_WIDE=1 vs 0) -- kept as a switch, off
   static const int wide = pk_env_int("EVMI_PK_WIDE", 0);
-  if (a.ksplit > 1) { cand[nc++] = 0; cand[nc++] = 1; cand[nc++] = 2; cand[nc++] = 3; }
+  // weights in registers for the wide tile wherever it would be picked (EVMI_PK_ADIR=0: the LDS form, A/B)
+  static const int use_adir = pk_env_int("EVMI_PK_ADIR", 1);
+  if (a.ksplit > 1) { if (use_adir) cand[nc++] = 9; cand[nc++] = 0; cand[nc++] = 1; cand[nc++] = 2; cand[nc++] = 3; }
   else if (a.cout_g > 64) {
     // Measured at the FastSpeech2 decoder's shapes (32 x 814 columns; tools/debug/pk_tile_bench.py, pack + convolution):
     //  * 128 x 256 tiles for long contractions on many columns (the postnet's 512 -> 512, k = 5: 150 vs 180 us): the staged window
@@ -660,7 +751,7 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     //    eight-wave 128 x 128 tile -- 71 vs 82 us (256 -> 1024), 56 vs 62 us (256 -> 768), pack included (tools/pk_tile_sweep.py);
     //    slower everywhere else (longer contractions, short items, grouped layers), as is the eight-wave 128 x 256 tile
     if (a.kblocks <= 16 && a.k == 1 && blocks(8) >= 2 * want0) cand[nc++] = 8;
-    if (blocks(0) >= want0) cand[nc++] = 0;
+    if (blocks(0) >= want0) { if (use_adir) cand[nc++] = 9; cand[nc++] = 0; }
     if (blocks(1) >= want || nc == 0) cand[nc++] = blocks(1) >= want ? 1 : 2;
     cand[nc++] = 2; cand[nc++] = 3;
   } else if (a.cout_g > 32) {
@@ -687,8 +778,9 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     if (win > 64 * 24) { if (last) return "input window too long"; continue; }
     a.pieces = (int)((win + 63) / 64);
     a.xrow = a.pieces * 64;
+    const bool adir = ti == 9;
     auto rows_of = [&](int kbs) { return std::min(a.octs, (2 * kbs + a.k - 2) / a.k + 1); };
-    auto lds_of = [&](int kbs, int nst) { return (size_t)nst * ((bm / 32) * kbs * 64 + rows_of(kbs) * a.xrow) * 16; };
+    auto lds_of = [&](int kbs, int nst) { return (size_t)nst * ((adir ? 0 : (bm / 32) * kbs * 64) + rows_of(kbs) * a.xrow) * 16; };
     if (lds_of(1, 2) > one_wg) { if (last) return "LDS budget"; continue; }
     // deepest step (K blocks) that leaves two workgroups per CU; three slots when they fit at that depth
     int kbs = 1, nst = 2;
@@ -698,9 +790,11 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     // (three slots at 2/3 of the depth measured slower on every layer: the per-step cost -- barrier, scalar bookkeeping, the
     // un-overlapped first fragment reads -- outweighs the extra step of load latency hidden)
     if (0 && lds_of(std::max(1, kbs * 2 / 3), 3) <= budget && kbs >= 3) { nst = 3; kbs = std::max(1, kbs * 2 / 3); }
-    const int fk = 0, fn = 0;
-    if (fn == 2 || fn == 3) nst = fn;
-    if (fk > 0) kbs = std::min(fk, a.kblocks);
+    if (adir) {  // fixed step depth (the fragment registers are indexed at compile time), two slots
+      if (a.kblocks < PK_ADIR_KBS || lds_of(PK_ADIR_KBS, 2) > two_wg) { if (last) return "LDS budget"; continue; }
+      kbs = PK_ADIR_KBS;
+      nst = 2;
+    }
     while (kbs > 1 && lds_of(kbs, nst) > one_wg) --kbs;
     if (lds_of(kbs, nst) > one_wg) return "LDS budget";
     a.kb_step = kbs;
@@ -710,7 +804,7 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     pl.lds = lds_of(kbs, nst);
     if ((n_total + bn - 1) / bn > 0x7fffffffLL || groups * a.mtiles_per_group > 65535 || groups * a.mblocks > 65535) return "grid limits";
     a.ntiles_n = (int)((n_total + bn - 1) / bn);
-    if (a.ksplit > 1 && ti != ti_first) a.ksplit = 1;  // (the wide tile did not fit: no split)
+    if (a.ksplit > 1 && ti != ti_first && !(ti == 0 && ti_first == 9)) a.ksplit = 1;  // (the wide tile did not fit: no split)
     if (a.ksplit > 1) {
       const int nsteps_all = (a.kblocks + kbs - 1) / kbs;
       a.ksplit = std::min(a.ksplit, nsteps_all);
@@ -718,6 +812,23 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
       a.ksplit = (nsteps_all + a.steps_per_split - 1) / a.steps_per_split;  // no empty splits
     }
     pl.grid = dim3((unsigned)(a.ntiles_n * a.ksplit), groups * a.mtiles_per_group, a.phases);
+    {  // band height of the XCD order: the run of an XCD (1/8 of the list) as square as the tile grid allows -- fewest unique
+       // weight rows + window columns per L2.  Rows of different groups share nothing: bands stay inside a group's m-tiles.
+      const long long Y = a.mtiles_per_group, X = (long long)a.ntiles_n * a.ksplit, N = a.ntiles_n;
+      double best = 1e300;
+      a.xcd_hb = 1;
+      static const int fixed_hb = pk_env_int("EVMI_PK_XCD_HB", 0);
+      for (int xm = 8; xm >= 1; xm >>= 1) {
+        const long long hb = (Y + xm - 1) / xm;
+        if (groups > 1 && hb > 1 && (Y % hb)) continue;  // (a band must not straddle two groups)
+        const double run = std::max(1.0, (double)X * Y * groups / 8.0 / hb);  // columns per run
+        const double c = std::max(1.0, run / N);                              // K slices (splits) a run spans
+        const double cols = std::min<double>(run, N);
+        const double cost = (hb * bm + cols * bn) * c / a.ksplit;
+        if (cost < best) { best = cost; a.xcd_hb = (int)hb; }
+      }
+      if (fixed_hb > 0) a.xcd_hb = (int)std::min<long long>(fixed_hb, Y);
+    }
     break;
   }
   pl.c_out = a.cout_g * groups;
@@ -766,6 +877,14 @@ static int launch_pk_tile(ConvPkArgs& a, const PkPlan& pl, hipStream_t stream) {
     case 6: EVMI_PK_LAUNCH(128, 256, 2, 2, 6) break;
     case 7: EVMI_PK_LAUNCH(128, 256, 2, 4, 7) break;
     case 8: EVMI_PK_LAUNCH(128, 128, 2, 4, 8) break;
+    case 9: {
+      if (lds > configured[9]) {
+        EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pk_kernel<128, 128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured[9] = lds;
+      }
+      hipLaunchKernelGGL((conv_pk_kernel<128, 128, 2, 2, true>), pl.grid, dim3(256), lds, stream, a);
+      break;
+    }
     default: EVMI_PK_LAUNCH(32, 128, 1, 4, 3) break;
   }
 #undef EVMI_PK_LAUNCH

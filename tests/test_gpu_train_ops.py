@@ -444,16 +444,16 @@ def test_bf16_packed_kernels_edge_shapes(cuda_device, bf16_operands, case):
 # instantiations are what evmi_conv1d_*_bf16pk_plan reports with no EVMI_PK_* switch set (tile index: see include/evmi.h)
 BENCH_SHAPE_CASES = [
     ("fs2 postnet 512->512 k5 on 32 x 814", 32, 814, 512, 512, 5, 1, 2, 1, 1, 6, 6, 8),        # conv_pk_kernel<128, 256>
-    ("fs2 ffn 256->1024 on 32 x 814", 32, 814, 256, 1024, 1, 1, 0, 1, 1, 8, 0, 4),             # the eight-wave <128, 128> for short contractions
-    ("fs2 ffn 1024->256 on 32 x 814", 32, 814, 1024, 256, 1, 1, 0, 1, 1, 0, 8, 4),
-    ("fs2 postnet 80->512 k5 on 32 x 947", 32, 947, 80, 512, 5, 1, 2, 1, 1, 0, 0, 8),          # dgrad: split-K <128, 128>
+    ("fs2 ffn 256->1024 on 32 x 814", 32, 814, 256, 1024, 1, 1, 0, 1, 1, 8, 9, 4),             # the eight-wave <128, 128> for short contractions
+    ("fs2 ffn 1024->256 on 32 x 814", 32, 814, 1024, 256, 1, 1, 0, 1, 1, 9, 8, 4),             # 9: <128, 128> with the weight fragments in registers
+    ("fs2 postnet 80->512 k5 on 32 x 947", 32, 947, 80, 512, 5, 1, 2, 1, 1, 9, 9, 8),          # dgrad: split-K <128, 128>
     ("fs2 encoder 256->768 on 32 x 187", 32, 187, 256, 768, 1, 1, 0, 1, 1, 1, 2, 4),           # <64, 128> / <64, 64>
     ("gan generator c32 k11 d5 on 16 x 8192", 16, 8192, 32, 32, 11, 1, 25, 5, 1, 3, 3, 8),     # <32, 128>
     ("gan generator c64 k7 d3 on 16 x 4096", 16, 4096, 64, 64, 7, 1, 9, 3, 1, 1, 1, 8),        # <64, 128>
     ("gan generator c128 k3 on 16 x 2048", 16, 2048, 128, 128, 3, 1, 1, 1, 1, 1, 1, 4),
-    ("gan generator c512 k11 d5 on 16 x 32", 16, 32, 512, 512, 11, 1, 25, 5, 1, 0, 0, 8),      # split-K over workgroups
-    ("mpd p2 32->128 s3 on 64 x 4096", 64, 4096, 32, 128, 5, 3, 2, 1, 1, 0, 3, 8),
-    ("mpd p11 1024->1024 on 352 x 28", 352, 28, 1024, 1024, 5, 1, 2, 1, 1, 0, 0, 8),           # short items: <128, 128>
+    ("gan generator c512 k11 d5 on 16 x 32", 16, 32, 512, 512, 11, 1, 25, 5, 1, 9, 9, 8),      # split-K over workgroups
+    ("mpd p2 32->128 s3 on 64 x 4096", 64, 4096, 32, 128, 5, 3, 2, 1, 1, 9, 3, 8),
+    ("mpd p11 1024->1024 on 352 x 28", 352, 28, 1024, 1024, 5, 1, 2, 1, 1, 9, 9, 8),           # short items: <128, 128>
     ("msd 512->1024 k41 s4 g16 on 32 x 512", 32, 512, 512, 1024, 41, 4, 20, 1, 16, 1, 3, 8),
     ("msd 128->128 k41 s2 g4 on 32 x 8192", 32, 8192, 128, 128, 41, 2, 20, 1, 4, 3, 3, 8),
 ]
@@ -474,7 +474,7 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
     name, B, T, cin, cout, k, s, p, d, groups, tile_f, tile_d, taps_w = case
     lib = _lib.load()
     n_out = (T + 2 * p - d * (k - 1) - 1) // s + 1
-    if not any(os.environ.get(v) for v in ("EVMI_PK_TILE", "EVMI_PK_SPLITK", "EVMI_PK_WIDE")):
+    if not any(os.environ.get(v) for v in ("EVMI_PK_TILE", "EVMI_PK_SPLITK", "EVMI_PK_WIDE", "EVMI_PK_ADIR", "EVMI_PK_XCD_HB")):
         geo = (B, cin, T, cout, n_out, k, s, p, d, groups)
         assert lib.evmi_conv1d_cbt_bf16pk_plan(*geo) % 16 == tile_f, name
         assert lib.evmi_conv1d_dgrad_cbt_bf16pk_plan(*geo) % 16 == tile_d, name
@@ -495,9 +495,10 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
         assert err <= 1e-4, (name, what, err)  # fp32 accumulation of exact bf16 products: summation order only
 
 
-@pytest.mark.parametrize("tile", range(9))
+@pytest.mark.parametrize("tile", range(10))
 def test_packed_conv_every_tile_forced(tile):
-    """conv_pk_kernel<128,128 | 64,128 | 64,64 | 32,128 | 64,256 | 32,256 | 128,256> and the eight-wave <128,256> / <128,128> (indices 7, 8):
+    """conv_pk_kernel<128,128 | 64,128 | 64,64 | 32,128 | 64,256 | 32,256 | 128,256>, the eight-wave <128,256> / <128,128> (indices 7, 8) and
+    <128,128> with the weight fragments in registers (index 9):
     the planner picks one per shape; here every one
     of them is FORCED (EVMI_PK_TILE, read once per process -> a child process each) through the bf16 comparisons with torch of
     this file -- the bench shapes, the edge shapes and the strided / grouped input-gradient shapes -- so a tile the planner starts choosing tomorrow (as <128, 256>
@@ -514,9 +515,10 @@ def test_packed_conv_every_tile_forced(tile):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("switch", ["EVMI_PK_SPLITK=0", "EVMI_PK_WIDE=1", "EVMI_WG_SPLITS=1", "EVMI_WG_NST=2"])
+@pytest.mark.parametrize("switch", ["EVMI_PK_SPLITK=0", "EVMI_PK_WIDE=1", "EVMI_WG_SPLITS=1", "EVMI_WG_NST=2", "EVMI_PK_ADIR=0", "EVMI_PK_XCD_HB=1"])
 def test_packed_conv_planner_switches(switch):
-    """The planner's other A/B switches (no split-K, 256-column tiles for narrow layers, unsplit / two-slot weight gradients)
+    """The planner's other A/B switches (no split-K, 256-column tiles for narrow layers, unsplit / two-slot weight gradients, weight
+    fragments through the LDS everywhere, the plain m-tile-major XCD order)
     through the same comparisons in a child process each."""
     import os
     import subprocess

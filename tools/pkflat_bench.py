@@ -50,7 +50,12 @@ def timed(fn):
 
 print(f"{'layer':9s} {'items':>5s} {'t_in':>5s} {'cin':>5s} {'cout':>5s} {'k':>3s} {'s':>2s} {'g':>3s} | {'fwd us':>8s} {'TF/s':>6s} {'plan':>5s} | {'dgrad us':>8s} {'TF/s':>6s} {'plan':>5s} | {'wgrad us':>8s} {'TF/s':>6s} | frag us")
 tot = [0.0, 0.0, 0.0, 0.0]
+import os  # noqa: E402
+
+ONLY = os.environ.get("PKFLAT_ONLY")  # e.g. "mpd2.4": one shape (for a profiler run)
 for name, n, t_in, cin, cout, k, s, pad, g in SHAPES:
+    if ONLY and name != ONLY:
+        continue
     t_out = _conv_len(t_in, k, s, pad)
     right = (t_out - 1) * s + (k - 1) - pad - (t_in - 1)
     gdy = -(-max(0, k - 1 - pad) // s)
