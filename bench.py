@@ -224,6 +224,29 @@ def roofline_from_records(passes: list[list[dict]]) -> dict:
     }
 
 
+def git_head() -> str | None:
+    """The commit this tree was built from: `git rev-parse HEAD`, or the `.git_head` file a gpurun snapshot carries (no .git there)."""
+    import subprocess
+
+    try:
+        r = subprocess.run(["git", "-C", str(ROOT), "rev-parse", "HEAD"], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            return r.stdout.strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    f = ROOT / ".git_head"
+    return f.read_text().strip() if f.exists() else None
+
+
+def profile_commit(summary_path) -> str | None:
+    """The commit a committed PMC summary was collected at (its .meta.json), so a reader sees whether `traffic` is from this tree."""
+    meta = Path(str(summary_path).replace("_pmc_summary.json", "_pmc_summary.meta.json"))
+    try:
+        return json.loads(meta.read_text()).get("commit")
+    except (OSError, ValueError):
+        return None
+
+
 def recorded_pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary (profiles/*_pmc_summary.json,
     produced by tools/gpu_profile.sh + tools/pmc_summarize.py from separate rocprofv3 --pmc passes of this
@@ -254,7 +277,7 @@ def cpu_baseline(frames: int, batch: int) -> dict:
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     best = None
     with torch.no_grad():
-        probe = mel[:1, :, : min(256, mel.shape[2])]  # long enough that the thread count matters as it does on the sample itself
+        probe = mel[:, :, : min(256, mel.shape[2])]  # the sample's own batch size, long enough that the thread count matters as on the sample
         for n in sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)}):
             torch.set_num_threads(n)
             ref(probe)
@@ -265,9 +288,12 @@ def cpu_baseline(frames: int, batch: int) -> dict:
                 best = (dt, n)
         cores = best[1]
         torch.set_num_threads(cores)
-        t0 = time.perf_counter()
-        wav = ref(mel)
-        dt = time.perf_counter() - t0
+        times = []
+        for _ in range(3):  # median of three
+            t0 = time.perf_counter()
+            wav = ref(mel)
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[1]
     return {
         "value": round(wav.numel() / dt, 1),
         "unit": "samples/s",
@@ -275,7 +301,7 @@ def cpu_baseline(frames: int, batch: int) -> dict:
         "host_cores_available": avail,
         "kind": "port",
         "sample": f"oracle/hifigan_ref.py GeneratorRef fp32, torch {torch.__version__} CPU, {cores} threads, "
-                  f"mel [{batch},80,{frames}] slice of the bench input ({wav.numel()} samples in {dt:.2f} s)",
+                  f"mel [{batch},80,{frames}] slice of the bench input ({wav.numel()} samples in {dt:.2f} s, median of 3; thread count probed at this batch size)",
     }
 
 
@@ -461,7 +487,13 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
         steps_profiled = json.loads(pmc_files[-1].with_suffix(".meta.json").read_text())["steps"] if pmc_files[-1].with_suffix(".meta.json").exists() else 3
         roof["traffic"] = round(sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in pmc.values()) / steps_profiled)
         roof["traffic_over_algorithmic"] = round(roof["traffic"] / algorithmic_bytes, 2)
-        roof["traffic_source"] = f"profiles/{pmc_files[-1].name}: HBM bytes per step, all kernels (FETCH_SIZE + WRITE_SIZE, raw KiB counters)"
+        meta = json.loads(pmc_files[-1].with_suffix(".meta.json").read_text()) if pmc_files[-1].with_suffix(".meta.json").exists() else {}
+        if "hbm_bytes_per_step" in meta:  # (the summariser's own total: counters with the calibration of profiles/*_pmc_calibration.json applied)
+            roof["traffic"] = round(meta["hbm_bytes_per_step"])
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / algorithmic_bytes, 2)
+        roof["traffic_source"] = (f"profiles/{pmc_files[-1].name}: HBM bytes per step, all kernels (FETCH_SIZE + WRITE_SIZE, separate --pmc passes; "
+                                  f"{meta.get('convention', 'raw KiB counters')})")
+        roof["traffic_commit"] = meta.get("commit")
         roof["dominant_kernel"] = {"name": name, "mfma_busy_frac": round(top["mfma"] / max(top["cycles"], 1.0), 4),
                                    "lds_bank_conflict_frac": round(top["lds"] / max(top["cycles"], 1.0), 4),
                                    "hbm_bytes_per_launch": round(top["bytes"] / max(top["launches"], 1)),
@@ -554,8 +586,17 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     def step():
         out["losses"] = tr.training_step(batch)
 
+    from everyvoice_amd.train import autograd as ag
+
     steps, warmup = 30, 5
+    ag.activation_elements(reset=True)
+    step()  # (eager: shapes are captured on a later warm-up step) -- counts the activation tensors one step creates
+    act_elems = ag.activation_elements(reset=True)
     elapsed = timed_region(step, steps, warmup, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    # the same step run eagerly (what a shape costs until it has been captured, and what EVMI / a caller without graphs gets)
+    tr.use_graph = False
+    elapsed_eager = timed_region(step, 10, 2, lambda: torch.cuda.synchronize(dev), barrier, max_reduce)
+    tr.use_graph = True
     other = "f32" if prec == "bf16" else "bf16"
     tr.precision = other
     graph_info = _graph_info(tr)
@@ -565,20 +606,31 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
     flops = 3.0 * forward_flops(batch["lens"], t_i, int(batch["ids"].shape[1]), int(t_i.max()), 32)
     tflops = flops * steps / elapsed / 1e12
     peak = MFMA_PEAK_TFLOPS_BF16 if prec == "bf16" else 157.0
+    # algorithmic HBM bytes, priced as the GAN leg's: every activation written once and read once forward, read once more and its
+    # gradient written and read backward (5 passes of 4 bytes); every parameter through weight use, gradient and AdamW (19 passes)
+    n_params = tr.params.numel()
+    algorithmic_bytes = 4 * (5 * act_elems + 19 * n_params)
     traffic, traffic_src = None, None
     metas = sorted((ROOT / "profiles").glob("*fs2_pmc_summary.meta.json"))
     if metas:  # recorded rocprofv3 --pmc passes over this step (tools/gpu_profile_fs2_train.sh): HBM bytes per step, all kernels
-        traffic = round(json.loads(metas[-1].read_text())["hbm_bytes_per_step"])
-        traffic_src = f"profiles/{metas[-1].name.replace('.meta', '')}: FETCH_SIZE + WRITE_SIZE of every kernel of the step (raw KiB counters, separate --pmc passes)"
+        meta = json.loads(metas[-1].read_text())
+        traffic = round(meta["hbm_bytes_per_step"])
+        traffic_src = (f"profiles/{metas[-1].name.replace('.meta', '')}: FETCH_SIZE + WRITE_SIZE of every kernel of the step (separate --pmc passes; "
+                       f"{meta.get('convention', 'raw KiB counters')}; collected at commit {meta.get('commit')})")
     return {"metric": "fastspeech2_train_steps_per_sec_bs32", "value": round(steps / elapsed, 3), "unit": "steps/s",
             "ms_per_step": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": warmup, "batch_per_gpu": 32, "global_batch": 32 * world,
             "frames_per_sec": round(world * int(t_i.sum()) * steps / elapsed, 1), "scaling": "weak", "dtype": prec,
             "other_precision": {"dtype": other, "value": round(n_other / elapsed_other, 3), "unit": "steps/s", "ms_per_step": round(elapsed_other / n_other * 1e3, 2), "steps": n_other},
             "graph": graph_info,
+            "eager": {"value": round(10 / elapsed_eager, 3), "unit": "steps/s", "ms_per_step": round(elapsed_eager / 10 * 1e3, 2), "steps": 10,
+                      "note": "the same resident batch without graph replay: the rate of shapes not (yet) captured; train_base_command runs "
+                              "lightning.FastSpeech2(use_graph=True, graph_buckets=(16, 64)) -- batches padded to those multiples replay"},
             "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient buffer in two buckets, the first under the rest of backward)" if world > 1 else ""),
             "params": tr.params.numel(), "last_losses": {k: round(float(v), 4) for k, v in out["losses"].items()},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
-                         "traffic": traffic, "traffic_source": traffic_src, "flop_per_step": flops, "scope": "whole step (forward + backward + optimiser)"}}
+                         "traffic": traffic, "traffic_source": traffic_src, "flop_per_step": flops, "scope": "whole step (forward + backward + optimiser)",
+                         "algorithmic_bytes_per_step": algorithmic_bytes, "activation_elements_per_step": act_elems,
+                         "traffic_over_algorithmic": round(traffic / algorithmic_bytes, 2) if traffic else None}}
 
 
 def cpu_baseline_fs2_train(cores: int, batch: int = 8) -> dict:
@@ -723,6 +775,7 @@ def main(argv=None) -> int:
         if pmc:
             roof["traffic"] = pmc[0]
             roof["traffic_source"] = f"profiles/{pmc[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
+            roof["traffic_commit"] = profile_commit(ROOT / "profiles" / pmc[1])
             roof["algorithmic_bytes_per_launch"] = round(roof["algorithmic_hbm_gbs"] * 1e9 * roof["avg_launch_ms"] * 1e-3)
         flops_per_sample = 2.0 * gen.macs_per_sample()
         result = {
@@ -752,6 +805,7 @@ def main(argv=None) -> int:
             "other_precision": other_precision,
             "length_sensitivity": lengths,
             "roofline": roof,
+            "commit": git_head(),
         }
         if use_dist:
             result["rccl_ranks"] = rccl_ranks

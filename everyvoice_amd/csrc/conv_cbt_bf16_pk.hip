@@ -405,7 +405,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
     // windows is compiled only into the loop that needs it.  Reads past the step's last block re-read that block (in bounds, unused).
     auto kloop = [&](auto swz_c) {
       constexpr bool SWZ = decltype(swz_c)::value;
-      bf16x8 fa[4][MT], fb[4][NT];
+      // four sets (reads two K blocks ahead) where the accumulators leave room, two (one block ahead) for the 64 x 128 wave tiles:
+      // <128, 256> on four waves holds 128 accumulator registers, and four sets of its six fragments spilled 520 registers
+      constexpr int NSETS = (MT * NT * 16 + 16 * (MT + NT) > 176) ? 2 : 4, D = NSETS / 2;
+      bf16x8 fa[NSETS][MT], fb[NSETS][NT];
       auto load = [&](int set, int qi) {
         qi = min(qi, nq - 1);
         const int2 e = tb_at(qi);
@@ -424,21 +427,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][mt], fb[set][nt], acc[mt][nt], 0, 0, 0);
       };
-      load(0, 0);
-      load(1, 1);
-      for (int qi = 0; qi < nq; qi += 4) {
-        load(2, qi + 2);
-        load(3, qi + 3);
+#pragma unroll
+      for (int u = 0; u < D; ++u) load(u, u);
+      for (int qi = 0; qi < nq; qi += NSETS) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) load(D + u, qi + D + u);
         __builtin_amdgcn_sched_barrier(0);
-        mma(0);
-        if (qi + 1 < nq) mma(1);
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+          if (u == 0 || qi + u < nq) mma(u);
         __builtin_amdgcn_sched_barrier(0);
-        if (qi + 2 >= nq) break;
-        load(0, qi + 4);
-        load(1, qi + 5);
+        if (qi + D >= nq) break;
+#pragma unroll
+        for (int u = 0; u < D; ++u) load(u, qi + NSETS + u);
         __builtin_amdgcn_sched_barrier(0);
-        mma(2);
-        if (qi + 3 < nq) mma(3);
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+          if (u == 0 || qi + D + u < nq) mma(D + u);
         __builtin_amdgcn_sched_barrier(0);
       }
     };
@@ -605,37 +610,55 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a) {
   *dst = pk_tail(v, fac, add, old);
 }
 
-// The same for a flat packed output: one thread per (channel octet, column n); grid (ceil(n / 256), c_out / 8, phases)
+// The same for a flat packed output: one thread per (channel octet, FOUR consecutive columns) -- 16-byte reads of the partial rows
+// (part_ld is a multiple of 4), one 16-byte unit stored per column; grid (ceil(n / 1024), c_out / 8, phases)
 __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int n4 = (blockIdx.x * 256 + threadIdx.x) * 4;
   const int oc = blockIdx.y, ph = blockIdx.z;
   const int n_out = a.ph_nout[ph];
-  if (n_out <= 0 || n >= n_out) return;  // (flat: B == 1)
-  const int w = n * a.out_stride + a.ph_off[ph];
-  const int bb = w / a.po.Tc, u = w - bb * a.po.Tc;
-  if (w < 0 || u >= a.po.valid) return;
-  float v[8];
+  if (n_out <= 0 || n4 >= n_out) return;  // (flat: B == 1)
+  float v[4][8];
+  const float* src = a.part + (long long)ph * a.part_stride + (long long)(oc * 8) * a.part_ld + n4;
+  const long long sstride = (long long)a.phases * a.part_stride;
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
-    v[e] = ordered_sum_strided(a.part + (long long)ph * a.part_stride + (long long)(oc * 8 + e) * a.part_ld + n, (long long)a.phases * a.part_stride, a.ksplit);
-  if (a.bias) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += a.bias[oc * 8 + e];
+  for (int e = 0; e < 8; ++e) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sp = 0; sp < a.ksplit; ++sp) {  // split order: fixed summation order
+      const float4 t = *reinterpret_cast<const float4*>(src + (long long)e * a.part_ld + sp * sstride);
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    v[0][e] = acc.x; v[1][e] = acc.y; v[2][e] = acc.z; v[3][e] = acc.w;
   }
-  pk_with_act(a.act, [&](auto act_c) {
+  float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = pk_act<decltype(act_c)::value>(v[e], a.act_param);
-  });
-  if (a.po.mask) {
-    const long long mu = (long long)oc * a.po.mplane + (long long)bb * a.po.Tm + u;
-    const uint4 mk = a.po.mask[mu];
-    const uint4 fr = a.po.fm ? a.po.fm[mu] : mk;
-    pk_flat_tail4(v, make_uint2(mk.x, mk.y), make_uint2(fr.x, fr.y), a.po.fm_scale, a.po.mask_slope);
-    pk_flat_tail4(v + 4, make_uint2(mk.z, mk.w), make_uint2(fr.z, fr.w), a.po.fm_scale, a.po.mask_slope);
+  for (int e = 0; e < 8; ++e) bv[e] = a.bias ? a.bias[oc * 8 + e] : 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int n = n4 + c;
+    if (n >= n_out) break;
+    const int w = n * a.out_stride + a.ph_off[ph];
+    const int bb = w / a.po.Tc, u = w - bb * a.po.Tc;
+    if (w < 0 || u >= a.po.valid) continue;
+    float* vc = v[c];
+    if (a.bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vc[e] += bv[e];
+    }
+    pk_with_act(a.act, [&](auto act_c) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vc[e] = pk_act<decltype(act_c)::value>(vc[e], a.act_param);
+    });
+    if (a.po.mask) {
+      const long long mu = (long long)oc * a.po.mplane + (long long)bb * a.po.Tm + u;
+      const uint4 mk = a.po.mask[mu];
+      const uint4 fr = a.po.fm ? a.po.fm[mu] : mk;
+      pk_flat_tail4(vc, make_uint2(mk.x, mk.y), make_uint2(fr.x, fr.y), a.po.fm_scale, a.po.mask_slope);
+      pk_flat_tail4(vc + 4, make_uint2(mk.z, mk.w), make_uint2(fr.z, fr.w), a.po.fm_scale, a.po.mask_slope);
+    }
+    uint4 st;
+    st.x = pack_bf16x2(vc[0], vc[1]); st.y = pack_bf16x2(vc[2], vc[3]); st.z = pack_bf16x2(vc[4], vc[5]); st.w = pack_bf16x2(vc[6], vc[7]);
+    a.po.y[(long long)oc * a.po.plane + (long long)bb * a.po.Ts + u] = st;
   }
-  uint4 st;
-  st.x = pack_bf16x2(v[0], v[1]); st.y = pack_bf16x2(v[2], v[3]); st.z = pack_bf16x2(v[4], v[5]); st.w = pack_bf16x2(v[6], v[7]);
-  a.po.y[(long long)oc * a.po.plane + (long long)bb * a.po.Ts + u] = st;
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
@@ -832,8 +855,8 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     break;
   }
   pl.c_out = a.cout_g * groups;
-  a.part_ld = n_total;  // B * longest phase
-  a.part_stride = (long long)pl.c_out * n_total;
+  a.part_ld = (n_total + 3) / 4 * 4;  // B * longest phase (rows 16-byte aligned: the flat reduce reads them four columns at a time)
+  a.part_stride = (long long)pl.c_out * a.part_ld;
   pl.part_elems = a.ksplit > 1 ? a.part_stride * a.ksplit * a.phases : 0;
   pl.ti = ti;
   pl.PL = PL;
@@ -1099,7 +1122,7 @@ static int launch_flat(const PkFlatShape& sh, const void* in_dev, long long in_p
   if (a.ksplit > 1) {
     int n_max = 0;
     for (int p = 0; p < a.phases; ++p) n_max = std::max(n_max, a.ph_nout[p]);
-    hipLaunchKernelGGL(conv_pk_reduce_flat_kernel, dim3((unsigned)((n_max + 255) / 256), pl.c_out / 8, a.phases), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(conv_pk_reduce_flat_kernel, dim3((unsigned)((n_max + 1023) / 1024), pl.c_out / 8, a.phases), dim3(256), 0, stream, a);
     EVMI_LAUNCH_CHECK("conv_pk_reduce_flat");
   }
   return EVMI_OK;

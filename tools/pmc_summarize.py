@@ -52,6 +52,10 @@ def counters(sub):
     return agg, n
 
 
+_cal = sorted((ROOT / "profiles").glob("*_pmc_calibration.json"))
+_c = json.loads(_cal[-1].read_text()) if _cal else {}
+FETCH16 = float(_c.get("fetch_factor_16B_per_lane") or 2.0)
+WRITE16 = float(_c.get("write_factor_16B_per_lane") or 1.0)
 stats = next((src / f"{tag}_trace").rglob("*kernel_stats.csv"), None)
 if stats:
     shutil.copy(stats, dst / f"{tag}_kernel_stats.csv")
@@ -65,11 +69,11 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
     if "FETCH_SIZE" in fetch[k]:
         per = fetch[k]["FETCH_SIZE"] / nf[k]["FETCH_SIZE"]
         e["fetch_size_kib_per_launch_raw"] = round(per, 1)
-        e["hbm_read_bytes_per_launch"] = round(per * 1024 * 2)  # gfx950: x2 for wide coalesced reads
+        e["hbm_read_bytes_per_launch"] = round(per * 1024 * FETCH16)  # measured factor for 16 B per lane streaming reads (2.0 without a calibration file: the guide's gfx950 note)
     if "WRITE_SIZE" in write[k]:
         per = write[k]["WRITE_SIZE"] / nw[k]["WRITE_SIZE"]
         e["write_size_kib_per_launch_raw"] = round(per, 1)
-        e["hbm_write_bytes_per_launch"] = round(per * 1024)
+        e["hbm_write_bytes_per_launch"] = round(per * 1024 * WRITE16)
     if "hbm_read_bytes_per_launch" in e and "hbm_write_bytes_per_launch" in e:
         e["hbm_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
     if "SQ_WAVE_CYCLES" in sq[k]:
@@ -81,10 +85,20 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
         }
         if sq[k].get("SQ_LDS_IDX_ACTIVE"):
             e["lds_bank_conflict_frac"] = round(sq[k]["SQ_LDS_BANK_CONFLICT"] / sq[k]["SQ_LDS_IDX_ACTIVE"], 4)
-        if sq[k].get("SQ_BUSY_CYCLES"):
-            e["mfma_busy_over_sq_busy"] = round(sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / sq[k]["SQ_BUSY_CYCLES"] / 4, 3)
+        if l2[k].get("GRBM_GUI_ACTIVE"):
+            # MFMA utilisation against the chip: SQ_VALU_MFMA_BUSY_CYCLES sums the busy cycles of all 1024 SIMDs (256 CUs x 4),
+            # GRBM_GUI_ACTIVE the 8 XCDs' active cycles (separate passes of the same command: per-launch averages of each)
+            mf = sq[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / max(1, nsq[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
+            ga = l2[k]["GRBM_GUI_ACTIVE"] / max(1, nl2[k]["GRBM_GUI_ACTIVE"])
+            e["mfma_busy_frac"] = round(mf / (ga / 8 * 1024), 4)
+            e["active_cycles_per_launch"] = round(ga / 8)
     if l2[k].get("TCC_HIT_sum") is not None and (l2[k]["TCC_HIT_sum"] + l2[k]["TCC_MISS_sum"]) > 0:
         e["l2_hit_rate"] = round(l2[k]["TCC_HIT_sum"] / (l2[k]["TCC_HIT_sum"] + l2[k]["TCC_MISS_sum"]), 3)
     out[k] = e
 (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(out, indent=1, sort_keys=True))
+_head = ROOT / ".git_head"
+(dst / f"{tag}_pmc_summary.meta.json").write_text(json.dumps({
+    "commit": _head.read_text().strip() if _head.exists() else None,
+    "convention": f"counters x factors of profiles/{_cal[-1].name}" if _cal else "FETCH_SIZE x 2 (guide), WRITE_SIZE raw",
+    "fetch_factor": FETCH16, "write_factor": WRITE16}, indent=1))
 print(json.dumps({k: v for k, v in out.items() if "conv_tc_mfma<c128,k11" in k or "pair_mfma<c64,k11" in k}, indent=1))
