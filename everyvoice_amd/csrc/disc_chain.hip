@@ -85,12 +85,17 @@ __global__ __launch_bounds__(256) void disc_first_fwd_kernel(FirstFwdArgs a) {
 }
 
 // ---- first layer, weight + bias gradient: partial[blk][co][k + 1] (last column: sum of dy) -----------------------------------------
-constexpr int DC_WCOLS = 4;  // columns per thread
+// columns per thread: chosen per call so that the launch is ~512 workgroups -- every workgroup ends with a fixed-order reduction of its
+// 8 x (taps + 1) accumulators over its 256 threads (~12 us), which at 4 columns per thread was half of the kernel's time
+static int first_wgrad_cols(long long n_total, int c_out) {
+  const long long want = (n_total * (c_out / 8) + 256LL * 512 - 1) / (256LL * 512);
+  return (int)std::min<long long>(32, std::max<long long>(4, want));
+}
 struct FirstWgradArgs {
   AudioView xv;
   const uint4* dy;
   long long plane;
-  int T, n_out, n_items, c_out, k, stride, pad;
+  int T, n_out, n_items, c_out, k, stride, pad, wcols;
   float* partial;
 };
 template <int KT>  // taps held in registers (8: the period discriminators' k = 5; 16: the scale discriminators' k = 15)
@@ -98,13 +103,13 @@ __global__ __launch_bounds__(256) void disc_first_wgrad_kernel(FirstWgradArgs a)
   extern __shared__ float red[];  // [8 * (KT + 1)][257]
   const int tid = threadIdx.x, o = blockIdx.y;
   const int n_total = a.n_items * a.n_out;
-  const int n0 = blockIdx.x * (256 * DC_WCOLS);
+  const int n0 = blockIdx.x * (256 * a.wcols);
   float acc[8][KT + 1];
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
     for (int j = 0; j <= KT; ++j) acc[e][j] = 0.f;
-  for (int i = 0; i < DC_WCOLS; ++i) {
+  for (int i = 0; i < a.wcols; ++i) {
     const int n = n0 + i * 256 + tid;
     const bool live = n < n_total;
     const int nc = live ? n : n_total - 1;
@@ -516,8 +521,8 @@ int evmi_disc_first_fwd(const float* audio_dev, int n_audio, int t_audio, int pe
 
 long long evmi_disc_first_wgrad_ws_elems(int n_items, int n_out, int c_out, int k) {
   const long long n = (long long)n_items * n_out;
-  const long long nblk = (n + 256 * DC_WCOLS - 1) / (256 * DC_WCOLS);
-  return nblk * c_out * (k + 1);
+  const long long per = 256LL * first_wgrad_cols(n, c_out);
+  return (n + per - 1) / per * c_out * (k + 1);
 }
 
 int evmi_disc_first_wgrad(const float* audio_dev, int n_audio, int t_audio, int period, const void* dy_pk, long long dy_plane, int T_dy, int n_out,
@@ -532,7 +537,8 @@ int evmi_disc_first_wgrad(const float* audio_dev, int n_audio, int t_audio, int 
   a.dy = reinterpret_cast<const uint4*>(dy_pk); a.plane = dy_plane; a.T = T_dy; a.n_out = n_out; a.n_items = n_items; a.c_out = c_out; a.k = k;
   a.stride = stride; a.pad = pad; a.partial = ws_dev;
   const long long n = (long long)n_items * n_out;
-  const int nblk = (int)((n + 256 * DC_WCOLS - 1) / (256 * DC_WCOLS));
+  a.wcols = first_wgrad_cols(n, c_out);
+  const int nblk = (int)((n + 256LL * a.wcols - 1) / (256LL * a.wcols));
   const bool k8 = k <= 8;
   const size_t lds = (size_t)8 * ((k8 ? 8 : DC_KMAX) + 1) * 257 * sizeof(float);
   static thread_local bool configured[kMaxDevices][2] = {};

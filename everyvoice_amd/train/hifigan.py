@@ -718,16 +718,34 @@ class HiFiGANTrainer:
     def _sn_layers(self):
         return [layer for layer in self.d_layers() if isinstance(layer, SNConv)]
 
-    def _prepare_chain_fragments(self, probe: torch.Tensor, generator_step: bool):
+    def _fragments_beside(self, probe: torch.Tensor, generator_step: bool):
+        """The weight-normed chains' fragments (280 MB of weights re-laid: ~0.6 ms when it runs alone) on a side stream, forked here;
+        returns ``join()`` for the point where the chains are about to fork.  One fork from the step's stream, one join: no nesting."""
+        if self.device.type != "cuda":
+            self._prepare_chain_fragments(probe, generator_step, "wn")
+            return lambda: None
+        if getattr(self, "_frag_stream", None) is None:
+            self._frag_stream = torch.cuda.Stream(self.device)
+        main = torch.cuda.current_stream(self.device)
+        self._frag_stream.wait_stream(main)
+        with torch.cuda.stream(self._frag_stream):
+            self._prepare_chain_fragments(probe, generator_step, "wn")
+        return lambda: torch.cuda.current_stream(self.device).wait_stream(self._frag_stream)
+
+    def _prepare_chain_fragments(self, probe: torch.Tensor, generator_step: bool, which: str = "all"):
         """Packed discriminator chains (train/disc_chain.py): the bf16 weight fragments of every matrix-core layer of every chain for the
-        coming phase, on the current stream BEFORE the chains fork onto theirs -- a few launches for all eight discriminators, and the
-        generator step's real and generated calls share one set."""
+        coming phase, BEFORE the chains fork onto their streams -- a few launches for all eight discriminators, and the generator
+        step's real and generated calls share one set.  ``which``: "wn" (the weight-normed discriminators: their weights stand since
+        the optimiser step, so this part runs early, beside other work: ``_fragments_beside``), "sn" (the spectral-norm scale: its
+        per-call weights exist once ``_prepare_spectral_norm`` has run) or "all"."""
         jobs = []
         for d in self.discriminators():
             chain = _chain_for(d, getattr(d, "period", 1), probe)
             if chain is None:
                 continue
             sn = any(isinstance(layer, SNConv) for layer in d.layers())
+            if which != "all" and sn != (which == "sn"):
+                continue
             # spectral norm: two calls (real, generated) with their own weights; in the generator step only the generated call runs backward
             jobs += chain.frag_jobs(((False, True) if generator_step else (True, True)) if sn else (True,))
         if jobs:
@@ -824,7 +842,7 @@ class HiFiGANTrainer:
                 marks.append((name, ev))
 
         mark("start")
-        ctx = self._phase_generator_forward(mel_bct, audio_bct)
+        ctx = self._phase_generator_forward(mel_bct, audio_bct, d_step=not warm)
         mark("generator forward")
         if not warm:
             d_red = self._reducer(self.d_params)
@@ -854,7 +872,7 @@ class HiFiGANTrainer:
         return self._loss_buf
 
     # ---- the phases of a step (each one a stretch without communication: what a HIP graph captures) ----
-    def _phase_generator_forward(self, mel_bct, audio_bct):
+    def _phase_generator_forward(self, mel_bct, audio_bct, d_step: bool = True):
         B = audio_bct.shape[0]
         y = audio_bct.to(torch.float32).reshape(1, B, -1)  # [B,1,T] and [1,B,T] are the same bytes
         if not y.is_contiguous():
@@ -865,12 +883,14 @@ class HiFiGANTrainer:
         g_layers, d_layers = self.generator.layers(), self.d_layers()
         self._materialize(g_layers)
         self._materialize(d_layers)
+        # the discriminator step's weight fragments run UNDER the generator's forward
+        frag_join = self._fragments_beside(y, generator_step=False) if d_step else None
         g_tape = ag.Tape()
         g_reducer = [None]  # filled in before the generator's backward (the reducer object is created per phase)
         y_hat = self.generator.forward(
             g_tape, ag.Var(mel, needs_grad=False),
             lambda layers: self._bucket_hook_late(g_tape, self.g_params, layers, g_reducer), branches=self.branches)
-        return dict(B=B, y=y, y_hat=y_hat, g_tape=g_tape, g_reducer=g_reducer, d_layers=d_layers)
+        return dict(B=B, y=y, y_hat=y_hat, g_tape=g_tape, g_reducer=g_reducer, d_layers=d_layers, frag_join=frag_join)
 
     def _bucket_hook_late(self, tape, group, layers, reducer_box):
         """As `_bucket_hook`, with the reducer looked up when backward runs (the generator's tape is recorded long before it)."""
@@ -908,7 +928,12 @@ class HiFiGANTrainer:
         for layer in ctx["d_layers"]:
             layer.frozen = False
         self._prepare_spectral_norm(2)  # real call, then generated call
-        self._prepare_chain_fragments(y, generator_step=False)
+        self._prepare_chain_fragments(y, generator_step=False, which="sn")
+        join = ctx.pop("frag_join", None)
+        if join is not None:
+            join()  # (the weight-normed chains' fragments, started beside the generator's forward)
+        else:
+            self._prepare_chain_fragments(y, generator_step=False, which="wn")
         T = y.shape[-1]
         pair_t = torch.empty(1, 2 * B, T, device=self.device, dtype=torch.float32)
         ops.copy(y, out=pair_t[:, :B])
@@ -976,8 +1001,10 @@ class HiFiGANTrainer:
         y_hat_in = ag.Var(y_hat.data)  # boundary between the discriminator tape and the generator tape
         recon = [None]
         if adversarial:
+            frag_join = self._fragments_beside(y, generator_step=True)  # (under the spectral-norm power iterations)
             self._prepare_spectral_norm(2)  # real call, then generated call
-            self._prepare_chain_fragments(y, generator_step=True)
+            self._prepare_chain_fragments(y, generator_step=True, which="sn")
+            frag_join()
             gd_tape = ag.Tape()
             real = ag.Var(y, needs_grad=False)
             xs_r = self._scale_inputs(gd_tape, real)
@@ -1118,7 +1145,7 @@ class HiFiGANTrainer:
             after.append(then)
 
         def whole():
-            ctx.update(self._phase_generator_forward(mel_s, audio_s))
+            ctx.update(self._phase_generator_forward(mel_s, audio_s, d_step=not warm))
             if not warm:
                 self._phase_d_backward(ctx, None)
                 self._phase_d_update(ctx)
@@ -1148,7 +1175,7 @@ class HiFiGANTrainer:
             thens.append(None)
 
         def first():
-            ctx.update(self._phase_generator_forward(mel_s, audio_s))
+            ctx.update(self._phase_generator_forward(mel_s, audio_s, d_step=not warm))
             if not warm:
                 self._phase_d_prelude(ctx)
 

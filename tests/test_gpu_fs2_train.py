@@ -494,6 +494,9 @@ def _grad_agreement(got_flat, want_flat):
     return float(torch.dot(g_, w_) / (g_.norm() * w_.norm())), float(g_.norm() / w_.norm())
 
 
+PER_TENSOR_COS_FLOOR = 0.98  # (measured worst large tensor: text_input_layer.weight 0.9875; whole gradient 0.99983 -- the test prints both)
+
+
 def test_training_step_at_the_bench_shape_bf16_follows_fp32(cuda_device):
     """BASELINE config 3 at the batch bench.py times (32 utterances, <= 187 symbols, <= 947 frames): the planner's tile and
     split-K choices depend on the column count, so the B = 4 tests do not run the timed kernels (conv_pk_kernel<128, 256>,
@@ -501,7 +504,7 @@ def test_training_step_at_the_bench_shape_bf16_follows_fp32(cuda_device):
     timed arithmetic (precision="bf16") runs the whole forward + backward at that size against the exact fp32 step of the same
     trainer class on the same parameters and batch -- that fp32 path is pinned against the torch-CPU oracle (tests above), and
     per operator the bench-shape kernels are pinned against torch in test_gpu_train_ops.py.  Every loss within 2e-2, whole
-    gradient cosine >= 0.99 and norm within 5 %, every large tensor's gradient cosine >= 0.97."""
+    gradient cosine >= 0.999 and norm within 3 %, every large tensor's gradient cosine >= 0.98 (measured 0.99983 / 0.9875)."""
     from everyvoice_amd.train import ops
 
     ref_cfg = _ref_cfg(0.0, 0, default_size=True)
@@ -520,11 +523,14 @@ def test_training_step_at_the_bench_shape_bf16_follows_fp32(cuda_device):
     for k, v in out["f32"][0].items():
         assert math.isfinite(out["bf16"][0][k]) and out["bf16"][0][k] == pytest.approx(v, rel=2e-2, abs=1e-4), k
     cos, ratio = _grad_agreement(out["bf16"][2], out["f32"][2])
-    assert cos >= 0.99 and 0.95 <= ratio <= 1.05, (cos, ratio)
+    assert cos >= 0.999 and 0.97 <= ratio <= 1.03, (cos, ratio)
+    worst = (2.0, None)
     for name, g32 in out["f32"][1].items():
         if g32.numel() >= 4096 and float(g32.norm()) > 1e-6:
             c, _ = _grad_agreement(out["bf16"][1][name].flatten(), g32.flatten())
-            assert c >= 0.97, f"{name}: cos {c:.4f}"
+            worst = min(worst, (c, name))
+            assert c >= PER_TENSOR_COS_FLOOR, f"{name}: cos {c:.4f}"
+    print(f"bench shape bf16 vs fp32: whole cos {cos:.6f}, worst large tensor {worst}")
     assert float((out["bf16"][2] - out["f32"][2]).abs().max()) > 0.0  # the bf16 kernels did run
 
 
@@ -555,6 +561,42 @@ def test_training_step_bench_slice_bf16_follows_oracle(cuda_device):
             flat_w.append(p.grad.flatten())
     cos, ratio = _grad_agreement(torch.cat(flat_g), torch.cat(flat_w))
     assert cos >= 0.99 and 0.95 <= ratio <= 1.05, (cos, ratio)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_training_step_at_the_bench_batch_follows_oracle(cuda_device, prec):
+    """the WHOLE bench batch (32 utterances x <= 947 frames, default-size model) against torch-CPU autograd of the
+    oracle module -- not the trainer's own fp32 step, and not a slice.  fp32: every loss 2e-4, whole gradient within 4e-3 (relative L2);
+    bf16: losses 2e-2, whole-gradient cosine >= 0.999 (measured 0.99983), norm within 3 %."""
+    from everyvoice_amd.train import ops
+
+    torch.set_num_threads(8)
+    ref_cfg = _ref_cfg(0.0, 0, default_size=True)
+    tr = _trainer(ref_cfg, cuda_device, precision=prec)
+    batch = _bench_batch(32)
+    ref = _oracle_from(tr, ref_cfg)
+    want = training_losses_ref(ref, batch)
+    want["total"].backward()
+    ops.CONV_BACKEND["operands"] = prec
+    try:
+        got = tr.forward_backward(batch)
+    finally:
+        ops.CONV_BACKEND["operands"] = "f32"
+    for k, v in want.items():
+        assert float(got[k]) == pytest.approx(float(v), rel=2e-4 if prec == "f32" else 2e-2, abs=1e-5 if prec == "f32" else 1e-4), k
+    grads = tr.params.gradients()
+    flat_g, flat_w = [], []
+    for name, p in ref.named_parameters():
+        if p.grad is not None:
+            flat_g.append(grads[name].cpu().flatten())
+            flat_w.append(p.grad.flatten())
+    g, w = torch.cat(flat_g).double(), torch.cat(flat_w).double()
+    cos, ratio = _grad_agreement(g, w)
+    print(f"bench batch vs oracle [{prec}]: cos {cos:.6f} ratio {ratio:.5f} rel L2 {float((g - w).norm() / w.norm()):.3e}")
+    if prec == "f32":
+        assert float((g - w).norm() / w.norm()) <= 4e-3, float((g - w).norm() / w.norm())
+    else:
+        assert cos >= 0.999 and 0.97 <= ratio <= 1.03, (cos, ratio)
 
 
 def test_noam_schedule(cuda_device):

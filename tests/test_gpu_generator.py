@@ -3,7 +3,8 @@
 Tolerances (stated per BASELINE.json north_star, "within a stated fp tolerance"):
   * EVMI_PREC_F32 (fp32 fmaf chains):  max |diff| <= 2e-4 on wav in [-1, 1]
   * EVMI_PREC_BF16 (bf16 operands / activations in HBM, fp32 accumulate on MFMA):
-        relative L2 error <= 3e-2 and max |diff| <= 8e-2 on wav in [-1, 1]
+        relative L2 error <= 1e-2 and max |diff| <= 5e-2 on wav in [-1, 1]   (measured 4.8e-3 relative L2: a kernel change that
+        doubles the error fails)
 """
 
 import numpy as np
@@ -15,8 +16,11 @@ from helpers import make_ref_generator, rel_l2, synthetic_mel
 pytestmark = pytest.mark.gpu
 
 F32_ATOL = 2e-4
-BF16_REL_L2 = 3e-2
-BF16_ATOL = 8e-2
+BF16_REL_L2 = 1e-2
+BF16_ATOL = 5e-2  # (a single-sample metric: measured 0.5e-2 ... 3.7e-2 over the input sizes and kernel variants)
+# the iSTFTNet head puts exp() behind conv_post: its output error is the logit's error times the magnitude (measured 1.33e-2 on the
+# hop-512 configuration, 6e-3 on C8C8I)
+BF16_REL_L2_ISTFT = 2.5e-2
 
 
 def _product_from_ref(ref, device, precision):
@@ -205,7 +209,7 @@ def test_istft_generator_vs_oracle(cuda_device, name, B, T):
     got16 = _product_from_ref(ref, cuda_device, "bf16")(mel.to(cuda_device)).cpu()
     err = rel_l2(got16, want)
     print(f"istft {name} B={B} T={T}: bf16 rel_l2={err:.3e} (|wav| max {scale:.2f})")
-    assert torch.isfinite(got16).all() and err <= BF16_REL_L2
+    assert torch.isfinite(got16).all() and err <= BF16_REL_L2_ISTFT
 
 
 @pytest.mark.gpu
