@@ -99,3 +99,98 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_concatenated_batch(cuda_devi
             for k in a:
                 assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-7), k
         assert torch.equal(r0["d"], e0["d"]) and torch.equal(r0["g"], e0["g"])  # graph replays == eager steps, exchange included
+
+
+# ---- FastSpeech2: the bucketed exchange and the Tape.cut stretches with TWO ranks -----------------------------
+# BatchNorm normalises with per-rank batch statistics (as under Lightning DDP: no SyncBatchNorm in the reference), so two ranks on
+# half batches are NOT one rank on the whole batch.  What data parallelism promises is: after the exchange every rank holds the MEAN
+# of the ranks' local gradients (then clips and steps on it).  The local gradients of a shard are what a one-rank trainer computes on
+# that shard; so: mean(one-rank gradient of shard 0, of shard 1), clipped, is what both ranks must hold -- in eager mode (buckets
+# launched inside backward) and in graph mode (the step captured in stretches cut at the bucket boundary, all-reduces between replays).
+def _fs2_shard(batch, rank, B):
+    return {k: v[rank * B:(rank + 1) * B] for k, v in batch.items()}
+
+
+def _fs2_rank_main(rank, world, port, use_graph, steps, out_dir, learn_alignment):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import torch.distributed as dist
+
+    import test_gpu_fs2_train as T
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    try:
+        ref_cfg = T._ref_cfg(0.0, 0)
+        tr = T._trainer(ref_cfg, dev, learn_alignment=learn_alignment, process_group=True, use_graph=use_graph)
+        full = T._shaped_batch(ref_cfg, 5, learn_alignment, dev, B=8) if learn_alignment else {k: v.to(dev) for k, v in T._train_batch(ref_cfg, 8, 23, seed=5).items()}
+        shard = _fs2_shard(full, rank, 4)
+        losses = []
+        for _ in range(steps):
+            losses.append({k: float(v) for k, v in tr.training_step(shard).items()})
+        torch.cuda.synchronize(dev)
+        torch.save({"grad": tr.params.grad.cpu(), "flat": tr.params.flat.cpu(), "losses": losses, "graph_failed": tr._graph_failed,
+                    "was_graph": tr.last_step_was_graph, "stretches": [len(e["graphs"]) for e in tr._graphs.values()]}, Path(out_dir) / f"fs2_rank{rank}.pt")
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_two_fs2_ranks(tmp_path, use_graph, steps, learn_alignment):
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_fs2_rank_main, args=(r, 2, port, use_graph, steps, str(tmp_path), learn_alignment)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    return [torch.load(tmp_path / f"fs2_rank{r}.pt", weights_only=False) for r in range(2)]
+
+
+@pytest.mark.parametrize("learn_alignment", [False, True])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fastspeech2_two_ranks_hold_the_mean_of_their_local_gradients(cuda_device, tmp_path, use_graph, learn_alignment):
+    sys.path.insert(0, str(ROOT / "tests"))
+    import test_gpu_fs2_train as T
+
+    steps = 4 if use_graph else 1  # graph mode: two eager steps, the capture, one pure replay
+    r0, r1 = _run_two_fs2_ranks(tmp_path, use_graph, steps, learn_alignment)
+    assert r0["graph_failed"] is None and r1["graph_failed"] is None
+    # both ranks hold the same (averaged, clipped) gradients and the same parameters, bit for bit
+    assert torch.equal(r0["grad"], r1["grad"]) and torch.equal(r0["flat"], r1["flat"])
+    if use_graph:
+        assert r0["was_graph"] and r0["stretches"] and r0["stretches"][0] >= 3  # cut at the decoder boundary, exchanges between the replays
+        tmp2 = tmp_path / "eager"
+        tmp2.mkdir()
+        e0, _ = _run_two_fs2_ranks(tmp2, False, steps, learn_alignment)
+        for a, b in zip(r0["losses"], e0["losses"]):
+            for k in a:
+                assert a[k] == b[k], k
+        assert torch.equal(r0["flat"], e0["flat"]) and torch.equal(r0["grad"], e0["grad"])  # replays == eager steps, exchange included
+        return
+    # eager, first step: mean of the two shards' one-rank gradients, clipped as the step clips
+    from everyvoice_amd.train import ops
+
+    ref_cfg = T._ref_cfg(0.0, 0)
+    local = []
+    for rank in range(2):
+        one = T._trainer(ref_cfg, cuda_device, learn_alignment=learn_alignment)
+        full = T._shaped_batch(ref_cfg, 5, learn_alignment, cuda_device, B=8) if learn_alignment else {k: v.to(cuda_device) for k, v in T._train_batch(ref_cfg, 8, 23, seed=5).items()}
+        ops.CONV_BACKEND["operands"] = one.precision
+        try:
+            one.forward_backward(_fs2_shard(full, rank, 4))
+        finally:
+            ops.CONV_BACKEND["operands"] = "f32"
+        local.append(one.params.grad.double().cpu())
+        clip = one.training.gradient_clip_val
+    mean = (local[0] + local[1]) / 2
+    if clip is not None:
+        mean = mean * min(1.0, clip / (float(mean.norm()) + 1e-6))
+    got = r0["grad"].double()
+    scale = float(mean.abs().max())
+    assert scale > 0 and float((got - mean).abs().max()) <= 2e-4 * scale, (float((got - mean).abs().max()), scale)
