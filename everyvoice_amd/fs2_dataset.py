@@ -98,6 +98,11 @@ class FastSpeech2Dataset(Dataset):
         self.text_key = TEXT_KEYS[self.level]
         self.pfs = self.level == "phonological_features"
         self.learn_alignment = bool(m.learn_alignment)
+        # phone- or frame-level variance files: decided by the configuration (the preprocessor writes per-symbol averages only with
+        # given durations AND a "phone"-level predictor, preprocessor.py:641-669), never guessed from a tensor's length
+        vp = m.variance_predictors
+        self.phone_level = {key: (not self.learn_alignment) and str(getattr(getattr(vp, key).level, "value", getattr(vp, key).level)) == "phone"
+                            for key in ("pitch", "energy")}
         self.save_dir = Path(config.preprocessing.save_dir)
         self.spec_fn = f"spec-{a.input_sampling_rate}-{a.spec_type}.pt"
         self.lang2id, self.speaker2id = dict(lang2id or {}), dict(speaker2id or {})
@@ -138,12 +143,24 @@ class FastSpeech2Dataset(Dataset):
             dur = self._load(item, "duration", "duration.pt").to(torch.long)
             if dur.shape[0] != L or abs(int(dur.sum()) - T) > 10:  # tests/test_preprocessing.py:527 allows the aligner 10 frames of slack
                 raise ValueError(f"{item['basename']}: durations ({dur.shape[0]} symbols, {int(dur.sum())} frames) do not fit {L} tokens / {T} frames")
+            over = int(dur.sum()) - T
+            if over > 0:  # within the slack, but the step would count zero-padded frames as targets: take the excess off the tail
+                for i in range(L - 1, -1, -1):
+                    cut = min(over, int(dur[i]))
+                    dur[i] -= cut
+                    over -= cut
+                    if over == 0:
+                        break
             out["duration"] = dur
         # frame-level files under alignment learning (durations are not known at preprocessing time, preprocessor.py:641-669);
         # with given durations the files hold one value per symbol when the predictor's level is "phone", one per frame otherwise
         for key in ("pitch", "energy"):
             v = self._load(item, key, f"{key}.pt").to(torch.float32)
-            out[key if (not self.learn_alignment and v.shape[0] == L and L != T) else key + "_frames"] = v
+            want = L if self.phone_level[key] else T
+            if v.shape[0] != want:
+                raise ValueError(f"{item['basename']}: {key} has {v.shape[0]} values, the configuration "
+                                 f"({'phone' if self.phone_level[key] else 'frame'} level) wants {want}")
+            out[key if self.phone_level[key] else key + "_frames"] = v
         return out
 
 

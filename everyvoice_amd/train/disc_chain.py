@@ -116,6 +116,7 @@ class DiscChain:
         self.disc, self.period, self.device = disc, period, torch.device(device)
         self.convs, self.conv_post = disc.convs, disc.conv_post
         self._cfgs: dict = {}
+        self._pinned: set = set()
         c0 = self.convs[0]
         ok = (c0.cin == 1 and c0.groups == 1 and c0.k <= 16 and c0.cout % 8 == 0 and c0.dil == 1 and self.conv_post.cout == 1
               and self.conv_post.k <= 8 and self.conv_post.groups == 1 and self.conv_post.stride == 1 and self.conv_post.dil == 1)
@@ -172,13 +173,24 @@ class DiscChain:
         self._frag_map[(i, mode, w.data_ptr())] = (self.EPOCH[0], wf)
         return wf
 
+    MAX_CFGS = 8  # buffer sets kept (least recently used out first; a set a graph capture has touched stays)
+
     def cfg(self, n_audio, t_audio, role, with_grad) -> _Cfg:
         key = (n_audio, t_audio, role, with_grad)
+        capturing = torch.cuda.is_current_stream_capturing()
         c = self._cfgs.get(key)
         if c is None:
-            if torch.cuda.is_current_stream_capturing():
+            if capturing:
                 raise RuntimeError("disc chain: buffers would have to be created during graph capture: warm the step up eagerly first")
-            c = self._cfgs[key] = _Cfg(self, n_audio, t_audio, with_grad, self.device)
+            c = _Cfg(self, n_audio, t_audio, with_grad, self.device)
+            loose = [k for k in self._cfgs if k not in self._pinned]
+            while len(loose) >= self.MAX_CFGS:
+                del self._cfgs[loose.pop(0)]
+        else:
+            del self._cfgs[key]  # (re-inserted below: most recently used last)
+        self._cfgs[key] = c
+        if capturing:
+            self._pinned.add(key)
         return c
 
     # ---- forward ------------------------------------------------------------------------------------------------------------------

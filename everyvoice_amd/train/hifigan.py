@@ -183,12 +183,16 @@ class GeneratorT:
         if not (self.time_major and self.fused_pairs and not self.resblock2 and x.is_cuda and ops.CONV_BACKEND["operands"] == "bf16"
                 and ops.CONV_BACKEND["packed"] and 1 < self.num_kernels <= 3):
             return None
+        # the decision is per (stage, length): the kernels take row counts that are multiples of 16 (a decision cached from
+        # the first shape would send other lengths down the time-major path whatever their length)
+        if x.shape[2] % 16:
+            return None
         st = self._tm_stages.get(i)
         if st is None:
             from .mrf_tm import MRFStageTM, stage_supported
 
             pairs = [self.resblocks[i * self.num_kernels + j] for j in range(self.num_kernels)]
-            ok = stage_supported(x.shape[0], [p[0][0].k for p in pairs], [[c1.dil for c1, _ in p] for p in pairs]) and x.shape[2] % 16 == 0
+            ok = stage_supported(x.shape[0], [p[0][0].k for p in pairs], [[c1.dil for c1, _ in p] for p in pairs])
             st = self._tm_stages[i] = MRFStageTM(x.shape[0], pairs, self.slope, x.device) if ok else False
         return st or None
 

@@ -70,11 +70,36 @@ class MRFStageTM:
     def __init__(self, C: int, branch_pairs, slope: float, device):
         self.C, self.pairs, self.slope, self.device = C, branch_pairs, slope, torch.device(device)
         self._bufs: dict = {}
+        self._shape_lru: list = []
+        self._pinned: set = set()
         self._table = self._table_base = self._arena = None
         self.zero_bias = torch.zeros(max(C, 8), device=self.device, dtype=torch.float32)
 
     # ---- storage ---------------------------------------------------------------------------------------------------
+    MAX_SHAPES = 3  # (batch, length) buffer sets kept: the training segment shape + validation / synthesis lengths in turn
+
     def buf(self, key, B, T) -> TMBuf:
+        """Buffers are persistent per (batch, length) -- a captured graph needs static addresses -- but only for the MAX_SHAPES most
+        recently used shapes: ``HiFiGANTrainer.generate`` on utterances of many lengths would otherwise keep ~19 buffers per stage
+        for every length it ever saw.  A shape a graph capture has touched is pinned."""
+        shape = (B, T)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            self._pinned.add(shape)  # a captured graph holds these addresses: replays do not pass through here, so the shape stays for good
+        if shape in self._shape_lru:
+            if self._shape_lru[-1] != shape:
+                self._shape_lru.remove(shape)
+                self._shape_lru.append(shape)
+        else:
+            if capturing:
+                raise RuntimeError("MRFStageTM: a time-major buffer would have to be allocated during graph capture: warm the step up eagerly first")
+            self._shape_lru.append(shape)
+            loose = [sh for sh in self._shape_lru if sh not in self._pinned]
+            while len(loose) > self.MAX_SHAPES:
+                old = loose.pop(0)
+                self._shape_lru.remove(old)
+                for k in [k for k in self._bufs if (k[1], k[2]) == old]:
+                    del self._bufs[k]
         k = (key, B, T)
         b = self._bufs.get(k)
         if b is None:
