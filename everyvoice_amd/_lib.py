@@ -61,7 +61,7 @@ class PkFlatJob(C.Structure):  # evmi_pkflat_job
 
 
 class PkFlatPair(C.Structure):  # evmi_pkflat_pair
-    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("units", C.c_longlong), ("scale", C.c_float)]
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("units", C.c_longlong), ("plane", C.c_longlong), ("rows", C.c_int), ("scale", C.c_float)]
 
 
 class PkFlatRows(C.Structure):  # evmi_pkflat_rows

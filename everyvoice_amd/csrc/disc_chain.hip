@@ -365,6 +365,8 @@ struct AbsdiffBatch {
   const uint4* a[DC_MAX_PAIRS];
   const uint4* b[DC_MAX_PAIRS];
   long long units[DC_MAX_PAIRS];
+  long long plane[DC_MAX_PAIRS];
+  int rows[DC_MAX_PAIRS];
   float scale[DC_MAX_PAIRS];
   int n;
   double* partial;  // [n][DC_ABS_BLOCKS]
@@ -373,34 +375,36 @@ struct AbsdiffBatch {
 __global__ __launch_bounds__(256) void pkflat_absdiff_kernel(AbsdiffBatch q) {
   __shared__ double sh[4];
   const int l = blockIdx.y;
-  const uint4* pa = q.a[l];
-  const uint4* pb = q.b[l];
   const long long n = q.units[l], step = (long long)DC_ABS_BLOCKS * 256;
   double acc = 0.0;
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * step < n; i += 4 * step) {
-    uint4 ua[4], ub[4];
+  for (int row = 0; row < q.rows[l]; ++row) {
+    const uint4* pa = q.a[l] + (long long)row * q.plane[l];
+    const uint4* pb = q.b[l] + (long long)row * q.plane[l];
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < n; i += 4 * step) {
+      uint4 ua[4], ub[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { ua[u] = pa[i + u * step]; ub[u] = pb[i + u * step]; }
+      for (int u = 0; u < 4; ++u) { ua[u] = pa[i + u * step]; ub[u] = pb[i + u * step]; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 4; ++u) {
+        float x[8], y[8];
+        unpack8(ua[u], x);
+        unpack8(ub[u], y);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += fabsf(x[e] - y[e]);
+        acc += (double)s;
+      }
+    }
+    for (; i < n; i += step) {
       float x[8], y[8];
-      unpack8(ua[u], x);
-      unpack8(ub[u], y);
+      unpack8(pa[i], x);
+      unpack8(pb[i], y);
       float s = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += fabsf(x[e] - y[e]);
       acc += (double)s;
     }
-  }
-  for (; i < n; i += step) {
-    float x[8], y[8];
-    unpack8(pa[i], x);
-    unpack8(pb[i], y);
-    float s = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) s += fabsf(x[e] - y[e]);
-    acc += (double)s;
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
@@ -653,7 +657,7 @@ int evmi_pkflat_absdiff(int n_pairs, const evmi_pkflat_pair* pairs, float* out_d
   for (int l = 0; l < n_pairs; ++l) {
     if (!pairs[l].a || !pairs[l].b || pairs[l].units < 0) return fail(EVMI_ERR_INVALID_ARG, "pkflat_absdiff: null tensor");
     q.a[l] = reinterpret_cast<const uint4*>(pairs[l].a); q.b[l] = reinterpret_cast<const uint4*>(pairs[l].b);
-    q.units[l] = pairs[l].units; q.scale[l] = pairs[l].scale;
+    q.units[l] = pairs[l].units; q.scale[l] = pairs[l].scale; q.plane[l] = pairs[l].plane; q.rows[l] = pairs[l].rows > 0 ? pairs[l].rows : 1;
   }
   hipLaunchKernelGGL(pkflat_absdiff_kernel, dim3(DC_ABS_BLOCKS, n_pairs), dim3(256), 0, (hipStream_t)stream, q);
   EVMI_LAUNCH_CHECK("pkflat_absdiff");

@@ -57,11 +57,15 @@ def _conv_len(t, k, s, p, d=1):
 class _Cfg:
     """Everything static about one (chain, item count, length, role): tensor geometry, buffers, per-call workspaces."""
 
-    def __init__(self, chain, n_audio, t_audio, with_grad, device):
+    def __init__(self, chain, n_audio, t_audio, with_grad, device, grad_audio=None):
         lib = _lib.load()
         self.n_audio, self.t_audio = n_audio, t_audio
         p = chain.period
         self.n_items = n_audio * p
+        # items gradients flow into: all of them, or the LAST grad_audio waveforms (generator step: real and generated waveforms run
+        # forward as one batch -- half the launches, better filled -- and only the generated half runs backward)
+        self.n_items_g = (n_audio if grad_audio is None else grad_audio) * p
+        self.off_g = self.n_items - self.n_items_g
         self.H = (t_audio + p - 1) // p
         convs = chain.convs
         L = len(convs)
@@ -88,7 +92,7 @@ class _Cfg:
         if with_grad:
             for i in range(1, L + 1):
                 T_G = self.Tc[i - 1] if i >= 2 else T_A[1]
-                self.G[i] = PF(convs[i - 1].cout, self.n_items, T_G, self.lens[i], device)
+                self.G[i] = PF(convs[i - 1].cout, self.n_items_g, T_G, self.lens[i], device)
         # per-call workspaces: the call's static K-block offset table and split counters (written once, here) + its split partial tiles
         self.ws_f, self.ws_d = [None] * L, [None] * L
         st = _lib.current_stream_ptr(device)
@@ -97,7 +101,7 @@ class _Cfg:
             for mode, T, dst in ((0, T_A[i], self.ws_f), (1, self.Tc[i], self.ws_d)):
                 if mode == 1 and not with_grad:
                     continue
-                shape = (mode, self.n_items, T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups)
+                shape = (mode, self.n_items if mode == 0 else self.n_items_g, T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups)
                 n = lib.evmi_conv_pkflat_ws_elems(*shape)
                 if n <= 0:
                     raise RuntimeError(f"disc chain: layer {c.name} (direction {mode}) not taken by the flat packed kernel")
@@ -106,7 +110,7 @@ class _Cfg:
         self.logits_n = _conv_len(self.lens[L], post.k, post.stride, post.pad, post.dil)
         assert post.stride == 1 and self.logits_n == self.lens[L], "the logit layer is a 'same' convolution"
         # feature-matching scales: 2 / numel of every feature map (upstream feature_loss: mean |.| per map, times 2)
-        self.fm_scale = [0.0] + [2.0 / (convs[i - 1].cout * self.n_items * self.lens[i]) for i in range(1, L + 1)]
+        self.fm_scale = [0.0] + [2.0 / (convs[i - 1].cout * self.n_items_g * self.lens[i]) for i in range(1, L + 1)]
 
 
 class DiscChain:
@@ -175,14 +179,14 @@ class DiscChain:
 
     MAX_CFGS = 8  # buffer sets kept (least recently used out first; a set a graph capture has touched stays)
 
-    def cfg(self, n_audio, t_audio, role, with_grad) -> _Cfg:
-        key = (n_audio, t_audio, role, with_grad)
+    def cfg(self, n_audio, t_audio, role, with_grad, grad_audio=None) -> _Cfg:
+        key = (n_audio, t_audio, role, with_grad, grad_audio)
         capturing = torch.cuda.is_current_stream_capturing()
         c = self._cfgs.get(key)
         if c is None:
             if capturing:
                 raise RuntimeError("disc chain: buffers would have to be created during graph capture: warm the step up eagerly first")
-            c = _Cfg(self, n_audio, t_audio, with_grad, self.device)
+            c = _Cfg(self, n_audio, t_audio, with_grad, self.device, grad_audio)
             loose = [k for k in self._cfgs if k not in self._pinned]
             while len(loose) >= self.MAX_CFGS:
                 del self._cfgs[loose.pop(0)]
@@ -194,14 +198,18 @@ class DiscChain:
         return c
 
     # ---- forward ------------------------------------------------------------------------------------------------------------------
-    def forward(self, tape: ag.Tape, audio: ag.Var, training=True, role="pair"):
-        """audio.data [1, n_audio, t_audio] fp32 -> (logits Var [1, n_items, n], ChainFmaps)."""
+    def forward(self, tape: ag.Tape, audio: ag.Var, training=True, role="pair", grad_from=None):
+        """audio.data [1, n_audio, t_audio] fp32 -> (logits Var [1, n_items, n], ChainFmaps).  ``grad_from`` = B (generator step, frozen
+        layers): the batch is [real (B waveforms) | generated]; the forward runs over all of it, the backward over the generated half
+        only, its feature-matching reference being the real half of the same tensors."""
         lib = _lib.load()
         x = audio.data
         _, n_audio, t_audio = x.shape
         frozen = all(layer.frozen for layer in self.convs)
         with_grad = audio.needs_grad or not frozen
-        cfg = self.cfg(n_audio, t_audio, role, with_grad)
+        if grad_from is not None and not (frozen and 0 < grad_from < n_audio):
+            raise ValueError("disc chain: a split batch is the generator step's (frozen layers, 0 < grad_from < n_audio)")
+        cfg = self.cfg(n_audio, t_audio, role, with_grad, None if grad_from is None else n_audio - grad_from)
         convs, post, L = self.convs, self.conv_post, len(self.convs)
         st = ops._s(x)
         eff = [c.effective(training) + (c.call_db_sink(),) for c in convs]  # (w, dw sink, db sink) per call, in layer order
@@ -229,6 +237,7 @@ class DiscChain:
         ag._ACTIVATION_ELEMS[0] += sum(a.C * cfg.n_items * a.valid for a in A[1:]) // 2  # (bf16: half an fp32 element each)
         out = ag.Var(logits)
         fm = ChainFmaps(self, cfg, out)
+        fm.split = grad_from is not None
 
         def bwd():
             if out.grad is None:
@@ -249,14 +258,21 @@ class DiscChain:
         w_post, dw_post, db_post = post_eff
         n = cfg.logits_n
 
-        def fm_args(i):
-            return (A[i].ptr, ref.A[i].ptr if ref is not None else 0, A[i].plane, A[i].T, 0.1, cfg.fm_scale[i] if ref is not None else 0.0)
+        ng, off = cfg.n_items_g, cfg.off_g  # items that run backward: the last ng of the batch
+        split = fm.split and ref is not None
 
-        if ref is not None:
+        def fm_args(i):
+            mask = A[i].ptr + off * A[i].T * 16  # the activations of the items that run backward
+            if ref is None:
+                return (mask, 0, A[i].plane, A[i].T, 0.1, 0.0)
+            return (mask, A[i].ptr if split else ref.A[i].ptr, A[i].plane, A[i].T, 0.1, cfg.fm_scale[i])
+
+        if ref is not None and not split:
             assert all(ref.A[i].T == A[i].T and ref.A[i].plane == A[i].plane for i in range(1, L + 1)), "feature-matching pair: different geometry"
-        _lib.check(lib.evmi_disc_post_dgrad(dlogits.data_ptr(), w_post.data_ptr(), G[L].ptr, G[L].plane, G[L].T, cfg.n_items, n, post.cin, post.k, post.pad,
+        dl_ptr = dlogits.data_ptr() + off * n * 4
+        _lib.check(lib.evmi_disc_post_dgrad(dl_ptr, w_post.data_ptr(), G[L].ptr, G[L].plane, G[L].T, ng, n, post.cin, post.k, post.pad,
                                             *fm_args(L), st), "evmi_disc_post_dgrad")
-        ops._count_conv(cfg.n_items, n, 1, post.cin, post.k)
+        ops._count_conv(ng, n, 1, post.cin, post.k)
         if not frozen:
             ws = ops.WS.get("dc_postw", lib.evmi_disc_post_wgrad_ws_elems(cfg.n_items, n, post.cin, post.k), dev)
             _lib.check(lib.evmi_disc_post_wgrad(A[L].ptr, A[L].plane, A[L].T, cfg.n_items, n, dlogits.data_ptr(), dw_post.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -268,9 +284,9 @@ class DiscChain:
             need_dx = i > 1 or audio.needs_grad or not frozen  # G_1 feeds the first layer's weight gradient / the waveform's gradient
             if need_dx:
                 _lib.check(lib.evmi_conv_pkflat_dgrad(G[i + 1].ptr, G[i + 1].plane, wf_d[i].data_ptr(), G[i].ptr, G[i].plane, cfg.ws_d[i].data_ptr(),
-                                                      cfg.ws_d[i].numel(), cfg.n_items, G[i + 1].T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups,
+                                                      cfg.ws_d[i].numel(), ng, G[i + 1].T, c.cin, c.cout, c.k, c.stride, c.pad, c.dil, c.groups,
                                                       cfg.lens[i], G[i].T, *fm_args(i), st), "evmi_conv_pkflat_dgrad")
-                ops._count_conv(cfg.n_items, cfg.lens[i + 1], c.cout, c.cin // c.groups, c.k)
+                ops._count_conv(ng, cfg.lens[i + 1], c.cout, c.cin // c.groups, c.k)
             if not frozen:
                 nws = lib.evmi_conv_pkflat_wgrad_ws_elems(cfg.n_items, G[i + 1].T, c.cin, c.cout, c.k, c.stride, c.dil, c.groups)
                 if nws < 0:
@@ -296,10 +312,11 @@ class DiscChain:
             ws = ops.WS.get("dc_rows", lib.evmi_pkflat_rowsum_ws_elems(L - 1, rows), dev)
             _lib.check(lib.evmi_pkflat_rowsum(L - 1, rows, ws.data_ptr(), ws.numel(), st), "evmi_pkflat_rowsum")
         if audio.needs_grad:
-            dxv = torch.empty(1, cfg.n_items, cfg.H, device=dev, dtype=torch.float32)
-            _lib.check(lib.evmi_disc_first_dgrad(G[1].ptr, G[1].plane, G[1].T, cfg.lens[1], eff[0][0].data_ptr(), dxv.data_ptr(), cfg.n_items, cfg.H, c0.cout,
-                                                 c0.k, c0.stride, c0.pad, st), "evmi_disc_first_dgrad")
-            ops._count_conv(cfg.n_items, cfg.lens[1], c0.cout, 1, c0.k)
+            # (a split batch: zeros for the waveforms that take no gradient)
+            dxv = ops.zeros(1, cfg.n_items, cfg.H, device=dev) if off else torch.empty(1, cfg.n_items, cfg.H, device=dev, dtype=torch.float32)
+            _lib.check(lib.evmi_disc_first_dgrad(G[1].ptr, G[1].plane, G[1].T, cfg.lens[1], eff[0][0].data_ptr(), dxv.data_ptr() + off * cfg.H * 4, ng, cfg.H,
+                                                 c0.cout, c0.k, c0.stride, c0.pad, st), "evmi_disc_first_dgrad")
+            ops._count_conv(ng, cfg.lens[1], c0.cout, 1, c0.k)
             audio.accumulate(dxv if self.period == 1 else ops.period_view_bwd(dxv, cfg.n_audio, cfg.t_audio, self.period))
 
 
@@ -322,6 +339,7 @@ class ChainFmaps:
         self.chain, self.cfg, self.logits = chain, cfg, logits
         self.A = cfg.A
         self.ref = None  # set by feature_matching(): the real-waveform call whose activations the backward compares with
+        self.split = False  # the batch is [real | generated]: the reference is the first half of this call's own tensors
 
     def feature_matching(self, real: "ChainFmaps", slot: torch.Tensor) -> None:
         """slot[0] += 2 * sum over the feature maps of mean |fake - real| (upstream feature_loss); the gradients are produced by
@@ -332,10 +350,24 @@ class ChainFmaps:
         pairs = (_lib.PkFlatPair * L)()
         for i in range(1, L + 1):
             p = pairs[i - 1]
-            p.a, p.b, p.units, p.scale = self.A[i].buf.data_ptr(), real.A[i].buf.data_ptr(), self.A[i].units, cfg.fm_scale[i]
+            if self.split:  # the generated half against the real half of the same tensor: row by row
+                a = self.A[i]
+                p.a, p.b, p.rows, p.plane, p.units = a.ptr + cfg.off_g * a.T * 16, a.ptr, a.C // 8, a.plane, cfg.n_items_g * a.T
+            else:
+                p.a, p.b, p.rows, p.plane, p.units = self.A[i].buf.data_ptr(), real.A[i].buf.data_ptr(), 1, 0, self.A[i].units
+            p.scale = cfg.fm_scale[i]
         dev = slot.device
         ws = ops.WS.get("dc_fm", lib.evmi_pkflat_absdiff_ws_elems(L), dev)
         _lib.check(lib.evmi_pkflat_absdiff(L, pairs, slot.data_ptr(), ws.data_ptr(), ws.numel(), ops._s(slot)), "evmi_pkflat_absdiff")
+        if self.split:
+            h = cfg.off_g
+            fg_d, fr_d = self.logits.data[:, h:], self.logits.data[:, :h]
+            n = fg_d.numel()
+            ops.scalar_reduce(0, fg_d.contiguous(), fr_d.contiguous(), slot, scale=2.0 / n, accumulate=True)
+            g = self.logits.grad[:, h:]
+            ops.axpby(1.0, g, 1.0, ops.elementwise(ops.EW_SIGN_DIFF, fg_d.contiguous(), fr_d.contiguous(), p0=2.0 / n), out=g)
+            self.ref = self
+            return
         fg, fr = self.logits, real.logits
         n = fg.data.numel()
         ops.scalar_reduce(0, fg.data, fr.data, slot, scale=2.0 / n, accumulate=True)

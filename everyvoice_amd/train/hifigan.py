@@ -260,10 +260,11 @@ class DiscriminatorPT:
     def layers(self):
         return [*self.convs, self.conv_post]
 
-    def forward(self, tape, audio: ag.Var, training=True, role="pair"):
+    def forward(self, tape, audio: ag.Var, training=True, role="pair", grad_from=None):
         chain = _chain_for(self, self.period, audio.data)
         if chain is not None:
-            return chain.forward(tape, audio, training, role)
+            return chain.forward(tape, audio, training, role, grad_from)
+        assert grad_from is None, "a [real | generated] batch is a packed chain's (train/disc_chain.py)"
         x = ag.period_view(tape, audio, self.period)  # [1, B*p, H]: Conv2d((k,1)) == Conv1d over H per column
         fmap = []
         for conv in self.convs:
@@ -287,10 +288,11 @@ class DiscriminatorST:
     def layers(self):
         return [*self.convs, self.conv_post]
 
-    def forward(self, tape, x: ag.Var, training=True, role="pair"):
+    def forward(self, tape, x: ag.Var, training=True, role="pair", grad_from=None):
         chain = _chain_for(self, 1, x.data)
         if chain is not None:
-            return chain.forward(tape, x, training, role)
+            return chain.forward(tape, x, training, role, grad_from)
+        assert grad_from is None, "a [real | generated] batch is a packed chain's (train/disc_chain.py)"
         fmap = []
         for conv in self.convs:
             x = ag.conv1d_lrelu(tape, x, conv, 0.1, training)
@@ -787,6 +789,14 @@ class HiFiGANTrainer:
 
     def _g_losses(self, i: int, real, fake):
         """Adversarial and feature-matching terms of one discriminator (into slots i) with their gradients."""
+        if real is None:  # a packed chain over [real | generated] (train/disc_chain.py: grad_from): the generated half's terms
+            dg, fm = fake
+            h = fm.cfg.off_g
+            dg.grad = ops.zeros(*dg.data.shape, device=dg.data.device)
+            d_f, g_f = dg.data[:, h:], dg.grad[:, h:]
+            self._logit_loss(d_f, g_f, True, d_f.numel(), self._slots[1, i : i + 1])
+            fm.feature_matching(None, self._slots[2, i : i + 1])
+            return
         (_, fr_list), (dg, fg_list) = real, fake
         n = dg.data.numel()
         dg.grad = torch.empty_like(dg.data)
@@ -1011,31 +1021,86 @@ class HiFiGANTrainer:
             frag_join()
             gd_tape = ag.Tape()
             real = ag.Var(y, needs_grad=False)
-            xs_r = self._scale_inputs(gd_tape, real)
-            xs_f = self._scale_inputs(gd_tape, y_hat_in)
-            n_p = len(self.mpd)
-            fake_leaves = fan_out(gd_tape, y_hat_in, n_p + 1)
-            ins_r = [real] * (n_p + 1) + xs_r[1:]
-            ins_f = [*fake_leaves[:n_p], fake_leaves[-1], *[fan_out(gd_tape, x, 1)[0] for x in xs_f[1:]]]
             ds = self.discriminators()
             nd = len(ds)
-            # generated-waveform chains on streams 0 .. nd-1 (their backward too), real-waveform chains (forward only) and the
-            # reconstruction loss on the streams after them; the spectral-norm scale hands out its real call first
+            n_p = len(self.mpd)
+            is_sn = [any(isinstance(l, SNConv) for l in d.layers()) for d in ds]
+            # Packed chains (precision "bf16"): every weight-normed discriminator sees [real | generated] as ONE batch -- forward once
+            # over 2B waveforms (half the launches of two B-waveform passes, each better filled), backward over the generated half,
+            # feature matching between the two halves of the same tensors.  The spectral-norm scale keeps its two calls (each call
+            # runs its own power iteration: two different effective weights).
+            pair_mode = all(sn or _chain_for(d, getattr(d, "period", 1), y) is not None for d, sn in zip(ds, is_sn)) and not all(is_sn)
             res_r, res_f = [None] * nd, [None] * nd
+            pair_in = None
+            if pair_mode:
+                T = y.shape[-1]
+                pair_t = torch.empty(1, 2 * B, T, device=self.device, dtype=torch.float32)
+                ops.copy(y, out=pair_t[:, :B])
+                ops.copy(y_hat.data, out=pair_t[:, B:])
+                pair_in = ag.Var(pair_t)
+                xs_p = self._scale_inputs(gd_tape, pair_in)
+                sn_pooled = any(is_sn[i] and i > n_p for i in range(nd))  # (a spectral-norm scale behind the pooling: not in the upstream model)
+                xs_r = self._scale_inputs(gd_tape, real) if sn_pooled else [real]
+                xs_f = self._scale_inputs(gd_tape, y_hat_in) if sn_pooled else [y_hat_in]
+                n_wave = sum(1 for i in range(nd) if not is_sn[i] and i <= n_p)  # chains reading the waveform itself: the periods (+ scale 0 when weight-normed)
+                p_leaves = fan_out(gd_tape, pair_in, n_wave)
+                f_leaves = fan_out(gd_tape, y_hat_in, sum(1 for i in range(nd) if is_sn[i] and i <= n_p))
+                ins_p, ins_r, ins_f = [None] * nd, [None] * nd, [None] * nd
+                pi = fi = 0
+                for i in range(nd):
+                    scale = max(0, i - n_p)
+                    if is_sn[i]:
+                        ins_r[i] = xs_r[scale]
+                        if scale == 0:
+                            ins_f[i] = f_leaves[fi]
+                            fi += 1
+                        else:
+                            ins_f[i] = fan_out(gd_tape, xs_f[scale], 1)[0]
+                    elif scale == 0:
+                        ins_p[i] = p_leaves[pi]
+                        pi += 1
+                    else:
+                        ins_p[i] = fan_out(gd_tape, xs_p[scale], 1)[0]
 
-            def fwd_real(i):
-                return lambda sub: res_r.__setitem__(i, self._g_forward(sub, ds[i], ins_r[i], "g_real"))
+                def fwd_pair(i):
+                    return lambda sub: res_f.__setitem__(i, ds[i].forward(sub, ins_p[i], role="g_both", grad_from=B))
 
-            def fwd_fake(i):
-                return lambda sub: res_f.__setitem__(i, self._g_forward(sub, ds[i], ins_f[i], "g_fake"))
+                def fwd_real(i):
+                    return lambda sub: res_r.__setitem__(i, self._g_forward(sub, ds[i], ins_r[i], "g_real"))
 
-            sn_first = [i for i, d in enumerate(ds) if any(isinstance(l, SNConv) for l in d.layers())]
-            order_fake = [fwd_fake(i) for i in range(nd)]
-            order_real = [fwd_real(i) for i in range(nd)]
-            # host order decides which prepared spectral-norm call a chain receives: issue the real chains of those scales first
-            self._ordered_section(gd_tape, order_fake, order_real + [lambda sub: recon.__setitem__(0, self._recon_grad(y, y_hat.data, B))], first=[nd + i for i in sn_first])
+                def fwd_fake(i):
+                    return lambda sub: res_f.__setitem__(i, self._g_forward(sub, ds[i], ins_f[i], "g_fake"))
+
+                sn_idx = [i for i in range(nd) if is_sn[i]]
+                order_a = [fwd_fake(i) if is_sn[i] else fwd_pair(i) for i in range(nd)]
+                order_b = [fwd_real(i) for i in sn_idx]
+                # host order decides which prepared spectral-norm call a chain receives: issue the real chains of those scales first
+                self._ordered_section(gd_tape, order_a, order_b + [lambda sub: recon.__setitem__(0, self._recon_grad(y, y_hat.data, B))],
+                                      first=[nd + j for j in range(len(sn_idx))])
+            else:
+                xs_r = self._scale_inputs(gd_tape, real)
+                xs_f = self._scale_inputs(gd_tape, y_hat_in)
+                fake_leaves = fan_out(gd_tape, y_hat_in, n_p + 1)
+                ins_r = [real] * (n_p + 1) + xs_r[1:]
+                ins_f = [*fake_leaves[:n_p], fake_leaves[-1], *[fan_out(gd_tape, x, 1)[0] for x in xs_f[1:]]]
+                # generated-waveform chains on streams 0 .. nd-1 (their backward too), real-waveform chains (forward only) and the
+                # reconstruction loss on the streams after them; the spectral-norm scale hands out its real call first
+
+                def fwd_real(i):
+                    return lambda sub: res_r.__setitem__(i, self._g_forward(sub, ds[i], ins_r[i], "g_real"))
+
+                def fwd_fake(i):
+                    return lambda sub: res_f.__setitem__(i, self._g_forward(sub, ds[i], ins_f[i], "g_fake"))
+
+                sn_first = [i for i in range(nd) if is_sn[i]]
+                order_fake = [fwd_fake(i) for i in range(nd)]
+                order_real = [fwd_real(i) for i in range(nd)]
+                # host order decides which prepared spectral-norm call a chain receives: issue the real chains of those scales first
+                self._ordered_section(gd_tape, order_fake, order_real + [lambda sub: recon.__setitem__(0, self._recon_grad(y, y_hat.data, B))], first=[nd + i for i in sn_first])
             self.branches.run([(lambda i=i: self._g_losses(i, res_r[i], res_f[i])) for i in range(nd)])
             gd_tape.backward()
+            if pair_in is not None and pair_in.grad is not None:  # the generated half of the batched chains' waveform gradient
+                y_hat_in.accumulate(ops.copy(pair_in.grad[:, B:].contiguous()))
             ops.scalar_reduce(2, self._slots[1], None, self._loss_buf[1:2])
             ops.scalar_reduce(2, self._slots[2], None, self._loss_buf[2:3])
             for layer in ctx["d_layers"]:

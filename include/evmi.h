@@ -404,7 +404,8 @@ int evmi_tm_lrelu_bf16(const void* x_tm, void* y_tm, long long n_elems, float sl
  *                             weight / bias gradient from a flat packed dy, input gradient -> fp32 [n_items][H]
  *   evmi_disc_post_*          the one-output-channel logit layer: flat packed x -> fp32 logits [n_items][n]; dlogits -> flat packed dx
  *                             (with the mask / feature-matching tail); weight gradient
- *   evmi_pkflat_absdiff       out[0] += sum_l scale_l * sum |a_l - b_l| over pairs of whole buffers (gaps are zero in both)
+ *   evmi_pkflat_absdiff       out[0] += sum_l scale_l * sum |a_l - b_l| over pairs of whole buffers (gaps are zero in both), or of two item
+ *                             ranges of one tensor row by row (the generator step's [real | generated] batch)
  *   evmi_pkflat_rowsum        db_l[c] += sum of row c of dy_l (bias gradients of a whole chain in one launch pair) */
 typedef struct {
   int mode; /* 0: forward, 1: input gradient */
@@ -416,7 +417,9 @@ typedef struct {
 typedef struct {
   const void* a;
   const void* b;
-  long long units; /* 16-byte units of each buffer */
+  long long units; /* 16-byte units compared per row */
+  long long plane; /* units between two rows (rows > 1) */
+  int rows;        /* 1: a / b are whole buffers; C / 8: two item ranges of packed tensors, row by row */
   float scale;
 } evmi_pkflat_pair;
 typedef struct {

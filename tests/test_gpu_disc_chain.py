@@ -126,6 +126,48 @@ def _run_g_step(tr, i, d, y, y_hat, chain):
             layer.frozen = False
 
 
+@pytest.mark.parametrize("which", ["mpd0", "mpd4", "msd1", "msd2"])
+def test_generator_step_on_one_real_and_generated_batch_equals_two_passes(which):
+    """The generator step of a weight-normed discriminator as ONE forward over [real | generated] with the backward over the generated
+    half (DiscChain.forward(grad_from=B)) against the two separate passes: same kernels on the same values, only the column counts
+    (hence tiles and split-K sums) differ."""
+    from everyvoice_amd.train import autograd as ag
+    from everyvoice_amd.train import ops
+
+    tr = _trainer()
+    i = int(which[3]) if which.startswith("mpd") else len(tr.mpd) + int(which[3])
+    d = tr.discriminators()[i]
+    B, T = 2, 8192
+    g = torch.Generator().manual_seed(9)
+    y = (0.5 * torch.tanh(torch.randn(1, B, T, generator=g))).cuda()
+    y_hat = (0.5 * torch.tanh(torch.randn(1, B, T, generator=g))).cuda()
+    for _ in range(int(which[3]) if which.startswith("msd") else 0):
+        y, y_hat = ops.avgpool4s2(y), ops.avgpool4s2(y_hat)
+    want_slots, want_dx = _run_g_step(tr, i, d, y, y_hat, chain=True)
+    ops.CONV_BACKEND["operands"] = "bf16"
+    try:
+        for layer in d.layers():
+            layer.frozen = True
+        tr._materialize(d.layers())
+        ops.fill_(tr._slots, 0.0)
+        tape = ag.Tape()
+        both = ag.Var(torch.cat([y, y_hat], 1).contiguous())
+        res = d.forward(tape, both, role="g_both", grad_from=B)
+        tr._g_losses(i, None, res)
+        tape.backward()
+        torch.cuda.synchronize()
+        got_slots, got_dx = tr._slots[:, i].clone(), both.grad.clone()
+    finally:
+        ops.CONV_BACKEND["operands"] = "f32"
+        for layer in d.layers():
+            layer.frozen = False
+    assert float(got_dx[:, :B].abs().max()) == 0.0  # nothing flows into the real half
+    for row in (1, 2):
+        assert abs(float(got_slots[row]) - float(want_slots[row])) <= 1e-4 * abs(float(want_slots[row])), (row, got_slots, want_slots)
+    c, r = _cos(got_dx[:, B:], want_dx), float(got_dx[:, B:].norm() / want_dx.norm())
+    assert c >= 0.9999 and abs(r - 1) <= 2e-3, (c, r)
+
+
 @pytest.mark.parametrize("which", ["mpd1", "mpd3", "msd0", "msd1"])
 def test_generator_step_pass_of_a_chain_equals_the_op_by_op_path(which):
     tr = _trainer()

@@ -37,7 +37,7 @@ def run():
     slot = torch.zeros(1, device=dev)
     ws = torch.empty(lib.evmi_pkflat_absdiff_ws_elems(1), device=dev)
     pair = (_lib.PkFlatPair * 1)()
-    pair[0].a, pair[0].b, pair[0].units, pair[0].scale = a.data_ptr(), b.data_ptr(), N_UNITS, 1.0
+    pair[0].a, pair[0].b, pair[0].units, pair[0].plane, pair[0].rows, pair[0].scale = a.data_ptr(), b.data_ptr(), N_UNITS, 0, 1, 1.0
     for _ in range(3):
         ops.copy(a, out=b)
         torch.cuda.synchronize()
