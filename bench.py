@@ -552,8 +552,15 @@ def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
     flops = forward_flops(lens.cpu(), t_i, int(ids.shape[1]), int(t_i.max()), 32)
     tflops = flops * steps / elapsed / 1e12
     peak = MFMA_PEAK_TFLOPS_BF16 if prec == "bf16" else 157.0
+    traffic, traffic_src = None, None
+    metas = sorted((ROOT / "profiles").glob("*fs2infer_pmc_summary.meta.json"))
+    if metas:  # recorded rocprofv3 --pmc passes over this forward (tools/gpu_profile_fs2_infer.sh): HBM bytes per forward, all kernels
+        meta = json.loads(metas[-1].read_text())
+        traffic = round(meta["hbm_bytes_per_step"])
+        traffic_src = (f"profiles/{metas[-1].name.replace('.meta', '')}: FETCH_SIZE + WRITE_SIZE of every kernel of a forward (separate --pmc passes; "
+                       f"{meta.get('convention', 'raw KiB counters')}; collected at commit {meta.get('commit')})")
     return {"roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
-                         "traffic": None, "flop_per_batch": flops, "scope": "whole forward (dense layers on the padded grids)"},
+                         "traffic": traffic, "traffic_source": traffic_src, "flop_per_batch": flops, "scope": "whole forward (dense layers on the padded grids)"},
             "metric": "fastspeech2_infer_mel_frames_per_sec", "value": round(world * frames * steps / elapsed, 1), "unit": "frames/s",
             "ms_per_batch": round(elapsed / steps * 1e3, 3), "batch": 32, "max_tokens": int(ids.shape[1]), "frames_per_batch": frames,
             "dtype": prec, "steps": steps, "warmup": warmup, "parallelism": f"replicas x{world}",

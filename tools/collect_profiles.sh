@@ -1,6 +1,6 @@
 #!/bin/bash
 # One round's profile set on the GPU box, reduced to what gets committed (summaries, not raw traces: gpurun merges <= 64 MiB back).
-# usage (through gpurun): bash tools/collect_profiles.sh <tag> <what...>   what: bench | stats | pmc_infer | pmc_train | pmc_fs2
+# usage (through gpurun): bash tools/collect_profiles.sh <tag> <what...>   what: bench | stats | pmc_infer | pmc_train | pmc_fs2 | pmc_fs2infer
 # Everything ends up in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 TAG=$1; shift
 R=$GRAFT_REPO_ROOT
@@ -31,6 +31,11 @@ for what in "$@"; do
       python3 $R/tools/pmc_summarize_train.py ${TAG}_fs2 5 > $OUT/${TAG}_fs2_pmc_summarize.log 2>&1
       cp $R/profiles/${TAG}_fs2_pmc_summary.json $R/profiles/${TAG}_fs2_pmc_summary.meta.json $OUT/ 2>/dev/null
       rm -rf $OUT/${TAG}_fs2_pmc_fetch $OUT/${TAG}_fs2_pmc_write $OUT/${TAG}_fs2_pmc_sq ;;
+    pmc_fs2infer)
+      bash $R/tools/gpu_profile_fs2_infer.sh ${TAG}_fs2infer > $OUT/${TAG}_fs2infer_pmc.log 2>&1
+      python3 $R/tools/pmc_summarize_train.py ${TAG}_fs2infer 5 > $OUT/${TAG}_fs2infer_pmc_summarize.log 2>&1
+      cp $R/profiles/${TAG}_fs2infer_pmc_summary.json $R/profiles/${TAG}_fs2infer_pmc_summary.meta.json $OUT/ 2>/dev/null
+      rm -rf $OUT/${TAG}_fs2infer_pmc_fetch $OUT/${TAG}_fs2infer_pmc_write $OUT/${TAG}_fs2infer_pmc_sq ;;
   esac
 done
 du -sh $OUT; ls $OUT | grep $TAG
