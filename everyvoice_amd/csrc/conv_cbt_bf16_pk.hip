@@ -1032,9 +1032,13 @@ struct FragBatch {
   int start[PKFLAT_MAX_JOBS + 1];
   int n;
 };
-// One workgroup per (group, 32-row block, channel octet): reads the block's weights once, coalesced (forward: 8 x kt contiguous
-// floats per row; input gradient: 32 rows x k contiguous floats per channel), and writes the half-fragments of every (phase, tap).
+// One workgroup per (group, 32-row block, channel octet): its 256 (row, channel) pairs own k contiguous floats each -- the block is a
+// set of contiguous runs (forward: 8 x k floats per row; input gradient: 32 x k floats per channel).  Every thread copies its run into
+// the LDS first (each cache line requested once: the loop over (phase, tap) that picked single floats out of the runs re-fetched
+// the lines per tap -- 5.2 GB per GAN step for 1.7 GB of weights and fragments, profiles/r04v_train_pmc_summary.json), then the half-fragments
+// of every (phase, tap) are assembled from there.
 __global__ __launch_bounds__(256) void wfrag_flat_kernel(FragBatch b) {
+  extern __shared__ float runs[];  // [256][k_full + 1]
   int jn = 0;
   while (jn + 1 < b.n && (int)blockIdx.x >= b.start[jn + 1]) ++jn;
   const FragJob& f = b.job[jn];
@@ -1045,15 +1049,18 @@ __global__ __launch_bounds__(256) void wfrag_flat_kernel(FragBatch b) {
   const int r = f.mode == 0 ? t >> 3 : t & 31, c = f.mode == 0 ? t & 7 : t >> 5;
   const int row = mb * 32 + r, kc = o * 8 + c;
   const bool valid = row < f.rows_g && kc < f.kch_g;
-  const int kt = f.kt;
-  const float* src = f.mode == 0 ? f.w + ((long long)(g * f.rows_g + row) * f.kch_g + kc) * kt
-                                 : f.w + ((long long)(g * f.kch_g + kc) * f.rows_g + row) * f.k_full;
+  const int kt = f.kt, kf = f.k_full, ld = kf + 1;
+  const float* src = f.mode == 0 ? f.w + ((long long)(g * f.rows_g + row) * f.kch_g + kc) * kf
+                                 : f.w + ((long long)(g * f.kch_g + kc) * f.rows_g + row) * kf;
+  float* mine = runs + t * ld;
+  for (int j = 0; j < kf; ++j) mine[j] = valid ? src[j] : 0.f;
+  // (no barrier: a thread reads back its own run only; the partner's value comes through the shuffle)
   for (int phi = 0; phi < f.phases; ++phi) {
-    const int m_phi = f.mode == 0 ? kt : (f.k_full - phi + f.stride - 1) / f.stride, lead = kt - m_phi;
+    const int m_phi = f.mode == 0 ? kt : (kf - phi + f.stride - 1) / f.stride, lead = kt - m_phi;
     unsigned* dst = f.wf + phi * f.phase_stride_words + (long long)gmb * f.kblocks * 256;
     for (int j = 0; j < kt; ++j) {
       float v = 0.f;
-      if (valid && j >= lead) v = f.mode == 0 ? src[j] : src[phi + f.stride * (m_phi - 1 - (j - lead))];
+      if (j >= lead) v = f.mode == 0 ? mine[j] : mine[phi + f.stride * (m_phi - 1 - (j - lead))];
       const float other = __shfl_xor(v, f.mode == 0 ? 1 : 32, 64);
       if ((c & 1) == 0) {
         const int h = o * kt + j;
@@ -1313,7 +1320,11 @@ int evmi_conv_pkflat_fragments(int n_jobs, const evmi_pkflat_job* jobs, void* st
       if (b.start[j] + nb > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv_pkflat_fragments: grid limits");
       b.start[j + 1] = b.start[j] + (int)nb;
     }
-    if (b.start[b.n] > 0) hipLaunchKernelGGL(wfrag_flat_kernel, dim3((unsigned)b.start[b.n]), dim3(256), 0, (hipStream_t)stream, b);
+    int k_max = 1;
+    for (int j = 0; j < b.n; ++j) k_max = std::max(k_max, b.job[j].k_full);
+    if (k_max > 48) return fail(EVMI_ERR_UNSUPPORTED, "conv_pkflat_fragments: kernels longer than 48 taps");
+    if (b.start[b.n] > 0)
+      hipLaunchKernelGGL(wfrag_flat_kernel, dim3((unsigned)b.start[b.n]), dim3(256), (size_t)256 * (k_max + 1) * sizeof(float), (hipStream_t)stream, b);
     EVMI_LAUNCH_CHECK("conv_pkflat_fragments");
   }
   return EVMI_OK;
