@@ -61,6 +61,11 @@ constexpr int WG_KS = 64;  // positions per K step (4 MFMA K blocks)
 // read touches (4 consecutive positions = 64 bytes each) fall on different banks (a stride of 1 KB puts them on the same ones:
 // SQ_LDS_BANK_CONFLICT was 75 % of the LDS cycles); the staged x rows get the same 4 units of padding
 constexpr int WG_YROW = WG_KS + 4;
+// ... and of the staged x rows.  A 16-lane group of the transposing read touches two octet rows x four positions `stride` units apart:
+// positions sit 4 * stride banks apart, so with strides 2 / 4 a row offset of 16 banks (4 units) lands the second row ON the first
+// one's positions (SQ_LDS_BANK_CONFLICT 40.8 % of the LDS cycles of the flat weight gradients, profiles/r04v_train_pmc_summary.json);
+// one unit (4 banks) interleaves them.  Strides 1 and 3 keep the 4 units (positions 4 / 12 banks apart: one unit would collide).
+static inline int wg_xrow_pad(int stride) { return (stride == 2 || stride == 4) ? 1 : 4; }
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ s16x4 lds_read_tr(const char* p) {
@@ -116,18 +121,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
     uint4* sx = sy + y_units;
     const long long f0 = (long long)t * WG_KS;
     int issued = 0;
+    // (octet rows past the group are NOT staged: what the transposing reads find there multiplies into accumulator rows / columns
+    // that are never stored -- staging the last valid row again in their place was half of the loads of the 32-channel groups)
+    const int ny = min(8, a.octs_y - oy0), nx = min(8, a.octs_x - ox0);
     int u = wave;
-    for (; u < 8; u += 4) {  // dy: 8 octet rows x 64 units = one 1 KB piece each
-      const int o = min(oy0 + u, a.octs_y - 1);
+    for (; u < ny; u += 4) {  // dy: up to 8 octet rows x 64 units = one 1 KB piece each
+      const int o = oy0 + u;
       if (TM) pk_lds_direct(reinterpret_cast<const uint4*>(a.dy_tm + (f0 + lane) * a.cy_row + (g * a.cout_g + o * 8)), sy + u * WG_YROW);
       else pk_lds_direct(dy_g + (long long)o * a.plane_y + f0 + lane, sy + u * WG_YROW);
       ++issued;
     }
-    u -= 8;
+    u = wave;
     const long long x0 = f0 * s + (long long)j_lo * d + (TM ? 0 : a.x_unit_off);
-    for (; u < 8 * xpieces; u += 4) {
+    for (; u < nx * xpieces; u += 4) {
       const int r = u / xpieces, pi = u - r * xpieces;
-      const int o = min(ox0 + r, a.octs_x - 1);
+      const int o = ox0 + r;
       if (TM) pk_lds_direct(reinterpret_cast<const uint4*>(a.x_tm + (x0 + a.x_row_off + pi * 64 + lane) * a.cx_row + (g * a.cin_g + o * 8)),
                             sx + r * xrow + pi * 64);
       else pk_lds_direct(x_g + (long long)o * a.plane_x + x0 + pi * 64 + lane, sx + r * xrow + pi * 64);
@@ -299,7 +307,7 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
   const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;
   if (xwin > 64 * 12) return "input window too long";
   a.xpieces = (int)((xwin + 63) / 64);
-  a.xrow = a.xpieces * 64 + 4;
+  a.xrow = a.xpieces * 64 + wg_xrow_pad(stride);
   const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
   a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
   const int fn = wg_env_int("EVMI_WG_NST", 0);
@@ -508,7 +516,7 @@ static const char* plan_wgrad_flat(WgradPkArgs& a, WgradPkPlan& pl, int& sgroups
   if (stride > 8) return "stride above 8";
   a.bd_cout = a.bd_cin = 0;
   sgroups = groups;
-  if (groups > 1 && (cin_g < 32 || cout_g < 32)) {  // super-groups of m convolution groups: 64 output channels where the group count allows
+  if (groups > 1 && (cin_g < 64 && cout_g < 64)) {  // super-groups of m convolution groups: 64 output channels where the group count allows
     int m = std::max(1, 64 / cout_g);
     while (m > 1 && groups % m) m >>= 1;
     if (m > 1) {
@@ -529,7 +537,7 @@ static const char* plan_wgrad_flat(WgradPkArgs& a, WgradPkPlan& pl, int& sgroups
   const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;
   if (xwin > 64 * 12) return "input window too long";
   a.xpieces = (int)((xwin + 63) / 64);
-  a.xrow = a.xpieces * 64 + 4;
+  a.xrow = a.xpieces * 64 + wg_xrow_pad(stride);
   const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
   a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
   pl.lds = a.nst * stage_bytes;
