@@ -70,6 +70,7 @@ class PkFlatRows(C.Structure):  # evmi_pkflat_rows
 
 # name -> (restype, argtypes); every symbol include/evmi.h declares
 SYMBOLS = {
+    "evmi_tm_colsum_batch_bf16": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
     "evmi_conv_pkflat_ws_elems": (C.c_longlong, [C.c_int] * 10),
     "evmi_conv_pkflat_plan": (C.c_int, [C.c_int] * 10),
     "evmi_conv_pkflat_tab": (C.c_int, [C.c_int] * 10 + [C.c_void_p, C.c_longlong, C.c_void_p]),

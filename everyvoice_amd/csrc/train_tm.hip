@@ -166,6 +166,69 @@ __global__ __launch_bounds__(256) void tm_colsum_final_kernel(const float* __res
   }
 }
 
+// The same for up to TM_COLSUM_JOBS tensors of one shape in one launch pair (the bias gradients of a whole residual stack: 18 tensors per
+// stage -- 144 launches of 5-7 us on the backward chains of a GAN step as single calls): grid.y = tensor
+constexpr int TM_COLSUM_JOBS = 24;
+struct ColsumBatch {
+  const bf16_t* dy[TM_COLSUM_JOBS];
+  float* db[TM_COLSUM_JOBS];
+};
+__global__ __launch_bounds__(256) void tm_colsum_partial_batch_kernel(ColsumBatch b, float* __restrict__ part, long long rows, int C, int nblk) {
+  const bf16_t* dy = b.dy[blockIdx.y];
+  part += (long long)blockIdx.y * nblk * C;
+  const int octs = C >> 3;
+  const int o = threadIdx.x % octs, rl = threadIdx.x / octs, rstep = 256 / octs;
+  const long long r0 = (long long)blockIdx.x * COLSUM_ROWS;
+  const long long r1 = min(rows, r0 + COLSUM_ROWS);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < rstep) {
+    bf16x8 v[4];
+    long long r = r0 + rl;
+    for (; r + 3 * rstep < r1; r += 4 * rstep) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8*>(dy + (r + (long long)u * rstep) * C + o * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
+    }
+    for (; r < r1; r += rstep) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(dy + r * C + o * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)w[e];
+    }
+  }
+  __shared__ float sh[256 * 8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sh[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int c = threadIdx.x, oo = c >> 3, e = c & 7;
+    float s = 0.f;
+    for (int q = 0; q < rstep; ++q) s += sh[(q * octs + oo) * 8 + e];
+    part[(long long)blockIdx.x * C + c] = s;
+  }
+}
+__global__ __launch_bounds__(256) void tm_colsum_final_batch_kernel(ColsumBatch b, const float* __restrict__ part, int nblk, int C, int accumulate) {
+  __shared__ float sh[8][32];
+  float* db = b.db[blockIdx.y];
+  part += (long long)blockIdx.y * nblk * C;
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int per = (nblk + 7) / 8;
+  float s = 0.f;
+  const int lo = sl * per, hi = min(nblk, (sl + 1) * per);
+  if (c < C && hi > lo) s = ordered_sum_strided(part + (long long)lo * C + c, C, hi - lo);
+  sh[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += sh[q][cl];
+    db[c] = accumulate ? db[c] + t : t;
+  }
+}
+
 // Every weight of a residual stack into its convolution kernel's tile layout in ONE launch: table[l] = {src offset (floats, from
 // w_base), dst offset (bf16 elements, from dst_base), ks, BM, KC, wlayout, mode, 0}; grid (ceil(C * C * ks_max / 256), layers)
 __global__ void relayout_tc_batched_kernel(const float* __restrict__ w_base, bf16_t* __restrict__ dst_base, const long long* __restrict__ table, int C) {
@@ -288,6 +351,27 @@ int evmi_tm_colsum_bf16(const void* dy_tm, float* db_dev, float* ws_dev, long lo
   EVMI_LAUNCH_CHECK("tm_colsum_partial");
   hipLaunchKernelGGL(tm_colsum_final_kernel, dim3((C + 31) / 32), dim3(256), 0, s, ws_dev, db_dev, (int)nblk, C, accumulate);
   EVMI_LAUNCH_CHECK("tm_colsum_final");
+  return EVMI_OK;
+}
+
+/* The same for n (<= 24) tensors of one shape, one launch pair: dy_tm[i] -> db_dev[i]; ws: n * evmi_tm_colsum_bf16_ws_elems floats. */
+int evmi_tm_colsum_batch_bf16(int n, const void* const* dy_tm, float* const* db_dev, float* ws_dev, long long ws_elems, long long rows, int C, int accumulate,
+                              void* stream) {
+  if (n <= 0 || n > TM_COLSUM_JOBS || !dy_tm || !db_dev || !ws_dev || rows <= 0 || C <= 0 || (C & 7) || C > 256)
+    return fail(EVMI_ERR_INVALID_ARG, "tm_colsum_batch_bf16: bad arguments (1..24 tensors, C: multiple of 8, <= 256)");
+  const long long nblk = (rows + COLSUM_ROWS - 1) / COLSUM_ROWS;
+  if (ws_elems < (long long)n * nblk * C) return fail(EVMI_ERR_INVALID_ARG, "tm_colsum_batch_bf16: workspace too small");
+  ColsumBatch b;
+  for (int i = 0; i < n; ++i) {
+    if (!dy_tm[i] || !db_dev[i]) return fail(EVMI_ERR_INVALID_ARG, "tm_colsum_batch_bf16: null tensor");
+    b.dy[i] = reinterpret_cast<const bf16_t*>(dy_tm[i]);
+    b.db[i] = db_dev[i];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tm_colsum_partial_batch_kernel, dim3((unsigned)nblk, n), dim3(256), 0, s, b, ws_dev, rows, C, (int)nblk);
+  EVMI_LAUNCH_CHECK("tm_colsum_partial_batch");
+  hipLaunchKernelGGL(tm_colsum_final_batch_kernel, dim3((C + 31) / 32, n), dim3(256), 0, s, b, ws_dev, (int)nblk, C, accumulate);
+  EVMI_LAUNCH_CHECK("tm_colsum_final_batch");
   return EVMI_OK;
 }
 

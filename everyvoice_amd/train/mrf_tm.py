@@ -161,6 +161,21 @@ class MRFStageTM:
         ws = ops.WS.get("tm_colsum", n, self.device)
         _lib.check(lib.evmi_tm_colsum_bf16(dy.ptr, db.data_ptr(), ws.data_ptr(), n, dy.rows, self.C, 1, _s(self.device)), "evmi_tm_colsum_bf16")
 
+    def _colsum_batch(self, jobs):
+        """jobs: (TMBuf, bias-gradient sink) of one shape: db += column sums, 24 tensors per launch pair."""
+        import ctypes as C
+
+        lib = _lib.load()
+        for i in range(0, len(jobs), 24):
+            part = jobs[i:i + 24]
+            n = len(part)
+            rows = part[0][0].rows
+            dys = (C.c_void_p * n)(*[b.ptr for b, _ in part])
+            dbs = (C.c_void_p * n)(*[d.data_ptr() for _, d in part])
+            ne = n * lib.evmi_tm_colsum_bf16_ws_elems(rows, self.C)
+            ws = ops.WS.get("tm_colsum_b", ne, self.device)
+            _lib.check(lib.evmi_tm_colsum_batch_bf16(n, dys, dbs, ws.data_ptr(), ne, rows, self.C, 1, _s(self.device)), "evmi_tm_colsum_batch_bf16")
+
     def _lrelu(self, x: TMBuf, y: TMBuf):
         _lib.check(_lib.load().evmi_tm_lrelu_bf16(x.ptr, y.ptr, x.numel_body, self.slope, _s(self.device)), "evmi_tm_lrelu_bf16")
 
@@ -211,6 +226,9 @@ class MRFStageTM:
             dy0 = self.buf("dy0", B, T)
             self._to_tm(out.grad, dy0, 1.0 / nb)
             dxs = [None] * nb
+            bias_jobs = [[] for _ in range(nb)]  # (gradient tensor, bias-gradient sink) of every convolution: column sums of the whole
+                                                 # stack in ONE launch pair behind the branches (18 tensors: 36 launches of 5-7 us on
+                                                 # the branch chains as single calls); every pair keeps its own gradient buffers for it
 
             def bwd_branch(j):
                 def go():
@@ -222,20 +240,21 @@ class MRFStageTM:
                         t = self.buf(("t", j, m), B, T)
                         _, dw1 = c1.effective(True)
                         _, dw2 = c2.effective(True)
-                        self._colsum(dcur, c2.call_db_sink())
+                        bias_jobs[j].append((dcur, c2.call_db_sink()))
                         self._wgrad(t, dcur, dw2, c2.k, 1)
-                        dc1 = self.buf(("dc1", j), B, T)
+                        dc1 = self.buf(("dc1", j, m), B, T)
                         self._conv(dcur, self._laid_ptr(c2, True), self.zero_bias, dc1, c2.k, 1, mask=t, mask_slope=slope)
-                        self._colsum(dc1, c1.call_db_sink())
+                        bias_jobs[j].append((dc1, c1.call_db_sink()))
                         self._lrelu(cur, act)
                         self._wgrad(act, dc1, dw1, c1.k, c1.dil)
-                        dx = self.buf(("dx", j, m % 2), B, T)
+                        dx = self.buf(("dx", j, m), B, T)
                         self._conv(dc1, self._laid_ptr(c1, True), self.zero_bias, dx, c1.k, c1.dil, mask=cur, mask_slope=slope, res=dcur)
                         dcur = dx
                     dxs[j] = dcur
                 return go
 
             run([bwd_branch(j) for j in range(nb)])
+            self._colsum_batch([job for jobs in bias_jobs for job in jobs])
             x.accumulate(self._to_cbt(dxs, 1.0))
 
         tape.record(bwd)

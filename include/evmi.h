@@ -370,6 +370,9 @@ int evmi_conv1d_wgrad_tm_bf16(const void* x_tm, const void* dy_tm, float* dw_dev
 long long evmi_tm_colsum_bf16_ws_elems(long long rows, int C);
 int evmi_tm_colsum_bf16(const void* dy_tm, float* db_dev, float* ws_dev, long long ws_elems, long long rows, int C, int accumulate,
                         void* stream);
+/* ... the bias gradients of n (<= 24) tensors of one shape in one launch pair (a whole residual stack); ws: n x the single call's. */
+int evmi_tm_colsum_batch_bf16(int n, const void* const* dy_tm, float* const* db_dev, float* ws_dev, long long ws_elems, long long rows, int C, int accumulate,
+                              void* stream);
 int evmi_cbt_f32_to_tm_bf16(const float* x_dev, void* tm_dev, int C, int B, int T, int Tp, int PL, float slope, float scale, void* stream);
 int evmi_tm_bf16_to_cbt_f32(const void* a_tm, const void* b_tm, const void* c_tm, float* out_dev, int C, int B, int T, int Tp, int PL,
                             float scale, void* stream);
