@@ -664,7 +664,9 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct PkTile { int bm, bn; };
 // (index 7, 8: eight-wave forms of 128 x 256 and 128 x 128 -- 64 x 64 / 64 x 32 per wave)
-// (index 9: 128 x 128 with the weight fragments in registers -- conv_pk_kernel<..., ADIR>)
+// (index 9: 128 x 128 with the weight fragments in registers -- conv_pk_kernel<..., ADIR>.  The same for the 32 x 128 tile of the
+// narrow-group layers was built and measured SLOWER -- 110 -> 130 us, 66 -> 87 us on the scale discriminators' first grouped layers:
+// its four waves all need the same 32 rows, so registers mean four fetches of every fragment where the LDS needs one)
 static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {64, 256}, {32, 256}, {128, 256}, {128, 256}, {128, 128}, {128, 128}};
 constexpr int kNumPkTiles = sizeof(kPkTiles) / sizeof(kPkTiles[0]);
 

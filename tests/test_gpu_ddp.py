@@ -25,7 +25,7 @@ def _batch(B, S, seed=8):
     return mel, y
 
 
-def _rank_main(rank, world, port, use_graph, steps, out_dir, B, S):
+def _rank_main(rank, world, port, use_graph, steps, out_dir, B, S, precision="f32"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, str(ROOT))
     import torch.distributed as dist
@@ -35,7 +35,7 @@ def _rank_main(rank, world, port, use_graph, steps, out_dir, B, S):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda:0")
     try:
-        tr = HiFiGANTrainer(device=dev, seed=5, process_group=True, use_graph=use_graph)
+        tr = HiFiGANTrainer(device=dev, seed=5, process_group=True, use_graph=use_graph, precision=precision)
         mel, y = _batch(B * world, S)
         mel, y = mel[rank * B:(rank + 1) * B].to(dev), y[rank * B:(rank + 1) * B].to(dev)
         losses = [tr.training_step(mel, y) for _ in range(steps)]
@@ -47,14 +47,14 @@ def _rank_main(rank, world, port, use_graph, steps, out_dir, B, S):
         dist.destroy_process_group()
 
 
-def _run_two_ranks(tmp_path, use_graph, steps, B, S):
+def _run_two_ranks(tmp_path, use_graph, steps, B, S, precision="f32"):
     import torch.multiprocessing as mp
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, use_graph, steps, str(tmp_path), B, S)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, use_graph, steps, str(tmp_path), B, S, precision)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -99,6 +99,22 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_concatenated_batch(cuda_devi
             for k in a:
                 assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-7), k
         assert torch.equal(r0["d"], e0["d"]) and torch.equal(r0["g"], e0["g"])  # graph replays == eager steps, exchange included
+
+
+def test_two_ranks_in_bf16_on_the_packed_chains_graph_equals_eager(cuda_device, tmp_path):
+    """precision="bf16" (what bench.py times): the discriminators run as packed chains (train/disc_chain.py), their weight fragments are
+    prepared on a side stream inside the first captured stretch, the generator step batches [real | generated].  Two ranks: both end
+    with the same gradients and parameters, and four steps in graph mode (stretches cut at bucket boundaries) end bit for bit where four
+    eager steps end."""
+    B, S, steps = 2, 2048, 4
+    r0, r1 = _run_two_ranks(tmp_path, True, steps, B, S, "bf16")
+    assert r0["graph_failed"] is None and r1["graph_failed"] is None and r0["graphs"] and r0["graphs"][0] >= 5
+    for k in ("d_grad", "g_grad", "d", "g"):
+        assert torch.equal(r0[k], r1[k]), k
+    tmp2 = tmp_path / "eager"
+    tmp2.mkdir()
+    e0, _ = _run_two_ranks(tmp2, False, steps, B, S, "bf16")
+    assert torch.equal(r0["d"], e0["d"]) and torch.equal(r0["g"], e0["g"])
 
 
 # ---- FastSpeech2: the bucketed exchange and the Tape.cut stretches with TWO ranks (VERDICT r03 item 5) -----------------------------
