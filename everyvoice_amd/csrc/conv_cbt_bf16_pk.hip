@@ -783,7 +783,11 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     if (wide && blocks(4) >= want) cand[nc++] = 4;
     cand[nc++] = blocks(1) >= want ? 1 : 2; cand[nc++] = 2; cand[nc++] = 3;
   } else {
-    if (wide && blocks(5) >= want) cand[nc++] = 5;
+    // flat one-item calls of narrow groups (the scale discriminators' grouped 41-tap layers: 8-32 rows, 65-131 k columns): the weight
+    // fragments are four fifths of a step's loads there and every column tile re-loads them -- 256-column tiles halve that:
+    // forward 110 -> 87 / input gradient 143 -> 106 us (128 -> 128, g 4), 180 -> 129 us (128 -> 256, g 16); stride-4 windows get too
+    // long for it (40 -> 55 us), those keep 128 columns (tools/pkflat_bench.py, EVMI_PK_WIDE=1 against 0)
+    if ((wide || (a.B == 1 && a.stride <= 2)) && blocks(5) >= want) cand[nc++] = 5;
     cand[nc++] = 3;
   }
   const int forced = pk_env_int("EVMI_PK_TILE", -1);
