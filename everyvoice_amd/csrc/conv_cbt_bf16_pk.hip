@@ -667,7 +667,7 @@ struct PkTile { int bm, bn; };
 // (index 9: 128 x 128 with the weight fragments in registers -- conv_pk_kernel<..., ADIR>.  The same for the 32 x 128 tile of the
 // narrow-group layers was built and measured SLOWER -- 110 -> 130 us, 66 -> 87 us on the scale discriminators' first grouped layers:
 // its four waves all need the same 32 rows, so registers mean four fetches of every fragment where the LDS needs one)
-static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {64, 256}, {32, 256}, {128, 256}, {128, 256}, {128, 128}, {128, 128}};
+static const PkTile kPkTiles[] = {{128, 128}, {64, 128}, {64, 64}, {32, 128}, {64, 256}, {32, 256}, {128, 256}, {128, 256}, {128, 128}, {128, 128}, {32, 512}};
 constexpr int kNumPkTiles = sizeof(kPkTiles) / sizeof(kPkTiles[0]);
 
 static int pk_env_int(const char* name, int dflt) {
@@ -787,6 +787,8 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     // fragments are four fifths of a step's loads there and every column tile re-loads them -- 256-column tiles halve that:
     // forward 110 -> 87 / input gradient 143 -> 106 us (128 -> 128, g 4), 180 -> 129 us (128 -> 256, g 16); stride-4 windows get too
     // long for it (40 -> 55 us), those keep 128 columns (tools/pkflat_bench.py, EVMI_PK_WIDE=1 against 0)
+    static const int wide2 = pk_env_int("EVMI_PK_WIDE2", 0);
+    if (wide2 && a.B == 1 && a.stride <= 2 && blocks(10) >= want) cand[nc++] = 10;
     if ((wide || (a.B == 1 && a.stride <= 2)) && blocks(5) >= want) cand[nc++] = 5;
     cand[nc++] = 3;
   }
@@ -906,6 +908,7 @@ static int launch_pk_tile(ConvPkArgs& a, const PkPlan& pl, hipStream_t stream) {
     case 6: EVMI_PK_LAUNCH(128, 256, 2, 2, 6) break;
     case 7: EVMI_PK_LAUNCH(128, 256, 2, 4, 7) break;
     case 8: EVMI_PK_LAUNCH(128, 128, 2, 4, 8) break;
+    case 10: EVMI_PK_LAUNCH(32, 512, 1, 4, 10) break;
     case 9: {
       if (lds > configured[9]) {
         EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pk_kernel<128, 128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
