@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void attention_train_fwd_kernel(const float* _
   const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
 
   for (int k0 = 0, gen = 0; k0 < len; k0 += 32, gen ^= 1) {
-    __syncthreads();  // this step's tiles have landed (vmcnt(0) of every wave); the other generation's readers are done
+    lds_dma_barrier();  // this step's tiles have landed (explicit vmcnt(0) of every wave); the other generation's readers are done
     if (k0 + 32 < len) {
       tile_request_swz<DH>(Kb + (gen ^ 1) * DH * 32, kg, N, k0 + 32, T, tid);
       tile_request_swz<DH>(Vb + (gen ^ 1) * DH * 32, vg, N, k0 + 32, T, tid);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void attention_train_dq_kernel(const float* __
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   for (int k0 = 0, gen = 0; k0 < len; k0 += 32, gen ^= 1) {
-    __syncthreads();
+    lds_dma_barrier();
     if (k0 + 32 < len) {
       tile_request_swz<DH>(Kb + (gen ^ 1) * DH * 32, kg, N, k0 + 32, T, tid);
       tile_request_swz<DH>(Vb + (gen ^ 1) * DH * 32, vg, N, k0 + 32, T, tid);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void attention_train_dkv_kernel(const float* _
   if (block_live) request(0, 0);
 
   for (int q0 = 0, gen = 0; q0 < T && block_live; q0 += 32, gen ^= 1) {
-    __syncthreads();
+    lds_dma_barrier();
     if (q0 + 32 < T) request(q0 + 32, gen ^ 1);
     const float* Qs = Qb + gen * DH * 32;
     const float* Os = Ob + gen * DH * 32;
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_fwd_bf16_kernel(const 
   const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
 
   for (int k0 = 0; k0 < len; k0 += 32) {
-    __syncthreads();  // the requested tile has landed (vmcnt(0) of every wave); the previous step's operand reads are over
+    lds_dma_barrier();  // the requested tile has landed (vmcnt(0) of every wave); the previous step's operand reads are over
     tile_convert<DH, true, false>(rawK, Ks, nullptr, k0, T, tid);
     tile_convert<DH, false, true>(rawV, nullptr, Vs, k0, T, tid);
     __syncthreads();
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_dq_bf16_kernel(const f
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   for (int k0 = 0; k0 < len; k0 += 32) {
-    __syncthreads();
+    lds_dma_barrier();
     tile_convert<DH, true, true>(rawK, Ks, Kt, k0, T, tid);
     tile_convert<DH, true, false>(rawV, Vs, nullptr, k0, T, tid);
     __syncthreads();
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_dkv_bf16_kernel(const 
     for (int r = 0; r < 16; ++r) acck[i][r] = accv[i][r] = 0.f;
 
   for (int q0 = 0, gen = 0; q0 < T && block_live; q0 += 32, gen ^= 1) {
-    __syncthreads();
+    lds_dma_barrier();
     tile_convert<DH, true, true>(rawQ, Qs, Qt, q0, T, tid);
     tile_convert<DH, true, true>(rawO, Os, Ot, q0, T, tid);
     __syncthreads();

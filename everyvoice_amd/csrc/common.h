@@ -77,12 +77,22 @@ __device__ __forceinline__ float bf16_lo(unsigned d) { return __builtin_bit_cast
 __device__ __forceinline__ float bf16_hi(unsigned d) { return __builtin_bit_cast(float, d & 0xffff0000u); }
 
 // Workgroup barrier for LDS hand-offs only.  __syncthreads() carries a workgroup-scope release fence,
-// which on gfx950 waits vmcnt(0): in a persistent kernel it would drain every global load that is
+// which on gfx950 waits vmcnt(0) while stores may be outstanding: in a persistent kernel it would drain every global load that is
 // deliberately kept in flight across the barrier (next tile's activation rows, next tap group's
 // weights) and every epilogue store.  Here only this wave's LDS operations are completed before the
 // barrier; global loads are waited for by the compiler exactly where their registers are consumed.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Barrier behind which the tiles requested with LDS-direct loads (global_load_lds: counted by vmcnt) have landed for EVERY wave.
+// A plain __syncthreads() does not promise that: its release fence waits for outstanding STORES, and where the compiler sees none
+// it emits s_waitcnt lgkmcnt(0) + s_barrier only, nor does it order an LDS-direct load against a later ds_read of the same bytes.
+// The bf16 dK/dV attention kernel read its dO tile with no vmcnt wait at all -- a stale tile about once per 60 FastSpeech2 training
+// steps, seen as run-to-run differences of otherwise bit-reproducible steps (tests/test_gpu_fs2_train.py: lockstep trainers).
+__device__ __forceinline__ void lds_dma_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 
 // One tap group of the implicit GEMM for one wave: NTAPS taps x KSTEPS 16-deep k-steps, fragments

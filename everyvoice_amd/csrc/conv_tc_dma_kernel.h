@@ -211,7 +211,7 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
       issue_x(chunk);
     }
     if (pre != 1.f && !((C::VAR & 64) && chunk > 0)) {
-      __syncthreads();  // vmcnt(0) of every wave, then the barrier: the whole tile has landed
+      lds_dma_barrier();  // vmcnt(0) of every wave (explicit: common.h), then the barrier: the whole tile has landed
       // leaky-ReLU in place (slope in [0, 1]: lrelu(x) = max(x, slope * x)); the swizzle is a permutation inside a row
 #pragma unroll
       for (int i = 0; i < C::X_VEC_PER_THREAD; ++i) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs 
 #pragma unroll 1
     for (int tap = 0; tap < C::KS; ++tap) {
       const int step = chunk * C::KS + tap;
-      if (!(C::VAR & (16 | 256)) || step == 0) __syncthreads();  // weight image of this step (and, at tap 0, the tile) landed and visible; slot (step + 1) & 1 is free
+      if (!(C::VAR & (16 | 256)) || step == 0) lds_dma_barrier();  // weight image of this step (and, at tap 0, the tile) landed and visible; slot (step + 1) & 1 is free
       stamp();
       const bool more = step + 1 < C::NSTEP && !(C::VAR & (16 | 512));
       if (more && !(C::VAR & 2048)) issue_a(step + 1);

@@ -150,8 +150,7 @@ def resblock_pair(tape: Tape, x: Var, c1, c2, slope: float, training: bool = Tru
             return
         C2, N2 = dy.shape[0], dy.shape[1] * dy.shape[2]
         if not c2.frozen:
-            with ops.side_wgrad(dy, db2):
-                ops.row_reduce(0, dy, None, db2, C2, N2, accumulate=True)
+            ops.side_wgrad(dy, db2).run(lambda: ops.row_reduce(0, dy, None, db2, C2, N2, accumulate=True))
             ops.conv1d_fused_wgrad(t, w2.shape, dy, dw2, c2.stride, c2.pad, c2.dil, c2.groups)
         dt = ops.conv1d_fused_dgrad(dy, w2, t.shape[2], c2.stride, c2.pad, c2.dil, c2.groups, x_for_fallback=t)
         if c1.frozen:

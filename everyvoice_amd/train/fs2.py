@@ -1019,6 +1019,7 @@ class FastSpeech2Trainer:
             ops.CONV_BACKEND["operands"] = prev
             ops.SIDE_WGRAD["on"] = prev_side
             ops.SEED_BASE[0] = prev_base
+        ops.side_check_drained()
         self.global_step += 1
         return losses
 

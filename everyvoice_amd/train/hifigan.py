@@ -834,6 +834,7 @@ class HiFiGANTrainer:
         finally:
             ops.CONV_BACKEND["operands"] = prev
             ops.SIDE_WGRAD["on"] = prev_side
+        ops.side_check_drained()
         self.global_step += 1
         if not sync:
             return buf

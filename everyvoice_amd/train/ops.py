@@ -157,7 +157,9 @@ class _SideState:
     def __init__(self, device):
         self.stream = torch.cuda.Stream(device)
         self.pending = None
-        self.keep = []
+        self.keep = []      # tensors read by the launches of the group now on the sibling stream
+        self.queue = []     # launches of the group being collected (closures), their tensors in keep_next
+        self.keep_next = []
         # one event object per direction, re-recorded on every use (a wait takes the record that precedes it in host order);
         # creating two events and entering torch.cuda.stream() per weight gradient cost ~33 us of host time each, 3.8 ms per
         # FastSpeech2 step
@@ -173,30 +175,86 @@ def _side_state(device):
     return st
 
 
+# Launches per fork: the weight gradients of SIDE_GROUP[0] layers are collected on the host and put on the sibling stream together --
+# ONE fork behind the last of those layers, ONE join (of the group before) in front of it.  A fork per layer is what a captured step
+# cannot use: a chain of 300 side launches each waiting for its own node of the main chain replays SERIALLY on ROCm 7.0 (the whole
+# side chain after the main chain: 6.5 ms for two chains of 2.8 ms -- the FastSpeech2 step's weight gradients all ran behind its
+# backward, profiles/r04x_fs2_queues_before.txt), groups of 8 / 16 in 3.2 ms, eager 7.8 -> 3.9 ms (tools/microbench/graph_side_chain.py).
+# <= 1: the per-layer fork.
+import os as _os
+
+SIDE_GROUP = [int(_os.environ.get("EVMI_SIDE_GROUP", "8"))]
+
+
+def _side_flush(st, cur):
+    """The collected launches go to the sibling stream: the chain joins the previous group, forks here."""
+    if st.pending is not None:
+        cur.wait_event(st.pending)
+    st.keep = st.keep_next
+    st.keep_next = []
+    queue, st.queue = st.queue, []
+    st.ready.record(cur)
+    st.stream.wait_event(st.ready)
+    torch.cuda.set_stream(st.stream)
+    try:
+        for fn in queue:
+            fn()
+        st.done.record(st.stream)
+    finally:
+        torch.cuda.set_stream(cur)
+    st.pending = st.done
+
+
 class side_wgrad:
-    """``with side_wgrad(x, dy): <launch weight-gradient kernels>`` -- on the sibling stream when enabled, in place otherwise."""
+    """``side_wgrad(x, dy, ...).run(fn)``: fn launches weight-gradient kernels (on the current stream) -- on the sibling stream when
+    enabled (at once with a per-layer fork, or collected into groups: SIDE_GROUP), in place otherwise.  Also a context manager
+    (``with side_wgrad(x, dy): ...``) for the per-layer form."""
 
     def __init__(self, *tensors):
         self.tensors = [t for t in tensors if t is not None]
         self.ctx = None
         self.state = None
+        self.grouped = False
 
-    def mark(self):
-        """Fork point: the sibling stream will wait for what the current stream holds NOW, whatever is queued on it before the
-        ``with`` block is entered -- so a caller can put the chain's next kernel (the input gradient) on the device first and
-        queue the weight-gradient launches, which nothing waits for, behind it in HOST order (the main queue otherwise sits idle
-        while the host issues them: 85-130 us per layer in the FastSpeech2 trace)."""
+    def _enabled_state(self):
         dev = self.tensors[0].device if self.tensors else None
         if not SIDE_WGRAD["on"] or dev is None or dev.type != "cuda" or _lib.current_stream_ptr(dev) in _SIDE_STREAMS:
-            return self
-        st = self.state = _side_state(dev)
+            return None
         self.prev = torch.cuda.current_stream(dev)
+        return _side_state(dev)
+
+    def mark(self):
+        """Fork point of the per-layer form: the sibling stream will wait for what the current stream holds NOW, whatever is queued
+        on it before the launches are issued -- so a caller can put the chain's next kernel (the input gradient) on the device first
+        and queue the weight-gradient launches, which nothing waits for, behind it in HOST order (the main queue otherwise sits idle
+        while the host issues them: 85-130 us per layer in the FastSpeech2 trace).  (Grouped form: nothing to do here.)"""
+        if SIDE_GROUP[0] > 1:
+            self.grouped = True
+            return self
+        st = self.state = self._enabled_state()
+        if st is None:
+            return self
         st.ready.record(self.prev)
         st.stream.wait_event(st.ready)
         st.keep.extend(self.tensors)
         return self
 
+    def run(self, fn):
+        if SIDE_GROUP[0] > 1:
+            st = self._enabled_state()
+            if st is None:  # not enabled / already beside a chain: here
+                return fn()
+            st.queue.append(fn)
+            st.keep_next.extend(self.tensors)
+            if len(st.queue) >= SIDE_GROUP[0]:
+                _side_flush(st, self.prev)
+            return None
+        with self:
+            return fn()
+
     def __enter__(self):
+        if self.grouped:
+            raise RuntimeError("side_wgrad: the grouped form takes its launches through run()")
         if self.state is None:
             self.mark()
         if self.state is None:  # not enabled / already beside a chain: stay here
@@ -215,16 +273,32 @@ class side_wgrad:
         return False
 
 
+def side_check_drained():
+    """Raises if weight-gradient launches are still collected on the host (a chain ended without its ``wgrad_join``): the trainers
+    call this at the end of every step."""
+    left = sum(len(st.queue) for st in _SIDE.values())
+    if left:
+        for st in _SIDE.values():
+            st.queue.clear()
+            st.keep_next.clear()
+        raise RuntimeError(f"side_wgrad: {left} weight-gradient launches were never issued (a backward chain ended without wgrad_join on its stream)")
+
+
 def wgrad_join(device=None):
-    """The current stream waits for the weight-gradient kernels its sibling stream still has queued; their inputs may go."""
+    """The current stream waits for the weight-gradient kernels its sibling stream still has queued (the launches still collected on
+    the host are issued first); their inputs may go."""
     if not _SIDE:
         return
     cur = torch.cuda.current_stream(device)
     st = _SIDE.get(cur.cuda_stream)
-    if st is not None and st.pending is not None:
+    if st is None:
+        return
+    if st.queue:
+        _side_flush(st, cur)
+    if st.pending is not None:
         cur.wait_event(st.pending)
         st.pending = None
-        st.keep.clear()
+    st.keep.clear()
 
 
 # ---- convolutions ---------------------------------------------------------------------------------------
@@ -333,12 +407,13 @@ def conv1d_fused_wgrad(x, w_shape, dy, dw_out, stride=1, pad=0, dil=1, groups=1,
         pk = lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t_in, cout, t_out, k, stride, pad, dil, groups)
         if pk > 0:
           _count_conv(B, t_out, cout, cin // groups, k)
-          with side_wgrad(x, dy, dw_out):
+          def launch():
             ws = WS.get("pkw", pk, x.device)
             _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk_fused(x.data_ptr(), dy.data_ptr(), dw_out.data_ptr(), ws.data_ptr(), pk, B, cin, t_in, cout, t_out, k,
                                                         stride, pad, dil, groups, int(accumulate), float(x_pre_slope), 0, 1.0, _s(x)),
                  "evmi_conv1d_wgrad_cbt_bf16pk_fused")
-            return dw_out
+          side_wgrad(x, dy, dw_out).run(launch)
+          return dw_out
     xa = x if x_pre_slope == 1.0 else lrelu(x, x_pre_slope)
     w_dummy = dw_out  # (only its shape is read on this path)
     conv1d_bwd(xa, w_dummy, dy, stride, pad, dil, groups, need_dx=False, dw_out=dw_out, accumulate=accumulate)
@@ -558,8 +633,9 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
         gemm_groups(w, dy, dcol, groups, kg, N, cout_g, kg, N, N, cout_g * kg, cout_g * N, kg * N, ta=True)
         dx = dcol.view(cin, B, t_in) if pointwise else fold(dcol, cin, B, t_in, t_out, k, stride, pad, dil)
     if side is not None:
-        with side:
-            db = _weight_and_bias_grad(x, w.shape, dy, dw, db_out, stride, pad, dil, groups, accumulate, packed=packed if share else None)
+        db = db_out  # (what _weight_and_bias_grad returns: the caller's bias-gradient buffer, filled by the launch)
+        pk = dict(packed) if share else None  # (a snapshot: the caller clears its dict when this returns, the launch may come later)
+        side.run(lambda: _weight_and_bias_grad(x, w.shape, dy, dw, db_out, stride, pad, dil, groups, accumulate, packed=pk))
     return dx, dw, db
 
 
@@ -806,10 +882,11 @@ def dwconv_bwd(x, w, dy, dw, db, k, need_dx=True):
     if need_dx:
         _chk(lib.evmi_dwconv1d_bwd_cbt_f32(x.data_ptr(), w.data_ptr(), dy.data_ptr(), dx.data_ptr(), 0, 0, 0, 0, C, B, T, k, (k - 1) // 2, _s(x)),
              "evmi_dwconv1d_bwd_cbt_f32")
-    with side:  # the filter / bias gradient (partial sums per item, then the reduction) beside the chain, issued behind dx
+    def launch():  # the filter / bias gradient (partial sums per item, then the reduction) beside the chain, issued behind dx
         ws = WS.get("dw_bwd", n, x.device)
         _chk(lib.evmi_dwconv1d_bwd_cbt_f32(x.data_ptr(), w.data_ptr(), dy.data_ptr(), 0, dw.data_ptr(), db.data_ptr(), ws.data_ptr(), n, C, B, T, k,
                                            (k - 1) // 2, _s(x)), "evmi_dwconv1d_bwd_cbt_f32")
+    side.run(launch)
     return dx
 
 

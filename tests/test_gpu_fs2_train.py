@@ -599,6 +599,22 @@ def test_training_step_at_the_bench_batch_follows_oracle(cuda_device, prec):
         assert cos >= 0.999 and 0.97 <= ratio <= 1.03, (cos, ratio)
 
 
+def test_bench_size_steps_are_reproducible_run_to_run(cuda_device):
+    """Two trainers in lockstep on the bench batch (default-size model, precision="bf16", dropout on): 120 steps each, the parameters
+    bitwise equal after every one.  Nothing in the step is order-dependent (no atomics, fixed-order reductions), so any difference is a
+    race.  This is the test that would have caught the dK/dV attention kernel reading its LDS-direct dO tile with no vmcnt wait (a
+    stale tile about once per 60 steps at this size -- common.h: lds_dma_barrier): with that bug the chance of 120 clean steps is ~2 %."""
+    ref_cfg = _ref_cfg(0.1, 0, default_size=True)
+    batch = _bench_batch(32)
+    a = _trainer(ref_cfg, cuda_device, precision="bf16")
+    b = _trainer(ref_cfg, cuda_device, precision="bf16")
+    assert torch.equal(a.params.flat, b.params.flat)
+    for step in range(120):
+        la, lb = a.training_step(batch), b.training_step(batch)
+        assert torch.equal(a.params.flat, b.params.flat), f"parameters differ after step {step}"
+        assert all(torch.equal(la[k], lb[k]) for k in la), f"losses differ at step {step}"
+
+
 def test_noam_schedule(cuda_device):
     tr = _trainer(_ref_cfg(), cuda_device)
     o = tr.training.optimizer
@@ -850,6 +866,32 @@ def test_graph_replays_equal_eager_steps_bitwise(cuda_device, learn_alignment, p
     a = float(graph.training_step(batches[0])["mel"])
     b_ = float(graph.training_step(batches[0])["mel"])
     assert a != b_
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_weight_gradient_schedules_give_the_same_step(cuda_device, use_graph):
+    """The weight / bias gradients of a backward run (a) in place, (b) on the sibling stream with a fork per layer, (c) collected
+    into groups of 8 layers per fork (the default: what a captured step can overlap, ops.SIDE_GROUP) or (d) groups of 3 (groups
+    that end inside a block, a last partial group): the same launches in the same order per gradient buffer, so four steps end bit for
+    bit in the same place -- eager and captured."""
+    from everyvoice_amd.train import ops
+
+    ref_cfg = _ref_cfg(0.1, 0)
+    batches = [_shaped_batch(ref_cfg, seed, True, cuda_device) for seed in (5, 6)]
+    prev = ops.SIDE_GROUP[0]
+    finals = []
+    try:
+        for side, group in ((False, 8), (True, 1), (True, 8), (True, 3)):
+            ops.SIDE_GROUP[0] = group
+            tr = _trainer(ref_cfg, cuda_device, learn_alignment=True, precision="bf16", use_graph=use_graph, side_wgrad=side)
+            losses = [tr.training_step(batches[i % 2]) for i in range(4)]
+            assert tr.last_step_was_graph == use_graph and tr._graph_failed is None
+            finals.append((tr.params.flat.clone(), [{k: float(v) for k, v in l.items()} for l in losses]))
+    finally:
+        ops.SIDE_GROUP[0] = prev
+    for flat, losses in finals[1:]:
+        assert losses == finals[0][1]
+        assert torch.equal(flat, finals[0][0])
 
 
 def test_graph_buckets_pad_to_a_small_set_of_shapes(cuda_device):

@@ -474,7 +474,7 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
     name, B, T, cin, cout, k, s, p, d, groups, tile_f, tile_d, taps_w = case
     lib = _lib.load()
     n_out = (T + 2 * p - d * (k - 1) - 1) // s + 1
-    if not any(os.environ.get(v) for v in ("EVMI_PK_TILE", "EVMI_PK_SPLITK", "EVMI_PK_WIDE", "EVMI_PK_ADIR", "EVMI_PK_XCD_HB")):
+    if not any(os.environ.get(v) for v in ("EVMI_PK_TILE", "EVMI_PK_SPLITK", "EVMI_PK_WIDE", "EVMI_PK_WIDE2", "EVMI_PK_ADIR", "EVMI_PK_XCD_HB")):
         geo = (B, cin, T, cout, n_out, k, s, p, d, groups)
         assert lib.evmi_conv1d_cbt_bf16pk_plan(*geo) % 16 == tile_f, name
         assert lib.evmi_conv1d_dgrad_cbt_bf16pk_plan(*geo) % 16 == tile_d, name
@@ -495,10 +495,10 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
         assert err <= 1e-4, (name, what, err)  # fp32 accumulation of exact bf16 products: summation order only
 
 
-@pytest.mark.parametrize("tile", range(10))
+@pytest.mark.parametrize("tile", range(11))
 def test_packed_conv_every_tile_forced(tile):
     """conv_pk_kernel<128,128 | 64,128 | 64,64 | 32,128 | 64,256 | 32,256 | 128,256>, the eight-wave <128,256> / <128,128> (indices 7, 8) and
-    <128,128> with the weight fragments in registers (index 9):
+    <128,128> with the weight fragments in registers (index 9), <32,512> (index 10):
     the planner picks one per shape; here every one
     of them is FORCED (EVMI_PK_TILE, read once per process -> a child process each) through the bf16 comparisons with torch of
     this file -- the bench shapes, the edge shapes and the strided / grouped input-gradient shapes -- so a tile the planner starts choosing tomorrow (as <128, 256>
@@ -515,7 +515,7 @@ def test_packed_conv_every_tile_forced(tile):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("switch", ["EVMI_PK_SPLITK=0", "EVMI_PK_WIDE=1", "EVMI_WG_SPLITS=1", "EVMI_WG_NST=2", "EVMI_PK_ADIR=0", "EVMI_PK_XCD_HB=1"])
+@pytest.mark.parametrize("switch", ["EVMI_PK_SPLITK=0", "EVMI_PK_WIDE=1", "EVMI_PK_WIDE2=2", "EVMI_WG_SPLITS=1", "EVMI_WG_NST=2", "EVMI_PK_ADIR=0", "EVMI_PK_XCD_HB=1"])
 def test_packed_conv_planner_switches(switch):
     """The planner's other A/B switches (no split-K, 256-column tiles for narrow layers, unsplit / two-slot weight gradients, weight
     fragments through the LDS everywhere, the plain m-tile-major XCD order)
