@@ -709,6 +709,26 @@ def test_weight_gradients_on_sibling_streams_do_not_change_the_step(cuda_device)
         assert torch.equal(sds[0][k], sds[1][k]), k
 
 
+def test_bench_size_gan_steps_are_reproducible_run_to_run(cuda_device):
+    """Two trainers in lockstep on a bench-size batch (16 x 8192 samples, bf16, the captured step with its eight discriminator
+    streams): 60 steps each, generator and discriminator parameters and the losses bitwise equal after every one -- no atomics and
+    fixed-order reductions everywhere, so a difference would be a race between streams or inside a kernel."""
+    from everyvoice_amd.spectral import MelSpectrogram
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(1234)
+    B, S = 16, 8192
+    y = (0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device)
+    mel = MelSpectrogram()(y.squeeze(1), log=True)[:, :, : S // 256].contiguous()
+    a = HiFiGANTrainer(device=cuda_device, seed=3, precision="bf16", use_graph=True)
+    b = HiFiGANTrainer(device=cuda_device, seed=3, precision="bf16", use_graph=True)
+    for step in range(60):
+        la, lb = a.training_step(mel, y, sync=False), b.training_step(mel, y, sync=False)
+        assert torch.equal(la, lb), f"losses differ at step {step}"
+        assert torch.equal(a.g_params.flat, b.g_params.flat) and torch.equal(a.d_params.flat, b.d_params.flat), f"parameters differ after step {step}"
+    assert a._graph_failed is None and b._graph_failed is None
+
+
 def test_channel_major_generator_path_behind_its_switch():
     """precision="bf16" trains the generator's residual stacks in time-major bf16 on the inference kernels by default
     (train/mrf_tm.py); EVMI_TRAIN_TM=0 keeps every layer on the channel-major packed kernels.  The switch is read when a trainer is
