@@ -54,6 +54,10 @@ struct WgradPkArgs {
   // block-diagonal mode for narrow groups: the workgroup's "group" is a super-group of several convolution groups (cout_g / cin_g
   // above are the super-group's widths); only the blocks (co / bd_cout == ci / bd_cin) are stored, as dw[co][ci % bd_cin][j]
   int bd_cout, bd_cin;
+  // tiles whose input-channel extent is one 32-column MFMA tile (cin_g <= 32: the wn = 1 waves would idle): the two waves of a row share
+  // the x rows and split the workgroup's TAPS instead (1); block-diagonal super-groups of two 32 x 32 groups: wave (wm, wn) takes the
+  // diagonal block wm and half of the taps (2)
+  int tap_split;
 };
 
 constexpr int WG_KS = 64;  // positions per K step (4 MFMA K blocks)
@@ -89,7 +93,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   const int tile_ci = blockIdx.x % a.tiles_ci, tgi = blockIdx.x / a.tiles_ci;
   const int g = blockIdx.y / a.tiles_co, tile_co = blockIdx.y % a.tiles_co;
   const int j_lo = tgi * tg;
-  const int tgc = min(tg, k - j_lo);  // taps of this group
+  const int tgw = min(tg, k - j_lo);  // taps of this group
+  int j0 = 0, tgc = tgw;              // ... of this wave: [j0, j0 + tgc) of them
+  if (a.tap_split) {
+    const int half = (tgw + 1) >> 1;
+    j0 = wn * half;
+    tgc = max(0, min(half, tgw - j0));
+  }
+  const int xb = a.tap_split == 2 ? wm : (a.tap_split ? 0 : wn);  // 32-channel block of the staged x rows this wave multiplies
   const int split = blockIdx.z;
   const int t_lo = split * a.steps_per_split, t_hi = min(a.ksteps, t_lo + a.steps_per_split);
   if (t_lo >= t_hi) return;  // (the reduce pass only reads the splits that exist)
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   const int i16 = lane & 15, hf = (lane >> 4) & 1;
   const int oct_in_blk = 2 * hf + ((i16 & 3) >> 1);
   const int a_base = (((wm * 4 + oct_in_blk) * WG_YROW) + 8 * kh + (i16 >> 2)) * 16 + (i16 & 1) * 8;
-  const int b_base = (y_units + (wn * 4 + oct_in_blk) * xrow + (8 * kh + (i16 >> 2)) * s) * 16 + (i16 & 1) * 8;
+  const int b_base = (y_units + (xb * 4 + oct_in_blk) * xrow + (8 * kh + (i16 >> 2)) * s + j0 * d) * 16 + (i16 & 1) * 8;
 
   f32x16 acc[TGMAX];
 #pragma unroll
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   }
 
   // ---- store: lane column = input channel, registers = output channels ----
-  const int ci_sg = tile_ci * 64 + wn * 32 + (lane & 31);
+  const int ci_sg = tile_ci * 64 + xb * 32 + (lane & 31);
   if (ci_sg >= a.cin_g) return;
   const int cig = a.bd_cin ? ci_sg / a.bd_cin : 0;           // convolution group inside the super-group (block-diagonal mode)
   const int ci = a.bd_cin ? ci_sg - cig * a.bd_cin : ci_sg;  // input channel inside its convolution group
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
       for (int r = 0; r < 16; ++r) {
         const int m = tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
         if (m >= a.cout_g || (a.bd_cout && m / a.bd_cout != cig)) continue;
-        outp[(j_lo + j) * tap_stride + (long long)(g * a.cout_g + m) * cin_st + ci] = acc[j][r];
+        outp[(j_lo + j0 + j) * tap_stride + (long long)(g * a.cout_g + m) * cin_st + ci] = acc[j][r];
       }
     }
     return;
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int m = min(tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, a.cout_g - 1);
-      off[r] = ((long long)(g * a.cout_g + m) * cin_st + ci) * k + j_lo + j;
+      off[r] = ((long long)(g * a.cout_g + m) * cin_st + ci) * k + j_lo + j0 + j;
       prev[r] = -0.f;
     }
     if (a.accumulate) {
@@ -528,10 +539,15 @@ static const char* plan_wgrad_flat(WgradPkArgs& a, WgradPkPlan& pl, int& sgroups
   pl.octs_y = a.octs_y = cout_g / 8;
   pl.octs_x = a.octs_x = cin_g / 8;
   a.ksteps = (int)((n_pos + WG_KS - 1) / WG_KS);
-  const int tgcap = 8;
+  // one 32-column tile of input channels (or two 32 x 32 groups on the diagonal): the waves of a row split the taps -- up to 16 per
+  // workgroup, 8 per wave, half the workgroups staging the same windows (EVMI_WG_TAPSPLIT=0: off)
+  static const int tap_split_on = wg_env_int("EVMI_WG_TAPSPLIT", 1);
+  a.tap_split = !tap_split_on ? 0 : (cin_g <= 32 ? 1 : (a.bd_cin == 32 && a.bd_cout == 32 && cin_g == 64 && cout_g == 64 ? 2 : 0));
+  const int tgcap = a.tap_split ? 16 : 8;
   a.ntg = (k + tgcap - 1) / tgcap;
   a.tg = (k + a.ntg - 1) / a.ntg;
-  pl.tgmax = a.tg <= 4 ? 4 : 8;
+  const int tg_wave = a.tap_split ? (a.tg + 1) / 2 : a.tg;
+  pl.tgmax = tg_wave <= 4 ? 4 : 8;
   a.tiles_ci = (cin_g + 63) / 64;
   a.tiles_co = (cout_g + 63) / 64;
   const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;

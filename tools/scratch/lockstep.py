@@ -13,7 +13,7 @@ prec = os.environ.get("OPERANDS", "bf16")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 batch, T_i = training_batch(32, learn_alignment=learn, device=dev)
 mk = lambda: FastSpeech2Trainer(FastSpeech2ModelConfig(learn_alignment=learn), training=FastSpeech2TrainingConfig(gradient_clip_val=None), device=dev,
-                                precision=prec, use_graph=False, side_wgrad=os.environ.get("SIDE", "0") == "1")
+                                precision=prec, use_graph=os.environ.get("GRAPH", "0") == "1", side_wgrad=os.environ.get("SIDE", "0") == "1")
 a, b = mk(), mk()
 events = collections.Counter()
 for step in range(steps):
