@@ -410,3 +410,17 @@ def test_chain_against_torch_autograd_with_its_roundings(which, n, T, generator_
             small = n * T < 16000  # (items of 10-20 positions in the late layers)
             floor = 0.995 if small else (0.999 if name.endswith(".bias") else 0.9995)
             assert c >= floor and abs(r - 1) <= 1e-2, (name, c, r)
+
+
+@pytest.mark.parametrize("switch", ["EVMI_WG_TAPSPLIT=0", "EVMI_PK_WIDE2=0"])
+def test_flat_kernels_behind_their_switches(switch):
+    """The flat weight gradient without the tap split over a row's waves, the flat convolutions without the 512-column tiles: the
+    comparisons with torch of this file once more in a child process each (the switches are read once per process)."""
+    import os
+    import subprocess
+    import sys
+
+    key, val = switch.split("=")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "flat_packed_kernels_against_torch or chain_against_torch_autograd"],
+                       env=dict(os.environ, **{key: val}), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
