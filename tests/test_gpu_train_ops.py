@@ -490,8 +490,15 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
     want_y = F.conv1d(_bf(x), _bf(w), b, s, p, d, groups)
     want_dx = torch.nn.grad.conv1d_input(x.shape, _bf(w), _bf(dy), s, p, d, groups)
     want_dw = torch.nn.grad.conv1d_weight(_bf(x), w.shape, _bf(dy), s, p, d, groups)
-    for got, want, what in ((y, want_y, "forward"), (bct(dx.cpu()), want_dx, "input gradient"), (dw.cpu(), want_dw, "weight gradient")):
+    # a FORCED tile that cannot stage a shape leaves it to the exact fp32 kernels: then the unrounded operands are the oracle
+    forced = bool(os.environ.get("EVMI_PK_TILE"))
+    exact = ((F.conv1d(x, w, b, s, p, d, groups), torch.nn.grad.conv1d_input(x.shape, w, dy, s, p, d, groups),
+              torch.nn.grad.conv1d_weight(x, w.shape, dy, s, p, d, groups)) if forced else (None, None, None))
+    for got, want, want_exact, what in ((y, want_y, exact[0], "forward"), (bct(dx.cpu()), want_dx, exact[1], "input gradient"),
+                                        (dw.cpu(), want_dw, exact[2], "weight gradient")):
         err = float((got - want).abs().max() / want.abs().max())
+        if forced:
+            err = min(err, float((got - want_exact).abs().max() / want_exact.abs().max()))
         assert err <= 1e-4, (name, what, err)  # fp32 accumulation of exact bf16 products: summation order only
 
 
