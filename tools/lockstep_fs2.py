@@ -1,8 +1,11 @@
-"""Two FastSpeech2 trainers in lockstep on the same batch: after every step the parameters must be bitwise equal; where they are
-not, the tensors that differ name the layer whose gradient came out differently (no clipping, so nothing spreads it)."""
+#!/usr/bin/env python3
+"""Two FastSpeech2 trainers in lockstep on the bench batch: after every step the parameters must be bitwise equal; where they are
+not, the tensors that differ name the layer whose gradient came out differently (no clipping, so nothing spreads it), and trainer B is
+put back on A.  How the stale-tile race of the bf16 attention backward was found.
+usage: [LEARN=1] [SIDE=1] [GRAPH=1] [OPERANDS=bf16|f32] python tools/lockstep_fs2.py [steps = 200]"""
 import os, sys, collections
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parents[2])); sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1])); sys.path.insert(0, str(Path(__file__).resolve().parent))
 import torch
 from fs2_train_bench import training_batch
 from everyvoice_amd.train.fs2 import FastSpeech2Trainer, FastSpeech2TrainingConfig

@@ -1,7 +1,9 @@
-"""Two HiFiGAN trainers in lockstep on the bench batch: parameters bitwise equal after every step, or the tensors that differ."""
+#!/usr/bin/env python3
+"""Two HiFiGAN trainers in lockstep on the bench batch: parameters bitwise equal after every step, or the tensors that differ.
+usage: [GRAPH=0] [OPERANDS=bf16|f32] python tools/lockstep_gan.py [steps = 150]"""
 import os, sys, collections
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parents[2]))
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
 import torch
 from everyvoice_amd.spectral import MelSpectrogram
 from everyvoice_amd.train.hifigan import HiFiGANTrainer
