@@ -185,6 +185,18 @@ __device__ __forceinline__ float ordered_sum_strided(const float* __restrict__ p
 // seed is (value + *base) & (2^63 - 1): a step captured into a HIP graph keeps `value` (the draw's index inside the step) and gets
 // a new mask every replay because the host rewrites *base (seed, step, rank) before it -- and an eager step that stores the same
 // base draws bit for bit the same masks.  base == NULL: the seed is `value`, as before.
+// silu'(z) = s (1 + z (1 - s)), s = sigmoid(z): ONE statement of the arithmetic, without contraction, for every kernel that applies it
+// (the separate dropout / activation passes and the packs that fuse them round the same values to bf16)
+__device__ __forceinline__ float silu_grad(float z) {
+#pragma clang fp contract(off)
+  const float sg = 1.f / (1.f + expf(-z));
+  return sg * (1.f + z * (1.f - sg));
+}
+__device__ __forceinline__ float silu_value(float v) {
+#pragma clang fp contract(off)
+  return v / (1.f + expf(-v));
+}
+
 struct SeedArg {
   unsigned long long value;
   const unsigned long long* base;

@@ -884,6 +884,10 @@ struct PkInputFusion {  // what the pack applies to the input on its way in (see
   float pre_slope = 1.f;
   const float* mask = nullptr;
   float mask_slope = 1.f;
+  int fuse = 0;  // 1: dropout(silu(x)); 2: dropout(x) * silu'(aux)
+  const float* aux = nullptr;
+  float p_drop = 0.f;
+  SeedArg seed = SeedArg{0ull, nullptr};
 };
 
 static int launch_pk_tile(ConvPkArgs& a, const PkPlan& pl, hipStream_t stream) {
@@ -940,6 +944,7 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   PackArgs pa = make_pack_args(x, xp, pl.cin_g, a.octs, a.B, pl.t_in, a.Tp, pl.PL,
                                (int)(pl.xp_units - (long long)pl.groups * a.octs * a.B * a.Tp), pl.groups);
   pa.pre_slope = in.pre_slope; pa.mask = in.mask; pa.mask_slope = in.mask_slope;
+  pa.fuse = in.fuse; pa.aux = in.aux; pa.p_drop = in.p_drop; pa.seed = in.seed;
   WfragArgs fa;
   fa.w = w; fa.wf = reinterpret_cast<unsigned*>(wf); fa.rows_g = rows_g; fa.kch_g = kch_g; fa.kt = a.k; fa.MB = a.mblocks; fa.octs = a.octs;
   fa.kblocks = a.kblocks; fa.mode = wmode; fa.k_full = k_full; fa.stride = stride_full; fa.phase_stride_words = a.wf_phase_stride * 4;
@@ -1243,6 +1248,44 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged(int stage, const float* dy_dev, const fl
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk_staged: ") + why);
   a.y = dx_dev;
   return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream, PkInputFusion(), stage);
+}
+
+/* The two halves of a feed-forward block's middle -- dense2(dropout(silu(a), p)) and its backward -- with the activation and the mask
+ * applied while the tensors are packed (PackArgs::fuse), so that neither dropout(silu(a)) nor dropout(ds) * silu'(a) exists in fp32:
+ *   _silu_dropout:         y = conv(dropout(silu(x), p)) + bias                    (x = a; stride 1, no dilation, one group)
+ *   _staged_silu_dropout:  evmi_conv1d_dgrad_cbt_bf16pk_staged on dy = dropout(ds, p) * silu'(pre) (stage 1 packs THAT; stage 2 as usual)
+ * Mask stream and arithmetic of evmi_dropout_fused_f32 modes 2 / 3 (seed_value + *seed_base_dev, element index = index in the tensor). */
+int evmi_conv1d_cbt_bf16pk_silu_dropout(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev,
+                                        long long ws_elems, int B, int c_in, int t_in, int c_out, int k, int pad, float p,
+                                        unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream) {
+  if (!x_dev || !w_dev || !y_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_silu_dropout: null pointer");
+  if (p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_silu_dropout: p outside [0, 1)");
+  const int t_out = t_in + 2 * pad - (k - 1);
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_fwd_pk(a, pl, B, c_in, t_in, c_out, t_out, t_out, k, 1, pad, 1, 1, 1, 0))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk_silu_dropout: ") + why);
+  a.bias = bias_dev; a.y = y_dev; a.accumulate = 0; a.act = 0; a.act_param = 0.f;
+  PkInputFusion in;
+  in.fuse = 1; in.p_drop = p; in.seed = SeedArg{seed_value, seed_base_dev};
+  return launch_pk(a, pl, x_dev, w_dev, ws_dev, ws_elems, 0, c_out, c_in, k, 1, (hipStream_t)stream, in);
+}
+
+int evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout(int stage, const float* ds_dev, const float* pre_dev, float p, unsigned long long seed_value,
+                                                     const unsigned long long* seed_base_dev, const float* w_dev, float* dx_dev, float* ws_dev,
+                                                     long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k, int stride,
+                                                     int pad, int dil, int groups, void* stream) {
+  if (stage != 1 && stage != 2) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged_silu_dropout: stage 1 or 2");
+  if (!ds_dev || !pre_dev || !w_dev || !dx_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged_silu_dropout: null pointer");
+  if (p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged_silu_dropout: p outside [0, 1)");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_dgrad_pk(a, pl, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk_staged_silu_dropout: ") + why);
+  a.y = dx_dev;
+  PkInputFusion in;
+  in.fuse = 2; in.aux = pre_dev; in.p_drop = p; in.seed = SeedArg{seed_value, seed_base_dev};
+  return launch_pk(a, pl, ds_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream, in, stage);
 }
 
 /* Input gradient with the fusions of a backward pass: dy is multiplied by (dy_mask > 0 ? 1 : dy_mask_slope) while it is packed

@@ -50,6 +50,14 @@ struct PackArgs {
   float pre_slope;
   const float* mask;
   float mask_slope;
+  // the activation + dropout between two dense layers, applied while the tensor is packed (the fp32 result is never stored; the
+  // arithmetic and the mask stream of evmi_dropout_fused_f32: element index = the element's index in x):
+  //   fuse 1: x -> dropout(silu(x), p_drop)            (the forward of the second layer: its input)
+  //   fuse 2: x -> dropout(x, p_drop) * silu'(aux)     (the backward of the first layer: its output gradient; aux = its pre-activation output)
+  int fuse;
+  const float* aux;
+  float p_drop;
+  SeedArg seed;
 };
 __device__ __forceinline__ void pack_x_block(const PackArgs& p, int bx, int b, int go) {
   const int u = bx * 256 + threadIdx.x;
@@ -89,6 +97,27 @@ __device__ __forceinline__ void pack_x_block(const PackArgs& p, int bx, int b, i
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] *= m[i];
+    if (p.fuse) {
+      const long long i0 = src - p.x;
+      float z[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) z[i] = 0.f;
+      if (p.fuse == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) z[i] = p.aux[i0 + min(i, nch - 1) * cs];
+      }
+      const unsigned long long seed = p.seed.get();
+      const float inv_keep = 1.f - p.p_drop;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bool keep = uniform01(seed, (unsigned long long)(i0 + min(i, nch - 1) * cs)) >= p.p_drop;
+        float val = v[i];
+        if (p.fuse == 1) val = silu_value(val);
+        float d = keep ? val / inv_keep : 0.f;
+        if (p.fuse == 2) d = d * silu_grad(z[i]);
+        v[i] = i < nch ? d : 0.f;
+      }
+    }
   }
   uint4 out;
   out.x = pk_bf16x2(v[0], v[1]);
@@ -115,6 +144,7 @@ static inline PackArgs make_pack_args(const float* x, uint4* xp, int cin_g, int 
   p.x = x; p.xp = xp; p.cin_g = cin_g; p.octs = octs; p.B = B; p.t_in = t_in; p.Tp = Tp; p.PL = PL; p.slack_units = slack_units;
   p.gx = (Tp + 255) / 256; p.gy = B; p.gz = groups * octs;
   p.pre_slope = 1.f; p.mask = nullptr; p.mask_slope = 1.f;
+  p.fuse = 0; p.aux = nullptr; p.p_drop = 0.f; p.seed = SeedArg{0ull, nullptr};
   return p;
 }
 // decode a flat block index into the logical 3-D grid of a pack (x fastest)

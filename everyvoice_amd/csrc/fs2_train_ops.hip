@@ -429,13 +429,10 @@ __global__ __launch_bounds__(256) void dropout_fused_kernel(const float* __restr
   for (int e = 0; e < 4; ++e) {
     const bool keep = uniform01(seed, (unsigned long long)(i0 + e)) >= p;
     float v = av[e];
-    if (MODE == 2) v = v / (1.f + expf(-v));
+    if (MODE == 2) v = silu_value(v);
     float d = keep ? v / inv_keep : 0.f;
     if (MODE == 1) d = bv[e] + scale * d;
-    if (MODE == 3) {
-      const float z = bv[e], sg = 1.f / (1.f + expf(-z));
-      d = d * sg * (1.f + z * (1.f - sg));
-    }
+    if (MODE == 3) d = d * silu_grad(bv[e]);
     if (MODE == 4) d = scale * d;
     r[e] = d;
   }

@@ -295,6 +295,38 @@ def silu_dropout(tape: Tape, x: Var, p: float, seed: int) -> Var:
     return y
 
 
+def ffn_core(tape: Tape, h: Var, l1, l2, p: float, seed: int) -> Var:
+    """dense2(dropout(silu(dense1(h)), p)): the middle of a Conformer feed-forward block as ONE tape operator.  On the packed bf16 kernels
+    the activation and the mask are applied while the second layer's input is packed, and in the backward while the first layer's
+    output gradient is packed: neither dropout(silu(a)) nor its gradient is stored in fp32 (two elementwise passes over the block's
+    widest tensor and one fp32 copy of it per direction less).  Elsewhere: the three operators it stands for."""
+    C1, B, T = h.data.shape
+    if p <= 0.0 or _EVAL[0] or not ops.ffn_fused_supported(B, T, l1.cout, l2.cout):
+        return dense(tape, silu_dropout(tape, dense(tape, h, l1), p, seed), l2)
+    w1, dw1 = l1.effective(True)
+    w2, dw2 = l2.effective(True)
+    packed1, packed2 = {}, {}
+    a = ops.conv1d_fwd(h.data, w1, l1.bias_data(), 1, l1.pad, 1, 1, keep=packed1)
+    y = Var(ops.conv1d_fwd_silu_dropout(a, w2, l2.bias_data(), p, seed, packed2))
+    autograd_elems = a.numel()
+    from .autograd import _ACTIVATION_ELEMS
+    _ACTIVATION_ELEMS[0] += autograd_elems  # (the pre-activation: the tensor the separate operators count as dense1's output)
+
+    def bwd():
+        if y.grad is None:
+            return
+        # second layer: its packed input is the forward's (a stands in for the fp32 tensor that was never stored: only its shape is read)
+        ds, _, _ = ops.conv1d_bwd(a, w2, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw2, db_out=l2.db_sink(), accumulate=True, packed=packed2)
+        packed2.clear()
+        dh = ops.conv1d_bwd_silu_dropout_dy(h.data, w1, ds, a, p, seed, dw1, l1.db_sink(), packed1)
+        packed1.clear()
+        if h.needs_grad:
+            h.accumulate(dh)
+
+    tape.record(bwd)
+    return y
+
+
 def residual(tape: Tape, a: Var, b: Var, sb: float = 1.0) -> Var:
     """a + sb * b"""
     y = Var(ops.axpby(1.0, a.data, sb, b.data))
@@ -382,8 +414,8 @@ class _ConformerT:
 
     @staticmethod
     def _ffn_fwd(tape, x, F, p, seeds):
-        h = silu_dropout(tape, dense(tape, layernorm(tape, x, F["ln"]), F["l1"]), p, seeds())
-        return residual_dropout(tape, x, dense(tape, h, F["l2"]), p, seeds(), 0.5)
+        h = ffn_core(tape, layernorm(tape, x, F["ln"]), F["l1"], F["l2"], p, seeds())
+        return residual_dropout(tape, x, h, p, seeds(), 0.5)
 
 
 class _VariancePredictorT:

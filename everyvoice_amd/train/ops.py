@@ -639,6 +639,73 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
     return dx, dw, db
 
 
+# ---- dense2(dropout(silu(a))) and its backward with the activation / mask applied while the operands are packed ---------------------
+def ffn_fused_supported(B, t, c_mid, c_out) -> bool:
+    """True where both halves below run on the packed bf16 kernels with shared packed operands (pointwise layers, B * t a multiple of
+    the weight gradient's K step): the FastSpeech2 feed-forward blocks at precision="bf16"."""
+    if not (_packed() and CONV_BACKEND["fwd"] == "mfma" and CONV_BACKEND["dgrad"] == "mfma" and CONV_BACKEND["wgrad"] != "gemm"):
+        return False
+    lib = _lib.load()
+    return bool(shares_packed(B, t, 1, 1, 0, 1, 1)
+                and lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, c_mid, t, c_out, t, 1, 1, 0, 1, 1) > 0
+                and lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, c_out, t, c_mid, t, 1, 1, 0, 1, 1) > 0
+                and lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, c_out, t, c_mid, t, 1, 1, 0, 1, 1) > 0
+                and dgrad_mfma_supported(B, c_out, t, c_mid, t, 1, 1, 1, 1))
+
+
+def conv1d_fwd_silu_dropout(a, w, bias, p, seed, keep):
+    """y = dense(dropout(silu(a), p)) (pointwise w [cout, cin, 1]); the activated, masked tensor exists only packed, in ``keep["x_packed"]``
+    (the layer's weight gradient reads it there).  Caller: ffn_fused_supported."""
+    cin, B, t = a.shape
+    cout = w.shape[0]
+    lib = _lib.load()
+    pk_elems = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t, cout, t, 1, 1, 0, 1, 1)
+    ws = keep["x_packed"] = torch.empty(pk_elems, device=a.device, dtype=torch.float32)
+    out = torch.empty(cout, B, t, device=a.device, dtype=torch.float32)
+    _count_conv(B, t, cout, cin, 1)
+    _chk(lib.evmi_conv1d_cbt_bf16pk_silu_dropout(a.data_ptr(), w.data_ptr(), _lib.ptr(bias), out.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t, cout, 1, 0,
+                                                 float(p), int(seed), _lib.ptr(SEED_BASE[0]), _s(a)), "evmi_conv1d_cbt_bf16pk_silu_dropout")
+    return out
+
+
+def conv1d_bwd_silu_dropout_dy(x, w, ds, pre, p, seed, dw_out, db_out, packed):
+    """Backward of a pointwise layer y = w x + b whose output gradient is dy = dropout(ds, p) * silu'(pre) (y = pre feeds the activation
+    behind it): dy is formed while ds is packed -- it exists only as the packed bf16 operand that the input gradient, the weight gradient
+    and the bias gradient (row sums of the packed rows) all read.  Returns dx; dw_out / db_out are accumulated into.  ``packed``: the
+    forward's ``keep`` dict (x_packed).  Caller: ffn_fused_supported."""
+    import ctypes as C
+
+    cin, B, t = x.shape
+    cout = w.shape[0]
+    lib = _lib.load()
+    pk_elems = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t, cout, t, 1, 1, 0, 1, 1)
+    ws = torch.empty(pk_elems, device=ds.device, dtype=torch.float32)
+    dx = torch.empty(cin, B, t, device=ds.device, dtype=torch.float32)
+    args = (ds.data_ptr(), pre.data_ptr(), float(p), int(seed), _lib.ptr(SEED_BASE[0]), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t, cout, t,
+            1, 1, 0, 1, 1)
+    _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout(1, *args, _s(ds)), "evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout")
+    xp = packed.get("x_packed") if packed else None
+    side = side_wgrad(x, ds, pre, dw_out, db_out, ws, xp).mark()  # fork behind the pack, in front of the input gradient
+    _count_conv(B, t, cout, cin, 1)
+    _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout(2, *args, _s(ds)), "evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout")
+
+    def launch():
+        n_w = lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t, cout, t, 1, 1, 0, 1, 1)
+        wsw = WS.get("pkw", n_w, x.device)
+        _count_conv(B, t, cout, cin, 1)
+        _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk_prepacked(x.data_ptr(), _lib.ptr(xp), ds.data_ptr(), ws.data_ptr(), dw_out.data_ptr(), wsw.data_ptr(), n_w, B, cin, t,
+                                                        cout, t, 1, 1, 0, 1, 1, 1, _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk_prepacked")
+        if db_out is not None:  # row sums of the packed dy: [cout / 8 octet rows][B * t units]
+            job = (_lib.PkFlatRows * 1)()
+            job[0].dy, job[0].plane, job[0].units, job[0].C, job[0].db = ws.data_ptr(), B * t, B * t, cout, db_out.data_ptr()
+            n_r = lib.evmi_pkflat_rowsum_ws_elems(1, job)
+            wsr = WS.get("pkrow", n_r, x.device)
+            _chk(lib.evmi_pkflat_rowsum(1, job, wsr.data_ptr(), n_r, _s(x)), "evmi_pkflat_rowsum")
+
+    side.run(launch)
+    return dx
+
+
 def _convt_via_dgrad():
     import os
     if CONV_BACKEND["dgrad"] != "mfma":

@@ -296,6 +296,21 @@ int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float*
 int evmi_conv1d_dgrad_cbt_bf16pk_staged(int stage, const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems,
                                         int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
                                         void* stream);
+/* The middle of a feed-forward block, dense2(dropout(silu(a), p)), and its backward with the activation and the dropout mask applied while
+ * the operands are PACKED -- neither dropout(silu(a)) nor dropout(ds) * silu'(a) is ever stored in fp32 (reference: the Conformer
+ * feed-forward module, Linear -> SiLU -> Dropout -> Linear; arithmetic and mask stream of evmi_dropout_fused_f32 modes 2 / 3:
+ * seed_value + *seed_base_dev, element index = the element's index in the tensor):
+ *   evmi_conv1d_cbt_bf16pk_silu_dropout:              y = conv(dropout(silu(x), p)) + bias   (stride 1, no dilation, one group; the head of
+ *                                                     ws is the packed activated input, what the layer's weight gradient reads again)
+ *   evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout: evmi_conv1d_dgrad_cbt_bf16pk_staged on dy = dropout(ds, p) * silu'(pre): stage 1
+ *                                                     packs that product into the head of ws, stage 2 runs the convolution on it. */
+int evmi_conv1d_cbt_bf16pk_silu_dropout(const float* x_dev, const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev,
+                                        long long ws_elems, int B, int c_in, int t_in, int c_out, int k, int pad, float p,
+                                        unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream);
+int evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout(int stage, const float* ds_dev, const float* pre_dev, float p, unsigned long long seed_value,
+                                                     const unsigned long long* seed_base_dev, const float* w_dev, float* dx_dev, float* ws_dev,
+                                                     long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k, int stride,
+                                                     int pad, int dil, int groups, void* stream);
 /* The packed bf16 convolution kernels with a residual block's neighbours fused in (no separate activation / add passes, no
  * activated copies in HBM) -- the training-side counterpart of SURVEY.md 8b's evmi_resblock1_fused_{fwd,bwd}:
  *   forward   y = act(conv(leaky_relu(x, pre_slope)) + bias) + residual

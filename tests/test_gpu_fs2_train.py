@@ -599,6 +599,51 @@ def test_training_step_at_the_bench_batch_follows_oracle(cuda_device, prec):
         assert cos >= 0.999 and 0.97 <= ratio <= 1.03, (cos, ratio)
 
 
+@pytest.mark.parametrize("B,T", [(4, 112), (32, 814)])
+def test_feed_forward_middle_fused_into_the_packs_equals_the_separate_passes(cuda_device, B, T):
+    """ops.conv1d_fwd_silu_dropout / conv1d_bwd_silu_dropout_dy (train/fs2.py: ffn_core): dense2(dropout(silu(a))) and its backward with
+    the activation and the mask applied while the operands are packed, against the three separate operators on the same seed -- the
+    same values are rounded to bf16 either way, so outputs, input gradients and weight gradients agree to summation order; the first
+    layer's bias gradient is summed from the ROUNDED output gradient in the fused form (2e-3)."""
+    from everyvoice_amd.train import ops
+
+    D, F_, p, seed = 256, 1024, 0.1, 12345
+    g = torch.Generator().manual_seed(B + T)
+    h = torch.randn(D, B, T, generator=g).to(cuda_device)
+    w1 = (torch.randn(F_, D, 1, generator=g) * D ** -0.5).to(cuda_device)
+    w2 = (torch.randn(D, F_, 1, generator=g) * F_ ** -0.5).to(cuda_device)
+    b1, b2 = torch.randn(F_, generator=g).to(cuda_device) * 0.1, torch.randn(D, generator=g).to(cuda_device) * 0.1
+    dy = torch.randn(D, B, T, generator=g).to(cuda_device)
+    prev = ops.CONV_BACKEND["operands"]
+    ops.CONV_BACKEND["operands"] = "bf16"
+    try:
+        assert ops.ffn_fused_supported(B, T, F_, D)
+        k1, k2 = {}, {}
+        a = ops.conv1d_fwd(h, w1, b1, 1, 0, 1, 1, keep=k1)
+        s = ops.dropout_fused(2, a, None, p, seed)
+        y = ops.conv1d_fwd(s, w2, b2, 1, 0, 1, 1, keep=k2)
+        dw1, dw2, db1, db2 = torch.zeros_like(w1), torch.zeros_like(w2), torch.zeros_like(b1), torch.zeros_like(b2)
+        ds, _, _ = ops.conv1d_bwd(s, w2, dy, 1, 0, 1, 1, need_dx=True, dw_out=dw2, db_out=db2, accumulate=True, packed=k2)
+        da = ops.dropout_fused(3, ds, a, p, seed)
+        dh, _, _ = ops.conv1d_bwd(h, w1, da, 1, 0, 1, 1, need_dx=True, dw_out=dw1, db_out=db1, accumulate=True, packed=k1)
+        # fused
+        f1, f2 = {}, {}
+        a_f = ops.conv1d_fwd(h, w1, b1, 1, 0, 1, 1, keep=f1)
+        y_f = ops.conv1d_fwd_silu_dropout(a_f, w2, b2, p, seed, f2)
+        ew1, ew2, eb1, eb2 = torch.zeros_like(w1), torch.zeros_like(w2), torch.zeros_like(b1), torch.zeros_like(b2)
+        ds_f, _, _ = ops.conv1d_bwd(a_f, w2, dy, 1, 0, 1, 1, need_dx=True, dw_out=ew2, db_out=eb2, accumulate=True, packed=f2)
+        dh_f = ops.conv1d_bwd_silu_dropout_dy(h, w1, ds_f, a_f, p, seed, ew1, eb1, f1)
+        ops.wgrad_join(cuda_device)
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_BACKEND["operands"] = prev
+    rel = lambda got, want: float((got - want).abs().max() / want.abs().max())  # noqa: E731
+    assert float((s == 0).float().mean()) == pytest.approx(p, abs=0.01)  # (the mask is there)
+    for name, got, want, tol in (("y", y_f, y, 2e-6), ("ds", ds_f, ds, 2e-6), ("dh", dh_f, dh, 2e-6), ("dw2", ew2, dw2, 2e-6), ("dw1", ew1, dw1, 2e-5),
+                                 ("db2", eb2, db2, 2e-6), ("db1", eb1, db1, 2e-3)):
+        assert rel(got, want) <= tol, (name, rel(got, want))
+
+
 def test_bench_size_steps_are_reproducible_run_to_run(cuda_device):
     """Two trainers in lockstep on the bench batch (default-size model, precision="bf16", dropout on): 120 steps each, the parameters
     bitwise equal after every one.  Nothing in the step is order-dependent (no atomics, fixed-order reductions), so any difference is a
