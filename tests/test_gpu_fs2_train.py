@@ -922,7 +922,14 @@ def test_weight_gradient_schedules_give_the_same_step(cuda_device, use_graph):
     from everyvoice_amd.train import ops
 
     ref_cfg = _ref_cfg(0.1, 0)
-    batches = [_shaped_batch(ref_cfg, seed, True, cuda_device) for seed in (5, 6)]
+    # (T = 64: B * T a multiple of 64, so the decoder's feed-forward blocks take the fused form of ffn_core under every schedule too)
+    batches = [_shaped_batch(ref_cfg, seed, True, cuda_device, T=64) for seed in (5, 6)]
+    prev_ops = ops.CONV_BACKEND["operands"]
+    ops.CONV_BACKEND["operands"] = "bf16"
+    try:
+        assert ops.ffn_fused_supported(4, 64, ref_cfg.decoder.feedforward_dim, ref_cfg.decoder.input_dim)
+    finally:
+        ops.CONV_BACKEND["operands"] = prev_ops
     prev = ops.SIDE_GROUP[0]
     finals = []
     try:

@@ -19,7 +19,7 @@ for what in "$@"; do
     pmc_infer)
       BENCH_FLAGS="--no-train --no-fs2" bash $R/tools/gpu_profile.sh $TAG > $OUT/${TAG}_gpu_profile.log 2>&1
       python3 $R/tools/pmc_summarize.py $TAG > $OUT/${TAG}_pmc_summarize.log 2>&1
-      cp $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_pmc_summary.json $OUT/ 2>/dev/null
+      cp $R/profiles/${TAG}_kernel_stats.csv $R/profiles/${TAG}_pmc_summary.json $R/profiles/${TAG}_pmc_summary.meta.json $OUT/ 2>/dev/null
       rm -rf $OUT/${TAG}_trace $OUT/${TAG}_pmc_fetch $OUT/${TAG}_pmc_write $OUT/${TAG}_pmc_sq $OUT/${TAG}_pmc_l2 ;;
     pmc_train)
       GRAPH=0 bash $R/tools/gpu_profile_train.sh ${TAG}_train > $OUT/${TAG}_train_pmc.log 2>&1
