@@ -28,7 +28,7 @@ import torch
 from .. import _lib
 from ..fs2 import N_PHONOLOGICAL_FEATURES, FastSpeech2ModelConfig, Stats
 from . import ops
-from .autograd import Tape, Var
+from .autograd import _ACTIVATION_ELEMS, Tape, Var
 from .layers import ParamGroup, WNConv
 
 
@@ -308,9 +308,7 @@ def ffn_core(tape: Tape, h: Var, l1, l2, p: float, seed: int) -> Var:
     packed1, packed2 = {}, {}
     a = ops.conv1d_fwd(h.data, w1, l1.bias_data(), 1, l1.pad, 1, 1, keep=packed1)
     y = Var(ops.conv1d_fwd_silu_dropout(a, w2, l2.bias_data(), p, seed, packed2))
-    autograd_elems = a.numel()
-    from .autograd import _ACTIVATION_ELEMS
-    _ACTIVATION_ELEMS[0] += autograd_elems  # (the pre-activation: the tensor the separate operators count as dense1's output)
+    _ACTIVATION_ELEMS[0] += a.numel()  # (the pre-activation: the tensor the separate operators count as dense1's output)
 
     def bwd():
         if y.grad is None:

@@ -673,8 +673,6 @@ def conv1d_bwd_silu_dropout_dy(x, w, ds, pre, p, seed, dw_out, db_out, packed):
     behind it): dy is formed while ds is packed -- it exists only as the packed bf16 operand that the input gradient, the weight gradient
     and the bias gradient (row sums of the packed rows) all read.  Returns dx; dw_out / db_out are accumulated into.  ``packed``: the
     forward's ``keep`` dict (x_packed).  Caller: ffn_fused_supported."""
-    import ctypes as C
-
     cin, B, t = x.shape
     cout = w.shape[0]
     lib = _lib.load()
