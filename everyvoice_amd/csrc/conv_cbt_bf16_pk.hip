@@ -661,6 +661,61 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
   }
 }
 
+// LayerNorm over the channels of every column, written STRAIGHT into the packed layout of a pointwise layer's input (tight items:
+// [octet][B * T units]): workgroup = 64 columns x 4 channel slices as fs2_ops.hip's layernorm_cbt_kernel (same arithmetic, same
+// order), but a thread's slice of C / 4 channels is whole octets, so it leaves as 16-byte units -- consecutive lanes, consecutive
+// units.  The normalised tensor never exists in fp32 (its only reader is the dense layer behind it).
+template <int CPT>  // channels per thread = C / 4 (a multiple of 8)
+__global__ __launch_bounds__(256) void layernorm_pack_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, uint4* __restrict__ xp, int C, long long N,
+                                                            float eps, int slack_units) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const long long n = (long long)blockIdx.x * 64 + lane;
+  const bool live = n < N;
+  if (blockIdx.x == 0) {  // the zero slack behind the packed tensor (what pack_x_block's last block writes)
+    uint4* tail = xp + (long long)(C / 8) * N;
+    for (int i = threadIdx.x; i < slack_units; i += 256) tail[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  const int c0 = slice * CPT;
+  float v[CPT];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    v[i] = live ? x[(long long)(c0 + i) * N + n] : 0.f;
+    s += v[i];
+  }
+  red[0][slice][lane] = s;
+  __syncthreads();
+  const float mean = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const float d = v[i] - mean;
+    q = fmaf(d, d, q);
+  }
+  red[1][slice][lane] = q;
+  __syncthreads();
+  const float var = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (!live) return;
+#pragma unroll
+  for (int o = 0; o < CPT / 8; ++o) {
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = c0 + 8 * o + e;
+      r[e] = (v[8 * o + e] - mean) * rstd * gamma[c] + beta[c];
+    }
+    uint4 out;
+    out.x = pk_bf16x2(r[0], r[1]);
+    out.y = pk_bf16x2(r[2], r[3]);
+    out.z = pk_bf16x2(r[4], r[5]);
+    out.w = pk_bf16x2(r[6], r[7]);
+    xp[(long long)(c0 / 8 + o) * N + n] = out;
+  }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 struct PkTile { int bm, bn; };
 // (index 7, 8: eight-wave forms of 128 x 256 and 128 x 128 -- 64 x 64 / 64 x 32 per wave)
@@ -1193,6 +1248,46 @@ int evmi_conv1d_cbt_bf16pk(const float* x_dev, const float* w_dev, const float* 
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk: ") + why);
   a.bias = bias_dev; a.y = y_dev; a.accumulate = accumulate; a.act = act; a.act_param = act_param;
   return launch_pk(a, pl, x_dev, w_dev, ws_dev, ws_elems, 0, c_out / groups, c_in / groups, k, stride, (hipStream_t)stream);
+}
+
+/* LayerNorm in front of a pointwise layer, written as that layer's packed input (the layers of evmi_conv1d_bf16pk_shares_packed: tight
+ * items, B * t a multiple of 64; c_in 128 or 256), and the layer itself on an input that is already packed in the head of ws:
+ *   evmi_layernorm_pack_bf16pk(x, gamma, beta, ws, ...)   ws head <- packed bf16 LayerNorm(x) (+ the zero slack the kernels read past it)
+ *   evmi_conv1d_cbt_bf16pk_prepacked(w, bias, y, ws, ...) y = act(conv(that) + bias); ws as evmi_conv1d_cbt_bf16pk's, same geometry
+ * The normalised tensor is never stored in fp32; the head of ws is what the layer's weight gradient reads again (..._wgrad_..._prepacked). */
+int evmi_layernorm_pack_bf16pk(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* ws_dev, long long ws_elems, int B,
+                               int c_in, int t_in, int c_out, float eps, void* stream) {
+  if (!x_dev || !gamma_dev || !beta_dev || !ws_dev) return fail(EVMI_ERR_INVALID_ARG, "layernorm_pack_bf16pk: null pointer");
+  if (c_in != 128 && c_in != 256) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: 128 or 256 channels");
+  if (!pk_shared_items(B, t_in)) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: B * t must be a multiple of 64");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_fwd_pk(a, pl, B, c_in, t_in, c_out, t_in, t_in, 1, 1, 0, 1, 1, 1, 0))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("layernorm_pack_bf16pk: ") + why);
+  if (a.Tp != t_in || pl.PL != 0) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: the layer's items are not packed tight");
+  if (ws_elems < (pl.xp_units + pl.wf_units) * 4 + pl.part_elems || (reinterpret_cast<uintptr_t>(ws_dev) & 15))
+    return fail(EVMI_ERR_INVALID_ARG, "layernorm_pack_bf16pk: workspace too small or unaligned");
+  const long long N = (long long)B * t_in;
+  const int slack = (int)(pl.xp_units - (long long)a.octs * N);
+  const dim3 grid((unsigned)((N + 63) / 64));
+  uint4* xp = reinterpret_cast<uint4*>(ws_dev);
+  if (c_in == 256) hipLaunchKernelGGL(layernorm_pack_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, eps, slack);
+  else hipLaunchKernelGGL(layernorm_pack_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, eps, slack);
+  EVMI_LAUNCH_CHECK("layernorm_pack");
+  return EVMI_OK;
+}
+
+int evmi_conv1d_cbt_bf16pk_prepacked(const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev, long long ws_elems, int B,
+                                     int c_in, int t_in, int c_out, int act, float act_param, void* stream) {
+  if (!w_dev || !y_dev || !ws_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_prepacked: null pointer");
+  if (act < 0 || act > 4) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_prepacked: activation");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_fwd_pk(a, pl, B, c_in, t_in, c_out, t_in, t_in, 1, 1, 0, 1, 1, 1, 0))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk_prepacked: ") + why);
+  a.bias = bias_dev; a.y = y_dev; a.accumulate = 0; a.act = act; a.act_param = act_param;
+  // (stage 2: the pack is an empty grid; the fp32 input pointer is never read)
+  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 2);
 }
 
 /* The same with the fusions of a residual block's forward: the input passes through leaky_relu(., pre_slope) while it is packed

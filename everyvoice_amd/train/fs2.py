@@ -295,18 +295,48 @@ def silu_dropout(tape: Tape, x: Var, p: float, seed: int) -> Var:
     return y
 
 
-def ffn_core(tape: Tape, h: Var, l1, l2, p: float, seed: int) -> Var:
-    """dense2(dropout(silu(dense1(h)), p)): the middle of a Conformer feed-forward block as ONE tape operator.  On the packed bf16 kernels
-    the activation and the mask are applied while the second layer's input is packed, and in the backward while the first layer's
-    output gradient is packed: neither dropout(silu(a)) nor its gradient is stored in fp32 (two elementwise passes over the block's
-    widest tensor and one fp32 copy of it per direction less).  Elsewhere: the three operators it stands for."""
-    C1, B, T = h.data.shape
+def ln_dense(tape: Tape, x: Var, ln: Affine, layer) -> Var:
+    """dense(LayerNorm(x)) as one tape operator: on the packed bf16 kernels the normalised tensor is written straight into the layer's
+    packed input (ops.layernorm_dense_fwd) and never exists in fp32 -- its only other reader, the layer's weight gradient, takes the
+    packed copy; LayerNorm's own backward needs x, not its output.  Elsewhere: the two operators."""
+    C, B, T = x.data.shape
+    if not ops.ln_dense_fused_supported(B, T, C, layer.cout) or layer.k != 1:
+        return dense(tape, layernorm(tape, x, ln), layer)
+    w, dw_sink = layer.effective(True)
+    packed = {}
+    y = Var(ops.layernorm_dense_fwd(x.data, ln.gamma(), ln.beta(), w, layer.bias_data(), packed))
+
+    def bwd():
+        if y.grad is None:
+            return
+        # (x.data stands in for the normalised tensor, which was never stored: only its shape is read -- the weight gradient takes the packed copy)
+        dh, _, _ = ops.conv1d_bwd(x.data, w, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True, packed=packed)
+        packed.clear()
+        x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh, ln.dgamma(), ln.dbeta()))
+
+    tape.record(bwd)
+    return y
+
+
+def ffn_core(tape: Tape, x: Var, ln: Affine, l1, l2, p: float, seed: int) -> Var:
+    """dense2(dropout(silu(dense1(LayerNorm(x))), p)): a Conformer feed-forward block up to its residual add as ONE tape operator.  On the
+    packed bf16 kernels LayerNorm writes the first layer's packed input, the activation and the mask are applied while the second
+    layer's input is packed, and in the backward while the first layer's output gradient is packed: neither the normalised tensor nor
+    dropout(silu(a)) nor its gradient is stored in fp32 (per direction two elementwise passes over the block's widest tensor and one
+    fp32 copy of it less).  Elsewhere: the four operators it stands for."""
+    C, B, T = x.data.shape
     if p <= 0.0 or _EVAL[0] or not ops.ffn_fused_supported(B, T, l1.cout, l2.cout):
-        return dense(tape, silu_dropout(tape, dense(tape, h, l1), p, seed), l2)
+        return dense(tape, silu_dropout(tape, ln_dense(tape, x, ln, l1), p, seed), l2)
     w1, dw1 = l1.effective(True)
     w2, dw2 = l2.effective(True)
     packed1, packed2 = {}, {}
-    a = ops.conv1d_fwd(h.data, w1, l1.bias_data(), 1, l1.pad, 1, 1, keep=packed1)
+    ln_fused = ops.ln_dense_fused_supported(B, T, C, l1.cout)
+    if ln_fused:
+        h = None
+        a = ops.layernorm_dense_fwd(x.data, ln.gamma(), ln.beta(), w1, l1.bias_data(), packed1)
+    else:
+        h = layernorm(tape, x, ln)
+        a = ops.conv1d_fwd(h.data, w1, l1.bias_data(), 1, l1.pad, 1, 1, keep=packed1)
     y = Var(ops.conv1d_fwd_silu_dropout(a, w2, l2.bias_data(), p, seed, packed2))
     _ACTIVATION_ELEMS[0] += a.numel()  # (the pre-activation: the tensor the separate operators count as dense1's output)
 
@@ -316,9 +346,12 @@ def ffn_core(tape: Tape, h: Var, l1, l2, p: float, seed: int) -> Var:
         # second layer: its packed input is the forward's (a stands in for the fp32 tensor that was never stored: only its shape is read)
         ds, _, _ = ops.conv1d_bwd(a, w2, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw2, db_out=l2.db_sink(), accumulate=True, packed=packed2)
         packed2.clear()
-        dh = ops.conv1d_bwd_silu_dropout_dy(h.data, w1, ds, a, p, seed, dw1, l1.db_sink(), packed1)
+        # first layer: x.data / h.data only lend their shape (the weight gradient reads the packed copy)
+        dh = ops.conv1d_bwd_silu_dropout_dy(x.data if ln_fused else h.data, w1, ds, a, p, seed, dw1, l1.db_sink(), packed1)
         packed1.clear()
-        if h.needs_grad:
+        if ln_fused:
+            x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh, ln.dgamma(), ln.dbeta()))
+        else:
             h.accumulate(dh)
 
     tape.record(bwd)
@@ -400,10 +433,10 @@ class _ConformerT:
         p = 0.0 if _EVAL[0] else self.cfg.dropout
         for L in self.layers:
             x = self._ffn_fwd(tape, x, L["ffn1"], p, seeds)
-            h = dense(tape, layernorm(tape, x, L["attn_ln"]), L["in_proj"])
+            h = ln_dense(tape, x, L["attn_ln"], L["in_proj"])
             h = attention(tape, h, lens32, self.cfg.heads, p, seeds(self.cfg.heads))
             x = residual_dropout(tape, x, dense(tape, h, L["out_proj"]), p, seeds())
-            h = glu(tape, dense(tape, layernorm(tape, x, L["conv_ln"]), L["pw1"]))
+            h = glu(tape, ln_dense(tape, x, L["conv_ln"], L["pw1"]))
             h = batchnorm(tape, dwconv(tape, h, L["dw"]), L["bn"], ops.ACT_SILU)
             x = residual_dropout(tape, x, dense(tape, h, L["pw2"]), p, seeds())
             x = self._ffn_fwd(tape, x, L["ffn2"], p, seeds)
@@ -412,7 +445,7 @@ class _ConformerT:
 
     @staticmethod
     def _ffn_fwd(tape, x, F, p, seeds):
-        h = ffn_core(tape, layernorm(tape, x, F["ln"]), F["l1"], F["l2"], p, seeds())
+        h = ffn_core(tape, x, F["ln"], F["l1"], F["l2"], p, seeds())
         return residual_dropout(tape, x, h, p, seeds(), 0.5)
 
 

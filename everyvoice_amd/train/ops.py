@@ -653,6 +653,33 @@ def ffn_fused_supported(B, t, c_mid, c_out) -> bool:
                 and dgrad_mfma_supported(B, c_out, t, c_mid, t, 1, 1, 1, 1))
 
 
+def ln_dense_fused_supported(B, t, c_in, c_out) -> bool:
+    """True where LayerNorm -> pointwise layer runs with the normalised tensor written straight into the layer's packed input."""
+    if not (_packed() and CONV_BACKEND["fwd"] == "mfma" and CONV_BACKEND["dgrad"] == "mfma" and CONV_BACKEND["wgrad"] != "gemm"):
+        return False
+    lib = _lib.load()
+    return bool(c_in in (128, 256) and shares_packed(B, t, 1, 1, 0, 1, 1)
+                and lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, c_in, t, c_out, t, 1, 1, 0, 1, 1) > 0
+                and lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, c_in, t, c_out, t, 1, 1, 0, 1, 1) > 0)
+
+
+def layernorm_dense_fwd(x, gamma, beta, w, bias, keep, act=ACT_NONE, eps=1e-5):
+    """y = act(dense(LayerNorm(x))) (pointwise w [cout, cin, 1]); LayerNorm(x) exists only packed, in ``keep["x_packed"]`` (the layer's
+    weight gradient reads it there).  Caller: ln_dense_fused_supported."""
+    cin, B, t = x.shape
+    cout = w.shape[0]
+    lib = _lib.load()
+    pk_elems = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t, cout, t, 1, 1, 0, 1, 1)
+    ws = keep["x_packed"] = torch.empty(pk_elems, device=x.device, dtype=torch.float32)
+    out = torch.empty(cout, B, t, device=x.device, dtype=torch.float32)
+    _chk(lib.evmi_layernorm_pack_bf16pk(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t, cout, eps, _s(x)),
+         "evmi_layernorm_pack_bf16pk")
+    _count_conv(B, t, cout, cin, 1)
+    _chk(lib.evmi_conv1d_cbt_bf16pk_prepacked(w.data_ptr(), _lib.ptr(bias), out.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t, cout, act, 0.0, _s(x)),
+         "evmi_conv1d_cbt_bf16pk_prepacked")
+    return out
+
+
 def conv1d_fwd_silu_dropout(a, w, bias, p, seed, keep):
     """y = dense(dropout(silu(a), p)) (pointwise w [cout, cin, 1]); the activated, masked tensor exists only packed, in ``keep["x_packed"]``
     (the layer's weight gradient reads it there).  Caller: ffn_fused_supported."""

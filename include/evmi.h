@@ -311,6 +311,13 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout(int stage, const float* ds_
                                                      const unsigned long long* seed_base_dev, const float* w_dev, float* dx_dev, float* ws_dev,
                                                      long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k, int stride,
                                                      int pad, int dil, int groups, void* stream);
+/* LayerNorm in front of a pointwise layer written as that layer's packed input, and the layer on an input already packed in the head
+ * of ws (the Conformer's LayerNorm -> Linear pairs; layers of evmi_conv1d_bf16pk_shares_packed, 128 or 256 input channels): the
+ * normalised tensor is never stored in fp32.  ws: evmi_conv1d_cbt_bf16pk_ws_elems floats of the layer (k = 1, stride 1, no padding). */
+int evmi_layernorm_pack_bf16pk(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* ws_dev, long long ws_elems, int B,
+                               int c_in, int t_in, int c_out, float eps, void* stream);
+int evmi_conv1d_cbt_bf16pk_prepacked(const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev, long long ws_elems, int B,
+                                     int c_in, int t_in, int c_out, int act, float act_param, void* stream);
 /* The packed bf16 convolution kernels with a residual block's neighbours fused in (no separate activation / add passes, no
  * activated copies in HBM) -- the training-side counterpart of SURVEY.md 8b's evmi_resblock1_fused_{fwd,bwd}:
  *   forward   y = act(conv(leaky_relu(x, pre_slope)) + bias) + residual

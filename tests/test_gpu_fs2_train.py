@@ -644,6 +644,39 @@ def test_feed_forward_middle_fused_into_the_packs_equals_the_separate_passes(cud
         assert rel(got, want) <= tol, (name, rel(got, want))
 
 
+@pytest.mark.parametrize("B,T,C,F_", [(4, 112, 256, 1024), (32, 814, 256, 768), (8, 64, 128, 256)])
+def test_layernorm_written_as_the_packed_input_of_the_dense_layer_behind_it(cuda_device, B, T, C, F_):
+    """ops.layernorm_dense_fwd (train/fs2.py: ln_dense, ffn_core): LayerNorm -> pointwise layer with the normalised tensor written
+    straight into the layer's packed bf16 input, against LayerNorm then the layer (which packs the same values): same output, and the
+    layer's backward from the kept packed copy gives the same input / weight / bias gradients."""
+    from everyvoice_amd.train import ops
+
+    g = torch.Generator().manual_seed(B + T + C)
+    x = (torch.randn(C, B, T, generator=g) * 1.7 + 0.3).to(cuda_device)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(cuda_device), (torch.randn(C, generator=g) * 0.1).to(cuda_device)
+    w = (torch.randn(F_, C, 1, generator=g) * C ** -0.5).to(cuda_device)
+    b = (torch.randn(F_, generator=g) * 0.1).to(cuda_device)
+    dy = torch.randn(F_, B, T, generator=g).to(cuda_device)
+    prev = ops.CONV_BACKEND["operands"]
+    ops.CONV_BACKEND["operands"] = "bf16"
+    try:
+        assert ops.ln_dense_fused_supported(B, T, C, F_)
+        k1, k2 = {}, {}
+        h = ops.layernorm(x, gamma, beta)
+        y = ops.conv1d_fwd(h, w, b, 1, 0, 1, 1, keep=k1)
+        y_f = ops.layernorm_dense_fwd(x, gamma, beta, w, b, k2)
+        dw, db, ew, eb = torch.zeros_like(w), torch.zeros_like(b), torch.zeros_like(w), torch.zeros_like(b)
+        dh, _, _ = ops.conv1d_bwd(h, w, dy, 1, 0, 1, 1, need_dx=True, dw_out=dw, db_out=db, accumulate=True, packed=k1)
+        dh_f, _, _ = ops.conv1d_bwd(x, w, dy, 1, 0, 1, 1, need_dx=True, dw_out=ew, db_out=eb, accumulate=True, packed=k2)
+        ops.wgrad_join(cuda_device)
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_BACKEND["operands"] = prev
+    rel = lambda got, want: float((got - want).abs().max() / want.abs().max())  # noqa: E731
+    for name, got, want in (("y", y_f, y), ("dh", dh_f, dh), ("dw", ew, dw), ("db", eb, db)):
+        assert rel(got, want) <= 2e-6, (name, rel(got, want))
+
+
 def test_bench_size_steps_are_reproducible_run_to_run(cuda_device):
     """Two trainers in lockstep on the bench batch (default-size model, precision="bf16", dropout on): 120 steps each, the parameters
     bitwise equal after every one.  Nothing in the step is order-dependent (no atomics, fixed-order reductions), so any difference is a
