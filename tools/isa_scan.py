@@ -15,6 +15,39 @@ def demangle(n):
         return n
 
 
+def lds_dma_handover_findings(path):
+    """Second rule: in a kernel that uses LDS-direct loads (global_load_lds), a loop whose header runs into an s_barrier
+    must wait `vmcnt(0)` in front of that barrier -- the barrier is where the tiles requested a step ago are handed over, the compiler does
+    not order an LDS-direct load against a later ds_read, and a __syncthreads() alone only waits while stores may be outstanding.
+    Returns [(kernel, loop label, the instructions from the label to the barrier)] of the loops that do not."""
+    lines = open(path).read().split("\n")
+    fn, bodies = None, {}
+    for line in lines:
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            fn = m.group(1)
+            bodies[fn] = []
+        elif fn is not None:
+            t = line.strip()
+            if t.startswith(".LBB") or (t and not t.startswith(";") and not t.startswith(".")):
+                bodies[fn].append(t)
+            if "s_endpgm" in t:
+                fn = None
+    bad = []
+    for name, body in bodies.items():
+        if not any("global_load_lds" in x for x in body):
+            continue
+        for i, x in enumerate(body):
+            if x.startswith(".LBB") and "Loop Header" in x:
+                win = body[i + 1:i + 8]
+                for j, y in enumerate(win):
+                    if y.startswith("s_barrier"):
+                        if "vmcnt(0)" not in " ".join(win[:j]):
+                            bad.append((demangle(name), x.split(":")[0], win[:j + 1]))
+                        break
+    return bad
+
+
 def main():
     rows = []
     loops = []
@@ -68,5 +101,12 @@ def main():
         print(f"{r[0]:4d} thin loop(s): <= 2 loads then vmcnt(0) per trip  {r[1]:22s} {r[2]}")
 
 
+def main_lds_dma(d):
+    for f in sorted(Path(d).glob("*.s")):
+        for kernel, label, win in lds_dma_handover_findings(f):
+            print(f"{f.name}: {kernel[:90]}: loop {label}: barrier without vmcnt(0) in front of it: {win}")
+
+
 if __name__ == "__main__":
     main()
+    main_lds_dma(sys.argv[1])
