@@ -126,6 +126,15 @@ def _layernorm(x, g, b):
     return y
 
 
+def _ln_conv(x, g, b, w, bias, act=ops.ACT_NONE):
+    """act(conv1x1(LayerNorm(x))): on the packed bf16 kernels the normalised tensor is written straight into the convolution's packed input
+    (ops.layernorm_dense_fwd: one launch and one fp32 round trip of the tensor less); elsewhere the two operators."""
+    C, B, T = x.shape
+    if ops.ln_dense_fused_supported(B, T, C, w.shape[0]):
+        return ops.layernorm_dense_fwd(x, g, b, w, bias, {}, act=act, eps=_LN_EPS)
+    return _conv(_layernorm(x, g, b), w, bias, act=act)
+
+
 def _dwconv(x, w, b, k, act):
     y = torch.empty_like(x)
     C, B, T = x.shape
@@ -174,7 +183,7 @@ class _Conformer:
             self.layers.append(L)
 
     def _ffn(self, x, P):
-        h = _conv(_layernorm(x, P["ln_g"], P["ln_b"]), P["w1"], P["b1"], act=ops.ACT_SILU)
+        h = _ln_conv(x, P["ln_g"], P["ln_b"], P["w1"], P["b1"], act=ops.ACT_SILU)
         return _conv_add(h, P["w2"], P["b2"], x)
 
     def forward(self, x, lens):
@@ -184,13 +193,13 @@ class _Conformer:
         for L in self.layers:
             x = self._ffn(x, L["ffn1"])
             A = L["attn"]
-            qkv = _conv(_layernorm(x, A["ln_g"], A["ln_b"]), A["w_in"], A["b_in"])
+            qkv = _ln_conv(x, A["ln_g"], A["ln_b"], A["w_in"], A["b_in"])
             att = torch.empty_like(x)
             attn = lib.evmi_attention_cbt_bf16 if ops.CONV_BACKEND["operands"] == "bf16" else lib.evmi_attention_cbt_f32
             _chk(attn(qkv.data_ptr(), lens.data_ptr(), att.data_ptr(), B, T, D, self.cfg.heads, _s(x)), "evmi_attention_cbt")
             x = _conv_add(att, A["w_out"], A["b_out"], x)
             Cm = L["conv"]
-            p = _conv(_layernorm(x, Cm["ln_g"], Cm["ln_b"]), Cm["w_pw1"], Cm["b_pw1"])
+            p = _ln_conv(x, Cm["ln_g"], Cm["ln_b"], Cm["w_pw1"], Cm["b_pw1"])
             g = ops.elementwise(15, p[:D], p[D:])  # GLU over the channel halves
             h = _dwconv(g, Cm["w_dw"], Cm["b_dw"], self.cfg.conv_kernel_size, 1)  # depthwise + folded BatchNorm + SiLU
             x = _conv_add(h, Cm["w_pw2"], Cm["b_pw2"], x)
