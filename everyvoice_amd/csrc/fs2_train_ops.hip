@@ -455,8 +455,8 @@ __global__ __launch_bounds__(256) void fs2_table_bwd_kernel(const float* __restr
                                                            const int* __restrict__ lens, float* __restrict__ dtable, int B, int L,
                                                            int D, int skip_id) {
   __shared__ int sid[TABLE_CHUNK];    // row index of every token of the chunk (-1: skipped)
-  __shared__ int mlist[TABLE_CHUNK];  // the chunk's tokens that map to row r, in token order
-  __shared__ int mcount;
+  __shared__ int mlist[TABLE_CHUNK];  // the chunk's tokens that map to row r: four lists (one per quarter of the chunk), each in token order
+  __shared__ int mcount[4];
   const int r = blockIdx.x;
   const int c = blockIdx.y * 256 + threadIdx.x;
   const int N = B * L;
@@ -471,31 +471,37 @@ __global__ __launch_bounds__(256) void fs2_table_bwd_kernel(const float* __restr
       sid[i] = (lens && l >= lens[b]) || id == skip_id ? -1 : id;
     }
     __syncthreads();
-    // wave 0 compacts the matches (64 tokens per ballot, positions by prefix population count): the additions below then run over
-    // a list with eight loads in flight instead of one dependent load per match (250 -> ? us for the 26 k positions of a variance
-    // table); the order of the additions -- token order -- is unchanged
-    if (threadIdx.x < 64) {
-      const int lane = threadIdx.x;
+    // the matches are compacted (64 tokens per ballot, positions by prefix population count): the additions below then run over
+    // lists with eight loads in flight instead of one dependent load per match.  Every wave compacts ITS quarter of the chunk into
+    // its own list (one wave walking the whole chunk was the kernel: 140 us for the 26 k positions of a frame-level table, 64
+    // serial ballot steps per 4 k tokens); the lists are read in wave order, so the additions still run in token order -- the same bits
+    {
+      constexpr int QUARTER = TABLE_CHUNK / 4;
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int q0 = wave * QUARTER, q1 = min(cnt, q0 + QUARTER);
       int total = 0;
-      for (int i0 = 0; i0 < cnt; i0 += 64) {
-        const bool hit = i0 + lane < cnt && sid[i0 + lane] == r;
+      for (int i0 = q0; i0 < q1; i0 += 64) {
+        const bool hit = i0 + lane < q1 && sid[i0 + lane] == r;
         const unsigned long long m = __ballot(hit);
-        if (hit) mlist[total + __popcll(m & ((1ull << lane) - 1ull))] = base + i0 + lane;
+        if (hit) mlist[q0 + total + __popcll(m & ((1ull << lane) - 1ull))] = base + i0 + lane;
         total += __popcll(m);
       }
-      if (lane == 0) mcount = total;
+      if (lane == 0) mcount[wave] = total;
     }
     __syncthreads();
-    const int nm = mcount;
-    int q = 0;
-    for (; q + 8 <= nm; q += 8) {
-      float v[8];
+    for (int w = 0; w < 4; ++w) {
+      const int nm = mcount[w];
+      const int* ml = mlist + w * (TABLE_CHUNK / 4);
+      int q = 0;
+      for (; q + 8 <= nm; q += 8) {
+        float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = row[mlist[q + u]];
+        for (int u = 0; u < 8; ++u) v[u] = row[ml[q + u]];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) acc += v[u];
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; q < nm; ++q) acc += row[ml[q]];
     }
-    for (; q < nm; ++q) acc += row[mlist[q]];
   }
   if (c < D) dtable[(long long)r * D + c] += acc;
 }
