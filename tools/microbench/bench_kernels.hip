@@ -5,6 +5,7 @@
 
 #include "conv_tc_dma_kernel.h"
 #include "conv_tc_kernel.h"
+#include "conv_tc_pp_kernel.h"
 #include "resblock_pair_kernel.h"
 
 namespace evmi {
@@ -132,6 +133,13 @@ static const std::vector<Variant>& variants() {
       X("c128k11_dma_v2048", 128, 11, 5, 0, 2048) X("c256k11_dma_v2048", 256, 11, 5, 0, 2048)
       X("c128k11_dma_a208", 128, 11, 5, 0, 208) X("c128k11_dma_a256", 128, 11, 5, 0, 256) X("c128k11_dma_a512", 128, 11, 5, 0, 512)
       X("c256k11_dma_v1", 256, 11, 5, 0, 1) X("c256k11_dma_v2", 256, 11, 5, 0, 2) X("c256k11_dma_v3", 256, 11, 5, 0, 3)
+#undef X
+#define X(name, cin, ks, md, dbg, var) Variant{name, cin, ks, md, make_conv_pp_launch<ConvPpCfg<cin, ks, md, dbg, var>>(name)},
+      X("c128k11_pp", 128, 11, 5, 0, 0) X("c128k7_pp", 128, 7, 5, 0, 0) X("c256k11_pp", 256, 11, 5, 0, 0) X("c256k7_pp", 256, 7, 5, 0, 0)
+      X("c128k11_pp_tl", 128, 11, 5, 1, 0)
+      X("c128k11_pp_v1", 128, 11, 5, 0, 1) X("c128k11_pp_v2", 128, 11, 5, 0, 2)
+      X("c128k11_pp_a16", 128, 11, 5, 0, 16) X("c128k11_pp_a32", 128, 11, 5, 0, 32) X("c128k11_pp_a64", 128, 11, 5, 0, 64)
+      X("c128k11_pp_a112", 128, 11, 5, 0, 112)
 #undef X
   };
   return v;
