@@ -843,9 +843,8 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     // forward 110 -> 87 / input gradient 143 -> 106 us (128 -> 128, g 4), 180 -> 129 us (128 -> 256, g 16); stride-4 windows get too
     // long for it (40 -> 55 us), those keep 128 columns (tools/pkflat_bench.py, EVMI_PK_WIDE=1 against 0)
     // ... and 512-column tiles (index 10) the 8 / 16-row groups: 128 -> 256, g 16 forward 62 -> 52, input gradient 129 -> 111 us, the
-    // input gradient of 256 -> 512, g 16 87 -> 81 us; 32-row groups lose on them (86 -> 124 us) (EVMI_PK_WIDE2=0: off, 2: all narrow groups)
-    static const int wide2 = pk_env_int("EVMI_PK_WIDE2", 1);
-    if (wide2 && a.B == 1 && a.stride <= 2 && (a.cout_g <= 16 || wide2 == 2) && blocks(10) >= want) cand[nc++] = 10;
+    // input gradient of 256 -> 512, g 16 87 -> 81 us; 32-row groups lose on them (86 -> 124 us)
+    if (a.B == 1 && a.stride <= 2 && a.cout_g <= 16 && blocks(10) >= want) cand[nc++] = 10;
     if ((wide || (a.B == 1 && a.stride <= 2)) && blocks(5) >= want) cand[nc++] = 5;
     cand[nc++] = 3;
   }

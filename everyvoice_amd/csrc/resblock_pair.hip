@@ -2,7 +2,6 @@
 #include <cstdlib>
 
 #include "resblock_branch_kernel.h"
-#include "resblock_pair32_kernel.h"
 #include "resblock_pair_chunked_kernel.h"
 
 namespace evmi {
@@ -10,14 +9,10 @@ namespace evmi {
 //                  C  KS  BN  TAPS MAXDIL WAVES NWBUF OVL WRES WM   (sixteen waves at 32 channels: four per SIMD keep the VALU-bound activation
 //                  passes and the LDS latency of the short MFMA steps covered, -7 ... -9 %; at 64 channels the 2 (channels) x 8 (rows) split
 //                  costs a fragment read per MFMA instead of 0.75 and measured equal or slower: eight waves there)
-// C = 32: all taps of one convolution fit LDS at once (single buffer): 2 weight steps per tile.  The first three entries are
-// the two-workgroups-per-CU form (4 waves, 256 rows, T1 over XA), selected by EVMI_PAIR_OVL=1 only: measured 1.22 vs 1.16 ms
-// on c32 / k11 (and 3.1 vs 1.95 ms for a 128-row two-workgroup form at C = 64) -- with half the waves per workgroup the phases
-// of one workgroup are not filled by the other.
+// C = 32: all taps of one convolution fit LDS at once (single buffer): 2 weight steps per tile.  (Measured and removed in round 5:
+// a two-workgroups-per-CU form with T1 overlaying the operand tile, 1.22 vs 1.16 ms on c32 / k11; a conv1 / conv2 wave pipeline
+// with the weights in registers, 17.82 vs 17.63 ms per forward -- DESIGN.md §9.7, §9.11.)
 #define EVMI_PAIR_TABLE(X)               \
-  X(32, 3, 256, 3, 5, 4, 2, 1, 0, 1)     \
-  X(32, 7, 256, 7, 5, 4, 1, 1, 0, 1)     \
-  X(32, 11, 256, 11, 5, 4, 1, 1, 0, 1)   \
   X(64, 3, 256, 2, 5, 8, 2, 0, WR, 1)    \
   X(64, 7, 256, 2, 5, 8, 2, 0, WR, 1)    \
   X(64, 11, 256, 2, 5, 8, 2, 0, WR, 1)   \
@@ -30,11 +25,6 @@ static const PairLaunch* pair_table(int* n) {
 #define X(c, ks, bn, taps, md, waves, nwbuf, ovl, wres, wm) \
   make_pair_launch<PairCfg<c, ks, bn, taps, md, waves, 0, nwbuf, ovl, wres, wm>>("resblock_pair_mfma<c" #c ",k" #ks ",bn" #bn ",t" #taps ">"),
   static const PairLaunch table[] = {
-      // C = 32 as a conv1 / conv2 wave pipeline with the weights in registers (resblock_pair32_kernel.h): EVMI_PAIR32=1 only
-      // (measured equal or slower than the single-team kernels below, see the header)
-      make_pair32_launch<Pair32Cfg<3, 5>>("resblock_pair32<k3>"),
-      make_pair32_launch<Pair32Cfg<7, 5>>("resblock_pair32<k7>"),
-      make_pair32_launch<Pair32Cfg<11, 5>>("resblock_pair32<k11>"),
       EVMI_PAIR_TABLE(X)
       // C = 128: chunked variant (64-channel operand chunks, 2 x 4 waves of 64 x 64).  Measured on MI355X
       // (B=32, T=49152): k3 0.49 ms fused vs 0.56 ms as two conv_tc launches; k7 / k11 are MFMA/LDS-bound
@@ -54,18 +44,10 @@ const PairLaunch* find_resblock_pair(int c, int ks, int dil) {
     return !(e && e[0] == '0');
   }();
   if (c >= 128 && !c128_pairs) return nullptr;
-  static const int ovl = [] {
-    const char* e = getenv("EVMI_PAIR_OVL");
-    return e ? atoi(e) : 0;
-  }();
-  static const bool pair32 = [] {
-    const char* e = getenv("EVMI_PAIR32");
-    return e && e[0] == '1';
-  }();
   int n = 0;
   const PairLaunch* t = pair_table(&n);
-  for (int i = pair32 ? 0 : 3; i < n; ++i)
-    if (t[i].c == c && t[i].ks == ks && dil <= t[i].max_dil && (t[i].wg_per_cu == 1 || ovl)) return &t[i];
+  for (int i = 0; i < n; ++i)
+    if (t[i].c == c && t[i].ks == ks && dil <= t[i].max_dil) return &t[i];
   return nullptr;
 }
 

@@ -48,9 +48,7 @@ struct PairLaunch {
   const char* name;
 };
 
-// OVL_: the intermediate T1 overlays the conv1 operand tile XA (dead once conv1's last MFMA has read it; one more barrier
-// before T1 is written).  With it a 32-channel, 256-row tile needs ~73 KB: TWO 4-wave workgroups share a CU (WG_PER_CU) and one's
-// tile load / epilogue phases run under the other's MFMAs, where a single 8-wave workgroup per CU exposes every phase.
+// OVL_: must be 0 (round 2's form with T1 overlaying the conv1 operand tile, two workgroups per CU, was measured slower and removed in round 5)
 // WRES_: the weights of both convolutions stay in registers for the life of the persistent workgroup (NSTEP x W_PER_THREAD vectors,
 // loaded once) and are committed to the LDS from there: a two-tap step at 64 channels is 16 MFMAs per wave, shorter than the L2 round
 // trip of the next step's weights that the one-step-ahead prefetch has to cover.
@@ -79,13 +77,13 @@ struct PairCfg {
   static constexpr int X_PER_THREAD = (X_VECS_MAX + NTHREADS - 1) / NTHREADS;
   static constexpr size_t OFF_XA = 0;
   static constexpr size_t OFF_RS = OFF_XA + size_t(RA_MAX) * S;
-  static constexpr size_t OFF_T1 = OVL ? OFF_XA : OFF_RS + size_t(BN) * S;
-  static constexpr size_t OFF_WS = OVL ? OFF_RS + size_t(BN) * S : OFF_T1 + size_t(T1_ROWS) * S;
+  static constexpr size_t OFF_T1 = OFF_RS + size_t(BN) * S;
+  static constexpr size_t OFF_WS = OFF_T1 + size_t(T1_ROWS) * S;
   static constexpr size_t OFF_BIAS = OFF_WS + NWBUF * size_t(W_TILE);  // 2 copies x 2 x C floats (in bf16 units: 8 C)
   static constexpr size_t LDS = (OFF_BIAS + 8 * size_t(C)) * 2;
   static constexpr int WG_PER_CU = (2 * LDS <= 160 * 1024 && WAVES <= 4) ? 2 : 1;
   static_assert(BN % (WN * 32) == 0 && C % (WM * 32) == 0 && WAVES % WM == 0, "tiling");
-  static_assert(!OVL || T1_ROWS <= RA_MAX, "T1 fits the operand tile it overlays");
+  static_assert(OVL == 0, "the overlay form was removed");
   static_assert(LDS <= 160 * 1024, "LDS budget");
 };
 
@@ -241,7 +239,6 @@ __global__ __launch_bounds__(P::NTHREADS) void resblock_pair_kernel(PairArgs a) 
       }
       if (conv == 0) {
         // T1[n] = lrelu(conv1 + b1) for global row r0 - H2 + n, zero outside the sequence
-        if (P::OVL) lds_barrier();  // T1 overlays XA: every wave is done with conv1's last fragment reads
         const float sl = a.slope;
         const bool edge = r0 - H2 < 0 || r0 - H2 + P::BN > a.T;  // (wave-uniform) rows outside the sequence in this tile
 #pragma unroll

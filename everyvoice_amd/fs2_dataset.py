@@ -157,6 +157,11 @@ class FastSpeech2Dataset(Dataset):
         for key in ("pitch", "energy"):
             v = self._load(item, key, f"{key}.pt").to(torch.float32)
             want = L if self.phone_level[key] else T
+            if not self.phone_level[key] and v.shape[0] != want and abs(v.shape[0] - want) <= 1 and v.shape[0] > 0:
+                # frame-level values from pyworld's DIO have int(n / fs / frame_period_ms * 1000) + 1 frames, computed in float
+                # milliseconds (preprocessor.py:244-285): one more or one fewer than the centred STFT's n // hop + 1 on some
+                # files.  The reference trains on those; here: drop the extra value / repeat the last one.
+                v = v[:want] if v.shape[0] > want else torch.cat([v, v[-1:]])
             if v.shape[0] != want:
                 raise ValueError(f"{item['basename']}: {key} has {v.shape[0]} values, the configuration "
                                  f"({'phone' if self.phone_level[key] else 'frame'} level) wants {want}")

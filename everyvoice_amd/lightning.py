@@ -298,10 +298,13 @@ class FastSpeech2(_Module):
     """``fs2.model.FastSpeech2(config, stats, lang2id, speaker2id)`` (tests/model_stubs.py:44-58)."""
 
     def __init__(self, config: FastSpeech2Config | None = None, stats=None, lang2id: dict | None = None, speaker2id: dict | None = None,
-                 device=None, precision: str = "bf16", process_group=None, use_graph: bool = True, graph_buckets: tuple | None = (16, 64)):
-        """``use_graph`` / ``graph_buckets``: steps replay as HIP graphs per padded batch shape (train/fs2.py); batches are padded up to
-        multiples of (symbols, frames) = ``graph_buckets`` so that the variable-length batches of a real loader fall on a small set of
-        shapes (an LRU of captured shapes; unseen shapes run eagerly twice first).  ``model_kwargs`` of ``train_base_command`` reach here."""
+                 device=None, precision: str = "bf16", process_group=None, use_graph: bool = True, graph_buckets: tuple | None = None):
+        """``use_graph`` / ``graph_buckets``: steps replay as HIP graphs per padded batch shape (train/fs2.py): an LRU of captured shapes,
+        unseen shapes run eagerly twice first.  ``graph_buckets=(symbols, frames)`` (e.g. (16, 64)) pads batches up to multiples so that
+        the variable-length batches of a real loader fall on a small set of shapes -- OFF by default since round 5: the
+        Conformer's BatchNorm takes its batch statistics over every column, padded ones included (as torchaudio's does), so extra
+        padding shifts mean / variance and the running statistics away from a run padded to the batch maximum only; opt in where
+        replay rate matters more than that drift.  ``model_kwargs`` of ``train_base_command`` reach here."""
         super().__init__()
         from .fs2 import Stats
 

@@ -207,8 +207,9 @@ class DiscChain:
         _, n_audio, t_audio = x.shape
         frozen = all(layer.frozen for layer in self.convs)
         with_grad = audio.needs_grad or not frozen
-        if grad_from is not None and not (frozen and 0 < grad_from < n_audio):
-            raise ValueError("disc chain: a split batch is the generator step's (frozen layers, 0 < grad_from < n_audio)")
+        if grad_from is not None and not (frozen and n_audio == 2 * grad_from and grad_from > 0):
+            # (feature matching pairs generated item i with real item i row by row: only an even split pairs the right items)
+            raise ValueError("disc chain: a split batch is the generator step's [real | generated] (frozen layers, n_audio == 2 * grad_from)")
         cfg = self.cfg(n_audio, t_audio, role, with_grad, None if grad_from is None else n_audio - grad_from)
         convs, post, L = self.convs, self.conv_post, len(self.convs)
         st = ops._s(x)

@@ -310,7 +310,8 @@ def ln_dense(tape: Tape, x: Var, ln: Affine, layer) -> Var:
         if y.grad is None:
             return
         # (x.data stands in for the normalised tensor, which was never stored: only its shape is read -- the weight gradient takes the packed copy)
-        dh, _, _ = ops.conv1d_bwd(x.data, w, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True, packed=packed)
+        dh, _, _ = ops.conv1d_bwd(x.data, w, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True, packed=packed,
+                                   x_standin=True)
         packed.clear()
         x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh, ln.dgamma(), ln.dbeta()))
 
@@ -344,7 +345,8 @@ def ffn_core(tape: Tape, x: Var, ln: Affine, l1, l2, p: float, seed: int) -> Var
         if y.grad is None:
             return
         # second layer: its packed input is the forward's (a stands in for the fp32 tensor that was never stored: only its shape is read)
-        ds, _, _ = ops.conv1d_bwd(a, w2, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw2, db_out=l2.db_sink(), accumulate=True, packed=packed2)
+        ds, _, _ = ops.conv1d_bwd(a, w2, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw2, db_out=l2.db_sink(), accumulate=True, packed=packed2,
+                                   x_standin=True)
         packed2.clear()
         # first layer: x.data / h.data only lend their shape (the weight gradient reads the packed copy)
         dh = ops.conv1d_bwd_silu_dropout_dy(x.data if ln_fused else h.data, w1, ds, a, p, seed, dw1, l1.db_sink(), packed1)
@@ -1061,6 +1063,7 @@ class FastSpeech2Trainer:
         ops.CONV_BACKEND["operands"] = self.precision
         ops.SIDE_WGRAD["on"] = self.side_wgrad and self.device.type == "cuda"
         ops.SEED_BASE[0] = self._seed_base
+        ops.side_reset()  # nothing an aborted step left collected reaches this one (ops.side_reset)
         try:
             d, meta = self._prepare_on_upload_stream(batch)
             self._store_step_scalars(meta)
@@ -1078,6 +1081,9 @@ class FastSpeech2Trainer:
                 # losses across steps (running means, deferred logging) -- eager steps hand out fresh tensors too
                 losses = {k: v.clone() for k, v in entry["losses"].items()}
                 self.last_step_was_graph = True
+        except BaseException:
+            ops.side_reset()
+            raise
         finally:
             ops.CONV_BACKEND["operands"] = prev
             ops.SIDE_WGRAD["on"] = prev_side
@@ -1138,6 +1144,7 @@ class FastSpeech2Trainer:
         except Exception as e:  # noqa: BLE001 -- whatever the runtime objected to: the eager path is always available
             self._graph_failed = f"{type(e).__name__}: {e}"
             torch.cuda.synchronize(self.device)
+            ops.side_reset()  # the aborted capture's collected weight-gradient launches and its events must not reach the eager step
             return None
         self._graphs[key] = entry
         while len(self._graphs) > self.GRAPH_CACHE:

@@ -406,15 +406,6 @@ def allreduce_mean_(flat_grad: torch.Tensor, process_group, scale_fn) -> torch.T
     return flat_grad
 
 
-def capture_agreed(ok: bool, pg, device) -> bool:
-    """True when every rank of the group reports ``ok`` (one MIN all-reduce of a flag, issued by every rank whatever its own outcome)."""
-    import torch.distributed as dist
-
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if dist.get_backend(None if pg is True else pg) == "nccl" else "cpu")
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=None if pg is True else pg)
-    return bool(int(flag.item()))
-
-
 class BucketReducer:
     """Data-parallel gradient exchange overlapped with backward: the flat gradient buffer of one optimiser is
     reduced in contiguous buckets, each launched -- asynchronously, on a side stream when the buffer lives on a GPU -- the
@@ -817,6 +808,7 @@ class HiFiGANTrainer:
         prev, prev_side = ops.CONV_BACKEND["operands"], ops.SIDE_WGRAD["on"]
         ops.CONV_BACKEND["operands"] = self.precision
         ops.SIDE_WGRAD["on"] = self.side_wgrad and self.device.type == "cuda"
+        ops.side_reset()  # nothing an aborted step left collected reaches this one (ops.side_reset)
         try:
             if self.device.type != "cuda":
                 buf = self._eager_step(mel_bct, audio_bct)
@@ -831,6 +823,9 @@ class HiFiGANTrainer:
                     else:
                         buf = self._eager_step(mel_bct, audio_bct)
                 caller.wait_stream(self._stream)
+        except BaseException:
+            ops.side_reset()
+            raise
         finally:
             ops.CONV_BACKEND["operands"] = prev
             ops.SIDE_WGRAD["on"] = prev_side
@@ -848,6 +843,8 @@ class HiFiGANTrainer:
 
     def _eager_step(self, mel_bct, audio_bct):
         warm = self.global_step < self.generator_warmup_steps
+        if self.pg is not None and self.phase_times is None:
+            return self._eager_data_parallel_step(mel_bct, audio_bct, warm)
         marks = []
 
         def mark(name):  # EVMI_PHASE_TIMES=1: device time of every phase of the step (HIP events on the step's stream)
@@ -1153,16 +1150,18 @@ class HiFiGANTrainer:
             steps = (self.g_params.step, self.d_params.step)
             failure = None
             try:
+                if getattr(self, "_force_capture_failure", False):  # (tests/test_gpu_ddp.py: one rank eager beside one that replays)
+                    raise RuntimeError("capture failure forced by a test")
                 entry = self._capture(key, mel_bct, audio_bct, warm)
             except Exception as e:  # noqa: BLE001 -- whatever the runtime objected to: the eager path is always available
                 failure = f"{type(e).__name__}: {e}"
-            # data parallel: the captured schedule and the eager one cut the gradients into different buckets, i.e. issue different
-            # sequences of collectives -- every rank takes the eager path unless the capture succeeded on all of them
-            if self.pg is not None and not capture_agreed(failure is None, self.pg, self.device) and failure is None:
-                failure, entry = "graph capture failed on another rank", None
+            # data parallel: the eager step runs the captured step's schedule (`_eager_data_parallel_step`: same stretches, same
+            # buckets, same collective sequence), so a rank whose capture failed goes on eagerly beside ranks that replay --
+            # no agreement between the ranks is needed (round 4 all-reduced a flag here, a collective only capturing ranks issued)
             if failure is not None:
                 self._graph_failed = failure
                 torch.cuda.synchronize(self.device)
+                ops.side_reset()  # the aborted capture's collected weight-gradient launches and events must not reach the eager step
                 # nothing of the aborted capture has run, but its host-side bookkeeping has: the spectral-norm layers hold
                 # prepared (weight, sigma, u, v) tuples that live in the dead graph's pool and were never computed, and the
                 # optimisers' host counters were bumped.  Put both back before the eager step.
@@ -1234,15 +1233,37 @@ class HiFiGANTrainer:
         return dict(graphs=graphs, after=after, mel=mel_s, audio=audio_s)
 
     def _capture_data_parallel(self, cap_raw, ctx, mel_s, audio_s, warm):
-        scale = lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc)  # noqa: E731
-        pg = self.pg if self.pg is not True else None
-        d_red, g_red = BucketReducer(self.d_params.grad, pg, scale), BucketReducer(self.g_params.grad, pg, scale)
-        self._dp_reducers = (d_red, g_red)  # (kept: their side streams live across replays)
+        """The data-parallel schedule with every stretch captured and every exchange stored for the replay loop."""
         thens = []
 
-        def cap(fn):
+        def run(fn):
             cap_raw(fn, lambda i=len(thens): thens[i] and thens[i]())
             thens.append(None)
+
+        def emit(then):
+            thens[-1] = then
+
+        self._data_parallel_schedule(run, emit, ctx, mel_s, audio_s, warm)
+
+    def _eager_data_parallel_step(self, mel_bct, audio_bct, warm):
+        """The data-parallel schedule executed eagerly: the SAME stretches and the SAME exchanges between them as the captured step
+        (`_capture_data_parallel`), so a rank that runs eagerly -- a shape not captured yet, a capture that failed on this rank only --
+        issues exactly the collective sequence of a rank that replays (the reference: every rank runs the same DDP bucket sequence,
+        everyvoice/base_cli/interfaces.py:90-97 -> base_cli/helpers.py:252-270).  No agreement between ranks is needed any more."""
+        ctx = {}
+        try:
+            self._data_parallel_schedule(lambda fn: fn(), lambda then: then(), ctx, mel_bct, audio_bct, warm)
+        finally:
+            ctx.clear()
+        return self._loss_buf
+
+    def _data_parallel_schedule(self, run, emit, ctx, mel_s, audio_s, warm):
+        """``run(fn)``: execute (or capture) one stretch; ``emit(then)``: the exchange that follows it (called at once, or stored)."""
+        if getattr(self, "_dp_reducers", None) is None:
+            scale = lambda t, sc: ops.elementwise(ops.EW_SCALE, t, out=t, p0=sc)  # noqa: E731
+            pg = self.pg if self.pg is not True else None
+            self._dp_reducers = (BucketReducer(self.d_params.grad, pg, scale), BucketReducer(self.g_params.grad, pg, scale))  # (their side streams live across steps)
+        d_red, g_red = self._dp_reducers
 
         def first():
             ctx.update(self._phase_generator_forward(mel_s, audio_s, d_step=not warm))
@@ -1250,7 +1271,7 @@ class HiFiGANTrainer:
                 self._phase_d_prelude(ctx)
 
         if warm:
-            cap(first)
+            run(first)
         else:
             groups = self.d_bucket_groups()
             ds = self.discriminators()
@@ -1266,11 +1287,11 @@ class HiFiGANTrainer:
                     if last:
                         self._phase_d_epilogue(ctx)
 
-                cap(stretch)
+                run(stretch)
                 if last:  # the discriminators' optimiser comes next: wait for every bucket, scale by 1 / world
-                    thens[-1] = lambda lo=lo, hi=hi: (d_red.launch(lo, hi), d_red.launch(0, d_front), d_red.finish())
+                    emit(lambda lo=lo, hi=hi: (d_red.launch(lo, hi), d_red.launch(0, d_front), d_red.finish()))
                 else:  # runs on the side stream UNDER the next group's forward + backward
-                    thens[-1] = lambda lo=lo, hi=hi: d_red.launch(lo, hi)
+                    emit(lambda lo=lo, hi=hi: d_red.launch(lo, hi))
         # generator step: the first stretch runs the discriminators' update, the generator-step discriminator pass, the losses
         # and the generator's backward down to the first bucket boundary worth a cut; then one stretch per further bucket
         ctx["g_segmented"] = True
@@ -1299,15 +1320,16 @@ class HiFiGANTrainer:
             advance()
 
         hi = self.g_params.grad.numel()
-        cap(g_first)
+        run(g_first)
         while True:
             lo, done = state["cut"], state["done"]
-            thens[-1] = (lambda lo=lo, hi=hi: (g_red.launch(lo, hi), g_red.finish())) if done else (lambda lo=lo, hi=hi: g_red.launch(lo, hi))
+            emit((lambda lo=lo, hi=hi: (g_red.launch(lo, hi), g_red.finish())) if done else (lambda lo=lo, hi=hi: g_red.launch(lo, hi)))
             hi = lo
             if done:
                 break
-            cap(advance)
-        cap(lambda: self._phase_g_update(ctx))
+            run(advance)
+        run(lambda: self._phase_g_update(ctx))
+
 
 def _to_cbt_kernel(x_bct: torch.Tensor) -> torch.Tensor:
     """[B, C, T] -> [C, B, T] with library copy kernels (one strided row-block copy per item: layout change only)."""

@@ -284,6 +284,20 @@ def side_check_drained():
         raise RuntimeError(f"side_wgrad: {left} weight-gradient launches were never issued (a backward chain ended without wgrad_join on its stream)")
 
 
+def side_reset():
+    """Forget every weight-gradient launch that was collected but not issued, and every pending event.  A step that aborts half way
+    -- a graph capture that fails and falls back to the eager body, an out-of-memory error a caller retries -- leaves closures in
+    ``queue`` whose tensors were never written (they live in the aborted capture's pool) and a ``pending`` event recorded inside that
+    capture: the next step's first flush would wait on that event and launch the stale closures with accumulate=1 into the live
+    weight-gradient buffers (silent gradient corruption; ``side_check_drained`` does not see it because the flush empties
+    the queue).  Called at the start of every step, and where a step aborts."""
+    for st in _SIDE.values():
+        st.queue.clear()
+        st.keep_next.clear()
+        st.keep.clear()
+        st.pending = None
+
+
 def wgrad_join(device=None):
     """The current stream waits for the weight-gradient kernels its sibling stream still has queued (the launches still collected on
     the host are issued first); their inputs may go."""
@@ -543,8 +557,10 @@ def conv1d_fwd(x, w, bias, stride=1, pad=0, dil=1, groups=1, lrelu_slope=None, a
     return y
 
 
-def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, accumulate, packed=None):
-    """dw (+)= conv_weight_grad(x, dy) and, when asked, db_out (+)= row sums of dy -- on whichever kernel takes the shape."""
+def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, accumulate, packed=None, x_standin=False):
+    """dw (+)= conv_weight_grad(x, dy) and, when asked, db_out (+)= row sums of dy -- on whichever kernel takes the shape.
+    ``x_standin``: x only lends its shape (the layer's real input exists as ``packed["x_packed"]`` alone: fused LayerNorm -> dense,
+    fused feed-forward middle); any path that would read x itself is an error then, not a fallback."""
     cin, B, t_in = x.shape
     cout, cin_g, k = w_shape
     t_out = dy.shape[2]
@@ -562,7 +578,11 @@ def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, 
         ws = WS.get("pkw", pk_elems, x.device)
         xp = packed.get("x_packed") if packed else None
         dyp = packed.get("dy_packed") if packed else None
-        if (xp is not None or dyp is not None) and shares_packed(B, t_in, k, stride, pad, dil, groups):
+        prepacked = (xp is not None or dyp is not None) and shares_packed(B, t_in, k, stride, pad, dil, groups)
+        if x_standin and not (prepacked and xp is not None):
+            raise RuntimeError("weight gradient of a fused layer: the packed input is gone or the shape left the pre-packed path "
+                               "(x is a stand-in for a tensor that was never stored)")
+        if prepacked:
             # the forward's packed input / the input gradient's packed dy, read where they lie (no second pack)
             _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk_prepacked(x.data_ptr(), _lib.ptr(xp), dy.data_ptr(), _lib.ptr(dyp), dw.data_ptr(), ws.data_ptr(),
                                                             pk_elems, B, cin, t_in, cout, t_out, k, stride, pad, dil, groups, int(accumulate),
@@ -570,6 +590,9 @@ def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, 
         else:
             _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t_in, cout, t_out,
                                                   k, stride, pad, dil, groups, int(accumulate), _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk")
+    elif x_standin:
+        raise RuntimeError("weight gradient of a fused layer fell off the packed bf16 kernels (backend switched since the forward?): "
+                           "x is a stand-in for a tensor that was never stored")
     elif ws_elems > 0:  # implicit GEMM on the fp32 matrix cores (conv_wgrad_f32_mfma.hip)
         ws = WS.get("wgrad", ws_elems, x.device)
         _chk(lib.evmi_conv1d_wgrad_cbt_f32(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_elems, B, cin, t_in, cout, t_out,
@@ -585,7 +608,7 @@ def _weight_and_bias_grad(x, w_shape, dy, dw, db_out, stride, pad, dil, groups, 
 
 
 def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=None, db_out=None, accumulate=False,
-               need_dw=True, packed=None):
+               need_dw=True, packed=None, x_standin=False):
     """Returns (dx, dw, db); dw/db are written (or accumulated) into the given buffers when provided.
     ``packed``: the dict the layer's forward call filled (``conv1d_fwd(..., keep=packed)``): a pointwise stride-1 layer on the packed
     bf16 kernels then packs x once (forward) and dy once (input gradient) for all three of its products."""
@@ -635,7 +658,9 @@ def conv1d_bwd(x, w, dy, stride=1, pad=0, dil=1, groups=1, need_dx=True, dw_out=
     if side is not None:
         db = db_out  # (what _weight_and_bias_grad returns: the caller's bias-gradient buffer, filled by the launch)
         pk = dict(packed) if share else None  # (a snapshot: the caller clears its dict when this returns, the launch may come later)
-        side.run(lambda: _weight_and_bias_grad(x, w.shape, dy, dw, db_out, stride, pad, dil, groups, accumulate, packed=pk))
+        if x_standin and not (share and pk.get("x_packed") is not None):
+            raise RuntimeError("conv1d_bwd(x_standin=True): the forward's packed input is required")
+        side.run(lambda: _weight_and_bias_grad(x, w.shape, dy, dw, db_out, stride, pad, dil, groups, accumulate, packed=pk, x_standin=x_standin))
     return dx, dw, db
 
 
@@ -646,11 +671,19 @@ def ffn_fused_supported(B, t, c_mid, c_out) -> bool:
     if not (_packed() and CONV_BACKEND["fwd"] == "mfma" and CONV_BACKEND["dgrad"] == "mfma" and CONV_BACKEND["wgrad"] != "gemm"):
         return False
     lib = _lib.load()
+    geo = (t, 1, 1, 0, 1, 1)
     return bool(shares_packed(B, t, 1, 1, 0, 1, 1)
-                and lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, c_mid, t, c_out, t, 1, 1, 0, 1, 1) > 0
-                and lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, c_out, t, c_mid, t, 1, 1, 0, 1, 1) > 0
-                and lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, c_out, t, c_mid, t, 1, 1, 0, 1, 1) > 0
-                and dgrad_mfma_supported(B, c_out, t, c_mid, t, 1, 1, 1, 1))
+                # layer 1 (c_out -> c_mid): forward, input gradient, weight gradient
+                and lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, c_out, t, c_mid, *geo) > 0
+                and lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, c_out, t, c_mid, *geo) > 0
+                and lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, c_out, t, c_mid, *geo) > 0
+                and dgrad_mfma_supported(B, c_out, t, c_mid, t, 1, 1, 1, 1)
+                # layer 2 (c_mid -> c_out): its weight gradient reads the packed dropout(silu(a)) -- the fp32 tensor handed to
+                # conv1d_bwd is the pre-activation a, a stand-in (probe these too)
+                and lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, c_mid, t, c_out, *geo) > 0
+                and lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, c_mid, t, c_out, *geo) > 0
+                and lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, c_mid, t, c_out, *geo) > 0
+                and dgrad_mfma_supported(B, c_mid, t, c_out, t, 1, 1, 1, 1))
 
 
 def ln_dense_fused_supported(B, t, c_in, c_out) -> bool:

@@ -42,3 +42,47 @@ def synthetic_mel(B: int, T: int, n_mels: int = 80, seed: int = 1234) -> torch.T
 
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+_CHILD_RESULTS: dict = {}
+
+
+def child_pytest_results(group: str, jobs: dict, parallel: int = 4, timeout: int = 1500) -> dict:
+    """Run the child ``pytest`` processes of one test family side by side and cache the outcome per family.
+
+    ``jobs``: key -> (pytest arguments, extra environment).  The kernels' A/B switches are read once per process, so every switch /
+    forced tile needs a process of its own; run one after the other those children were 40 % of the GPU suite's wall time (start-up
+    and ``import torch`` mostly), although each uses a sliver of the GPU.  The first test of a family that asks starts ALL of the
+    family's children, ``parallel`` at a time; every parametrised test then asserts on its own child's result."""
+    import os
+    import subprocess
+    import sys
+    import time
+
+    if group in _CHILD_RESULTS:
+        return _CHILD_RESULTS[group]
+    # the children compute torch references on the CPU: side by side each gets its share of the cores (N processes x all cores
+    # oversubscribes the OpenMP pools -- the first version of this helper took > 20 minutes for what runs in 5 one after the other)
+    threads = str(max(1, min(32, (os.cpu_count() or 8) // max(1, parallel))))
+    pending = list(jobs.items())
+    running: list = []
+    results: dict = {}
+    while pending or running:
+        while pending and len(running) < parallel:
+            key, (args, env) = pending.pop(0)
+            proc = subprocess.Popen([sys.executable, "-m", "pytest", *args], env=dict(os.environ, OMP_NUM_THREADS=threads, MKL_NUM_THREADS=threads, **env),
+                                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            running.append((key, proc, time.time()))
+        for item in list(running):
+            key, proc, t0 = item
+            if proc.poll() is None:
+                if time.time() - t0 > timeout:
+                    proc.kill()
+                else:
+                    continue
+            out = proc.communicate()[0]
+            results[key] = (proc.returncode, out[-4000:])
+            running.remove(item)
+        time.sleep(0.2)
+    _CHILD_RESULTS[group] = results
+    return results

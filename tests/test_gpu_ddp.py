@@ -25,7 +25,7 @@ def _batch(B, S, seed=8):
     return mel, y
 
 
-def _rank_main(rank, world, port, use_graph, steps, out_dir, B, S, precision="f32"):
+def _rank_main(rank, world, port, use_graph, steps, out_dir, B, S, precision="f32", fail_capture_rank=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, str(ROOT))
     import torch.distributed as dist
@@ -36,6 +36,7 @@ def _rank_main(rank, world, port, use_graph, steps, out_dir, B, S, precision="f3
     dev = torch.device("cuda:0")
     try:
         tr = HiFiGANTrainer(device=dev, seed=5, process_group=True, use_graph=use_graph, precision=precision)
+        tr._force_capture_failure = rank == fail_capture_rank
         mel, y = _batch(B * world, S)
         mel, y = mel[rank * B:(rank + 1) * B].to(dev), y[rank * B:(rank + 1) * B].to(dev)
         losses = [tr.training_step(mel, y) for _ in range(steps)]
@@ -47,20 +48,30 @@ def _rank_main(rank, world, port, use_graph, steps, out_dir, B, S, precision="f3
         dist.destroy_process_group()
 
 
-def _run_two_ranks(tmp_path, use_graph, steps, B, S, precision="f32"):
+def _start_two_ranks(tmp_path, use_graph, steps, B, S, precision="f32", fail_capture_rank=None):
+    """Starts the two rank processes; returns a function that joins them and loads what they saved."""
     import torch.multiprocessing as mp
 
+    tmp_path.mkdir(parents=True, exist_ok=True)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, use_graph, steps, str(tmp_path), B, S, precision)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, use_graph, steps, str(tmp_path), B, S, precision, fail_capture_rank)) for r in range(2)]
     for p in procs:
         p.start()
-    for p in procs:
-        p.join(600)
-        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
-    return [torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(2)]
+
+    def join():
+        for p in procs:
+            p.join(600)
+            assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+        return [torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(2)]
+
+    return join
+
+
+def _run_two_ranks(tmp_path, use_graph, steps, B, S, precision="f32"):
+    return _start_two_ranks(tmp_path, use_graph, steps, B, S, precision)()
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -69,6 +80,9 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_concatenated_batch(cuda_devi
 
     B, S = 2, 2048
     steps = 4 if use_graph else 1  # graph mode: two eager steps, the capture, one pure replay
+    eager = None
+    if use_graph:  # the eager two-rank run it is compared with runs beside it (four processes on GPU 0: half the wall time)
+        eager = _start_two_ranks(tmp_path / "eager", False, steps, B, S)
     r0, r1 = _run_two_ranks(tmp_path, use_graph, steps, B, S)
     assert r0["graph_failed"] is None and r1["graph_failed"] is None
     if use_graph:
@@ -92,9 +106,7 @@ def test_two_ranks_on_one_gpu_equal_one_rank_on_the_concatenated_batch(cuda_devi
     else:
         # graph mode: four steps of two ranks vs four eager steps of two ranks would be the bitwise comparison; here: the losses of
         # every step agree with the eager two-rank run's to summation order (same shards, same arithmetic, exchanges moved)
-        tmp2 = tmp_path / "eager"
-        tmp2.mkdir()
-        e0, _ = _run_two_ranks(tmp2, False, steps, B, S)
+        e0, _ = eager()
         for a, b in zip(r0["losses"], e0["losses"]):
             for k in a:
                 assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-7), k
@@ -107,14 +119,29 @@ def test_two_ranks_in_bf16_on_the_packed_chains_graph_equals_eager(cuda_device, 
     with the same gradients and parameters, and four steps in graph mode (stretches cut at bucket boundaries) end bit for bit where four
     eager steps end."""
     B, S, steps = 2, 2048, 4
+    eager = _start_two_ranks(tmp_path / "eager", False, steps, B, S, "bf16")
     r0, r1 = _run_two_ranks(tmp_path, True, steps, B, S, "bf16")
     assert r0["graph_failed"] is None and r1["graph_failed"] is None and r0["graphs"] and r0["graphs"][0] >= 5
     for k in ("d_grad", "g_grad", "d", "g"):
         assert torch.equal(r0[k], r1[k]), k
-    tmp2 = tmp_path / "eager"
-    tmp2.mkdir()
-    e0, _ = _run_two_ranks(tmp2, False, steps, B, S, "bf16")
+    e0, _ = eager()
     assert torch.equal(r0["d"], e0["d"]) and torch.equal(r0["g"], e0["g"])
+
+
+def test_a_rank_whose_capture_failed_steps_eagerly_beside_one_that_replays(cuda_device, tmp_path):
+    """rank 1 is forced to fail its capture and runs every step eagerly, rank 0 captures and replays.  The eager
+    data-parallel step runs the captured step's schedule (train/hifigan.py: _data_parallel_schedule -- same stretches, same buckets), so
+    the two ranks' all-reduces pair one for one: both finish all four steps (no hang, no mismatched collective) holding the same
+    gradients and parameters, bit for bit, in the bench's precision.  Reference behaviour: every rank runs the same DDP bucket
+    sequence (everyvoice/base_cli/helpers.py:252-270)."""
+    B, S, steps = 2, 2048, 4
+    r0, r1 = _start_two_ranks(tmp_path, True, steps, B, S, "bf16", fail_capture_rank=1)()
+    assert r0["graph_failed"] is None and r0["graphs"] and r0["graphs"][0] >= 5
+    assert r1["graph_failed"] is not None and "forced" in r1["graph_failed"] and not r1["graphs"]
+    for k in ("d_grad", "g_grad", "d", "g"):
+        assert torch.equal(r0[k], r1[k]), k
+    for a, b in zip(r0["losses"], r1["losses"]):
+        assert all(torch.isfinite(torch.tensor(v)) for v in a.values()) and set(a) == set(b)
 
 
 # ---- FastSpeech2: the bucketed exchange and the Tape.cut stretches with TWO ranks (VERDICT r03 item 5) -----------------------------

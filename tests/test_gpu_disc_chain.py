@@ -412,7 +412,7 @@ def test_chain_against_torch_autograd_with_its_roundings(which, n, T, generator_
             assert c >= floor and abs(r - 1) <= 1e-2, (name, c, r)
 
 
-@pytest.mark.parametrize("switch", ["EVMI_WG_TAPSPLIT=0", "EVMI_PK_WIDE2=0"])
+@pytest.mark.parametrize("switch", ["EVMI_WG_TAPSPLIT=0"])
 def test_flat_kernels_behind_their_switches(switch):
     """The flat weight gradient without the tap split over a row's waves, the flat convolutions without the 512-column tiles: the
     comparisons with torch of this file once more in a child process each (the switches are read once per process)."""

@@ -644,6 +644,76 @@ def test_feed_forward_middle_fused_into_the_packs_equals_the_separate_passes(cud
         assert rel(got, want) <= tol, (name, rel(got, want))
 
 
+def test_fused_feed_forward_block_against_torch_with_the_kernels_own_mask(cuda_device):
+    """the fused feed-forward block (train/fs2.py: ffn_core = LayerNorm written packed -> dense1 -> SiLU + dropout
+    applied while dense2's input is packed -> dense2; backward with dropout(ds) * silu'(a) applied while dense1's output gradient is
+    packed) at the BENCH shape (32 x 814 columns, 256 -> 1024 -> 256) against TORCH -- not against the library's own separate passes --
+    with the kernels' mask exported through the one-operator dropout kernel (same counter-based stream: element i of the [1024, B, T]
+    tensor) and the path's rounding points restated: every matrix operand is rounded to bf16 (LayerNorm output, dropout(silu(a)), both
+    output gradients, the weights), products accumulate in fp32, the first layer's bias gradient sums the ROUNDED gradient.
+    Tolerances: a value that lands within summation-order noise of a bf16 rounding boundary rounds the other way on one side (4e-3 of
+    that element); relative L2 <= 1e-3 per tensor (measured 1e-4 .. 4e-4) and every element within 1 % of the tensor's largest."""
+    from everyvoice_amd.train import ops
+
+    D, F_, B, T, p, seed = 256, 1024, 32, 814, 0.2, 4321
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(D, B, T, generator=g) * 1.3 + 0.2
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    w1 = torch.randn(F_, D, 1, generator=g) * D ** -0.5
+    w2 = torch.randn(D, F_, 1, generator=g) * F_ ** -0.5
+    b1, b2 = torch.randn(F_, generator=g) * 0.1, torch.randn(D, generator=g) * 0.1
+    dy = torch.randn(D, B, T, generator=g)
+    dev = cuda_device
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    prev = ops.CONV_BACKEND["operands"]
+    ops.CONV_BACKEND["operands"] = "bf16"
+    try:
+        assert ops.ffn_fused_supported(B, T, F_, D) and ops.ln_dense_fused_supported(B, T, D, F_)
+        xd, w1d, w2d = x.to(dev), w1.to(dev), w2.to(dev)
+        gd, bd = gamma.to(dev), beta.to(dev)
+        keep = (ops.dropout(torch.ones(F_ * B * T, device=dev), p, seed) > 0).float().view(F_, B * T).cpu()
+        f1, f2 = {}, {}
+        a = ops.layernorm_dense_fwd(xd, gd, bd, w1d, b1.to(dev), f1)
+        y = ops.conv1d_fwd_silu_dropout(a, w2d, b2.to(dev), p, seed, f2)
+        ew1, ew2, eb1, eb2 = torch.zeros_like(w1d), torch.zeros_like(w2d), torch.zeros(F_, device=dev), torch.zeros(D, device=dev)
+        dgam, dbet = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        ds, _, _ = ops.conv1d_bwd(a, w2d, dy.to(dev), 1, 0, 1, 1, need_dx=True, dw_out=ew2, db_out=eb2, accumulate=True, packed=f2, x_standin=True)
+        dh = ops.conv1d_bwd_silu_dropout_dy(xd, w1d, ds, a, p, seed, ew1, eb1, f1)
+        dx = ops.layernorm_bwd(xd, gd, dh, dgam, dbet)
+        ops.wgrad_join(dev)
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_BACKEND["operands"] = prev
+    assert float(keep.mean()) == pytest.approx(1 - p, abs=0.005)
+    # ---- torch, with the rounding points of the packed path
+    N = B * T
+    xm = x.view(D, N)
+    mu, var = xm.mean(0, keepdim=True), xm.var(0, unbiased=False, keepdim=True)
+    xhat = (xm - mu) * torch.rsqrt(var + 1e-5)
+    hn = bf(xhat * gamma[:, None] + beta[:, None])
+    W1, W2 = bf(w1.view(F_, D)), bf(w2.view(D, F_))
+    a_ref = W1 @ hn + b1[:, None]
+    sig = torch.sigmoid(a_ref)
+    s_ref = bf(a_ref * sig * keep / (1 - p))
+    y_ref = W2 @ s_ref + b2[:, None]
+    dyr = bf(dy.view(D, N))
+    ds_ref = W2.t() @ dyr
+    dw2_ref, db2_ref = dyr @ s_ref.t(), dy.view(D, N).sum(1)
+    da_ref = bf(ds_ref * keep / (1 - p) * (sig * (1 + a_ref * (1 - sig))))
+    dh_ref = W1.t() @ da_ref
+    dw1_ref, db1_ref = da_ref @ hn.t(), da_ref.sum(1)
+    dxhat = dh_ref * gamma[:, None]
+    dx_ref = torch.rsqrt(var + 1e-5) * (dxhat - dxhat.mean(0, keepdim=True) - xhat * (dxhat * xhat).mean(0, keepdim=True))
+    dgam_ref, dbet_ref = (dh_ref * xhat).sum(1), dh_ref.sum(1)
+    for name, got, want in (("a", a, a_ref), ("y", y, y_ref), ("ds", ds, ds_ref), ("dh", dh, dh_ref), ("dx", dx, dx_ref), ("dw2", ew2, dw2_ref), ("dw1", ew1, dw1_ref),
+                            ("db2", eb2, db2_ref), ("db1", eb1, db1_ref), ("dgamma", dgam, dgam_ref), ("dbeta", dbet, dbet_ref)):
+        got = got.cpu().reshape(want.shape)
+        l2 = float((got - want).norm() / want.norm())
+        mx = float((got - want).abs().max() / want.abs().max())
+        print(f"fused feed-forward vs torch, {name}: rel L2 {l2:.2e}, max {mx:.2e}")
+        assert l2 <= 1e-3 and mx <= 1e-2, (name, l2, mx)
+
+
 @pytest.mark.parametrize("B,T,C,F_", [(4, 112, 256, 1024), (32, 814, 256, 768), (8, 64, 128, 256)])
 def test_layernorm_written_as_the_packed_input_of_the_dense_layer_behind_it(cuda_device, B, T, C, F_):
     """ops.layernorm_dense_fwd (train/fs2.py: ln_dense, ffn_core): LayerNorm -> pointwise layer with the normalised tensor written

@@ -212,22 +212,23 @@ def test_istft_generator_vs_oracle(cuda_device, name, B, T):
     assert torch.isfinite(got16).all() and err <= BF16_REL_L2_ISTFT
 
 
+_GEN_SWITCHES = ["EVMI_CONV_DMA=0", "EVMI_PAIR_C128=0", "EVMI_BRANCH=0", "EVMI_CONV_PP=1"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["EVMI_CONV_DMA=0", "EVMI_PAIR32=1", "EVMI_PAIR_OVL=1", "EVMI_PAIR_C128=0", "EVMI_BRANCH=0"])
+@pytest.mark.parametrize("switch", _GEN_SWITCHES)
 def test_kernel_variants_behind_switches_match_the_oracle(switch):
     """The library picks its inference kernels once per process: the variants behind the A/B switches (register-staged convolutions,
-    the conv1 / conv2 wave pipeline and the two-workgroup form of the 32-channel pairs, unfused 128-channel pairs) run the oracle
-    comparisons of this file in a child process each, so a switch that is off by default cannot rot."""
-    import os
-    import subprocess
-    import sys
+    unfused 128-channel pairs, pair kernels instead of the whole-branch kernels, the ping-pong convolution) run the oracle
+    comparisons of this file in a child process each (started together, tests/helpers.py), so a switch that is off by default cannot rot."""
+    from helpers import child_pytest_results
 
-    key, val = switch.split("=")
-    env = dict(os.environ, **{key: val})
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k",
-                        "bf16_vs_oracle or committed_fixture or full_size_properties or istft_generator"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    jobs = {}
+    for sw in _GEN_SWITCHES:
+        key, val = sw.split("=")
+        jobs[sw] = ([__file__, "-q", "-x", "-k", "bf16_vs_oracle or committed_fixture or full_size_properties or istft_generator"], {key: val})
+    rc, out = child_pytest_results("generator_switches", jobs, parallel=2, timeout=600)[switch]
+    assert rc == 0, out
 
 
 _BRANCH_CHILD = """

@@ -459,6 +459,31 @@ BENCH_SHAPE_CASES = [
 ]
 
 
+_BENCH_REF: dict = {}
+
+
+def _bench_shape_reference(case, with_exact):
+    """Seeded operands of a bench shape and torch's answers on the rounded operands (and, for the forced-tile runs, on the exact ones: a
+    FORCED tile that cannot stage a shape leaves it to the exact fp32 kernels) -- computed once per shape and process."""
+    name, B, T, cin, cout, k, s, p, d, groups = case[:10]
+    ent = _BENCH_REF.get(name)
+    if ent is None:
+        n_out = (T + 2 * p - d * (k - 1) - 1) // s + 1
+        g = torch.Generator().manual_seed(B * 7 + T + k)
+        x = torch.randn(B, cin, T, generator=g)
+        w = torch.randn(cout, cin // groups, k, generator=g) * (2.0 / (cin // groups * k) ** 0.5)
+        b = torch.randn(cout, generator=g)
+        dy = torch.randn(B, cout, n_out, generator=g)
+        ent = _BENCH_REF[name] = dict(x=x, w=w, b=b, dy=dy, want_y=F.conv1d(_bf(x), _bf(w), b, s, p, d, groups),
+                                      want_dx=torch.nn.grad.conv1d_input(x.shape, _bf(w), _bf(dy), s, p, d, groups),
+                                      want_dw=torch.nn.grad.conv1d_weight(_bf(x), w.shape, _bf(dy), s, p, d, groups), exact=None)
+    if with_exact and ent["exact"] is None:
+        x, w, b, dy = ent["x"], ent["w"], ent["b"], ent["dy"]
+        ent["exact"] = (F.conv1d(x, w, b, s, p, d, groups), torch.nn.grad.conv1d_input(x.shape, w, dy, s, p, d, groups),
+                        torch.nn.grad.conv1d_weight(x, w.shape, dy, s, p, d, groups))
+    return ent["x"], ent["w"], ent["b"], ent["dy"], ent["want_y"], ent["want_dx"], ent["want_dw"], ent["exact"] if with_exact else (None, None, None)
+
+
 @pytest.mark.parametrize("case", BENCH_SHAPE_CASES, ids=[c[0] for c in BENCH_SHAPE_CASES])
 def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
     """Forward, input gradient and weight gradient of the packed bf16 kernels at the layer shapes bench.py's training legs run
@@ -474,26 +499,16 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
     name, B, T, cin, cout, k, s, p, d, groups, tile_f, tile_d, taps_w = case
     lib = _lib.load()
     n_out = (T + 2 * p - d * (k - 1) - 1) // s + 1
-    if not any(os.environ.get(v) for v in ("EVMI_PK_TILE", "EVMI_PK_SPLITK", "EVMI_PK_WIDE", "EVMI_PK_WIDE2", "EVMI_PK_ADIR", "EVMI_PK_XCD_HB")):
+    if not any(os.environ.get(v) for v in ("EVMI_PK_TILE", "EVMI_PK_SPLITK", "EVMI_PK_WIDE", "EVMI_PK_ADIR", "EVMI_PK_XCD_HB")):
         geo = (B, cin, T, cout, n_out, k, s, p, d, groups)
         assert lib.evmi_conv1d_cbt_bf16pk_plan(*geo) % 16 == tile_f, name
         assert lib.evmi_conv1d_dgrad_cbt_bf16pk_plan(*geo) % 16 == tile_d, name
         assert lib.evmi_conv1d_wgrad_cbt_bf16pk_plan(*geo) % 16 == taps_w, name
-    g = torch.Generator().manual_seed(B * 7 + T + k)
-    x = torch.randn(B, cin, T, generator=g)
-    w = torch.randn(cout, cin // groups, k, generator=g) * (2.0 / (cin // groups * k) ** 0.5)
-    b = torch.randn(cout, generator=g)
-    dy = torch.randn(B, cout, n_out, generator=g)
+    forced = bool(os.environ.get("EVMI_PK_TILE"))
+    x, w, b, dy, want_y, want_dx, want_dw, exact = _bench_shape_reference(case, forced)
     xd, wd, dyd = cbt(x).to(cuda_device), w.to(cuda_device), cbt(dy).to(cuda_device)
     y = bct(ops.conv1d_fwd(xd, wd, b.to(cuda_device), s, p, d, groups).cpu())
     dx, dw, _ = ops.conv1d_bwd(xd, wd, dyd, s, p, d, groups)
-    want_y = F.conv1d(_bf(x), _bf(w), b, s, p, d, groups)
-    want_dx = torch.nn.grad.conv1d_input(x.shape, _bf(w), _bf(dy), s, p, d, groups)
-    want_dw = torch.nn.grad.conv1d_weight(_bf(x), w.shape, _bf(dy), s, p, d, groups)
-    # a FORCED tile that cannot stage a shape leaves it to the exact fp32 kernels: then the unrounded operands are the oracle
-    forced = bool(os.environ.get("EVMI_PK_TILE"))
-    exact = ((F.conv1d(x, w, b, s, p, d, groups), torch.nn.grad.conv1d_input(x.shape, w, dy, s, p, d, groups),
-              torch.nn.grad.conv1d_weight(x, w.shape, dy, s, p, d, groups)) if forced else (None, None, None))
     for got, want, want_exact, what in ((y, want_y, exact[0], "forward"), (bct(dx.cpu()), want_dx, exact[1], "input gradient"),
                                         (dw.cpu(), want_dw, exact[2], "weight gradient")):
         err = float((got - want).abs().max() / want.abs().max())
@@ -502,40 +517,42 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
         assert err <= 1e-4, (name, what, err)  # fp32 accumulation of exact bf16 products: summation order only
 
 
+_PK_CHILD_TESTS = "bf16_packed_kernels_at_bench_shapes or bf16_packed_kernels_edge_shapes"
+_PK_SWITCHES = ["EVMI_PK_SPLITK=0", "EVMI_PK_WIDE=1", "EVMI_WG_SPLITS=1", "EVMI_WG_NST=2", "EVMI_PK_ADIR=0", "EVMI_PK_XCD_HB=1"]
+
+
 @pytest.mark.parametrize("tile", range(11))
-def test_packed_conv_every_tile_forced(tile):
+def test_packed_conv_every_tile_forced(cuda_device, bf16_operands, monkeypatch, tile):
     """conv_pk_kernel<128,128 | 64,128 | 64,64 | 32,128 | 64,256 | 32,256 | 128,256>, the eight-wave <128,256> / <128,128> (indices 7, 8) and
-    <128,128> with the weight fragments in registers (index 9), <32,512> (index 10):
-    the planner picks one per shape; here every one
-    of them is FORCED (EVMI_PK_TILE, read once per process -> a child process each) through the bf16 comparisons with torch of
-    this file -- the bench shapes, the edge shapes and the strided / grouped input-gradient shapes -- so a tile the planner starts choosing tomorrow (as <128, 256>
-    was switched on at the end of round 2) has already met the oracle.  Shapes a forced tile cannot stage fall back to the exact
-    fp32 kernels, which the comparisons accept (closest of the two oracles) or the test's own tolerance covers."""
-    import os
-    import subprocess
-    import sys
+    <128,128> with the weight fragments in registers (index 9), <32,512> (index 10): the planner picks one per shape; here every one
+    of them is FORCED through the bf16 comparisons with torch of this file -- the bench shapes, the edge shapes and the strided /
+    grouped input-gradient shapes -- so a tile the planner starts choosing tomorrow (as <128, 256> was switched on at the end of
+    round 2) has already met the oracle.  EVMI_PK_TILE is read at every planning call (csrc/conv_cbt_bf16_pk.hip), so the tiles are
+    forced in THIS process (round 4 started a child process per tile: 220 s of the GPU suite, most of it torch's reference
+    convolutions recomputed eleven times -- they are cached per shape now).  Shapes a forced tile cannot stage fall back to the exact
+    fp32 kernels, which the comparisons accept (closest of the two oracles)."""
+    monkeypatch.setenv("EVMI_PK_TILE", str(tile))
+    for case in BENCH_SHAPE_CASES:
+        test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case)
+    for case in BF16_EDGE_CASES:
+        test_bf16_packed_kernels_edge_shapes(cuda_device, bf16_operands, case)
+    for case in DGRAD_CASES:
+        test_conv1d_bf16_operands_dgrad(cuda_device, bf16_operands, case)
 
-    env = dict(os.environ, EVMI_PK_TILE=str(tile))
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k",
-                        "bf16_packed_kernels_at_bench_shapes or bf16_packed_kernels_edge_shapes or conv1d_bf16_operands_dgrad"],
-                       env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
-
-@pytest.mark.parametrize("switch", ["EVMI_PK_SPLITK=0", "EVMI_PK_WIDE=1", "EVMI_PK_WIDE2=2", "EVMI_WG_SPLITS=1", "EVMI_WG_NST=2", "EVMI_PK_ADIR=0", "EVMI_PK_XCD_HB=1"])
+@pytest.mark.parametrize("switch", _PK_SWITCHES)
 def test_packed_conv_planner_switches(switch):
     """The planner's other A/B switches (no split-K, 256-column tiles for narrow layers, unsplit / two-slot weight gradients, weight
-    fragments through the LDS everywhere, the plain m-tile-major XCD order)
-    through the same comparisons in a child process each."""
-    import os
-    import subprocess
-    import sys
+    fragments through the LDS everywhere, the plain m-tile-major XCD order) are read ONCE per process:
+    the same comparisons in a child process each."""
+    from helpers import child_pytest_results
 
-    key, val = switch.split("=")
-    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k",
-                        "bf16_packed_kernels_at_bench_shapes or bf16_packed_kernels_edge_shapes or conv1d_wgrad_bf16_packed"],
-                       env=dict(os.environ, **{key: val}), capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    jobs = {}
+    for sw in _PK_SWITCHES:
+        key, val = sw.split("=")
+        jobs[sw] = ([__file__, "-q", "-x", "-k", _PK_CHILD_TESTS + " or conv1d_wgrad_bf16_packed"], {key: val})
+    rc, out = child_pytest_results("train_ops_pk", jobs, parallel=3, timeout=600)[switch]
+    assert rc == 0, out
 
 
 def test_conv_kernels_edge_shapes(cuda_device):
