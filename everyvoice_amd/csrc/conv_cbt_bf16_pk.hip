@@ -66,6 +66,11 @@ struct ConvPkArgs {
   const float* out_mask;
   float out_mask_slope;
   const float* res;
+  // ... and, with drop_p > 0, v is multiplied by (keep(drop_seed, element index in y) ? drop_fac : 0) in front of `+ res`:
+  // y = res + s * dropout(act(conv + bias), p) with drop_fac = s / (1 - p) -- the residual add + dropout behind a Conformer
+  // sub-layer's last dense layer in its epilogue (the mask stream of evmi_dropout_fused_f32: same seed, same element index)
+  float drop_p, drop_fac;
+  SeedArg drop_seed;
   // Flat packed output (the discriminator chains, csrc/disc_chain.hip): po.y != nullptr -- the tile is written as 16-byte units of
   // 8 bf16 channels into a packed tensor [channel octet][unit] (rows `plane` units apart), the layout the next layer's loads read.
   // Column n of phase ph is unit w = n * out_stride + ph_off[ph] of the COMPUTE geometry: items Tc units apart, of which the first
@@ -575,6 +580,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
 #pragma unroll
             for (int e = 0; e < EB; ++e) add[e] = a.res[off[e]];
           }
+          if (a.drop_p > 0.f) {
+            const unsigned long long dseed = a.drop_seed.get();
+#pragma unroll
+            for (int e = 0; e < EB; ++e) fac[e] *= uniform01(dseed, (unsigned long long)off[e]) >= a.drop_p ? a.drop_fac : 0.f;
+          }
           if (a.accumulate) {
 #pragma unroll
             for (int e = 0; e < EB; ++e) old[e] = a.y[off[e]];
@@ -604,7 +614,8 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_kernel(ConvPkArgs a) {
   const long long bb = n / n_out;
   const int to = (int)(n - bb * n_out);
   float* dst = a.y + ((long long)co * a.B + bb) * a.t_out_total + (long long)to * a.out_stride + a.ph_off[ph];
-  const float fac = a.out_mask ? (a.out_mask[dst - a.y] > 0.f ? 1.f : a.out_mask_slope) : 1.f;
+  float fac = a.out_mask ? (a.out_mask[dst - a.y] > 0.f ? 1.f : a.out_mask_slope) : 1.f;
+  if (a.drop_p > 0.f) fac *= uniform01(a.drop_seed.get(), (unsigned long long)(dst - a.y)) >= a.drop_p ? a.drop_fac : 0.f;
   const float add = a.res ? a.res[dst - a.y] : -0.f;
   const float old = a.accumulate ? *dst : -0.f;
   *dst = pk_tail(v, fac, add, old);
@@ -938,7 +949,8 @@ struct PkInputFusion {  // what the pack applies to the input on its way in (see
   float pre_slope = 1.f;
   const float* mask = nullptr;
   float mask_slope = 1.f;
-  int fuse = 0;  // 1: dropout(silu(x)); 2: dropout(x) * silu'(aux)
+  int fuse = 0;  // 1: dropout(silu(x)); 2: dropout(x) * silu'(aux); 3: fuse_scale * dropout(x)
+  float fuse_scale = 1.f;
   const float* aux = nullptr;
   float p_drop = 0.f;
   SeedArg seed = SeedArg{0ull, nullptr};
@@ -998,7 +1010,7 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   PackArgs pa = make_pack_args(x, xp, pl.cin_g, a.octs, a.B, pl.t_in, a.Tp, pl.PL,
                                (int)(pl.xp_units - (long long)pl.groups * a.octs * a.B * a.Tp), pl.groups);
   pa.pre_slope = in.pre_slope; pa.mask = in.mask; pa.mask_slope = in.mask_slope;
-  pa.fuse = in.fuse; pa.aux = in.aux; pa.p_drop = in.p_drop; pa.seed = in.seed;
+  pa.fuse = in.fuse; pa.fuse_scale = in.fuse_scale; pa.aux = in.aux; pa.p_drop = in.p_drop; pa.seed = in.seed;
   WfragArgs fa;
   fa.w = w; fa.wf = reinterpret_cast<unsigned*>(wf); fa.rows_g = rows_g; fa.kch_g = kch_g; fa.kt = a.k; fa.MB = a.mblocks; fa.octs = a.octs;
   fa.kblocks = a.kblocks; fa.mode = wmode; fa.k_full = k_full; fa.stride = stride_full; fa.phase_stride_words = a.wf_phase_stride * 4;
@@ -1380,6 +1392,56 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout(int stage, const float* ds_
   PkInputFusion in;
   in.fuse = 2; in.aux = pre_dev; in.p_drop = p; in.seed = SeedArg{seed_value, seed_base_dev};
   return launch_pk(a, pl, ds_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream, in, stage);
+}
+
+/* A Conformer sub-layer's LAST pointwise layer with the residual add and the dropout behind it in the epilogue, and the matching pack
+ * of the backward (the FastSpeech2 step's residual_dropout sites: feed-forward blocks, attention out_proj, convolution module):
+ *   _resdrop:        y = residual + out_scale * dropout(conv(in) + bias, out_p)       (k = 1, stride 1, one group)
+ *                    in_mode 0: in = x;  1: in = dropout(silu(x), in_p) (the feed-forward middle, as _silu_dropout);  2: the packed
+ *                    input already sits at the head of ws (as _prepacked; x is not read)
+ *   _staged_dropout: evmi_conv1d_dgrad_cbt_bf16pk_staged on dz = scale * dropout(dy, p): stage 1 packs THAT (what the layer's input
+ *                    gradient, weight gradient and bias gradient read); stage 2 as usual
+ * Mask streams and arithmetic of evmi_dropout_fused_f32 modes 1 / 2 / 4 (seed + *seed_base_dev; element index = index in the tensor). */
+int evmi_conv1d_cbt_bf16pk_resdrop(int in_mode, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
+                                   float* y_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in, int c_out, float in_p,
+                                   unsigned long long in_seed, float out_p, unsigned long long out_seed, float out_scale,
+                                   const unsigned long long* seed_base_dev, void* stream) {
+  if (!w_dev || !y_dev || !residual_dev || (in_mode != 2 && !x_dev)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_resdrop: null pointer");
+  if (in_mode < 0 || in_mode > 2) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_resdrop: in_mode 0, 1 or 2");
+  if (in_p < 0.f || in_p >= 1.f || out_p < 0.f || out_p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_resdrop: p outside [0, 1)");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_fwd_pk(a, pl, B, c_in, t_in, c_out, t_in, t_in, 1, 1, 0, 1, 1, 1, 0))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk_resdrop: ") + why);
+  a.bias = bias_dev; a.y = y_dev; a.accumulate = 0; a.act = 0; a.act_param = 0.f; a.res = residual_dev;
+  a.drop_p = out_p; a.drop_fac = out_scale / (1.f - out_p); a.drop_seed = SeedArg{out_seed, seed_base_dev};
+  if (out_p == 0.f) {  // no mask: the scale alone goes through the same factor (a.drop_p > 0 gates the hash)
+    if (out_scale != 1.f) return fail(EVMI_ERR_UNSUPPORTED, "conv1d_cbt_bf16pk_resdrop: a scale needs out_p > 0");
+  }
+  PkInputFusion in;
+  if (in_mode == 1) {
+    in.fuse = 1; in.p_drop = in_p; in.seed = SeedArg{in_seed, seed_base_dev};
+  }
+  if (in_mode == 2)
+    return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 2);
+  return launch_pk(a, pl, x_dev, w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, in);
+}
+
+int evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(int stage, const float* dy_dev, float p, unsigned long long seed_value,
+                                                const unsigned long long* seed_base_dev, float scale, const float* w_dev, float* dx_dev,
+                                                float* ws_dev, long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k,
+                                                int stride, int pad, int dil, int groups, void* stream) {
+  if (stage != 1 && stage != 2) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged_dropout: stage 1 or 2");
+  if (!dy_dev || !w_dev || !dx_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged_dropout: null pointer");
+  if (p <= 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged_dropout: p outside (0, 1)");
+  ConvPkArgs a = {};
+  PkPlan pl;
+  if (const char* why = plan_dgrad_pk(a, pl, B, c_in, t_in, c_out, t_out, k, stride, pad, dil, groups))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk_staged_dropout: ") + why);
+  a.y = dx_dev;
+  PkInputFusion in;
+  in.fuse = 3; in.fuse_scale = scale; in.p_drop = p; in.seed = SeedArg{seed_value, seed_base_dev};
+  return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream, in, stage);
 }
 
 /* Input gradient with the fusions of a backward pass: dy is multiplied by (dy_mask > 0 ? 1 : dy_mask_slope) while it is packed

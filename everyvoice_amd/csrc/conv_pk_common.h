@@ -54,7 +54,9 @@ struct PackArgs {
   // arithmetic and the mask stream of evmi_dropout_fused_f32: element index = the element's index in x):
   //   fuse 1: x -> dropout(silu(x), p_drop)            (the forward of the second layer: its input)
   //   fuse 2: x -> dropout(x, p_drop) * silu'(aux)     (the backward of the first layer: its output gradient; aux = its pre-activation output)
+  //   fuse 3: x -> fuse_scale * dropout(x, p_drop)     (the backward of a + s * dropout(dense(h)): the gradient the dense layer sees)
   int fuse;
+  float fuse_scale;
   const float* aux;
   float p_drop;
   SeedArg seed;
@@ -115,6 +117,7 @@ __device__ __forceinline__ void pack_x_block(const PackArgs& p, int bx, int b, i
         if (p.fuse == 1) val = silu_value(val);
         float d = keep ? val / inv_keep : 0.f;
         if (p.fuse == 2) d = d * silu_grad(z[i]);
+        if (p.fuse == 3) d = p.fuse_scale * d;
         v[i] = i < nch ? d : 0.f;
       }
     }
@@ -144,7 +147,7 @@ static inline PackArgs make_pack_args(const float* x, uint4* xp, int cin_g, int 
   p.x = x; p.xp = xp; p.cin_g = cin_g; p.octs = octs; p.B = B; p.t_in = t_in; p.Tp = Tp; p.PL = PL; p.slack_units = slack_units;
   p.gx = (Tp + 255) / 256; p.gy = B; p.gz = groups * octs;
   p.pre_slope = 1.f; p.mask = nullptr; p.mask_slope = 1.f;
-  p.fuse = 0; p.aux = nullptr; p.p_drop = 0.f; p.seed = SeedArg{0ull, nullptr};
+  p.fuse = 0; p.fuse_scale = 1.f; p.aux = nullptr; p.p_drop = 0.f; p.seed = SeedArg{0ull, nullptr};
   return p;
 }
 // decode a flat block index into the logical 3-D grid of a pack (x fastest)

@@ -286,6 +286,30 @@ def residual_dropout(tape: Tape, a: Var, b: Var, p: float, seed: int, sb: float 
     return y
 
 
+def dense_residual_dropout(tape: Tape, a: Var, h: Var, layer, p: float, seed: int, sb: float = 1.0) -> Var:
+    """a + sb * dropout(dense(h), p) as ONE tape operator.  On the packed bf16 kernels the residual add and the mask sit in the
+    layer's epilogue (ops.conv1d_fwd_resdrop) and, in the backward, sb * dropout(dy) is formed while dy is packed for the layer's
+    three products (ops.conv1d_bwd_dropout_dy): per site one elementwise launch and one fp32 tensor write + read less in each
+    direction (32 sites per FastSpeech2 step).  Elsewhere: the two operators it stands for."""
+    C, B, T = h.data.shape
+    if p <= 0.0 or _EVAL[0] or layer.k != 1 or not ops.resdrop_fused_supported(B, T, C, layer.cout):
+        return residual_dropout(tape, a, dense(tape, h, layer), p, seed, sb)
+    w, dw_sink = layer.effective(True)
+    packed = {}
+    y = Var(ops.conv1d_fwd_resdrop(h.data, w, layer.bias_data(), a.data, p, seed, sb, packed))
+
+    def bwd():
+        if y.grad is None:
+            return
+        dh = ops.conv1d_bwd_dropout_dy(h.data, w, y.grad, p, seed, sb, dw_sink, layer.db_sink(), packed)
+        packed.clear()
+        h.accumulate(dh)
+        a.accumulate(y.grad)
+
+    tape.record(bwd)
+    return y
+
+
 def silu_dropout(tape: Tape, x: Var, p: float, seed: int) -> Var:
     """dropout(silu(x), p) in one pass; backward dropout(dy) * silu'(x) in one pass."""
     if p <= 0.0:
@@ -319,15 +343,18 @@ def ln_dense(tape: Tape, x: Var, ln: Affine, layer) -> Var:
     return y
 
 
-def ffn_core(tape: Tape, x: Var, ln: Affine, l1, l2, p: float, seed: int) -> Var:
+def ffn_core(tape: Tape, x: Var, ln: Affine, l1, l2, p: float, seed: int, res: Var | None = None, seed_out: int = 0, sb: float = 1.0) -> Var:
     """dense2(dropout(silu(dense1(LayerNorm(x))), p)): a Conformer feed-forward block up to its residual add as ONE tape operator.  On the
     packed bf16 kernels LayerNorm writes the first layer's packed input, the activation and the mask are applied while the second
     layer's input is packed, and in the backward while the first layer's output gradient is packed: neither the normalised tensor nor
     dropout(silu(a)) nor its gradient is stored in fp32 (per direction two elementwise passes over the block's widest tensor and one
-    fp32 copy of it less).  Elsewhere: the four operators it stands for."""
+    fp32 copy of it less).  Elsewhere: the four operators it stands for.
+    ``res``: the block's residual input -- the operator then returns res + sb * dropout(that, p) with the add and the mask (seed_out) in
+    the second layer's epilogue and sb * dropout(dy) formed while dy is packed (dense_residual_dropout's fusion)."""
     C, B, T = x.data.shape
     if p <= 0.0 or _EVAL[0] or not ops.ffn_fused_supported(B, T, l1.cout, l2.cout):
-        return dense(tape, silu_dropout(tape, ln_dense(tape, x, ln, l1), p, seed), l2)
+        h = dense(tape, silu_dropout(tape, ln_dense(tape, x, ln, l1), p, seed), l2)
+        return h if res is None else residual_dropout(tape, res, h, p, seed_out, sb)
     w1, dw1 = l1.effective(True)
     w2, dw2 = l2.effective(True)
     packed1, packed2 = {}, {}
@@ -338,15 +365,22 @@ def ffn_core(tape: Tape, x: Var, ln: Affine, l1, l2, p: float, seed: int) -> Var
     else:
         h = layernorm(tape, x, ln)
         a = ops.conv1d_fwd(h.data, w1, l1.bias_data(), 1, l1.pad, 1, 1, keep=packed1)
-    y = Var(ops.conv1d_fwd_silu_dropout(a, w2, l2.bias_data(), p, seed, packed2))
+    fuse_out = res is not None and ops.resdrop_fused_supported(B, T, l1.cout, l2.cout)
+    if fuse_out:
+        y = Var(ops.conv1d_fwd_resdrop(a, w2, l2.bias_data(), res.data, p, seed_out, sb, packed2, in_p=p, in_seed=seed))
+    else:
+        y = Var(ops.conv1d_fwd_silu_dropout(a, w2, l2.bias_data(), p, seed, packed2))
     _ACTIVATION_ELEMS[0] += a.numel()  # (the pre-activation: the tensor the separate operators count as dense1's output)
 
     def bwd():
         if y.grad is None:
             return
         # second layer: its packed input is the forward's (a stands in for the fp32 tensor that was never stored: only its shape is read)
-        ds, _, _ = ops.conv1d_bwd(a, w2, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw2, db_out=l2.db_sink(), accumulate=True, packed=packed2,
-                                   x_standin=True)
+        if fuse_out:
+            ds = ops.conv1d_bwd_dropout_dy(a, w2, y.grad, p, seed_out, sb, dw2, l2.db_sink(), packed2, x_standin=True)
+        else:
+            ds, _, _ = ops.conv1d_bwd(a, w2, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw2, db_out=l2.db_sink(), accumulate=True, packed=packed2,
+                                       x_standin=True)
         packed2.clear()
         # first layer: x.data / h.data only lend their shape (the weight gradient reads the packed copy)
         dh = ops.conv1d_bwd_silu_dropout_dy(x.data if ln_fused else h.data, w1, ds, a, p, seed, dw1, l1.db_sink(), packed1)
@@ -355,9 +389,11 @@ def ffn_core(tape: Tape, x: Var, ln: Affine, l1, l2, p: float, seed: int) -> Var
             x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh, ln.dgamma(), ln.dbeta()))
         else:
             h.accumulate(dh)
+        if fuse_out:
+            res.accumulate(y.grad)
 
     tape.record(bwd)
-    return y
+    return y if (res is None or fuse_out) else residual_dropout(tape, res, y, p, seed_out, sb)
 
 
 def residual(tape: Tape, a: Var, b: Var, sb: float = 1.0) -> Var:
@@ -437,18 +473,18 @@ class _ConformerT:
             x = self._ffn_fwd(tape, x, L["ffn1"], p, seeds)
             h = ln_dense(tape, x, L["attn_ln"], L["in_proj"])
             h = attention(tape, h, lens32, self.cfg.heads, p, seeds(self.cfg.heads))
-            x = residual_dropout(tape, x, dense(tape, h, L["out_proj"]), p, seeds())
+            x = dense_residual_dropout(tape, x, h, L["out_proj"], p, seeds())
             h = glu(tape, ln_dense(tape, x, L["conv_ln"], L["pw1"]))
             h = batchnorm(tape, dwconv(tape, h, L["dw"]), L["bn"], ops.ACT_SILU)
-            x = residual_dropout(tape, x, dense(tape, h, L["pw2"]), p, seeds())
+            x = dense_residual_dropout(tape, x, h, L["pw2"], p, seeds())
             x = self._ffn_fwd(tape, x, L["ffn2"], p, seeds)
             x = layernorm(tape, x, L["final_ln"])
         return x
 
     @staticmethod
     def _ffn_fwd(tape, x, F, p, seeds):
-        h = ffn_core(tape, x, F["ln"], F["l1"], F["l2"], p, seeds())
-        return residual_dropout(tape, x, h, p, seeds(), 0.5)
+        s1, s2 = seeds(), seeds()  # (the order of the separate operators: the block's inner mask, then the residual's)
+        return ffn_core(tape, x, F["ln"], F["l1"], F["l2"], p, s1, res=x, seed_out=s2, sb=0.5)
 
 
 class _VariancePredictorT:

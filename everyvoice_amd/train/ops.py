@@ -764,6 +764,79 @@ def conv1d_bwd_silu_dropout_dy(x, w, ds, pre, p, seed, dw_out, db_out, packed):
     return dx
 
 
+# ---- a + s * dropout(dense(h)): the residual add and the dropout in the layer's epilogue, their backward in the pack of dy ---------------
+RESDROP_FUSION = [_os.environ.get("EVMI_FS2_RESDROP", "1") != "0"]  # A/B switch of the fusion below (tools/fs2_train_bench.py)
+
+
+def resdrop_fused_supported(B, t, c_in, c_out) -> bool:
+    """True where a pointwise layer c_in -> c_out runs on the packed bf16 kernels with shared packed operands in all three products
+    (the FastSpeech2 sub-layers' last dense layers at precision="bf16")."""
+    if not RESDROP_FUSION[0] or not (_packed() and CONV_BACKEND["fwd"] == "mfma" and CONV_BACKEND["dgrad"] == "mfma" and CONV_BACKEND["wgrad"] != "gemm"):
+        return False
+    lib = _lib.load()
+    geo = (t, 1, 1, 0, 1, 1)
+    return bool(shares_packed(B, t, 1, 1, 0, 1, 1)
+                and lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, c_in, t, c_out, *geo) > 0
+                and lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, c_in, t, c_out, *geo) > 0
+                and lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, c_in, t, c_out, *geo) > 0
+                and dgrad_mfma_supported(B, c_in, t, c_out, t, 1, 1, 1, 1))
+
+
+def conv1d_fwd_resdrop(x, w, bias, res, p, seed, scale, keep, in_p=None, in_seed=0):
+    """res + scale * dropout(dense(in) + bias, p) in ONE launch pair (pack + convolution): in = x, or dropout(silu(x), in_p) when
+    ``in_p`` is given (the second layer of a feed-forward block: conv1d_fwd_silu_dropout's input fusion).  The packed input stays in
+    ``keep["x_packed"]`` for the weight gradient.  Caller: resdrop_fused_supported (and ffn_fused_supported for the input fusion)."""
+    cin, B, t = x.shape
+    cout = w.shape[0]
+    lib = _lib.load()
+    pk_elems = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t, cout, t, 1, 1, 0, 1, 1)
+    ws = keep["x_packed"] = torch.empty(pk_elems, device=x.device, dtype=torch.float32)
+    out = torch.empty(cout, B, t, device=x.device, dtype=torch.float32)
+    _count_conv(B, t, cout, cin, 1)
+    _chk(lib.evmi_conv1d_cbt_bf16pk_resdrop(0 if in_p is None else 1, x.data_ptr(), w.data_ptr(), _lib.ptr(bias), res.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                            pk_elems, B, cin, t, cout, float(in_p or 0.0), int(in_seed), float(p), int(seed), float(scale),
+                                            _lib.ptr(SEED_BASE[0]), _s(x)), "evmi_conv1d_cbt_bf16pk_resdrop")
+    return out
+
+
+def conv1d_bwd_dropout_dy(x, w, dy, p, seed, scale, dw_out, db_out, packed, x_standin=False):
+    """Backward of a pointwise layer z = w x + b behind which sits y = a + scale * dropout(z, p): the layer's output gradient
+    dz = scale * dropout(dy, p) is formed while dy is packed -- it exists only as the packed bf16 operand that the input gradient, the
+    weight gradient and the bias gradient (row sums of the packed rows) read.  Returns dx; dw_out / db_out are accumulated into.
+    ``packed``: the forward's ``keep`` dict (x_packed)."""
+    cin, B, t = x.shape
+    cout = w.shape[0]
+    lib = _lib.load()
+    pk_elems = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t, cout, t, 1, 1, 0, 1, 1)
+    ws = torch.empty(pk_elems, device=dy.device, dtype=torch.float32)
+    dx = torch.empty(cin, B, t, device=dy.device, dtype=torch.float32)
+    args = (dy.data_ptr(), float(p), int(seed), _lib.ptr(SEED_BASE[0]), float(scale), w.data_ptr(), dx.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t, cout, t,
+            1, 1, 0, 1, 1)
+    _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(1, *args, _s(dy)), "evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout")
+    xp = packed.get("x_packed") if packed else None
+    if xp is None:
+        raise RuntimeError("conv1d_bwd_dropout_dy: the forward's packed input is required")
+    side = side_wgrad(x, dy, dw_out, db_out, ws, xp).mark()  # fork behind the pack, in front of the input gradient
+    _count_conv(B, t, cout, cin, 1)
+    _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(2, *args, _s(dy)), "evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout")
+
+    def launch():
+        n_w = lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, cin, t, cout, t, 1, 1, 0, 1, 1)
+        wsw = WS.get("pkw", n_w, x.device)
+        _count_conv(B, t, cout, cin, 1)
+        _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk_prepacked(x.data_ptr(), _lib.ptr(xp), dy.data_ptr(), ws.data_ptr(), dw_out.data_ptr(), wsw.data_ptr(), n_w, B, cin, t,
+                                                        cout, t, 1, 1, 0, 1, 1, 1, _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk_prepacked")
+        if db_out is not None:  # row sums of the packed dz: [cout / 8 octet rows][B * t units]
+            job = (_lib.PkFlatRows * 1)()
+            job[0].dy, job[0].plane, job[0].units, job[0].C, job[0].db = ws.data_ptr(), B * t, B * t, cout, db_out.data_ptr()
+            n_r = lib.evmi_pkflat_rowsum_ws_elems(1, job)
+            wsr = WS.get("pkrow", n_r, x.device)
+            _chk(lib.evmi_pkflat_rowsum(1, job, wsr.data_ptr(), n_r, _s(x)), "evmi_pkflat_rowsum")
+
+    side.run(launch)
+    return dx
+
+
 def _convt_via_dgrad():
     import os
     if CONV_BACKEND["dgrad"] != "mfma":

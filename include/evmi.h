@@ -311,6 +311,21 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout(int stage, const float* ds_
                                                      const unsigned long long* seed_base_dev, const float* w_dev, float* dx_dev, float* ws_dev,
                                                      long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k, int stride,
                                                      int pad, int dil, int groups, void* stream);
+/* A Conformer sub-layer's last pointwise layer with the residual add + dropout behind it in the epilogue (the reference:
+ * torchaudio-style Conformer sub-layers `x + dropout(sublayer(x))`, FastSpeech2_lightning -- absent submodule), and the
+ * matching pack of the backward:
+ *   evmi_conv1d_cbt_bf16pk_resdrop:              y = residual + out_scale * dropout(conv(in) + bias, out_p); in_mode 0: in = x, 1: in =
+ *                                                dropout(silu(x), in_p), 2: packed input already at the head of ws (x not read)
+ *   evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout: evmi_conv1d_dgrad_cbt_bf16pk_staged on dz = scale * dropout(dy, p) (stage 1 packs it)
+ * Mask streams of evmi_dropout_fused_f32 (seed + *seed_base_dev, element index = index in the tensor). */
+int evmi_conv1d_cbt_bf16pk_resdrop(int in_mode, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
+                                   float* y_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in, int c_out, float in_p,
+                                   unsigned long long in_seed, float out_p, unsigned long long out_seed, float out_scale,
+                                   const unsigned long long* seed_base_dev, void* stream);
+int evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(int stage, const float* dy_dev, float p, unsigned long long seed_value,
+                                                const unsigned long long* seed_base_dev, float scale, const float* w_dev, float* dx_dev,
+                                                float* ws_dev, long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k,
+                                                int stride, int pad, int dil, int groups, void* stream);
 /* LayerNorm in front of a pointwise layer written as that layer's packed input, and the layer on an input already packed in the head
  * of ws (the Conformer's LayerNorm -> Linear pairs; layers of evmi_conv1d_bf16pk_shares_packed, 128 or 256 input channels): the
  * normalised tensor is never stored in fp32.  ws: evmi_conv1d_cbt_bf16pk_ws_elems floats of the layer (k = 1, stride 1, no padding). */

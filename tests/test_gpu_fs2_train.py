@@ -644,6 +644,52 @@ def test_feed_forward_middle_fused_into_the_packs_equals_the_separate_passes(cud
         assert rel(got, want) <= tol, (name, rel(got, want))
 
 
+@pytest.mark.parametrize("B,T,cin,cout,sb", [(32, 814, 256, 256, 1.0), (4, 112, 1024, 256, 0.5)])
+def test_residual_add_and_dropout_in_the_dense_layers_epilogue_equal_the_separate_passes(cuda_device, B, T, cin, cout, sb):
+    """ops.conv1d_fwd_resdrop / conv1d_bwd_dropout_dy (train/fs2.py: dense_residual_dropout, ffn_core with a residual): a + sb *
+    dropout(dense(h)) with the add and the mask in the layer's epilogue, and sb * dropout(dy) formed while dy is packed, against
+    dense -> evmi_dropout_fused_f32 (modes 1 / 4) -> the layer's backward on the same seed.  The same values are rounded to bf16 either
+    way: outputs and the three gradients agree to rounding of one fused scale (2e-6); the bias gradient is summed from the ROUNDED
+    gradient in the fused form (2e-3).  Also against torch with the exported mask: y = a + sb * keep / (1 - p) * (W bf16(h) + b)."""
+    from everyvoice_amd.train import ops
+
+    p, seed = 0.2, 977
+    g = torch.Generator().manual_seed(B + T + cin)
+    h = torch.randn(cin, B, T, generator=g).to(cuda_device)
+    a = torch.randn(cout, B, T, generator=g).to(cuda_device)
+    w = (torch.randn(cout, cin, 1, generator=g) * cin ** -0.5).to(cuda_device)
+    b = (torch.randn(cout, generator=g) * 0.1).to(cuda_device)
+    dy = torch.randn(cout, B, T, generator=g).to(cuda_device)
+    prev = ops.CONV_BACKEND["operands"]
+    ops.CONV_BACKEND["operands"] = "bf16"
+    try:
+        assert ops.resdrop_fused_supported(B, T, cin, cout)
+        k1, k2 = {}, {}
+        z = ops.conv1d_fwd(h, w, b, 1, 0, 1, 1, keep=k1)
+        y = ops.dropout_fused(1, z, a, p, seed, sb)
+        dz = ops.dropout_fused(4, dy, None, p, seed, sb)
+        dw, db, ew, eb = torch.zeros_like(w), torch.zeros_like(b), torch.zeros_like(w), torch.zeros_like(b)
+        dh, _, _ = ops.conv1d_bwd(h, w, dz, 1, 0, 1, 1, need_dx=True, dw_out=dw, db_out=db, accumulate=True, packed=k1)
+        y_f = ops.conv1d_fwd_resdrop(h, w, b, a, p, seed, sb, k2)
+        dh_f = ops.conv1d_bwd_dropout_dy(h, w, dy, p, seed, sb, ew, eb, k2)
+        keep = (ops.dropout(torch.ones(cout * B * T, device=cuda_device), p, seed) > 0).float().view(cout, B * T).cpu()
+        ops.wgrad_join(cuda_device)
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_BACKEND["operands"] = prev
+    rel = lambda got, want: float((got - want).abs().max() / want.abs().max())  # noqa: E731
+    for name, got, want, tol in (("y", y_f, y, 2e-6), ("dh", dh_f, dh, 2e-6), ("dw", ew, dw, 2e-6), ("db", eb, db, 2e-3)):
+        assert rel(got, want) <= tol, (name, rel(got, want))
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    z_ref = bf(w.cpu().view(cout, cin)) @ bf(h.cpu().view(cin, B * T)) + b.cpu()[:, None]
+    y_ref = a.cpu().view(cout, B * T) + sb * keep / (1 - p) * z_ref
+    assert float((y_f.cpu().view(cout, B * T) - y_ref).abs().max() / y_ref.abs().max()) <= 2e-5
+    dz_ref = bf(sb * (keep * dy.cpu().view(cout, B * T) / (1 - p)))
+    dh_ref = bf(w.cpu().view(cout, cin)).t() @ dz_ref
+    # (a gradient within fp32 rounding of a bf16 boundary rounds the other way on one side: 4e-3 of that ONE term of a 256-term sum)
+    assert float((dh_f.cpu().view(cin, B * T) - dh_ref).norm() / dh_ref.norm()) <= 1e-3
+
+
 def test_fused_feed_forward_block_against_torch_with_the_kernels_own_mask(cuda_device):
     """the fused feed-forward block (train/fs2.py: ffn_core = LayerNorm written packed -> dense1 -> SiLU + dropout
     applied while dense2's input is packed -> dense2; backward with dropout(ds) * silu'(a) applied while dense1's output gradient is
