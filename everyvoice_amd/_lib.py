@@ -247,6 +247,9 @@ SYMBOLS = {
     "evmi_loudness_lkfs_f32": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "evmi_loudness_scratch_elems": (C.c_longlong, [C.c_int] * 4),
     "evmi_pitch_acf_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float] * 3 + [C.c_void_p]),
+    "evmi_pitch_world_ws_elems": (C.c_longlong, [C.c_int] * 5 + [C.c_float] * 3),
+    "evmi_pitch_world_f64": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 5 + [C.c_float] * 4 + [C.c_void_p]),
+    "evmi_pitch_world_decimator": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p]),
     "evmi_peak_normalize_f32": (C.c_int, [C.c_void_p] * 3 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "evmi_transpose_bct_cbt_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "evmi_counter_add_i32": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

@@ -143,30 +143,54 @@ def loudness(audio: torch.Tensor, lens: torch.Tensor, sample_rate: int) -> torch
     return out
 
 
+def world_frames(n_samples: int, hop: int, sample_rate: int) -> int:
+    """pyworld's frame count for n_samples: GetSamplesForDIO with frame_period = hop / fs * 1000, in the same double arithmetic."""
+    frame_period = hop / sample_rate * 1000.0
+    return int(1000.0 * n_samples / sample_rate / frame_period) + 1
+
+
 def extract_pitch(audio: torch.Tensor, lens: torch.Tensor | None, hop: int, sample_rate: int, f0_floor: float = 71.0, f0_ceil: float = 800.0,
-                  voicing_threshold: float = 0.8, interpolate: bool = True) -> torch.Tensor:
-    """Frame-level pitch [items, S // hop + 1] (Hz) of a zero-padded batch [items, t_max] on the device -- the interface and the
-    post-processing of ``Preprocessor.extract_pitch`` (preprocessor.py:244-285: unvoiced frames -> NaN -> linear interpolation
-    across them, an utterance without any voiced frame -> zeros), with a normalised-autocorrelation estimator in place of
-    pyworld's dio + stonemask (third-party CPU DSP, not reproduced: the VALUES differ from the reference's, the format does not).
-    A frame is voiced when its best normalised autocorrelation reaches ``voicing_threshold``; 0.8 (and the 95 % rule for the
-    shortest acceptable lag) are what the speech anchor of tests/test_pipeline.py settled: at 0.5 / 85 % weakly periodic frames
-    produced octave-up runs on the reference's LJ010-0008 (phone-level correlation with its ming024 pitch fixture 0.40; now 0.96)."""
+                  voicing_threshold: float = 0.8, interpolate: bool = True, estimator: str = "world", speed: int = 4) -> torch.Tensor:
+    """Frame-level pitch (Hz) of a zero-padded batch [items, t_max] on the device: ``Preprocessor.extract_pitch``
+    (preprocessor.py:244-285) -- ``pyworld.dio(x.f64, fs, frame_period = hop / fs * 1000, speed = 4)`` -> ``pyworld.stonemask`` -> unvoiced
+    frames -> NaN -> linear interpolation across them, an utterance without any voiced frame -> zeros.
+
+    ``estimator="world"`` (default, round 5): WORLD's DIO + StoneMask themselves, in float64 on the device (csrc/pitch_world.hip;
+    oracle/pitch_world_ref.py restates the algorithm and reproduces the reference's pyworld fixture to 1e-13 Hz).  Output
+    [items, world_frames(t_max)]: pyworld's frame count ((int)(1000 n / fs / frame_period) + 1, which is n // hop + 1 or one fewer when
+    the double division lands below the integer); item i is valid up to world_frames(lens[i]), zero behind.
+    ``estimator="acf"``: the normalised-autocorrelation tracker of rounds 2-4 (its own estimator: values differ from the reference's;
+    output [items, t_max // hop + 1]; ``voicing_threshold`` applies to it only)."""
     from . import _lib
 
     if not audio.is_cuda:
         raise RuntimeError("everyvoice_amd.pipeline.extract_pitch computes on the GPU only (no CPU fallback)")
+    if estimator not in ("world", "acf"):
+        raise ValueError("extract_pitch: estimator 'world' (DIO + StoneMask, the reference's) or 'acf'")
     x = audio.to(torch.float32).reshape(-1, audio.shape[-1]).contiguous()
     items, t_max = x.shape
     lens32 = (torch.full((items,), t_max) if lens is None else lens).to(x.device, torch.int32).contiguous()
-    f0 = torch.empty(items, t_max // hop + 1, device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().evmi_pitch_acf_f32(x.data_ptr(), lens32.data_ptr(), f0.data_ptr(), items, t_max, hop, int(sample_rate), float(f0_floor),
-                                              float(f0_ceil), float(voicing_threshold), _lib.current_stream_ptr(x.device)), "evmi_pitch_acf_f32")
+    lib = _lib.load()
+    if estimator == "world":
+        frames = world_frames(t_max, hop, sample_rate)
+        f0 = torch.empty(items, frames, device=x.device, dtype=torch.float32)
+        n_ws = lib.evmi_pitch_world_ws_elems(items, t_max, int(sample_rate), hop, int(speed), float(f0_floor), float(f0_ceil), 2.0)
+        if n_ws <= 0:
+            raise RuntimeError("extract_pitch: evmi_pitch_world_ws_elems rejected the shape")
+        ws = torch.empty(n_ws, device=x.device, dtype=torch.float64)
+        _lib.check(lib.evmi_pitch_world_f64(x.data_ptr(), lens32.data_ptr(), f0.data_ptr(), ws.data_ptr(), n_ws, items, t_max, int(sample_rate), hop, int(speed),
+                                            float(f0_floor), float(f0_ceil), 2.0, 0.1, _lib.current_stream_ptr(x.device)), "evmi_pitch_world_f64")
+        n_valid = [world_frames(int(n), hop, sample_rate) for n in lens32.cpu().tolist()]
+    else:
+        f0 = torch.empty(items, t_max // hop + 1, device=x.device, dtype=torch.float32)
+        _lib.check(lib.evmi_pitch_acf_f32(x.data_ptr(), lens32.data_ptr(), f0.data_ptr(), items, t_max, hop, int(sample_rate), float(f0_floor),
+                                          float(f0_ceil), float(voicing_threshold), _lib.current_stream_ptr(x.device)), "evmi_pitch_acf_f32")
+        n_valid = [int(n) // hop + 1 for n in lens32.cpu().tolist()]
     if not interpolate:
         return f0
     out = f0.cpu().numpy().astype(np.float64)  # (per-utterance 1-D interpolation over a few hundred frames: host plumbing, as in the reference)
     for i in range(items):
-        n = int(lens32[i]) // hop + 1
+        n = min(n_valid[i], out.shape[1])
         row = out[i, :n]
         voiced = row > 0
         if voiced.any():
@@ -271,7 +295,7 @@ class GpuPreprocessor:
         self.cfg = cfg or AudioConfig()
         self.device = torch.device(device)
         self.batch_items = batch_items
-        self.pitch = pitch  # also write pitch/<...>--pitch.pt (FastSpeech2's pitch targets; this library's own estimator, see extract_pitch)
+        self.pitch = pitch  # also write pitch/<...>--pitch.pt (FastSpeech2's pitch targets: WORLD's DIO + StoneMask on the device, see extract_pitch)
         self.transform = MelSpectrogram(self.cfg.n_fft, self.cfg.fft_window_size, self.cfg.fft_hop_size,
                                         self.cfg.input_sampling_rate, self.cfg.n_mels, self.cfg.f_min, self.cfg.f_max)
         # spec_type "mel" / "linear" (heavy.py:59-68, 101-107): the generic transforms, one utterance at a time (the ragged one-launch

@@ -648,6 +648,21 @@ int evmi_peak_normalize_f32(const float* src_dev, float* dst_dev, const int* len
  * frames that follows in the reference is host-side in everyvoice_amd/pipeline.py: extract_pitch. */
 int evmi_pitch_acf_f32(const float* audio_dev, const int* lens_dev, float* f0_dev, int items, int t_max, int hop,
                        int sample_rate, float f0_floor, float f0_ceil, float threshold, void* stream);
+/* The reference's estimator itself: WORLD's DIO + StoneMask in float64 on the device (replaces pyworld.dio(x, fs, frame_period = hop / fs
+ * * 1000, speed) -> pyworld.stonemask at everyvoice/preprocessor/preprocessor.py:244-285; the algorithm of WORLD's src/dio.cpp,
+ * src/stonemask.cpp, src/matlabfunctions.cpp, restated independently in oracle/pitch_world_ref.py, which reproduces the reference's own
+ * pyworld fixture to 1e-13 Hz).  audio [items][t_max] fp32 (zero padded; lens NULL = t_max each) -> f0 [items][frames_max] fp32 in Hz at
+ * t = f * hop / fs, 0 where unvoiced, frames_max = (int)(1000.0 * t_max / fs / (hop / fs * 1000.0)) + 1 (pyworld's frame count, in
+ * the same double arithmetic); item i has (int)(1000.0 * lens[i] / fs / frame_period) + 1 frames, the rest of its row is 0.
+ * f0_floor / f0_ceil / channels_in_octave / allowed_range: pyworld's defaults are 71, 800, 2, 0.1; speed 1..12 (the reference passes 4).
+ * ws: evmi_pitch_world_ws_elems doubles, 16-byte aligned.  evmi_pitch_world_decimator: the anti-alias filter the path designs for a
+ * decimation ratio (host-side, no GPU: a[3], b[2] of WORLD's FilterForDecimate). */
+long long evmi_pitch_world_ws_elems(int items, int t_max, int sample_rate, int hop, int speed, float f0_floor, float f0_ceil,
+                                    float channels_in_octave);
+int evmi_pitch_world_f64(const float* audio_dev, const int* lens_dev, float* f0_dev, double* ws_dev, long long ws_elems, int items, int t_max,
+                         int sample_rate, int hop, int speed, float f0_floor, float f0_ceil, float channels_in_octave, float allowed_range,
+                         void* stream);
+int evmi_pitch_world_decimator(int ratio, double* a3_host, double* b2_host);
 
 /* ------------------------------------------------------------------------------------------
  * FastSpeech2 feature-prediction forward path, channel-major fp32 x[c][b][t].

@@ -138,3 +138,53 @@ def test_slaney_basis_properties():
     assert not b[:, 372:].any()  # nothing above f_max = 8000 Hz (bin 371.5)
     energy = heavy_ref.energy_ref(np.log(np.maximum(b @ np.ones((513, 3), np.float32), 1e-5)))
     assert energy.shape == (3,)
+
+
+def test_world_pitch_oracle_reproduces_the_reference_pyworld_fixture(golden_dir):
+    """oracle/pitch_world_ref.py (DIO + StoneMask restated from the published algorithm; pyworld is not in the image) is PINNED on
+    reference-side data: LJ010-0008 (everyvoice/tests/data/LJ010-0008.wav) through dio(speed = 1) -> stonemask -> interpolation ->
+    per-phone means with the durations of the reference's ming024 fixture equals that fixture's phone-level pitch
+    (everyvoice/tests/data/ming024/eng-LJSpeech-pitch-LJ010-0008.npy: another codebase's pyworld track, standardised) up to the
+    standardisation's line, for all 67 phones: max residual <= 1e-9 Hz (measured 1.4e-13), i.e. every voiced frame carries pyworld's value."""
+    from oracle.pitch_world_ref import dio, stonemask
+
+    g = np.load(golden_dir / "data_side.npz")
+    pcm = np.load(golden_dir / "mel_anchor.npz")["pcm"].astype(np.float64) / 32768.0
+    durs, want = g["ming024_duration"], g["ming024_pitch"].astype(np.float64)
+    hop, sr = 256, 22050
+    f0, t = dio(pcm, sr, frame_period=hop / sr * 1000.0, speed=1)
+    f0 = stonemask(pcm, f0, t, sr)
+    v = f0 > 0
+    assert len(f0) == 501 and 300 < v.sum() < 350
+    f0[~v] = np.interp(np.nonzero(~v)[0], np.nonzero(v)[0], f0[v])
+    frames = int(durs.sum())
+    starts = np.concatenate([[0], np.cumsum(durs)[:-1]])
+    got = np.array([f0[:frames][p:p + d].mean() if d > 0 else 0.0 for p, d in zip(starts, durs)])
+    ok = durs > 0
+    a, b = np.polyfit(want[ok], got[ok], 1)
+    res = np.abs(a * want[ok] + b - got[ok]).max()
+    assert ok.sum() == 67 and res <= 1e-9 and 46.0 < a < 47.5 and 207.0 < b < 208.5, (res, a, b)
+
+
+def test_world_decimation_filter_design_matches_the_tables_world_prints():
+    """WORLD hard-codes one 3rd-order IIR per decimation ratio (matlabfunctions.cpp: FilterForDecimate).  The two sets known by heart
+    (ratio 11 and 12) equal scipy's Chebyshev-I design (order 3, 0.05 dB, cut-off 0.8 / r) AND the design the device path computes
+    itself (evmi_pitch_world_decimator, host code of the library: no GPU needed) to 1e-12 -- the rule the reference's ratio 4 is generated
+    from on both sides."""
+    import ctypes as C
+
+    from scipy import signal
+
+    from everyvoice_amd import _lib
+    from oracle.pitch_world_ref import _KNOWN_DECIMATORS, decimator_coefficients
+
+    lib = _lib.load()
+    for r in (2, 4, 11, 12):
+        a3, b2 = (C.c_double * 3)(), (C.c_double * 2)()
+        assert lib.evmi_pitch_world_decimator(r, a3, b2) == 0
+        b, a = signal.cheby1(3, 0.05, 0.8 / r)
+        want = [-a[1], -a[2], -a[3], b[0], b[1]]
+        assert np.abs(np.array(list(a3) + list(b2)) - want).max() <= 1e-12, r
+        assert np.abs(np.array(sum(map(list, decimator_coefficients(r)), [])) - want).max() <= 1e-12, r
+        if r in _KNOWN_DECIMATORS:
+            assert np.abs(np.array(sum(map(list, _KNOWN_DECIMATORS[r]), [])) - want).max() <= 1e-12, r
