@@ -1328,7 +1328,14 @@ class HiFiGANTrainer:
             if done:
                 break
             run(advance)
-        run(lambda: self._phase_g_update(ctx))
+
+        def g_last():
+            if self.keep_grads:  # (tests; never while capturing: keep_grads keeps a step eager)
+                self.last_grads["g"] = {k: v.clone() for k, v in self.g_params.gradients().items()}
+                self.last_grads["y_hat"] = ctx["y_hat"].data.clone()
+            self._phase_g_update(ctx)
+
+        run(g_last)
 
 
 def _to_cbt_kernel(x_bct: torch.Tensor) -> torch.Tensor:
