@@ -631,7 +631,8 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
             "graph": graph_info,
             "eager": {"value": round(10 / elapsed_eager, 3), "unit": "steps/s", "ms_per_step": round(elapsed_eager / 10 * 1e3, 2), "steps": 10,
                       "note": "the same resident batch without graph replay: the rate of shapes not (yet) captured; train_base_command runs "
-                              "lightning.FastSpeech2(use_graph=True, graph_buckets=(16, 64)) -- batches padded to those multiples replay"},
+                              "lightning.FastSpeech2(use_graph=True): captured shapes replay; graph_buckets=(16, 64) (opt-in) pads batches to multiples so that a "
+                              "loader's variable lengths fall on few shapes"},
             "parallelism": f"dp{world}" + (" (RCCL all-reduce of the flat gradient buffer in two buckets, the first under the rest of backward)" if world > 1 else ""),
             "params": tr.params.numel(), "last_losses": {k: round(float(v), 4) for k, v in out["losses"].items()},
             "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
