@@ -11,7 +11,6 @@
 //   conv_post + tanh (VALU, HBM-bound) -> wav[B,1,T*hop] fp32
 // Every convolution's input activation is therefore applied exactly once per element, either
 // in the producer's epilogue or on load of the residual stream.
-#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -106,22 +105,6 @@ struct evmi_generator {
   int n_cu = 256;
   size_t istft_w_off = 0, istft_b_off = 0;
   bool use_pairs = true;
-
-  // The resblocks of one stage read the same upsampled rows and only meet in the stage's sum: with
-  // mrf_lanes > 1 they run on their own streams (own intermediate rows), so one branch's last,
-  // partly filled wave of workgroups overlaps the next branch's first; the launches that add into
-  // the sum stay in branch order through events, which keeps the bits of the one-stream schedule.
-  int mrf_lanes = 1;
-  hipStream_t lane_stream[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr;
-  std::vector<hipEvent_t> ev_done;
-  int n_bufs() const { return 5 + 3 * (mrf_lanes - 1); }
-  ~evmi_generator() {
-    for (hipStream_t st : lane_stream)
-      if (st) (void)hipStreamDestroy(st);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    for (hipEvent_t e : ev_done) (void)hipEventDestroy(e);
-  }
 
   DevBuf ws;
 
@@ -429,14 +412,11 @@ static int forward_tc(evmi_generator* g, const float* mel, float* wav, int B, in
   if (!g->tc_ok) return fail(EVMI_ERR_UNSUPPORTED, "bf16 MFMA path unavailable: " + g->tc_why);
   const size_t se = align_up(stage_elems_max(g, B, T), 64);
   const size_t in_e = align_up((size_t)B * T * c.n_mels, 64);
-  // per-launch timings only mean something on one stream
-  const int lanes = rec.on() ? 1 : g->mrf_lanes;
-  EVMI_TRY(g->ws.ensure((in_e + (size_t)g->n_bufs() * se) * 2));
+  EVMI_TRY(g->ws.ensure((in_e + 5 * se) * 2));
   bf16_t* base = (bf16_t*)g->ws.p;
   bf16_t* X0 = base;
-  bf16_t* buf[11];
-  for (int i = 0; i < g->n_bufs(); ++i) buf[i] = base + in_e + (size_t)i * se;
-  hipStream_t cs = s;  // the stream the next launch goes to
+  bf16_t* buf[5];
+  for (int i = 0; i < 5; ++i) buf[i] = base + in_e + (size_t)i * se;
   const bf16_t* warena = (const bf16_t*)g->tc_w_arena.p;
   const float* barena = (const float*)g->tc_bias_arena.p;
 
@@ -451,7 +431,7 @@ static int forward_tc(evmi_generator* g, const float* mel, float* wav, int B, in
     a.out_row_stride = row_stride; a.out_shift = shift; a.out_limit = limit;
     a.pre_slope = pre; a.post_slope = post; a.out_scale = scale; a.accumulate = accumulate;
     EVMI_TRY(rec.begin());
-    EVMI_TRY(launch_conv_tc(t.launch, a, B, cs));
+    EVMI_TRY(launch_conv_tc(t.launch, a, B, s));
     const double flops = 2.0 * B * (double)n_rows * t.c_out * t.ks * t.c_in;
     const double bytes = 2.0 * B * ((double)t_in * t.c_in + (double)limit * (1 + (res ? 1 : 0) + (accumulate ? 1 : 0))) +
                          2.0 * t.c_out * t.ks * t.c_in;
@@ -472,34 +452,18 @@ static int forward_tc(evmi_generator* g, const float* mel, float* wav, int B, in
     const int cout = g->ch(i + 1);
     const int len_out = len * u;
     bf16_t* U = buf[0];
+    bf16_t* P[2] = {buf[1], buf[2]};
+    bf16_t* T1 = buf[3];
     // A is read by the upsampler only; the stage output ACC reuses buf[4] after that
     EVMI_TRY(run(g->tc_ups[i], A, len, len + 1, U, nullptr, (long long)u * cout, -(long long)p * cout,
                  (long long)len_out * cout, 1.f, 1.f, 1.f, 0));
     bf16_t* ACC = buf[4];
     const bool last_stage = i == c.num_upsamples - 1;
     const long long lim = (long long)len_out * cout;
-    if (lanes > 1) {
-      EVMI_HIP_CHECK(hipEventRecord(g->ev_fork, s));
-      for (int l = 1; l < lanes; ++l) EVMI_HIP_CHECK(hipStreamWaitEvent(g->lane_stream[l - 1], g->ev_fork, 0));
-    }
-    // branch j adds into the stage's sum after branch j - 1 has
-    auto before_sum = [&](int j) -> int {
-      if (lanes > 1 && j > 0) EVMI_HIP_CHECK(hipStreamWaitEvent(cs, g->ev_done[j - 1], 0));
-      return EVMI_OK;
-    };
     for (int j = 0; j < c.num_kernels; ++j) {
       const std::vector<TcConv>& convs = g->tc_rb[i * c.num_kernels + j];
       const int nd = c.num_dilations[j];
       const bf16_t* cur = U;
-      const int lane = j % lanes;
-      cs = lane == 0 ? s : g->lane_stream[lane - 1];
-      bf16_t** lb = lane == 0 ? buf + 1 : buf + 5 + 3 * (lane - 1);
-      bf16_t* P[2] = {lb[0], lb[1]};
-      bf16_t* T1 = lb[2];
-      auto branch_done = [&]() -> int {
-        if (lanes > 1) EVMI_HIP_CHECK(hipEventRecord(g->ev_done[j], cs));
-        return EVMI_OK;
-      };
       // the whole branch in one launch where its pairs are bound by the residual stream's round trips (resblock_branch_kernel.h)
       if (c.resblock_type == 1 && nd >= 1 && nd <= 3) {
         int dils[3] = {1, 1, 1};
@@ -527,12 +491,10 @@ static int forward_tc(evmi_generator* g, const float* mel, float* wav, int B, in
           ba.post_slope = (j == c.num_kernels - 1) ? (last_stage ? c.post_lrelu_slope : c.lrelu_slope) : 1.f;
           ba.out_scale = 1.f / c.num_kernels;
           ba.accumulate = j > 0;
-          EVMI_TRY(before_sum(j));
           EVMI_TRY(rec.begin());
-          EVMI_TRY(launch_resblock_branch(bl, ba, B, g->n_cu, cs));
+          EVMI_TRY(launch_resblock_branch(bl, ba, B, g->n_cu, s));
           EVMI_TRY(rec.end(bl->name, convs[0].layer + "+" + std::to_string(2 * nd), 4.0 * nd * B * (double)len_out * cout * cout * convs[0].ks,
                            2.0 * B * (double)lim * (2 + ba.accumulate) + 4.0 * nd * cout * cout * convs[0].ks));
-          EVMI_TRY(branch_done());
           continue;
         }
       }
@@ -558,26 +520,20 @@ static int forward_tc(evmi_generator* g, const float* mel, float* wav, int B, in
           pa.out_scale = scale;
           pa.accumulate = accum;
           pa.timeline = nullptr;
-          if (last) EVMI_TRY(before_sum(j));
           EVMI_TRY(rec.begin());
-          EVMI_TRY(launch_resblock_pair(pl, pa, B, g->n_cu, cs));
+          EVMI_TRY(launch_resblock_pair(pl, pa, B, g->n_cu, s));
           EVMI_TRY(rec.end(pl->name, convs[2 * m].layer + "+2", 4.0 * B * (double)len_out * cout * cout * convs[2 * m].ks,
                            2.0 * B * (double)lim * (2 + accum) + 4.0 * cout * cout * convs[2 * m].ks));
         } else if (c.resblock_type == 1) {
           EVMI_TRY(run(convs[2 * m], cur, len_out, len_out, T1, nullptr, cout, 0, lim, c.lrelu_slope,
                        c.lrelu_slope, 1.f, 0));
-          if (last) EVMI_TRY(before_sum(j));
           EVMI_TRY(run(convs[2 * m + 1], T1, len_out, len_out, nxt, cur, cout, 0, lim, 1.f, post, scale, accum));
         } else {
-          if (last) EVMI_TRY(before_sum(j));
           EVMI_TRY(run(convs[m], cur, len_out, len_out, nxt, cur, cout, 0, lim, c.lrelu_slope, post, scale, accum));
         }
         cur = nxt;
       }
-      EVMI_TRY(branch_done());
     }
-    cs = s;
-    if (lanes > 1 && c.num_kernels > 1) EVMI_HIP_CHECK(hipStreamWaitEvent(s, g->ev_done[c.num_kernels - 1], 0));
     A = ACC;
     len = len_out;
   }
@@ -747,18 +703,6 @@ int evmi_generator_finalize(evmi_generator* g) {
     g->n_cu = prop.multiProcessorCount;
     const char* e = getenv("EVMI_NO_FUSED_PAIRS");  // tuning switch: fall back to two launches per pair
     g->use_pairs = !(e && e[0] == '1');
-    const char* l = getenv("EVMI_MRF_LANES");  // tuning switch: 1 keeps every launch on the caller's stream
-    int lanes = l ? atoi(l) : 3;
-    lanes = std::max(1, std::min({lanes, 3, g->cfg.num_kernels}));
-    for (int k = 0; k + 1 < lanes; ++k)
-      if (!g->lane_stream[k]) EVMI_HIP_CHECK(hipStreamCreateWithFlags(&g->lane_stream[k], hipStreamNonBlocking));
-    if (lanes > 1 && !g->ev_fork) EVMI_HIP_CHECK(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
-    while (lanes > 1 && (int)g->ev_done.size() < g->cfg.num_kernels) {
-      hipEvent_t ev;
-      EVMI_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      g->ev_done.push_back(ev);
-    }
-    g->mrf_lanes = lanes;
   }
   EVMI_TRY(prepare_tc(g));
   g->finalized = true;
@@ -770,8 +714,7 @@ int evmi_generator_hop(const evmi_generator* g) { return g ? g->hop() : 0; }
 int64_t evmi_generator_workspace_bytes(const evmi_generator* g, int B, int T, int precision) {
   if (!g || B <= 0 || T <= 0) return 0;
   const size_t se = align_up(stage_elems_max(g, B, T), 64);
-  if (precision == EVMI_PREC_BF16)
-    return (int64_t)((align_up((size_t)B * T * g->cfg.n_mels, 64) + (size_t)g->n_bufs() * se) * 2);
+  if (precision == EVMI_PREC_BF16) return (int64_t)((align_up((size_t)B * T * g->cfg.n_mels, 64) + 5 * se) * 2);
   return (int64_t)(5 * se * 4);
 }
 
