@@ -165,6 +165,10 @@ SYMBOLS = {
                                                     + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
     "evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_ulonglong, C.c_void_p] + [C.c_void_p] * 3
                                                          + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
+    "evmi_conv1d_cbt_bf16pk_ffn_up": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 5
+                                      + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
+    "evmi_conv1d_dgrad_cbt_bf16pk_ffn_down": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 5
+                                              + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
     "evmi_conv1d_wgrad_cbt_bf16pk_prepacked": (C.c_int, [C.c_void_p] * 6 + [C.c_longlong] + [C.c_int] * 11 + [C.c_void_p]),
     "evmi_conv1d_bf16pk_shares_packed": (C.c_int, [C.c_int] * 7),
     "evmi_conv1d_wgrad_cbt_bf16pk_fused": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 11 + [C.c_float, C.c_void_p, C.c_float, C.c_void_p]),

@@ -87,9 +87,43 @@ struct ConvPkArgs {
     long long mplane;
     int Tm;
     float mask_slope, fm_scale;
+    // The wide middle tensor of a feed-forward block, kept packed in both directions (the FastSpeech2 step; flat_tail_silu):
+    //   tail 1: y <- bf16(v) (the pre-activation, read again by the backward) and y2 <- bf16(dropout(silu(v), drop_p)) (the packed
+    //           input of the block's second layer), v = act(acc + bias)
+    //   tail 2: y <- bf16(dropout(v, drop_p) * silu'(pre)), pre = the packed pre-activation tail 1 stored, passed in `fm` (rows
+    //           mplane apart, item pitch Tm; `mask` stays null): the first layer's packed output gradient, formed in the epilogue of
+    //           the second layer's input gradient
+    // Mask stream and arithmetic of PackArgs::fuse 1 / 2 (drop_seed; element index = channel * drop_ld + unit).
+    int tail;
+    uint4* y2;
+    long long drop_ld;
   } po;
 };
 
+// the feed-forward tails of a flat packed output for four channels of one unit (channels c .. c + 3 at element index idx0 + e * ld)
+template <int TAIL>
+__device__ __forceinline__ void pk_flat_tail_silu(float& v0, float& v1, float& v2, float& v3, float& s0, float& s1, float& s2, float& s3,
+                                                  uint2 pre, unsigned long long dseed, float p_drop, unsigned long long idx0,
+                                                  unsigned long long ld) {
+  // (hardware exp2 / reciprocal, a multiply for the 1 / (1 - p) scale: the results are rounded to bf16 on the spot -- their last bits
+  // do not survive it -- and this tail is ~40 vector instructions per element in the epilogue of a matrix kernel)
+  const float rk = 1.f / (1.f - p_drop);
+  const float z[4] = {bf16_lo(pre.x), bf16_hi(pre.x), bf16_lo(pre.y), bf16_hi(pre.y)};
+  float* vp[4] = {&v0, &v1, &v2, &v3};
+  float* sp[4] = {&s0, &s1, &s2, &s3};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool keep = uniform01(dseed, idx0 + (unsigned long long)e * ld) >= p_drop;
+    if (TAIL == 1) {
+      const float val = *vp[e] * __builtin_amdgcn_rcpf(1.f + __expf(-*vp[e]));
+      *sp[e] = keep ? val * rk : 0.f;
+    } else {
+      const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-z[e]));
+      const float d = keep ? *vp[e] * rk : 0.f;
+      *vp[e] = d * (sg * (1.f + z[e] * (1.f - sg)));
+    }
+  }
+}
 template <int ACT>
 __device__ __forceinline__ float pk_act(float v, float p) {
   if (ACT == 1) return v > 0.f ? v : v * p;
@@ -186,7 +220,9 @@ __global__ __launch_bounds__(256) void prep_pk_kernel(PackArgs p, WfragArgs f) {
 // cycles per CU while the LDS feeds the matrix cores.  With the weights off that path the LDS holds input windows
 // only (a third of the bytes) and serves half the fragment reads.
 constexpr int PK_ADIR_KBS = 5;
-template <int BM, int BN, int WM, int WN, bool ADIR = false>
+// TAILS: the instantiations that carry the feed-forward tails of a flat packed output (FlatOut::tail; their per-element hash and
+// exponentials are ~10 k instructions of epilogue the other launches should neither fetch nor allocate registers for)
+template <int BM, int BN, int WM, int WN, bool ADIR = false, bool TAILS = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) {
   static_assert(WM * WN == 4 || WM * WN == 8, "four or eight waves");
   constexpr int NW = WM * WN;  // eight-wave tiles: the loads of a ring step are issued by twice the waves (an LDS-direct load costs its
@@ -515,19 +551,50 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
 #pragma unroll
             for (int i = 0; i < 4; ++i) pk_flat_tail4(v + 4 * i, mk[i], fr[i], a.po.fm_scale, a.po.mask_slope);
           }
+          float s2[16];
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            u32x4 d;
-            d[0] = pack_bf16x2(v[8 * p + 0], v[8 * p + 1]);
-            d[1] = pack_bf16x2(v[8 * p + 2], v[8 * p + 3]);
-            d[2] = pack_bf16x2(v[8 * p + 4], v[8 * p + 5]);
-            d[3] = pack_bf16x2(v[8 * p + 6], v[8 * p + 7]);
-            const u32x4 o = swap_quads_bf16(d);  // lane (n, kh): the 8 channels of octet 2 p + kh
-            const int m_oct = mb + 8 * (2 * p + kh);
-            if (ok && m_oct < m_valid) {
-              uint4 st;
-              st.x = o[0]; st.y = o[1]; st.z = o[2]; st.w = o[3];
-              a.po.y[(long long)((co0 + m_oct) >> 3) * a.po.plane + dst_u] = st;
+          for (int r = 0; r < 16; ++r) s2[r] = 0.f;
+          if (TAILS && a.po.tail) {  // (po.mask is not set with a tail: evmi_conv1d_cbt_bf16pk_ffn_up / ..._ffn_down)
+            uint2 pre[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pre[i] = make_uint2(0u, 0u);
+            if (a.po.tail == 2) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const long long row = (co0 + min(mb + 8 * i, m_last & ~7)) >> 3;
+                pre[i] = *(reinterpret_cast<const uint2*>(a.po.fm + row * a.po.mplane + msk_u) + kh);
+              }
+            }
+            const unsigned long long dseed = a.drop_seed.get(), ld = (unsigned long long)a.po.drop_ld;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int c = co0 + min(mb + 8 * i + 4 * kh, m_last & ~3);
+              const unsigned long long i0 = (unsigned long long)c * ld + (unsigned long long)dst_u;
+              if (a.po.tail == 1)
+                pk_flat_tail_silu<1>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3], pre[i],
+                                     dseed, a.drop_p, i0, ld);
+              else
+                pk_flat_tail_silu<2>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3], pre[i],
+                                     dseed, a.drop_p, i0, ld);
+            }
+          }
+#pragma unroll
+          for (int which = 0; which < 2; ++which) {
+            if (which == 1 && !(TAILS && a.po.tail == 1)) break;
+            uint4* dst = which ? a.po.y2 : a.po.y;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+              u32x4 d;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                d[q] = which ? pack_bf16x2(s2[8 * p + 2 * q], s2[8 * p + 2 * q + 1]) : pack_bf16x2(v[8 * p + 2 * q], v[8 * p + 2 * q + 1]);
+              const u32x4 o = swap_quads_bf16(d);  // lane (n, kh): the 8 channels of octet 2 p + kh
+              const int m_oct = mb + 8 * (2 * p + kh);
+              if (ok && m_oct < m_valid) {
+                uint4 st;
+                st.x = o[0]; st.y = o[1]; st.z = o[2]; st.w = o[3];
+                dst[(long long)((co0 + m_oct) >> 3) * a.po.plane + dst_u] = st;
+              }
             }
           }
         }
@@ -627,7 +694,8 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
   const int n4 = (blockIdx.x * 256 + threadIdx.x) * 4;
   const int oc = blockIdx.y, ph = blockIdx.z;
   const int n_out = a.ph_nout[ph];
-  if (n_out <= 0 || n4 >= n_out) return;  // (flat: B == 1)
+  const int n_cols = a.B * n_out;  // (the chains' calls: B == 1; the FastSpeech2 feed-forward layers: B tight items, one row)
+  if (n_out <= 0 || n4 >= n_cols) return;
   float v[4][8];
   const float* src = a.part + (long long)ph * a.part_stride + (long long)(oc * 8) * a.part_ld + n4;
   const long long sstride = (long long)a.phases * a.part_stride;
@@ -646,7 +714,7 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int n = n4 + c;
-    if (n >= n_out) break;
+    if (n >= n_cols) break;
     const int w = n * a.out_stride + a.ph_off[ph];
     const int bb = w / a.po.Tc, u = w - bb * a.po.Tc;
     if (w < 0 || u >= a.po.valid) continue;
@@ -666,9 +734,28 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
       pk_flat_tail4(vc, make_uint2(mk.x, mk.y), make_uint2(fr.x, fr.y), a.po.fm_scale, a.po.mask_slope);
       pk_flat_tail4(vc + 4, make_uint2(mk.z, mk.w), make_uint2(fr.z, fr.w), a.po.fm_scale, a.po.mask_slope);
     }
+    const long long du = (long long)bb * a.po.Ts + u;
+    float s2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.po.tail) {
+      uint4 pre = make_uint4(0u, 0u, 0u, 0u);
+      if (a.po.tail == 2) pre = a.po.fm[(long long)oc * a.po.mplane + (long long)bb * a.po.Tm + u];
+      const unsigned long long dseed = a.drop_seed.get(), ld = (unsigned long long)a.po.drop_ld;
+      const unsigned long long i0 = (unsigned long long)(oc * 8) * ld + (unsigned long long)du;
+      if (a.po.tail == 1) {
+        pk_flat_tail_silu<1>(vc[0], vc[1], vc[2], vc[3], s2[0], s2[1], s2[2], s2[3], make_uint2(pre.x, pre.y), dseed, a.drop_p, i0, ld);
+        pk_flat_tail_silu<1>(vc[4], vc[5], vc[6], vc[7], s2[4], s2[5], s2[6], s2[7], make_uint2(pre.z, pre.w), dseed, a.drop_p, i0 + 4ull * ld, ld);
+      } else {
+        pk_flat_tail_silu<2>(vc[0], vc[1], vc[2], vc[3], s2[0], s2[1], s2[2], s2[3], make_uint2(pre.x, pre.y), dseed, a.drop_p, i0, ld);
+        pk_flat_tail_silu<2>(vc[4], vc[5], vc[6], vc[7], s2[4], s2[5], s2[6], s2[7], make_uint2(pre.z, pre.w), dseed, a.drop_p, i0 + 4ull * ld, ld);
+      }
+    }
     uint4 st;
     st.x = pack_bf16x2(vc[0], vc[1]); st.y = pack_bf16x2(vc[2], vc[3]); st.z = pack_bf16x2(vc[4], vc[5]); st.w = pack_bf16x2(vc[6], vc[7]);
-    a.po.y[(long long)oc * a.po.plane + (long long)bb * a.po.Ts + u] = st;
+    a.po.y[(long long)oc * a.po.plane + du] = st;
+    if (a.po.tail == 1) {
+      st.x = pack_bf16x2(s2[0], s2[1]); st.y = pack_bf16x2(s2[2], s2[3]); st.z = pack_bf16x2(s2[4], s2[5]); st.w = pack_bf16x2(s2[6], s2[7]);
+      a.po.y2[(long long)oc * a.po.plane + du] = st;
+    }
   }
 }
 
@@ -960,37 +1047,37 @@ static int launch_pk_tile(ConvPkArgs& a, const PkPlan& pl, hipStream_t stream) {
   static const int xcd_remap = 1;
   a.xcd_remap = xcd_remap;
   const size_t lds = pl.lds;
-  static thread_local size_t configured_dev[kMaxDevices][kNumPkTiles] = {};
+  static thread_local size_t configured_dev[kMaxDevices][2 * kNumPkTiles] = {};
   size_t* configured = configured_dev[device_slot()];
-#define EVMI_PK_LAUNCH(BM, BN, WM, WN, IDX)                                                                              \
+#define EVMI_PK_LAUNCH_AS(BM, BN, WM, WN, ADIR, TAILS, IDX)                                                              \
   {                                                                                                                      \
     if (lds > configured[IDX]) {                                                                                         \
-      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pk_kernel<BM, BN, WM, WN>,                                    \
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pk_kernel<BM, BN, WM, WN, ADIR, TAILS>,                       \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                        \
       configured[IDX] = lds;                                                                                             \
     }                                                                                                                    \
-    hipLaunchKernelGGL((conv_pk_kernel<BM, BN, WM, WN>), pl.grid, dim3(WM * WN * 64), lds, stream, a);                   \
+    hipLaunchKernelGGL((conv_pk_kernel<BM, BN, WM, WN, ADIR, TAILS>), pl.grid, dim3(WM * WN * 64), lds, stream, a);      \
   }
+#define EVMI_PK_LAUNCH(BM, BN, WM, WN, ADIR, IDX)                                                                        \
+  {                                                                                                                      \
+    if (tails) EVMI_PK_LAUNCH_AS(BM, BN, WM, WN, ADIR, true, kNumPkTiles + IDX)                                          \
+    else EVMI_PK_LAUNCH_AS(BM, BN, WM, WN, ADIR, false, IDX)                                                             \
+  }
+  const bool tails = a.po.y && a.po.tail;
   switch (pl.ti) {
-    case 0: EVMI_PK_LAUNCH(128, 128, 2, 2, 0) break;
-    case 1: EVMI_PK_LAUNCH(64, 128, 1, 4, 1) break;
-    case 2: EVMI_PK_LAUNCH(64, 64, 2, 2, 2) break;
-    case 4: EVMI_PK_LAUNCH(64, 256, 1, 4, 4) break;
-    case 5: EVMI_PK_LAUNCH(32, 256, 1, 4, 5) break;
-    case 6: EVMI_PK_LAUNCH(128, 256, 2, 2, 6) break;
-    case 7: EVMI_PK_LAUNCH(128, 256, 2, 4, 7) break;
-    case 8: EVMI_PK_LAUNCH(128, 128, 2, 4, 8) break;
-    case 10: EVMI_PK_LAUNCH(32, 512, 1, 4, 10) break;
-    case 9: {
-      if (lds > configured[9]) {
-        EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)conv_pk_kernel<128, 128, 2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured[9] = lds;
-      }
-      hipLaunchKernelGGL((conv_pk_kernel<128, 128, 2, 2, true>), pl.grid, dim3(256), lds, stream, a);
-      break;
-    }
-    default: EVMI_PK_LAUNCH(32, 128, 1, 4, 3) break;
+    case 0: EVMI_PK_LAUNCH(128, 128, 2, 2, false, 0) break;
+    case 1: EVMI_PK_LAUNCH(64, 128, 1, 4, false, 1) break;
+    case 2: EVMI_PK_LAUNCH(64, 64, 2, 2, false, 2) break;
+    case 4: EVMI_PK_LAUNCH(64, 256, 1, 4, false, 4) break;
+    case 5: EVMI_PK_LAUNCH(32, 256, 1, 4, false, 5) break;
+    case 6: EVMI_PK_LAUNCH(128, 256, 2, 2, false, 6) break;
+    case 7: EVMI_PK_LAUNCH(128, 256, 2, 4, false, 7) break;
+    case 8: EVMI_PK_LAUNCH(128, 128, 2, 4, false, 8) break;
+    case 10: EVMI_PK_LAUNCH(32, 512, 1, 4, false, 10) break;
+    case 9: EVMI_PK_LAUNCH(128, 128, 2, 2, true, 9) break;
+    default: EVMI_PK_LAUNCH(32, 128, 1, 4, false, 3) break;
   }
+#undef EVMI_PK_LAUNCH_AS
 #undef EVMI_PK_LAUNCH
   EVMI_LAUNCH_CHECK("conv_cbt_bf16_pk");
   return EVMI_OK;
@@ -1029,7 +1116,10 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   a.xp = xp;
   a.wf = wf;
   if (int rc = launch_pk_tile(a, pl, stream)) return rc;
-  if (a.ksplit > 1) {
+  if (a.ksplit > 1 && a.po.y) {
+    hipLaunchKernelGGL(conv_pk_reduce_flat_kernel, dim3((unsigned)((a.part_ld + 1023) / 1024), pl.c_out / 8, a.phases), dim3(256), 0, stream, a);
+    EVMI_LAUNCH_CHECK("conv_pk_reduce_flat");
+  } else if (a.ksplit > 1) {
     hipLaunchKernelGGL(conv_pk_reduce_kernel, dim3((unsigned)((a.part_ld + 255) / 256), pl.c_out, a.phases), dim3(256), 0, stream, a);
     EVMI_LAUNCH_CHECK("conv_pk_reduce");
   }
@@ -1442,6 +1532,76 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(int stage, const float* dy_dev, 
   PkInputFusion in;
   in.fuse = 3; in.fuse_scale = scale; in.p_drop = p; in.seed = SeedArg{seed_value, seed_base_dev};
   return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream, in, stage);
+}
+
+/* A feed-forward block's wide middle tensor kept PACKED in both directions (pointwise layers c_in -> c_mid -> c_out on tight items,
+ * the geometry of evmi_conv1d_bf16pk_shares_packed): neither the pre-activation a, nor dropout(silu(a)), nor the gradient
+ * dropout(ds) * silu'(a) is ever stored in fp32, and no pack pass reads them back.
+ *   _ffn_up:   the first layer on the packed input at the head of ws (as _prepacked), its result a = conv + bias leaving the epilogue twice:
+ *                a_pk [c_mid / 8][B * t] 16-byte units  <- bf16(a)                          (the backward's silu' reads it)
+ *                head of next_ws                        <- bf16(dropout(silu(a), p))        (next_ws = the SECOND layer's workspace, whose
+ *                head is that layer's packed input: run it with evmi_conv1d_cbt_bf16pk_prepacked / _resdrop in_mode 2)
+ *   _ffn_down_dgrad:  the second layer's input gradient on the packed dz at the head of ws (stage 1 of ..._dgrad_..._staged[_dropout] put
+ *              it there), its result ds leaving the epilogue as
+ *                head of next_ws <- bf16(dropout(ds, p) * silu'(a_pk))   (next_ws = the workspace of the FIRST layer's input gradient,
+ *                whose head is that layer's packed dy: run evmi_conv1d_dgrad_cbt_bf16pk_staged stage 2 on it; the weight gradient and the
+ *                bias gradient read the same units)
+ * Same mask stream and arithmetic as evmi_conv1d_cbt_bf16pk_silu_dropout / ..._staged_silu_dropout (seed_value + *seed_base_dev, element
+ * index = index in the fp32 tensor that is no longer stored); the one difference: silu' is taken at bf16(a) instead of a. */
+static int ffn_tail_check(const ConvPkArgs& a2, const PkPlan& pl2, int B, int t, int c_mid, float* next_ws, long long next_ws_elems, const char* who) {
+  if (a2.Tp != t || pl2.PL != 0 || !pk_shared_items(B, t)) return fail(EVMI_ERR_UNSUPPORTED, std::string(who) + ": the consumer's items are not packed tight");
+  if ((long long)B * t >= (1LL << 31) || c_mid % 8) return fail(EVMI_ERR_UNSUPPORTED, std::string(who) + ": shape");
+  if (!next_ws || next_ws_elems < (pl2.xp_units + pl2.wf_units) * 4 + pl2.part_elems || (reinterpret_cast<uintptr_t>(next_ws) & 15))
+    return fail(EVMI_ERR_INVALID_ARG, std::string(who) + ": the consumer's workspace is missing, too small or unaligned");
+  return EVMI_OK;
+}
+
+int evmi_conv1d_cbt_bf16pk_ffn_up(const float* w_dev, const float* bias_dev, float* ws_dev, long long ws_elems, void* a_pk_dev,
+                                  float* next_ws_dev, long long next_ws_elems, int B, int c_in, int t, int c_mid, int c_out, float p,
+                                  unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream) {
+  if (!w_dev || !ws_dev || !a_pk_dev || (reinterpret_cast<uintptr_t>(a_pk_dev) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_ffn_up: null / unaligned pointer");
+  if (p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_ffn_up: p outside [0, 1)");
+  ConvPkArgs a = {}, a2 = {};
+  PkPlan pl, pl2;
+  if (const char* why = plan_fwd_pk(a, pl, B, c_in, t, c_mid, t, t, 1, 1, 0, 1, 1, 1, 0))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk_ffn_up: ") + why);
+  if (const char* why = plan_fwd_pk(a2, pl2, B, c_mid, t, c_out, t, t, 1, 1, 0, 1, 1, 1, 0))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk_ffn_up (second layer): ") + why);
+  if (int rc = ffn_tail_check(a2, pl2, B, t, c_mid, next_ws_dev, next_ws_elems, "conv1d_cbt_bf16pk_ffn_up")) return rc;
+  const long long N = (long long)B * t;
+  uint4* nxt = reinterpret_cast<uint4*>(next_ws_dev);
+  // the zero slack behind the second layer's packed input (the pack pass that no longer runs wrote it)
+  const long long used = (long long)a2.octs * N;
+  EVMI_HIP_CHECK(hipMemsetAsync(nxt + used, 0, (size_t)(pl2.xp_units - used) * 16, (hipStream_t)stream));
+  a.bias = bias_dev; a.y = nullptr; a.accumulate = 0; a.act = 0; a.act_param = 0.f;
+  a.po.y = reinterpret_cast<uint4*>(a_pk_dev); a.po.y2 = nxt; a.po.plane = N; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
+  a.po.tail = 1; a.po.drop_ld = N; a.po.Tm = (int)N; a.po.mplane = N;
+  a.drop_p = p; a.drop_seed = SeedArg{seed_value, seed_base_dev};
+  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_mid, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 2);
+}
+
+int evmi_conv1d_dgrad_cbt_bf16pk_ffn_down(const float* w_dev, float* ws_dev, long long ws_elems, const void* a_pk_dev, float* next_ws_dev,
+                                          long long next_ws_elems, int B, int c_in, int t, int c_mid, int c_out, float p,
+                                          unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream) {
+  if (!w_dev || !ws_dev || !a_pk_dev || (reinterpret_cast<uintptr_t>(a_pk_dev) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_ffn_down: null / unaligned pointer");
+  if (p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_ffn_down: p outside [0, 1)");
+  ConvPkArgs a = {}, a1 = {};
+  PkPlan pl, pl1;
+  // the second layer (c_mid -> c_out): its input gradient has c_mid rows; the first layer's (c_in -> c_mid) input gradient reads them packed
+  if (const char* why = plan_dgrad_pk(a, pl, B, c_mid, t, c_out, t, 1, 1, 0, 1, 1))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk_ffn_down: ") + why);
+  if (const char* why = plan_dgrad_pk(a1, pl1, B, c_in, t, c_mid, t, 1, 1, 0, 1, 1))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk_ffn_down (first layer): ") + why);
+  if (int rc = ffn_tail_check(a1, pl1, B, t, c_mid, next_ws_dev, next_ws_elems, "conv1d_dgrad_cbt_bf16pk_ffn_down")) return rc;
+  const long long N = (long long)B * t;
+  uint4* nxt = reinterpret_cast<uint4*>(next_ws_dev);
+  const long long used = (long long)a1.octs * N;
+  EVMI_HIP_CHECK(hipMemsetAsync(nxt + used, 0, (size_t)(pl1.xp_units - used) * 16, (hipStream_t)stream));
+  a.y = nullptr;
+  a.po.y = nxt; a.po.plane = N; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
+  a.po.tail = 2; a.po.drop_ld = N; a.po.fm = reinterpret_cast<const uint4*>(a_pk_dev); a.po.Tm = (int)N; a.po.mplane = N;
+  a.drop_p = p; a.drop_seed = SeedArg{seed_value, seed_base_dev};
+  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 1, c_mid, c_out, 1, 1, (hipStream_t)stream, PkInputFusion(), 2);
 }
 
 /* Input gradient with the fusions of a backward pass: dy is multiplied by (dy_mask > 0 ? 1 : dy_mask_slope) while it is packed

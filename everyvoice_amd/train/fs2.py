@@ -357,6 +357,23 @@ def ffn_core(tape: Tape, x: Var, ln: Affine, l1, l2, p: float, seed: int, res: V
         return h if res is None else residual_dropout(tape, res, h, p, seed_out, sb)
     w1, dw1 = l1.effective(True)
     w2, dw2 = l2.effective(True)
+    if res is not None and ops.ffn_packed_supported(B, T, C, l1.cout, l2.cout):
+        # the whole block as a packed chain: the c_mid-channel tensors (pre-activation, activated + masked, and its gradient) exist as
+        # packed bf16 only, written by the producing layers' epilogues (ops.ffn_packed_fwd)
+        keep = {}
+        yp = Var(ops.ffn_packed_fwd(x.data, ln.gamma(), ln.beta(), w1, l1.bias_data(), w2, l2.bias_data(), res.data, p, seed, seed_out, sb, keep))
+        _ACTIVATION_ELEMS[0] += l1.cout * B * T  # (the pre-activation: the tensor the separate operators count as dense1's output)
+
+        def bwd_packed():
+            if yp.grad is None:
+                return
+            dh = ops.ffn_packed_bwd(x.data, w1, w2, yp.grad, p, seed, seed_out, sb, dw1, l1.db_sink(), dw2, l2.db_sink(), keep)
+            keep.clear()
+            x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh, ln.dgamma(), ln.dbeta()))
+            res.accumulate(yp.grad)
+
+        tape.record(bwd_packed)
+        return yp
     packed1, packed2 = {}, {}
     ln_fused = ops.ln_dense_fused_supported(B, T, C, l1.cout)
     if ln_fused:

@@ -764,6 +764,91 @@ def conv1d_bwd_silu_dropout_dy(x, w, ds, pre, p, seed, dw_out, db_out, packed):
     return dx
 
 
+# ---- a feed-forward block whose wide middle tensor exists packed only ----------------------------------------------------------
+FFN_PACKED = [_os.environ.get("EVMI_FS2_FFN_PACKED", "1") != "0"]  # A/B switch (tools/fs2_train_bench.py)
+
+
+def ffn_packed_supported(B, t, c_in, c_mid, c_out) -> bool:
+    """True where LayerNorm -> dense(c_in -> c_mid) -> SiLU -> dropout -> dense(c_mid -> c_out) -> (+ residual, dropout) runs as the packed
+    chain of ffn_packed_fwd / ffn_packed_bwd (every fusion it is built from is available)."""
+    return bool(FFN_PACKED[0] and c_mid % 8 == 0 and ffn_fused_supported(B, t, c_mid, c_out) and ln_dense_fused_supported(B, t, c_in, c_mid)
+                and resdrop_fused_supported(B, t, c_mid, c_out))
+
+
+def ffn_packed_fwd(x, gamma, beta, w1, b1, w2, b2, res, p, seed, seed_out, scale, keep, eps=1e-5):
+    """res + scale * dropout(dense2(dropout(silu(dense1(LayerNorm(x))), p)), p) with NO fp32 copy of the c_mid-channel tensors: LayerNorm
+    writes dense1's packed input, dense1's epilogue writes bf16(a) (``keep["a_pk"]``, for the backward) and dense2's packed input
+    dropout(silu(a)) (``keep["s_packed"]``), dense2's epilogue adds the residual.  ``keep["x_packed"]``: LayerNorm(x), packed."""
+    cin, B, t = x.shape
+    cmid, cout = w1.shape[0], w2.shape[0]
+    lib = _lib.load()
+    geo = (t, 1, 1, 0, 1, 1)
+    n1 = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t, cmid, *geo)
+    n2 = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cmid, t, cout, *geo)
+    ws1 = keep["x_packed"] = torch.empty(n1, device=x.device, dtype=torch.float32)
+    ws2 = keep["s_packed"] = torch.empty(n2, device=x.device, dtype=torch.float32)
+    a_pk = keep["a_pk"] = torch.empty(cmid // 8 * B * t * 4, device=x.device, dtype=torch.float32)  # 16-byte units of 8 bf16 channels
+    out = torch.empty(cout, B, t, device=x.device, dtype=torch.float32)
+    st = _s(x)
+    _chk(lib.evmi_layernorm_pack_bf16pk(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws1.data_ptr(), n1, B, cin, t, cmid, eps, st), "evmi_layernorm_pack_bf16pk")
+    _count_conv(B, t, cmid, cin, 1)
+    _chk(lib.evmi_conv1d_cbt_bf16pk_ffn_up(w1.data_ptr(), _lib.ptr(b1), ws1.data_ptr(), n1, a_pk.data_ptr(), ws2.data_ptr(), n2, B, cin, t, cmid, cout, float(p),
+                                           int(seed), _lib.ptr(SEED_BASE[0]), st), "evmi_conv1d_cbt_bf16pk_ffn_up")
+    _count_conv(B, t, cout, cmid, 1)
+    _chk(lib.evmi_conv1d_cbt_bf16pk_resdrop(2, None, w2.data_ptr(), _lib.ptr(b2), res.data_ptr(), out.data_ptr(), ws2.data_ptr(), n2, B, cmid, t, cout, 0.0, 0,
+                                            float(p), int(seed_out), float(scale), _lib.ptr(SEED_BASE[0]), st), "evmi_conv1d_cbt_bf16pk_resdrop")
+    return out
+
+
+def ffn_packed_bwd(x, w1, w2, dy, p, seed, seed_out, scale, dw1, db1, dw2, db2, keep):
+    """Backward of ffn_packed_fwd up to LayerNorm: returns d LayerNorm(x) [c_in, B, t] (fp32); the weight and bias gradients of both
+    layers go to the sibling stream (side_wgrad) reading the packed operands.  dz = scale * dropout(dy) is packed once; the second
+    layer's input gradient leaves its epilogue as the first layer's packed dy = dropout(ds) * silu'(a)."""
+    cin, B, t = x.shape
+    cmid, cout = w1.shape[0], w2.shape[0]
+    lib = _lib.load()
+    geo = (t, 1, 1, 0, 1, 1)
+    n_d2 = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cmid, t, cout, *geo)
+    n_d1 = lib.evmi_conv1d_dgrad_cbt_bf16pk_ws_elems(B, cin, t, cmid, *geo)
+    wsd2 = torch.empty(n_d2, device=dy.device, dtype=torch.float32)
+    wsd1 = torch.empty(n_d1, device=dy.device, dtype=torch.float32)
+    dh = torch.empty(cin, B, t, device=dy.device, dtype=torch.float32)
+    ws1, ws2, a_pk = keep["x_packed"], keep["s_packed"], keep["a_pk"]
+    st = _s(dy)
+    # second layer: pack dz (stage 1), fork its weight gradient, input gradient into the first layer's packed dy
+    args2 = (dy.data_ptr(), float(p), int(seed_out), _lib.ptr(SEED_BASE[0]), float(scale), w2.data_ptr(), wsd2.data_ptr(), wsd2.data_ptr(), n_d2, B, cmid, t, cout, t,
+             1, 1, 0, 1, 1)
+    _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(1, *args2, st), "evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout")
+    side2 = side_wgrad(dy, dw2, db2, wsd2, ws2).mark()
+    _count_conv(B, t, cout, cmid, 1)
+    _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_ffn_down(w2.data_ptr(), wsd2.data_ptr(), n_d2, a_pk.data_ptr(), wsd1.data_ptr(), n_d1, B, cin, t, cmid, cout, float(p),
+                                                   int(seed), _lib.ptr(SEED_BASE[0]), st), "evmi_conv1d_dgrad_cbt_bf16pk_ffn_down")
+
+    def wgrad(c_i, c_o, xp, dyp, dw, db):
+        def launch():
+            n_w = lib.evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(B, c_i, t, c_o, *geo)
+            wsw = WS.get("pkw", n_w, x.device)
+            _count_conv(B, t, c_o, c_i, 1)
+            # (the fp32 operands are stand-ins: both packed copies are given)
+            _chk(lib.evmi_conv1d_wgrad_cbt_bf16pk_prepacked(xp.data_ptr(), xp.data_ptr(), dyp.data_ptr(), dyp.data_ptr(), dw.data_ptr(), wsw.data_ptr(), n_w, B, c_i, t,
+                                                            c_o, t, 1, 1, 0, 1, 1, 1, _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk_prepacked")
+            if db is not None:  # row sums of the packed output gradient: [c_o / 8 octet rows][B * t units]
+                job = (_lib.PkFlatRows * 1)()
+                job[0].dy, job[0].plane, job[0].units, job[0].C, job[0].db = dyp.data_ptr(), B * t, B * t, c_o, db.data_ptr()
+                n_r = lib.evmi_pkflat_rowsum_ws_elems(1, job)
+                wsr = WS.get("pkrow", n_r, x.device)
+                _chk(lib.evmi_pkflat_rowsum(1, job, wsr.data_ptr(), n_r, _s(x)), "evmi_pkflat_rowsum")
+        return launch
+
+    side2.run(wgrad(cmid, cout, ws2, wsd2, dw2, db2))
+    side1 = side_wgrad(x, dw1, db1, wsd1, ws1, a_pk).mark()  # fork behind the epilogue that wrote the packed dy, in front of the input gradient
+    _count_conv(B, t, cmid, cin, 1)
+    _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged(2, wsd1.data_ptr(), w1.data_ptr(), dh.data_ptr(), wsd1.data_ptr(), n_d1, B, cin, t, cmid, t, 1, 1, 0, 1, 1, st),
+         "evmi_conv1d_dgrad_cbt_bf16pk_staged")
+    side1.run(wgrad(cin, cmid, ws1, wsd1, dw1, db1))
+    return dh
+
+
 # ---- a + s * dropout(dense(h)): the residual add and the dropout in the layer's epilogue, their backward in the pack of dy ---------------
 RESDROP_FUSION = [_os.environ.get("EVMI_FS2_RESDROP", "1") != "0"]  # A/B switch of the fusion below (tools/fs2_train_bench.py)
 

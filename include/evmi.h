@@ -326,6 +326,22 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(int stage, const float* dy_dev, 
                                                 const unsigned long long* seed_base_dev, float scale, const float* w_dev, float* dx_dev,
                                                 float* ws_dev, long long ws_elems, int B, int c_in, int t_in, int c_out, int t_out, int k,
                                                 int stride, int pad, int dil, int groups, void* stream);
+/* A feed-forward block's wide middle tensor kept packed in both directions (FastSpeech2_lightning's Conformer feed-forward modules
+ * Linear -> SiLU -> Dropout -> Linear -- absent submodule; pointwise layers c_in -> c_mid -> c_out on tight items):
+ *   evmi_conv1d_cbt_bf16pk_ffn_up:          the first layer on the packed input at the head of ws; a = conv + bias is written as
+ *                                           a_pk [c_mid / 8][B * t] 16-byte units (bf16) and dropout(silu(a), p) as the packed input
+ *                                           at the head of next_ws, the SECOND layer's workspace (run it with ..._prepacked /
+ *                                           ..._resdrop in_mode 2)
+ *   evmi_conv1d_dgrad_cbt_bf16pk_ffn_down:  the second layer's input gradient on the packed dz at the head of ws (stage 1 of
+ *                                           ..._staged[_dropout]); dropout(ds, p) * silu'(a_pk) is written as the packed dy at the
+ *                                           head of next_ws, the workspace of the FIRST layer's input gradient (run ..._staged stage 2)
+ * Mask streams of evmi_conv1d_cbt_bf16pk_silu_dropout / ..._staged_silu_dropout; silu' is taken at bf16(a). */
+int evmi_conv1d_cbt_bf16pk_ffn_up(const float* w_dev, const float* bias_dev, float* ws_dev, long long ws_elems, void* a_pk_dev,
+                                  float* next_ws_dev, long long next_ws_elems, int B, int c_in, int t, int c_mid, int c_out, float p,
+                                  unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream);
+int evmi_conv1d_dgrad_cbt_bf16pk_ffn_down(const float* w_dev, float* ws_dev, long long ws_elems, const void* a_pk_dev, float* next_ws_dev,
+                                          long long next_ws_elems, int B, int c_in, int t, int c_mid, int c_out, float p,
+                                          unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream);
 /* LayerNorm in front of a pointwise layer written as that layer's packed input, and the layer on an input already packed in the head
  * of ws (the Conformer's LayerNorm -> Linear pairs; layers of evmi_conv1d_bf16pk_shares_packed, 128 or 256 input channels): the
  * normalised tensor is never stored in fp32.  ws: evmi_conv1d_cbt_bf16pk_ws_elems floats of the layer (k = 1, stride 1, no padding). */

@@ -760,6 +760,74 @@ def test_fused_feed_forward_block_against_torch_with_the_kernels_own_mask(cuda_d
         assert l2 <= 1e-3 and mx <= 1e-2, (name, l2, mx)
 
 
+@pytest.mark.parametrize("B,T", [(32, 814), (4, 112), (2, 32)])
+def test_feed_forward_block_as_a_packed_chain_against_torch_with_the_kernels_own_masks(cuda_device, B, T):
+    """The feed-forward block with its 1024-channel tensors packed end to end (train/fs2.py: ffn_core -> ops.ffn_packed_fwd / _bwd:
+    LayerNorm written packed -> dense1, whose epilogue writes bf16(a) and the packed dropout(silu(a)) -> dense2 with the residual add and
+    the outer dropout in its epilogue; backward: scale * dropout(dy) packed -> dense2's input gradient, whose epilogue writes the packed
+    dropout(ds) * silu'(bf16(a)) -> dense1's input gradient -> LayerNorm backward) against TORCH with both masks exported through the
+    one-operator dropout kernel and the chain's rounding points restated (bench shape, and two small ones that take the split-K
+    launches whose reduce pass carries the same tails).  Tolerances as the test above: relative L2 <= 1e-3, elements within 1 %."""
+    from everyvoice_amd.train import ops
+
+    D, F_, p, seed, seed_out, sb = 256, 1024, 0.2, 4321, 977, 0.5
+    g = torch.Generator().manual_seed(11 + B)
+    x = torch.randn(D, B, T, generator=g) * 1.3 + 0.2
+    gamma, beta = torch.rand(D, generator=g) + 0.5, torch.randn(D, generator=g) * 0.1
+    w1 = torch.randn(F_, D, 1, generator=g) * D ** -0.5
+    w2 = torch.randn(D, F_, 1, generator=g) * F_ ** -0.5
+    b1, b2 = torch.randn(F_, generator=g) * 0.1, torch.randn(D, generator=g) * 0.1
+    dy = torch.randn(D, B, T, generator=g)
+    dev = cuda_device
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    prev = ops.CONV_BACKEND["operands"]
+    ops.CONV_BACKEND["operands"] = "bf16"
+    try:
+        assert ops.ffn_packed_supported(B, T, D, F_, D)
+        xd, w1d, w2d = x.to(dev), w1.to(dev), w2.to(dev)
+        gd, bd = gamma.to(dev), beta.to(dev)
+        keep1 = (ops.dropout(torch.ones(F_ * B * T, device=dev), p, seed) > 0).float().view(F_, B * T).cpu()
+        keep2 = (ops.dropout(torch.ones(D * B * T, device=dev), p, seed_out) > 0).float().view(D, B * T).cpu()
+        kp = {}
+        y = ops.ffn_packed_fwd(xd, gd, bd, w1d, b1.to(dev), w2d, b2.to(dev), xd, p, seed, seed_out, sb, kp)
+        ew1, ew2, eb1, eb2 = torch.zeros_like(w1d), torch.zeros_like(w2d), torch.zeros(F_, device=dev), torch.zeros(D, device=dev)
+        dgam, dbet = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+        dh = ops.ffn_packed_bwd(xd, w1d, w2d, dy.to(dev), p, seed, seed_out, sb, ew1, eb1, ew2, eb2, kp)
+        dx = ops.layernorm_bwd(xd, gd, dh, dgam, dbet)
+        ops.wgrad_join(dev)
+        torch.cuda.synchronize()
+        a_pk = kp["a_pk"].view(torch.bfloat16).view(F_ // 8, B * T, 8).permute(0, 2, 1).reshape(F_, B * T).float().cpu()
+    finally:
+        ops.CONV_BACKEND["operands"] = prev
+    N = B * T
+    xm = x.view(D, N)
+    mu, var = xm.mean(0, keepdim=True), xm.var(0, unbiased=False, keepdim=True)
+    xhat = (xm - mu) * torch.rsqrt(var + 1e-5)
+    hn = bf(xhat * gamma[:, None] + beta[:, None])
+    W1, W2 = bf(w1.view(F_, D)), bf(w2.view(D, F_))
+    a_ref = W1 @ hn + b1[:, None]
+    s_ref = bf(a_ref * torch.sigmoid(a_ref) * keep1 / (1 - p))
+    y_ref = xm + sb * keep2 / (1 - p) * (W2 @ s_ref + b2[:, None])
+    dz = bf(sb * keep2 / (1 - p) * dy.view(D, N))
+    ds_ref = W2.t() @ dz
+    dw2_ref, db2_ref = dz @ s_ref.t(), dz.sum(1)
+    ab = bf(a_ref)  # the backward's silu' is taken at the stored bf16 pre-activation
+    sig = torch.sigmoid(ab)
+    da_ref = bf(ds_ref * keep1 / (1 - p) * (sig * (1 + ab * (1 - sig))))
+    dh_ref = W1.t() @ da_ref
+    dw1_ref, db1_ref = da_ref @ hn.t(), da_ref.sum(1)
+    dxhat = dh_ref * gamma[:, None]
+    dx_ref = torch.rsqrt(var + 1e-5) * (dxhat - dxhat.mean(0, keepdim=True) - xhat * (dxhat * xhat).mean(0, keepdim=True))
+    dgam_ref, dbet_ref = (dh_ref * xhat).sum(1), dh_ref.sum(1)
+    for name, got, want in (("a_pk", a_pk, ab), ("y", y, y_ref), ("dh", dh, dh_ref), ("dx", dx, dx_ref), ("dw2", ew2, dw2_ref), ("dw1", ew1, dw1_ref),
+                            ("db2", eb2, db2_ref), ("db1", eb1, db1_ref), ("dgamma", dgam, dgam_ref), ("dbeta", dbet, dbet_ref)):
+        got = got.cpu().reshape(want.shape)
+        l2 = float((got - want).norm() / want.norm())
+        mx = float((got - want).abs().max() / want.abs().max())
+        print(f"packed feed-forward chain vs torch ({B} x {T}), {name}: rel L2 {l2:.2e}, max {mx:.2e}")
+        assert l2 <= 1e-3 and mx <= 1e-2, (name, l2, mx)
+
+
 @pytest.mark.parametrize("B,T,C,F_", [(4, 112, 256, 1024), (32, 814, 256, 768), (8, 64, 128, 256)])
 def test_layernorm_written_as_the_packed_input_of_the_dense_layer_behind_it(cuda_device, B, T, C, F_):
     """ops.layernorm_dense_fwd (train/fs2.py: ln_dense, ffn_core): LayerNorm -> pointwise layer with the normalised tensor written
