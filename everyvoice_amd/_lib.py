@@ -68,6 +68,10 @@ class PkFlatRows(C.Structure):  # evmi_pkflat_rows
     _fields_ = [("dy", C.c_void_p), ("plane", C.c_longlong), ("units", C.c_longlong), ("C", C.c_int), ("db", C.c_void_p)]
 
 
+class LnPartials(C.Structure):  # evmi_ln_partials
+    _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("C", C.c_int), ("n_cols", C.c_longlong)]
+
+
 # name -> (restype, argtypes); every symbol include/evmi.h declares
 SYMBOLS = {
     "evmi_tm_colsum_batch_bf16": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_int, C.c_void_p]),
@@ -192,6 +196,7 @@ SYMBOLS = {
     "evmi_monotonic_align_f32": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]),
     "evmi_layernorm_bwd_cbt_f32_ws_elems": (C.c_longlong, [C.c_int, C.c_longlong]),
     "evmi_layernorm_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 7 + [C.c_longlong, C.c_int, C.c_longlong, C.c_float, C.c_int, C.c_void_p]),
+    "evmi_layernorm_bwd_partials_reduce": (C.c_int, [C.c_int, C.POINTER(LnPartials), C.c_void_p]),
     "evmi_batchnorm_fwd_cbt_f32": (C.c_int, [C.c_void_p] * 8 + [C.c_int, C.c_longlong, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "evmi_batchnorm_bwd_cbt_f32": (C.c_int, [C.c_void_p] * 9 + [C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
     "evmi_dwconv1d_bwd_cbt_f32_ws_elems": (C.c_longlong, [C.c_int] * 3),

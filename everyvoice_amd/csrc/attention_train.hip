@@ -33,6 +33,54 @@ __device__ __forceinline__ float live_load(const float* __restrict__ p, bool liv
 // register r of a 32x32 accumulator <-> row index within the tile, for half-wave kh
 __device__ __forceinline__ int acc_row(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
 
+// Dropout factors (keep or 0) of the 16 accumulator registers of a 32 x 32 score tile.
+//   attn_drop_rows: the registers are keys k0 + acc_row(r, kh) of ONE query row (row_base = the row's first element): registers r, r + 1
+//                   (r even) are the two elements of a pair -- one hash for both (pairs: T even and the tensor below 2^33 elements)
+//   attn_drop_cols: the lane holds ONE key, the registers are queries q0 + acc_row(r, kh): the pair's other element sits in the
+//                   neighbouring lane (key ^ 1) at the same register -- each lane hashes the registers of its own parity and the two
+//                   exchange (one DPP move per hash)
+// Same bits as uniform01(seed, element index) per element (common.h), which the other parities / sizes take.
+__device__ __forceinline__ void attn_drop_rows(float (&dm)[16], bool pairs, unsigned long long seed, unsigned long long row_base, int k0, int kh,
+                                               float p_drop, float keep) {
+  if (pairs) {
+    const unsigned jb = (unsigned)(row_base >> 1) + (unsigned)(k0 >> 1) + 2u * (unsigned)kh;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      float u0, u1;
+      dropout_pair(seed, jb + (unsigned)(((r & 3) >> 1) + 4 * (r >> 2)), u0, u1);
+      dm[r] = u0 >= p_drop ? keep : 0.f;
+      dm[r + 1] = u1 >= p_drop ? keep : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dm[r] = uniform01(seed, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? keep : 0.f;
+  }
+}
+// (four registers at a time -- 4 g4 .. 4 g4 + 3 -- so that the factors do not stay live across the whole tile)
+__device__ __forceinline__ void attn_drop_cols(float (&dm)[4], int g4, bool pairs, unsigned long long seed, unsigned long long batch_base, int tk,
+                                               int tkc, int q0, int kh, int T, float p_drop, float keep) {
+  if (pairs) {
+    const unsigned par = (unsigned)tk & 1u, th = (unsigned)T >> 1;
+    const unsigned jb = (unsigned)((batch_base + (unsigned long long)(tk & ~1)) >> 1);  // (the pair's index: not the clamped key's)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int tq = q0 + 8 * g4 + 4 * kh + 2 * c + (int)par;  // query of register 4 g4 + 2 c + par
+      const unsigned mine = dropout_hash(seed, jb + (unsigned)min(tq, T - 1) * th, 0u);
+      const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]: lane ^ 1
+      const unsigned h0 = par ? other : mine, h1 = par ? mine : other;                              // registers 4 g4 + 2 c and + 1
+      dm[2 * c] = dropout_u16(h0, par) >= p_drop ? keep : 0.f;
+      dm[2 * c + 1] = dropout_u16(h1, par) >= p_drop ? keep : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int tq = q0 + 8 * g4 + 4 * kh + e;
+      dm[e] = uniform01(seed, batch_base + (unsigned long long)tkc + (unsigned long long)min(tq, T - 1) * (unsigned long long)T) >= p_drop ? keep : 0.f;
+    }
+  }
+}
+static inline bool attn_drop_pairs(int B, int T) { return !(T & 1) && (unsigned long long)B * T * T < (1ull << 33); }
+
 // A [DH][32] tile of a channel-major [DH][B][T] slice, columns t0 .. t0 + 31, by LDS-direct loads straight into the operand layout: rows of 32 floats, element (d, t) at d * 32 + (t ^ (d & 31)).
 // The XOR swizzle replaces the odd row stride (a tile is read along its rows and across them: both are conflict-free), and is
 // applied on the SOURCE side -- lane (d, p) of a request fetches column p ^ (d & 31) -- because the hardware writes lane i of a
@@ -406,7 +454,7 @@ __device__ __forceinline__ bf16x8 load_pos_slots(const bf16_t* __restrict__ row,
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int DH, bool DROP>
+template <int DH, int DROP>  // DROP 0: no dropout; 1: one hash per element; 2: one hash per pair of elements (attn_drop_pairs)
 __global__ __launch_bounds__(256, 2) void attention_train_fwd_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                       float* __restrict__ out, float* __restrict__ lse, int B, int T, int D,
                                                                       float scale, float p_drop, SeedArg seed_arg) {
@@ -441,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_fwd_bf16_kernel(const 
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const float keep = DROP ? 1.f / (1.f - p_drop) : 1.f;
+  constexpr bool drop_pairs = DROP == 2;
   const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
 
   for (int k0 = 0; k0 < len; k0 += 32) {
@@ -469,11 +518,13 @@ __global__ __launch_bounds__(256, 2) void attention_train_fwd_bf16_kernel(const 
     const float corr = __expf(m_run - m_new);
     float ps = 0.f;
     bf16x8 pb[2];
+    float dm[16];
+    if (DROP) attn_drop_rows(dm, drop_pairs, seed + h, row_base, k0, kh, p_drop, keep);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float pr = __expf(st[r] - m_new);
       ps += pr;
-      if (DROP) pr = uniform01(seed + h, row_base + (unsigned long long)(k0 + acc_row(r, kh))) >= p_drop ? pr * keep : 0.f;
+      if (DROP) pr = dm[r] != 0.f ? pr * keep : 0.f;
       pb[r >> 3][r & 7] = (bf16_t)pr;
     }
     ps += __shfl_xor(ps, 32, 64);
@@ -498,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_fwd_bf16_kernel(const 
   if (kh == 0 && lse) lse[((long long)b * H + h) * T + tq] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;  // (inference: no lse)
 }
 
-template <int DH, bool DROP>
+template <int DH, int DROP>  // DROP 0: no dropout; 1: one hash per element; 2: one hash per pair of elements (attn_drop_pairs)
 __global__ __launch_bounds__(256, 2) void attention_train_dq_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                      const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                      const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
@@ -537,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void attention_train_dq_bf16_kernel(const f
   const float my_lse = qlive ? my_lse_raw : INFINITY;
   const float my_d = live_load(dsum + ((long long)b * H + h) * T + tqc, qlive);
   const float keep = DROP ? 1.f / (1.f - p_drop) : 1.f;
+  constexpr bool drop_pairs = DROP == 2;
   const unsigned long long row_base = ((unsigned long long)b * T + (unsigned long long)(qlive ? tq : 0)) * T;
   f32x16 acc[DH / 32];
 #pragma unroll
@@ -562,13 +614,15 @@ __global__ __launch_bounds__(256, 2) void attention_train_dq_bf16_kernel(const f
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&Vs[ln * LP + 16 * s + 8 * kh]), doreg[s], dp, 0, 0, 0);
     }
     bf16x8 dsb[2];
+    float dm[16];
+    if (DROP) attn_drop_rows(dm, drop_pairs, seed + h, row_base, k0, kh, p_drop, keep);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = k0 + acc_row(r, kh);
       float pr = __expf(st[r] - my_lse);
       pr = key < len ? pr : 0.f;
       float g = dp[r];
-      if (DROP) g = uniform01(seed + h, row_base + (unsigned long long)key) >= p_drop ? g * keep : 0.f;
+      if (DROP) g = dm[r] != 0.f ? g * keep : 0.f;
       dsb[r >> 3][r & 7] = (bf16_t)(pr * (g - my_d));
     }
 #pragma unroll
@@ -591,7 +645,7 @@ constexpr size_t attention_dkv_bf16_lds() {
   return (size_t)(2 * 32 * (DH + ATB_PD) + 2 * DH * (32 + ATB_PD)) * sizeof(bf16_t) + (size_t)(2 * DH * 32 + 2 * 64) * sizeof(float);
 }
 
-template <int DH, bool DROP>
+template <int DH, int DROP>  // DROP 0: no dropout; 1: one hash per element; 2: one hash per pair of elements (attn_drop_pairs)
 __global__ __launch_bounds__(256, 2) void attention_train_dkv_bf16_kernel(const float* __restrict__ qkv, const int* __restrict__ lens,
                                                                       const float* __restrict__ d_o, const float* __restrict__ lse,
                                                                       const float* __restrict__ dsum, float* __restrict__ dqkv, int B, int T,
@@ -635,7 +689,8 @@ __global__ __launch_bounds__(256, 2) void attention_train_dkv_bf16_kernel(const 
       vreg[s][e] = (bf16_t)live_load(vg + off, klive);
     }
   const float keep = DROP ? 1.f / (1.f - p_drop) : 1.f;
-  const unsigned long long col_base = (unsigned long long)b * T * T + (unsigned long long)tkc;
+  const unsigned long long batch_base = (unsigned long long)b * T * T;
+  constexpr bool drop_pairs = DROP == 2;
   f32x16 acck[DH / 32], accv[DH / 32];
 #pragma unroll
   for (int i = 0; i < DH / 32; ++i)
@@ -668,14 +723,15 @@ __global__ __launch_bounds__(256, 2) void attention_train_dkv_bf16_kernel(const 
     for (int g4 = 0; g4 < 4; ++g4) {
       const f32x4 lse_q = *reinterpret_cast<const f32x4*>(st_l + 8 * g4);
       const f32x4 d_q = *reinterpret_cast<const f32x4*>(st_l + 32 + 8 * g4);
+      float dm[4];
+      if (DROP) attn_drop_cols(dm, g4, drop_pairs, seed + h, batch_base, tk, tkc, q0, kh, T, p_drop, keep);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g4 + e;
         const int tq = q0 + 8 * g4 + 4 * kh + e;
         float pr = __expf(st[r] - lse_q[e]);
         pr = (klive && tq < T) ? pr : 0.f;
-        float mk = 1.f;
-        if (DROP) mk = uniform01(seed + h, col_base + (unsigned long long)min(tq, T - 1) * (unsigned long long)T) >= p_drop ? keep : 0.f;
+        const float mk = DROP ? dm[e] : 1.f;
         pdb[r >> 3][r & 7] = (bf16_t)(pr * mk);
         dsb[r >> 3][r & 7] = (bf16_t)(pr * (dp[r] * mk - d_q[e]));
       }
@@ -707,9 +763,9 @@ int launch_mha_fwd_bf16_plain(const float* qkv, const int* lens, float* out, flo
   const int dh = D / heads;
   const float scale = 1.f / sqrtf((float)dh);
   const dim3 grid((T + 127) / 128, heads, B);
-  if (dh == 128) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<128, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, SeedArg{0ull, nullptr});
-  else if (dh == 64) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<64, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, SeedArg{0ull, nullptr});
-  else if (dh == 32) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<32, false>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, SeedArg{0ull, nullptr});
+  if (dh == 128) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<128, 0>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, SeedArg{0ull, nullptr});
+  else if (dh == 64) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<64, 0>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, SeedArg{0ull, nullptr});
+  else if (dh == 32) hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<32, 0>), grid, dim3(256), 0, s, qkv, lens, out, lse_or_null, B, T, D, scale, 0.f, SeedArg{0ull, nullptr});
   else return 1;
   return 0;
 }
@@ -764,11 +820,14 @@ int evmi_mha_fwd_bf16(const float* qkv_dev, const int* lens_dev, float* out_dev,
   hipStream_t s = (hipStream_t)stream;
 #define EVMI_MHA_FWD(DH)                                                                                                          \
   {                                                                                                                               \
-    if (p_drop > 0.f)                                                                                                             \
-      hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<DH, true>), grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, \
+    if (p_drop > 0.f && attn_drop_pairs(B, T))                                                                                    \
+      hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<DH, 2>), grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, \
+                         scale, p_drop, seed);                                                                                    \
+    else if (p_drop > 0.f)                                                                                                        \
+      hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<DH, 1>), grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, \
                          scale, p_drop, seed);                                                                                    \
     else                                                                                                                          \
-      hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<DH, false>), grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, \
+      hipLaunchKernelGGL((attention_train_fwd_bf16_kernel<DH, 0>), grid, dim3(256), 0, s, qkv_dev, lens_dev, out_dev, lse_dev, B, T, D, \
                          scale, p_drop, seed);                                                                                    \
   }
   if (dh == 128) EVMI_MHA_FWD(128)
@@ -796,7 +855,7 @@ int evmi_mha_bwd_bf16(const float* qkv_dev, const int* lens_dev, const float* ou
 #define EVMI_MHA_BWD_DROP(DH, DROP, SLOT)                                                                                        \
   {                                                                                                                               \
     constexpr size_t lds = attention_dkv_bf16_lds<DH>();                                                                          \
-    static thread_local bool configured_dev[kMaxDevices][8] = {};                                                \
+    static thread_local bool configured_dev[kMaxDevices][12] = {};                                               \
     bool* configured = configured_dev[device_slot()];          \
     if (!configured[SLOT]) {                                                                                                      \
       EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)attention_train_dkv_bf16_kernel<DH, DROP>,                                  \
@@ -810,12 +869,13 @@ int evmi_mha_bwd_bf16(const float* qkv_dev, const int* lens_dev, const float* ou
   }
 #define EVMI_MHA_BWD(DH, SLOT)                                                                                                    \
   {                                                                                                                               \
-    if (p_drop > 0.f) EVMI_MHA_BWD_DROP(DH, true, SLOT)                                                                           \
-    else EVMI_MHA_BWD_DROP(DH, false, SLOT + 1)                                                                                   \
+    if (p_drop > 0.f && attn_drop_pairs(B, T)) EVMI_MHA_BWD_DROP(DH, 2, SLOT)                                                     \
+    else if (p_drop > 0.f) EVMI_MHA_BWD_DROP(DH, 1, SLOT + 1)                                                                     \
+    else EVMI_MHA_BWD_DROP(DH, 0, SLOT + 2)                                                                                       \
   }
   if (dh == 128) EVMI_MHA_BWD(128, 0)
-  else if (dh == 64) EVMI_MHA_BWD(64, 2)
-  else if (dh == 32) EVMI_MHA_BWD(32, 4)
+  else if (dh == 64) EVMI_MHA_BWD(64, 3)
+  else if (dh == 32) EVMI_MHA_BWD(32, 6)
   else return fail(EVMI_ERR_UNSUPPORTED, "mha_bwd_bf16: head dimension must be 32, 64 or 128");
 #undef EVMI_MHA_BWD
 #undef EVMI_MHA_BWD_DROP

@@ -206,24 +206,54 @@ struct SeedArg {
 // Counter-based uniform in [0, 1) for dropout masks: element i of the stream `seed`; the backward (and the attention kernels,
 // tile by tile) regenerate the same mask from the same (seed, i).  A keyed two-round 32-bit mix (the multiply / xor-shift rounds of
 // the `lowbias32` integer hash, the second key injected between the rounds so that streams are not shifted or permuted copies of
-// each other): 3 quarter-rate 32-bit multiplies per draw against the 12 of the splitmix64 it replaces -- at one draw per
-// probability the generator, not the exp, was the larger part of the attention kernels' element loop, and the fused dropout
-// passes sat at the edge of being compute-bound.  The seed-only part is wave-uniform (scalar unit).
-__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long i) {
+// each other): 3 quarter-rate 32-bit multiplies per hash against the 12 of the splitmix64 it replaces.  The seed-only part is
+// wave-uniform (scalar unit).
+// ONE hash serves TWO elements: elements 2 j and 2 j + 1 take the low and the high 16 bits of hash(seed, j) (a draw has 16 bits: the
+// keep probability is 1 - ceil(65536 p) / 65536, within 1.5e-5 of 1 - p).  Where the generator, not the memory system, bounds a
+// kernel -- the attention kernels draw one mask bit per probability, the matrix kernels' dropout epilogues one per output -- a
+// thread that holds both elements of a pair hashes once (dropout_pair), and two lanes that hold one each hash half of their
+// registers and exchange (dropout_lane_pairs); every other caller asks per element (uniform01): all three give the same bits.
+__device__ __forceinline__ unsigned dropout_hash(unsigned long long seed, unsigned j_lo, unsigned j_hi) {
   const unsigned k0 = (unsigned)seed * 0x9E3779B1u + 0x7F4A7C15u;
   unsigned k1 = (unsigned)(seed >> 32) ^ (k0 >> 15);
   k1 = k1 * 0x85EBCA6Bu + 0xC2B2AE35u;
-  unsigned h = (unsigned)i ^ k0;
-  h += (unsigned)(i >> 32) * 0x27D4EB2Fu;  // indices past 2^32 (not reached by these models) still get their own draws
+  unsigned h = j_lo ^ k0;
+  h += j_hi * 0x27D4EB2Fu;  // pair indices past 2^32 (not reached by these models) still get their own draws
   h ^= h >> 16;
   h *= 0x7FEB352Du;
   h ^= k1;
   h ^= h >> 15;
   h *= 0x846CA68Bu;
   h ^= h >> 16;
-  return (float)(h >> 8) * (1.0f / 16777216.0f);
+  return h;
+}
+__device__ __forceinline__ float dropout_u16(unsigned h, unsigned odd) { return (float)(odd ? h >> 16 : h & 0xFFFFu) * (1.0f / 65536.0f); }
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long i) {
+  const unsigned long long j = i >> 1;
+  return dropout_u16(dropout_hash(seed, (unsigned)j, (unsigned)(j >> 32)), (unsigned)i & 1u);
+}
+// elements 2 j and 2 j + 1 (j < 2^32: the caller's host side checks the tensor's size)
+__device__ __forceinline__ void dropout_pair(unsigned long long seed, unsigned j, float& u_even, float& u_odd) {
+  const unsigned h = dropout_hash(seed, j, 0u);
+  u_even = dropout_u16(h, 0u);
+  u_odd = dropout_u16(h, 1u);
 }
 
+
+// Sum over the 64 lanes of a wave, the same value returned in every lane: four DPP adds inside the rows of 16 lanes (quad swaps, half
+// mirror, mirror), then the four row sums through the scalar registers.  (`__shfl_xor` compiles to ds_bpermute_b32 -- an LDS-crossbar
+// round trip with its own s_waitcnt per step: the LayerNorm backward's 64 reductions per thread were 384 of them in a dependent
+// chain, a ~10 us floor under a kernel that moves 5-27 MB.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2, 3, 0, 1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
 
 // wait until at most n (wave-uniform) vector-memory operations of this wave are outstanding
 __device__ __forceinline__ void wait_vmcnt_le(int n) {

@@ -100,10 +100,13 @@ struct ConvPkArgs {
   } po;
 };
 
-// the feed-forward tails of a flat packed output for four channels of one unit (channels c .. c + 3 at element index idx0 + e * ld)
-template <int TAIL>
+// The feed-forward tails of a flat packed output for four channels of one unit: channels c .. c + 3 of column n, element index
+// (c + e) * ld + n.  ld is even (tight items: a multiple of 64), so the two elements of a dropout pair (common.h) are columns n, n ^ 1
+// of one channel -- neighbouring lanes, same register.  LANES: each lane hashes the two channels of its own parity and exchanges with
+// its neighbour (the matrix kernel's epilogue: all lanes live); otherwise one hash per element (the split-K reduce pass).
+template <int TAIL, bool LANES>
 __device__ __forceinline__ void pk_flat_tail_silu(float& v0, float& v1, float& v2, float& v3, float& s0, float& s1, float& s2, float& s3,
-                                                  uint2 pre, unsigned long long dseed, float p_drop, unsigned long long idx0,
+                                                  uint2 pre, unsigned long long dseed, float p_drop, unsigned long long c, unsigned long long n,
                                                   unsigned long long ld) {
   // (hardware exp2 / reciprocal, a multiply for the 1 / (1 - p) scale: the results are rounded to bf16 on the spot -- their last bits
   // do not survive it -- and this tail is ~40 vector instructions per element in the epilogue of a matrix kernel)
@@ -111,9 +114,24 @@ __device__ __forceinline__ void pk_flat_tail_silu(float& v0, float& v1, float& v
   const float z[4] = {bf16_lo(pre.x), bf16_hi(pre.x), bf16_lo(pre.y), bf16_hi(pre.y)};
   float* vp[4] = {&v0, &v1, &v2, &v3};
   float* sp[4] = {&s0, &s1, &s2, &s3};
+  float u[4];
+  if (LANES) {
+    const unsigned par = (unsigned)n & 1u, ldh = (unsigned)(ld >> 1);
+    const unsigned j0 = (unsigned)c * ldh + (unsigned)(n >> 1);  // (below 2^32: ffn_tail_check)
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      const unsigned mine = dropout_hash(dseed, j0 + (2u * c2 + par) * ldh, 0u);
+      const unsigned other = (unsigned)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]: lane ^ 1
+      u[2 * c2] = dropout_u16(par ? other : mine, par);
+      u[2 * c2 + 1] = dropout_u16(par ? mine : other, par);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = uniform01(dseed, (c + (unsigned long long)e) * ld + n);
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const bool keep = uniform01(dseed, idx0 + (unsigned long long)e * ld) >= p_drop;
+    const bool keep = u[e] >= p_drop;
     if (TAIL == 1) {
       const float val = *vp[e] * __builtin_amdgcn_rcpf(1.f + __expf(-*vp[e]));
       *sp[e] = keep ? val * rk : 0.f;
@@ -569,13 +587,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const int c = co0 + min(mb + 8 * i + 4 * kh, m_last & ~3);
-              const unsigned long long i0 = (unsigned long long)c * ld + (unsigned long long)dst_u;
+              // (the column itself, not dst_u: a lane past the last column still hashes for its pair -- with tight items they are equal)
               if (a.po.tail == 1)
-                pk_flat_tail_silu<1>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3], pre[i],
-                                     dseed, a.drop_p, i0, ld);
+                pk_flat_tail_silu<1, true>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3],
+                                           pre[i], dseed, a.drop_p, (unsigned long long)c, (unsigned long long)n, ld);
               else
-                pk_flat_tail_silu<2>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3], pre[i],
-                                     dseed, a.drop_p, i0, ld);
+                pk_flat_tail_silu<2, true>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3],
+                                           pre[i], dseed, a.drop_p, (unsigned long long)c, (unsigned long long)n, ld);
             }
           }
 #pragma unroll
@@ -740,13 +758,13 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
       uint4 pre = make_uint4(0u, 0u, 0u, 0u);
       if (a.po.tail == 2) pre = a.po.fm[(long long)oc * a.po.mplane + (long long)bb * a.po.Tm + u];
       const unsigned long long dseed = a.drop_seed.get(), ld = (unsigned long long)a.po.drop_ld;
-      const unsigned long long i0 = (unsigned long long)(oc * 8) * ld + (unsigned long long)du;
+      const unsigned long long c0 = (unsigned long long)(oc * 8), nn = (unsigned long long)du;
       if (a.po.tail == 1) {
-        pk_flat_tail_silu<1>(vc[0], vc[1], vc[2], vc[3], s2[0], s2[1], s2[2], s2[3], make_uint2(pre.x, pre.y), dseed, a.drop_p, i0, ld);
-        pk_flat_tail_silu<1>(vc[4], vc[5], vc[6], vc[7], s2[4], s2[5], s2[6], s2[7], make_uint2(pre.z, pre.w), dseed, a.drop_p, i0 + 4ull * ld, ld);
+        pk_flat_tail_silu<1, false>(vc[0], vc[1], vc[2], vc[3], s2[0], s2[1], s2[2], s2[3], make_uint2(pre.x, pre.y), dseed, a.drop_p, c0, nn, ld);
+        pk_flat_tail_silu<1, false>(vc[4], vc[5], vc[6], vc[7], s2[4], s2[5], s2[6], s2[7], make_uint2(pre.z, pre.w), dseed, a.drop_p, c0 + 4ull, nn, ld);
       } else {
-        pk_flat_tail_silu<2>(vc[0], vc[1], vc[2], vc[3], s2[0], s2[1], s2[2], s2[3], make_uint2(pre.x, pre.y), dseed, a.drop_p, i0, ld);
-        pk_flat_tail_silu<2>(vc[4], vc[5], vc[6], vc[7], s2[4], s2[5], s2[6], s2[7], make_uint2(pre.z, pre.w), dseed, a.drop_p, i0 + 4ull * ld, ld);
+        pk_flat_tail_silu<2, false>(vc[0], vc[1], vc[2], vc[3], s2[0], s2[1], s2[2], s2[3], make_uint2(pre.x, pre.y), dseed, a.drop_p, c0, nn, ld);
+        pk_flat_tail_silu<2, false>(vc[4], vc[5], vc[6], vc[7], s2[4], s2[5], s2[6], s2[7], make_uint2(pre.z, pre.w), dseed, a.drop_p, c0 + 4ull, nn, ld);
       }
     }
     uint4 st;
@@ -1550,7 +1568,8 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(int stage, const float* dy_dev, 
  * index = index in the fp32 tensor that is no longer stored); the one difference: silu' is taken at bf16(a) instead of a. */
 static int ffn_tail_check(const ConvPkArgs& a2, const PkPlan& pl2, int B, int t, int c_mid, float* next_ws, long long next_ws_elems, const char* who) {
   if (a2.Tp != t || pl2.PL != 0 || !pk_shared_items(B, t)) return fail(EVMI_ERR_UNSUPPORTED, std::string(who) + ": the consumer's items are not packed tight");
-  if ((long long)B * t >= (1LL << 31) || c_mid % 8) return fail(EVMI_ERR_UNSUPPORTED, std::string(who) + ": shape");
+  if ((long long)B * t >= (1LL << 31) || c_mid % 8 || (long long)c_mid * B * t >= (1LL << 33))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string(who) + ": shape (channels a multiple of 8, fewer than 2^33 elements)");
   if (!next_ws || next_ws_elems < (pl2.xp_units + pl2.wf_units) * 4 + pl2.part_elems || (reinterpret_cast<uintptr_t>(next_ws) & 15))
     return fail(EVMI_ERR_INVALID_ARG, std::string(who) + ": the consumer's workspace is missing, too small or unaligned");
   return EVMI_OK;

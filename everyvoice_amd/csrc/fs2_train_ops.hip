@@ -13,6 +13,7 @@
 //   softmax_rows / softmax_bwd   key-masked softmax rows (+ dropout) and its backward, in place on [B][Tq][Tk]
 //   glu_bwd, dropout             elementwise
 //   embedding / bucket / item-embedding backward (scatter-add), length regulator backward (segment sums)
+#include <algorithm>
 #include <cmath>
 
 #include "common.h"
@@ -24,11 +25,7 @@ namespace evmi {
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }  // (all 64 lanes live at every call site)
 
 // ---- LayerNorm backward --------------------------------------------------------------------------------------------
 // Workgroup = 64 columns x SL channel slices (one wave per slice): every thread keeps x and dy of its slice of one
@@ -131,6 +128,40 @@ __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __res
 #pragma unroll
     for (int q = 0; q < 16; ++q) t += sh[q][ch];
     float* dst = i < C ? out0 + i : out1 + (i - C);
+    *dst += (float)t;
+  }
+}
+
+// The same for a batch of partial lists in ONE launch (a training step's LayerNorm backwards leave their partials in buffers of
+// their own and the step reduces them together where its backward ends: one launch instead of one per LayerNorm on the chain).
+constexpr int COLSUM_MAX_JOBS = 32;
+struct ColsumBatch {
+  const float* part[COLSUM_MAX_JOBS];
+  float* out0[COLSUM_MAX_JOBS];
+  float* out1[COLSUM_MAX_JOBS];
+  int C[COLSUM_MAX_JOBS], nblk[COLSUM_MAX_JOBS];
+  int blk_start[COLSUM_MAX_JOBS + 1];  // workgroups, prefix sums
+  int n;
+};
+__global__ __launch_bounds__(256) void colsum_partials_batch_kernel(ColsumBatch q) {
+  __shared__ double sh[16][17];
+  int l = 0;
+  while (l + 1 < q.n && (int)blockIdx.x >= q.blk_start[l + 1]) ++l;
+  const float* __restrict__ part = q.part[l];
+  const int C = q.C[l], nblk = q.nblk[l];
+  const int ch = threadIdx.x & 15, seg = threadIdx.x >> 4;
+  const int i = ((int)blockIdx.x - q.blk_start[l]) * 16 + ch;
+  const int per = (nblk + 15) / 16;
+  double acc = 0.0;
+  if (i < 2 * C)
+    for (int b = seg * per; b < min(nblk, (seg + 1) * per); ++b) acc += (double)part[(long long)b * 2 * C + i];
+  sh[seg][ch] = acc;
+  __syncthreads();
+  if (seg == 0 && i < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int qq = 0; qq < 16; ++qq) t += sh[qq][ch];
+    float* dst = i < C ? q.out0[l] + i : q.out1[l] + (i - C);
     *dst += (float)t;
   }
 }
@@ -562,7 +593,7 @@ long long evmi_layernorm_bwd_cbt_f32_ws_elems(int C, long long n_cols) { return 
 
 int evmi_layernorm_bwd_cbt_f32(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* ws,
                                long long ws_elems, int C, long long n_cols, float eps, int accumulate_dx, void* stream) {
-  if (!x || !gamma || !dy || !dx || !dgamma || !dbeta || !ws) return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd: null pointer");
+  if (!x || !gamma || !dy || !dx || !ws || (dgamma == nullptr) != (dbeta == nullptr)) return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd: null pointer");
   if (C < 1 || C > 256 || n_cols < 1) return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd: 1 <= C <= 256 and n_cols >= 1 required");
   if (ws_elems < evmi_layernorm_bwd_cbt_f32_ws_elems(C, n_cols)) return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd: workspace too small");
   hipStream_t s = (hipStream_t)stream;
@@ -570,8 +601,28 @@ int evmi_layernorm_bwd_cbt_f32(const float* x, const float* gamma, const float* 
   if (C <= 64) hipLaunchKernelGGL((layernorm_bwd_cbt_kernel<16, 4>), dim3(nblk), dim3(256), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
   else hipLaunchKernelGGL((layernorm_bwd_cbt_kernel<32, 8>), dim3(nblk), dim3(512), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
   EVMI_LAUNCH_CHECK("layernorm_bwd_cbt");
+  if (!dgamma) return EVMI_OK;  // (the partial sums stay in ws: evmi_layernorm_bwd_partials_reduce)
   hipLaunchKernelGGL(colsum_partials_kernel, dim3((2 * C + 15) / 16), dim3(256), 0, s, ws, dgamma, dbeta, C, (int)nblk);
   EVMI_LAUNCH_CHECK("colsum_partials");
+  return EVMI_OK;
+}
+
+int evmi_layernorm_bwd_partials_reduce(int n_jobs, const evmi_ln_partials* jobs, void* stream) {
+  if (n_jobs < 0 || (n_jobs && !jobs)) return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd_partials_reduce: bad job list");
+  for (int j0 = 0; j0 < n_jobs; j0 += COLSUM_MAX_JOBS) {
+    ColsumBatch q;
+    q.n = std::min(COLSUM_MAX_JOBS, n_jobs - j0);
+    q.blk_start[0] = 0;
+    for (int j = 0; j < q.n; ++j) {
+      const evmi_ln_partials& jb = jobs[j0 + j];
+      if (!jb.ws || !jb.dgamma || !jb.dbeta || jb.C < 1 || jb.C > 256 || jb.n_cols < 1)
+        return fail(EVMI_ERR_INVALID_ARG, "layernorm_bwd_partials_reduce: null pointer or bad shape");
+      q.part[j] = jb.ws; q.out0[j] = jb.dgamma; q.out1[j] = jb.dbeta; q.C[j] = jb.C; q.nblk[j] = (int)((jb.n_cols + 63) / 64);
+      q.blk_start[j + 1] = q.blk_start[j] + (2 * jb.C + 15) / 16;
+    }
+    hipLaunchKernelGGL(colsum_partials_batch_kernel, dim3((unsigned)q.blk_start[q.n]), dim3(256), 0, (hipStream_t)stream, q);
+    EVMI_LAUNCH_CHECK("colsum_partials_batch");
+  }
   return EVMI_OK;
 }
 

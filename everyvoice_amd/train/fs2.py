@@ -1112,9 +1112,10 @@ class FastSpeech2Trainer:
     GRAPH_CACHE = 24  # captured shapes kept (least recently used out first)
 
     def _training_step(self, batch: dict) -> dict:
-        prev, prev_side, prev_base = ops.CONV_BACKEND["operands"], ops.SIDE_WGRAD["on"], ops.SEED_BASE[0]
+        prev, prev_side, prev_base, prev_ln = ops.CONV_BACKEND["operands"], ops.SIDE_WGRAD["on"], ops.SEED_BASE[0], ops.LN_DEFER["on"]
         ops.CONV_BACKEND["operands"] = self.precision
         ops.SIDE_WGRAD["on"] = self.side_wgrad and self.device.type == "cuda"
+        ops.LN_DEFER["on"] = self.device.type == "cuda"  # (reduced where the backward chains end: ops.wgrad_join)
         ops.SEED_BASE[0] = self._seed_base
         ops.side_reset()  # nothing an aborted step left collected reaches this one (ops.side_reset)
         try:
@@ -1141,6 +1142,7 @@ class FastSpeech2Trainer:
             ops.CONV_BACKEND["operands"] = prev
             ops.SIDE_WGRAD["on"] = prev_side
             ops.SEED_BASE[0] = prev_base
+            ops.LN_DEFER["on"] = prev_ln
         ops.side_check_drained()
         self.global_step += 1
         return losses

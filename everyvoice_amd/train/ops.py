@@ -276,6 +276,10 @@ class side_wgrad:
 def side_check_drained():
     """Raises if weight-gradient launches are still collected on the host (a chain ended without its ``wgrad_join``): the trainers
     call this at the end of every step."""
+    if _LN_PENDING:
+        n_ln = len(_LN_PENDING)
+        _LN_PENDING.clear()
+        raise RuntimeError(f"layernorm_bwd: {n_ln} deferred parameter-gradient reductions were never issued (a backward chain ended without wgrad_join)")
     left = sum(len(st.queue) for st in _SIDE.values())
     if left:
         for st in _SIDE.values():
@@ -296,11 +300,13 @@ def side_reset():
         st.keep_next.clear()
         st.keep.clear()
         st.pending = None
+    _LN_PENDING.clear()
 
 
 def wgrad_join(device=None):
     """The current stream waits for the weight-gradient kernels its sibling stream still has queued (the launches still collected on
     the host are issued first); their inputs may go."""
+    layernorm_flush()
     if not _SIDE:
         return
     cur = torch.cuda.current_stream(device)
@@ -1118,13 +1124,40 @@ def layernorm(x, gamma, beta, eps=1e-5):
     return y
 
 
+# LayerNorm parameter gradients reduced once per backward chain: with LN_DEFER["on"] (the FastSpeech2 trainer, around its step) a
+# LayerNorm backward leaves its per-workgroup partial sums in a buffer of its own and ``wgrad_join`` -- where every chain ends --
+# reduces all the lists collected since in one launch (55 small launches on the step's critical chain otherwise).
+LN_DEFER = {"on": False}
+_LN_PENDING = []  # (partials, dgamma, dbeta, C, N, stream)
+
+
+def layernorm_flush():
+    """Reduce the partial lists the deferred LayerNorm backwards left (on the current stream, which issued them)."""
+    if not _LN_PENDING:
+        return
+    jobs = (_lib.LnPartials * len(_LN_PENDING))()
+    for j, (ws, dg, db, C, N) in zip(jobs, _LN_PENDING):
+        j.ws, j.dgamma, j.dbeta, j.C, j.n_cols = ws.data_ptr(), dg.data_ptr(), db.data_ptr(), C, N
+    dev = _LN_PENDING[0][0].device
+    try:
+        _chk(_lib.load().evmi_layernorm_bwd_partials_reduce(len(_LN_PENDING), jobs, _lib.current_stream_ptr(dev)), "evmi_layernorm_bwd_partials_reduce")
+    finally:
+        _LN_PENDING.clear()
+
+
 def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5):
-    """dx; dgamma / dbeta are accumulated into."""
+    """dx; dgamma / dbeta are accumulated into (with LN_DEFER["on"]: by the chain's ``wgrad_join``)."""
     lib = _lib.load()
     C, N = x.shape[0], x.shape[1] * x.shape[2]
     n = lib.evmi_layernorm_bwd_cbt_f32_ws_elems(C, N)
-    ws = WS.get("ln_bwd", n, x.device)
     dx = torch.empty_like(x)
+    if LN_DEFER["on"] and x.is_cuda:
+        ws = torch.empty(n, device=x.device, dtype=torch.float32)
+        _chk(lib.evmi_layernorm_bwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), n, C, N, eps, 0, _s(x)),
+             "evmi_layernorm_bwd_cbt_f32")
+        _LN_PENDING.append((ws, dgamma, dbeta, C, N))
+        return dx
+    ws = WS.get("ln_bwd", n, x.device)
     _chk(lib.evmi_layernorm_bwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                         ws.data_ptr(), n, C, N, eps, 0, _s(x)), "evmi_layernorm_bwd_cbt_f32")
     return dx

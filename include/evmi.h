@@ -762,6 +762,17 @@ long long evmi_layernorm_bwd_cbt_f32_ws_elems(int C, long long n_cols);
 int evmi_layernorm_bwd_cbt_f32(const float* x_dev, const float* gamma_dev, const float* dy_dev, float* dx_dev,
                                float* dgamma_dev, float* dbeta_dev, float* ws_dev, long long ws_elems, int C,
                                long long n_cols, float eps, int accumulate_dx, void* stream);
+/* dgamma_dev == dbeta_dev == NULL above: the parameter gradients are NOT reduced -- their partial sums stay in ws (which the caller
+ * then keeps) and a later call reduces the partial lists of many LayerNorms in one launch (same fixed order, same bits): a training
+ * step's backward issues it once where the chain ends instead of one small launch per LayerNorm on the chain. */
+typedef struct evmi_ln_partials {
+  const float* ws;     /* the ws of an evmi_layernorm_bwd_cbt_f32 call with NULL gradients */
+  float* dgamma;       /* [C], accumulated into */
+  float* dbeta;        /* [C], accumulated into */
+  int C;
+  long long n_cols;    /* of that call */
+} evmi_ln_partials;
+int evmi_layernorm_bwd_partials_reduce(int n_jobs, const evmi_ln_partials* jobs, void* stream);
 /* BatchNorm1d in training mode over every column of a channel row, followed by act (0 none, 2 SiLU, 4 tanh):
  * writes the batch mean / 1/sqrt(var + eps) [C] and, when given, updates the running statistics (unbiased variance).
  * momentum < 0: evaluation mode (model.eval() in the reference's validation loop) -- the running statistics normalise and are
