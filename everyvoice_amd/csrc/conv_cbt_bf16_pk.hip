@@ -101,9 +101,9 @@ struct ConvPkArgs {
 };
 
 // The feed-forward tails of a flat packed output for four channels of one unit: channels c .. c + 3 of column n, element index
-// (c + e) * ld + n.  ld is even (tight items: a multiple of 64), so the two elements of a dropout pair (common.h) are columns n, n ^ 1
-// of one channel -- neighbouring lanes, same register.  LANES: each lane hashes the two channels of its own parity and exchanges with
-// its neighbour (the matrix kernel's epilogue: all lanes live); otherwise one hash per element (the split-K reduce pass).
+// (c + e) * ld + n.  With ld even the two elements of a dropout pair (common.h) are columns n, n ^ 1 of one channel -- neighbouring
+// lanes, same register.  LANES (ld even, all lanes live: the matrix kernel's epilogue): each lane hashes the two channels of its own
+// parity and exchanges with its neighbour; otherwise one hash per element (odd ld; the split-K reduce pass).
 template <int TAIL, bool LANES>
 __device__ __forceinline__ void pk_flat_tail_silu(float& v0, float& v1, float& v2, float& v3, float& s0, float& s1, float& s2, float& s3,
                                                   uint2 pre, unsigned long long dseed, float p_drop, unsigned long long c, unsigned long long n,
@@ -588,12 +588,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
             for (int i = 0; i < 4; ++i) {
               const int c = co0 + min(mb + 8 * i + 4 * kh, m_last & ~3);
               // (the column itself, not dst_u: a lane past the last column still hashes for its pair -- with tight items they are equal)
-              if (a.po.tail == 1)
-                pk_flat_tail_silu<1, true>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3],
-                                           pre[i], dseed, a.drop_p, (unsigned long long)c, (unsigned long long)n, ld);
-              else
-                pk_flat_tail_silu<2, true>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3],
-                                           pre[i], dseed, a.drop_p, (unsigned long long)c, (unsigned long long)n, ld);
+              // (an odd row length -- a single item of any length -- puts a pair's elements in lanes n, n +- 1 depending on the channel:
+              // one hash per element there)
+#define EVMI_PK_TAIL(T_, L_)                                                                                                                  \
+  pk_flat_tail_silu<T_, L_>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3], pre[i], dseed, \
+                            a.drop_p, (unsigned long long)c, (unsigned long long)n, ld)
+              if (ld & 1ull) {
+                if (a.po.tail == 1) EVMI_PK_TAIL(1, false);
+                else EVMI_PK_TAIL(2, false);
+              } else {
+                if (a.po.tail == 1) EVMI_PK_TAIL(1, true);
+                else EVMI_PK_TAIL(2, true);
+              }
+#undef EVMI_PK_TAIL
             }
           }
 #pragma unroll
@@ -784,13 +791,14 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
 template <int CPT>  // channels per thread = C / 4 (a multiple of 8)
 __global__ __launch_bounds__(256) void layernorm_pack_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, uint4* __restrict__ xp, int C, long long N,
-                                                            float eps, int slack_units) {
+                                                            long long plane, float eps, int slack_units) {
+  // (plane >= N: units per octet row; the units behind column N - 1 of every row are zero -- grid = ceil(plane / 64))
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const long long n = (long long)blockIdx.x * 64 + lane;
   const bool live = n < N;
   if (blockIdx.x == 0) {  // the zero slack behind the packed tensor (what pack_x_block's last block writes)
-    uint4* tail = xp + (long long)(C / 8) * N;
+    uint4* tail = xp + (long long)(C / 8) * plane;
     for (int i = threadIdx.x; i < slack_units; i += 256) tail[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   const int c0 = slice * CPT;
@@ -814,7 +822,13 @@ __global__ __launch_bounds__(256) void layernorm_pack_kernel(const float* __rest
   __syncthreads();
   const float var = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / (float)C;
   const float rstd = 1.f / sqrtf(var + eps);
-  if (!live) return;
+  if (!live) {
+    if (n < plane) {
+#pragma unroll
+      for (int o = 0; o < CPT / 8; ++o) xp[(long long)(slice * CPT / 8 + o) * plane + n] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    return;
+  }
 #pragma unroll
   for (int o = 0; o < CPT / 8; ++o) {
     float r[8];
@@ -828,7 +842,7 @@ __global__ __launch_bounds__(256) void layernorm_pack_kernel(const float* __rest
     out.y = pk_bf16x2(r[2], r[3]);
     out.z = pk_bf16x2(r[4], r[5]);
     out.w = pk_bf16x2(r[6], r[7]);
-    xp[(long long)(c0 / 8 + o) * N + n] = out;
+    xp[(long long)(c0 / 8 + o) * plane + n] = out;
   }
 }
 
@@ -891,8 +905,11 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
     const long long want_mod = ((long long)n_max * a.stride) & 15;
     if (align_tp && ext >= 96) ext += ((want_mod - (ext & 15)) + 16) & 15;  // (short items: the padding would cost more than the conflicts)
   }
-  // pointwise stride-1 layers are packed tight (ext == t_in here): the layout the weight gradient reads too (conv_pk_common.h)
-  const bool shared = a.phases == 1 && PL == 0 && pk_shared_shape(a.k, a.stride, 0, a.dil, groups) && ext == t_in && pk_shared_items(a.B, t_in);
+  // pointwise stride-1 layers are packed tight (ext == t_in here): the layout the weight gradient reads too (conv_pk_common.h); a
+  // single item's row is rounded up to the weight gradient's K step (nothing follows it: the pitch is free)
+  const bool pointwise = a.phases == 1 && PL == 0 && pk_shared_shape(a.k, a.stride, 0, a.dil, groups) && ext == t_in;
+  if (pointwise && a.B == 1) ext = pk_shared_pitch(1, t_in);
+  const bool shared = pointwise && pk_shared_items(a.B, t_in);
   a.Tp = (int)ext;
   const long long n_total = (long long)a.B * n_max;
   auto blocks = [&](int i) {
@@ -1378,20 +1395,20 @@ int evmi_layernorm_pack_bf16pk(const float* x_dev, const float* gamma_dev, const
                                int c_in, int t_in, int c_out, float eps, void* stream) {
   if (!x_dev || !gamma_dev || !beta_dev || !ws_dev) return fail(EVMI_ERR_INVALID_ARG, "layernorm_pack_bf16pk: null pointer");
   if (c_in != 128 && c_in != 256) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: 128 or 256 channels");
-  if (!pk_shared_items(B, t_in)) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: B * t must be a multiple of 64");
+  if (!pk_shared_items(B, t_in)) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: B * t must be a multiple of 64 (or one item)");
   ConvPkArgs a = {};
   PkPlan pl;
   if (const char* why = plan_fwd_pk(a, pl, B, c_in, t_in, c_out, t_in, t_in, 1, 1, 0, 1, 1, 1, 0))
     return fail(EVMI_ERR_UNSUPPORTED, std::string("layernorm_pack_bf16pk: ") + why);
-  if (a.Tp != t_in || pl.PL != 0) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: the layer's items are not packed tight");
+  if (a.Tp != pk_shared_pitch(B, t_in) || pl.PL != 0) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: the layer's items are not packed tight");
   if (ws_elems < (pl.xp_units + pl.wf_units) * 4 + pl.part_elems || (reinterpret_cast<uintptr_t>(ws_dev) & 15))
     return fail(EVMI_ERR_INVALID_ARG, "layernorm_pack_bf16pk: workspace too small or unaligned");
-  const long long N = (long long)B * t_in;
-  const int slack = (int)(pl.xp_units - (long long)a.octs * N);
-  const dim3 grid((unsigned)((N + 63) / 64));
+  const long long N = (long long)B * t_in, plane = (long long)B * a.Tp;
+  const int slack = (int)(pl.xp_units - (long long)a.octs * plane);
+  const dim3 grid((unsigned)((plane + 63) / 64));
   uint4* xp = reinterpret_cast<uint4*>(ws_dev);
-  if (c_in == 256) hipLaunchKernelGGL(layernorm_pack_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, eps, slack);
-  else hipLaunchKernelGGL(layernorm_pack_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, eps, slack);
+  if (c_in == 256) hipLaunchKernelGGL(layernorm_pack_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, plane, eps, slack);
+  else hipLaunchKernelGGL(layernorm_pack_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, plane, eps, slack);
   EVMI_LAUNCH_CHECK("layernorm_pack");
   return EVMI_OK;
 }
@@ -1566,8 +1583,17 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(int stage, const float* dy_dev, 
  *                bias gradient read the same units)
  * Same mask stream and arithmetic as evmi_conv1d_cbt_bf16pk_silu_dropout / ..._staged_silu_dropout (seed_value + *seed_base_dev, element
  * index = index in the fp32 tensor that is no longer stored); the one difference: silu' is taken at bf16(a) instead of a. */
+// zero what a pack pass would have: units [N, plane) of every octet row (a single item's rounded-up pitch) and the slack behind the tensor
+static int ffn_zero_tails(uint4* xp, int octs, long long N, long long plane, long long xp_units, hipStream_t stream) {
+  if (plane > N) EVMI_HIP_CHECK(hipMemset2DAsync(xp + N, (size_t)plane * 16, 0, (size_t)(plane - N) * 16, (size_t)octs, stream));
+  const long long used = (long long)octs * plane;
+  if (xp_units > used) EVMI_HIP_CHECK(hipMemsetAsync(xp + used, 0, (size_t)(xp_units - used) * 16, stream));
+  return EVMI_OK;
+}
+
 static int ffn_tail_check(const ConvPkArgs& a2, const PkPlan& pl2, int B, int t, int c_mid, float* next_ws, long long next_ws_elems, const char* who) {
-  if (a2.Tp != t || pl2.PL != 0 || !pk_shared_items(B, t)) return fail(EVMI_ERR_UNSUPPORTED, std::string(who) + ": the consumer's items are not packed tight");
+  if (a2.Tp != pk_shared_pitch(B, t) || pl2.PL != 0 || !pk_shared_items(B, t))
+    return fail(EVMI_ERR_UNSUPPORTED, std::string(who) + ": the consumer's items are not packed tight");
   if ((long long)B * t >= (1LL << 31) || c_mid % 8 || (long long)c_mid * B * t >= (1LL << 33))
     return fail(EVMI_ERR_UNSUPPORTED, std::string(who) + ": shape (channels a multiple of 8, fewer than 2^33 elements)");
   if (!next_ws || next_ws_elems < (pl2.xp_units + pl2.wf_units) * 4 + pl2.part_elems || (reinterpret_cast<uintptr_t>(next_ws) & 15))
@@ -1587,14 +1613,14 @@ int evmi_conv1d_cbt_bf16pk_ffn_up(const float* w_dev, const float* bias_dev, flo
   if (const char* why = plan_fwd_pk(a2, pl2, B, c_mid, t, c_out, t, t, 1, 1, 0, 1, 1, 1, 0))
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk_ffn_up (second layer): ") + why);
   if (int rc = ffn_tail_check(a2, pl2, B, t, c_mid, next_ws_dev, next_ws_elems, "conv1d_cbt_bf16pk_ffn_up")) return rc;
-  const long long N = (long long)B * t;
+  const long long N = (long long)B * t, plane = (long long)B * a2.Tp;
   uint4* nxt = reinterpret_cast<uint4*>(next_ws_dev);
-  // the zero slack behind the second layer's packed input (the pack pass that no longer runs wrote it)
-  const long long used = (long long)a2.octs * N;
-  EVMI_HIP_CHECK(hipMemsetAsync(nxt + used, 0, (size_t)(pl2.xp_units - used) * 16, (hipStream_t)stream));
+  // the zeros the pack pass that no longer runs wrote: the slack behind the second layer's packed input and, in a single item's rows,
+  // the units behind the last column
+  if (int rc = ffn_zero_tails(nxt, a2.octs, N, plane, pl2.xp_units, (hipStream_t)stream)) return rc;
   a.bias = bias_dev; a.y = nullptr; a.accumulate = 0; a.act = 0; a.act_param = 0.f;
-  a.po.y = reinterpret_cast<uint4*>(a_pk_dev); a.po.y2 = nxt; a.po.plane = N; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
-  a.po.tail = 1; a.po.drop_ld = N; a.po.Tm = (int)N; a.po.mplane = N;
+  a.po.y = reinterpret_cast<uint4*>(a_pk_dev); a.po.y2 = nxt; a.po.plane = plane; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
+  a.po.tail = 1; a.po.drop_ld = N; a.po.Tm = (int)N; a.po.mplane = plane;
   a.drop_p = p; a.drop_seed = SeedArg{seed_value, seed_base_dev};
   return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_mid, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 2);
 }
@@ -1612,13 +1638,12 @@ int evmi_conv1d_dgrad_cbt_bf16pk_ffn_down(const float* w_dev, float* ws_dev, lon
   if (const char* why = plan_dgrad_pk(a1, pl1, B, c_in, t, c_mid, t, 1, 1, 0, 1, 1))
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_dgrad_cbt_bf16pk_ffn_down (first layer): ") + why);
   if (int rc = ffn_tail_check(a1, pl1, B, t, c_mid, next_ws_dev, next_ws_elems, "conv1d_dgrad_cbt_bf16pk_ffn_down")) return rc;
-  const long long N = (long long)B * t;
+  const long long N = (long long)B * t, plane = (long long)B * a1.Tp;
   uint4* nxt = reinterpret_cast<uint4*>(next_ws_dev);
-  const long long used = (long long)a1.octs * N;
-  EVMI_HIP_CHECK(hipMemsetAsync(nxt + used, 0, (size_t)(pl1.xp_units - used) * 16, (hipStream_t)stream));
+  if (int rc = ffn_zero_tails(nxt, a1.octs, N, plane, pl1.xp_units, (hipStream_t)stream)) return rc;
   a.y = nullptr;
-  a.po.y = nxt; a.po.plane = N; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
-  a.po.tail = 2; a.po.drop_ld = N; a.po.fm = reinterpret_cast<const uint4*>(a_pk_dev); a.po.Tm = (int)N; a.po.mplane = N;
+  a.po.y = nxt; a.po.plane = plane; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
+  a.po.tail = 2; a.po.drop_ld = N; a.po.fm = reinterpret_cast<const uint4*>(a_pk_dev); a.po.Tm = (int)N; a.po.mplane = plane;
   a.drop_p = p; a.drop_seed = SeedArg{seed_value, seed_base_dev};
   return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 1, c_mid, c_out, 1, 1, (hipStream_t)stream, PkInputFusion(), 2);
 }

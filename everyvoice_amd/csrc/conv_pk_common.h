@@ -138,7 +138,11 @@ __device__ __forceinline__ void pack_x_block(const PackArgs& p, int bx, int b, i
 // 90 launches, 1.6 ms of a FastSpeech2 step).  PK_SHARED_SLACK: units behind the tensor that are kept zero (the weight gradient's
 // staging reads a window past the end).
 static inline bool pk_shared_shape(int k, int stride, int pad, int dil, int groups) { return k == 1 && stride == 1 && pad == 0 && dil == 1 && groups == 1; }
-static inline bool pk_shared_items(int B, int n) { return ((long long)B * n) % 64 == 0; }
+// A layer called with ONE item (B == 1: a caller whose layer is position-wise hands over all its columns as one row -- the FastSpeech2
+// dense layers do) shares for EVERY length: the row pitch of a single item is free, so it is rounded up to the K step and the units
+// behind the row's last column are zero (pk_shared_pitch).
+static inline bool pk_shared_items(int B, int n) { return B == 1 || ((long long)B * n) % 64 == 0; }
+static inline long long pk_shared_pitch(int B, int n) { return B == 1 ? ((long long)n + 63) / 64 * 64 : n; }  // units per item
 constexpr int PK_SHARED_SLACK = 384;
 
 static inline PackArgs make_pack_args(const float* x, uint4* xp, int cin_g, int octs, int B, int t_in, int Tp, int PL, int slack_units,

@@ -302,7 +302,7 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
   while (Tq * stride < need || ((long long)B * Tq) % WG_KS) Tq += 16;
   // pointwise stride-1 layers whose rows end on a K step anyway: tight items, the layout the convolution kernels pack (conv_pk_common.h)
   static_assert(WG_KS == 64, "pk_shared_items states the K step");
-  if (pk_shared_shape(k, stride, pad, dil, groups) && pk_shared_items(B, n_out) && t_in == n_out) Tq = n_out;
+  if (pk_shared_shape(k, stride, pad, dil, groups) && pk_shared_items(B, n_out) && t_in == n_out) Tq = pk_shared_pitch(B, n_out);
   if (Tq > (1 << 22)) return "row too long";
   pl.Tq = (int)Tq;
   a.plane_y = (long long)B * Tq;
@@ -642,7 +642,7 @@ static int wgrad_pk_impl(const float* x_dev, const float* dy_dev, float* dw_dev,
   py.mask = dy_mask_dev; py.mask_slope = dy_mask_slope;
   // an operand that arrives packed (the forward convolution's input / the input-gradient convolution's dy, in the shared item
   // layout: plan_wgrad_pk's Tq is the tight t_in for these shapes) is read where it lies; its pack is an empty grid
-  if ((x_packed_dev || dy_packed_dev) && !(pk_shared_items(B, n_out) && pl.Tq == n_out && t_in == n_out))
+  if ((x_packed_dev || dy_packed_dev) && !(pk_shared_items(B, n_out) && pl.Tq == pk_shared_pitch(B, n_out) && t_in == n_out))
     return fail(EVMI_ERR_INVALID_ARG, "conv1d_wgrad_cbt_bf16pk: packed operands need rows that end on a K step (B * t a multiple of 64)");
   if (dy_packed_dev) py.gx = py.gy = py.gz = 0;
   if (x_packed_dev) px.gx = px.gy = px.gz = 0;

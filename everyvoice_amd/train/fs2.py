@@ -188,6 +188,18 @@ class Table:
 
 
 # ---- tape operators ---------------------------------------------------------------------------------------------------
+def _row(t):
+    """[C, B, T] -> [C, 1, B * T] (a view): a position-wise layer sees all its columns as ONE item, the form in which the packed bf16
+    kernels share one packed copy of every operand between forward, input gradient and weight gradient for any B * T
+    (csrc/conv_pk_common.h: pk_shared_items) -- with B items that needs B * T to be a multiple of 64."""
+    return t if (t.shape[1] == 1 or not ops._packed()) else t.reshape(t.shape[0], 1, -1)
+
+
+def _items(B, T):
+    """(items, columns per item) as `_row` hands a [C, B, T] tensor to a position-wise layer."""
+    return (1, B * T) if ops._packed() else (B, T)
+
+
 _EVAL = [False]  # FastSpeech2Trainer.evaluate: dropout off, BatchNorm on its running statistics (and not updating them)
 
 
@@ -196,7 +208,9 @@ def dense(tape: Tape, x: Var, layer, act=ops.ACT_NONE) -> Var:
     assert act in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_TANH)
     w, dw_sink = layer.effective(True)
     packed = {}  # pointwise layers on the packed bf16 kernels: x is packed once (here), dy once (input gradient), for all three products
-    y = Var(ops.conv1d_fwd(x.data, w, layer.bias_data(), 1, layer.pad, 1, 1, act=act, keep=packed))
+    shape = x.data.shape
+    row = (lambda t: _row(t)) if layer.k == 1 else (lambda t: t)  # (pointwise: one item)
+    y = Var(ops.conv1d_fwd(row(x.data), w, layer.bias_data(), 1, layer.pad, 1, 1, act=act, keep=packed).view(-1, shape[1], shape[2] + 2 * layer.pad - layer.k + 1))
 
     def bwd():
         if y.grad is None:
@@ -206,11 +220,11 @@ def dense(tape: Tape, x: Var, layer, act=ops.ACT_NONE) -> Var:
             dy = ops.elementwise(ops.EW_RELU_BWD, dy, y.data)
         elif act == ops.ACT_TANH:
             dy = ops.tanh_bwd(dy, y.data)
-        dx, _, _ = ops.conv1d_bwd(x.data, w, dy, 1, layer.pad, 1, 1, need_dx=x.needs_grad, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True,
+        dx, _, _ = ops.conv1d_bwd(row(x.data), w, row(dy), 1, layer.pad, 1, 1, need_dx=x.needs_grad, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True,
                                   packed=packed)
         packed.clear()
         if dx is not None:
-            x.accumulate(dx)
+            x.accumulate(dx.view(shape))
 
     tape.record(bwd)
     return y
@@ -292,18 +306,18 @@ def dense_residual_dropout(tape: Tape, a: Var, h: Var, layer, p: float, seed: in
     three products (ops.conv1d_bwd_dropout_dy): per site one elementwise launch and one fp32 tensor write + read less in each
     direction (32 sites per FastSpeech2 step).  Elsewhere: the two operators it stands for."""
     C, B, T = h.data.shape
-    if p <= 0.0 or _EVAL[0] or layer.k != 1 or not ops.resdrop_fused_supported(B, T, C, layer.cout):
+    if p <= 0.0 or _EVAL[0] or layer.k != 1 or not ops.resdrop_fused_supported(*_items(B, T), C, layer.cout):
         return residual_dropout(tape, a, dense(tape, h, layer), p, seed, sb)
     w, dw_sink = layer.effective(True)
     packed = {}
-    y = Var(ops.conv1d_fwd_resdrop(h.data, w, layer.bias_data(), a.data, p, seed, sb, packed))
+    y = Var(ops.conv1d_fwd_resdrop(_row(h.data), w, layer.bias_data(), _row(a.data), p, seed, sb, packed).view(a.data.shape))
 
     def bwd():
         if y.grad is None:
             return
-        dh = ops.conv1d_bwd_dropout_dy(h.data, w, y.grad, p, seed, sb, dw_sink, layer.db_sink(), packed)
+        dh = ops.conv1d_bwd_dropout_dy(_row(h.data), w, _row(y.grad), p, seed, sb, dw_sink, layer.db_sink(), packed)
         packed.clear()
-        h.accumulate(dh)
+        h.accumulate(dh.view(h.data.shape))
         a.accumulate(y.grad)
 
     tape.record(bwd)
@@ -324,20 +338,20 @@ def ln_dense(tape: Tape, x: Var, ln: Affine, layer) -> Var:
     packed input (ops.layernorm_dense_fwd) and never exists in fp32 -- its only other reader, the layer's weight gradient, takes the
     packed copy; LayerNorm's own backward needs x, not its output.  Elsewhere: the two operators."""
     C, B, T = x.data.shape
-    if not ops.ln_dense_fused_supported(B, T, C, layer.cout) or layer.k != 1:
+    if not ops.ln_dense_fused_supported(*_items(B, T), C, layer.cout) or layer.k != 1:
         return dense(tape, layernorm(tape, x, ln), layer)
     w, dw_sink = layer.effective(True)
     packed = {}
-    y = Var(ops.layernorm_dense_fwd(x.data, ln.gamma(), ln.beta(), w, layer.bias_data(), packed))
+    y = Var(ops.layernorm_dense_fwd(_row(x.data), ln.gamma(), ln.beta(), w, layer.bias_data(), packed).view(-1, B, T))
 
     def bwd():
         if y.grad is None:
             return
         # (x.data stands in for the normalised tensor, which was never stored: only its shape is read -- the weight gradient takes the packed copy)
-        dh, _, _ = ops.conv1d_bwd(x.data, w, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True, packed=packed,
+        dh, _, _ = ops.conv1d_bwd(_row(x.data), w, _row(y.grad), 1, 0, 1, 1, need_dx=True, dw_out=dw_sink, db_out=layer.db_sink(), accumulate=True, packed=packed,
                                    x_standin=True)
         packed.clear()
-        x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh, ln.dgamma(), ln.dbeta()))
+        x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh.view(x.data.shape), ln.dgamma(), ln.dbeta()))
 
     tape.record(bwd)
     return y
@@ -352,41 +366,43 @@ def ffn_core(tape: Tape, x: Var, ln: Affine, l1, l2, p: float, seed: int, res: V
     ``res``: the block's residual input -- the operator then returns res + sb * dropout(that, p) with the add and the mask (seed_out) in
     the second layer's epilogue and sb * dropout(dy) formed while dy is packed (dense_residual_dropout's fusion)."""
     C, B, T = x.data.shape
-    if p <= 0.0 or _EVAL[0] or not ops.ffn_fused_supported(B, T, l1.cout, l2.cout):
+    N = B * T  # (position-wise layers: all columns as one item, _row)
+    if p <= 0.0 or _EVAL[0] or not ops.ffn_fused_supported(*_items(B, T), l1.cout, l2.cout):
         h = dense(tape, silu_dropout(tape, ln_dense(tape, x, ln, l1), p, seed), l2)
         return h if res is None else residual_dropout(tape, res, h, p, seed_out, sb)
     w1, dw1 = l1.effective(True)
     w2, dw2 = l2.effective(True)
-    if res is not None and ops.ffn_packed_supported(B, T, C, l1.cout, l2.cout):
+    xr = _row(x.data)
+    if res is not None and ops.ffn_packed_supported(*_items(B, T), C, l1.cout, l2.cout):
         # the whole block as a packed chain: the c_mid-channel tensors (pre-activation, activated + masked, and its gradient) exist as
         # packed bf16 only, written by the producing layers' epilogues (ops.ffn_packed_fwd)
         keep = {}
-        yp = Var(ops.ffn_packed_fwd(x.data, ln.gamma(), ln.beta(), w1, l1.bias_data(), w2, l2.bias_data(), res.data, p, seed, seed_out, sb, keep))
-        _ACTIVATION_ELEMS[0] += l1.cout * B * T  # (the pre-activation: the tensor the separate operators count as dense1's output)
+        yp = Var(ops.ffn_packed_fwd(xr, ln.gamma(), ln.beta(), w1, l1.bias_data(), w2, l2.bias_data(), _row(res.data), p, seed, seed_out, sb, keep).view(-1, B, T))
+        _ACTIVATION_ELEMS[0] += l1.cout * N  # (the pre-activation: the tensor the separate operators count as dense1's output)
 
         def bwd_packed():
             if yp.grad is None:
                 return
-            dh = ops.ffn_packed_bwd(x.data, w1, w2, yp.grad, p, seed, seed_out, sb, dw1, l1.db_sink(), dw2, l2.db_sink(), keep)
+            dh = ops.ffn_packed_bwd(xr, w1, w2, _row(yp.grad), p, seed, seed_out, sb, dw1, l1.db_sink(), dw2, l2.db_sink(), keep)
             keep.clear()
-            x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh, ln.dgamma(), ln.dbeta()))
+            x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh.view(x.data.shape), ln.dgamma(), ln.dbeta()))
             res.accumulate(yp.grad)
 
         tape.record(bwd_packed)
         return yp
     packed1, packed2 = {}, {}
-    ln_fused = ops.ln_dense_fused_supported(B, T, C, l1.cout)
+    ln_fused = ops.ln_dense_fused_supported(*_items(B, T), C, l1.cout)
     if ln_fused:
         h = None
-        a = ops.layernorm_dense_fwd(x.data, ln.gamma(), ln.beta(), w1, l1.bias_data(), packed1)
+        a = ops.layernorm_dense_fwd(xr, ln.gamma(), ln.beta(), w1, l1.bias_data(), packed1)
     else:
         h = layernorm(tape, x, ln)
-        a = ops.conv1d_fwd(h.data, w1, l1.bias_data(), 1, l1.pad, 1, 1, keep=packed1)
-    fuse_out = res is not None and ops.resdrop_fused_supported(B, T, l1.cout, l2.cout)
+        a = ops.conv1d_fwd(_row(h.data), w1, l1.bias_data(), 1, l1.pad, 1, 1, keep=packed1)
+    fuse_out = res is not None and ops.resdrop_fused_supported(*_items(B, T), l1.cout, l2.cout)
     if fuse_out:
-        y = Var(ops.conv1d_fwd_resdrop(a, w2, l2.bias_data(), res.data, p, seed_out, sb, packed2, in_p=p, in_seed=seed))
+        y = Var(ops.conv1d_fwd_resdrop(a, w2, l2.bias_data(), _row(res.data), p, seed_out, sb, packed2, in_p=p, in_seed=seed).view(-1, B, T))
     else:
-        y = Var(ops.conv1d_fwd_silu_dropout(a, w2, l2.bias_data(), p, seed, packed2))
+        y = Var(ops.conv1d_fwd_silu_dropout(a, w2, l2.bias_data(), p, seed, packed2).view(-1, B, T))
     _ACTIVATION_ELEMS[0] += a.numel()  # (the pre-activation: the tensor the separate operators count as dense1's output)
 
     def bwd():
@@ -394,13 +410,13 @@ def ffn_core(tape: Tape, x: Var, ln: Affine, l1, l2, p: float, seed: int, res: V
             return
         # second layer: its packed input is the forward's (a stands in for the fp32 tensor that was never stored: only its shape is read)
         if fuse_out:
-            ds = ops.conv1d_bwd_dropout_dy(a, w2, y.grad, p, seed_out, sb, dw2, l2.db_sink(), packed2, x_standin=True)
+            ds = ops.conv1d_bwd_dropout_dy(a, w2, _row(y.grad), p, seed_out, sb, dw2, l2.db_sink(), packed2, x_standin=True)
         else:
-            ds, _, _ = ops.conv1d_bwd(a, w2, y.grad, 1, 0, 1, 1, need_dx=True, dw_out=dw2, db_out=l2.db_sink(), accumulate=True, packed=packed2,
+            ds, _, _ = ops.conv1d_bwd(a, w2, _row(y.grad), 1, 0, 1, 1, need_dx=True, dw_out=dw2, db_out=l2.db_sink(), accumulate=True, packed=packed2,
                                        x_standin=True)
         packed2.clear()
         # first layer: x.data / h.data only lend their shape (the weight gradient reads the packed copy)
-        dh = ops.conv1d_bwd_silu_dropout_dy(x.data if ln_fused else h.data, w1, ds, a, p, seed, dw1, l1.db_sink(), packed1)
+        dh = ops.conv1d_bwd_silu_dropout_dy(xr if ln_fused else _row(h.data), w1, ds, a, p, seed, dw1, l1.db_sink(), packed1).view(x.data.shape)
         packed1.clear()
         if ln_fused:
             x.accumulate(ops.layernorm_bwd(x.data, ln.gamma(), dh, ln.dgamma(), ln.dbeta()))

@@ -325,6 +325,12 @@ def wgrad_join(device=None):
 ACT_NONE, ACT_LRELU, ACT_SILU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
 
 
+def pk_pitch(B, t) -> int:
+    """Units per channel-octet row of a shared packed operand (csrc/conv_pk_common.h: pk_shared_pitch): tight items, or -- one item -- its
+    length rounded up to the weight gradient's K step (the units behind the last column are zero)."""
+    return (t + 63) // 64 * 64 if B == 1 else B * t
+
+
 def shares_packed(B, t, k, stride, pad, dil, groups) -> bool:
     """True for the layers whose packed bf16 operands serve forward, input gradient AND weight gradient (pointwise, stride 1, B * t a
     multiple of the weight gradient's K step)."""
@@ -761,7 +767,7 @@ def conv1d_bwd_silu_dropout_dy(x, w, ds, pre, p, seed, dw_out, db_out, packed):
                                                         cout, t, 1, 1, 0, 1, 1, 1, _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk_prepacked")
         if db_out is not None:  # row sums of the packed dy: [cout / 8 octet rows][B * t units]
             job = (_lib.PkFlatRows * 1)()
-            job[0].dy, job[0].plane, job[0].units, job[0].C, job[0].db = ws.data_ptr(), B * t, B * t, cout, db_out.data_ptr()
+            job[0].dy, job[0].plane, job[0].units, job[0].C, job[0].db = ws.data_ptr(), pk_pitch(B, t), pk_pitch(B, t), cout, db_out.data_ptr()
             n_r = lib.evmi_pkflat_rowsum_ws_elems(1, job)
             wsr = WS.get("pkrow", n_r, x.device)
             _chk(lib.evmi_pkflat_rowsum(1, job, wsr.data_ptr(), n_r, _s(x)), "evmi_pkflat_rowsum")
@@ -793,7 +799,7 @@ def ffn_packed_fwd(x, gamma, beta, w1, b1, w2, b2, res, p, seed, seed_out, scale
     n2 = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cmid, t, cout, *geo)
     ws1 = keep["x_packed"] = torch.empty(n1, device=x.device, dtype=torch.float32)
     ws2 = keep["s_packed"] = torch.empty(n2, device=x.device, dtype=torch.float32)
-    a_pk = keep["a_pk"] = torch.empty(cmid // 8 * B * t * 4, device=x.device, dtype=torch.float32)  # 16-byte units of 8 bf16 channels
+    a_pk = keep["a_pk"] = torch.empty(cmid // 8 * pk_pitch(B, t) * 4, device=x.device, dtype=torch.float32)  # 16-byte units of 8 bf16 channels
     out = torch.empty(cout, B, t, device=x.device, dtype=torch.float32)
     st = _s(x)
     _chk(lib.evmi_layernorm_pack_bf16pk(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws1.data_ptr(), n1, B, cin, t, cmid, eps, st), "evmi_layernorm_pack_bf16pk")
@@ -840,7 +846,7 @@ def ffn_packed_bwd(x, w1, w2, dy, p, seed, seed_out, scale, dw1, db1, dw2, db2, 
                                                             c_o, t, 1, 1, 0, 1, 1, 1, _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk_prepacked")
             if db is not None:  # row sums of the packed output gradient: [c_o / 8 octet rows][B * t units]
                 job = (_lib.PkFlatRows * 1)()
-                job[0].dy, job[0].plane, job[0].units, job[0].C, job[0].db = dyp.data_ptr(), B * t, B * t, c_o, db.data_ptr()
+                job[0].dy, job[0].plane, job[0].units, job[0].C, job[0].db = dyp.data_ptr(), pk_pitch(B, t), pk_pitch(B, t), c_o, db.data_ptr()
                 n_r = lib.evmi_pkflat_rowsum_ws_elems(1, job)
                 wsr = WS.get("pkrow", n_r, x.device)
                 _chk(lib.evmi_pkflat_rowsum(1, job, wsr.data_ptr(), n_r, _s(x)), "evmi_pkflat_rowsum")
@@ -919,7 +925,7 @@ def conv1d_bwd_dropout_dy(x, w, dy, p, seed, scale, dw_out, db_out, packed, x_st
                                                         cout, t, 1, 1, 0, 1, 1, 1, _s(x)), "evmi_conv1d_wgrad_cbt_bf16pk_prepacked")
         if db_out is not None:  # row sums of the packed dz: [cout / 8 octet rows][B * t units]
             job = (_lib.PkFlatRows * 1)()
-            job[0].dy, job[0].plane, job[0].units, job[0].C, job[0].db = ws.data_ptr(), B * t, B * t, cout, db_out.data_ptr()
+            job[0].dy, job[0].plane, job[0].units, job[0].C, job[0].db = ws.data_ptr(), pk_pitch(B, t), pk_pitch(B, t), cout, db_out.data_ptr()
             n_r = lib.evmi_pkflat_rowsum_ws_elems(1, job)
             wsr = WS.get("pkrow", n_r, x.device)
             _chk(lib.evmi_pkflat_rowsum(1, job, wsr.data_ptr(), n_r, _s(x)), "evmi_pkflat_rowsum")

@@ -599,7 +599,7 @@ def test_training_step_at_the_bench_batch_follows_oracle(cuda_device, prec):
         assert cos >= 0.999 and 0.97 <= ratio <= 1.03, (cos, ratio)
 
 
-@pytest.mark.parametrize("B,T", [(4, 112), (32, 814)])
+@pytest.mark.parametrize("B,T", [(4, 112), (32, 814), (1, 4513)])  # (one item: any length shares its packed operands)
 def test_feed_forward_middle_fused_into_the_packs_equals_the_separate_passes(cuda_device, B, T):
     """ops.conv1d_fwd_silu_dropout / conv1d_bwd_silu_dropout_dy (train/fs2.py: ffn_core): dense2(dropout(silu(a))) and its backward with
     the activation and the mask applied while the operands are packed, against the three separate operators on the same seed -- the
@@ -644,7 +644,7 @@ def test_feed_forward_middle_fused_into_the_packs_equals_the_separate_passes(cud
         assert rel(got, want) <= tol, (name, rel(got, want))
 
 
-@pytest.mark.parametrize("B,T,cin,cout,sb", [(32, 814, 256, 256, 1.0), (4, 112, 1024, 256, 0.5)])
+@pytest.mark.parametrize("B,T,cin,cout,sb", [(32, 814, 256, 256, 1.0), (4, 112, 1024, 256, 0.5), (1, 4513, 256, 256, 1.0)])
 def test_residual_add_and_dropout_in_the_dense_layers_epilogue_equal_the_separate_passes(cuda_device, B, T, cin, cout, sb):
     """ops.conv1d_fwd_resdrop / conv1d_bwd_dropout_dy (train/fs2.py: dense_residual_dropout, ffn_core with a residual): a + sb *
     dropout(dense(h)) with the add and the mask in the layer's epilogue, and sb * dropout(dy) formed while dy is packed, against
@@ -760,7 +760,7 @@ def test_fused_feed_forward_block_against_torch_with_the_kernels_own_mask(cuda_d
         assert l2 <= 1e-3 and mx <= 1e-2, (name, l2, mx)
 
 
-@pytest.mark.parametrize("B,T", [(32, 814), (4, 112), (2, 32)])
+@pytest.mark.parametrize("B,T", [(32, 814), (4, 112), (2, 32), (1, 4513), (1, 77)])  # (one item: the row pitch is rounded up to 64)
 def test_feed_forward_block_as_a_packed_chain_against_torch_with_the_kernels_own_masks(cuda_device, B, T):
     """The feed-forward block with its 1024-channel tensors packed end to end (train/fs2.py: ffn_core -> ops.ffn_packed_fwd / _bwd:
     LayerNorm written packed -> dense1, whose epilogue writes bf16(a) and the packed dropout(silu(a)) -> dense2 with the residual add and
@@ -796,7 +796,7 @@ def test_feed_forward_block_as_a_packed_chain_against_torch_with_the_kernels_own
         dx = ops.layernorm_bwd(xd, gd, dh, dgam, dbet)
         ops.wgrad_join(dev)
         torch.cuda.synchronize()
-        a_pk = kp["a_pk"].view(torch.bfloat16).view(F_ // 8, B * T, 8).permute(0, 2, 1).reshape(F_, B * T).float().cpu()
+        a_pk = kp["a_pk"].view(torch.bfloat16).view(F_ // 8, ops.pk_pitch(B, T), 8)[:, : B * T].permute(0, 2, 1).reshape(F_, B * T).float().cpu()
     finally:
         ops.CONV_BACKEND["operands"] = prev
     N = B * T
@@ -828,7 +828,7 @@ def test_feed_forward_block_as_a_packed_chain_against_torch_with_the_kernels_own
         assert l2 <= 1e-3 and mx <= 1e-2, (name, l2, mx)
 
 
-@pytest.mark.parametrize("B,T,C,F_", [(4, 112, 256, 1024), (32, 814, 256, 768), (8, 64, 128, 256)])
+@pytest.mark.parametrize("B,T,C,F_", [(4, 112, 256, 1024), (32, 814, 256, 768), (8, 64, 128, 256), (1, 4513, 256, 1024)])
 def test_layernorm_written_as_the_packed_input_of_the_dense_layer_behind_it(cuda_device, B, T, C, F_):
     """ops.layernorm_dense_fwd (train/fs2.py: ln_dense, ffn_core): LayerNorm -> pointwise layer with the normalised tensor written
     straight into the layer's packed bf16 input, against LayerNorm then the layer (which packs the same values): same output, and the
