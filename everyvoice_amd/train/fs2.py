@@ -29,7 +29,7 @@ from .. import _lib
 from ..fs2 import N_PHONOLOGICAL_FEATURES, FastSpeech2ModelConfig, Stats
 from . import ops
 from .autograd import _ACTIVATION_ELEMS, Tape, Var
-from .layers import ParamGroup, WNConv
+from .layers import ParamGroup, WNBatch, WNConv
 
 
 @dataclass
@@ -682,6 +682,9 @@ class FastSpeech2Trainer:
         lin = lambda st, n: torch.linspace(st.norm_min, st.norm_max, n - 1).to(self.device)
         self.pitch_bins, self.energy_bins = lin(self.stats.pitch, vp.pitch.n_bins), lin(self.stats.energy, vp.energy.n_bins)
         self._wn = [cv for vpred in (self.duration_predictor, self.pitch_predictor, self.energy_predictor) for cv in vpred.convs() if isinstance(cv, WNConv)]
+        # effective weights, norms and gradient sinks of the 30 weight-normed layers in three flat buffers: ONE launch per step computes
+        # w = g v / ||v|| for all of them and one turns the sinks into (dg, dv) -- 90 launches of ~4 us at the two ends of the step otherwise
+        self._wn_batch = WNBatch(self.params, self._wn)
         self._bn = self.encoder.batchnorms() + self.decoder.batchnorms() + [bn for _, bn in self.postnet]
         self.global_step = 0
         self.current_epoch = 0  # the driver advances it; only the binarisation-loss warm-up reads it
@@ -736,9 +739,7 @@ class FastSpeech2Trainer:
             if bn.prefix + ".running_mean" in sd:
                 bn.running_mean.copy_(sd[bn.prefix + ".running_mean"])
                 bn.running_var.copy_(sd[bn.prefix + ".running_var"])
-        for cv in self._wn:
-            cv._w = None
-        return self
+        return self  # (the effective weights are recomputed at the start of every step: WNBatch.materialize)
 
     def state_dict(self) -> dict:
         """Exactly what ``everyvoice_amd.fs2.FastSpeech2.load_state_dict`` (and the oracle module) take."""
@@ -921,8 +922,7 @@ class FastSpeech2Trainer:
 
         if not _EVAL[0]:
             self.params.zero_grad()
-        for cv in self._wn:
-            cv.materialize()
+        self._wn_batch.materialize()
         tape = Tape()
         counter = [0]
 
@@ -1028,8 +1028,7 @@ class FastSpeech2Trainer:
 
     def _finish_backward(self, losses: dict, grads: bool = True) -> dict:
         if grads:
-            for cv in self._wn:
-                cv.finish_grads()
+            self._wn_batch.finish(self._wn)
         total = torch.zeros(1, device=self.device)
         for v in losses.values():
             ops.axpby(1.0, total, 1.0, v, out=total)
@@ -1144,8 +1143,9 @@ class FastSpeech2Trainer:
             if entry is None:
                 losses = self._step_body(d, meta)
             else:
-                for k, v in d.items():  # into the captured step's static inputs (same shapes by construction of the key)
-                    entry["inputs"][k].copy_(v)
+                # into the captured step's static inputs (same shapes and types by construction of the key): one multi-tensor launch
+                keys = list(d)
+                torch._foreach_copy_([entry["inputs"][k] for k in keys], [d[k] for k in keys])
                 self._replay(entry)
                 # copies: the graph's own loss tensors are overwritten by the next replay of this shape, and a caller may keep
                 # losses across steps (running means, deferred logging) -- eager steps hand out fresh tensors too
@@ -1188,8 +1188,6 @@ class FastSpeech2Trainer:
             ops.elementwise(ops.EW_CLIP_SCALE, g.grad, None, self._grad_norm, out=g.grad, p0=float(clip))
         o = self.training.optimizer
         g.adamw(0.0, tuple(o.betas), o.eps, o.weight_decay, lr_dev=self._scal[0:1])  # the rate of this step: _store_step_scalars
-        for cv in self._wn:
-            cv._w = None
 
     # -- HIP-graph execution -----------------------------------------------------------------------------------------------------
     def _graph_key(self, d: dict, meta: dict):
