@@ -255,6 +255,30 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
+// ... and in double precision (the two halves of the value move together)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_mov_dpp((int)(b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp((int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp_f64(double v) {
+  v += dpp_move_f64<0xB1>(v);
+  v += dpp_move_f64<0x4E>(v);
+  v += dpp_move_f64<0x141>(v);
+  v += dpp_move_f64<0x140>(v);
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = (int)(b & 0xFFFFFFFFll), hi = (int)(b >> 32);
+  double r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int l = __builtin_amdgcn_readlane(lo, 16 * q), h = __builtin_amdgcn_readlane(hi, 16 * q);
+    r[q] = __builtin_bit_cast(double, ((long long)h << 32) | (long long)(unsigned)l);
+  }
+  return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 // wait until at most n (wave-uniform) vector-memory operations of this wave are outstanding
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
   n = __builtin_amdgcn_readfirstlane(n);

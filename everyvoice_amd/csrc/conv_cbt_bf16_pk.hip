@@ -97,6 +97,12 @@ struct ConvPkArgs {
     int tail;
     uint4* y2;
     long long drop_ld;
+    // what a pack pass would have zeroed, written by the same epilogue (no memset launches in front of the call): the units of columns
+    // [valid, pad_end) of every row (a single item's pitch rounded up: conv_pk_common.h) and zero_n units at zero_p (the slack behind
+    // the tensor).  Tails only.
+    int pad_end;
+    uint4* zero_p;
+    int zero_n;
   } po;
 };
 
@@ -529,6 +535,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
     return;
   }
   if (a.po.y) {  // ---- flat packed output: bf16 units [octet][unit], straight from the accumulators ----
+    if (TAILS && a.po.zero_n > 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+      for (int i = tid; i < a.po.zero_n; i += NW * 64) a.po.zero_p[i] = make_uint4(0u, 0u, 0u, 0u);
     pk_with_act(a.act, [&](auto act_c) {
       constexpr int ACT = decltype(act_c)::value;
       const int m_last = m_valid - 1;
@@ -539,7 +547,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
         const int bb = w / a.po.Tc;
         const int u = w - bb * a.po.Tc;
         const bool ok = col_b[nt] >= 0 && w >= 0 && u < a.po.valid;
-        const long long dst_u = ok ? (long long)bb * a.po.Ts + u : 0;
+        const bool pad_col = TAILS && a.po.tail && !ok && n >= a.po.valid && n < a.po.pad_end;  // (tails: one row, w == n)
+        const long long dst_u = ok ? (long long)bb * a.po.Ts + u : (pad_col ? (long long)n : 0);
         const long long msk_u = ok ? (long long)bb * a.po.Tm + u : 0;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -615,9 +624,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
                 d[q] = which ? pack_bf16x2(s2[8 * p + 2 * q], s2[8 * p + 2 * q + 1]) : pack_bf16x2(v[8 * p + 2 * q], v[8 * p + 2 * q + 1]);
               const u32x4 o = swap_quads_bf16(d);  // lane (n, kh): the 8 channels of octet 2 p + kh
               const int m_oct = mb + 8 * (2 * p + kh);
-              if (ok && m_oct < m_valid) {
+              if ((ok || pad_col) && m_oct < m_valid) {
                 uint4 st;
                 st.x = o[0]; st.y = o[1]; st.z = o[2]; st.w = o[3];
+                if (pad_col) st = make_uint4(0u, 0u, 0u, 0u);
                 dst[(long long)((co0 + m_oct) >> 3) * a.po.plane + dst_u] = st;
               }
             }
@@ -720,6 +730,17 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
   const int oc = blockIdx.y, ph = blockIdx.z;
   const int n_out = a.ph_nout[ph];
   const int n_cols = a.B * n_out;  // (the chains' calls: B == 1; the FastSpeech2 feed-forward layers: B tight items, one row)
+  if (a.po.tail && a.po.zero_n > 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    for (int i = threadIdx.x; i < a.po.zero_n; i += 256) a.po.zero_p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (a.po.tail && n4 < a.po.pad_end && n4 + 3 >= n_cols && n_out > 0) {  // the zero units behind the row's last column
+    for (int c = 0; c < 4; ++c) {
+      const int n = n4 + c;
+      if (n >= max(n_cols, a.po.valid) && n < a.po.pad_end) {
+        a.po.y[(long long)oc * a.po.plane + n] = make_uint4(0u, 0u, 0u, 0u);
+        if (a.po.tail == 1) a.po.y2[(long long)oc * a.po.plane + n] = make_uint4(0u, 0u, 0u, 0u);
+      }
+    }
+  }
   if (n_out <= 0 || n4 >= n_cols) return;
   float v[4][8];
   const float* src = a.part + (long long)ph * a.part_stride + (long long)(oc * 8) * a.part_ld + n4;
@@ -1118,8 +1139,10 @@ static int launch_pk_tile(ConvPkArgs& a, const PkPlan& pl, hipStream_t stream) {
   return EVMI_OK;
 }
 
-// stage 0: pack + weight fragments + convolution; 1: the pack alone (the packed input is left at the head of ws); 2: the rest, on the
-// input stage 1 packed into the same ws (same shape, hence the same plan)
+// stage 0: pack + weight fragments + convolution in one call; 1: the preparation alone -- pack AND fragments, one launch; the packed
+// input is left at the head of ws; 2: the convolution alone, on what stage 1 left in the same ws (same shape, hence the same plan: no
+// launch in front of it); 3: fragments + convolution on a packed input that something else put at the head of ws (a producer's
+// epilogue, LayerNorm's pack)
 static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float* w, float* ws, long long ws_elems, int wmode,
                      int rows_g, int kch_g, int k_full, int stride_full, hipStream_t stream, PkInputFusion in = PkInputFusion(),
                      int stage = 0) {
@@ -1138,8 +1161,8 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   fa.kblocks = a.kblocks; fa.mode = wmode; fa.k_full = k_full; fa.stride = stride_full; fa.phase_stride_words = a.wf_phase_stride * 4;
   fa.tab = reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases); fa.kb_step = a.kb_step; fa.xrow = a.xrow; fa.dil = a.dil;
   fa.gx = a.kblocks; fa.gy = pl.groups * a.mblocks; fa.gz = a.phases;
-  if (stage == 1) fa.gx = fa.gy = fa.gz = 0;
-  if (stage == 2) pa.gx = pa.gy = pa.gz = 0;
+  if (stage == 2) fa.gx = fa.gy = fa.gz = 0;
+  if (stage == 2 || stage == 3) pa.gx = pa.gy = pa.gz = 0;
   const long long n_prep = (long long)pa.gx * pa.gy * pa.gz + (long long)fa.gx * fa.gy * fa.gz;
   if (n_prep > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "conv_cbt_bf16_pk: grid limits (preparation pass)");
   if (n_prep > 0) hipLaunchKernelGGL(prep_pk_kernel, dim3((unsigned)n_prep), dim3(256), 0, stream, pa, fa);
@@ -1152,7 +1175,8 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
   a.wf = wf;
   if (int rc = launch_pk_tile(a, pl, stream)) return rc;
   if (a.ksplit > 1 && a.po.y) {
-    hipLaunchKernelGGL(conv_pk_reduce_flat_kernel, dim3((unsigned)((a.part_ld + 1023) / 1024), pl.c_out / 8, a.phases), dim3(256), 0, stream, a);
+    const long long cols = std::max<long long>(a.part_ld, a.po.tail ? a.po.pad_end : 0);
+    hipLaunchKernelGGL(conv_pk_reduce_flat_kernel, dim3((unsigned)((cols + 1023) / 1024), pl.c_out / 8, a.phases), dim3(256), 0, stream, a);
     EVMI_LAUNCH_CHECK("conv_pk_reduce_flat");
   } else if (a.ksplit > 1) {
     hipLaunchKernelGGL(conv_pk_reduce_kernel, dim3((unsigned)((a.part_ld + 255) / 256), pl.c_out, a.phases), dim3(256), 0, stream, a);
@@ -1422,8 +1446,8 @@ int evmi_conv1d_cbt_bf16pk_prepacked(const float* w_dev, const float* bias_dev, 
   if (const char* why = plan_fwd_pk(a, pl, B, c_in, t_in, c_out, t_in, t_in, 1, 1, 0, 1, 1, 1, 0))
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk_prepacked: ") + why);
   a.bias = bias_dev; a.y = y_dev; a.accumulate = 0; a.act = act; a.act_param = act_param;
-  // (stage 2: the pack is an empty grid; the fp32 input pointer is never read)
-  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 2);
+  // (stage 3: the pack is an empty grid; the fp32 input pointer is never read)
+  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 3);
 }
 
 /* The same with the fusions of a residual block's forward: the input passes through leaky_relu(., pre_slope) while it is packed
@@ -1464,14 +1488,15 @@ int evmi_conv1d_dgrad_cbt_bf16pk(const float* dy_dev, const float* w_dev, float*
   return launch_pk(a, pl, dy_dev, w_dev, ws_dev, ws_elems, 1, c_in / groups, c_out / groups, k, stride, (hipStream_t)stream);
 }
 
-/* The same call in two steps, so that a caller can put something between them: stage 1 packs dy into the head of ws and returns;
- * stage 2 (same arguments, same ws, untouched in between) prepares the weight fragments and runs the convolution on it.  What goes
+/* The same call in two steps, so that a caller can put something between them: stage 1 packs dy into the head of ws, prepares the weight
+ * fragments behind it (one launch) and returns; stage 2 (same arguments, same ws, untouched in between) runs the convolution on them.
+ * Stage 3: fragments + convolution on a packed dy that something else left at the head of ws (evmi_conv1d_dgrad_cbt_bf16pk_ffn_down).  What goes
  * between them in training: the fork of the weight-gradient stream -- the weight gradient of a pointwise layer reads that packed dy
  * (evmi_conv1d_wgrad_cbt_bf16pk_prepacked) and can then run BESIDE the input gradient instead of behind it. */
 int evmi_conv1d_dgrad_cbt_bf16pk_staged(int stage, const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems,
                                         int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
                                         void* stream) {
-  if (stage != 1 && stage != 2) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged: stage 1 or 2");
+  if (stage < 1 || stage > 3) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged: stage 1, 2 or 3");
   if (!dy_dev || !w_dev || !dx_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_dgrad_cbt_bf16pk_staged: null pointer");
   ConvPkArgs a = {};
   PkPlan pl;
@@ -1548,7 +1573,7 @@ int evmi_conv1d_cbt_bf16pk_resdrop(int in_mode, const float* x_dev, const float*
     in.fuse = 1; in.p_drop = in_p; in.seed = SeedArg{in_seed, seed_base_dev};
   }
   if (in_mode == 2)
-    return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 2);
+    return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 3);
   return launch_pk(a, pl, x_dev, w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, in);
 }
 
@@ -1583,14 +1608,6 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(int stage, const float* dy_dev, 
  *                bias gradient read the same units)
  * Same mask stream and arithmetic as evmi_conv1d_cbt_bf16pk_silu_dropout / ..._staged_silu_dropout (seed_value + *seed_base_dev, element
  * index = index in the fp32 tensor that is no longer stored); the one difference: silu' is taken at bf16(a) instead of a. */
-// zero what a pack pass would have: units [N, plane) of every octet row (a single item's rounded-up pitch) and the slack behind the tensor
-static int ffn_zero_tails(uint4* xp, int octs, long long N, long long plane, long long xp_units, hipStream_t stream) {
-  if (plane > N) EVMI_HIP_CHECK(hipMemset2DAsync(xp + N, (size_t)plane * 16, 0, (size_t)(plane - N) * 16, (size_t)octs, stream));
-  const long long used = (long long)octs * plane;
-  if (xp_units > used) EVMI_HIP_CHECK(hipMemsetAsync(xp + used, 0, (size_t)(xp_units - used) * 16, stream));
-  return EVMI_OK;
-}
-
 static int ffn_tail_check(const ConvPkArgs& a2, const PkPlan& pl2, int B, int t, int c_mid, float* next_ws, long long next_ws_elems, const char* who) {
   if (a2.Tp != pk_shared_pitch(B, t) || pl2.PL != 0 || !pk_shared_items(B, t))
     return fail(EVMI_ERR_UNSUPPORTED, std::string(who) + ": the consumer's items are not packed tight");
@@ -1615,14 +1632,14 @@ int evmi_conv1d_cbt_bf16pk_ffn_up(const float* w_dev, const float* bias_dev, flo
   if (int rc = ffn_tail_check(a2, pl2, B, t, c_mid, next_ws_dev, next_ws_elems, "conv1d_cbt_bf16pk_ffn_up")) return rc;
   const long long N = (long long)B * t, plane = (long long)B * a2.Tp;
   uint4* nxt = reinterpret_cast<uint4*>(next_ws_dev);
-  // the zeros the pack pass that no longer runs wrote: the slack behind the second layer's packed input and, in a single item's rows,
-  // the units behind the last column
-  if (int rc = ffn_zero_tails(nxt, a2.octs, N, plane, pl2.xp_units, (hipStream_t)stream)) return rc;
+  // the zeros the pack pass that no longer runs wrote -- the slack behind the second layer's packed input and, in a single item's rows,
+  // the units behind the last column -- come from the epilogue too (FlatOut::pad_end / zero_p)
+  a.po.pad_end = (int)plane; a.po.zero_p = nxt + (long long)a2.octs * plane; a.po.zero_n = (int)(pl2.xp_units - (long long)a2.octs * plane);
   a.bias = bias_dev; a.y = nullptr; a.accumulate = 0; a.act = 0; a.act_param = 0.f;
   a.po.y = reinterpret_cast<uint4*>(a_pk_dev); a.po.y2 = nxt; a.po.plane = plane; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
   a.po.tail = 1; a.po.drop_ld = N; a.po.Tm = (int)N; a.po.mplane = plane;
   a.drop_p = p; a.drop_seed = SeedArg{seed_value, seed_base_dev};
-  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_mid, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 2);
+  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_mid, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 3);
 }
 
 int evmi_conv1d_dgrad_cbt_bf16pk_ffn_down(const float* w_dev, float* ws_dev, long long ws_elems, const void* a_pk_dev, float* next_ws_dev,
@@ -1640,7 +1657,7 @@ int evmi_conv1d_dgrad_cbt_bf16pk_ffn_down(const float* w_dev, float* ws_dev, lon
   if (int rc = ffn_tail_check(a1, pl1, B, t, c_mid, next_ws_dev, next_ws_elems, "conv1d_dgrad_cbt_bf16pk_ffn_down")) return rc;
   const long long N = (long long)B * t, plane = (long long)B * a1.Tp;
   uint4* nxt = reinterpret_cast<uint4*>(next_ws_dev);
-  if (int rc = ffn_zero_tails(nxt, a1.octs, N, plane, pl1.xp_units, (hipStream_t)stream)) return rc;
+  a.po.pad_end = (int)plane; a.po.zero_p = nxt + (long long)a1.octs * plane; a.po.zero_n = (int)(pl1.xp_units - (long long)a1.octs * plane);
   a.y = nullptr;
   a.po.y = nxt; a.po.plane = plane; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
   a.po.tail = 2; a.po.drop_ld = N; a.po.fm = reinterpret_cast<const uint4*>(a_pk_dev); a.po.Tm = (int)N; a.po.mplane = plane;

@@ -295,16 +295,18 @@ constexpr int DW_KMAX = 32;
 // part[c][b][j] = sum_t x[c][b][t + j - pad] * dy[c][b][t] (j < k), part[c][b][k] = sum_t dy : one workgroup per (c, b) row
 // STAGED: the row of x sits in LDS, zero padded by the kernel's reach (each thread otherwise issues k conditional global loads per
 // position: the anti-pattern of DESIGN.md 9.12; rows longer than the LDS take the direct form)
-template <bool STAGED>
+// KM: the taps the unrolled loops cover (k <= KM <= DW_KMAX: 4 for the variance predictors' k = 3, 12 for the Conformer's k = 9 -- the
+// 32-tap form spent three quarters of its multiply-adds on taps that do not exist)
+template <bool STAGED, int KM>
 __global__ __launch_bounds__(256) void dwconv_bwd_dw_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                    float* __restrict__ part, int B, int T, int k, int pad) {
   extern __shared__ float xs[];  // STAGED: [T + k - 1], xs[i] = x[i - pad]
   const int b = blockIdx.x, c = blockIdx.y;
   const float* xr = x + ((long long)c * B + b) * T;
   const float* dr = dy + ((long long)c * B + b) * T;
-  float acc[DW_KMAX];
+  float acc[KM];
 #pragma unroll
-  for (int j = 0; j < DW_KMAX; ++j) acc[j] = 0.f;
+  for (int j = 0; j < KM; ++j) acc[j] = 0.f;
   float sb = 0.f;
   if (STAGED) {
     for (int i = threadIdx.x; i < T + k - 1; i += 256) {
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dw_partial_kernel(const float*
       const float d = dr[t];
       sb += d;
 #pragma unroll
-      for (int j = 0; j < DW_KMAX; ++j)
+      for (int j = 0; j < KM; ++j)
         if (j < k) acc[j] = fmaf(xs[t + j], d, acc[j]);  // (a padded position adds 0 * d: the sum's bits do not change)
     }
   } else {
@@ -325,23 +327,22 @@ __global__ __launch_bounds__(256) void dwconv_bwd_dw_partial_kernel(const float*
       const float d = dr[t];
       sb += d;
 #pragma unroll
-      for (int j = 0; j < DW_KMAX; ++j) {
+      for (int j = 0; j < KM; ++j) {
         const int ti = t + j - pad;
         if (j < k && ti >= 0 && ti < T) acc[j] = fmaf(xr[ti], d, acc[j]);
       }
     }
   }
-  // k + 1 workgroup sums: the wave-level halves of all of them first, ONE barrier, then the four wave sums of value j added by thread
-  // j in the order block_sum adds them (same bits as k + 1 calls of block_sum, without their 2 (k + 1) barriers: 46.7 -> ? us per launch)
+  // k + 1 workgroup sums: the wave sums of all of them first (DPP adds: no LDS round trips -- as ds_bpermute butterflies on doubles these
+  // were 12 crossbar trips per value, the larger part of the workgroup's time), ONE barrier, then the four wave sums of value j added
+  // by thread j
   __shared__ double shw[4][DW_KMAX + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int j = 0; j <= DW_KMAX; ++j) {
-    if (j < k || j == DW_KMAX) {
-      double v = j == DW_KMAX ? (double)sb : (double)acc[j < DW_KMAX ? j : 0];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-      if (lane == 0) shw[wave][j] = v;
+  for (int j = 0; j <= KM; ++j) {
+    if (j < k || j == KM) {
+      const double v = wave_sum_dpp_f64(j == KM ? (double)sb : (double)acc[j < KM ? j : 0]);
+      if (lane == 0) shw[wave][j == KM ? DW_KMAX : j] = v;
     }
   }
   __syncthreads();
@@ -477,64 +478,47 @@ __global__ __launch_bounds__(256) void dropout_fused_kernel(const float* __restr
 }
 
 // ---- embeddings, backward ------------------------------------------------------------------------------------------
-// One thread per (table row, channel) walks the tokens in order and adds the ones that map to its row: a fixed order
-// of additions (bitwise reproducible, unlike a scatter with atomics); the row test is wave-uniform (scalar loads).
-// text embedding: row = ids[b][l] for l < lens[b], ids != skip_id;  variance buckets: ids = precomputed bucket index of
-// every position, lens = NULL (the forward adds everywhere, pads included).  Row indices are staged through LDS.
+// dtable[r][c] += sum of dx[c][n] over the tokens n that map to row r, added in token order (a fixed order: bitwise reproducible,
+// unlike a scatter with atomics).  text embedding: row = ids[b][l] for l < lens[b], ids != skip_id;  variance buckets: ids = the
+// precomputed bucket index of every position, lens = NULL (the forward adds everywhere, pads included).
+// One workgroup per CHANNEL (x 256 table rows): the channel's gradient row and the row indices go through LDS in chunks (coalesced
+// reads, each once), and thread r walks the chunk's tokens for ITS table row -- every LDS read is a broadcast, there is no gather.
+// (The form this replaces had one workgroup per table row gather its matches from the channel-major tensor: 64 cache lines per wave
+// load, 105 us per call at 4.5 k positions; same order of additions, same bits.)
 constexpr int TABLE_CHUNK = 4096;
 __global__ __launch_bounds__(256) void fs2_table_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ ids,
                                                            const int* __restrict__ lens, float* __restrict__ dtable, int B, int L,
-                                                           int D, int skip_id) {
-  __shared__ int sid[TABLE_CHUNK];    // row index of every token of the chunk (-1: skipped)
-  __shared__ int mlist[TABLE_CHUNK];  // the chunk's tokens that map to row r: four lists (one per quarter of the chunk), each in token order
-  __shared__ int mcount[4];
-  const int r = blockIdx.x;
-  const int c = blockIdx.y * 256 + threadIdx.x;
+                                                           int D, int skip_id, int rows) {
+  __shared__ __attribute__((aligned(16))) int sid[TABLE_CHUNK];    // row index of every token of the chunk (-1: skipped)
+  __shared__ __attribute__((aligned(16))) float val[TABLE_CHUNK];  // the channel's gradient at those tokens
+  const int c = blockIdx.x;
+  const int r = blockIdx.y * 256 + threadIdx.x;
   const int N = B * L;
-  const float* row = dx + (long long)(c < D ? c : 0) * N;
+  const float* row = dx + (long long)c * N;
   float acc = 0.f;
   for (int base = 0; base < N; base += TABLE_CHUNK) {
     const int cnt = min(TABLE_CHUNK, N - base);
     __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-      const int n = base + i, b = n / L, l = n - b * L;
+    for (int i = threadIdx.x; i < TABLE_CHUNK; i += 256) {
+      const int n = min(base + i, N - 1), b = n / L, l = n - b * L;
       const int id = ids[n];
-      sid[i] = (lens && l >= lens[b]) || id == skip_id ? -1 : id;
+      const float v = row[n];
+      const bool live = i < cnt && !((lens && l >= lens[b]) || id == skip_id);
+      sid[i] = live ? id : -1;
+      val[i] = v;
     }
     __syncthreads();
-    // the matches are compacted (64 tokens per ballot, positions by prefix population count): the additions below then run over
-    // lists with eight loads in flight instead of one dependent load per match.  Every wave compacts ITS quarter of the chunk into
-    // its own list (one wave walking the whole chunk was the kernel: 140 us for the 26 k positions of a frame-level table, 64
-    // serial ballot steps per 4 k tokens); the lists are read in wave order, so the additions still run in token order -- the same bits
-    {
-      constexpr int QUARTER = TABLE_CHUNK / 4;
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      const int q0 = wave * QUARTER, q1 = min(cnt, q0 + QUARTER);
-      int total = 0;
-      for (int i0 = q0; i0 < q1; i0 += 64) {
-        const bool hit = i0 + lane < q1 && sid[i0 + lane] == r;
-        const unsigned long long m = __ballot(hit);
-        if (hit) mlist[q0 + total + __popcll(m & ((1ull << lane) - 1ull))] = base + i0 + lane;
-        total += __popcll(m);
-      }
-      if (lane == 0) mcount[wave] = total;
-    }
-    __syncthreads();
-    for (int w = 0; w < 4; ++w) {
-      const int nm = mcount[w];
-      const int* ml = mlist + w * (TABLE_CHUNK / 4);
-      int q = 0;
-      for (; q + 8 <= nm; q += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = row[ml[q + u]];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
-      }
-      for (; q < nm; ++q) acc += row[ml[q]];
+    const int cnt4 = (cnt + 3) & ~3;  // (the chunk's tail is staged as skipped tokens)
+    for (int i = 0; i < cnt4; i += 4) {
+      const int4 s4 = *reinterpret_cast<const int4*>(&sid[i]);
+      const float4 v4 = *reinterpret_cast<const float4*>(&val[i]);
+      acc += s4.x == r ? v4.x : 0.f;  // (+ 0.f: a token of another row leaves the sum's bits as they are)
+      acc += s4.y == r ? v4.y : 0.f;
+      acc += s4.z == r ? v4.z : 0.f;
+      acc += s4.w == r ? v4.w : 0.f;
     }
   }
-  if (c < D) dtable[(long long)r * D + c] += acc;
+  if (r < rows) dtable[(long long)r * D + c] += acc;
 }
 
 // bucket index of every token: first boundary >= value (torch.bucketize, right = False)
@@ -665,8 +649,15 @@ int evmi_dwconv1d_bwd_cbt_f32(const float* x, const float* w, const float* dy, f
   if (dw) {
     if (!ws || ws_elems < evmi_dwconv1d_bwd_cbt_f32_ws_elems(C, B, k)) return fail(EVMI_ERR_INVALID_ARG, "dwconv_bwd: workspace missing or too small");
     const size_t lds = (size_t)(T + k - 1) * sizeof(float);
-    if (lds <= 40 * 1024) hipLaunchKernelGGL(dwconv_bwd_dw_partial_kernel<true>, dim3(B, C), dim3(256), lds, s, x, dy, ws, B, T, k, pad);
-    else hipLaunchKernelGGL(dwconv_bwd_dw_partial_kernel<false>, dim3(B, C), dim3(256), 0, s, x, dy, ws, B, T, k, pad);
+#define EVMI_DW_PARTIAL(KM)                                                                                                          \
+  {                                                                                                                                  \
+    if (lds <= 40 * 1024) hipLaunchKernelGGL((dwconv_bwd_dw_partial_kernel<true, KM>), dim3(B, C), dim3(256), lds, s, x, dy, ws, B, T, k, pad); \
+    else hipLaunchKernelGGL((dwconv_bwd_dw_partial_kernel<false, KM>), dim3(B, C), dim3(256), 0, s, x, dy, ws, B, T, k, pad);        \
+  }
+    if (k <= 4) EVMI_DW_PARTIAL(4)
+    else if (k <= 12) EVMI_DW_PARTIAL(12)
+    else EVMI_DW_PARTIAL(DW_KMAX)
+#undef EVMI_DW_PARTIAL
     EVMI_LAUNCH_CHECK("dwconv_bwd_dw_partial");
     hipLaunchKernelGGL(dwconv_bwd_dw_final_kernel, dim3(blocks_for((long long)C * (k + 1))), dim3(256), 0, s, ws, dw, db, C, B, k);
     EVMI_LAUNCH_CHECK("dwconv_bwd_dw_final");
@@ -730,8 +721,8 @@ int evmi_dropout_f32(const float* x, float* y, long long n, float p, unsigned lo
 int evmi_fs2_embed_bwd_f32(const float* dx, const int* ids, const int* lens, float* dtable, int rows, int B, int L, int D, int skip_id,
                            void* stream) {
   if (!dx || !ids || !lens || !dtable || rows < 1 || B < 1 || L < 1 || D < 1) return fail(EVMI_ERR_INVALID_ARG, "fs2_embed_bwd: bad arguments");
-  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(rows, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, ids, lens, dtable, B, L, D,
-                     skip_id);
+  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(D, (rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, ids, lens, dtable, B, L, D,
+                     skip_id, rows);
   EVMI_LAUNCH_CHECK("fs2_embed_bwd");
   return EVMI_OK;
 }
@@ -744,7 +735,7 @@ int evmi_fs2_bucket_embed_bwd_f32(const float* dx, const float* values, const fl
   hipLaunchKernelGGL(fs2_bucket_index_kernel, dim3(blocks_for((long long)B * L)), dim3(256), 0, s, values, bins, idx_ws, B * L, n_bins, control);
   EVMI_LAUNCH_CHECK("fs2_bucket_index");
   // the text-embedding walk over precomputed indices: every position counts (lens = NULL -> full rows), no skipped id
-  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(n_bins, (D + 255) / 256), dim3(256), 0, s, dx, idx_ws, nullptr, dtable, B, L, D, -1);
+  hipLaunchKernelGGL(fs2_table_bwd_kernel, dim3(D, (n_bins + 255) / 256), dim3(256), 0, s, dx, idx_ws, nullptr, dtable, B, L, D, -1, n_bins);
   EVMI_LAUNCH_CHECK("fs2_bucket_embed_bwd");
   return EVMI_OK;
 }

@@ -855,7 +855,7 @@ def ffn_packed_bwd(x, w1, w2, dy, p, seed, seed_out, scale, dw1, db1, dw2, db2, 
     side2.run(wgrad(cmid, cout, ws2, wsd2, dw2, db2))
     side1 = side_wgrad(x, dw1, db1, wsd1, ws1, a_pk).mark()  # fork behind the epilogue that wrote the packed dy, in front of the input gradient
     _count_conv(B, t, cmid, cin, 1)
-    _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged(2, wsd1.data_ptr(), w1.data_ptr(), dh.data_ptr(), wsd1.data_ptr(), n_d1, B, cin, t, cmid, t, 1, 1, 0, 1, 1, st),
+    _chk(lib.evmi_conv1d_dgrad_cbt_bf16pk_staged(3, wsd1.data_ptr(), w1.data_ptr(), dh.data_ptr(), wsd1.data_ptr(), n_d1, B, cin, t, cmid, t, 1, 1, 0, 1, 1, st),
          "evmi_conv1d_dgrad_cbt_bf16pk_staged")
     side1.run(wgrad(cin, cmid, ws1, wsd1, dw1, db1))
     return dh
