@@ -161,7 +161,9 @@ SYMBOLS = {
     "evmi_conv1d_dgrad_cbt_bf16pk_fused": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "evmi_conv1d_dgrad_cbt_bf16pk_staged": (C.c_int, [C.c_int] + [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
     "evmi_layernorm_pack_bf16pk": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
-    "evmi_conv1d_cbt_bf16pk_prepacked": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
+    "evmi_layernorm_pack_bf16pk_w": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong,
+                                                                                                   C.c_int, C.c_void_p]),
+    "evmi_conv1d_cbt_bf16pk_prepacked": (C.c_int, [C.c_void_p] * 4 + [C.c_longlong] + [C.c_int] * 5 + [C.c_float, C.c_int, C.c_void_p]),
     "evmi_conv1d_cbt_bf16pk_silu_dropout": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong] + [C.c_int] * 6 + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
     "evmi_conv1d_cbt_bf16pk_resdrop": (C.c_int, [C.c_int] + [C.c_void_p] * 6 + [C.c_longlong] + [C.c_int] * 4 + [C.c_float, C.c_ulonglong, C.c_float, C.c_ulonglong,
                                                   C.c_float, C.c_void_p, C.c_void_p]),
@@ -170,7 +172,7 @@ SYMBOLS = {
     "evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_ulonglong, C.c_void_p] + [C.c_void_p] * 3
                                                          + [C.c_longlong] + [C.c_int] * 10 + [C.c_void_p]),
     "evmi_conv1d_cbt_bf16pk_ffn_up": (C.c_int, [C.c_void_p] * 3 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 5
-                                      + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
+                                      + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_int, C.c_void_p]),
     "evmi_conv1d_dgrad_cbt_bf16pk_ffn_down": (C.c_int, [C.c_void_p] * 2 + [C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 5
                                               + [C.c_float, C.c_ulonglong, C.c_void_p, C.c_void_p]),
     "evmi_conv1d_wgrad_cbt_bf16pk_prepacked": (C.c_int, [C.c_void_p] * 6 + [C.c_longlong] + [C.c_int] * 11 + [C.c_void_p]),

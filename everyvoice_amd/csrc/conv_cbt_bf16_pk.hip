@@ -812,8 +812,20 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
 template <int CPT>  // channels per thread = C / 4 (a multiple of 8)
 __global__ __launch_bounds__(256) void layernorm_pack_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, uint4* __restrict__ xp, int C, long long N,
-                                                            long long plane, float eps, int slack_units) {
-  // (plane >= N: units per octet row; the units behind column N - 1 of every row are zero -- grid = ceil(plane / 64))
+                                                            long long plane, float eps, int slack_units, unsigned n_ln, WfragArgs f1,
+                                                            WfragArgs f2) {
+  // (plane >= N: units per octet row; the units behind column N - 1 of every row are zero -- n_ln = ceil(plane / 64) workgroups)
+  // The workgroups behind those re-lay weights (prep_pk_kernel's second half): the fragments of the layer this LayerNorm feeds and,
+  // for a feed-forward block, of the layer behind that one -- the convolutions then start without a preparation launch of their own.
+  if (blockIdx.x >= n_ln) {
+    unsigned b = blockIdx.x - n_ln;
+    const unsigned n1 = (unsigned)f1.gx * f1.gy * f1.gz;
+    const WfragArgs& f = b < n1 ? f1 : f2;
+    if (b >= n1) b -= n1;
+    const unsigned q = b % f.gx, r = b / f.gx;
+    wfrag_pk_block(f, (int)q, (int)(r % f.gy), (int)(r / f.gy));
+    return;
+  }
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const long long n = (long long)blockIdx.x * 64 + lane;
@@ -1139,6 +1151,16 @@ static int launch_pk_tile(ConvPkArgs& a, const PkPlan& pl, hipStream_t stream) {
   return EVMI_OK;
 }
 
+static WfragArgs make_wfrag_args(const ConvPkArgs& a, const PkPlan& pl, const float* w, uint4* wf, int wmode, int rows_g, int kch_g, int k_full,
+                                 int stride_full) {
+  WfragArgs fa;
+  fa.w = w; fa.wf = reinterpret_cast<unsigned*>(wf); fa.rows_g = rows_g; fa.kch_g = kch_g; fa.kt = a.k; fa.MB = a.mblocks; fa.octs = a.octs;
+  fa.kblocks = a.kblocks; fa.mode = wmode; fa.k_full = k_full; fa.stride = stride_full; fa.phase_stride_words = a.wf_phase_stride * 4;
+  fa.tab = reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases); fa.kb_step = a.kb_step; fa.xrow = a.xrow; fa.dil = a.dil;
+  fa.gx = a.kblocks; fa.gy = pl.groups * a.mblocks; fa.gz = a.phases;
+  return fa;
+}
+
 // stage 0: pack + weight fragments + convolution in one call; 1: the preparation alone -- pack AND fragments, one launch; the packed
 // input is left at the head of ws; 2: the convolution alone, on what stage 1 left in the same ws (same shape, hence the same plan: no
 // launch in front of it); 3: fragments + convolution on a packed input that something else put at the head of ws (a producer's
@@ -1156,11 +1178,7 @@ static int launch_pk(ConvPkArgs a, const PkPlan& pl, const float* x, const float
                                (int)(pl.xp_units - (long long)pl.groups * a.octs * a.B * a.Tp), pl.groups);
   pa.pre_slope = in.pre_slope; pa.mask = in.mask; pa.mask_slope = in.mask_slope;
   pa.fuse = in.fuse; pa.fuse_scale = in.fuse_scale; pa.aux = in.aux; pa.p_drop = in.p_drop; pa.seed = in.seed;
-  WfragArgs fa;
-  fa.w = w; fa.wf = reinterpret_cast<unsigned*>(wf); fa.rows_g = rows_g; fa.kch_g = kch_g; fa.kt = a.k; fa.MB = a.mblocks; fa.octs = a.octs;
-  fa.kblocks = a.kblocks; fa.mode = wmode; fa.k_full = k_full; fa.stride = stride_full; fa.phase_stride_words = a.wf_phase_stride * 4;
-  fa.tab = reinterpret_cast<int2*>(wf + a.wf_phase_stride * a.phases); fa.kb_step = a.kb_step; fa.xrow = a.xrow; fa.dil = a.dil;
-  fa.gx = a.kblocks; fa.gy = pl.groups * a.mblocks; fa.gz = a.phases;
+  WfragArgs fa = make_wfrag_args(a, pl, w, wf, wmode, rows_g, kch_g, k_full, stride_full);
   if (stage == 2) fa.gx = fa.gy = fa.gz = 0;
   if (stage == 2 || stage == 3) pa.gx = pa.gy = pa.gz = 0;
   const long long n_prep = (long long)pa.gx * pa.gy * pa.gz + (long long)fa.gx * fa.gy * fa.gz;
@@ -1415,8 +1433,9 @@ int evmi_conv1d_cbt_bf16pk(const float* x_dev, const float* w_dev, const float* 
  *   evmi_layernorm_pack_bf16pk(x, gamma, beta, ws, ...)   ws head <- packed bf16 LayerNorm(x) (+ the zero slack the kernels read past it)
  *   evmi_conv1d_cbt_bf16pk_prepacked(w, bias, y, ws, ...) y = act(conv(that) + bias); ws as evmi_conv1d_cbt_bf16pk's, same geometry
  * The normalised tensor is never stored in fp32; the head of ws is what the layer's weight gradient reads again (..._wgrad_..._prepacked). */
-int evmi_layernorm_pack_bf16pk(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* ws_dev, long long ws_elems, int B,
-                               int c_in, int t_in, int c_out, float eps, void* stream) {
+static int layernorm_pack_impl(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in,
+                               int c_out, float eps, const float* w_dev, const float* w2_dev, float* ws2_dev, long long ws2_elems, int c_out2,
+                               void* stream) {
   if (!x_dev || !gamma_dev || !beta_dev || !ws_dev) return fail(EVMI_ERR_INVALID_ARG, "layernorm_pack_bf16pk: null pointer");
   if (c_in != 128 && c_in != 256) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: 128 or 256 channels");
   if (!pk_shared_items(B, t_in)) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: B * t must be a multiple of 64 (or one item)");
@@ -1429,16 +1448,46 @@ int evmi_layernorm_pack_bf16pk(const float* x_dev, const float* gamma_dev, const
     return fail(EVMI_ERR_INVALID_ARG, "layernorm_pack_bf16pk: workspace too small or unaligned");
   const long long N = (long long)B * t_in, plane = (long long)B * a.Tp;
   const int slack = (int)(pl.xp_units - (long long)a.octs * plane);
-  const dim3 grid((unsigned)((plane + 63) / 64));
   uint4* xp = reinterpret_cast<uint4*>(ws_dev);
-  if (c_in == 256) hipLaunchKernelGGL(layernorm_pack_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, plane, eps, slack);
-  else hipLaunchKernelGGL(layernorm_pack_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, plane, eps, slack);
+  // the fragment jobs riding in the same launch (empty grids when the weights are not given)
+  WfragArgs f1 = {}, f2 = {};
+  if (w_dev) f1 = make_wfrag_args(a, pl, w_dev, xp + pl.xp_units, 0, c_out, c_in, 1, 1);
+  if (w2_dev) {
+    ConvPkArgs a2 = {};
+    PkPlan pl2;
+    if (const char* why = plan_fwd_pk(a2, pl2, B, c_out, t_in, c_out2, t_in, t_in, 1, 1, 0, 1, 1, 1, 0))
+      return fail(EVMI_ERR_UNSUPPORTED, std::string("layernorm_pack_bf16pk (second layer): ") + why);
+    if (!w_dev || !ws2_dev || ws2_elems < (pl2.xp_units + pl2.wf_units) * 4 + pl2.part_elems || (reinterpret_cast<uintptr_t>(ws2_dev) & 15))
+      return fail(EVMI_ERR_INVALID_ARG, "layernorm_pack_bf16pk: the second layer's workspace is missing, too small or unaligned");
+    f2 = make_wfrag_args(a2, pl2, w2_dev, reinterpret_cast<uint4*>(ws2_dev) + pl2.xp_units, 0, c_out2, c_out, 1, 1);
+  }
+  const unsigned n_ln = (unsigned)((plane + 63) / 64);
+  const long long n_blk = (long long)n_ln + (long long)f1.gx * f1.gy * f1.gz + (long long)f2.gx * f2.gy * f2.gz;
+  if (n_blk > 0x7fffffffLL) return fail(EVMI_ERR_UNSUPPORTED, "layernorm_pack_bf16pk: grid limits");
+  const dim3 grid((unsigned)n_blk);
+  if (c_in == 256) hipLaunchKernelGGL(layernorm_pack_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, plane, eps, slack, n_ln, f1, f2);
+  else hipLaunchKernelGGL(layernorm_pack_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, x_dev, gamma_dev, beta_dev, xp, c_in, N, plane, eps, slack, n_ln, f1, f2);
   EVMI_LAUNCH_CHECK("layernorm_pack");
   return EVMI_OK;
 }
 
+int evmi_layernorm_pack_bf16pk(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* ws_dev, long long ws_elems, int B,
+                               int c_in, int t_in, int c_out, float eps, void* stream) {
+  return layernorm_pack_impl(x_dev, gamma_dev, beta_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, eps, nullptr, nullptr, nullptr, 0, 0, stream);
+}
+
+/* ... with the weight fragments of the layer(s) behind the LayerNorm prepared by the SAME launch: w_dev [c_out][c_in] into ws_dev (the
+ * layer then runs with fragments_ready = 1 / in_mode 3) and, for a feed-forward block, w2_dev [c_out2][c_out] into ws2_dev, the second
+ * layer's workspace (NULL: none). */
+int evmi_layernorm_pack_bf16pk_w(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* ws_dev, long long ws_elems, int B,
+                                 int c_in, int t_in, int c_out, float eps, const float* w_dev, const float* w2_dev, float* ws2_dev,
+                                 long long ws2_elems, int c_out2, void* stream) {
+  if (!w_dev) return fail(EVMI_ERR_INVALID_ARG, "layernorm_pack_bf16pk_w: null pointer");
+  return layernorm_pack_impl(x_dev, gamma_dev, beta_dev, ws_dev, ws_elems, B, c_in, t_in, c_out, eps, w_dev, w2_dev, ws2_dev, ws2_elems, c_out2, stream);
+}
+
 int evmi_conv1d_cbt_bf16pk_prepacked(const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev, long long ws_elems, int B,
-                                     int c_in, int t_in, int c_out, int act, float act_param, void* stream) {
+                                     int c_in, int t_in, int c_out, int act, float act_param, int fragments_ready, void* stream) {
   if (!w_dev || !y_dev || !ws_dev) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_prepacked: null pointer");
   if (act < 0 || act > 4) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_prepacked: activation");
   ConvPkArgs a = {};
@@ -1446,8 +1495,9 @@ int evmi_conv1d_cbt_bf16pk_prepacked(const float* w_dev, const float* bias_dev, 
   if (const char* why = plan_fwd_pk(a, pl, B, c_in, t_in, c_out, t_in, t_in, 1, 1, 0, 1, 1, 1, 0))
     return fail(EVMI_ERR_UNSUPPORTED, std::string("conv1d_cbt_bf16pk_prepacked: ") + why);
   a.bias = bias_dev; a.y = y_dev; a.accumulate = 0; a.act = act; a.act_param = act_param;
-  // (stage 3: the pack is an empty grid; the fp32 input pointer is never read)
-  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 3);
+  // (stage 3: the pack is an empty grid; the fp32 input pointer is never read.  stage 2: the fragments are there too)
+  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(),
+                   fragments_ready ? 2 : 3);
 }
 
 /* The same with the fusions of a residual block's forward: the input passes through leaky_relu(., pre_slope) while it is packed
@@ -1556,8 +1606,8 @@ int evmi_conv1d_cbt_bf16pk_resdrop(int in_mode, const float* x_dev, const float*
                                    float* y_dev, float* ws_dev, long long ws_elems, int B, int c_in, int t_in, int c_out, float in_p,
                                    unsigned long long in_seed, float out_p, unsigned long long out_seed, float out_scale,
                                    const unsigned long long* seed_base_dev, void* stream) {
-  if (!w_dev || !y_dev || !residual_dev || (in_mode != 2 && !x_dev)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_resdrop: null pointer");
-  if (in_mode < 0 || in_mode > 2) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_resdrop: in_mode 0, 1 or 2");
+  if (!w_dev || !y_dev || !residual_dev || (in_mode < 2 && !x_dev)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_resdrop: null pointer");
+  if (in_mode < 0 || in_mode > 3) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_resdrop: in_mode 0 .. 3");
   if (in_p < 0.f || in_p >= 1.f || out_p < 0.f || out_p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_resdrop: p outside [0, 1)");
   ConvPkArgs a = {};
   PkPlan pl;
@@ -1572,8 +1622,9 @@ int evmi_conv1d_cbt_bf16pk_resdrop(int in_mode, const float* x_dev, const float*
   if (in_mode == 1) {
     in.fuse = 1; in.p_drop = in_p; in.seed = SeedArg{in_seed, seed_base_dev};
   }
-  if (in_mode == 2)
-    return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 3);
+  if (in_mode >= 2)  // (3: the weight fragments are in ws too -- evmi_layernorm_pack_bf16pk_w)
+    return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(),
+                     in_mode == 3 ? 2 : 3);
   return launch_pk(a, pl, x_dev, w_dev, ws_dev, ws_elems, 0, c_out, c_in, 1, 1, (hipStream_t)stream, in);
 }
 
@@ -1620,7 +1671,7 @@ static int ffn_tail_check(const ConvPkArgs& a2, const PkPlan& pl2, int B, int t,
 
 int evmi_conv1d_cbt_bf16pk_ffn_up(const float* w_dev, const float* bias_dev, float* ws_dev, long long ws_elems, void* a_pk_dev,
                                   float* next_ws_dev, long long next_ws_elems, int B, int c_in, int t, int c_mid, int c_out, float p,
-                                  unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream) {
+                                  unsigned long long seed_value, const unsigned long long* seed_base_dev, int fragments_ready, void* stream) {
   if (!w_dev || !ws_dev || !a_pk_dev || (reinterpret_cast<uintptr_t>(a_pk_dev) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_ffn_up: null / unaligned pointer");
   if (p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_ffn_up: p outside [0, 1)");
   ConvPkArgs a = {}, a2 = {};
@@ -1639,7 +1690,8 @@ int evmi_conv1d_cbt_bf16pk_ffn_up(const float* w_dev, const float* bias_dev, flo
   a.po.y = reinterpret_cast<uint4*>(a_pk_dev); a.po.y2 = nxt; a.po.plane = plane; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
   a.po.tail = 1; a.po.drop_ld = N; a.po.Tm = (int)N; a.po.mplane = plane;
   a.drop_p = p; a.drop_seed = SeedArg{seed_value, seed_base_dev};
-  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_mid, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(), 3);
+  return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_mid, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(),
+                   fragments_ready ? 2 : 3);
 }
 
 int evmi_conv1d_dgrad_cbt_bf16pk_ffn_down(const float* w_dev, float* ws_dev, long long ws_elems, const void* a_pk_dev, float* next_ws_dev,

@@ -717,10 +717,11 @@ def layernorm_dense_fwd(x, gamma, beta, w, bias, keep, act=ACT_NONE, eps=1e-5):
     pk_elems = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t, cout, t, 1, 1, 0, 1, 1)
     ws = keep["x_packed"] = torch.empty(pk_elems, device=x.device, dtype=torch.float32)
     out = torch.empty(cout, B, t, device=x.device, dtype=torch.float32)
-    _chk(lib.evmi_layernorm_pack_bf16pk(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t, cout, eps, _s(x)),
-         "evmi_layernorm_pack_bf16pk")
+    # (the layer's weight fragments are prepared by LayerNorm's launch: the convolution starts without a preparation launch of its own)
+    _chk(lib.evmi_layernorm_pack_bf16pk_w(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t, cout, eps, w.data_ptr(), None, None,
+                                          0, 0, _s(x)), "evmi_layernorm_pack_bf16pk_w")
     _count_conv(B, t, cout, cin, 1)
-    _chk(lib.evmi_conv1d_cbt_bf16pk_prepacked(w.data_ptr(), _lib.ptr(bias), out.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t, cout, act, 0.0, _s(x)),
+    _chk(lib.evmi_conv1d_cbt_bf16pk_prepacked(w.data_ptr(), _lib.ptr(bias), out.data_ptr(), ws.data_ptr(), pk_elems, B, cin, t, cout, act, 0.0, 1, _s(x)),
          "evmi_conv1d_cbt_bf16pk_prepacked")
     return out
 
@@ -802,12 +803,14 @@ def ffn_packed_fwd(x, gamma, beta, w1, b1, w2, b2, res, p, seed, seed_out, scale
     a_pk = keep["a_pk"] = torch.empty(cmid // 8 * pk_pitch(B, t) * 4, device=x.device, dtype=torch.float32)  # 16-byte units of 8 bf16 channels
     out = torch.empty(cout, B, t, device=x.device, dtype=torch.float32)
     st = _s(x)
-    _chk(lib.evmi_layernorm_pack_bf16pk(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws1.data_ptr(), n1, B, cin, t, cmid, eps, st), "evmi_layernorm_pack_bf16pk")
+    # three launches: LayerNorm (+ the weight fragments of both layers), dense1, dense2
+    _chk(lib.evmi_layernorm_pack_bf16pk_w(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws1.data_ptr(), n1, B, cin, t, cmid, eps, w1.data_ptr(), w2.data_ptr(),
+                                          ws2.data_ptr(), n2, cout, st), "evmi_layernorm_pack_bf16pk_w")
     _count_conv(B, t, cmid, cin, 1)
     _chk(lib.evmi_conv1d_cbt_bf16pk_ffn_up(w1.data_ptr(), _lib.ptr(b1), ws1.data_ptr(), n1, a_pk.data_ptr(), ws2.data_ptr(), n2, B, cin, t, cmid, cout, float(p),
-                                           int(seed), _lib.ptr(SEED_BASE[0]), st), "evmi_conv1d_cbt_bf16pk_ffn_up")
+                                           int(seed), _lib.ptr(SEED_BASE[0]), 1, st), "evmi_conv1d_cbt_bf16pk_ffn_up")
     _count_conv(B, t, cout, cmid, 1)
-    _chk(lib.evmi_conv1d_cbt_bf16pk_resdrop(2, None, w2.data_ptr(), _lib.ptr(b2), res.data_ptr(), out.data_ptr(), ws2.data_ptr(), n2, B, cmid, t, cout, 0.0, 0,
+    _chk(lib.evmi_conv1d_cbt_bf16pk_resdrop(3, None, w2.data_ptr(), _lib.ptr(b2), res.data_ptr(), out.data_ptr(), ws2.data_ptr(), n2, B, cmid, t, cout, 0.0, 0,
                                             float(p), int(seed_out), float(scale), _lib.ptr(SEED_BASE[0]), st), "evmi_conv1d_cbt_bf16pk_resdrop")
     return out
 
@@ -1151,21 +1154,27 @@ def layernorm_flush():
         _LN_PENDING.clear()
 
 
-def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5):
-    """dx; dgamma / dbeta are accumulated into (with LN_DEFER["on"]: by the chain's ``wgrad_join``)."""
+def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5, acc_into=None):
+    """dx; dgamma / dbeta are accumulated into (with LN_DEFER["on"]: by the chain's ``wgrad_join``).  ``acc_into``: a tensor of x's shape
+    the kernel ADDS dx to (and which is returned) -- the input's gradient so far, e.g. the residual path's: no separate add pass."""
     lib = _lib.load()
     C, N = x.shape[0], x.shape[1] * x.shape[2]
     n = lib.evmi_layernorm_bwd_cbt_f32_ws_elems(C, N)
-    dx = torch.empty_like(x)
+    acc = 0
+    if acc_into is not None:
+        assert acc_into.shape == x.shape and acc_into.is_contiguous() and acc_into.dtype == torch.float32
+        dx, acc = acc_into, 1
+    else:
+        dx = torch.empty_like(x)
     if LN_DEFER["on"] and x.is_cuda:
         ws = torch.empty(n, device=x.device, dtype=torch.float32)
-        _chk(lib.evmi_layernorm_bwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), n, C, N, eps, 0, _s(x)),
+        _chk(lib.evmi_layernorm_bwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), n, C, N, eps, acc, _s(x)),
              "evmi_layernorm_bwd_cbt_f32")
         _LN_PENDING.append((ws, dgamma, dbeta, C, N))
         return dx
     ws = WS.get("ln_bwd", n, x.device)
     _chk(lib.evmi_layernorm_bwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                        ws.data_ptr(), n, C, N, eps, 0, _s(x)), "evmi_layernorm_bwd_cbt_f32")
+                                        ws.data_ptr(), n, C, N, eps, acc, _s(x)), "evmi_layernorm_bwd_cbt_f32")
     return dx
 
 

@@ -290,9 +290,11 @@ long long evmi_conv1d_wgrad_cbt_bf16pk_ws_elems(int B, int c_in, int t_in, int c
 int evmi_conv1d_wgrad_cbt_bf16pk(const float* x_dev, const float* dy_dev, float* dw_dev, float* ws_dev,
                                  long long ws_elems, int B, int c_in, int t_in, int c_out, int n_out, int k, int stride,
                                  int pad, int dil, int groups, int accumulate, void* stream);
-/* evmi_conv1d_dgrad_cbt_bf16pk in two steps (same arguments and workspace for both): stage 1 packs dy into the head of ws_dev, stage 2
- * runs the rest on it.  Between them a training step forks its weight-gradient stream: a pointwise layer's weight gradient reads the
- * packed dy (evmi_conv1d_wgrad_cbt_bf16pk_prepacked) beside the input gradient. */
+/* evmi_conv1d_dgrad_cbt_bf16pk in two steps (same arguments and workspace for both): stage 1 packs dy into the head of ws_dev and
+ * prepares the weight fragments behind it (one launch), stage 2 runs the convolution on them.  Between them a training step forks its
+ * weight-gradient stream: a pointwise layer's weight gradient reads the packed dy (evmi_conv1d_wgrad_cbt_bf16pk_prepacked) beside the
+ * input gradient.  Stage 3: fragments + convolution on a packed dy that a producer's epilogue left at the head of ws_dev
+ * (evmi_conv1d_dgrad_cbt_bf16pk_ffn_down). */
 int evmi_conv1d_dgrad_cbt_bf16pk_staged(int stage, const float* dy_dev, const float* w_dev, float* dx_dev, float* ws_dev, long long ws_elems,
                                         int B, int c_in, int t_in, int c_out, int t_out, int k, int stride, int pad, int dil, int groups,
                                         void* stream);
@@ -315,7 +317,8 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_silu_dropout(int stage, const float* ds_
  * torchaudio-style Conformer sub-layers `x + dropout(sublayer(x))`, FastSpeech2_lightning -- absent submodule), and the
  * matching pack of the backward:
  *   evmi_conv1d_cbt_bf16pk_resdrop:              y = residual + out_scale * dropout(conv(in) + bias, out_p); in_mode 0: in = x, 1: in =
- *                                                dropout(silu(x), in_p), 2: packed input already at the head of ws (x not read)
+ *                                                dropout(silu(x), in_p), 2: packed input already at the head of ws (x not read), 3: and
+ *                                                the weight fragments behind it (evmi_layernorm_pack_bf16pk_w)
  *   evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout: evmi_conv1d_dgrad_cbt_bf16pk_staged on dz = scale * dropout(dy, p) (stage 1 packs it)
  * Mask streams of evmi_dropout_fused_f32 (seed + *seed_base_dev, element index = index in the tensor). */
 int evmi_conv1d_cbt_bf16pk_resdrop(int in_mode, const float* x_dev, const float* w_dev, const float* bias_dev, const float* residual_dev,
@@ -338,7 +341,7 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(int stage, const float* dy_dev, 
  * Mask streams of evmi_conv1d_cbt_bf16pk_silu_dropout / ..._staged_silu_dropout; silu' is taken at bf16(a). */
 int evmi_conv1d_cbt_bf16pk_ffn_up(const float* w_dev, const float* bias_dev, float* ws_dev, long long ws_elems, void* a_pk_dev,
                                   float* next_ws_dev, long long next_ws_elems, int B, int c_in, int t, int c_mid, int c_out, float p,
-                                  unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream);
+                                  unsigned long long seed_value, const unsigned long long* seed_base_dev, int fragments_ready, void* stream);
 int evmi_conv1d_dgrad_cbt_bf16pk_ffn_down(const float* w_dev, float* ws_dev, long long ws_elems, const void* a_pk_dev, float* next_ws_dev,
                                           long long next_ws_elems, int B, int c_in, int t, int c_mid, int c_out, float p,
                                           unsigned long long seed_value, const unsigned long long* seed_base_dev, void* stream);
@@ -347,8 +350,15 @@ int evmi_conv1d_dgrad_cbt_bf16pk_ffn_down(const float* w_dev, float* ws_dev, lon
  * normalised tensor is never stored in fp32.  ws: evmi_conv1d_cbt_bf16pk_ws_elems floats of the layer (k = 1, stride 1, no padding). */
 int evmi_layernorm_pack_bf16pk(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* ws_dev, long long ws_elems, int B,
                                int c_in, int t_in, int c_out, float eps, void* stream);
+/* ... with the weight fragments of the layer(s) behind the LayerNorm prepared by the SAME launch: w_dev [c_out][c_in] into ws_dev (run the
+ * layer with fragments_ready = 1) and, for a feed-forward block, w2_dev [c_out2][c_out] into ws2_dev, the second layer's workspace
+ * (run it with evmi_conv1d_cbt_bf16pk_resdrop in_mode 3); w2_dev NULL: the first layer only. */
+int evmi_layernorm_pack_bf16pk_w(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* ws_dev, long long ws_elems, int B,
+                                 int c_in, int t_in, int c_out, float eps, const float* w_dev, const float* w2_dev, float* ws2_dev,
+                                 long long ws2_elems, int c_out2, void* stream);
+/* fragments_ready: the weight fragments are in ws already (evmi_layernorm_pack_bf16pk_w): the call is the convolution launch alone. */
 int evmi_conv1d_cbt_bf16pk_prepacked(const float* w_dev, const float* bias_dev, float* y_dev, float* ws_dev, long long ws_elems, int B,
-                                     int c_in, int t_in, int c_out, int act, float act_param, void* stream);
+                                     int c_in, int t_in, int c_out, int act, float act_param, int fragments_ready, void* stream);
 /* The packed bf16 convolution kernels with a residual block's neighbours fused in (no separate activation / add passes, no
  * activated copies in HBM) -- the training-side counterpart of SURVEY.md 8b's evmi_resblock1_fused_{fwd,bwd}:
  *   forward   y = act(conv(leaky_relu(x, pre_slope)) + bias) + residual

@@ -35,5 +35,7 @@ for B, T in ((32, 814), (32, 150)):
     t_f = timed(lambda: ops.layernorm(x, g, b))
     t_b = timed(lambda: ops.layernorm_bwd(x, g, dy, dg, db))
     t_e = timed(lambda: ops.axpby(1.0, x, 1.0, dy))
-    print(f"{B} x {T} ({mb:.1f} MB per tensor): layernorm {t_f:.1f} us ({2 * mb / t_f:.0f} GB/s), backward {t_b:.1f} us ({3 * mb / t_b:.0f} GB/s), "
-          f"a + b {t_e:.1f} us ({3 * mb / t_e:.0f} GB/s)")
+    acc = torch.zeros_like(x)
+    t_a = timed(lambda: ops.layernorm_bwd(x, g, dy, dg, db, acc_into=acc))
+    print(f"{B} x {T} ({mb:.1f} MB per tensor): layernorm {t_f:.1f} us ({2 * mb / t_f:.2f} TB/s), backward {t_b:.1f} us ({3 * mb / t_b:.2f} TB/s), "
+          f"backward adding into the gradient {t_a:.1f} us ({4 * mb / t_a:.2f} TB/s), a + b {t_e:.1f} us ({3 * mb / t_e:.2f} TB/s)")
