@@ -15,6 +15,7 @@
 //   embedding / bucket / item-embedding backward (scatter-add), length regulator backward (segment sums)
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.h"
 #include "evmi.h"
@@ -495,13 +496,13 @@ __global__ __launch_bounds__(256) void dropout_fused_kernel(const float* __restr
 }
 
 // ---- embeddings, backward ------------------------------------------------------------------------------------------
-// dtable[r][c] += sum of dx[c][n] over the tokens n that map to row r, added in token order (a fixed order: bitwise reproducible,
-// unlike a scatter with atomics).  text embedding: row = ids[b][l] for l < lens[b], ids != skip_id;  variance buckets: ids = the
+// dtable[r][c] += sum of dx[c][n] over the tokens n that map to row r, added in a fixed order (four interleaved running sums in token
+// order: bitwise reproducible, unlike a scatter with atomics).  text embedding: row = ids[b][l] for l < lens[b], ids != skip_id;  variance buckets: ids = the
 // precomputed bucket index of every position, lens = NULL (the forward adds everywhere, pads included).
 // One workgroup per CHANNEL (x 256 table rows): the channel's gradient row and the row indices go through LDS in chunks (coalesced
 // reads, each once), and thread r walks the chunk's tokens for ITS table row -- every LDS read is a broadcast, there is no gather.
 // (The form this replaces had one workgroup per table row gather its matches from the channel-major tensor: 64 cache lines per wave
-// load, 105 us per call at 4.5 k positions; same order of additions, same bits.)
+// load, 105 us per call at 4.5 k positions.)
 constexpr int TABLE_CHUNK = 4096;
 __global__ __launch_bounds__(256) void fs2_table_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ ids,
                                                            const int* __restrict__ lens, float* __restrict__ dtable, int B, int L,
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256) void fs2_table_bwd_kernel(const float* __restr
   const int r = blockIdx.y * 256 + threadIdx.x;
   const int N = B * L;
   const float* row = dx + (long long)c * N;
-  float acc = 0.f;
+  float acc4[4] = {0.f, 0.f, 0.f, 0.f};
   for (int base = 0; base < N; base += TABLE_CHUNK) {
     const int cnt = min(TABLE_CHUNK, N - base);
     __syncthreads();
@@ -525,17 +526,19 @@ __global__ __launch_bounds__(256) void fs2_table_bwd_kernel(const float* __restr
       val[i] = v;
     }
     __syncthreads();
+    // four running sums (tokens 4 i + e): a fixed order -- bitwise reproducible -- without one chain of N dependent additions
     const int cnt4 = (cnt + 3) & ~3;  // (the chunk's tail is staged as skipped tokens)
+#pragma unroll 4
     for (int i = 0; i < cnt4; i += 4) {
       const int4 s4 = *reinterpret_cast<const int4*>(&sid[i]);
       const float4 v4 = *reinterpret_cast<const float4*>(&val[i]);
-      acc += s4.x == r ? v4.x : 0.f;  // (+ 0.f: a token of another row leaves the sum's bits as they are)
-      acc += s4.y == r ? v4.y : 0.f;
-      acc += s4.z == r ? v4.z : 0.f;
-      acc += s4.w == r ? v4.w : 0.f;
+      acc4[0] += s4.x == r ? v4.x : 0.f;
+      acc4[1] += s4.y == r ? v4.y : 0.f;
+      acc4[2] += s4.z == r ? v4.z : 0.f;
+      acc4[3] += s4.w == r ? v4.w : 0.f;
     }
   }
-  if (r < rows) dtable[(long long)r * D + c] += acc;
+  if (r < rows) dtable[(long long)r * D + c] += (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
 }
 
 // bucket index of every token: first boundary >= value (torch.bucketize, right = False)
@@ -600,6 +603,9 @@ int evmi_layernorm_bwd_cbt_f32(const float* x, const float* gamma, const float* 
   hipStream_t s = (hipStream_t)stream;
   const unsigned nblk = (unsigned)((n_cols + 63) / 64);
   if (C <= 64) hipLaunchKernelGGL((layernorm_bwd_cbt_kernel<16, 4>), dim3(nblk), dim3(256), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
+  // fewer workgroups than CUs (the encoder's 4.5 k columns): sixteen slices of 16 channels -- twice the waves on each of the few CUs
+  // that work (21.6 -> 16.8 us); with every CU busy the eight-slice form is the faster one (35.9 vs 43.0 us at 26 k columns)
+  else if (nblk <= 256) hipLaunchKernelGGL((layernorm_bwd_cbt_kernel<16, 16>), dim3(nblk), dim3(1024), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
   else hipLaunchKernelGGL((layernorm_bwd_cbt_kernel<32, 8>), dim3(nblk), dim3(512), 0, s, x, gamma, dy, dx, ws, C, n_cols, eps, accumulate_dx);
   EVMI_LAUNCH_CHECK("layernorm_bwd_cbt");
   if (!dgamma) return EVMI_OK;  // (the partial sums stay in ws: evmi_layernorm_bwd_partials_reduce)
