@@ -653,6 +653,7 @@ class FastSpeech2Trainer:
         # of mostly small launches, so the two fill each other's gaps
         self.side_wgrad = (os.environ.get("EVMI_FS2_SIDE_WGRAD", "1") == "1") if side_wgrad is None else bool(side_wgrad)
         self._stream = None  # set at the end of __init__ (with its sibling streams)
+        self._pred_branch = os.environ.get("EVMI_FS2_PRED_STREAM", "1") == "1"  # the variance predictors beside the decoder (_step)
         self.use_graph = bool(use_graph)
         self.graph_buckets = tuple(int(v) for v in graph_buckets) if graph_buckets else None  # (symbols, frames) multiples to pad to
         self._graphs, self._graph_warm, self._graph_failed, self.last_step_was_graph = {}, {}, None, False
@@ -714,6 +715,9 @@ class FastSpeech2Trainer:
         if self.aligner is not None:
             self.aligner._side = torch.cuda.Stream(self.device)
             self.aligner._side_mas = torch.cuda.Stream(self.device)
+        if self.device.type == "cuda":
+            self._pred_stream = torch.cuda.Stream(self.device)
+            self._pred_fork, self._pred_done = torch.cuda.Event(), torch.cuda.Event()
 
     def _tail_offset(self) -> int:
         """First element of the flat buffers that belongs to the decoder / mel_linear / postnet (declared last, in this order)."""
@@ -965,7 +969,23 @@ class FastSpeech2Trainer:
             return v
 
         losses = {}
+        # The variance predictors are side branches under teacher forcing (see below): they get a tape of their own and ALIASES of their
+        # inputs, in every training schedule (one order of additions into the encoder output's gradient whatever stream runs them).
+        struct = not _EVAL[0]
+        on_stream = struct and self._pred_branch and not segmented and dev.type == "cuda"
+        pjoin = {"done": None, "tape": Tape()} if struct else None
+
+        def join_branch(var, alias):
+            """(a tape operator) the main chain waits for the branch and takes the gradient it left on its alias of `var`"""
+            if pjoin["done"] is not None:
+                torch.cuda.current_stream(dev).wait_event(pjoin["done"])
+                pjoin["done"] = None
+            if alias.grad is not None:
+                var.accumulate(alias.grad)
+
         if learn:
+            # (The aligner's backward on the predictors' stream as well -- it depends on its own losses only -- was measured: it gave the
+            # predictors' 1.2 ms back, 17.7 vs 16.5 ms; its fp32 products are large enough to take CUs from the decoder's backward.)
             align_join = self.aligner.forward(tape, embed(False), Var(mel_t, needs_grad=False), batch.get("attn_prior"), lens, mel_lens, n_frames,
                                               tr.attn_ctc_loss_weight, self._bin_weight() > 0.0, self._scal[4:5], self._scal[5:6])
         else:
@@ -987,15 +1007,41 @@ class FastSpeech2Trainer:
                 x = self._add_item_embedding(tape, x, table, batch[key], lens)
 
         w = tr.duration_loss_weight
-        # (Measured and not kept: the three variance predictors -- side branches under teacher forcing, ~200 small launches -- on
-        # streams of their own beside the length regulator and the decoder, forward and backward.  In graph mode, where issuing them
-        # costs nothing: 26.7 vs 24.1 ms per step, same box, twice.  The replayed graph already keeps the device busy; three more
-        # concurrent chains of small kernels take slots from the decoder's large ones.)
-        losses["duration"] = mse_loss(tape, self.duration_predictor.forward(tape, x, lens, seeds), log_d_t.view(1, B, L), n_tok, w)
-        losses["pitch"] = mse_loss(tape, self.pitch_predictor.forward(tape, x, lens, seeds), pitch_t.view(1, B, L), n_tok, tr.pitch_loss_weight)
-        x = self._add_bucket_embedding(tape, x, pitch_t, self.pitch_bins, self.pitch_table)
-        losses["energy"] = mse_loss(tape, self.energy_predictor.forward(tape, x, lens, seeds), energy_t.view(1, B, L), n_tok, tr.energy_loss_weight)
-        x = self._add_bucket_embedding(tape, x, energy_t, self.energy_bins, self.energy_table)
+        # The three variance predictors are side branches under teacher forcing (the decoder takes the TARGETS' embeddings): ~170 launches
+        # of ~8 us at 4.5 k columns, forward and backward.  They run as ONE chain on a stream of their own beside the length regulator, the
+        # decoder and its backward, on aliases of the encoder output whose gradients join the main chain where that output's backward
+        # starts: 17.7 -> 16.5 ms per step.  (Three chains on three streams, each forked per predictor, were measured in round 3 and lost
+        # 2.6 ms: ~600 small launches then, every one a cross-stream edge of the captured graph.)
+        if struct:
+            xe, xa = x, Var(x.data)  # the predictors' view of the encoder output: same data, its own gradient
+            _ACTIVATION_ELEMS[0] -= x.data.numel()  # (an alias, not another activation)
+            tape.record(lambda: join_branch(xe, xa))  # (runs in backward when everything behind x has contributed: in front of the encoder's backward)
+            x1 = self._add_bucket_embedding(tape, x, pitch_t, self.pitch_bins, self.pitch_table)
+            x1a = Var(x1.data)
+            _ACTIVATION_ELEMS[0] -= x1.data.numel()
+            tape.record(lambda: join_branch(x1, x1a))
+            tp = pjoin["tape"]
+
+            def predictors():
+                losses["duration"] = mse_loss(tp, self.duration_predictor.forward(tp, xa, lens, seeds), log_d_t.view(1, B, L), n_tok, w)
+                losses["pitch"] = mse_loss(tp, self.pitch_predictor.forward(tp, xa, lens, seeds), pitch_t.view(1, B, L), n_tok, tr.pitch_loss_weight)
+                losses["energy"] = mse_loss(tp, self.energy_predictor.forward(tp, x1a, lens, seeds), energy_t.view(1, B, L), n_tok, tr.energy_loss_weight)
+
+            if on_stream:
+                main = torch.cuda.current_stream(dev)
+                self._pred_fork.record(main)
+                self._pred_stream.wait_event(self._pred_fork)
+                with torch.cuda.stream(self._pred_stream):
+                    predictors()
+            else:
+                predictors()
+            x = self._add_bucket_embedding(tape, x1, energy_t, self.energy_bins, self.energy_table)
+        else:
+            losses["duration"] = mse_loss(tape, self.duration_predictor.forward(tape, x, lens, seeds), log_d_t.view(1, B, L), n_tok, w)
+            losses["pitch"] = mse_loss(tape, self.pitch_predictor.forward(tape, x, lens, seeds), pitch_t.view(1, B, L), n_tok, tr.pitch_loss_weight)
+            x = self._add_bucket_embedding(tape, x, pitch_t, self.pitch_bins, self.pitch_table)
+            losses["energy"] = mse_loss(tape, self.energy_predictor.forward(tape, x, lens, seeds), energy_t.view(1, B, L), n_tok, tr.energy_loss_weight)
+            x = self._add_bucket_embedding(tape, x, energy_t, self.energy_bins, self.energy_table)
 
         frames = torch.empty(D, B, T, device=dev, dtype=torch.float32)
         _chk(lib.evmi_length_regulate_cbt_f32(x.data.data_ptr(), cum.data_ptr(), frames.data_ptr(), D, B, L, T, _s(frames)), "evmi_length_regulate_cbt_f32")
@@ -1034,7 +1080,36 @@ class FastSpeech2Trainer:
             ops.wgrad_join(dev)
             return self._finish_backward(losses, grads=False)
         if segmented:
-            return tape.backward_segments(), losses
+            def segments():
+                pjoin["tape"].backward()  # (the predictors' backward: in front of the chain's first stretch, on its stream)
+                yield from tape.backward_segments()
+
+            return segments(), losses
+        if on_stream:
+            # the predictors' backward starts with the step's: on their stream, behind their forward, beside the decoder's backward
+            main = torch.cuda.current_stream(dev)
+            self._pred_fork.record(main)
+            self._pred_stream.wait_event(self._pred_fork)
+            with torch.cuda.stream(self._pred_stream):
+                side_on, ops.SIDE_WGRAD["on"] = ops.SIDE_WGRAD["on"], False  # (their weight gradients stay on this stream: it is a side chain already)
+                # (what the branch's operators hold must outlive the branch's KERNELS, not just their launches: kept until the chain has joined)
+                keep = list(pjoin["tape"]._ops)
+                try:
+                    pjoin["tape"].backward()
+                    self._pred_done.record(self._pred_stream)
+                finally:
+                    ops.SIDE_WGRAD["on"] = side_on
+            pjoin["done"] = self._pred_done
+            if not torch.cuda.is_current_stream_capturing():
+                for t in [v for v in losses.values() if torch.is_tensor(v)]:
+                    t.record_stream(main)
+            tape.backward()
+            if pjoin["done"] is not None:  # (no join ran: nothing needed the encoder output's gradient)
+                main.wait_event(pjoin["done"])
+            del keep
+            return self._finish_backward(losses)
+        if struct:
+            pjoin["tape"].backward()
         tape.backward()
         return self._finish_backward(losses)
 

@@ -276,8 +276,8 @@ class side_wgrad:
 def side_check_drained():
     """Raises if weight-gradient launches are still collected on the host (a chain ended without its ``wgrad_join``): the trainers
     call this at the end of every step."""
-    if _LN_PENDING:
-        n_ln = len(_LN_PENDING)
+    if any(_LN_PENDING.values()):
+        n_ln = sum(len(v) for v in _LN_PENDING.values())
         _LN_PENDING.clear()
         raise RuntimeError(f"layernorm_bwd: {n_ln} deferred parameter-gradient reductions were never issued (a backward chain ended without wgrad_join)")
     left = sum(len(st.queue) for st in _SIDE.values())
@@ -1137,21 +1137,28 @@ def layernorm(x, gamma, beta, eps=1e-5):
 # LayerNorm backward leaves its per-workgroup partial sums in a buffer of its own and ``wgrad_join`` -- where every chain ends --
 # reduces all the lists collected since in one launch (55 small launches on the step's critical chain otherwise).
 LN_DEFER = {"on": False}
-_LN_PENDING = []  # (partials, dgamma, dbeta, C, N, stream)
+_LN_PENDING = {}  # stream -> [(partials, dgamma, dbeta, C, N)]: a chain's partials are reduced on the stream that produced them
 
 
 def layernorm_flush():
-    """Reduce the partial lists the deferred LayerNorm backwards left (on the current stream, which issued them)."""
+    """Reduce the partial lists the deferred LayerNorm backwards of the CURRENT stream left."""
     if not _LN_PENDING:
         return
-    jobs = (_lib.LnPartials * len(_LN_PENDING))()
-    for j, (ws, dg, db, C, N) in zip(jobs, _LN_PENDING):
-        j.ws, j.dgamma, j.dbeta, j.C, j.n_cols = ws.data_ptr(), dg.data_ptr(), db.data_ptr(), C, N
-    dev = _LN_PENDING[0][0].device
-    try:
-        _chk(_lib.load().evmi_layernorm_bwd_partials_reduce(len(_LN_PENDING), jobs, _lib.current_stream_ptr(dev)), "evmi_layernorm_bwd_partials_reduce")
-    finally:
-        _LN_PENDING.clear()
+    for key in list(_LN_PENDING):
+        pend = _LN_PENDING[key]
+        if not pend:
+            del _LN_PENDING[key]
+            continue
+        dev = pend[0][0].device
+        if _lib.current_stream_ptr(dev) != key:
+            continue
+        jobs = (_lib.LnPartials * len(pend))()
+        for j, (ws, dg, db, C, N) in zip(jobs, pend):
+            j.ws, j.dgamma, j.dbeta, j.C, j.n_cols = ws.data_ptr(), dg.data_ptr(), db.data_ptr(), C, N
+        try:
+            _chk(_lib.load().evmi_layernorm_bwd_partials_reduce(len(pend), jobs, key), "evmi_layernorm_bwd_partials_reduce")
+        finally:
+            del _LN_PENDING[key]
 
 
 def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5, acc_into=None):
@@ -1170,7 +1177,7 @@ def layernorm_bwd(x, gamma, dy, dgamma, dbeta, eps=1e-5, acc_into=None):
         ws = torch.empty(n, device=x.device, dtype=torch.float32)
         _chk(lib.evmi_layernorm_bwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), None, None, ws.data_ptr(), n, C, N, eps, acc, _s(x)),
              "evmi_layernorm_bwd_cbt_f32")
-        _LN_PENDING.append((ws, dgamma, dbeta, C, N))
+        _LN_PENDING.setdefault(_s(x), []).append((ws, dgamma, dbeta, C, N))
         return dx
     ws = WS.get("ln_bwd", n, x.device)
     _chk(lib.evmi_layernorm_bwd_cbt_f32(x.data_ptr(), gamma.data_ptr(), dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),

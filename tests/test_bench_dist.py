@@ -126,6 +126,7 @@ class _ScheduleHost:
         self.log = log
         self._dp_reducers = (_RecordingReducer("d", log), _RecordingReducer("g", log))
         self.pg = True
+        self.keep_grads = False
         self.d_params = SimpleNamespace(names=lambda: ["p"], offset_of=lambda n: 2)
         self.g_params = SimpleNamespace(grad=torch.zeros(20))
 
