@@ -972,7 +972,9 @@ class FastSpeech2Trainer:
         # The variance predictors are side branches under teacher forcing (see below): they get a tape of their own and ALIASES of their
         # inputs, in every training schedule (one order of additions into the encoder output's gradient whatever stream runs them).
         struct = not _EVAL[0]
-        on_stream = struct and self._pred_branch and not segmented and dev.type == "cuda"
+        # (data parallel: the captured step is cut into stretches around the gradient exchanges, a forked stream would have to come back
+        # inside one stretch -- the predictors stay on the chain there, in the eager warm-up steps too: same workspaces as the capture)
+        on_stream = struct and self._pred_branch and not segmented and self._reducer is None and dev.type == "cuda"
         pjoin = {"done": None, "tape": Tape()} if struct else None
 
         def join_branch(var, alias):
