@@ -195,6 +195,40 @@ def _row(t):
     return t if (t.shape[1] == 1 or not ops._packed()) else t.reshape(t.shape[0], 1, -1)
 
 
+def _held_tensors(fns, depth: int = 4) -> list:
+    """Every tensor the closures `fns` (tape operators) can reach through their cells: Vars, dicts, lists, nested closures.  A branch
+    that runs on another stream keeps this list until the main chain has joined it: an operator that drops a tensor when it has
+    LAUNCHED its kernels (`packed.clear()`, a Var going out of scope) hands the block back to the pool of the stream that allocated it,
+    and that stream's next allocation may write it while the branch's kernels still read it."""
+    out, seen = [], set()
+
+    def visit(o, d):
+        if id(o) in seen or d < 0:
+            return
+        seen.add(id(o))
+        if torch.is_tensor(o):
+            out.append(o)
+        elif isinstance(o, Var):
+            visit(o.data, d)
+            visit(o.grad, d)
+        elif isinstance(o, dict):
+            for v in o.values():
+                visit(v, d - 1)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                visit(v, d - 1)
+        elif callable(o) and getattr(o, "__closure__", None):
+            for c in o.__closure__:
+                try:
+                    visit(c.cell_contents, d - 1)
+                except ValueError:  # (an empty cell)
+                    pass
+
+    for f in fns:
+        visit(f, depth)
+    return out
+
+
 def _items(B, T):
     """(items, columns per item) as `_row` hands a [C, B, T] tensor to a position-wise layer."""
     return (1, B * T) if ops._packed() else (B, T)
@@ -654,6 +688,7 @@ class FastSpeech2Trainer:
         self.side_wgrad = (os.environ.get("EVMI_FS2_SIDE_WGRAD", "1") == "1") if side_wgrad is None else bool(side_wgrad)
         self._stream = None  # set at the end of __init__ (with its sibling streams)
         self._pred_branch = os.environ.get("EVMI_FS2_PRED_STREAM", "1") == "1"  # the variance predictors beside the decoder (_step)
+        self._align_branch = os.environ.get("EVMI_FS2_ALIGN_STREAM", "1") == "1"  # the aligner's backward beside the encoder's (_step)
         self.use_graph = bool(use_graph)
         self.graph_buckets = tuple(int(v) for v in graph_buckets) if graph_buckets else None  # (symbols, frames) multiples to pad to
         self._graphs, self._graph_warm, self._graph_failed, self.last_step_was_graph = {}, {}, None, False
@@ -718,6 +753,7 @@ class FastSpeech2Trainer:
         if self.device.type == "cuda":
             self._pred_stream = torch.cuda.Stream(self.device)
             self._pred_fork, self._pred_done = torch.cuda.Event(), torch.cuda.Event()
+            self._align_fork, self._align_done = torch.cuda.Event(), torch.cuda.Event()
 
     def _tail_offset(self) -> int:
         """First element of the flat buffers that belongs to the decoder / mel_linear / postnet (declared last, in this order)."""
@@ -985,11 +1021,50 @@ class FastSpeech2Trainer:
             if alias.grad is not None:
                 var.accumulate(alias.grad)
 
+        # The aligner's backward depends on its own losses only (attention, five k = 3 convolutions over the mel frames, fp32 products:
+        # ~1 ms at the END of the chain).  On the predictors' stream from the start of backward it gave their 1.2 ms back (17.7 vs 16.5 ms:
+        # its kernels are large enough to take CUs from the decoder's backward); started where the ENCODER's backward starts -- 4.5 k
+        # columns, latency-bound launches that leave most of the chip idle -- it runs beside that.  Its own tape, an alias of the text
+        # embedding whose gradient joins the chain in front of the embedding's backward: the same additions in every schedule.
+        astruct = struct and learn
+
+        def start_aligner_backward():
+            if not astruct or pjoin.get("astarted"):
+                return
+            pjoin["astarted"] = True
+            if on_stream and self._align_branch:
+                main = torch.cuda.current_stream(dev)
+                self._align_fork.record(main)
+                self._pred_stream.wait_event(self._align_fork)
+                with torch.cuda.stream(self._pred_stream):
+                    side_on, ops.SIDE_WGRAD["on"] = ops.SIDE_WGRAD["on"], False
+                    pjoin["akeep"] = _held_tensors(pjoin["atape"]._ops)  # (outlive the KERNELS: the aligner's forward ran on the main stream)
+                    try:
+                        pjoin["atape"].backward()
+                        self._align_done.record(self._pred_stream)
+                    finally:
+                        ops.SIDE_WGRAD["on"] = side_on
+                pjoin["adone"] = self._align_done
+            else:
+                pjoin["atape"].backward()
+
+        def join_aligner(var, alias):
+            start_aligner_backward()  # (if the encoder output had no gradient to trigger it)
+            if pjoin.get("adone") is not None:
+                torch.cuda.current_stream(dev).wait_event(pjoin["adone"])
+                pjoin["adone"] = None
+            if alias.grad is not None:
+                var.accumulate(alias.grad)
+
         if learn:
-            # (The aligner's backward on the predictors' stream as well -- it depends on its own losses only -- was measured: it gave the
-            # predictors' 1.2 ms back, 17.7 vs 16.5 ms; its fp32 products are large enough to take CUs from the decoder's backward.)
-            align_join = self.aligner.forward(tape, embed(False), Var(mel_t, needs_grad=False), batch.get("attn_prior"), lens, mel_lens, n_frames,
-                                              tr.attn_ctc_loss_weight, self._bin_weight() > 0.0, self._scal[4:5], self._scal[5:6])
+            te = embed(False)
+            if astruct:
+                pjoin["atape"] = Tape()
+                ta = Var(te.data)
+                _ACTIVATION_ELEMS[0] -= te.data.numel()  # (an alias, not another activation)
+                tape.record(lambda: join_aligner(te, ta))
+            align_join = self.aligner.forward(pjoin["atape"] if astruct else tape, ta if astruct else te, Var(mel_t, needs_grad=False), batch.get("attn_prior"),
+                                              lens, mel_lens, n_frames, tr.attn_ctc_loss_weight, self._bin_weight() > 0.0, self._scal[4:5], self._scal[5:6])
         else:
             dur = batch["durations"]
 
@@ -1017,7 +1092,8 @@ class FastSpeech2Trainer:
         if struct:
             xe, xa = x, Var(x.data)  # the predictors' view of the encoder output: same data, its own gradient
             _ACTIVATION_ELEMS[0] -= x.data.numel()  # (an alias, not another activation)
-            tape.record(lambda: join_branch(xe, xa))  # (runs in backward when everything behind x has contributed: in front of the encoder's backward)
+            # (runs in backward when everything behind x has contributed: in front of the encoder's backward -- where the aligner's starts)
+            tape.record(lambda: (join_branch(xe, xa), start_aligner_backward()))
             x1 = self._add_bucket_embedding(tape, x, pitch_t, self.pitch_bins, self.pitch_table)
             x1a = Var(x1.data)
             _ACTIVATION_ELEMS[0] -= x1.data.numel()
@@ -1095,7 +1171,7 @@ class FastSpeech2Trainer:
             with torch.cuda.stream(self._pred_stream):
                 side_on, ops.SIDE_WGRAD["on"] = ops.SIDE_WGRAD["on"], False  # (their weight gradients stay on this stream: it is a side chain already)
                 # (what the branch's operators hold must outlive the branch's KERNELS, not just their launches: kept until the chain has joined)
-                keep = list(pjoin["tape"]._ops)
+                keep = _held_tensors(pjoin["tape"]._ops)
                 try:
                     pjoin["tape"].backward()
                     self._pred_done.record(self._pred_stream)
@@ -1106,9 +1182,11 @@ class FastSpeech2Trainer:
                 for t in [v for v in losses.values() if torch.is_tensor(v)]:
                     t.record_stream(main)
             tape.backward()
-            if pjoin["done"] is not None:  # (no join ran: nothing needed the encoder output's gradient)
-                main.wait_event(pjoin["done"])
+            for which in ("done", "adone"):  # (a join that did not run: nothing needed that gradient)
+                if pjoin.get(which) is not None:
+                    main.wait_event(pjoin[which])
             del keep
+            pjoin.pop("akeep", None)
             return self._finish_backward(losses)
         if struct:
             pjoin["tape"].backward()
