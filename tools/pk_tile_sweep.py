@@ -33,7 +33,7 @@ SHAPES = [
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 ops.CONV_BACKEND["operands"] = "bf16"
 lib = _lib.load()
-tiles = [None, 0, 1, 2, 6, 7, 8]
+tiles = [None, 0, 1, 2, 4, 6, 7, 8, 9]
 print(f"{'layer':32s} {'GFLOP':>7s} | " + " | ".join(f"{'auto' if t is None else 'tile ' + str(t):>13s}" for t in tiles))
 for name, cin, cout, k, s, p, d, g, b, t in SHAPES:
     if flt and flt not in name:
