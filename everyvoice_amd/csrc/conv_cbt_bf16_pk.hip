@@ -93,6 +93,7 @@ struct ConvPkArgs {
     //   tail 2: y <- bf16(dropout(v, drop_p) * silu'(pre)), pre = the packed pre-activation tail 1 stored, passed in `fm` (rows
     //           mplane apart, item pitch Tm; `mask` stays null): the first layer's packed output gradient, formed in the epilogue of
     //           the second layer's input gradient
+    //   tail 3: y <- bf16(dropout(silu(v), drop_p)) alone (inference, drop_p = 0: the activated tensor is all the second layer reads)
     // Mask stream and arithmetic of PackArgs::fuse 1 / 2 (drop_seed; element index = channel * drop_ld + unit).
     int tail;
     uint4* y2;
@@ -121,7 +122,10 @@ __device__ __forceinline__ void pk_flat_tail_silu(float& v0, float& v1, float& v
   float* vp[4] = {&v0, &v1, &v2, &v3};
   float* sp[4] = {&s0, &s1, &s2, &s3};
   float u[4];
-  if (LANES) {
+  if (p_drop <= 0.f) {  // (wave-uniform: inference -- no mask, no hash)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = 1.f;
+  } else if (LANES) {
     const unsigned par = (unsigned)n & 1u, ldh = (unsigned)(ld >> 1);
     const unsigned j0 = (unsigned)c * ldh + (unsigned)(n >> 1);  // (below 2^32: ffn_tail_check)
 #pragma unroll
@@ -603,10 +607,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
   pk_flat_tail_silu<T_, L_>(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3], s2[4 * i], s2[4 * i + 1], s2[4 * i + 2], s2[4 * i + 3], pre[i], dseed, \
                             a.drop_p, (unsigned long long)c, (unsigned long long)n, ld)
               if (ld & 1ull) {
-                if (a.po.tail == 1) EVMI_PK_TAIL(1, false);
+                if (a.po.tail != 2) EVMI_PK_TAIL(1, false);
                 else EVMI_PK_TAIL(2, false);
               } else {
-                if (a.po.tail == 1) EVMI_PK_TAIL(1, true);
+                if (a.po.tail != 2) EVMI_PK_TAIL(1, true);
                 else EVMI_PK_TAIL(2, true);
               }
 #undef EVMI_PK_TAIL
@@ -615,13 +619,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_pk_kernel(ConvPkArgs a) 
 #pragma unroll
           for (int which = 0; which < 2; ++which) {
             if (which == 1 && !(TAILS && a.po.tail == 1)) break;
+            const bool act_out = which || (TAILS && a.po.tail == 3);  // (tail 3: the activated tensor is the only output)
             uint4* dst = which ? a.po.y2 : a.po.y;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
               u32x4 d;
 #pragma unroll
               for (int q = 0; q < 4; ++q)
-                d[q] = which ? pack_bf16x2(s2[8 * p + 2 * q], s2[8 * p + 2 * q + 1]) : pack_bf16x2(v[8 * p + 2 * q], v[8 * p + 2 * q + 1]);
+                d[q] = act_out ? pack_bf16x2(s2[8 * p + 2 * q], s2[8 * p + 2 * q + 1]) : pack_bf16x2(v[8 * p + 2 * q], v[8 * p + 2 * q + 1]);
               const u32x4 o = swap_quads_bf16(d);  // lane (n, kh): the 8 channels of octet 2 p + kh
               const int m_oct = mb + 8 * (2 * p + kh);
               if ((ok || pad_col) && m_oct < m_valid) {
@@ -787,9 +792,13 @@ __global__ __launch_bounds__(256) void conv_pk_reduce_flat_kernel(ConvPkArgs a) 
       if (a.po.tail == 2) pre = a.po.fm[(long long)oc * a.po.mplane + (long long)bb * a.po.Tm + u];
       const unsigned long long dseed = a.drop_seed.get(), ld = (unsigned long long)a.po.drop_ld;
       const unsigned long long c0 = (unsigned long long)(oc * 8), nn = (unsigned long long)du;
-      if (a.po.tail == 1) {
+      if (a.po.tail != 2) {
         pk_flat_tail_silu<1, false>(vc[0], vc[1], vc[2], vc[3], s2[0], s2[1], s2[2], s2[3], make_uint2(pre.x, pre.y), dseed, a.drop_p, c0, nn, ld);
         pk_flat_tail_silu<1, false>(vc[4], vc[5], vc[6], vc[7], s2[4], s2[5], s2[6], s2[7], make_uint2(pre.z, pre.w), dseed, a.drop_p, c0 + 4ull, nn, ld);
+        if (a.po.tail == 3) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vc[e] = s2[e];
+        }
       } else {
         pk_flat_tail_silu<2, false>(vc[0], vc[1], vc[2], vc[3], s2[0], s2[1], s2[2], s2[3], make_uint2(pre.x, pre.y), dseed, a.drop_p, c0, nn, ld);
         pk_flat_tail_silu<2, false>(vc[4], vc[5], vc[6], vc[7], s2[4], s2[5], s2[6], s2[7], make_uint2(pre.z, pre.w), dseed, a.drop_p, c0 + 4ull, nn, ld);
@@ -1672,7 +1681,7 @@ static int ffn_tail_check(const ConvPkArgs& a2, const PkPlan& pl2, int B, int t,
 int evmi_conv1d_cbt_bf16pk_ffn_up(const float* w_dev, const float* bias_dev, float* ws_dev, long long ws_elems, void* a_pk_dev,
                                   float* next_ws_dev, long long next_ws_elems, int B, int c_in, int t, int c_mid, int c_out, float p,
                                   unsigned long long seed_value, const unsigned long long* seed_base_dev, int fragments_ready, void* stream) {
-  if (!w_dev || !ws_dev || !a_pk_dev || (reinterpret_cast<uintptr_t>(a_pk_dev) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_ffn_up: null / unaligned pointer");
+  if (!w_dev || !ws_dev || (reinterpret_cast<uintptr_t>(a_pk_dev) & 15)) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_ffn_up: null / unaligned pointer");
   if (p < 0.f || p >= 1.f) return fail(EVMI_ERR_INVALID_ARG, "conv1d_cbt_bf16pk_ffn_up: p outside [0, 1)");
   ConvPkArgs a = {}, a2 = {};
   PkPlan pl, pl2;
@@ -1689,6 +1698,9 @@ int evmi_conv1d_cbt_bf16pk_ffn_up(const float* w_dev, const float* bias_dev, flo
   a.bias = bias_dev; a.y = nullptr; a.accumulate = 0; a.act = 0; a.act_param = 0.f;
   a.po.y = reinterpret_cast<uint4*>(a_pk_dev); a.po.y2 = nxt; a.po.plane = plane; a.po.Tc = a.po.valid = a.po.Ts = (int)N;
   a.po.tail = 1; a.po.drop_ld = N; a.po.Tm = (int)N; a.po.mplane = plane;
+  if (!a_pk_dev) {  // (inference: no backward will ask for the pre-activation)
+    a.po.y = nxt; a.po.y2 = nullptr; a.po.tail = 3;
+  }
   a.drop_p = p; a.drop_seed = SeedArg{seed_value, seed_base_dev};
   return launch_pk(a, pl, reinterpret_cast<const float*>(ws_dev), w_dev, ws_dev, ws_elems, 0, c_mid, c_in, 1, 1, (hipStream_t)stream, PkInputFusion(),
                    fragments_ready ? 2 : 3);

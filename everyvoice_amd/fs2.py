@@ -130,6 +130,9 @@ def _ln_conv(x, g, b, w, bias, act=ops.ACT_NONE):
     """act(conv1x1(LayerNorm(x))): on the packed bf16 kernels the normalised tensor is written straight into the convolution's packed input
     (ops.layernorm_dense_fwd: one launch and one fp32 round trip of the tensor less); elsewhere the two operators."""
     C, B, T = x.shape
+    # (a position-wise layer: all columns as ONE item -- any B * T then shares the packed layout, csrc/conv_pk_common.h)
+    if ops._packed() and ops.ln_dense_fused_supported(1, B * T, C, w.shape[0]):
+        return ops.layernorm_dense_fwd(x.reshape(C, 1, B * T), g, b, w, bias, {}, act=act, eps=_LN_EPS).view(-1, B, T)
     if ops.ln_dense_fused_supported(B, T, C, w.shape[0]):
         return ops.layernorm_dense_fwd(x, g, b, w, bias, {}, act=act, eps=_LN_EPS)
     return _conv(_layernorm(x, g, b), w, bias, act=act)
@@ -183,6 +186,11 @@ class _Conformer:
             self.layers.append(L)
 
     def _ffn(self, x, P):
+        C, B, T = x.shape
+        if ops._packed() and ops.ffn_packed_supported(1, B * T, C, P["w1"].shape[0], P["w2"].shape[0]):
+            # the block as a packed chain (train/ops.py: ffn_packed_infer): the 1024-channel tensor exists as packed bf16 only
+            xr = x.reshape(C, 1, B * T)
+            return ops.ffn_packed_infer(xr, P["ln_g"], P["ln_b"], P["w1"], P["b1"], P["w2"], P["b2"], xr, eps=_LN_EPS).view(C, B, T)
         h = _ln_conv(x, P["ln_g"], P["ln_b"], P["w1"], P["b1"], act=ops.ACT_SILU)
         return _conv_add(h, P["w2"], P["b2"], x)
 

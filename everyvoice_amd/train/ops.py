@@ -815,6 +815,30 @@ def ffn_packed_fwd(x, gamma, beta, w1, b1, w2, b2, res, p, seed, seed_out, scale
     return out
 
 
+def ffn_packed_infer(x, gamma, beta, w1, b1, w2, b2, res, eps=1e-5):
+    """res + dense2(silu(dense1(LayerNorm(x)))) without dropout (inference): three launches -- LayerNorm (+ the weight fragments of both
+    layers), dense1 (its epilogue writes silu(a) as dense2's packed input; the pre-activation is not stored), dense2 (+ residual)."""
+    cin, B, t = x.shape
+    cmid, cout = w1.shape[0], w2.shape[0]
+    lib = _lib.load()
+    geo = (t, 1, 1, 0, 1, 1)
+    n1 = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cin, t, cmid, *geo)
+    n2 = lib.evmi_conv1d_cbt_bf16pk_ws_elems(B, cmid, t, cout, *geo)
+    ws1 = torch.empty(n1, device=x.device, dtype=torch.float32)
+    ws2 = torch.empty(n2, device=x.device, dtype=torch.float32)
+    out = torch.empty(cout, B, t, device=x.device, dtype=torch.float32)
+    st = _s(x)
+    _chk(lib.evmi_layernorm_pack_bf16pk_w(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws1.data_ptr(), n1, B, cin, t, cmid, eps, w1.data_ptr(), w2.data_ptr(),
+                                          ws2.data_ptr(), n2, cout, st), "evmi_layernorm_pack_bf16pk_w")
+    _count_conv(B, t, cmid, cin, 1)
+    _chk(lib.evmi_conv1d_cbt_bf16pk_ffn_up(w1.data_ptr(), _lib.ptr(b1), ws1.data_ptr(), n1, None, ws2.data_ptr(), n2, B, cin, t, cmid, cout, 0.0, 0, None, 1, st),
+         "evmi_conv1d_cbt_bf16pk_ffn_up")
+    _count_conv(B, t, cout, cmid, 1)
+    _chk(lib.evmi_conv1d_cbt_bf16pk_resdrop(3, None, w2.data_ptr(), _lib.ptr(b2), res.data_ptr(), out.data_ptr(), ws2.data_ptr(), n2, B, cmid, t, cout, 0.0, 0,
+                                            0.0, 0, 1.0, None, st), "evmi_conv1d_cbt_bf16pk_resdrop")
+    return out
+
+
 def ffn_packed_bwd(x, w1, w2, dy, p, seed, seed_out, scale, dw1, db1, dw2, db2, keep):
     """Backward of ffn_packed_fwd up to LayerNorm: returns d LayerNorm(x) [c_in, B, t] (fp32); the weight and bias gradients of both
     layers go to the sibling stream (side_wgrad) reading the packed operands.  dz = scale * dropout(dy) is packed once; the second

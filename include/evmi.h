@@ -331,6 +331,7 @@ int evmi_conv1d_dgrad_cbt_bf16pk_staged_dropout(int stage, const float* dy_dev, 
                                                 int stride, int pad, int dil, int groups, void* stream);
 /* A feed-forward block's wide middle tensor kept packed in both directions (FastSpeech2_lightning's Conformer feed-forward modules
  * Linear -> SiLU -> Dropout -> Linear -- absent submodule; pointwise layers c_in -> c_mid -> c_out on tight items):
+ *   (a_pk_dev NULL in evmi_conv1d_cbt_bf16pk_ffn_up: inference -- only the activated tensor is written; p = 0: no mask, no hash)
  *   evmi_conv1d_cbt_bf16pk_ffn_up:          the first layer on the packed input at the head of ws; a = conv + bias is written as
  *                                           a_pk [c_mid / 8][B * t] 16-byte units (bf16) and dropout(silu(a), p) as the packed input
  *                                           at the head of next_ws, the SECOND layer's workspace (run it with ..._prepacked /
