@@ -144,3 +144,33 @@ def test_trainer_state_dict_loads_strictly_into_the_upstream_modules():
     tr2 = HiFiGANTrainer(device="cpu", seed=7)
     tr2.load_checkpoint(tr.checkpoint())
     assert torch.equal(tr2.d_params.flat, tr.d_params.flat) and torch.equal(tr2.g_params.flat, tr.g_params.flat)
+
+
+def test_a_branch_keeps_every_tensor_its_tape_operators_can_reach():
+    """train/fs2.py: _held_tensors -- what a side branch holds until the main chain has joined it: tensors behind Vars, dicts (the
+    packed operands an operator clears when it has launched), lists and nested closures."""
+    import torch
+
+    from everyvoice_amd.train.autograd import Var
+    from everyvoice_amd.train.fs2 import _held_tensors
+
+    a, b, c, d, e = (torch.zeros(i + 1) for i in range(5))
+    v = Var(a)
+    v.grad = b
+    packed = {"x_packed": c}
+    inner = lambda: d  # noqa: E731
+
+    def op():
+        return v, packed, inner, [e]
+
+    held = _held_tensors([op])
+    assert {t.numel() for t in held} == {1, 2, 3, 4, 5}
+    packed.clear()  # (what the operator does when it has launched its kernels)
+    assert any(t is c for t in held)
+
+
+def test_the_row_pitch_of_a_shared_packed_operand():
+    """train/ops.py: pk_pitch mirrors csrc/conv_pk_common.h: pk_shared_pitch -- tight items, or one item rounded up to 64 units."""
+    from everyvoice_amd.train import ops
+
+    assert ops.pk_pitch(32, 814) == 32 * 814 and ops.pk_pitch(1, 4513) == 4544 and ops.pk_pitch(1, 64) == 64 and ops.pk_pitch(1, 1) == 64

@@ -1163,6 +1163,28 @@ def test_weight_gradient_schedules_give_the_same_step(cuda_device, use_graph):
         assert torch.equal(flat, finals[0][0])
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_side_branches_on_their_stream_leave_the_same_bits_as_on_the_chain(cuda_device, use_graph):
+    """The variance predictors (forward and backward) and the aligner's backward run on a stream of their own beside the main chain
+    (train/fs2.py: _step); the tape structure -- their own tapes, aliases of their inputs, the joins -- is the same with the branch
+    stream off (`_pred_branch = False`: everything on the chain), so the two schedules must agree bit for bit: parameters, optimiser
+    moments and losses after five steps in bf16 with dropout on, eager and captured, at a shape large enough for the streams to really
+    overlap.  A tensor released while the other stream still reads it, or a reduction flushed on the wrong stream, shows up here
+    (the aligner's backward did: DESIGN.md 12.9, item 9)."""
+    ref_cfg = _ref_cfg(0.1, 0)
+    batches = [_shaped_batch(ref_cfg, seed, True, cuda_device, B=8, L=40, T=128) for seed in (3, 4)]
+    finals = []
+    for branch in (True, False):
+        tr = _trainer(ref_cfg, cuda_device, learn_alignment=True, precision="bf16", use_graph=use_graph)
+        tr._pred_branch = branch
+        losses = [tr.training_step(batches[i % 2]) for i in range(5)]
+        torch.cuda.synchronize()
+        assert tr.last_step_was_graph == use_graph and tr._graph_failed is None
+        finals.append((tr.params.flat.clone(), [{k: float(v) for k, v in l.items()} for l in losses]))
+    assert finals[0][1] == finals[1][1]
+    assert torch.equal(finals[0][0], finals[1][0])
+
+
 def test_graph_buckets_pad_to_a_small_set_of_shapes(cuda_device):
     """graph_buckets=(8, 32): symbol and frame axes are padded up to multiples, so batches of different raw shapes share one
     captured step; the padded step equals the eager step on the same batch padded by hand (padding is explicit zeros: ids 0,
