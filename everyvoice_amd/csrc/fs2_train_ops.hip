@@ -186,13 +186,16 @@ __global__ __launch_bounds__(256) void colsum_partials_batch_kernel(ColsumBatch 
 
 // ---- BatchNorm1d, training mode --------------------------------------------------------------------------------------
 // one workgroup per channel row (N = B * T contiguous values)
+template <int NT = 256>
 __device__ __forceinline__ double block_sum(double v, double* sh) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  v = wave_sum_dpp_f64(v);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
-  return sh[0] + sh[1] + sh[2] + sh[3];
+  double t = sh[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) t += sh[w];  // (wave order: fixed)
+  return t;
 }
 
 __device__ __forceinline__ float bn_act(float z, int act) {
@@ -206,28 +209,32 @@ __device__ __forceinline__ float bn_act_grad(float z, int act) {
   return 1.f;
 }
 
-// A 256-thread workgroup walking ONE row of N values (thread t takes t, t + 256, ...): `body(i, u)`-style loops compile to one load ->
-// wait -> use per trip (a memory round trip per 256 values: 68 us for a 26 k-value BatchNorm row).  row_walk issues the loads of eight
-// trips before the first use; the order in which a thread meets its values -- and with it every sum's bits -- is unchanged.
-template <class Load, class Use>
+// An NT-thread workgroup walking ONE row of N values (thread t takes t, t + NT, ...): `body(i, u)`-style loops compile to one load ->
+// wait -> use per trip (a memory round trip per NT values: 68 us for a 26 k-value BatchNorm row at 256 threads).  row_walk issues the
+// loads of eight trips before the first use.  NT = 1024 for the long rows (BN_LONG_ROW): one workgroup per channel is one workgroup per
+// CU at 256 channels, and four waves do not keep enough loads in flight to reach the CU's share of the bandwidth (34 / 48 us forward /
+// backward at 26 k values; the sums are added in another -- still fixed -- order than with 256 threads).
+template <int NT, class Load, class Use>
 __device__ __forceinline__ void row_walk(long long N, Load load, Use use) {
   long long i = threadIdx.x;
-  for (; i + 7 * 256 < N; i += 8 * 256) {
+  for (; i + 7 * NT < N; i += 8 * NT) {
     decltype(load(i)) v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = load(i + u * 256);
+    for (int u = 0; u < 8; ++u) v[u] = load(i + u * NT);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) use(i + u * 256, v[u]);
+    for (int u = 0; u < 8; ++u) use(i + u * NT, v[u]);
   }
-  for (; i < N; i += 256) use(i, load(i));
+  for (; i < N; i += NT) use(i, load(i));
 }
+constexpr long long BN_LONG_ROW = 8192;
 
-__global__ __launch_bounds__(256) void batchnorm_fwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <int NT>
+__global__ __launch_bounds__(NT) void batchnorm_fwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ y,
                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
                                                                long long N, float eps, float momentum, int act) {
-  __shared__ double sh[4];
+  __shared__ double sh[NT / 64];
   const int c = blockIdx.x;
   const float* xr = x + (long long)c * N;
   if (momentum < 0.f) {  // evaluation mode: the running statistics normalise, nothing is updated
@@ -235,15 +242,15 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_cbt_kernel(const float* __r
     if (threadIdx.x == 0) { mean_out[c] = mean; rstd_out[c] = rstd; }
     const float ga = gamma[c] * rstd, be = beta[c];
     float* yr = y + (long long)c * N;
-    row_walk(N, [&](long long i) { return xr[i]; }, [&](long long i, float v) { yr[i] = bn_act((v - mean) * ga + be, act); });
+    row_walk<NT>(N, [&](long long i) { return xr[i]; }, [&](long long i, float v) { yr[i] = bn_act((v - mean) * ga + be, act); });
     return;
   }
   double s = 0.0;
-  row_walk(N, [&](long long i) { return xr[i]; }, [&](long long, float v) { s += (double)v; });
-  const float mean = (float)(block_sum(s, sh) / (double)N);
+  row_walk<NT>(N, [&](long long i) { return xr[i]; }, [&](long long, float v) { s += (double)v; });
+  const float mean = (float)(block_sum<NT>(s, sh) / (double)N);
   double q = 0.0;
-  row_walk(N, [&](long long i) { return xr[i]; }, [&](long long, float v) { const float d = v - mean; q += (double)(d * d); });
-  const double ss = block_sum(q, sh);
+  row_walk<NT>(N, [&](long long i) { return xr[i]; }, [&](long long, float v) { const float d = v - mean; q += (double)(d * d); });
+  const double ss = block_sum<NT>(q, sh);
   const float var = (float)(ss / (double)N);
   const float rstd = 1.f / sqrtf(var + eps);
   if (threadIdx.x == 0) {
@@ -256,36 +263,37 @@ __global__ __launch_bounds__(256) void batchnorm_fwd_cbt_kernel(const float* __r
   }
   const float ga = gamma[c] * rstd, be = beta[c];
   float* yr = y + (long long)c * N;
-  row_walk(N, [&](long long i) { return xr[i]; }, [&](long long i, float v) { yr[i] = bn_act((v - mean) * ga + be, act); });
+  row_walk<NT>(N, [&](long long i) { return xr[i]; }, [&](long long i, float v) { yr[i] = bn_act((v - mean) * ga + be, act); });
 }
 
-__global__ __launch_bounds__(256) void batchnorm_bwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <int NT>
+__global__ __launch_bounds__(NT) void batchnorm_bwd_cbt_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const float* __restrict__ mean_in,
                                                                const float* __restrict__ rstd_in, const float* __restrict__ dy,
                                                                float* __restrict__ dx, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta, long long N, int act) {
-  __shared__ double sh[4];
+  __shared__ double sh[NT / 64];
   const int c = blockIdx.x;
   const float* xr = x + (long long)c * N;
   const float* dr = dy + (long long)c * N;
   const float mean = mean_in[c], rstd = rstd_in[c], ga = gamma[c], be = beta[c];
   double s1 = 0.0, s2 = 0.0;
   struct XD { float x, d; };
-  row_walk(N, [&](long long i) { return XD{xr[i], dr[i]}; }, [&](long long, XD v) {
+  row_walk<NT>(N, [&](long long i) { return XD{xr[i], dr[i]}; }, [&](long long, XD v) {
     const float xh = (v.x - mean) * rstd;
     const float dz = v.d * bn_act_grad(xh * ga + be, act);
     s1 += (double)dz;
     s2 += (double)(dz * xh);
   });
-  const double t1 = block_sum(s1, sh);
-  const double t2 = block_sum(s2, sh);
+  const double t1 = block_sum<NT>(s1, sh);
+  const double t2 = block_sum<NT>(s2, sh);
   if (threadIdx.x == 0) {
     dbeta[c] += (float)t1;
     dgamma[c] += (float)t2;
   }
   const float m1 = (float)(t1 / (double)N), m2 = (float)(t2 / (double)N);
   float* dxr = dx + (long long)c * N;
-  row_walk(N, [&](long long i) { return XD{xr[i], dr[i]}; }, [&](long long i, XD v) {
+  row_walk<NT>(N, [&](long long i) { return XD{xr[i], dr[i]}; }, [&](long long i, XD v) {
     const float xh = (v.x - mean) * rstd;
     const float dz = v.d * bn_act_grad(xh * ga + be, act);
     dxr[i] = ga * rstd * (dz - m1 - xh * m2);
@@ -641,8 +649,12 @@ int evmi_batchnorm_fwd_cbt_f32(const float* x, const float* gamma, const float* 
   if (C < 1 || n_cols < 1) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: empty input");
   if (act != 0 && act != 2 && act != 4) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: act must be 0 (none), 2 (SiLU) or 4 (tanh)");
   if (momentum < 0.f && (!running_mean || !running_var)) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_fwd: evaluation mode (momentum < 0) needs the running statistics");
-  hipLaunchKernelGGL(batchnorm_fwd_cbt_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean_out, rstd_out,
-                     running_mean, running_var, n_cols, eps, momentum, act);
+  if (n_cols >= BN_LONG_ROW)
+    hipLaunchKernelGGL(batchnorm_fwd_cbt_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, gamma, beta, y, mean_out, rstd_out,
+                       running_mean, running_var, n_cols, eps, momentum, act);
+  else
+    hipLaunchKernelGGL(batchnorm_fwd_cbt_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean_out, rstd_out,
+                       running_mean, running_var, n_cols, eps, momentum, act);
   EVMI_LAUNCH_CHECK("batchnorm_fwd_cbt");
   return EVMI_OK;
 }
@@ -652,8 +664,12 @@ int evmi_batchnorm_bwd_cbt_f32(const float* x, const float* gamma, const float* 
   if (!x || !gamma || !beta || !mean || !rstd || !dy || !dx || !dgamma || !dbeta) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_bwd: null pointer");
   if (C < 1 || n_cols < 1) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_bwd: empty input");
   if (act != 0 && act != 2 && act != 4) return fail(EVMI_ERR_INVALID_ARG, "batchnorm_bwd: act must be 0 (none), 2 (SiLU) or 4 (tanh)");
-  hipLaunchKernelGGL(batchnorm_bwd_cbt_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, mean, rstd, dy, dx, dgamma,
-                     dbeta, n_cols, act);
+  if (n_cols >= BN_LONG_ROW)
+    hipLaunchKernelGGL(batchnorm_bwd_cbt_kernel<1024>, dim3(C), dim3(1024), 0, (hipStream_t)stream, x, gamma, beta, mean, rstd, dy, dx, dgamma,
+                       dbeta, n_cols, act);
+  else
+    hipLaunchKernelGGL(batchnorm_bwd_cbt_kernel<256>, dim3(C), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, mean, rstd, dy, dx, dgamma,
+                       dbeta, n_cols, act);
   EVMI_LAUNCH_CHECK("batchnorm_bwd_cbt");
   return EVMI_OK;
 }
