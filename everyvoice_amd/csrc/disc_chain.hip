@@ -100,7 +100,10 @@ struct FirstWgradArgs {
 };
 template <int KT>  // taps held in registers (8: the period discriminators' k = 5; 16: the scale discriminators' k = 15)
 __global__ __launch_bounds__(256) void disc_first_wgrad_kernel(FirstWgradArgs a) {
-  extern __shared__ float red[];  // [8 * (KT + 1)][257]
+  // (The workgroup's 8 x (KT + 1) sums: wave sums by DPP, then the four waves in order.  The transposing reduction through
+  // [8 * (KT + 1)][257] floats of LDS this replaces -- 140 KB at KT = 16 -- left ONE workgroup of four waves per CU for a loop of
+  // gathered audio reads: 128 us per launch on the scale discriminators' first layers.)
+  __shared__ float red[4][8 * (KT + 1)];
   const int tid = threadIdx.x, o = blockIdx.y;
   const int n_total = a.n_items * a.n_out;
   const int n0 = blockIdx.x * (256 * a.wcols);
@@ -127,23 +130,19 @@ __global__ __launch_bounds__(256) void disc_first_wgrad_kernel(FirstWgradArgs a)
       acc[e][KT] += d;
     }
   }
+  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int j = 0; j <= KT; ++j) red[(e * (KT + 1) + j) * 257 + tid] = acc[e][j];
+    for (int j = 0; j <= KT; ++j) {
+      const float v = wave_sum_dpp(acc[e][j]);
+      if (lane == 0) red[wave][e * (KT + 1) + j] = v;
+    }
   __syncthreads();
   if (tid < 8 * (KT + 1)) {
     const int e = tid / (KT + 1), j = tid - e * (KT + 1);
     if (j < a.k || j == KT) {
-      const float* r = red + tid * 257;
-      float v = 0.f;
-      for (int t = 0; t < 256; t += 8) {  // fixed order, eight LDS reads in flight
-        float q[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) q[u] = r[t + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v += q[u];
-      }
+      const float v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];  // (wave order: fixed)
       a.partial[((long long)blockIdx.x * a.c_out + o * 8 + e) * (a.k + 1) + (j == KT ? a.k : j)] = v;
     }
   }
@@ -309,7 +308,7 @@ struct PostWgradArgs {
   float* partial;
 };
 __global__ __launch_bounds__(256) void disc_post_wgrad_kernel(PostWgradArgs a) {
-  extern __shared__ float red[];  // [8 * DC_PKMAX][257]
+  __shared__ float red[4][8 * DC_PKMAX];  // (wave sums by DPP, then the four waves in order: see disc_first_wgrad_kernel)
   const int tid = threadIdx.x, o = blockIdx.y;
   const int n_total = a.n_items * a.n;
   const int n0 = blockIdx.x * (256 * DC_PWCOLS);
@@ -337,19 +336,18 @@ __global__ __launch_bounds__(256) void disc_post_wgrad_kernel(PostWgradArgs a) {
       for (int e = 0; e < 8; ++e) acc[e][j] = fmaf(d, xv[e], acc[e][j]);
     }
   }
+  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int e = 0; e < 8; ++e)
 #pragma unroll
-    for (int j = 0; j < DC_PKMAX; ++j) red[(e * DC_PKMAX + j) * 257 + tid] = acc[e][j];
+    for (int j = 0; j < DC_PKMAX; ++j) {
+      const float v = wave_sum_dpp(acc[e][j]);
+      if (lane == 0) red[wave][e * DC_PKMAX + j] = v;
+    }
   __syncthreads();
   if (tid < 8 * DC_PKMAX) {
     const int e = tid / DC_PKMAX, j = tid - e * DC_PKMAX;
-    if (j < a.k) {
-      const float* r = red + tid * 257;
-      float v = 0.f;
-      for (int t = 0; t < 256; ++t) v += r[t];
-      a.partial[((long long)blockIdx.x * a.C + o * 8 + e) * a.k + j] = v;
-    }
+    if (j < a.k) a.partial[((long long)blockIdx.x * a.C + o * 8 + e) * a.k + j] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
   }
 }
 __global__ void disc_ordered_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int n, int nblk, int accumulate) {
@@ -544,15 +542,8 @@ int evmi_disc_first_wgrad(const float* audio_dev, int n_audio, int t_audio, int 
   a.wcols = first_wgrad_cols(n, c_out);
   const int nblk = (int)((n + 256LL * a.wcols - 1) / (256LL * a.wcols));
   const bool k8 = k <= 8;
-  const size_t lds = (size_t)8 * ((k8 ? 8 : DC_KMAX) + 1) * 257 * sizeof(float);
-  static thread_local bool configured[kMaxDevices][2] = {};
-  if (!configured[device_slot()][k8]) {
-    if (k8) EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)disc_first_wgrad_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)disc_first_wgrad_kernel<DC_KMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured[device_slot()][k8] = true;
-  }
-  if (k8) hipLaunchKernelGGL(disc_first_wgrad_kernel<8>, dim3(nblk, c_out / 8), dim3(256), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(disc_first_wgrad_kernel<DC_KMAX>, dim3(nblk, c_out / 8), dim3(256), lds, (hipStream_t)stream, a);
+  if (k8) hipLaunchKernelGGL(disc_first_wgrad_kernel<8>, dim3(nblk, c_out / 8), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(disc_first_wgrad_kernel<DC_KMAX>, dim3(nblk, c_out / 8), dim3(256), 0, (hipStream_t)stream, a);
   EVMI_LAUNCH_CHECK("disc_first_wgrad");
   const int nf = c_out * (k + 1);
   hipLaunchKernelGGL(disc_first_wgrad_final_kernel, dim3((nf + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws_dev, dw_dev, db_dev, c_out, k, nblk, accumulate);
@@ -634,13 +625,7 @@ int evmi_disc_post_wgrad(const void* x_pk, long long x_plane, int T_x, int n_ite
   a.x = reinterpret_cast<const uint4*>(x_pk); a.plane = x_plane; a.T = T_x; a.n = n; a.n_items = n_items; a.C = C; a.k = k; a.pad = pad;
   a.dl = dlogits_dev; a.partial = ws_dev;
   const int nblk = (n_items * n + 256 * DC_PWCOLS - 1) / (256 * DC_PWCOLS);
-  const size_t lds = (size_t)8 * DC_PKMAX * 257 * sizeof(float);
-  static thread_local bool configured[kMaxDevices] = {};
-  if (!configured[device_slot()]) {
-    EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)disc_post_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured[device_slot()] = true;
-  }
-  hipLaunchKernelGGL(disc_post_wgrad_kernel, dim3(nblk, C / 8), dim3(256), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(disc_post_wgrad_kernel, dim3(nblk, C / 8), dim3(256), 0, (hipStream_t)stream, a);
   EVMI_LAUNCH_CHECK("disc_post_wgrad");
   hipLaunchKernelGGL(disc_ordered_final_kernel, dim3((C * k + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws_dev, dw_dev, C * k, nblk, accumulate);
   EVMI_LAUNCH_CHECK("disc_post_wgrad_final");
