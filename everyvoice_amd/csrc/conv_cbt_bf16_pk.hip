@@ -1325,23 +1325,33 @@ __global__ __launch_bounds__(256) void wfrag_flat_kernel(FragBatch b) {
         if (j0 + u < kf) mine[j0 + u] = valid ? v[u] : 0.f;
     }
   }
-  // (no barrier: a thread reads back its own run only; the partner's value comes through the shuffle)
+  // The runs are re-read across threads: thread (row r, tap slot jq) assembles the eight channels of its row at taps jq, jq + 8, ...
+  // into one 16-byte unit per (phase, tap) and stores it whole.  (One channel per thread, the pair's other half through ds_bpermute
+  // and a 4-byte store per tap, was a dependent LDS round trip per tap and a quarter-filled store: 171 us for 47 MB.)
+  __syncthreads();
+  const int wr = t >> 3, jq = t & 7;
+  const bool row_ok = mb * 32 + wr < f.rows_g;
   for (int phi = 0; phi < f.phases; ++phi) {
     const int m_phi = f.mode == 0 ? kt : (kf - phi + f.stride - 1) / f.stride, lead = kt - m_phi;
-    unsigned* dst = f.wf + phi * f.phase_stride_words + (long long)gmb * f.kblocks * 256;
-    for (int j = 0; j < kt; ++j) {
-      float v = 0.f;
-      if (j >= lead) v = f.mode == 0 ? mine[j] : mine[phi + f.stride * (m_phi - 1 - (j - lead))];
-      const float other = __shfl_xor(v, f.mode == 0 ? 1 : 32, 64);
-      if ((c & 1) == 0) {
-        const int h = o * kt + j;
-        dst[((h >> 1) * 64 + (h & 1) * 32 + r) * 4 + (c >> 1)] = pk_bf16x2(v, other);
+    uint4* dst = reinterpret_cast<uint4*>(f.wf + phi * f.phase_stride_words + (long long)gmb * f.kblocks * 256);
+    for (int j = jq; j < kt; j += 8) {
+      const int idx = f.mode == 0 ? j : phi + f.stride * (m_phi - 1 - (j - lead));
+      float v[8];
+#pragma unroll
+      for (int cc = 0; cc < 8; ++cc) {
+        const int owner = f.mode == 0 ? wr * 8 + cc : cc * 32 + wr;  // the thread that staged (row wr, channel cc)
+        v[cc] = (j >= lead && row_ok) ? runs[owner * ld + idx] : 0.f;  // (a channel past kch_g was staged as zeros)
       }
+      const int h = o * kt + j;
+      uint4 u;
+      u.x = pk_bf16x2(v[0], v[1]); u.y = pk_bf16x2(v[2], v[3]); u.z = pk_bf16x2(v[4], v[5]); u.w = pk_bf16x2(v[6], v[7]);
+      dst[(h >> 1) * 64 + (h & 1) * 32 + wr] = u;
     }
-    if (o == f.octs - 1 && ((f.octs * kt) & 1) && (c & 1) == 0)  // odd tail: the upper half of the last K block is zero weights
-      dst[((f.kblocks - 1) * 64 + 32 + r) * 4 + (c >> 1)] = 0u;
+    if (o == f.octs - 1 && ((f.octs * kt) & 1) && jq == 0)  // odd tail: the upper half of the last K block is zero weights
+      dst[(f.kblocks - 1) * 64 + 32 + wr] = make_uint4(0u, 0u, 0u, 0u);
   }
 }
+
 // per K block: window offsets (units) of its two halves (as wfrag_pk_block writes them)
 __global__ void flat_tab_kernel(int2* tab, int kblocks, int kb_step, int kt, int octs, int xrow, int dil) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
