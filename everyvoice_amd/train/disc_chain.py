@@ -127,11 +127,13 @@ class DiscChain:
         for c in self.convs[1:]:
             ok = ok and (c.cin // c.groups) % 8 == 0 and (c.cout // c.groups) % 8 == 0 and c.k >= c.stride and not c.transposed
         self.ok = bool(ok)
+        self.epoch = 0
         self._frag_bufs: dict = {}   # (layer, direction, slot) -> fragment buffer
         self._frag_map: dict = {}    # (layer, direction, weight pointer) -> (epoch, fragment buffer)
 
     # ---- weight fragments: per (layer, direction, weights), shared by every call of the layer while the weights stand ----------
-    EPOCH = [0]  # bumped whenever discriminator weights change (HiFiGANTrainer._materialize): older fragments are stale
+    # (``self.epoch``: bumped by the chain's trainer whenever its discriminator's weights change (HiFiGANTrainer._materialize): older
+    # fragments are stale.  Per chain: a second trainer in the process must not age this one's fragments.)
 
     def _frag_buf(self, i, mode, slot):
         key = (i, mode, slot)
@@ -163,18 +165,18 @@ class DiscChain:
                     if mode == 1 and not dgrad_slots[min(s, len(dgrad_slots) - 1)]:
                         continue
                     wf = self._frag_buf(i, mode, s)
-                    self._frag_map[(i, mode, w.data_ptr())] = (self.EPOCH[0], wf)
+                    self._frag_map[(i, mode, w.data_ptr())] = (self.epoch, wf)
                     jobs.append((mode, self.convs[i], w, wf))
         return jobs
 
     def _frag(self, i, mode, w, role):
         """The fragments of `w` for layer i: prepared by the trainer at the start of the phase, or made here (direct calls)."""
         e = self._frag_map.get((i, mode, w.data_ptr()))
-        if e is not None and e[0] == self.EPOCH[0]:
+        if e is not None and e[0] == self.epoch:
             return e[1]
         wf = self._frag_buf(i, mode, ("local", role))
         launch_fragments([(mode, self.convs[i], w, wf)], self.device)
-        self._frag_map[(i, mode, w.data_ptr())] = (self.EPOCH[0], wf)
+        self._frag_map[(i, mode, w.data_ptr())] = (self.epoch, wf)
         return wf
 
     MAX_CFGS = 8  # buffer sets kept (least recently used out first; a set a graph capture has touched stays)

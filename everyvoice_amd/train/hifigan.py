@@ -645,9 +645,16 @@ class HiFiGANTrainer:
                 batches.append(b)
         for b in batches:
             b.materialize()
-        from .disc_chain import DiscChain
-
-        DiscChain.EPOCH[0] += 1  # weights may have changed: fragments made from older ones are stale
+        d_ids = getattr(self, "_d_layer_ids", None)
+        if d_ids is None:
+            d_ids = self._d_layer_ids = {id(l) for l in self.d_layers()}
+        if any(id(l) in d_ids for l in layers):
+            for d in self.discriminators():  # the discriminators' weights may have changed: fragments made from older ones are stale
+                ch = getattr(d, "_chain", None)
+                if ch is not None:
+                    ch.epoch += 1
+            self._d_eff_version = self.d_params.version
+            self._wn_frag_version = None
 
     def _reducer(self, group: ParamGroup):
         """Bucketed all-reduce of one optimiser's flat gradient buffer, overlapped with backward (None on one GPU)."""
@@ -749,6 +756,8 @@ class HiFiGANTrainer:
             from .disc_chain import launch_fragments
 
             launch_fragments(jobs, self.device)
+        if which in ("wn", "all"):
+            self._wn_frag_version = self.d_params.version  # (both directions of every weight-normed chain layer, for these weights)
 
     def _prepare_spectral_norm(self, n_calls: int):
         """Power iterations + effective weights of the spectral-norm scale's next forward calls, every layer on its own stream:
@@ -894,9 +903,15 @@ class HiFiGANTrainer:
         ops.fill_(self._slots, 0.0)
         g_layers, d_layers = self.generator.layers(), self.d_layers()
         self._materialize(g_layers)
-        self._materialize(d_layers)
-        # the discriminator step's weight fragments run UNDER the generator's forward
-        frag_join = self._fragments_beside(y, generator_step=False) if d_step else None
+        # The discriminators have not changed since the previous step's update: their effective weights (materialised behind that
+        # update) and the weight-normed chains' fragments (made for the generator phase from the same weights, in the same buffers) stand.
+        # Only a first step, a loaded checkpoint or a generator phase without its adversarial part leaves something to do here.
+        if getattr(self, "_d_eff_version", None) != self.d_params.version:
+            self._materialize(d_layers)
+        frag_join = None
+        if d_step and getattr(self, "_wn_frag_version", None) != self.d_params.version:
+            # the discriminator step's weight fragments run UNDER the generator's forward
+            frag_join = self._fragments_beside(y, generator_step=False)
         g_tape = ag.Tape()
         g_reducer = [None]  # filled in before the generator's backward (the reducer object is created per phase)
         y_hat = self.generator.forward(
@@ -944,7 +959,7 @@ class HiFiGANTrainer:
         join = ctx.pop("frag_join", None)
         if join is not None:
             join()  # (the weight-normed chains' fragments, started beside the generator's forward)
-        else:
+        elif getattr(self, "_wn_frag_version", None) != self.d_params.version:
             self._prepare_chain_fragments(y, generator_step=False, which="wn")
         T = y.shape[-1]
         pair_t = torch.empty(1, 2 * B, T, device=self.device, dtype=torch.float32)
