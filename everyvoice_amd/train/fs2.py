@@ -1319,7 +1319,7 @@ class FastSpeech2Trainer:
                 losses = {k: v.clone() for k, v in entry["losses"].items()}
                 self.last_step_was_graph = True
         except BaseException:
-            ops.side_reset()
+            ops.side_reset(abort=True)
             raise
         finally:
             ops.CONV_BACKEND["operands"] = prev

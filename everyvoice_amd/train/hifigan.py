@@ -529,6 +529,7 @@ class HiFiGANTrainer:
         import os
 
         self.phase_times = {} if os.environ.get("EVMI_PHASE_TIMES") else None
+        self._version_gate = os.environ.get("EVMI_D_VERSION_GATE", "1") != "0"  # (tools/ddp_repeat.py: 0 = remake every step)
         self.branch_times = None
         if self.phase_times is not None:
             self.branches.timing = []
@@ -833,7 +834,7 @@ class HiFiGANTrainer:
                         buf = self._eager_step(mel_bct, audio_bct)
                 caller.wait_stream(self._stream)
         except BaseException:
-            ops.side_reset()
+            ops.side_reset(abort=True)
             raise
         finally:
             ops.CONV_BACKEND["operands"] = prev
@@ -852,7 +853,10 @@ class HiFiGANTrainer:
 
     def _eager_step(self, mel_bct, audio_bct):
         warm = self.global_step < self.generator_warmup_steps
-        if self.pg is not None and self.phase_times is None:
+        if self.pg is not None:
+            # data parallel: ALWAYS the captured step's schedule -- a rank that steps eagerly (a shape not captured yet, a failed
+            # capture) must issue the collective sequence of the ranks that replay.  EVMI_PHASE_TIMES is a single-process
+            # measurement; under data parallelism it is ignored (the per-phase path's bucket hooks are another sequence)
             return self._eager_data_parallel_step(mel_bct, audio_bct, warm)
         marks = []
 
@@ -906,10 +910,10 @@ class HiFiGANTrainer:
         # The discriminators have not changed since the previous step's update: their effective weights (materialised behind that
         # update) and the weight-normed chains' fragments (made for the generator phase from the same weights, in the same buffers) stand.
         # Only a first step, a loaded checkpoint or a generator phase without its adversarial part leaves something to do here.
-        if getattr(self, "_d_eff_version", None) != self.d_params.version:
+        if not self._version_gate or getattr(self, "_d_eff_version", None) != self.d_params.version:
             self._materialize(d_layers)
         frag_join = None
-        if d_step and getattr(self, "_wn_frag_version", None) != self.d_params.version:
+        if d_step and (not self._version_gate or getattr(self, "_wn_frag_version", None) != self.d_params.version):
             # the discriminator step's weight fragments run UNDER the generator's forward
             frag_join = self._fragments_beside(y, generator_step=False)
         g_tape = ag.Tape()
@@ -959,7 +963,7 @@ class HiFiGANTrainer:
         join = ctx.pop("frag_join", None)
         if join is not None:
             join()  # (the weight-normed chains' fragments, started beside the generator's forward)
-        elif getattr(self, "_wn_frag_version", None) != self.d_params.version:
+        elif not self._version_gate or getattr(self, "_wn_frag_version", None) != self.d_params.version:
             self._prepare_chain_fragments(y, generator_step=False, which="wn")
         T = y.shape[-1]
         pair_t = torch.empty(1, 2 * B, T, device=self.device, dtype=torch.float32)

@@ -288,13 +288,20 @@ def side_check_drained():
         raise RuntimeError(f"side_wgrad: {left} weight-gradient launches were never issued (a backward chain ended without wgrad_join on its stream)")
 
 
-def side_reset():
+def side_reset(abort: bool = False):
     """Forget every weight-gradient launch that was collected but not issued, and every pending event.  A step that aborts half way
     -- a graph capture that fails and falls back to the eager body, an out-of-memory error a caller retries -- leaves closures in
     ``queue`` whose tensors were never written (they live in the aborted capture's pool) and a ``pending`` event recorded inside that
     capture: the next step's first flush would wait on that event and launch the stale closures with accumulate=1 into the live
     weight-gradient buffers (silent gradient corruption; ``side_check_drained`` does not see it because the flush empties
-    the queue).  Called at the start of every step, and where a step aborts."""
+    the queue).  Called at the start of every step, and where a step aborts -- there with ``abort=True``: weight-gradient kernels
+    already ISSUED on a sibling stream may still be reading the tensors ``keep`` holds (allocated on the chain's stream); the device is
+    drained before they are let go, so the allocator cannot hand their blocks to the caller's retry under running kernels."""
+    if abort and _SIDE and torch.cuda.is_available():
+        try:
+            torch.cuda.synchronize()
+        except RuntimeError:  # (a capture that is still being torn down: nothing was issued)
+            pass
     for st in _SIDE.values():
         st.queue.clear()
         st.keep_next.clear()
@@ -1176,11 +1183,22 @@ def layernorm_flush():
         dev = pend[0][0].device
         if _lib.current_stream_ptr(dev) != key:
             continue
-        jobs = (_lib.LnPartials * len(pend))()
-        for j, (ws, dg, db, C, N) in zip(jobs, pend):
-            j.ws, j.dgamma, j.dbeta, j.C, j.n_cols = ws.data_ptr(), dg.data_ptr(), db.data_ptr(), C, N
+        # one launch adds every job's column sums into its targets without atomics, the jobs side by side: two deferred backwards of
+        # ONE LayerNorm (a layer applied twice in a chain) go into separate, stream-ordered launches
+        rounds: list = []
+        for job in pend:
+            for r in rounds:
+                if all(job[1].data_ptr() != o[1].data_ptr() and job[2].data_ptr() != o[2].data_ptr() for o in r):
+                    r.append(job)
+                    break
+            else:
+                rounds.append([job])
         try:
-            _chk(_lib.load().evmi_layernorm_bwd_partials_reduce(len(pend), jobs, key), "evmi_layernorm_bwd_partials_reduce")
+            for r in rounds:
+                jobs = (_lib.LnPartials * len(r))()
+                for j, (ws, dg, db, C, N) in zip(jobs, r):
+                    j.ws, j.dgamma, j.dbeta, j.C, j.n_cols = ws.data_ptr(), dg.data_ptr(), db.data_ptr(), C, N
+                _chk(_lib.load().evmi_layernorm_bwd_partials_reduce(len(r), jobs, key), "evmi_layernorm_bwd_partials_reduce")
         finally:
             del _LN_PENDING[key]
 

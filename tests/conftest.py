@@ -24,3 +24,21 @@ def cuda_device():
     if not torch.cuda.is_available():
         pytest.fail("this test is marked gpu and needs a GPU: run it with -m gpu on the GPU box")
     return torch.device("cuda:0")
+
+
+# Collection order of the GPU suite: `pytest -x` stops at the first failure, so the oracle-parity files come first --
+# in-tree functions pinned on reference goldens, then the model kernels against the oracle, then whole training steps -- and the
+# multi-process data-parallel file (four processes on one GPU, the slowest and the most timing-sensitive tests) runs last.
+_ORDER = ["test_gpu_length_regulator", "test_gpu_mel", "test_pipeline", "test_gpu_generator", "test_gpu_fs2", "test_gpu_disc_chain",
+          "test_gpu_train_ops", "test_gpu_fs2_train", "test_gpu_train_step", "test_gpu_lightning"]
+_LAST = ["test_gpu_ddp"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        stem = Path(str(item.fspath)).stem
+        if stem in _LAST:
+            return len(_ORDER) + 1 + _LAST.index(stem)
+        return _ORDER.index(stem) if stem in _ORDER else len(_ORDER)
+
+    items.sort(key=rank)  # (stable: the order inside a file stays)

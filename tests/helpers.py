@@ -57,6 +57,7 @@ def child_pytest_results(group: str, jobs: dict, parallel: int = 4, timeout: int
     import os
     import subprocess
     import sys
+    import tempfile
     import time
 
     if group in _CHILD_RESULTS:
@@ -70,17 +71,23 @@ def child_pytest_results(group: str, jobs: dict, parallel: int = 4, timeout: int
     while pending or running:
         while pending and len(running) < parallel:
             key, (args, env) = pending.pop(0)
+            # output goes to a file, read after exit: a child that prints more than a pipe holds (several long tracebacks) would
+            # otherwise block on write until the timeout kills it, and the real failure would read as rc -9
+            log = tempfile.TemporaryFile(mode="w+", errors="replace")
             proc = subprocess.Popen([sys.executable, "-m", "pytest", *args], env=dict(os.environ, OMP_NUM_THREADS=threads, MKL_NUM_THREADS=threads, **env),
-                                    stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-            running.append((key, proc, time.time()))
+                                    stdout=log, stderr=subprocess.STDOUT, text=True)
+            running.append((key, proc, time.time(), log))
         for item in list(running):
-            key, proc, t0 = item
+            key, proc, t0, log = item
             if proc.poll() is None:
                 if time.time() - t0 > timeout:
                     proc.kill()
+                    proc.wait()
                 else:
                     continue
-            out = proc.communicate()[0]
+            log.seek(0)
+            out = log.read()
+            log.close()
             results[key] = (proc.returncode, out[-4000:])
             running.remove(item)
         time.sleep(0.2)

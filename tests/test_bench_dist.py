@@ -213,10 +213,41 @@ def test_dist_env_and_roofline_aggregation(monkeypatch):
     ]
     roof = bench.roofline_from_records([recs, recs])
     assert roof["kernel"] == "a" and roof["launches_per_forward"] == 2
-    assert abs(roof["avg_launch_ms"] - 2.0) < 1e-9
-    assert abs(roof["achieved"] - 2e9 / 2e-3 / 1e12) < 1e-2  # algorithmic FLOP per launch / mean duration
+    assert abs(roof["avg_launch_ms"] - 2.0) < 1e-9  # median of (1, 3, 1, 3)
+    assert abs(roof["achieved"] - 2e9 / 2e-3 / 1e12) < 1e-2  # algorithmic FLOP per launch / median duration
     assert roof["peak"] == 2500.0 and roof["bound"] == "mfma"
     assert abs(roof["frac"] - roof["achieved"] / 2500.0) < 1e-3
+    assert abs(roof["whole_forward"]["event_ms"] - 5.0) < 1e-9
+
+
+def test_roofline_block_survives_one_stretched_launch():
+    """one launch of a small kernel read 21 ms on the driver's box and the 3-pass MEAN named it the dominant kernel at
+    8x its rocprof time.  Medians over launches and passes do not move, and `measured_roofline` rejects the pass outright (its events
+    do not add up to the timed step) and measures again."""
+    def recs(stretch=1.0):
+        return [dict(kernel="big", layer=f"l{i}", ms=0.56, flops=567e9, bytes=1e9) for i in range(6)] + \
+               [dict(kernel="small", layer=f"s{i}", ms=0.34 * (stretch if i == 1 else 1.0), flops=50e9, bytes=1e8) for i in range(3)]
+    clean = bench.roofline_from_records([recs()] * 5)
+    dirty = bench.roofline_from_records([recs(), recs(60.0), recs(), recs(), recs()])
+    for k in ("kernel", "avg_launch_ms", "frac", "launches_per_forward"):
+        assert clean[k] == dirty[k], k
+    assert clean["kernel"] == "big" and abs(clean["avg_launch_ms"] - 0.56) < 1e-9
+    assert dirty["whole_forward"]["event_ms"] == clean["whole_forward"]["event_ms"]
+
+    class Gen:
+        def __init__(self, seq):
+            self.seq = list(seq)
+
+        def forward_profiled(self, mel):
+            return None, recs(self.seq.pop(0))
+
+    timed = 6 * 0.56 + 3 * 0.34
+    roof = bench.measured_roofline(Gen([1.0, 60.0, 1.0, 1.0, 1.0, 1.0]), None, timed, 5)
+    assert roof["check"] == {"event_ms": round(timed, 3), "timed_ms": round(timed, 3), "passes": 5, "rejected": 1, "tolerance": 0.1, "consistent": True}
+    assert roof["kernel"] == "big"
+    # a box that never agrees with its own timed region: the block says so instead of posing as evidence
+    bad = bench.measured_roofline(Gen([60.0] * 40), None, timed, 5)
+    assert bad["check"]["consistent"] is False and bad["check"]["rejected"] == 20
 
 
 def test_bare_multi_gpu_command_launches_its_own_ranks(monkeypatch, capfd):
