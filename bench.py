@@ -57,7 +57,7 @@ def parse_args(argv=None):
     p.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-frames", type=int, default=768, help="mel frames per item of the CPU-baseline sample")
-    p.add_argument("--cpu-batch", type=int, default=16, help="items of the bench batch the CPU baseline runs (10-20 s of CPU work)")
+    p.add_argument("--cpu-batch", type=int, default=8, help="items of the bench batch the CPU baseline runs (~10 s of CPU work per pass, three passes)")
     p.add_argument("--profile-passes", type=int, default=7)
     p.add_argument("--no-train", action="store_true", help="skip the GAN-training leg (second half of the metric)")
     p.add_argument("--no-fs2", action="store_true", help="skip the FastSpeech2 feature-prediction inference leg")
@@ -320,7 +320,7 @@ def cpu_baseline(frames: int, batch: int) -> dict:
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     best = None
     with torch.no_grad():
-        probe = mel[:, :, : min(256, mel.shape[2])]  # the sample's own batch size, long enough that the thread count matters as on the sample
+        probe = mel[:, :, : min(128, mel.shape[2])]  # the sample's own batch size, long enough that the thread count matters as on the sample
         for n in sorted({min(avail, c) for c in (8, 16, 32, 64, 128, avail)}):
             torch.set_num_threads(n)
             ref(probe)
@@ -359,7 +359,7 @@ def _median_time(fn, warmup: int, repeats: int) -> float:
     return sorted(ts)[len(ts) // 2]
 
 
-def cpu_baseline_train(cores: int, batch: int = 16) -> dict:
+def cpu_baseline_train(cores: int, batch: int = 8) -> dict:
     """One full GAN step (D step, then G step, AdamW on both) of the torch-CPU oracle on `batch` 8192-sample segments;
     steps/s scaled to the bench's 16 segments per step (the step is linear in the batch)."""
     import torch

@@ -689,6 +689,8 @@ class FastSpeech2Trainer:
         self._stream = None  # set at the end of __init__ (with its sibling streams)
         self._pred_branch = os.environ.get("EVMI_FS2_PRED_STREAM", "1") == "1"  # the variance predictors beside the decoder (_step)
         self._align_branch = os.environ.get("EVMI_FS2_ALIGN_STREAM", "1") == "1"  # the aligner's backward beside the encoder's (_step)
+        self._dp_branch = os.environ.get("EVMI_FS2_DP_BRANCH", "1") == "1"  # both branches under data parallelism too (stretches cut behind their joins)
+        self.last_step_branch_on_stream = False
         self.use_graph = bool(use_graph)
         self.graph_buckets = tuple(int(v) for v in graph_buckets) if graph_buckets else None  # (symbols, frames) multiples to pad to
         self._graphs, self._graph_warm, self._graph_failed, self.last_step_was_graph = {}, {}, None, False
@@ -1008,9 +1010,12 @@ class FastSpeech2Trainer:
         # The variance predictors are side branches under teacher forcing (see below): they get a tape of their own and ALIASES of their
         # inputs, in every training schedule (one order of additions into the encoder output's gradient whatever stream runs them).
         struct = not _EVAL[0]
-        # (data parallel: the captured step is cut into stretches around the gradient exchanges, a forked stream would have to come back
-        # inside one stretch -- the predictors stay on the chain there, in the eager warm-up steps too: same workspaces as the capture)
-        on_stream = struct and self._pred_branch and not segmented and self._reducer is None and dev.type == "cuda"
+        # (data parallel: the captured step is cut into stretches around the gradient exchanges and a forked stream has to come back
+        # inside one stretch -- so the stretch boundary sits BEHIND the branch's join (below: `dp_cut`), not across the branch, and the
+        # step a data-parallel run times is the step one GPU times.  EVMI_FS2_DP_BRANCH=0: the predictors on the chain there, as in round 5.)
+        data_parallel = segmented or self._reducer is not None
+        on_stream = struct and self._pred_branch and dev.type == "cuda" and (self._dp_branch or not data_parallel)
+        self.last_step_branch_on_stream = bool(on_stream)
         pjoin = {"done": None, "tape": Tape()} if struct else None
 
         def join_branch(var, alias):
@@ -1056,6 +1061,18 @@ class FastSpeech2Trainer:
             if alias.grad is not None:
                 var.accumulate(alias.grad)
 
+        def dp_cut():
+            """Data parallel: where the tail bucket (decoder / mel_linear / postnet: ~half of the parameters, final once backward has left
+            the decoder) goes to its all-reduce, which runs on a side stream under the rest of the backward.  Recorded in front of the
+            decoder's forward = reached after its backward.  With the predictors on their stream the point sits behind their join
+            (the bucket leaves a length-regulator backward and two embedding backwards later; every fork is closed inside a stretch)."""
+            if segmented:
+                # (captured step: the stretch ends here; every stream forked so far must be back on the main one)
+                tape.cut(self.aligner.join_side if learn else None)
+            else:
+                lo_tail, red = self._tail_offset(), self._reducer
+                tape.record(lambda: (ops.wgrad_join(dev), red.launch(lo_tail, self.params.grad.numel())))
+
         if learn:
             te = embed(False)
             if astruct:
@@ -1093,7 +1110,10 @@ class FastSpeech2Trainer:
             xe, xa = x, Var(x.data)  # the predictors' view of the encoder output: same data, its own gradient
             _ACTIVATION_ELEMS[0] -= x.data.numel()  # (an alias, not another activation)
             # (runs in backward when everything behind x has contributed: in front of the encoder's backward -- where the aligner's starts)
-            tape.record(lambda: (join_branch(xe, xa), start_aligner_backward()))
+            tape.record(start_aligner_backward)
+            if data_parallel and on_stream:
+                dp_cut()  # backward: ... join_branch(xe, xa) | exchange of the tail bucket | aligner beside the encoder ...
+            tape.record(lambda: join_branch(xe, xa))
             x1 = self._add_bucket_embedding(tape, x, pitch_t, self.pitch_bins, self.pitch_table)
             x1a = Var(x1.data)
             _ACTIVATION_ELEMS[0] -= x1.data.numel()
@@ -1136,15 +1156,8 @@ class FastSpeech2Trainer:
             x_enc.accumulate(dx)
 
         tape.record(lr_bwd)
-        if segmented:
-            # (captured data-parallel step: the stretch ends here; every stream forked so far must be back on the main one)
-            tape.cut(self.aligner.join_side if learn else None)
-        elif self._reducer is not None:
-            # data parallel: the decoder / mel_linear / postnet gradients -- the tail of the flat buffer, ~half of the parameters --
-            # are final once backward leaves the decoder; their all-reduce runs on a side stream under the backward of the
-            # variance adaptor, the aligner and the encoder (recorded BEFORE the decoder's forward = run AFTER its backward)
-            lo_tail, red = self._tail_offset(), self._reducer
-            tape.record(lambda: (ops.wgrad_join(dev), red.launch(lo_tail, self.params.grad.numel())))
+        if data_parallel and not on_stream:
+            dp_cut()
         y = self.decoder.forward(tape, f, mel_lens, seeds)
         mel = masked(tape, dense(tape, y, self.mel_linear), mel_lens)
         losses["mel"] = mse_loss(tape, mel, mel_t, n_el, tr.mel_loss_weight)
@@ -1157,20 +1170,14 @@ class FastSpeech2Trainer:
         if _EVAL[0]:
             ops.wgrad_join(dev)
             return self._finish_backward(losses, grads=False)
-        if segmented:
-            def segments():
-                pjoin["tape"].backward()  # (the predictors' backward: in front of the chain's first stretch, on its stream)
-                yield from tape.backward_segments()
-
-            return segments(), losses
-        if on_stream:
-            # the predictors' backward starts with the step's: on their stream, behind their forward, beside the decoder's backward
+        def branch_backward():
+            """The predictors' backward starts with the step's: on their stream, behind their forward, beside the decoder's backward.
+            -> what the branch's operators hold (it must outlive the branch's KERNELS, not just their launches: kept until the chain has joined)"""
             main = torch.cuda.current_stream(dev)
             self._pred_fork.record(main)
             self._pred_stream.wait_event(self._pred_fork)
             with torch.cuda.stream(self._pred_stream):
                 side_on, ops.SIDE_WGRAD["on"] = ops.SIDE_WGRAD["on"], False  # (their weight gradients stay on this stream: it is a side chain already)
-                # (what the branch's operators hold must outlive the branch's KERNELS, not just their launches: kept until the chain has joined)
                 keep = _held_tensors(pjoin["tape"]._ops)
                 try:
                     pjoin["tape"].backward()
@@ -1181,12 +1188,34 @@ class FastSpeech2Trainer:
             if not torch.cuda.is_current_stream_capturing():
                 for t in [v for v in losses.values() if torch.is_tensor(v)]:
                     t.record_stream(main)
-            tape.backward()
+            return keep
+
+        def branch_close(keep):
+            main = torch.cuda.current_stream(dev)
             for which in ("done", "adone"):  # (a join that did not run: nothing needed that gradient)
                 if pjoin.get(which) is not None:
                     main.wait_event(pjoin[which])
+                    pjoin[which] = None
             del keep
             pjoin.pop("akeep", None)
+
+        if segmented:
+            def segments():
+                if on_stream:
+                    keep = branch_backward()
+                    for tag in tape.backward_segments():
+                        # (a stretch ends here: the cut sits behind the predictors' join, so their stream is back; the aligner's starts behind it)
+                        yield tag
+                    branch_close(keep)
+                    return
+                pjoin["tape"].backward()  # (the predictors' backward: in front of the chain's first stretch, on its stream)
+                yield from tape.backward_segments()
+
+            return segments(), losses
+        if on_stream:
+            keep = branch_backward()
+            tape.backward()
+            branch_close(keep)
             return self._finish_backward(losses)
         if struct:
             pjoin["tape"].backward()

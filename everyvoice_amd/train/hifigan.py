@@ -529,7 +529,6 @@ class HiFiGANTrainer:
         import os
 
         self.phase_times = {} if os.environ.get("EVMI_PHASE_TIMES") else None
-        self._version_gate = os.environ.get("EVMI_D_VERSION_GATE", "1") != "0"  # (tools/ddp_repeat.py: 0 = remake every step)
         self.branch_times = None
         if self.phase_times is not None:
             self.branches.timing = []
@@ -654,8 +653,6 @@ class HiFiGANTrainer:
                 ch = getattr(d, "_chain", None)
                 if ch is not None:
                     ch.epoch += 1
-            self._d_eff_version = self.d_params.version
-            self._wn_frag_version = None
 
     def _reducer(self, group: ParamGroup):
         """Bucketed all-reduce of one optimiser's flat gradient buffer, overlapped with backward (None on one GPU)."""
@@ -757,8 +754,6 @@ class HiFiGANTrainer:
             from .disc_chain import launch_fragments
 
             launch_fragments(jobs, self.device)
-        if which in ("wn", "all"):
-            self._wn_frag_version = self.d_params.version  # (both directions of every weight-normed chain layer, for these weights)
 
     def _prepare_spectral_norm(self, n_calls: int):
         """Power iterations + effective weights of the spectral-norm scale's next forward calls, every layer on its own stream:
@@ -907,15 +902,13 @@ class HiFiGANTrainer:
         ops.fill_(self._slots, 0.0)
         g_layers, d_layers = self.generator.layers(), self.d_layers()
         self._materialize(g_layers)
-        # The discriminators have not changed since the previous step's update: their effective weights (materialised behind that
-        # update) and the weight-normed chains' fragments (made for the generator phase from the same weights, in the same buffers) stand.
-        # Only a first step, a loaded checkpoint or a generator phase without its adversarial part leaves something to do here.
-        if not self._version_gate or getattr(self, "_d_eff_version", None) != self.d_params.version:
-            self._materialize(d_layers)
-        frag_join = None
-        if d_step and (not self._version_gate or getattr(self, "_wn_frag_version", None) != self.d_params.version):
-            # the discriminator step's weight fragments run UNDER the generator's forward
-            frag_join = self._fragments_beside(y, generator_step=False)
+        # Every step re-derives what it reads from the discriminators' parameters -- effective weights here, the weight-normed chains'
+        # fragments beside the generator's forward -- although both stand since the previous step's update: a captured step is then
+        # self-contained (parameters written between two replays -- a checkpoint loaded into a live trainer, a lock-step tool -- are
+        # picked up by the next replay; round 5's host-side version gate baked "nothing to do" into the graph: ADVICE r05) at 0.04 ms.
+        self._materialize(d_layers)
+        # the discriminator step's weight fragments run UNDER the generator's forward
+        frag_join = self._fragments_beside(y, generator_step=False) if d_step else None
         g_tape = ag.Tape()
         g_reducer = [None]  # filled in before the generator's backward (the reducer object is created per phase)
         y_hat = self.generator.forward(
@@ -963,7 +956,7 @@ class HiFiGANTrainer:
         join = ctx.pop("frag_join", None)
         if join is not None:
             join()  # (the weight-normed chains' fragments, started beside the generator's forward)
-        elif not self._version_gate or getattr(self, "_wn_frag_version", None) != self.d_params.version:
+        else:
             self._prepare_chain_fragments(y, generator_step=False, which="wn")
         T = y.shape[-1]
         pair_t = torch.empty(1, 2 * B, T, device=self.device, dtype=torch.float32)

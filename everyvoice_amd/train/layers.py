@@ -25,7 +25,6 @@ class ParamGroup:
         self.flat = self.grad = self.m = self.v = self.step_dev = None
         self._step = 0
         self._views = {}
-        self.version = 0  # bumped by everything that writes the parameters (load, optimiser step): what was derived from them is stale
 
     def declare(self, name: str, shape, export_shape=None) -> int:
         """``export_shape``: the tensor shape upstream stores under this name when it differs from the one the kernels use
@@ -80,7 +79,6 @@ class ParamGroup:
         return {name: self._view(self.grad, i) for i, (name, _, _) in enumerate(self._specs)}
 
     def load(self, name: str, value: torch.Tensor):
-        self.version += 1
         self._view(self.flat, self._index[name]).copy_(value.to(self.device, torch.float32).reshape(self._specs[self._index[name]][1]))
 
     def zero_grad(self):
@@ -109,7 +107,6 @@ class ParamGroup:
         parameters (WGAN).  The step number lives on the device, so a captured HIP graph of the step replays correctly."""
         from .. import _lib
 
-        self.version += 1
         kind = self.OPTIMIZERS[name]
         self._step += 1
         lib = _lib.load()

@@ -174,7 +174,7 @@ def _fs2_rank_main(rank, world, port, use_graph, steps, out_dir, learn_alignment
             losses.append({k: float(v) for k, v in tr.training_step(shard).items()})
         torch.cuda.synchronize(dev)
         torch.save({"grad": tr.params.grad.cpu(), "flat": tr.params.flat.cpu(), "losses": losses, "graph_failed": tr._graph_failed,
-                    "was_graph": tr.last_step_was_graph, "stretches": [len(e["graphs"]) for e in tr._graphs.values()]}, Path(out_dir) / f"fs2_rank{rank}.pt")
+                    "was_graph": tr.last_step_was_graph, "branch": tr.last_step_branch_on_stream, "stretches": [len(e["graphs"]) for e in tr._graphs.values()]}, Path(out_dir) / f"fs2_rank{rank}.pt")
     finally:
         dist.destroy_process_group()
 
@@ -206,6 +206,9 @@ def test_fastspeech2_two_ranks_hold_the_mean_of_their_local_gradients(cuda_devic
     assert r0["graph_failed"] is None and r1["graph_failed"] is None
     # both ranks hold the same (averaged, clipped) gradients and the same parameters, bit for bit
     assert torch.equal(r0["grad"], r1["grad"]) and torch.equal(r0["flat"], r1["flat"])
+    # the step a data-parallel run times is the step one GPU times: the variance predictors (and the aligner's backward) ran on their
+    # stream beside the chain -- in the captured step inside one stretch each, the stretch boundary behind their join
+    assert r0["branch"] and r1["branch"]
     if use_graph:
         assert r0["was_graph"] and r0["stretches"] and r0["stretches"][0] >= 3  # cut at the decoder boundary, exchanges between the replays
         tmp2 = tmp_path / "eager"

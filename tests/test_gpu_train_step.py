@@ -331,6 +331,34 @@ def test_graph_replay_equals_eager_steps(cuda_device, precision):
         assert torch.equal(a["evmi_flat_adamw"]["exp_avg_sq"], b["evmi_flat_adamw"]["exp_avg_sq"])
 
 
+def test_parameters_written_between_replays_reach_the_next_replay(cuda_device):
+    """round 5 decided on the HOST whether the discriminators' effective weights and the chains' weight fragments
+    are remade, and a captured step baked "nothing to do" in -- a checkpoint loaded into a live trainer (or any write into the flat
+    parameter buffer) between two replays left the next discriminator phase on the pre-load weights.  Every step derives both again:
+    a trainer that replays, has another trainer's discriminators and generator loaded into it and replays again ends bit for bit where
+    an eager trainer treated the same way does."""
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(19)
+    B, S = 2, 2048
+    ys = [(0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device) for _ in range(6)]
+    mels = [torch.randn(B, 80, S // 256, generator=g).to(cuda_device) for _ in range(6)]
+    donor = HiFiGANTrainer(device=cuda_device, seed=77, precision="bf16").checkpoint()
+    res = {}
+    for graph in (False, True):
+        tr = HiFiGANTrainer(device=cuda_device, seed=5, precision="bf16", use_graph=graph)
+        for m, y in zip(mels[:4], ys[:4]):  # two eager steps, the capture, one replay
+            tr.training_step(m, y)
+        tr.load_checkpoint(donor, restore_optimizers=False)  # (a live trainer: its captured step stays)
+        tr.d_params.data(0).mul_(1.5)  # ... and a direct write into the flat buffer, the lock-step tool's kind
+        losses = [tr.training_step(m, y) for m, y in zip(mels[4:], ys[4:])]
+        if graph:
+            assert tr._graph_failed is None and len(tr._graphs) == 1
+        res[graph] = (losses, tr.d_params.flat.clone(), tr.g_params.flat.clone())
+    assert res[True][0] == res[False][0]
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+
+
 def test_generator_warmup_steps_train_the_generator_alone(cuda_device):
     """generator_warmup_steps (same schema): during the warm-up the discriminators are neither stepped nor consulted -- the
     generator follows the reconstruction loss only; afterwards the full GAN step runs."""

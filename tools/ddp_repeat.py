@@ -11,7 +11,7 @@ repeats must all agree -- and prints the first (step, buffer, parameter) that do
     python tools/ddp_repeat.py --jobs graph,eager --world 1 --trials 10      # one process per job, no exchange
     python tools/ddp_repeat.py --fresh 12 --parallel 3 --trials 1            # the test's situation: every comparison in fresh processes
     python tools/ddp_repeat.py --jobs graphP,eagerP,eager --world 1 --trials 2   # NaN-poisoned torch.empty / workspaces vs plain
-    EVMI_D_VERSION_GATE=0 python tools/ddp_repeat.py ...                      # switches read by the trainer pass through
+    EVMI_DISC_CHAIN=0 python tools/ddp_repeat.py ...                          # switches read by the trainer pass through
 """
 
 from __future__ import annotations
