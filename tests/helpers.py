@@ -93,3 +93,53 @@ def child_pytest_results(group: str, jobs: dict, parallel: int = 4, timeout: int
         time.sleep(0.2)
     _CHILD_RESULTS[group] = results
     return results
+
+
+def fuzz_gan_schedule(seed: int, setattr_fn=setattr):
+    """Schedule fuzzing of the GAN step (tools/ddp_repeat.py jobs "graphF" / "eagerF"; tests/test_gpu_train_step.py).  Every chain that is forked onto a side stream -- the discriminators' branches, the
+    spectral-norm preparation, the fragment stream, the gradient exchange's side streams -- starts behind a busy-wait kernel of a random
+    length (0 - 3 ms, seeded), so the streams of a step finish in orders a quiet GPU never produces.  A consumer that reads a tensor
+    without an edge from its producer's stream then reads it EARLY, every time, instead of once in fifty runs under contention; with
+    every edge in place the step's results cannot change (same kernels, same operands) and the checksums equal the plain job's.
+    Captured steps hold the busy-wait kernels as graph nodes: replays are perturbed the same way.
+    ``setattr_fn``: pytest's ``monkeypatch.setattr`` in a test (undone at its end)."""
+    import random
+
+    import torch
+
+    from everyvoice_amd.train import hifigan
+
+    rng = random.Random(seed)
+
+    def nap():
+        ms = rng.choice([0.0, 0.0, 0.3, 1.0, 3.0])
+        if ms:
+            torch.cuda._sleep(int(ms * 2.0e6))  # (cycles of the ~2 GHz shader clock)
+
+    real_run = hifigan.Branches.run_indexed
+
+    def run_indexed(self, items):
+        def wrap(fn):
+            def go():
+                nap()
+                fn()
+            return go
+        return real_run(self, [(j, wrap(fn)) for j, fn in items])
+
+    setattr_fn(hifigan.Branches, "run_indexed", run_indexed)
+    real_prepare = hifigan.HiFiGANTrainer._prepare_chain_fragments
+
+    def prepare(self, probe, generator_step, which="all"):
+        nap()
+        return real_prepare(self, probe, generator_step, which)
+
+    setattr_fn(hifigan.HiFiGANTrainer, "_prepare_chain_fragments", prepare)
+    real_launch = hifigan.BucketReducer.launch
+
+    def launch(self, lo, hi):
+        if self.stream is not None and hi > lo:
+            with torch.cuda.stream(self.stream):
+                nap()
+        return real_launch(self, lo, hi)
+
+    setattr_fn(hifigan.BucketReducer, "launch", launch)

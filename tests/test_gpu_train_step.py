@@ -359,6 +359,37 @@ def test_parameters_written_between_replays_reach_the_next_replay(cuda_device):
     assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_gan_step_under_schedule_fuzzing_is_bitwise_the_same(cuda_device, monkeypatch, graph):
+    """a bit-for-bit claim that holds on one box and not on another is a missing edge between streams.  Here every
+    chain that is forked onto a side stream (the eight discriminators' branches forward and backward, the spectral-norm preparation,
+    the weight fragments' stream) starts behind a busy-wait kernel of a random length (tests/helpers.py: fuzz_gan_schedule), so the
+    streams finish in orders a quiet GPU never produces and a consumer without an edge from its producer reads early EVERY time.
+    Four steps in the bench's precision -- eagerly, and as two eager steps, a capture and a replay (the busy-waits are graph nodes
+    then) -- end bit for bit where the unperturbed steps end."""
+    from helpers import fuzz_gan_schedule
+
+    from everyvoice_amd.train.hifigan import HiFiGANTrainer
+
+    g = torch.Generator().manual_seed(21)
+    B, S = 2, 2048
+    ys = [(0.3 * torch.tanh(torch.randn(B, 1, S, generator=g))).to(cuda_device) for _ in range(4)]
+    mels = [torch.randn(B, 80, S // 256, generator=g).to(cuda_device) for _ in range(4)]
+
+    def run():
+        tr = HiFiGANTrainer(device=cuda_device, seed=5, precision="bf16", use_graph=graph)
+        losses = [tr.training_step(m, y) for m, y in zip(mels, ys)]
+        assert tr._graph_failed is None and bool(tr._graphs) == graph
+        return losses, tr.d_params.flat.clone(), tr.g_params.flat.clone(), tr.d_params.grad.clone(), tr.g_params.grad.clone()
+
+    plain = run()
+    fuzz_gan_schedule(3, monkeypatch.setattr)
+    fuzzed = run()
+    assert fuzzed[0] == plain[0]
+    for a, b, name in zip(fuzzed[1:], plain[1:], ("d", "g", "d_grad", "g_grad")):
+        assert torch.equal(a, b), name
+
+
 def test_generator_warmup_steps_train_the_generator_alone(cuda_device):
     """generator_warmup_steps (same schema): during the warm-up the discriminators are neither stepped nor consulted -- the
     generator follows the reconstruction loss only; afterwards the full GAN step runs."""

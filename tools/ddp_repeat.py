@@ -11,6 +11,7 @@ repeats must all agree -- and prints the first (step, buffer, parameter) that do
     python tools/ddp_repeat.py --jobs graph,eager --world 1 --trials 10      # one process per job, no exchange
     python tools/ddp_repeat.py --fresh 12 --parallel 3 --trials 1            # the test's situation: every comparison in fresh processes
     python tools/ddp_repeat.py --jobs graphP,eagerP,eager --world 1 --trials 2   # NaN-poisoned torch.empty / workspaces vs plain
+    python tools/ddp_repeat.py --jobs graphF,eagerF,eager --world 2 --trials 3   # schedule fuzzing: forked chains start behind random busy-waits
     EVMI_DISC_CHAIN=0 python tools/ddp_repeat.py ...                          # switches read by the trainer pass through
 """
 
@@ -72,6 +73,13 @@ def _poison():
     ops.Workspace.get = lambda self, key, numel, device: fill(real_get(self, key, numel, device))
 
 
+def _fuzz(seed: int):
+    sys.path.insert(0, str(ROOT / "tests"))
+    from helpers import fuzz_gan_schedule
+
+    fuzz_gan_schedule(seed)
+
+
 def _rank_main(rank, world, port, mode, trials, steps, out_dir, B, S, precision):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, str(ROOT))
@@ -82,6 +90,9 @@ def _rank_main(rank, world, port, mode, trials, steps, out_dir, B, S, precision)
     tag = mode
     if mode.endswith("P"):  # job "graphP" / "eagerP": the poisoned twin of "graph" / "eager"
         _poison()
+        mode = mode[:-1]
+    if mode.endswith("F"):  # job "graphF" / "eagerF": the same steps with every forked chain delayed at random
+        _fuzz(1000 * rank + 17)
         mode = mode[:-1]
 
     dev = torch.device("cuda:0")
