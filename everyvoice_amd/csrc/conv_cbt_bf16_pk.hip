@@ -980,7 +980,7 @@ static const char* plan_pk(ConvPkArgs& a, int cin_g, int t_in, int groups, const
         if (cost < best) { best = cost; ks = c; }
       }
     } else {
-      static const int split_want = 384;
+      static const int split_want = pk_env_int("EVMI_PK_SPLIT_WANT", 384);
       ks = (int)std::min<long long>(8, (split_want + blocks(0) - 1) / blocks(0));
       while (ks > 1 && a.kblocks / ks < split_min_kb) --ks;
     }

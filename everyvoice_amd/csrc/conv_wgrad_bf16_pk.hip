@@ -58,6 +58,13 @@ struct WgradPkArgs {
   // the x rows and split the workgroup's TAPS instead (1); block-diagonal super-groups of two 32 x 32 groups: wave (wm, wn) takes the
   // diagonal block wm and half of the taps (2)
   int tap_split;
+  // XCD-aware order of the workgroups (set by the launchers): the hardware hands consecutive workgroups to the eight XCDs in turn, so
+  // in launch order the (tile_ci x tile_co) workgroups of ONE split -- which read the same K range of dy and x -- sit on eight different
+  // L2s and every operand byte crosses the fabric 4-16 times (256 -> 1024 pointwise layer: 420 MB requested for 66 MB of operands).
+  // Remapped, XCD c runs the contiguous range [c * n / 8, (c + 1) * n / 8) of the logical (x fastest, split slowest) order: the
+  // workgroups resident on an XCD at one time are the tiles of one or a few splits and share their operands in that XCD's L2.
+  // Which workgroup computes which tile changes, what a tile computes (K order, split order of the reduce) does not: same bits.
+  int xcd;
 };
 
 constexpr int WG_KS = 64;  // positions per K step (4 MFMA K blocks)
@@ -90,8 +97,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   const int kh = lane >> 5;
   const int k = a.k, s = a.stride, d = a.dil, tg = a.tg;
 
-  const int tile_ci = blockIdx.x % a.tiles_ci, tgi = blockIdx.x / a.tiles_ci;
-  const int g = blockIdx.y / a.tiles_co, tile_co = blockIdx.y % a.tiles_co;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    const unsigned lin = bx + gx * (by + gy * bz);
+    const unsigned c = lin & 7, q = n >> 3, r = n & 7;           // XCD c runs q (+ 1 for c < r) workgroups
+    const unsigned lg = c * q + min(c, r) + (lin >> 3);          // its slot-th one is logical id lg
+    bx = lg % gx;
+    by = (lg / gx) % gy;
+    bz = lg / (gx * gy);
+  }
+  const int tile_ci = bx % a.tiles_ci, tgi = bx / a.tiles_ci;
+  const int g = by / a.tiles_co, tile_co = by % a.tiles_co;
   const int j_lo = tgi * tg;
   const int tgw = min(tg, k - j_lo);  // taps of this group
   int j0 = 0, tgc = tgw;              // ... of this wave: [j0, j0 + tgc) of them
@@ -101,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
     tgc = max(0, min(half, tgw - j0));
   }
   const int xb = a.tap_split == 2 ? wm : (a.tap_split ? 0 : wn);  // 32-channel block of the staged x rows this wave multiplies
-  const int split = blockIdx.z;
+  const int split = bz;
   const int t_lo = split * a.steps_per_split, t_hi = min(a.ksteps, t_lo + a.steps_per_split);
   if (t_lo >= t_hi) return;  // (the reduce pass only reads the splits that exist)
 
@@ -326,7 +343,7 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
   pl.lds = a.nst * stage_bytes;
   if (pl.lds > 160 * 1024) return "LDS budget";
   const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co * groups;
-  static const long long want = 512;
+  static const long long want = wg_env_int("EVMI_WG_WANT", 512);  // (A/B: workgroups a weight gradient is split up to)
   static const int min_steps = 8;  // K steps per workgroup that pay for its prologue and tile store
   int splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / min_steps));
   const int fs = wg_env_int("EVMI_WG_SPLITS", 0);
@@ -347,7 +364,14 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
 }
 
 // the packed-operand instantiations (one attribute cache for every caller: the attribute belongs to the kernel, not to the call site)
-static int launch_wgrad_packed(const WgradPkArgs& a, const WgradPkPlan& pl, hipStream_t s) {
+static int wg_xcd_order() {
+  static const int on = wg_env_int("EVMI_WG_XCD", 1);
+  return on;
+}
+
+static int launch_wgrad_packed(const WgradPkArgs& a_in, const WgradPkPlan& pl, hipStream_t s) {
+  WgradPkArgs a = a_in;
+  a.xcd = wg_xcd_order();
   static thread_local size_t configured_dev[kMaxDevices][2] = {};
   size_t* configured = configured_dev[device_slot()];
   const size_t lds = pl.lds;
@@ -486,6 +510,7 @@ int evmi_conv1d_wgrad_tm_bf16(const void* x_tm, const void* dy_tm, float* dw_dev
   a.accumulate = pl.splits > 1 ? 0 : accumulate;
   a.partial = pl.splits > 1;
   a.c_out = c_out;
+  a.xcd = wg_xcd_order();
   static thread_local size_t configured_dev[kMaxDevices][2] = {};
   size_t* configured = configured_dev[device_slot()];
   const size_t lds = pl.lds;
