@@ -281,13 +281,23 @@ def git_head() -> str | None:
     return f.read_text().strip() if f.exists() else None
 
 
-def profile_commit(summary_path) -> str | None:
-    """The commit a committed PMC summary was collected at (its .meta.json), so a reader sees whether `traffic` is from this tree."""
+def profile_commit(summary_path, key: str = "commit") -> str | None:
+    """The commit (or product-code fingerprint, key "code") a committed PMC summary was collected at (its .meta.json), so a reader sees
+    whether `traffic` is from this tree."""
     meta = Path(str(summary_path).replace("_pmc_summary.json", "_pmc_summary.meta.json"))
     try:
-        return json.loads(meta.read_text()).get("commit")
+        return json.loads(meta.read_text()).get(key)
     except (OSError, ValueError):
         return None
+
+
+def code_fingerprint() -> str:
+    """sha256[:16] of the product's sources (tools/code_fingerprint.py): equal between this line and a counter summary's ``code`` means
+    the counters were collected on the code this line timed, whatever commits (profiles, docs) came in between."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    from code_fingerprint import code_fingerprint as fp
+
+    return fp(ROOT)
 
 
 def recorded_pmc_traffic(kernel: str):
@@ -537,6 +547,7 @@ def train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict:
         roof["traffic_source"] = (f"profiles/{pmc_files[-1].name}: HBM bytes per step, all kernels (FETCH_SIZE + WRITE_SIZE, separate --pmc passes; "
                                   f"{meta.get('convention', 'raw KiB counters')})")
         roof["traffic_commit"] = meta.get("commit")
+        roof["traffic_code"] = meta.get("code")
         roof["dominant_kernel"] = {"name": name, "mfma_busy_frac": round(top["mfma"] / max(top["cycles"], 1.0), 4),
                                    "lds_bank_conflict_frac": round(top["lds"] / max(top["cycles"], 1.0), 4),
                                    "hbm_bytes_per_launch": round(top["bytes"] / max(top["launches"], 1)),
@@ -601,7 +612,7 @@ def fs2_leg(args, dev, rank, world, barrier, max_reduce) -> dict:
         meta = json.loads(metas[-1].read_text())
         traffic = round(meta["hbm_bytes_per_step"])
         traffic_src = (f"profiles/{metas[-1].name.replace('.meta', '')}: FETCH_SIZE + WRITE_SIZE of every kernel of a forward (separate --pmc passes; "
-                       f"{meta.get('convention', 'raw KiB counters')}; collected at commit {meta.get('commit')})")
+                       f"{meta.get('convention', 'raw KiB counters')}; collected at commit {meta.get('commit')}, code {meta.get('code')})")
     return {"roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
                          "traffic": traffic, "traffic_source": traffic_src, "flop_per_batch": flops, "scope": "whole forward (dense layers on the padded grids)"},
             "metric": "fastspeech2_infer_mel_frames_per_sec", "value": round(world * frames * steps / elapsed, 1), "unit": "frames/s",
@@ -666,7 +677,7 @@ def fs2_train_leg(args, dev, rank, world, use_dist, barrier, max_reduce) -> dict
         meta = json.loads(metas[-1].read_text())
         traffic = round(meta["hbm_bytes_per_step"])
         traffic_src = (f"profiles/{metas[-1].name.replace('.meta', '')}: FETCH_SIZE + WRITE_SIZE of every kernel of the step (separate --pmc passes; "
-                       f"{meta.get('convention', 'raw KiB counters')}; collected at commit {meta.get('commit')})")
+                       f"{meta.get('convention', 'raw KiB counters')}; collected at commit {meta.get('commit')}, code {meta.get('code')})")
     return {"metric": "fastspeech2_train_steps_per_sec_bs32", "value": round(steps / elapsed, 3), "unit": "steps/s",
             "ms_per_step": round(elapsed / steps * 1e3, 2), "steps": steps, "warmup": warmup, "batch_per_gpu": 32, "global_batch": 32 * world,
             "frames_per_sec": round(world * int(t_i.sum()) * steps / elapsed, 1), "scaling": "weak", "dtype": prec,
@@ -831,6 +842,7 @@ def main(argv=None) -> int:
             roof["traffic"] = pmc[0]
             roof["traffic_source"] = f"profiles/{pmc[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)"
             roof["traffic_commit"] = profile_commit(ROOT / "profiles" / pmc[1])
+            roof["traffic_code"] = profile_commit(ROOT / "profiles" / pmc[1], "code")
             roof["algorithmic_bytes_per_launch"] = round(roof["algorithmic_hbm_gbs"] * 1e9 * roof["avg_launch_ms"] * 1e-3)
         flops_per_sample = 2.0 * gen.macs_per_sample()
         result = {
@@ -861,6 +873,7 @@ def main(argv=None) -> int:
             "length_sensitivity": lengths,
             "roofline": roof,
             "commit": git_head(),
+            "code": code_fingerprint(),
         }
         if use_dist:
             result["rccl_ranks"] = rccl_ranks

@@ -56,16 +56,13 @@ struct ConvTcLaunch {
   // weight layout the kernel reads: 0 = [mtile][chunk][tap][BM][KC]; 1 = the same with the eight 16-byte channel vectors of a
   // row permuted for the LDS-DMA kernels (slot p of row m holds vector p ^ ((m >> 1) & 7), see conv_tc_dma_kernel.h)
   // 3 = [mtile][32-channel sub-chunk][tap][BM][32]: rows of four 16-byte vectors, slot p of row m holds vector p ^ ((m >> 2) & 3)
-  // (conv_tc_pp_kernel.h)
+  // (tools/microbench/conv_tc_pp_kernel.h: the ping-pong kernel of round 5, measured slower and kept as a microbenchmark only)
   int wlayout = 0;
   int persistent = 0;  // 1: one workgroup per CU walks the tiles (grid = min(tiles, CUs))
 };
 
 // Returns nullptr if no instantiation covers (c_in, ks, max dilation).
 const ConvTcLaunch* find_conv_tc(int c_in, int c_out, int ks, int dil);
-// The ping-pong kernel for the generator's wide residual-stack layers at inference (no training mask); nullptr: not covered
-// (or not switched on: EVMI_CONV_PP=1).
-const ConvTcLaunch* find_conv_pp(int c_in, int c_out, int ks, int dil);
 int launch_conv_tc(const ConvTcLaunch* L, const ConvTcArgs& a, int B, hipStream_t stream);
 
 }  // namespace evmi

@@ -16,7 +16,6 @@
 
 #include "conv_tc_dma_kernel.h"
 #include "conv_tc_kernel.h"
-#include "conv_tc_pp_kernel.h"
 
 namespace evmi {
 
@@ -83,26 +82,6 @@ static const ConvTcEntry* conv_dma_table(int* n) {
 #undef X
   *n = (int)(sizeof(table) / sizeof(table[0]));
   return table;
-}
-
-// ping-pong kernels (conv_tc_pp_kernel.h): the k = 7 / 11 layers of the 128- and 256-channel residual stacks
-#define EVMI_CONV_PP_TABLE(X) X(256, 7, 5) X(256, 11, 5) X(128, 7, 5) X(128, 11, 5)
-
-const ConvTcLaunch* find_conv_pp(int c_in, int c_out, int ks, int dil) {
-  // Opt-in (EVMI_CONV_PP=1): parity-tested, but on MI355X it does not beat the lockstep kernel yet (c128 / k11: 0.61 vs 0.53 ms;
-  // DESIGN.md §12.2 has the timeline and the ablations that say why).
-  static const bool use_pp = [] {
-    const char* e = getenv("EVMI_CONV_PP");
-    return e && e[0] == '1';
-  }();
-  if (!use_pp || c_in != c_out) return nullptr;
-#define X(cin, ks_, md) \
-  ConvTcEntry{cin, ks_, md, 32, make_conv_pp_launch<ConvPpCfg<cin, ks_, md>>("conv_tc_pp<c" #cin ",k" #ks_ ",bm128,bn512,kc32>")},
-  static const ConvTcEntry table[] = {EVMI_CONV_PP_TABLE(X)};
-#undef X
-  for (const ConvTcEntry& e : table)
-    if (e.c_in == c_in && e.ks == ks && dil <= e.max_dil && c_out % e.launch.bm == 0) return &e.launch;
-  return nullptr;
 }
 
 const ConvTcLaunch* find_conv_tc(int c_in, int c_out, int ks, int dil) {

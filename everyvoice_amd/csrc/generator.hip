@@ -184,7 +184,7 @@ static void relayout_conv(const float* w, int c_out, int c_in, int ks, const Con
       for (int c = 0; c < c_in; ++c) {
         const int mt = m / BM, mi = m % BM, chn = c / KC, ci = c % KC;
         const int cs = L->wlayout == 1   ? ((((ci >> 3) ^ ((mi >> 1) & 7)) << 3) | (ci & 7))  // swizzled 16-byte slot, 128-byte rows
-                       : L->wlayout == 3 ? ((((ci >> 3) ^ ((mi >> 2) & 3)) << 3) | (ci & 7))  // 64-byte rows (conv_tc_pp_kernel.h)
+                       : L->wlayout == 3 ? ((((ci >> 3) ^ ((mi >> 2) & 3)) << 3) | (ci & 7))  // 64-byte rows (tools/microbench/conv_tc_pp_kernel.h)
                                          : ci;
         const size_t dst = ((((size_t)mt * nch + chn) * ks + j) * BM + mi) * KC + cs;
         arena[off + dst] = f32_to_bf16_bits(w[((size_t)m * c_in + c) * ks + j]);
@@ -265,8 +265,7 @@ static int prepare_tc(evmi_generator* g) {
           t.c_in = cc; t.c_out = cc; t.ks = k;
           t.dil = which == 1 ? c.resblock_dilations[j][m] : 1;
           t.pad = t.dil * (k - 1) / 2;
-          t.launch = find_conv_pp(cc, cc, k, t.dil);  // ping-pong kernel for the wide k = 7 / 11 layers
-          if (!t.launch) t.launch = find_conv_tc(cc, cc, k, t.dil);
+          t.launch = find_conv_tc(cc, cc, k, t.dil);
           if (!t.launch) return missing(t.layer + " c=" + std::to_string(cc) + " k=" + std::to_string(k));
           reserve(t);
           relayout_conv(g->host_w[rb_name(c, n, which, m, "weight")].data(), cc, cc, k, t.launch, warena, t.w_off);

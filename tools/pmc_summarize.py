@@ -96,9 +96,12 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
         e["l2_hit_rate"] = round(l2[k]["TCC_HIT_sum"] / (l2[k]["TCC_HIT_sum"] + l2[k]["TCC_MISS_sum"]), 3)
     out[k] = e
 (dst / f"{tag}_pmc_summary.json").write_text(json.dumps(out, indent=1, sort_keys=True))
+import sys as _sys
+_sys.path.insert(0, str(ROOT / "tools"))
 _head = ROOT / ".git_head"
 (dst / f"{tag}_pmc_summary.meta.json").write_text(json.dumps({
     "commit": _head.read_text().strip() if _head.exists() else None,
+    "code": __import__("code_fingerprint").code_fingerprint(ROOT),
     "convention": f"counters x factors of profiles/{_cal[-1].name}" if _cal else "FETCH_SIZE x 2 (guide), WRITE_SIZE raw",
     "fetch_factor": FETCH16, "write_factor": WRITE16}, indent=1))
 print(json.dumps({k: v for k, v in out.items() if "conv_tc_mfma<c128,k11" in k or "pair_mfma<c64,k11" in k}, indent=1))

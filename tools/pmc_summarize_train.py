@@ -74,10 +74,12 @@ json.dump(out, open(dst, "w"), indent=1)
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5  # tools/train_bench.py 1: four warm-up steps + one timed
 total = sum(v["launches"] * (v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in out.values())
 total_raw = sum(v["launches"] * (v["fetch_bytes_per_launch_raw"] + v["write_bytes_per_launch_raw"]) for v in out.values())
+sys.path.insert(0, str(ROOT / "tools"))
 head = ROOT / ".git_head"
 json.dump({"steps": steps, "hbm_bytes_per_step": total / steps, "hbm_bytes_per_step_raw": total_raw / steps,
            "launches_per_step": sum(v["launches"] for v in out.values()) / steps,
            "commit": head.read_text().strip() if head.exists() else None,
+           "code": __import__("code_fingerprint").code_fingerprint(ROOT),
            "convention": f"counters x factors of profiles/{cal_file}" if cal_file else "raw KiB counters (no calibration file)",
            "calibration": cal},
           open(dst.with_suffix(".meta.json"), "w"), indent=1)
