@@ -125,7 +125,11 @@ def test_two_ranks_in_bf16_on_the_packed_chains_graph_equals_eager(cuda_device, 
     for k in ("d_grad", "g_grad", "d", "g"):
         assert torch.equal(r0[k], r1[k]), k
     e0, _ = eager()
-    assert torch.equal(r0["d"], e0["d"]) and torch.equal(r0["g"], e0["g"])
+    # (round 5's driver run failed here once and could not say where: the message names the buffer, how many elements differ and the
+    #  first of them; tools/ddp_repeat.py repeats this comparison with per-step checksums of every named parameter)
+    for k in ("d", "g", "d_grad", "g_grad"):
+        ne = (r0[k] != e0[k]).nonzero()
+        assert ne.numel() == 0, (k, int(ne.shape[0]), int(ne[0]), float(r0[k][ne[0]]), float(e0[k][ne[0]]))
 
 
 def test_a_rank_whose_capture_failed_steps_eagerly_beside_one_that_replays(cuda_device, tmp_path):
