@@ -40,6 +40,8 @@ __device__ __forceinline__ void lds_dma_b128(const void* g, void* l) {
 //   64 = activation tile requested for chunk 0 only; 128 = no epilogue (accumulators kept live); 256 = no step barriers
 //   (weight requests kept); 512 = no weight requests after step 0 (barriers kept)
 // WN_ = 8: sixteen waves on 512 rows, ONE workgroup per CU (every weight image feeds twice the MFMAs); A/B variant
+// WN_ = 2: four waves on 128 rows -- the NARROW tile for problems too small to fill the chip with 256-row tiles (one utterance; the GAN
+// step's generator at 16 x 256 .. 2048 rows: 32 .. 128 workgroups of 256 rows on 256 CUs); same K order per output: same bits
 template <int CIN_, int KS_, int MAXDIL_, int DBG_ = 0, int VAR_ = 0, int WN_ = 4>
 struct ConvDmaCfg {
   static constexpr int CIN = CIN_, KS = KS_, MAXDIL = MAXDIL_, DBG = DBG_, VAR = VAR_;
@@ -63,7 +65,7 @@ struct ConvDmaCfg {
 
 template <class C>
 __global__ __launch_bounds__(C::NTHREADS, 4) void conv_tc_dma_kernel(ConvTcArgs a) {
-  static_assert(C::NWAVES == 8 || C::NWAVES == 16, "8 or 16 waves");
+  static_assert(C::NWAVES == 2 || C::NWAVES == 4 || C::NWAVES == 8 || C::NWAVES == 16, "2, 4, 8 or 16 waves");
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* Xs = smem;
   char* As = smem + C::X_BYTES;

@@ -59,6 +59,9 @@ struct ConvTcLaunch {
   // (tools/microbench/conv_tc_pp_kernel.h: the ping-pong kernel of round 5, measured slower and kept as a microbenchmark only)
   int wlayout = 0;
   int persistent = 0;  // 1: one workgroup per CU walks the tiles (grid = min(tiles, CUs))
+  // the same kernel on 128-row tiles (same weight layout, same bits): picked by launch_conv_tc when the 256-row grid would leave
+  // most of the chip idle; nullptr: none
+  const ConvTcLaunch* narrow = nullptr;
 };
 
 // Returns nullptr if no instantiation covers (c_in, ks, max dilation).

@@ -75,11 +75,27 @@ static const ConvTcEntry* conv_tc_table(int* n) {
 #define EVMI_CONV_DMA_TABLE(X) \
   X(512, 2, 1) X(256, 2, 1) X(128, 2, 1) X(256, 3, 5) X(256, 7, 5) X(256, 11, 5) X(128, 3, 5) X(128, 7, 5) X(128, 11, 5)
 
+// narrow row tiles of the residual-stack layers (bn 128: four waves), for grids that would not fill the chip.  (64-row tiles, two
+// waves, were measured too: every workgroup streams the layer's whole weight set, and at 64 rows that costs more than the extra
+// workgroups give -- 1 x 400 frames 1.13 ms with 256-row tiles, 1.00 ms with 128-row tiles, 1.14-1.23 ms with 64-row tiles.)
+#define EVMI_CONV_DMA_NARROW_TABLE(X) X(256, 3, 5) X(256, 7, 5) X(256, 11, 5) X(128, 3, 5) X(128, 7, 5) X(128, 11, 5)
+
 static const ConvTcEntry* conv_dma_table(int* n) {
 #define X(cin, ks, md)                                                                          \
   ConvTcEntry{cin, ks, md, 64, make_conv_dma_launch<ConvDmaCfg<cin, ks, md>>("conv_tc_dma<c" #cin ",k" #ks ",bm128,bn256,kc64>")},
-  static const ConvTcEntry table[] = {EVMI_CONV_DMA_TABLE(X)};
+  static ConvTcEntry table[] = {EVMI_CONV_DMA_TABLE(X)};
 #undef X
+#define X(cin, ks, md)                                                                                                                   \
+  ConvTcEntry{cin, ks, md, 64, make_conv_dma_launch<ConvDmaCfg<cin, ks, md, 0, 0, 2>>("conv_tc_dma<c" #cin ",k" #ks ",bm128,bn128,kc64>")},
+  static const ConvTcEntry narrow[] = {EVMI_CONV_DMA_NARROW_TABLE(X)};
+#undef X
+  static const bool linked = [] {
+    for (ConvTcEntry& e : table)
+      for (const ConvTcEntry& nr : narrow)
+        if (nr.c_in == e.c_in && nr.ks == e.ks && nr.max_dil == e.max_dil) e.launch.narrow = &nr.launch;
+    return true;
+  }();
+  (void)linked;
   *n = (int)(sizeof(table) / sizeof(table[0]));
   return table;
 }
@@ -105,6 +121,15 @@ const ConvTcLaunch* find_conv_tc(int c_in, int c_out, int ks, int dil) {
 }
 
 int launch_conv_tc(const ConvTcLaunch* L, const ConvTcArgs& a, int B, hipStream_t stream) {
+  // 128-row tiles while the 256-row grid is far from filling the chip (two workgroups per CU = 512 slots): one utterance at a time
+  // (1 x 400 frames: 1.13 -> 1.00 ms per forward), the GAN step's generator (16 items of 256 / 2048 rows per stage: 32 / 128
+  // workgroups; the step itself does not move, those launches are not on its critical chain).  EVMI_CONV_NARROW=0: never.
+  // The bits do not depend on the tile (same K order per output element).
+  static const int narrow_on = [] {
+    const char* e = getenv("EVMI_CONV_NARROW");
+    return e ? atoi(e) : 1;
+  }();
+  if (narrow_on && !L->persistent && L->narrow && (long long)((a.n_rows + L->bn - 1) / L->bn) * B * (a.c_out / L->bm) < 256) L = L->narrow;
   static thread_local const void* configured_dev[kMaxDevices][64];
   static thread_local int n_configured_dev[kMaxDevices] = {};
   const int dev_slot = device_slot();

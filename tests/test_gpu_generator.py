@@ -267,3 +267,43 @@ def test_whole_branch_kernel_gives_the_bits_of_the_pair_kernels(tmp_path, cuda_d
         b = outs["0"][name]
         assert torch.isfinite(a).all() and float(a.abs().max()) > 0
         assert torch.equal(a, b), (name, float((a - b).abs().max()))
+
+
+_NARROW_CHILD = """
+import sys, torch
+sys.path.insert(0, {root!r})
+import bench
+torch.manual_seed(0)
+model = bench.upstream_init_generator("bf16").to("cuda:0").eval()
+for B, T in ((1, 8), (2, 40), (3, 130), (16, 32)):
+    wav = model.generator(bench.synthetic_mel(B, T, 99 + T).to("cuda:0"))
+    torch.save(wav.cpu(), {out!r} + f"/wav_{{B}}_{{T}}.pt")
+"""
+
+
+@pytest.mark.gpu
+def test_narrow_row_tiles_give_the_bits_of_the_256_row_tiles(tmp_path, cuda_device):
+    """Round 6: where the 256-row tiles of the wide residual-stack convolutions (conv_tc_dma_kernel.h) would leave most of the chip idle
+    -- one utterance at a time, the GAN step's generator at 16 x 32 frames: 32 .. 128 workgroups on 256 CUs -- launch_conv_tc picks the
+    same kernel on 128-row tiles.  An output element's K order (channel chunk, tap) does not depend on the tile, so the waveform is
+    IDENTICAL to a process with EVMI_CONV_NARROW=0, at lengths whose stages take narrow tiles, wide tiles, and a mix (the bench's
+    training shape, 16 x 32 frames, among them)."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = str(Path(__file__).resolve().parents[1])
+    outs = {}
+    for flag in ("1", "0"):
+        d = tmp_path / f"narrow{flag}"
+        d.mkdir()
+        r = subprocess.run([sys.executable, "-c", _NARROW_CHILD.format(root=root, out=str(d))], env=dict(os.environ, EVMI_CONV_NARROW=flag),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[flag] = {p.name: torch.load(p) for p in sorted(d.iterdir())}
+    assert sorted(outs["1"]) == sorted(outs["0"]) and len(outs["1"]) == 4
+    for name, a in outs["0"].items():
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0
+        b = outs["1"][name]
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
