@@ -33,6 +33,7 @@ if os.environ.get("DP1") == "1":  # the data-parallel code path on a one-rank RC
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     pg = True
 tr = HiFiGANTrainer(device=dev, precision=os.environ.get("OPERANDS", "f32"), use_graph=os.environ.get("GRAPH", "0") == "1", process_group=pg,
+                    reconstruction_loss=os.environ.get("RECON", "mel"),
                     parallel_streams=os.environ.get("STREAMS", "1") == "1", side_wgrad=os.environ.get("SIDE_WGRAD", "0") == "1")
 for i in range(4):
     out = tr.training_step(mel, y)
