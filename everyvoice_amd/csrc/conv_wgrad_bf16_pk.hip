@@ -88,12 +88,21 @@ __device__ __forceinline__ bf16x8 join_tr(s16x4 lo, s16x4 hi) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int TGMAX, bool TM = false>
-__global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
+// WIDE: 128 output channels x 128 input channels per workgroup on EIGHT waves (2 x 4: a wave owns 64 x 32 x TG taps = 2 TG accumulator
+// tiles) instead of 64 x 64 on four.  The kernel is bound by the rate its 1 KB LDS-direct pieces arrive (a 64 x 64 K step of the
+// 1024 -> 1024, k = 5 layer stages 24 KB for 20 MFMAs per wave: 320 MB per launch at ~4.3 TB/s, MFMA-busy ~5 %); the wide tile stages
+// 48 KB for four times the products -- half the bytes per product.  Same K order per accumulator: the sums differ from the narrow
+// tile's only through the split count.  TGMAX <= 5 (160 accumulator registers), no tap split, no block-diagonal mode.
+template <int TGMAX, bool TM = false, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? 512 : 256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  constexpr int NW = WIDE ? 8 : 4;       // waves
+  constexpr int MB = WIDE ? 2 : 1;       // 32-channel output blocks per wave
+  constexpr int RT = WIDE ? 16 : 8;      // octet rows of a tile side (128 / 64 channels)
+  constexpr int TE = WIDE ? 128 : 64;    // channels of a tile side
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WIDE ? wave >> 2 : wave >> 1, wn = WIDE ? wave & 3 : wave & 1;
   const int kh = lane >> 5;
   const int k = a.k, s = a.stride, d = a.dil, tg = a.tg;
 
@@ -112,37 +121,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
   const int j_lo = tgi * tg;
   const int tgw = min(tg, k - j_lo);  // taps of this group
   int j0 = 0, tgc = tgw;              // ... of this wave: [j0, j0 + tgc) of them
-  if (a.tap_split) {
+  if (!WIDE && a.tap_split) {
     const int half = (tgw + 1) >> 1;
     j0 = wn * half;
     tgc = max(0, min(half, tgw - j0));
   }
-  const int xb = a.tap_split == 2 ? wm : (a.tap_split ? 0 : wn);  // 32-channel block of the staged x rows this wave multiplies
+  const int xb = WIDE ? wn : (a.tap_split == 2 ? wm : (a.tap_split ? 0 : wn));  // 32-channel block of the staged x rows this wave multiplies
   const int split = bz;
   const int t_lo = split * a.steps_per_split, t_hi = min(a.ksteps, t_lo + a.steps_per_split);
   if (t_lo >= t_hi) return;  // (the reduce pass only reads the splits that exist)
 
   // octet rows of this tile, clamped to the group (rows past it are staged from the last one and never stored)
-  const int oy0 = tile_co * 8, ox0 = tile_ci * 8;
+  const int oy0 = tile_co * RT, ox0 = tile_ci * RT;
   const uint4* dy_g = a.dyp + (long long)g * a.octs_y * a.plane_y;
   const uint4* x_g = a.xp + (long long)g * a.octs_x * a.plane_x;
   const int xrow = a.xrow, xpieces = a.xpieces;
-  const int y_units = 8 * WG_YROW;
-  const int stage = y_units + 8 * xrow;
+  const int y_units = RT * WG_YROW;
+  const int stage = y_units + RT * xrow;
 
   // ---- per-lane addresses of the transposing reads (bytes within a stage) ----
   // 16-lane group G: kh = G >> 1 (K half of the MFMA operand), hf = G & 1 (which 16 of the 32 channels); lane i of the group
   // supplies the address of 4 channels (i & 3) of position row (i >> 2) and receives channel i, 4 positions.
   const int i16 = lane & 15, hf = (lane >> 4) & 1;
   const int oct_in_blk = 2 * hf + ((i16 & 3) >> 1);
-  const int a_base = (((wm * 4 + oct_in_blk) * WG_YROW) + 8 * kh + (i16 >> 2)) * 16 + (i16 & 1) * 8;
+  const int a_base = (((wm * MB * 4 + oct_in_blk) * WG_YROW) + 8 * kh + (i16 >> 2)) * 16 + (i16 & 1) * 8;  // (+ mb * 4 rows per further block)
   const int b_base = (y_units + (xb * 4 + oct_in_blk) * xrow + (8 * kh + (i16 >> 2)) * s + j0 * d) * 16 + (i16 & 1) * 8;
 
-  f32x16 acc[TGMAX];
+  f32x16 acc[MB][TGMAX];
 #pragma unroll
-  for (int j = 0; j < TGMAX; ++j)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < TGMAX; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mb][j][r] = 0.f;
 
   auto issue = [&](int t, int slot) -> int {
     uint4* sy = smem + slot * stage;
@@ -151,9 +162,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
     int issued = 0;
     // (octet rows past the group are NOT staged: what the transposing reads find there multiplies into accumulator rows / columns
     // that are never stored -- staging the last valid row again in their place was half of the loads of the 32-channel groups)
-    const int ny = min(8, a.octs_y - oy0), nx = min(8, a.octs_x - ox0);
+    const int ny = min(RT, a.octs_y - oy0), nx = min(RT, a.octs_x - ox0);
     int u = wave;
-    for (; u < ny; u += 4) {  // dy: up to 8 octet rows x 64 units = one 1 KB piece each
+    for (; u < ny; u += NW) {  // dy: up to RT octet rows x 64 units = one 1 KB piece each
       const int o = oy0 + u;
       if (TM) pk_lds_direct(reinterpret_cast<const uint4*>(a.dy_tm + (f0 + lane) * a.cy_row + (g * a.cout_g + o * 8)), sy + u * WG_YROW);
       else pk_lds_direct(dy_g + (long long)o * a.plane_y + f0 + lane, sy + u * WG_YROW);
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
     }
     u = wave;
     const long long x0 = f0 * s + (long long)j_lo * d + (TM ? 0 : a.x_unit_off);
-    for (; u < nx * xpieces; u += 4) {
+    for (; u < nx * xpieces; u += NW) {
       const int r = u / xpieces, pi = u - r * xpieces;
       const int o = ox0 + r;
       if (TM) pk_lds_direct(reinterpret_cast<const uint4*>(a.x_tm + (x0 + a.x_row_off + pi * 64 + lane) * a.cx_row + (g * a.cin_g + o * 8)),
@@ -190,7 +201,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
 #pragma unroll
     for (int kb = 0; kb < WG_KS / 16; ++kb) {
       const char* pa = sm + a_base + kb * 256;
-      const bf16x8 fa = join_tr(lds_read_tr(pa), lds_read_tr(pa + 64));
+      bf16x8 fa[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        const char* pm = pa + mb * (4 * WG_YROW * 16);
+        fa[mb] = join_tr(lds_read_tr(pm), lds_read_tr(pm + 64));
+      }
       const char* pb = sm + b_base + kb * 16 * s * 16;
       bf16x8 fb[TGMAX];
 #pragma unroll
@@ -200,53 +216,59 @@ __global__ __launch_bounds__(256, 2) void wgrad_pk_kernel(WgradPkArgs a) {
           fb[j] = join_tr(lds_read_tr(q), lds_read_tr(q + 4 * s * 16));
         }
 #pragma unroll
-      for (int j = 0; j < TGMAX; ++j)
-        if (j < tgc) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb[j], acc[j], 0, 0, 0);
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < TGMAX; ++j)
+          if (j < tgc) acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[j], acc[mb][j], 0, 0, 0);
     }
   }
 
   // ---- store: lane column = input channel, registers = output channels ----
-  const int ci_sg = tile_ci * 64 + xb * 32 + (lane & 31);
+  const int ci_sg = tile_ci * TE + xb * 32 + (lane & 31);
   if (ci_sg >= a.cin_g) return;
   const int cig = a.bd_cin ? ci_sg / a.bd_cin : 0;           // convolution group inside the super-group (block-diagonal mode)
   const int ci = a.bd_cin ? ci_sg - cig * a.bd_cin : ci_sg;  // input channel inside its convolution group
   const int cin_st = a.bd_cin ? a.bd_cin : a.cin_g;
-  if (a.partial) {  // partial tiles [split][tap][c_out][cin_g]: consecutive lanes consecutive addresses
-    float* outp = a.out + (long long)split * a.split_stride;
-    const long long tap_stride = (long long)a.c_out * cin_st;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    const int m_blk = tile_co * TE + (wm * MB + mb) * 32;  // first output channel of this accumulator block
+    if (a.partial) {  // partial tiles [split][tap][c_out][cin_g]: consecutive lanes consecutive addresses
+      float* outp = a.out + (long long)split * a.split_stride;
+      const long long tap_stride = (long long)a.c_out * cin_st;
+#pragma unroll
+      for (int j = 0; j < TGMAX; ++j) {
+        if (j >= tgc) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m_blk + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          if (m >= a.cout_g || (a.bd_cout && m / a.bd_cout != cig)) continue;
+          outp[(j_lo + j0 + j) * tap_stride + (long long)(g * a.cout_g + m) * cin_st + ci] = acc[mb][j][r];
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < TGMAX; ++j) {
       if (j >= tgc) break;
+      // the previous values of the 16 rows are requested together, from clamped rows (a read per element under the `accumulate`
+      // condition is one drained round trip each); -0 is the neutral start of a plain store
+      long long off[16];
+      float prev[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-        if (m >= a.cout_g || (a.bd_cout && m / a.bd_cout != cig)) continue;
-        outp[(j_lo + j0 + j) * tap_stride + (long long)(g * a.cout_g + m) * cin_st + ci] = acc[j][r];
+        const int m = min(m_blk + (r & 3) + 8 * (r >> 2) + 4 * kh, a.cout_g - 1);
+        off[r] = ((long long)(g * a.cout_g + m) * cin_st + ci) * k + j_lo + j0 + j;
+        prev[r] = -0.f;
       }
-    }
-    return;
-  }
+      if (a.accumulate) {
 #pragma unroll
-  for (int j = 0; j < TGMAX; ++j) {
-    if (j >= tgc) break;
-    // the previous values of the 16 rows are requested together, from clamped rows (a read per element under the `accumulate`
-    // condition is one drained round trip each); -0 is the neutral start of a plain store
-    long long off[16];
-    float prev[16];
+        for (int r = 0; r < 16; ++r) prev[r] = a.out[off[r]];
+      }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = min(tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, a.cout_g - 1);
-      off[r] = ((long long)(g * a.cout_g + m) * cin_st + ci) * k + j_lo + j0 + j;
-      prev[r] = -0.f;
-    }
-    if (a.accumulate) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) prev[r] = a.out[off[r]];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = tile_co * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-      if (m < a.cout_g && !(a.bd_cout && m / a.bd_cout != cig)) a.out[off[r]] = prev[r] + acc[j][r];
+      for (int r = 0; r < 16; ++r) {
+        const int m = m_blk + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (m < a.cout_g && !(a.bd_cout && m / a.bd_cout != cig)) a.out[off[r]] = prev[r] + acc[mb][j][r];
+      }
     }
   }
 }
@@ -290,11 +312,45 @@ struct WgradPkPlan {
   size_t lds;
   dim3 grid;
   int tgmax;
+  int wide;  // 1: the 128 x 128 tile on eight waves (wgrad_pk_kernel<5, TM, true>)
 };
 
 static int wg_env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
+}
+
+// The 128 x 128 tile (wgrad_pk_kernel<.., true>) where both channel extents reach it, no wave splits taps or diagonal blocks, and the
+// shape still gives the chip a workgroup per CU: fills the tile geometry of `a` / `pl` (taps per workgroup <= 5) and returns true.
+// EVMI_WG_WIDE=0: never (A/B).
+static bool plan_wgrad_wide(WgradPkArgs& a, WgradPkPlan& pl, int k, int stride, int dil, int xrow_pad, long long n_groups) {
+  static const int on = wg_env_int("EVMI_WG_WIDE", 1);
+  pl.wide = 0;
+  if (!on || a.tap_split || a.bd_cin || a.cin_g < 128 || a.cout_g < 128) return false;
+  const int tgcap = 5;
+  const int ntg = (k + tgcap - 1) / tgcap, tg = (k + ntg - 1) / ntg;
+  const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(tg - 1) * dil + 1;
+  if (xwin > 64 * 12) return false;
+  const int xpieces = (int)((xwin + 63) / 64), xrow = xpieces * 64 + xrow_pad;
+  const size_t stage_bytes = (size_t)(16 * WG_YROW + 16 * xrow) * 16;
+  if (2 * stage_bytes > 160 * 1024) return false;
+  const int tiles_ci = (a.cin_g + 127) / 128, tiles_co = (a.cout_g + 127) / 128;
+  const long long tiles = (long long)tiles_ci * ntg * tiles_co * n_groups;
+  static const long long want = wg_env_int("EVMI_WG_WIDE_WANT", 256);  // one eight-wave workgroup per CU
+  int splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / 8));
+  const int steps = (a.ksteps + splits - 1) / splits;
+  splits = (a.ksteps + steps - 1) / steps;
+  if (tiles * splits < 192) return false;  // too few workgroups for the chip: the 64 x 64 tile (four times the tiles) fills it
+  a.ntg = ntg; a.tg = tg;
+  a.tiles_ci = tiles_ci; a.tiles_co = tiles_co;
+  a.xpieces = xpieces; a.xrow = xrow;
+  a.nst = 3 * stage_bytes <= 160 * 1024 ? 3 : 2;
+  a.steps_per_split = steps;
+  pl.lds = a.nst * stage_bytes;
+  pl.tgmax = 5;
+  pl.splits = splits;
+  pl.wide = 1;
+  return true;
 }
 
 static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_in, int t_in, int c_out, int n_out, int k, int stride, int pad,
@@ -325,35 +381,42 @@ static const char* plan_wgrad_pk(WgradPkArgs& a, WgradPkPlan& pl, int B, int c_i
   a.plane_y = (long long)B * Tq;
   a.plane_x = (long long)B * Tq * stride;
   a.ksteps = (int)((a.plane_y + WG_KS - 1) / WG_KS);
-  // taps per workgroup
-  const int tgcap = 8;
-  a.ntg = (k + tgcap - 1) / tgcap;
-  a.tg = (k + a.ntg - 1) / a.ntg;
-  pl.tgmax = a.tg <= 4 ? 4 : 8;
-  a.tiles_ci = (cin_g + 63) / 64;
-  a.tiles_co = (cout_g + 63) / 64;
-  const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;
-  if (xwin > 64 * 12) return "input window too long";
-  a.xpieces = (int)((xwin + 63) / 64);
-  a.xrow = a.xpieces * 64 + wg_xrow_pad(stride);
-  const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
-  a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
-  const int fn = wg_env_int("EVMI_WG_NST", 0);
-  if (fn == 2 || fn == 3) a.nst = fn;
-  pl.lds = a.nst * stage_bytes;
-  if (pl.lds > 160 * 1024) return "LDS budget";
-  const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co * groups;
-  static const long long want = wg_env_int("EVMI_WG_WANT", 512);  // (A/B: workgroups a weight gradient is split up to)
-  static const int min_steps = 8;  // K steps per workgroup that pay for its prologue and tile store
-  int splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / min_steps));
-  const int fs = wg_env_int("EVMI_WG_SPLITS", 0);
-  if (fs > 0) splits = std::min(fs, a.ksteps);
-  a.steps_per_split = (a.ksteps + splits - 1) / splits;
-  splits = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;  // no empty splits
-  pl.splits = splits;
+  a.tap_split = 0; a.bd_cin = a.bd_cout = 0;
+  int splits;
+  if (plan_wgrad_wide(a, pl, k, stride, dil, wg_xrow_pad(stride), groups)) {
+    splits = pl.splits;
+  } else {
+    // taps per workgroup
+    const int tgcap = 8;
+    a.ntg = (k + tgcap - 1) / tgcap;
+    a.tg = (k + a.ntg - 1) / a.ntg;
+    pl.tgmax = a.tg <= 4 ? 4 : 8;
+    a.tiles_ci = (cin_g + 63) / 64;
+    a.tiles_co = (cout_g + 63) / 64;
+    const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;
+    if (xwin > 64 * 12) return "input window too long";
+    a.xpieces = (int)((xwin + 63) / 64);
+    a.xrow = a.xpieces * 64 + wg_xrow_pad(stride);
+    const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
+    a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
+    const int fn = wg_env_int("EVMI_WG_NST", 0);
+    if (fn == 2 || fn == 3) a.nst = fn;
+    pl.lds = a.nst * stage_bytes;
+    if (pl.lds > 160 * 1024) return "LDS budget";
+    const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co * groups;
+    static const long long want = wg_env_int("EVMI_WG_WANT", 512);  // (A/B: workgroups a weight gradient is split up to)
+    static const int min_steps = 8;  // K steps per workgroup that pay for its prologue and tile store
+    splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / min_steps));
+    const int fs = wg_env_int("EVMI_WG_SPLITS", 0);
+    if (fs > 0) splits = std::min(fs, a.ksteps);
+    a.steps_per_split = (a.ksteps + splits - 1) / splits;
+    splits = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;  // no empty splits
+    pl.splits = splits;
+  }
   if ((long long)a.tiles_ci * a.ntg > 0x7fffffffLL || (long long)groups * a.tiles_co > 65535 || splits > 65535) return "grid limits";
   pl.grid = dim3(a.tiles_ci * a.ntg, groups * a.tiles_co, splits);
-  // slack: the last K step reads up to its full window past the end of the last row
+  // slack: the last K step reads up to its full window past the end of the last row (the wide tile's 16 octet rows: rows past the
+  // group are not staged, see the kernel)
   pl.dy_units = (long long)groups * a.octs_y * a.plane_y + WG_KS + 64;
   pl.x_units = (long long)groups * a.octs_x * a.plane_x + (long long)WG_KS * stride + a.xrow + 64;
   a.split_stride = (long long)c_out * cin_g * k;
@@ -375,7 +438,15 @@ static int launch_wgrad_packed(const WgradPkArgs& a_in, const WgradPkPlan& pl, h
   static thread_local size_t configured_dev[kMaxDevices][2] = {};
   size_t* configured = configured_dev[device_slot()];
   const size_t lds = pl.lds;
-  if (pl.tgmax == 4) {
+  if (pl.wide) {
+    static thread_local size_t wide_lds[kMaxDevices] = {};
+    size_t& cfg = wide_lds[device_slot()];
+    if (lds > cfg) {
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<5, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      cfg = lds;
+    }
+    hipLaunchKernelGGL((wgrad_pk_kernel<5, false, true>), pl.grid, dim3(512), lds, s, a);
+  } else if (pl.tgmax == 4) {
     if (lds > configured[0]) {
       EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       configured[0] = lds;
@@ -460,26 +531,32 @@ static const char* plan_wgrad_tm(WgradPkArgs& a, WgradPkPlan& pl, long long rows
   pl.octs_y = a.octs_y = c_out / 8;
   pl.octs_x = a.octs_x = c_in / 8;
   a.ksteps = (int)((rows + WG_KS - 1) / WG_KS);
-  const int tgcap = 8;
-  a.ntg = (k + tgcap - 1) / tgcap;
-  a.tg = (k + a.ntg - 1) / a.ntg;
-  pl.tgmax = a.tg <= 4 ? 4 : 8;
-  a.tiles_ci = (c_in + 63) / 64;
-  a.tiles_co = (c_out + 63) / 64;
-  const long long xwin = (long long)(WG_KS - 1) + (long long)(a.tg - 1) * dil + 1;
-  if (xwin > 64 * 12) return "input window too long";
-  a.xpieces = (int)((xwin + 63) / 64);
-  a.xrow = a.xpieces * 64 + 4;
-  const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
-  a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
-  pl.lds = a.nst * stage_bytes;
-  if (pl.lds > 160 * 1024) return "LDS budget";
-  const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co;
-  const long long want = 512;
-  int splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / 8));
-  a.steps_per_split = (a.ksteps + splits - 1) / splits;
-  splits = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;
-  pl.splits = splits;
+  int splits;
+  // (the 128 x 128 tile loses on the generator's time-major layers: c128 / k11 54 -> 58 us, c256 unchanged -- tools/bench_wgrad_bf16.py)
+  pl.wide = 0;
+  if (false) {
+  } else {
+    const int tgcap = 8;
+    a.ntg = (k + tgcap - 1) / tgcap;
+    a.tg = (k + a.ntg - 1) / a.ntg;
+    pl.tgmax = a.tg <= 4 ? 4 : 8;
+    a.tiles_ci = (c_in + 63) / 64;
+    a.tiles_co = (c_out + 63) / 64;
+    const long long xwin = (long long)(WG_KS - 1) + (long long)(a.tg - 1) * dil + 1;
+    if (xwin > 64 * 12) return "input window too long";
+    a.xpieces = (int)((xwin + 63) / 64);
+    a.xrow = a.xpieces * 64 + 4;
+    const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
+    a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
+    pl.lds = a.nst * stage_bytes;
+    if (pl.lds > 160 * 1024) return "LDS budget";
+    const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co;
+    const long long want = 512;
+    splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / 8));
+    a.steps_per_split = (a.ksteps + splits - 1) / splits;
+    splits = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;
+    pl.splits = splits;
+  }
   if (splits > 65535) return "grid limits";
   pl.grid = dim3(a.tiles_ci * a.ntg, a.tiles_co, splits);
   a.split_stride = (long long)c_out * c_in * k;
@@ -514,7 +591,15 @@ int evmi_conv1d_wgrad_tm_bf16(const void* x_tm, const void* dy_tm, float* dw_dev
   static thread_local size_t configured_dev[kMaxDevices][2] = {};
   size_t* configured = configured_dev[device_slot()];
   const size_t lds = pl.lds;
-  if (pl.tgmax == 4) {
+  if (pl.wide) {
+    static thread_local size_t wide_lds[kMaxDevices] = {};
+    size_t& cfg = wide_lds[device_slot()];
+    if (lds > cfg) {
+      EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<5, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      cfg = lds;
+    }
+    hipLaunchKernelGGL((wgrad_pk_kernel<5, true, true>), pl.grid, dim3(512), lds, s, a);
+  } else if (pl.tgmax == 4) {
     if (lds > configured[0]) {
       EVMI_HIP_CHECK(hipFuncSetAttribute((const void*)wgrad_pk_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       configured[0] = lds;
@@ -568,27 +653,32 @@ static const char* plan_wgrad_flat(WgradPkArgs& a, WgradPkPlan& pl, int& sgroups
   // workgroup, 8 per wave, half the workgroups staging the same windows (EVMI_WG_TAPSPLIT=0: off)
   static const int tap_split_on = wg_env_int("EVMI_WG_TAPSPLIT", 1);
   a.tap_split = !tap_split_on ? 0 : (cin_g <= 32 ? 1 : (a.bd_cin == 32 && a.bd_cout == 32 && cin_g == 64 && cout_g == 64 ? 2 : 0));
-  const int tgcap = a.tap_split ? 16 : 8;
-  a.ntg = (k + tgcap - 1) / tgcap;
-  a.tg = (k + a.ntg - 1) / a.ntg;
-  const int tg_wave = a.tap_split ? (a.tg + 1) / 2 : a.tg;
-  pl.tgmax = tg_wave <= 4 ? 4 : 8;
-  a.tiles_ci = (cin_g + 63) / 64;
-  a.tiles_co = (cout_g + 63) / 64;
-  const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;
-  if (xwin > 64 * 12) return "input window too long";
-  a.xpieces = (int)((xwin + 63) / 64);
-  a.xrow = a.xpieces * 64 + wg_xrow_pad(stride);
-  const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
-  a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
-  pl.lds = a.nst * stage_bytes;
-  if (pl.lds > 160 * 1024) return "LDS budget";
-  const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co * sgroups;
-  const long long want = 512;
-  int splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / 8));
-  a.steps_per_split = (a.ksteps + splits - 1) / splits;
-  splits = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;
-  pl.splits = splits;
+  int splits;
+  if (plan_wgrad_wide(a, pl, k, stride, dil, wg_xrow_pad(stride), sgroups)) {
+    splits = pl.splits;
+  } else {
+    const int tgcap = a.tap_split ? 16 : 8;
+    a.ntg = (k + tgcap - 1) / tgcap;
+    a.tg = (k + a.ntg - 1) / a.ntg;
+    const int tg_wave = a.tap_split ? (a.tg + 1) / 2 : a.tg;
+    pl.tgmax = tg_wave <= 4 ? 4 : 8;
+    a.tiles_ci = (cin_g + 63) / 64;
+    a.tiles_co = (cout_g + 63) / 64;
+    const long long xwin = (long long)(WG_KS - 1) * stride + (long long)(a.tg - 1) * dil + 1;
+    if (xwin > 64 * 12) return "input window too long";
+    a.xpieces = (int)((xwin + 63) / 64);
+    a.xrow = a.xpieces * 64 + wg_xrow_pad(stride);
+    const size_t stage_bytes = (size_t)(8 * WG_YROW + 8 * a.xrow) * 16;
+    a.nst = 3 * stage_bytes <= 78 * 1024 ? 3 : 2;
+    pl.lds = a.nst * stage_bytes;
+    if (pl.lds > 160 * 1024) return "LDS budget";
+    const long long tiles = (long long)a.tiles_ci * a.ntg * a.tiles_co * sgroups;
+    const long long want = 512;
+    splits = (int)std::min<long long>(std::max<long long>(1, (want + tiles - 1) / tiles), std::max(1, a.ksteps / 8));
+    a.steps_per_split = (a.ksteps + splits - 1) / splits;
+    splits = (a.ksteps + a.steps_per_split - 1) / a.steps_per_split;
+    pl.splits = splits;
+  }
   if ((long long)a.tiles_ci * a.ntg > 0x7fffffffLL || (long long)sgroups * a.tiles_co > 65535 || splits > 65535) return "grid limits";
   pl.grid = dim3(a.tiles_ci * a.ntg, sgroups * a.tiles_co, splits);
   a.split_stride = (long long)c_out * (c_in / groups) * k;

@@ -412,15 +412,16 @@ def test_chain_against_torch_autograd_with_its_roundings(which, n, T, generator_
             assert c >= floor and abs(r - 1) <= 1e-2, (name, c, r)
 
 
-@pytest.mark.parametrize("switch", ["EVMI_WG_TAPSPLIT=0"])
+@pytest.mark.parametrize("switch", ["EVMI_WG_TAPSPLIT=0", "EVMI_WG_WIDE=0 EVMI_WG_XCD=0"])
 def test_flat_kernels_behind_their_switches(switch):
-    """The flat weight gradient without the tap split over a row's waves, the flat convolutions without the 512-column tiles: the
-    comparisons with torch of this file once more in a child process each (the switches are read once per process)."""
+    """The flat weight gradient without the tap split over a row's waves; (round 6) on 64 x 64 tiles only, workgroups in launch order
+    instead of XCD order: the comparisons with torch of this file once more in a child process each (the switches are read once per
+    process)."""
     import os
     import subprocess
     import sys
 
-    key, val = switch.split("=")
+    env = dict(kv.split("=") for kv in switch.split())
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "flat_packed_kernels_against_torch or chain_against_torch_autograd"],
-                       env=dict(os.environ, **{key: val}), capture_output=True, text=True, timeout=1500)
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

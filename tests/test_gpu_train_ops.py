@@ -443,9 +443,10 @@ def test_bf16_packed_kernels_edge_shapes(cuda_device, bf16_operands, case):
 # (name, B, T, cin, cout, k, stride, pad, dil, groups, forward tile, input-gradient tile, weight-gradient taps): the expected
 # instantiations are what evmi_conv1d_*_bf16pk_plan reports with no EVMI_PK_* switch set (tile index: see include/evmi.h)
 BENCH_SHAPE_CASES = [
-    ("fs2 postnet 512->512 k5 on 32 x 814", 32, 814, 512, 512, 5, 1, 2, 1, 1, 6, 6, 8),        # conv_pk_kernel<128, 256>
-    ("fs2 ffn 256->1024 on 32 x 814", 32, 814, 256, 1024, 1, 1, 0, 1, 1, 8, 9, 4),             # the eight-wave <128, 128> for short contractions
-    ("fs2 ffn 1024->256 on 32 x 814", 32, 814, 1024, 256, 1, 1, 0, 1, 1, 9, 8, 4),             # 9: <128, 128> with the weight fragments in registers
+    # (weight-gradient taps 5 = wgrad_pk_kernel<5, false, true>: the 128 x 128 tile on eight waves, round 6)
+    ("fs2 postnet 512->512 k5 on 32 x 814", 32, 814, 512, 512, 5, 1, 2, 1, 1, 6, 6, 5),        # conv_pk_kernel<128, 256>
+    ("fs2 ffn 256->1024 on 32 x 814", 32, 814, 256, 1024, 1, 1, 0, 1, 1, 8, 9, 5),             # the eight-wave <128, 128> for short contractions
+    ("fs2 ffn 1024->256 on 32 x 814", 32, 814, 1024, 256, 1, 1, 0, 1, 1, 9, 8, 5),             # 9: <128, 128> with the weight fragments in registers
     ("fs2 postnet 80->512 k5 on 32 x 947", 32, 947, 80, 512, 5, 1, 2, 1, 1, 9, 9, 8),          # dgrad: split-K <128, 128>
     ("fs2 encoder 256->768 on 32 x 187", 32, 187, 256, 768, 1, 1, 0, 1, 1, 1, 2, 4),           # <64, 128> / <64, 64>
     ("gan generator c32 k11 d5 on 16 x 8192", 16, 8192, 32, 32, 11, 1, 25, 5, 1, 3, 3, 8),     # <32, 128>
@@ -453,7 +454,7 @@ BENCH_SHAPE_CASES = [
     ("gan generator c128 k3 on 16 x 2048", 16, 2048, 128, 128, 3, 1, 1, 1, 1, 1, 1, 4),
     ("gan generator c512 k11 d5 on 16 x 32", 16, 32, 512, 512, 11, 1, 25, 5, 1, 9, 9, 8),      # split-K over workgroups
     ("mpd p2 32->128 s3 on 64 x 4096", 64, 4096, 32, 128, 5, 3, 2, 1, 1, 9, 3, 8),
-    ("mpd p11 1024->1024 on 352 x 28", 352, 28, 1024, 1024, 5, 1, 2, 1, 1, 9, 9, 8),           # short items: <128, 128>
+    ("mpd p11 1024->1024 on 352 x 28", 352, 28, 1024, 1024, 5, 1, 2, 1, 1, 9, 9, 5),           # short items: <128, 128>
     ("msd 512->1024 k41 s4 g16 on 32 x 512", 32, 512, 512, 1024, 41, 4, 20, 1, 16, 1, 3, 8),
     ("msd 128->128 k41 s2 g4 on 32 x 8192", 32, 8192, 128, 128, 41, 2, 20, 1, 4, 3, 3, 8),
 ]
@@ -499,7 +500,7 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
     name, B, T, cin, cout, k, s, p, d, groups, tile_f, tile_d, taps_w = case
     lib = _lib.load()
     n_out = (T + 2 * p - d * (k - 1) - 1) // s + 1
-    if not any(os.environ.get(v) for v in ("EVMI_PK_TILE", "EVMI_PK_SPLITK", "EVMI_PK_WIDE", "EVMI_PK_ADIR", "EVMI_PK_XCD_HB")):
+    if not any(os.environ.get(v) for v in ("EVMI_PK_TILE", "EVMI_PK_SPLITK", "EVMI_PK_WIDE", "EVMI_PK_ADIR", "EVMI_PK_XCD_HB", "EVMI_WG_WIDE")):
         geo = (B, cin, T, cout, n_out, k, s, p, d, groups)
         assert lib.evmi_conv1d_cbt_bf16pk_plan(*geo) % 16 == tile_f, name
         assert lib.evmi_conv1d_dgrad_cbt_bf16pk_plan(*geo) % 16 == tile_d, name
@@ -518,7 +519,7 @@ def test_bf16_packed_kernels_at_bench_shapes(cuda_device, bf16_operands, case):
 
 
 _PK_CHILD_TESTS = "bf16_packed_kernels_at_bench_shapes or bf16_packed_kernels_edge_shapes"
-_PK_SWITCHES = ["EVMI_PK_SPLITK=0", "EVMI_PK_WIDE=1", "EVMI_WG_SPLITS=1", "EVMI_WG_NST=2", "EVMI_PK_ADIR=0", "EVMI_PK_XCD_HB=1"]
+_PK_SWITCHES = ["EVMI_PK_SPLITK=0", "EVMI_PK_WIDE=1", "EVMI_WG_SPLITS=1", "EVMI_WG_NST=2", "EVMI_PK_ADIR=0", "EVMI_PK_XCD_HB=1", "EVMI_WG_WIDE=0"]
 
 
 @pytest.mark.parametrize("tile", range(11))
