@@ -231,6 +231,9 @@ def roofline_from_records(passes: list[list[dict]]) -> dict:
         "traffic": None,
         "avg_launch_ms": round(avg_ms, 4),
         "statistic": "median over launches (per-launch figures) and over passes (per-forward sums)",
+        # the plain mean beside it: what `rocprofv3 --stats` prints as AverageNs for the same kernel (profiles/*_kernel_stats.csv)
+        "mean_launch_ms": round(sum(launches[dom]) / len(launches[dom]), 4),
+        "frac_by_mean": round(fl_launch[dom] / (sum(launches[dom]) / len(launches[dom]) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS_BF16, 4),
         "launches_per_forward": n_launch[dom],
         "share_of_forward_time": round(fam_ms[dom] / all_ms, 4),
         "algorithmic_gflop_per_launch": round(fl_launch[dom] / 1e9, 3),
