@@ -34,11 +34,16 @@ _ORDER = ["test_gpu_length_regulator", "test_gpu_mel", "test_pipeline", "test_gp
 _LAST = ["test_gpu_ddp"]
 
 
+# ... and inside that file the one test that differed once on the driver's box in round 5 (71 clean repetitions since,
+# profiles/r06_ddp_repeat.log) goes to the very end: should it ever differ again, everything else has run.
+_VERY_LAST = "test_two_ranks_in_bf16_on_the_packed_chains_graph_equals_eager"
+
+
 def pytest_collection_modifyitems(session, config, items):
     def rank(item):
         stem = Path(str(item.fspath)).stem
         if stem in _LAST:
-            return len(_ORDER) + 1 + _LAST.index(stem)
+            return len(_ORDER) + 1 + _LAST.index(stem) + (100 if item.name.startswith(_VERY_LAST) else 0)
         return _ORDER.index(stem) if stem in _ORDER else len(_ORDER)
 
     items.sort(key=rank)  # (stable: the order inside a file stays)
